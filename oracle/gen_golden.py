@@ -1,0 +1,351 @@
+"""TEST INFRASTRUCTURE (development container only): generate tests/golden/*.npz from the REAL reference.
+
+Run:  python oracle/gen_golden.py            (needs /root/reference; see oracle/refimport.py)
+
+Golden sets:
+  g1_kalman.npz    kernel-level vectors: inputs/outputs of the reference's kalman.predict / precalc /
+                   z_tilde / normalizedInnovationSquared / numpyFilter / nllr and the gate CSR
+  g2_trace_cfg1    scan trace, BASELINE config 1 (2 targets, 20 scans)
+  g3_trace_dense   scan trace, 20 targets in 400 m (clusters, ILPs, terminations, initiator births)
+  g3b_trace_cfg2   scan trace, BASELINE config 2 (50 targets, ~200 meas/scan), 10 scans
+  g4_ilp.npz       recorded 0-1 ILP instances (columns CSR, group sizes, cost) + exact optimum,
+                   uniqueness flag
+  g5_headline.npz  5000 x 500 batch: checksums, G, first/last rows
+While generating, every trace is replayed through oracle/mht_oracle.py and compared BITWISE with the
+reference; a mismatch aborts.  Fixtures hold numbers only (inputs + expected outputs).
+"""
+import hashlib
+import logging
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refimport  # noqa: E402
+import mht_oracle as orc  # noqa: E402
+from pymht_amd.utils.scenario import make_config  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+LAMBDA_NU = 1e-4
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------
+def ref_leaf_batch(trk):
+    rows = [(ti, l) for ti, r in enumerate(trk.__targetList__) for l in r.getLeafNodes()]
+    return dict(target=np.array([ti for ti, _ in rows], dtype=np.int64),
+                ID=np.array([l.ID for _, l in rows], dtype=np.int64),
+                x=np.array([np.asarray(l.x_0, dtype=np.float64) for _, l in rows]).reshape(-1, 4),
+                xf32=np.array([l.x_0.dtype == np.float32 for _, l in rows], dtype=bool),
+                P=np.array([np.asarray(l.P_0, dtype=np.float32) for _, l in rows]).reshape(-1, 4, 4),
+                cnllr=np.array([float(l.cumulativeNLLR) for _, l in rows], dtype=np.float64),
+                cf32=np.array([isinstance(l.cumulativeNLLR, np.float32) for _, l in rows], dtype=bool),
+                meas=np.array([l.measurementNumber for _, l in rows], dtype=np.int64))
+
+
+def ref_selected(trk):
+    nodes = list(trk.__trackNodes__)
+    hist, ptr = [], [0]
+    for n in nodes:
+        h = [0 if m.measurementNumber is None else int(m.measurementNumber) for m in n.backtrackNodes()]
+        hist.extend(h)
+        ptr.append(len(hist))
+    return dict(ID=np.array([n.ID for n in nodes], dtype=np.int64),
+                x=np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes]).reshape(-1, 4),
+                cnllr=np.array([float(n.cumulativeNLLR) for n in nodes], dtype=np.float64),
+                meas=np.array([n.measurementNumber for n in nodes], dtype=np.int64),
+                score=np.array([float(n.getScore()) for n in nodes], dtype=np.float64),
+                root_cnllr=np.array([float(n.getRoot().cumulativeNLLR) for n in nodes], dtype=np.float64),
+                hist=np.array(hist, dtype=np.int64), hist_ptr=np.array(ptr, dtype=np.int64))
+
+
+def orc_leaf_batch(o):
+    b = o.leaf_batch()
+    rows = [l for r in o.targets for l in r.leaves()]
+    b["xf32"] = np.array([l.x.dtype == np.float32 for l in rows], dtype=bool)
+    b["cf32"] = np.array([isinstance(l.cnllr, np.float32) for l in rows], dtype=bool)
+    return b
+
+
+class OracleInitiatorAdapter:
+    def __init__(self, initiator, make_list):
+        self.initiator, self.make_list = initiator, make_list
+
+    def processMeasurements(self, time_, z):
+        return [(t.x_0, t.P_0, t.measurementNumber, t.measurement)
+                for t in self.initiator.processMeasurements(self.make_list(time_, z))]
+
+
+def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=True):
+    """Run reference and oracle side by side on scenario `sc`; compare bitwise; dump a fixture."""
+    T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
+    ML = mods["classDefinitions"].MeasurementList
+    from pymht_amd.initiators.m_of_n import Initiator
+    from pymht_amd.utils.classDefinitions import MeasurementList as MyML
+    from pymht_amd.models import pv as mypv
+
+    trk = T.Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=5.99)
+    my_init = Initiator(trk.M_required, trk.N_checks, trk.maxSpeedMS, mypv.C_RADAR, mypv.R_RADAR(), trk.mergeThreshold)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=5.99,
+                          initiator=OracleInitiatorAdapter(my_init, MyML))
+    if record_ilp is not None:
+        mods["pywraplp"].RECORDER = []
+        o.ilp_recorder = []
+    accepted = []
+    for x in sc["x0"]:
+        n0 = len(trk.__targetList__)
+        trk.initiateTarget(Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized"))
+        ok = o.initiate_target(sc["t0"], x.copy(), orc.model_P0(), status="preinitialized")
+        assert ok == (len(trk.__targetList__) > n0)
+        accepted.append(ok)
+    fx = dict(x0=sc["x0"], accepted=np.array(accepted), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"],
+              lambda_phi=sc["lambda_phi"], lambda_nu=LAMBDA_NU, N=sc["N"], eta2=5.99, times=sc["times"])
+    K = len(sc["scans"]) if n_scans is None else n_scans
+    fx["n_scans"] = K
+    for k in range(K):
+        z, t = sc["scans"][k], float(sc["times"][k])
+        nT0 = len(trk.__targetList__)
+        ids_before = [r.ID for r in trk.__targetList__]
+        trk.addMeasurementList(ML(t, z))
+        info = o.add_scan(t, z)
+        rb, ob = ref_leaf_batch(trk), orc_leaf_batch(o)
+        for key in ("target", "ID", "x", "xf32", "P", "cnllr", "cf32", "meas"):
+            assert np.array_equal(rb[key], ob[key]), "scan %d: leaf batch field %s differs" % (k, key)
+        rs, os_ = ref_selected(trk), o.selected()
+        for key in ("ID", "x", "cnllr", "meas"):
+            assert np.array_equal(rs[key], os_[key]), "scan %d: selected %s differs" % (k, key)
+        rc = [np.asarray(c) for c in trk.__clusterList__]
+        assert len(rc) == len(o.clusters) and all(np.array_equal(a, b) for a, b in zip(rc, o.clusters)), "clusters"
+        ids_after = [r.ID for r in trk.__targetList__]
+        dead = [i for i in ids_before if i not in ids_after]
+        assert dead == sorted(info["dead"]) or sorted(dead) == sorted(info["dead"]), (dead, info["dead"])
+        p = "s%02d_" % k
+        fx[p + "z"] = z
+        fx[p + "ids"] = np.array(ids_after, dtype=np.int64)
+        fx[p + "dead"] = np.array(sorted(dead), dtype=np.int64)
+        fx[p + "new_ids"] = np.array(info["new_ids"], dtype=np.int64)
+        fx[p + "unused"] = info["unused"]
+        fx[p + "LGM"] = np.array([info["L"], info["G"], info["M"]], dtype=np.int64)
+        fx[p + "cl_members"] = np.concatenate(rc) if rc else np.zeros(0, dtype=np.int64)
+        fx[p + "cl_ptr"] = np.concatenate([[0], np.cumsum([len(c) for c in rc])]).astype(np.int64)
+        for key, v in rs.items():
+            fx[p + "sel_" + key] = v
+        if store_leaves:
+            for key, v in rb.items():
+                fx[p + "leaf_" + key] = v
+        else:
+            fx[p + "leaf_n"] = np.array([len(rb["ID"])])
+            fx[p + "leaf_sha_x"] = np.frombuffer(bytes.fromhex(sha(rb["x"])), dtype=np.uint8)
+            fx[p + "leaf_sha_cnllr"] = np.frombuffer(bytes.fromhex(sha(rb["cnllr"])), dtype=np.uint8)
+            fx[p + "leaf_sha_meas"] = np.frombuffer(bytes.fromhex(sha(rb["meas"])), dtype=np.uint8)
+        # new targets born this scan (roots that are leaves with parent None and scanNumber == k+1)
+        born = [r for r in trk.__targetList__ if r.ID in info["new_ids"]]
+        fx[p + "born_x"] = np.array([np.asarray(b.x_0, dtype=np.float64) for b in born]).reshape(-1, 4)
+        fx[p + "born_P"] = np.array([np.asarray(b.P_0, dtype=np.float32) for b in born]).reshape(-1, 4, 4)
+        print("  %s scan %2d  M=%3d  T=%3d->%3d  L=%5d G=%5d  leaves_after=%5d  ilp=%d  new=%s dead=%s" % (
+            out_name, k, len(z), nT0, len(ids_after), info["L"], info["G"], len(rb["ID"]), trk.nOptimSolved,
+            info["new_ids"], dead))
+    np.savez_compressed(os.path.join(GOLD, out_name + ".npz"), **fx)
+    if record_ilp is not None:
+        ref_rec = mods["pywraplp"].RECORDER
+        mods["pywraplp"].RECORDER = None
+        assert len(ref_rec) == len(o.ilp_recorder)
+        for a, b in zip(ref_rec, o.ilp_recorder):
+            # reference's (A1;A2) built by tracker.py:1042-1122 vs oracle's columns: same matrix, same cost
+            nM = a["A"].shape[0] - len(b["sizes"])
+            A1 = a["A"][:nM].tocsc()
+            for c in range(A1.shape[1]):
+                assert sorted(A1.indices[A1.indptr[c]:A1.indptr[c + 1]].tolist()) == b["cols"][c]
+            assert np.array_equal(a["c"], np.asarray(b["cost"], dtype=np.float64))
+            assert sorted(np.nonzero(a["x"] > 0.5)[0].tolist()) == b["sel"]
+        record_ilp.extend(o.ilp_recorder)
+    return trk, o
+
+
+# ------------------------------------------------------------------------------------------
+def gen_g1(mods):
+    """Kernel-level vectors from the reference's kalman module (pins SURVEY rows a-3 .. a-7)."""
+    kal, pv = mods["kalman"], mods["pv"]
+    rng = np.random.default_rng(20260928)
+    A, Q, C, R = pv.Phi(2.5), pv.Q(2.5), pv.C_RADAR, pv.R_RADAR()
+    fx = dict(A=A, Q=Q, C=C, R=R, eta2=5.99, lambda_ex=1e-4 + 2e-5)
+    case = 0
+    for n, M in ((1, 1), (10, 37), (257, 500), (64, 129)):
+        for f32state in (False, True):
+            # covariances reached after 0..6 CV steps with random hit/miss patterns
+            P = np.array([pv.P0] * n)
+            for i in range(n):
+                Pi = pv.P0
+                for _ in range(int(rng.integers(0, 7))):
+                    xb, Pb = kal.predict(A, Q, np.zeros((1, 4)), Pi.reshape(1, 4, 4))
+                    if rng.uniform() < 0.7:
+                        Pi = kal.precalc(C, R, xb, Pb)[4][0]
+                    else:
+                        Pi = Pb[0]
+                P[i] = Pi
+            x = np.concatenate([rng.uniform(-3000, 3000, size=(n, 2)), rng.normal(0, 8, size=(n, 2))], axis=1)
+            if f32state:
+                x = x.astype(np.float32)
+            # measurements: some near predicted positions (hits, incl. near the gate edge), some clutter
+            xb = A.dot(x.T).T
+            z = rng.uniform(-3000, 3000, size=(M, 2))
+            for j in range(M):
+                if rng.uniform() < 0.6:
+                    i = int(rng.integers(0, n))
+                    z[j] = xb[i, 0:2] + rng.normal(0, 6.0, size=2)
+            z = z.astype(np.float32)
+            P_d = 0.9
+            x_bar, P_bar = kal.predict(A, Q, x, P)
+            z_hat, S, S_inv, K, P_hat = kal.precalc(C, R, x_bar, P_bar)
+            zt = kal.z_tilde(z, z_hat, n, 2)
+            nis = kal.normalizedInnovationSquared(zt, S_inv)
+            gate = nis <= 5.99
+            idx = [np.nonzero(gate[i])[0] for i in range(n)]
+            x_hat = [kal.numpyFilter(x_bar[i], K[i], zt[i, idx[i]]) for i in range(n)]
+            nl = [kal.nllr(fx["lambda_ex"], P_d, S[i], nis[i, gate[i]]) for i in range(n)]
+            # oracle must agree bit for bit
+            r = orc.process_leaves(A, Q, C, R, 5.99, fx["lambda_ex"], x, P, [P_d] * n, z)
+            assert np.array_equal(r["x_bar"], x_bar) and np.array_equal(r["P_bar"], P_bar)
+            assert np.array_equal(r["P_hat"], P_hat) and np.array_equal(r["nis"], nis)
+            assert all(np.array_equal(a, b) for a, b in zip(r["idx"], idx))
+            assert all(np.array_equal(a, b) for a, b in zip(r["x_hat"], x_hat))
+            assert all(np.array_equal(a, b) for a, b in zip(r["nllr"], nl))
+            p = "c%d_" % case
+            fx[p + "x"], fx[p + "P"], fx[p + "z"], fx[p + "P_d"] = x, P, z, P_d
+            fx[p + "x_bar"], fx[p + "P_bar"], fx[p + "z_hat"] = x_bar, P_bar, z_hat
+            fx[p + "S"], fx[p + "S_inv"], fx[p + "K"], fx[p + "P_hat"] = S, S_inv, K, P_hat
+            if n * M <= 4096:
+                fx[p + "nis"] = nis
+            fx[p + "nis_gated"] = nis[gate]
+            fx[p + "row_ptr"] = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).astype(np.int64)
+            fx[p + "col_idx"] = np.concatenate(idx).astype(np.int64) if n else np.zeros(0, np.int64)
+            fx[p + "x_hat"] = np.concatenate(x_hat, axis=0)
+            fx[p + "nllr"] = np.concatenate(nl)
+            print("  g1 case %d: n=%d M=%d f32state=%s  G=%d  dtypes x_bar=%s nis=%s nllr=%s" % (
+                case, n, M, f32state, fx[p + "col_idx"].size, x_bar.dtype, nis.dtype, fx[p + "nllr"].dtype))
+            case += 1
+    fx["n_cases"] = case
+    np.savez_compressed(os.path.join(GOLD, "g1_kalman.npz"), **fx)
+
+
+def gen_g4(instances):
+    """Recorded ILP instances + exact optimum + uniqueness (re-solve with a no-good cut)."""
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    from scipy.sparse import csr_matrix
+    fx, kept = {}, 0
+    for inst in instances:
+        cols, sizes, cost, sel, obj = inst["cols"], inst["sizes"], inst["cost"], inst["sel"], inst["obj"]
+        nH, nT = len(cols), len(sizes)
+        nM = 1 + max((max(c) for c in cols if c), default=-1)
+        rows, cc = [], []
+        for c, rs in enumerate(cols):
+            rows += rs
+            cc += [c] * len(rs)
+        g = 0
+        for t, s in enumerate(sizes):
+            rows += [nM + t] * s
+            cc += list(range(g, g + s))
+            g += s
+        rows += [nM + nT] * nT                                # no-good cut: sum_{i in sel} tau_i <= nT-1
+        cc += sel
+        A = csr_matrix((np.ones(len(rows)), (rows, cc)), shape=(nM + nT + 1, nH))
+        lo = np.concatenate([np.full(nM, -np.inf), np.ones(nT), [-np.inf]])
+        hi = np.concatenate([np.ones(nM + nT), [nT - 1]])
+        res = milp(np.asarray(cost, dtype=np.float64), constraints=LinearConstraint(A, lo, hi),
+                   integrality=np.ones(nH), bounds=Bounds(0, 1), options={"mip_rel_gap": 0.0})
+        second = float(res.fun) if res.status == 0 else np.inf
+        unique = bool(second > obj + 1e-9 * max(1.0, abs(obj)))
+        if nH <= 60 and nT <= 4:
+            bs, bo, ties = orc.solve_blp_bruteforce(cols, sizes, cost)
+            assert abs(bo - obj) < 1e-9 and (not unique or sorted(bs) == sel)
+        p = "i%03d_" % kept
+        fx[p + "col_ptr"] = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)
+        fx[p + "col_rows"] = np.array([r for c in cols for r in c], dtype=np.int32)
+        fx[p + "sizes"] = np.array(sizes, dtype=np.int32)
+        fx[p + "cost"] = np.asarray(cost, dtype=np.float64)
+        fx[p + "sel"] = np.array(sel, dtype=np.int32)
+        fx[p + "obj"] = obj
+        fx[p + "second"] = second
+        fx[p + "unique"] = unique
+        kept += 1
+    fx["n_inst"] = kept
+    np.savez_compressed(os.path.join(GOLD, "g4_ilp.npz"), **fx)
+    print("  g4: %d instances, %d unique" % (kept, sum(bool(fx["i%03d_unique" % i]) for i in range(kept))))
+
+
+def gen_g5(mods):
+    """Headline-shape batch 5000 x 500 (500 targets x 10 jittered leaves): checksums + head/tail rows."""
+    kal, pv = mods["kalman"], mods["pv"]
+    rng = np.random.default_rng(5446)
+    A, Q, C, R = pv.Phi(2.5), pv.Q(2.5), pv.C_RADAR, pv.R_RADAR()
+    T, per, M = 500, 10, 500
+    base = np.concatenate([rng.uniform(-4000, 4000, size=(T, 2)), rng.normal(0, 8, size=(T, 2))], axis=1)
+    x = (base[:, None, :] + np.concatenate([rng.normal(0, 2.0, size=(T, per, 2)), rng.normal(0, 0.5, size=(T, per, 2))], axis=2)).reshape(-1, 4)
+    Ps = [pv.P0]
+    for _ in range(5):
+        xb, Pb = kal.predict(A, Q, np.zeros((1, 4)), Ps[-1].reshape(1, 4, 4))
+        Ps.append(kal.precalc(C, R, xb, Pb)[4][0])
+    P = np.array([Ps[int(k)] for k in rng.integers(1, 6, size=T * per)])
+    xb = A.dot(base.T).T
+    z = rng.uniform(-4000, 4000, size=(M, 2))
+    seen = rng.permutation(T)[:450]
+    z[:450] = xb[seen, 0:2] + rng.normal(0, 2.5, size=(450, 2))
+    z = z[rng.permutation(M)].astype(np.float32)
+    lam = 1e-4 + 6.4e-7
+    r = orc.process_leaves(A, Q, C, R, 5.99, lam, x, P, [0.9] * (T * per), z)
+    # reference, per-target granularity (bitwise identical to bulk: SURVEY 8(b))
+    idx_ref = []
+    for t in range(T):
+        sl = slice(t * per, (t + 1) * per)
+        x_bar, P_bar = kal.predict(A, Q, x[sl], P[sl])
+        z_hat, S, S_inv, K, P_hat = kal.precalc(C, R, x_bar, P_bar)
+        nis = kal.normalizedInnovationSquared(kal.z_tilde(z, z_hat, per, 2), S_inv)
+        assert np.array_equal(nis, r["nis"][sl])
+        idx_ref += [np.nonzero(nis[i] <= 5.99)[0] for i in range(per)]
+    assert all(np.array_equal(a, b) for a, b in zip(idx_ref, r["idx"]))
+    col = np.concatenate(r["idx"]).astype(np.int64)
+    row_ptr = np.concatenate([[0], np.cumsum([len(i) for i in r["idx"]])]).astype(np.int64)
+    xh, nl = np.concatenate(r["x_hat"], axis=0), np.concatenate(r["nllr"])
+    fx = dict(seed=5446, T=T, per=per, M=M, lambda_ex=lam, eta2=5.99, P_d=0.9, G=col.size,
+              x=x, Pidx=np.array([0]), z=z, P_table=np.array(Ps), row_ptr=row_ptr, col_idx=col,
+              sha_x_bar=sha(r["x_bar"]), sha_P_bar=sha(r["P_bar"]), sha_P_hat=sha(r["P_hat"]),
+              sha_x_hat=sha(xh), sha_nllr=sha(nl), x_hat_head=xh[:64], x_hat_tail=xh[-64:],
+              nllr_head=nl[:64], nllr_tail=nl[-64:])
+    # P is reconstructible from the table: store the per-leaf table index instead of 5000x16 floats
+    pidx = np.array([next(k for k, Pk in enumerate(Ps) if np.array_equal(Pk, P[i])) for i in range(T * per)], dtype=np.int8)
+    fx["Pidx"] = pidx
+    np.savez_compressed(os.path.join(GOLD, "g5_headline.npz"), **fx)
+    print("  g5: L=%d M=%d G=%d" % (T * per, M, col.size))
+
+
+def main():
+    logging.disable(logging.CRITICAL)
+    os.makedirs(GOLD, exist_ok=True)
+    mods = refimport.load()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5"]
+    if "g1" in which:
+        gen_g1(mods)
+    ilps = []
+    if "g2" in which:
+        run_trace(mods, make_config("cfg1", seed=172362), "g2_trace_cfg1", record_ilp=ilps)
+    if "g3" in which or "g4" in which:
+        run_trace(mods, make_config("dense", seed=1234), "g3_trace_dense", record_ilp=ilps)
+    if "g3b" in which or "g4" in which:
+        run_trace(mods, make_config("cfg2", seed=5446), "g3b_trace_cfg2", n_scans=10, record_ilp=ilps,
+                  store_leaves=False)
+    if "g4" in which:
+        gen_g4(ilps)
+    if "g5" in which:
+        gen_g5(mods)
+
+
+if __name__ == "__main__":
+    main()
