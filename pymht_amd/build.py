@@ -1,0 +1,37 @@
+"""Builds libmht_amd.so (HIP, gfx950) in-tree with hipcc.  `python -m pymht_amd.build` or build_library()."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmht_amd.so")
+SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_cluster.hip", "mht_blp.hip", "mht_forest.hip"]
+# -ffp-contract=off is REQUIRED: mht_math.h spells out every fused multiply-add of the reference's
+# BLAS evaluation order; letting the compiler contract anything else breaks bit-exact gating.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mht_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc] + FLAGS + srcs + ["-o", LIB]
+    if verbose:
+        print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

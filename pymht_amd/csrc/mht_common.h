@@ -1,0 +1,75 @@
+// Internal declarations shared by the translation units of libmht_amd.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mht_amd.h"
+#include "mht_math.h"
+
+namespace mht {
+
+void set_error(const char* fmt, ...);
+
+#define MHT_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            mht::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MHT_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+#define MHT_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            mht::set_error(__VA_ARGS__);       \
+            return MHT_E_INVALID;              \
+        }                                      \
+    } while (0)
+
+// A grow-only device buffer owned by the ctx (workspace).
+struct Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return MHT_OK;
+        if (ptr) MHT_HIP_CHECK(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+        size_t want = need + need / 2 + 4096;
+        MHT_HIP_CHECK(hipMalloc(&ptr, want));
+        bytes = want;
+        return MHT_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+
+constexpr int GATE_TILE = 16;    // leaves per workgroup of the gate kernel
+constexpr int GATE_THREADS = 256;
+constexpr int EMIT_THREADS = 64;  // one wavefront, one leaf per lane
+constexpr int MAX_MEAS = 4096;    // 64 hit-mask words per leaf, one per lane
+
+// device-side status word of a ctx (sticky until read)
+struct DevStatus {
+    int overflow;       // children did not fit `out`
+    int n_children;     // children produced by the last gate
+    int pad[2];
+};
+
+struct Forest;
+
+}  // namespace mht
+
+struct mht_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mht::Scratch hitmask;    // [L][W] uint64
+    mht::Scratch counts;     // [L] int32 hits per leaf, then [ntiles] per-tile totals
+    mht::DevStatus* status = nullptr;   // device
+    mht::Forest* forest = nullptr;
+};

@@ -1,0 +1,186 @@
+// Per-hypothesis Kalman arithmetic of the pyMHT scan path, written so that it reproduces the
+// reference's NumPy/OpenBLAS results BIT FOR BIT where that is achievable (SURVEY.md section 7
+// "Hard parts"): every small matrix product is evaluated as OpenBLAS's gemm micro-kernels evaluate
+// it -- one accumulator per output element, k ascending, fused multiply-add -- and everything else
+// (element-wise adds, the NIS reduction) as separate IEEE operations.  Compile with
+// -ffp-contract=off: every fma below is explicit, nothing else may be contracted.
+//
+// Reference lines restated here (file:line relative to /root/reference):
+//   predict   pymht/utils/kalman.py:55-64      precalc  kalman.py:82-101
+//   z_tilde   kalman.py:36-40                  NIS      kalman.py:25-28   gate tracker.py:829
+//   update    kalman.py:43-52                  NLLR     kalman.py:14-22
+//   miss hypothesis score  pymht/pyTarget.py:319-328, hit score pyTarget.py:250
+//
+// The header is shared by the HIP kernels (device) and by tests/hostmath (host build used ONLY by the
+// CPU test-suite to check the arithmetic against the golden vectors without a GPU).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MHT_HD __host__ __device__ __forceinline__
+#else
+#define MHT_HD inline
+#endif
+
+namespace mht {
+
+// The linear-Gaussian model, f32 like the reference's pv module (models/pv.py:7-34).
+struct Model {
+    float A[16];   // state transition Phi(T), row-major 4x4
+    float Q[16];   // process noise
+    float C[8];    // measurement matrix 2x4
+    float R[4];    // measurement noise 2x2
+    double eta2;   // gate threshold (chi-square, 2 dof)      tracker.py:110
+    double lambda_ex;  // lambda_phi + lambda_nu                tracker.py:107
+};
+
+MHT_HD float fmaT(float a, float b, float c) { return fmaf(a, b, c); }
+MHT_HD double fmaT(double a, double b, double c) { return fma(a, b, c); }
+
+// c[m x n] = a[m x k] * b[k x n], all row-major, one fma chain per element (k ascending)
+template <typename TO, typename TA, typename TB, int M_, int K_, int N_>
+MHT_HD void gemm_chain(const TA* a, const TB* b, TO* c) {
+#pragma unroll
+    for (int i = 0; i < M_; ++i)
+#pragma unroll
+        for (int j = 0; j < N_; ++j) {
+            TO acc = (TO)a[i * K_] * (TO)b[j];
+#pragma unroll
+            for (int k = 1; k < K_; ++k) acc = fmaT((TO)a[i * K_ + k], (TO)b[k * N_ + j], acc);
+            c[i * N_ + j] = acc;
+        }
+}
+
+// Per-leaf quantities that do not depend on the measurements.
+template <typename TS>
+struct Predicted {
+    TS x_bar[4];
+    TS z_hat[2];
+    float P_bar[16];
+    float P_hat[16];
+    float K[8];      // 4x2
+    float S[4];
+    float S_inv[4];
+};
+
+// LU with partial pivoting of a 2x2 f32 matrix as LAPACK sgetrf does it (first maximum wins).
+struct LU2 {
+    float u00, u01, u11, l10;
+    bool swapped;
+};
+MHT_HD LU2 lu2(const float* s) {
+    LU2 f;
+    float a = s[0], b = s[1], c = s[2], d = s[3];
+    f.swapped = fabsf(c) > fabsf(a);
+    if (f.swapped) { float t = a; a = c; c = t; t = b; b = d; d = t; }
+    f.l10 = c / a;
+    f.u00 = a;
+    f.u01 = b;
+    f.u11 = fmaf(-f.l10, b, d);
+    return f;
+}
+
+// np.linalg.inv on one 2x2 (gesv with the identity as right-hand side)
+MHT_HD void inv2(const float* s, float* out) {
+    LU2 f = lu2(s);
+    // solve for the two unit columns e0, e1 (row-swapped if pivoted)
+#pragma unroll
+    for (int col = 0; col < 2; ++col) {
+        float y0 = (col == 0) ? 1.0f : 0.0f, y1 = (col == 1) ? 1.0f : 0.0f;
+        if (f.swapped) { float t = y0; y0 = y1; y1 = t; }
+        y1 = fmaf(-f.l10, y0, y1);
+        float x1 = y1 / f.u11;
+        float x0 = fmaf(-f.u01, x1, y0) / f.u00;
+        out[0 + col] = x0;
+        out[2 + col] = x1;
+    }
+}
+
+template <typename TS>
+MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predicted<TS>& o) {
+    // kalman.py:61  x_bar = A.dot(x.T).T      (A promoted to the state dtype)
+    gemm_chain<TS, float, TS, 4, 4, 1>(m.A, x, o.x_bar);
+    // kalman.py:62  P_bar = matmul(matmul(A, P), A.T) + Q
+    float AP[16], At[16], APA[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) At[i * 4 + j] = m.A[j * 4 + i];
+    gemm_chain<float, float, float, 4, 4, 4>(m.A, P, AP);
+    gemm_chain<float, float, float, 4, 4, 4>(AP, At, APA);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.P_bar[i] = APA[i] + m.Q[i];
+    // kalman.py:89  z_hat = C.dot(x_bar.T).T
+    gemm_chain<TS, float, TS, 2, 4, 1>(m.C, o.x_bar, o.z_hat);
+    // kalman.py:90  S = matmul(matmul(C, P_bar), C.T) + R
+    float Ct[8], CP[8], CPC[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ct[j * 2 + i] = m.C[i * 4 + j];
+    gemm_chain<float, float, float, 2, 4, 4>(m.C, o.P_bar, CP);
+    gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, CPC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.S[i] = CPC[i] + m.R[i];
+    // kalman.py:91  S_inv = np.linalg.inv(S)
+    inv2(o.S, o.S_inv);
+    // kalman.py:92  K = matmul(matmul(P_bar, C.T), S_inv)
+    float PCt[8];
+    gemm_chain<float, float, float, 4, 4, 2>(o.P_bar, Ct, PCt);
+    gemm_chain<float, float, float, 4, 2, 2>(PCt, o.S_inv, o.K);
+    // kalman.py:93  P_hat = P_bar - matmul(K.dot(C), P_bar)
+    float KC[16], KCP[16];
+    gemm_chain<float, float, float, 4, 2, 4>(o.K, m.C, KC);
+    gemm_chain<float, float, float, 4, 4, 4>(KC, o.P_bar, KCP);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.P_hat[i] = o.P_bar[i] - KCP[i];
+}
+
+// kalman.py:19  ln( lambda_ex * sqrt(det(2 pi S)) / P_d ), evaluated in f32 exactly as NumPy evaluates it for an
+// f32 S: python floats are weak scalars (f32 arithmetic), det = sign * u00 * u11 of the pivoted LU factors,
+// sqrt and the divide are correctly rounded.  The final f32 log is NumPy's own SIMD polynomial, which is not
+// correctly rounded; here it is a double-precision log rounded to f32 (= correctly rounded), which differs
+// from NumPy's by at most 1 ulp(f32) (measured: 5 % of inputs, |delta| <= 4.8e-7).  DESIGN.md "NLLR tolerance".
+MHT_HD float nllr_const(const float* S, double lambda_ex, double P_d) {
+    const float two_pi = (float)(2.0 * 3.141592653589793);
+    float s2[4] = {S[0] * two_pi, S[1] * two_pi, S[2] * two_pi, S[3] * two_pi};
+    LU2 f = lu2(s2);
+    float det = f.u00 * f.u11;
+    if (f.swapped) det = -det;
+    float r = sqrtf(det);
+    r = (float)lambda_ex * r;
+    r = r / (float)P_d;
+    return (float)log((double)r);
+}
+
+// kalman.py:36-40 + :25-28 + tracker.py:829 for one (leaf, measurement) pair.
+template <typename TS>
+MHT_HD bool gate_pair(const TS* z_hat, const float* S_inv, float zx, float zy, TS eta2, TS* zt, TS& nis) {
+    zt[0] = (TS)zx - z_hat[0];
+    zt[1] = (TS)zy - z_hat[1];
+    TS t0 = fmaT(zt[1], (TS)S_inv[2], zt[0] * (TS)S_inv[0]);
+    TS t1 = fmaT(zt[1], (TS)S_inv[3], zt[0] * (TS)S_inv[1]);
+    nis = t0 * zt[0] + t1 * zt[1];
+    return nis <= eta2;
+}
+
+// kalman.py:43-52  x_hat = x_bar + K z_tilde
+template <typename TS>
+MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        TS acc = (TS)K[i * 2] * zt[0];
+        acc = fmaT((TS)K[i * 2 + 1], zt[1], acc);
+        x_hat[i] = x_bar[i] + acc;
+    }
+}
+
+// Node flags (one byte per hypothesis)
+enum : uint8_t {
+    F_STATE_F32 = 1,   // state chain (x, z_hat, z_tilde, NIS, NLLR) is float32: tracks born from the initiator
+    F_SCORE_F32 = 2,   // cumulativeNLLR currently holds a float32 value (all-hit path from an int-0 root)
+    F_SCORE_INT0 = 4   // cumulativeNLLR is the Python int 0 of a fresh root (weak scalar)
+};
+
+}  // namespace mht

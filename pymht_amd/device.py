@@ -1,0 +1,120 @@
+"""Device-memory plumbing: PyTorch-ROCm owns the HBM buffers, libmht_amd gets raw pointers.
+
+`NodeLayer` is the Python handle of one `mht_nodes` structure-of-arrays layer (include/mht_amd.h)."""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("pymht_amd needs an AMD GPU (MI355X / gfx950): torch.cuda.is_available() is False. "
+                           "There is no CPU fallback.")
+
+
+class Context:
+    """One mht_ctx bound to torch's current stream on `device`."""
+
+    def __init__(self, device=0):
+        require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        _lib.check(self.lib.mht_create(C.byref(h), device, C.c_void_p(self.stream.cuda_stream)))
+        self.handle = h
+
+    def synchronize(self):
+        _lib.check(self.lib.mht_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.mht_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_model(A, Q, Cm, R, eta2, lambda_ex, default_pd):
+    m = _lib.MhtModel()
+    for name, arr, n in (("A", A, 16), ("Q", Q, 16), ("C", Cm, 8), ("R", R, 4)):
+        a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        assert a.size == n, name
+        getattr(m, name)[:] = a.tolist()
+    m.eta2 = float(eta2)
+    m.lambda_ex = float(lambda_ex)
+    m.default_pd = float(default_pd)
+    m.default_miss_nllr = float(-np.log(1 - default_pd))      # host libm, as pyTarget.py:326 evaluates it
+    return m
+
+
+class NodeLayer:
+    def __init__(self, cap, cap_cov, device):
+        self.cap, self.cap_cov, self.device = int(cap), int(cap_cov), device
+        self.x = torch.zeros((4, self.cap), dtype=torch.float64, device=device)
+        self.cnllr = torch.zeros(self.cap, dtype=torch.float64, device=device)
+        self.pd = torch.zeros(self.cap, dtype=torch.float64, device=device)
+        self.parent = torch.full((self.cap,), -1, dtype=torch.int32, device=device)
+        self.meas = torch.zeros(self.cap, dtype=torch.int32, device=device)
+        self.cov = torch.zeros(self.cap, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(self.cap, dtype=torch.uint8, device=device)
+        self.P = torch.zeros((16, self.cap_cov), dtype=torch.float32, device=device)
+        self.struct = _lib.MhtNodes(self.x.data_ptr(), self.cnllr.data_ptr(), self.pd.data_ptr(),
+                                    self.parent.data_ptr(), self.meas.data_ptr(), self.cov.data_ptr(),
+                                    self.flags.data_ptr(), self.P.data_ptr(), self.cap, self.cap_cov)
+
+    @classmethod
+    def from_host(cls, x, P, cnllr, pd, flags, device, cap=None):
+        """x (n,4) f64|f32, P (n,4,4) f32: one covariance column per node."""
+        n = x.shape[0]
+        layer = cls(cap or max(n, 1), cap or max(n, 1), device)
+        layer.x[:, :n] = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).T)).to(device)
+        layer.P[:, :n] = torch.from_numpy(np.ascontiguousarray(np.asarray(P, dtype=np.float32).reshape(n, 16).T)).to(device)
+        layer.cnllr[:n] = torch.from_numpy(np.asarray(cnllr, dtype=np.float64)).to(device)
+        layer.pd[:n] = torch.from_numpy(np.asarray(pd, dtype=np.float64)).to(device)
+        layer.flags[:n] = torch.from_numpy(np.asarray(flags, dtype=np.uint8)).to(device)
+        layer.cov[:n] = torch.arange(n, dtype=torch.int32, device=device)
+        return layer
+
+
+def process_leaf_nodes(ctx, model, x, P, cnllr, pd, flags, z):
+    """Stateless use of seam (i) (`Tracker._processLeafNodes`, tracker.py:383): host arrays in, host arrays out.
+    Returns a dict shaped like the oracle's process_leaves() result (CSR instead of lists)."""
+    lib, dev = ctx.lib, ctx.device
+    n, M = x.shape[0], z.shape[0]
+    lin = NodeLayer.from_host(x, P, cnllr, pd, flags, dev)
+    zd = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 2)).to(dev)
+    cap = max(n * 4 + 64, 1)
+    while True:
+        out = NodeLayer(cap, max(2 * n, 1), dev)
+        child_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        inc = torch.zeros(cap, dtype=torch.float64, device=dev)
+        used = torch.zeros(max((M + 63) // 64, 1), dtype=torch.int64, device=dev)
+        total = C.c_int32(0)
+        rc = lib.mht_gate_scan(ctx.handle, C.byref(model), C.byref(lin.struct), None, n, zd.data_ptr(), M,
+                               C.byref(out.struct), child_ptr.data_ptr(), inc.data_ptr(), used.data_ptr(), C.byref(total))
+        if rc == _lib.MHT_E_CAPACITY:
+            cap = total.value + 64
+            continue
+        _lib.check(rc)
+        break
+    nc = total.value
+    cp = child_ptr.cpu().numpy().astype(np.int64)
+    xs = out.x[:, :nc].cpu().numpy().T.copy()
+    meas = out.meas[:nc].cpu().numpy()
+    cn = out.cnllr[:nc].cpu().numpy()
+    incs = inc[:nc].cpu().numpy()
+    Pall = out.P[:, :2 * n].cpu().numpy().T.reshape(-1, 4, 4)
+    hit = meas > 0
+    return dict(child_ptr=cp, x=xs, meas=meas, cnllr=cn, inc=incs, flags=out.flags[:nc].cpu().numpy(),
+                parent=out.parent[:nc].cpu().numpy(), cov=out.cov[:nc].cpu().numpy(),
+                x_bar=xs[cp[:-1]], P_bar=Pall[0::2], P_hat=Pall[1::2],
+                row_ptr=cp - np.arange(n + 1), col_idx=(meas[hit] - 1).astype(np.int64), x_hat=xs[hit],
+                nllr=incs[hit], used=used.cpu().numpy().view(np.uint64))

@@ -1,0 +1,94 @@
+"""GPU: seam (i) -- mht_gate_scan through the C ABI against the golden vectors and the oracle."""
+import os
+import numpy as np
+import pytest
+
+import mht_oracle as orc
+from util import NLLR_ATOL, flags_for, gate_sets
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(g, pd=0.9):
+    from pymht_amd.device import make_model
+    return make_model(g["A"], g["Q"], g["C"], g["R"], float(g["eta2"]), float(g["lambda_ex"]), pd)
+
+
+def _run(ctx, g, x, P, z, pd, cn=None):
+    from pymht_amd.device import process_leaf_nodes
+    n = x.shape[0]
+    cn = np.zeros(n) if cn is None else cn
+    return process_leaf_nodes(ctx, _model(g, pd), x, P, cn, np.full(n, pd), flags_for(x), z)
+
+
+def test_gate_matches_golden_vectors(gpu_ctx, gold_dir):
+    g = np.load(os.path.join(gold_dir, "g1_kalman.npz"))
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        r = _run(gpu_ctx, g, k("x"), k("P"), k("z"), float(k("P_d")))
+        assert np.array_equal(r["row_ptr"], k("row_ptr")), c            # gating indices: bit-exact
+        assert np.array_equal(r["col_idx"], k("col_idx")), c
+        assert np.array_equal(r["x_bar"], k("x_bar").astype(np.float64)), c
+        assert np.array_equal(r["P_bar"], k("P_bar")) and np.array_equal(r["P_hat"], k("P_hat")), c
+        assert np.array_equal(r["x_hat"], k("x_hat").astype(np.float64)), c
+        assert np.allclose(r["nllr"], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c
+        # children layout: miss child first, hits ascending; parent/cov bookkeeping
+        cp = r["child_ptr"]
+        assert np.all(r["meas"][cp[:-1]] == 0)
+        for i in range(len(cp) - 1):
+            m = r["meas"][cp[i]:cp[i + 1]]
+            assert np.all(np.diff(m) > 0) and np.all(r["parent"][cp[i]:cp[i + 1]] == i)
+            assert r["cov"][cp[i]] == 2 * i and np.all(r["cov"][cp[i] + 1:cp[i + 1]] == 2 * i + 1)
+        # used-measurement mask (tracker.py:331-332)
+        used = np.zeros(k("z").shape[0], bool)
+        used[k("col_idx")] = True
+        bits = np.unpackbits(r["used"].view(np.uint8), bitorder="little")[:len(used)].astype(bool)
+        assert np.array_equal(bits, used), c
+
+
+def test_gate_headline_shape_checksums(gpu_ctx, gold_dir):
+    """5000 leaves x 500 measurements (BASELINE headline shape): CSR bit-exact, states by checksum."""
+    import hashlib
+    g = np.load(os.path.join(gold_dir, "g5_headline.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    P = g["P_table"][g["Pidx"].astype(np.int64)]
+    A, Q, Cm, R = orc.model_Phi(2.5), orc.model_Q(2.5), orc.model_C(), orc.model_R()
+    gm = dict(A=A, Q=Q, C=Cm, R=R, eta2=float(g["eta2"]), lambda_ex=float(g["lambda_ex"]))
+    r = _run(gpu_ctx, gm, g["x"], P, g["z"], float(g["P_d"]))
+    assert np.array_equal(r["row_ptr"], g["row_ptr"]) and np.array_equal(r["col_idx"], g["col_idx"])
+    assert int(g["G"]) == len(r["col_idx"])
+    assert sha(r["x_bar"]) == str(g["sha_x_bar"]) and sha(r["P_bar"]) == str(g["sha_P_bar"])
+    assert sha(r["P_hat"]) == str(g["sha_P_hat"]) and sha(r["x_hat"]) == str(g["sha_x_hat"])
+    assert np.array_equal(r["x_hat"][:64], g["x_hat_head"]) and np.array_equal(r["x_hat"][-64:], g["x_hat_tail"])
+    assert np.allclose(r["nllr"][:64], g["nllr_head"], rtol=0, atol=NLLR_ATOL)
+    assert np.allclose(r["nllr"][-64:], g["nllr_tail"], rtol=0, atol=NLLR_ATOL)
+
+
+@pytest.mark.parametrize("n,M,seed", [(1, 0, 1), (0, 5, 2), (3, 1, 3), (700, 64, 4), (65, 65, 5), (129, 1000, 6), (33, 4096, 7)])
+def test_gate_vs_oracle_random_shapes(gpu_ctx, n, M, seed):
+    """Edge shapes (empty scan, empty batch, ragged tiles, M at word boundaries, maximum M) vs the oracle."""
+    rng = np.random.default_rng(seed)
+    A, Q, Cm, R = orc.model_Phi(2.5), orc.model_Q(2.5), orc.model_C(), orc.model_R()
+    gm = dict(A=A, Q=Q, C=Cm, R=R, eta2=5.99, lambda_ex=1.2e-4)
+    x = np.concatenate([rng.uniform(-500, 500, size=(n, 2)), rng.normal(0, 5, size=(n, 2))], axis=1)
+    P = np.array([orc.model_P0()] * n).reshape(n, 4, 4)
+    xb = A.astype(np.float64).dot(x.T).T if n else np.zeros((0, 4))
+    z = rng.uniform(-500, 500, size=(M, 2))
+    if n and M:
+        pick = rng.integers(0, n, size=M)
+        near = rng.uniform(size=M) < 0.5
+        z[near] = xb[pick[near], 0:2] + rng.normal(0, 7.0, size=(int(near.sum()), 2))
+    z = z.astype(np.float32)
+    cn = rng.normal(0, 1, size=n)
+    r = _run(gpu_ctx, gm, x, P, z, 0.8, cn)
+    if n == 0:
+        assert r["child_ptr"].tolist() == [0]
+        return
+    o = orc.process_leaves(A, Q, Cm, R, 5.99, 1.2e-4, x, P, [0.8] * n, z.reshape(-1, 2))
+    assert gate_sets(r["row_ptr"], r["col_idx"]) == [tuple(i.tolist()) for i in o["idx"]]
+    assert np.array_equal(r["x_bar"], o["x_bar"]) and np.array_equal(r["P_hat"], o["P_hat"])
+    if len(r["col_idx"]):
+        assert np.array_equal(r["x_hat"], np.concatenate(o["x_hat"], axis=0))
+        assert np.allclose(r["nllr"], np.concatenate(o["nllr"]), rtol=0, atol=NLLR_ATOL)
+    miss = r["cnllr"][r["child_ptr"][:-1]]
+    assert np.array_equal(miss, cn - np.log(1 - 0.8))

@@ -1,0 +1,44 @@
+"""CPU: the kernel arithmetic (pymht_amd/csrc/mht_math.h, host build) against the golden vectors -- bit for bit
+for everything that decides gating and for the Kalman states; 1 ulp(f32) on the NLLR constant."""
+import ctypes as C
+import os
+import numpy as np
+
+from util import NLLR_ATOL
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def run_host(lib, g, x, P, z, P_d):
+    f32 = x.dtype == np.float32
+    n, M = x.shape[0], z.shape[0]
+    xd, P, z = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(P), np.ascontiguousarray(z)
+    o = dict(x_bar=np.zeros((n, 4)), P_bar=np.zeros((n, 4, 4), np.float32), P_hat=np.zeros((n, 4, 4), np.float32),
+             S=np.zeros((n, 2, 2), np.float32), S_inv=np.zeros((n, 2, 2), np.float32), K=np.zeros((n, 4, 2), np.float32),
+             nis=np.zeros((n, M)), gate=np.zeros((n, M), np.uint8), x_hat=np.zeros((n, M, 4)), nllr=np.zeros((n, M)))
+    lib.mht_host_process(_p(g["A"]), _p(g["Q"]), _p(g["C"]), _p(g["R"]), C.c_double(float(g["eta2"])),
+                         C.c_double(float(g["lambda_ex"])), int(f32), n, M, _p(xd), _p(P), _p(z), C.c_double(P_d),
+                         *[_p(o[k]) for k in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K", "nis", "gate", "x_hat", "nllr")])
+    return o
+
+
+def test_hostmath_matches_reference_vectors(gold_dir, hostmath):
+    g = np.load(os.path.join(gold_dir, "g1_kalman.npz"))
+    g = {k: g[k] for k in g.files}
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        o = run_host(hostmath, g, k("x"), k("P"), k("z"), float(k("P_d")))
+        n, M = o["gate"].shape
+        assert np.array_equal(o["x_bar"], k("x_bar").astype(np.float64)), c
+        for name in ("P_bar", "P_hat", "S", "S_inv", "K"):
+            assert np.array_equal(o[name], k(name)), (c, name)
+        rp, ci = k("row_ptr"), k("col_idx")
+        mask = np.zeros((n, M), bool)
+        for i in range(n):
+            mask[i, ci[rp[i]:rp[i + 1]]] = True
+        assert np.array_equal(mask, o["gate"].astype(bool)), c                       # gating: bit-exact
+        assert np.array_equal(o["nis"][mask], k("nis_gated").astype(np.float64)), c  # NIS: bit-exact
+        assert np.array_equal(o["x_hat"][mask], k("x_hat").astype(np.float64)), c    # states: bit-exact
+        assert np.allclose(o["nllr"][mask], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c

@@ -1,0 +1,59 @@
+"""CPU: the oracle (oracle/mht_oracle.py) against the golden vectors generated from the real reference."""
+import os
+import numpy as np
+import pytest
+
+import mht_oracle as orc
+from util import gate_sets
+
+
+def test_model_matrices_match_reference(gold_dir):
+    g = np.load(os.path.join(gold_dir, "g1_kalman.npz"))
+    assert np.array_equal(orc.model_Phi(2.5), g["A"]) and np.array_equal(orc.model_Q(2.5), g["Q"])
+    assert np.array_equal(orc.model_C(), g["C"]) and np.array_equal(orc.model_R(), g["R"])
+    from pymht_amd.models import pv
+    assert np.array_equal(pv.Phi(2.5), g["A"]) and np.array_equal(pv.Q(2.5), g["Q"])
+    assert np.array_equal(pv.C_RADAR, g["C"]) and np.array_equal(pv.R_RADAR(), g["R"])
+    assert pv.P0.dtype == np.float32 and np.array_equal(pv.P0, orc.model_P0())
+
+
+def test_kalman_kernels_bitwise(gold_dir):
+    g = np.load(os.path.join(gold_dir, "g1_kalman.npz"))
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        x, P, z = k("x"), k("P"), k("z")
+        r = orc.process_leaves(g["A"], g["Q"], g["C"], g["R"], float(g["eta2"]), float(g["lambda_ex"]), x, P,
+                               [float(k("P_d"))] * len(x), z)
+        for name in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K", "z_hat"):
+            assert np.array_equal(r[name], k(name)), (c, name)
+            assert r[name].dtype == k(name).dtype
+        rp = np.concatenate([[0], np.cumsum([len(i) for i in r["idx"]])])
+        assert np.array_equal(rp, k("row_ptr")) and np.array_equal(np.concatenate(r["idx"]), k("col_idx"))
+        assert np.array_equal(np.concatenate(r["x_hat"], axis=0), k("x_hat"))
+        # NumPy's float32 log is CPU-dispatch dependent (AVX512F vs AVX2 kernels): 1 ulp(f32) slack off this box
+        assert np.allclose(np.concatenate(r["nllr"]), k("nllr"), rtol=0, atol=5e-7)
+
+
+def test_blp_exact_matches_recorded_and_bruteforce(gold_dir):
+    g = np.load(os.path.join(gold_dir, "g4_ilp.npz"))
+    n = int(g["n_inst"])
+    assert n >= 50
+    for i in range(n):
+        p = "i%03d_" % i
+        ptr, rows = g[p + "col_ptr"], g[p + "col_rows"]
+        cols = [rows[ptr[c]:ptr[c + 1]].tolist() for c in range(len(ptr) - 1)]
+        sizes, cost = g[p + "sizes"].tolist(), g[p + "cost"]
+        sel, obj = orc.solve_blp_exact(cols, sizes, cost)
+        assert abs(obj - float(g[p + "obj"])) <= 1e-9 * max(1.0, abs(obj))
+        if bool(g[p + "unique"]):
+            assert sel == g[p + "sel"].tolist()
+        if len(cols) <= 40 and len(sizes) <= 3:
+            bs, bo, ties = orc.solve_blp_bruteforce(cols, sizes, cost)
+            assert abs(bo - obj) < 1e-9 and (ties > 1 or sorted(bs) == sel)
+
+
+@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2"])
+def test_scan_trace_replay(gold_dir, name):
+    """Replays the recorded scans through OracleTracker and compares every scan with what the reference did."""
+    from trace_util import replay_oracle
+    replay_oracle(os.path.join(gold_dir, name + ".npz"))
