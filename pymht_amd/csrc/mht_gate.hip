@@ -326,6 +326,7 @@ static inline size_t gate_lds_bytes(int W) {
 
 int launch_gate(mht_ctx* ctx, GateArgs& a) {
     const int L = a.L, W = a.W;
+    a.status = ctx->status;
     if (L <= 0) {
         hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(EMIT_THREADS), 0, ctx->stream, a);
         MHT_HIP_CHECK(hipGetLastError());
