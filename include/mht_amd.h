@@ -105,6 +105,111 @@ int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nodes* in, con
                   const float* z, int32_t M, const mht_nodes* out, int32_t* child_ptr, double* nllr,
                   uint64_t* used, int32_t* n_children);
 
+
+/* ---- seam (ii): Tracker._findClustersFromSets (tracker.py:961-974) -------------------------------------------
+ * assoc  dev [T][words] uint64: bit b of row t set iff target t is associated with measurement node b
+ *        (the reference's __associatedMeasurements__ sets; a node is a (scan, measurement) of the window)
+ * label  dev [T] int32 out: smallest target index of the connected component of t.  Clusters ordered by label
+ *        with ascending members are exactly the reference's cluster list. */
+int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_t* assoc, int32_t* label);
+
+/* ---- seam (iii): Tracker._solveBLP_OR_TOOLS(A1, A2, f) (tracker.py:1155-1217) ---------------------------------
+ * One 0-1 ILP:  min f.tau  s.t.  A1 tau <= 1, A2 tau = 1, tau binary, in the sparse form the tree gives it:
+ *   group_ptr dev [nT+1] int32 : columns group_ptr[t] .. group_ptr[t+1]-1 belong to target t (A2, tracker.py:1115)
+ *   rows      dev [depth][nHyp] int32 : rows[d*nHyp+h] = d-th measurement row of column h or -1 (A1 by columns)
+ *   cost      dev [nHyp] double  (f = getScore()/N, tracker.py:1124-1136)
+ *   selected  dev [nT] int32 out : chosen column per target (ascending = the reference's return list)
+ *   objective/status/iterations/nodes : host out (status MHT_BLP_*).  Synchronises the stream. */
+int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRows, int32_t depth, const int32_t* group_ptr,
+                  const int32_t* rows, const double* cost, int32_t max_iter, int32_t node_limit, int32_t* selected,
+                  double* objective, int32_t* status, int32_t* iterations, int32_t* nodes);
+
+/* ---- the device-resident hypothesis forest: Tracker.addMeasurementList end to end -----------------------------
+ * Replaces steps 1-6 of tracker.py:162-307 (grow :207-209, cluster :220, optimise :228-236, terminate :252-253,
+ * N-scan prune :258 = seam (iv) Tracker._nScanPruning, tracker.py:1219-1231 / pyTarget.py:343-356) without a host
+ * round trip between the stages.  The tree store of pyTarget.Target objects becomes a ring of mht_nodes layers
+ * (one per scan of the window) owned by the ctx. */
+typedef struct mht_forest_config {
+    int32_t max_targets;  /* capacity of the target list */
+    int32_t max_nodes;    /* hypotheses per scan layer (children of one scan + roots born in it) */
+    int32_t max_meas;     /* measurements per scan (<= 2048) */
+    int32_t n_scan;       /* Tracker.N: N-scan window (tracker.py:112-114) */
+    int32_t blp_max_iter; /* dual-ascent steps before branch and bound (default 200 when <= 0) */
+    int32_t blp_node_limit; /* branch-and-bound node budget per cluster (default 1<<20 when <= 0) */
+    double score_limit;   /* Tracker.scoreUpperLimit  (tracker.py:115) */
+    double cnllr_limit;   /* Tracker.clnnrUpperLimit  (tracker.py:116) */
+    double radar_x, radar_y, radar_range; /* Tracker.position / radarRange (tracker.py:44-45), range may be +inf */
+    double merge_threshold; /* Tracker.mergeThreshold (tracker.py:65) used by initiateTarget */
+} mht_forest_config;
+
+/* per-target record of the scan report (old target-list order) */
+typedef struct mht_target_report {
+    int32_t id;         /* Target.ID */
+    int32_t status;     /* 0 alive, 1 out of range, 2 score too high, 3 cNLLR too high (tracker.py:891-916) */
+    int32_t sel_node;   /* index of the selected leaf (__trackNodes__[t]) in the layer of this scan */
+    int32_t sel_meas;   /* its measurementNumber */
+    int32_t new_index;  /* index in the target list after termination, -1 if terminated */
+    int32_t root_scan;  /* scanNumber of the root after N-scan pruning */
+    int32_t root_node;  /* node index of that root in its layer */
+    int32_t n_leaves;   /* leaves kept for the next scan */
+    double sel_x[4];    /* state of the selected leaf */
+    double sel_cnllr;   /* its cumulativeNLLR */
+    double score;       /* getScore() = cNLLR - root.cNLLR before pruning (pyTarget.py:124) */
+    double root_cnllr;  /* cumulativeNLLR of the root after pruning */
+    double root_x[4];   /* state of the root after pruning */
+    int32_t root_meas;  /* measurementNumber of the root after pruning */
+    int32_t cluster;    /* smallest target index of this target's cluster (tracker.py:961-974) */
+} mht_target_report;
+
+typedef struct mht_scan_report {
+    int32_t scan;          /* scanNumber just processed */
+    int32_t n_targets;     /* targets before termination (= number of records) */
+    int32_t n_alive;
+    int32_t n_leaves_in;   /* L: leaves gated in this scan */
+    int32_t n_children;    /* L + G */
+    int32_t n_leaves_out;  /* leaves kept for the next scan */
+    int32_t n_clusters, n_ilp; /* clusters, clusters with >= 2 targets (Tracker.nOptimSolved) */
+    int32_t n_branched;    /* ILPs that needed branch and bound */
+    int32_t n_limit;       /* ILPs that hit the node limit (selection feasible, not proven optimal) */
+    int32_t blp_iters_max;
+    int32_t error;         /* 0 or MHT_E_CAPACITY if a pool overflowed during the scan */
+    int32_t used_words;    /* number of valid words in `used` */
+    int32_t pad[3];
+    const uint64_t* used;              /* host: bit j set iff measurement j was gated by some leaf */
+    const mht_target_report* targets;  /* host: n_targets records */
+} mht_scan_report;
+
+int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg);
+/* Tracker.initiateTarget (tracker.py:147-160) for n candidates in order: a candidate closer than merge_threshold
+ * to any current leaf (or to an earlier accepted candidate) is discarded when check_neighbours != 0.
+ * x0 host [n][4] double, P0 host [n][16] float, flags host [n] uint8 (MHT_F_*), pd host [n] double,
+ * meas host [n] int32 (measurementNumber of the new root), accepted host [n] uint8 out (may be NULL),
+ * ids host [n] int32 out (assigned Target.ID or -1; may be NULL).  Synchronises when an output is requested. */
+int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
+                           const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
+                           int32_t* ids);
+/* One scan, asynchronous: z dev (M,2) float32.  */
+int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
+/* Same with z in host memory (copied through a pinned staging buffer of the ctx). */
+int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M);
+/* Wait for the last step and expose its report (pointers stay valid until the next call on this ctx). */
+int mht_forest_report(mht_ctx* ctx, mht_scan_report* out);
+/* Snapshot of the current leaves in target-list / DFS order (pyTarget.getLeafNodes order): any pointer may be
+ * NULL.  x host [n][4], P host [n][16], cnllr host [n], meas/target/id/node host [n] int32, flags host [n] uint8.
+ * capacity = length of the host arrays; *n_out = number of leaves.  Synchronises. */
+int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
+                      int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
+/* Per-stage device time of the last step in milliseconds: [0] grow (gate+emit) = the reference's toc['Process'],
+ * [1] cluster, [2] optimise (ILP + single-target selection), [3] terminate + N-scan prune, [4] whole step.
+ * Timing is off by default (two hipEventRecord per stage); enable != 0 switches it on for subsequent steps. */
+int mht_forest_set_timing(mht_ctx* ctx, int32_t enable);
+int mht_forest_stage_times(mht_ctx* ctx, float* ms5);
+/* Ancestor chain of one node: walks parents from (scan, node) towards the root of time, at most max_len steps
+ * (bounded by the ring: layers older than n_scan+1 scans are gone).  Outputs host arrays
+ * nodes/meas [max_len] int32, x [max_len][4], cnllr [max_len], P [max_len][16]; any may be NULL. */
+int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                     double* x, double* cnllr, float* P, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,7 +236,7 @@ def gen_g1(mods):
     np.savez_compressed(os.path.join(GOLD, "g1_kalman.npz"), **fx)
 
 
-def gen_g4(instances):
+def gen_g4(instances, name="g4_ilp"):
     """Recorded ILP instances + exact optimum + uniqueness (re-solve with a no-good cut)."""
     from scipy.optimize import milp, LinearConstraint, Bounds
     from scipy.sparse import csr_matrix
@@ -277,8 +277,8 @@ def gen_g4(instances):
         fx[p + "unique"] = unique
         kept += 1
     fx["n_inst"] = kept
-    np.savez_compressed(os.path.join(GOLD, "g4_ilp.npz"), **fx)
-    print("  g4: %d instances, %d unique" % (kept, sum(bool(fx["i%03d_unique" % i]) for i in range(kept))))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+    print("  " + name + ": %d instances, %d unique" % (kept, sum(bool(fx["i%03d_unique" % i]) for i in range(kept))))
 
 
 def gen_g5(mods):
@@ -330,7 +330,7 @@ def main():
     logging.disable(logging.CRITICAL)
     os.makedirs(GOLD, exist_ok=True)
     mods = refimport.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3b", "g4", "g5", "g6"]
     if "g1" in which:
         gen_g1(mods)
     ilps = []
@@ -345,6 +345,13 @@ def main():
         gen_g4(ilps)
     if "g5" in which:
         gen_g5(mods)
+    if "g6" in which:
+        # headline config (500 targets, ~500 meas/scan, N=5): hashed trace + the hardest ILP instances
+        big = []
+        run_trace(mods, make_config("cfg3", seed=5446), "g6_trace_cfg3", n_scans=9, record_ilp=big, store_leaves=False)
+        order = sorted(range(len(big)), key=lambda i: -len(big[i]["cols"]))
+        keep = sorted(set(order[:40]) | set(order[40::7]))
+        gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
 
 
 if __name__ == "__main__":

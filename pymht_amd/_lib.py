@@ -23,6 +23,27 @@ class MhtNodes(C.Structure):
                 ("cap", C.c_int32), ("cap_cov", C.c_int32)]
 
 
+class MhtForestConfig(C.Structure):
+    _fields_ = [("max_targets", C.c_int32), ("max_nodes", C.c_int32), ("max_meas", C.c_int32), ("n_scan", C.c_int32),
+                ("blp_max_iter", C.c_int32), ("blp_node_limit", C.c_int32), ("score_limit", C.c_double),
+                ("cnllr_limit", C.c_double), ("radar_x", C.c_double), ("radar_y", C.c_double),
+                ("radar_range", C.c_double), ("merge_threshold", C.c_double)]
+
+
+class MhtTargetReport(C.Structure):
+    _fields_ = [("id", C.c_int32), ("status", C.c_int32), ("sel_node", C.c_int32), ("sel_meas", C.c_int32),
+                ("new_index", C.c_int32), ("root_scan", C.c_int32), ("root_node", C.c_int32), ("n_leaves", C.c_int32),
+                ("sel_x", C.c_double * 4), ("sel_cnllr", C.c_double), ("score", C.c_double), ("root_cnllr", C.c_double),
+                ("root_x", C.c_double * 4), ("root_meas", C.c_int32), ("cluster", C.c_int32)]
+
+
+class MhtScanReport(C.Structure):
+    _fields_ = [("scan", C.c_int32), ("n_targets", C.c_int32), ("n_alive", C.c_int32), ("n_leaves_in", C.c_int32),
+                ("n_children", C.c_int32), ("n_leaves_out", C.c_int32), ("n_clusters", C.c_int32), ("n_ilp", C.c_int32),
+                ("n_branched", C.c_int32), ("n_limit", C.c_int32), ("blp_iters_max", C.c_int32), ("error", C.c_int32),
+                ("used_words", C.c_int32), ("pad", C.c_int32 * 3), ("used", C.c_void_p), ("targets", C.c_void_p)]
+
+
 class MhtError(RuntimeError):
     def __init__(self, code, message):
         RuntimeError.__init__(self, "libmht_amd error %d: %s" % (code, message))
@@ -62,6 +83,18 @@ def _declare(lib):
         "mht_synchronize": [vp],
         "mht_gate_scan": [vp, C.POINTER(MhtModel), C.POINTER(MhtNodes), vp, i32, vp, i32, C.POINTER(MhtNodes), vp,
                           vp, vp, C.POINTER(i32)],
+        "mht_cluster": [vp, i32, i32, vp, vp],
+        "mht_solve_blp": [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(dbl), C.POINTER(i32),
+                          C.POINTER(i32), C.POINTER(i32)],
+        "mht_forest_create": [vp, C.POINTER(MhtModel), C.POINTER(MhtForestConfig)],
+        "mht_forest_add_targets": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
+        "mht_forest_step": [vp, vp, i32],
+        "mht_forest_step_host": [vp, vp, i32],
+        "mht_forest_report": [vp, C.POINTER(MhtScanReport)],
+        "mht_forest_leaves": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
+        "mht_forest_chain": [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)],
+        "mht_forest_set_timing": [vp, i32],
+        "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,505 @@
+// Global-hypothesis selection: per cluster the 0-1 ILP
+//      min  sum_h f_h tau_h   s.t.  A1 tau <= 1 (a measurement in at most one selected leaf),
+//                                   A2 tau  = 1 (exactly one leaf per target),  tau binary
+// (reference: Tracker._solveOptimumAssociation / _solveBLP_OR_TOOLS, pymht/tracker.py:979-1027, :1155-1217, which
+// builds dense A1/A2 with recursive Python + list.index and hands them to OR-Tools CBC), and for a target that is
+// alone in its cluster Target._selectBestHypothesis (pymht/pyTarget.py:446-459).
+//
+// One workgroup per multi-target cluster.  Columns are the new leaf hypotheses (children) of the cluster's
+// targets in DFS order; the rows a column touches are the measurement nodes on its root->leaf path (path[d][h]).
+// Solver (all on the GPU):
+//   1. Lagrangian relaxation of A1 with prices u >= 0 on measurement nodes; per target the minimiser of the
+//      reduced cost f_h + sum u.  If the minimisers are conflict-free and every priced node is used exactly once
+//      (complementary slackness) the primal cost equals the dual bound: CERTIFIED optimal.  Projected subgradient
+//      steps (Polyak step length, upper bound from a greedy dive) move the prices otherwise.
+//   2. If the certificate is not reached in max_iter steps: depth-first branch and bound over the targets with
+//      the Lagrangian bound (valid for any u >= 0), exact up to 1e-12 relative: BRANCHED.
+// The reference's LP relaxation is integral in >99 % of instances, so step 2 is rare; it keeps
+// the selection exact without any host fallback.
+#include "mht_kernels.h"
+
+namespace mht {
+
+
+constexpr int BLP_THREADS = 256;
+constexpr int BLP_UW = 512;       // words of the cluster's measurement-node bitset kept in LDS (32768 nodes)
+constexpr double DINF = 1.0e300;
+
+struct Red {
+    double d[BLP_THREADS / 64];
+    int i[BLP_THREADS / 64];
+    double rd;
+    int ri;
+};
+
+__device__ __forceinline__ double block_sum(double v, Red* r) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) r->d[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLP_THREADS / 64; ++w) s += r->d[w];
+    return s;
+}
+
+__device__ __forceinline__ int block_or(int v, Red* r) {
+    v = __any(v) ? 1 : 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) r->i[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < BLP_THREADS / 64; ++w) s |= r->i[w];
+    return s;
+}
+
+// lexicographic (value, index) minimum; index -1 = none
+__device__ __forceinline__ void wave_min_pair(double& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (oi >= 0 && (i < 0 || ov < v || (ov == v && oi < i))) { v = ov; i = oi; }
+    }
+}
+__device__ __forceinline__ void block_min_pair(double& v, int& i, Red* r) {
+    wave_min_pair(v, i);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { r->d[threadIdx.x >> 6] = v; r->i[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    v = r->d[0];
+    i = r->i[0];
+#pragma unroll
+    for (int w = 1; w < BLP_THREADS / 64; ++w) {
+        const double ov = r->d[w];
+        const int oi = r->i[w];
+        if (oi >= 0 && (i < 0 || ov < v || (ov == v && oi < i))) { v = ov; i = oi; }
+    }
+}
+
+__device__ __forceinline__ double reduced_cost(const BlpArgs& a, int h) {
+    double rc = a.cost[h];
+    for (int d = 0; d < a.PD; ++d) {
+        const int e = a.path[(size_t)d * a.cap + h];
+        if (e >= 0) rc += a.u[e];
+    }
+    return rc;
+}
+__device__ __forceinline__ bool compatible(const BlpArgs& a, int h) {
+    for (int d = 0; d < a.PD; ++d) {
+        const int e = a.path[(size_t)d * a.cap + h];
+        if (e >= 0 && a.mark[e]) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void set_marks(const BlpArgs& a, int h, int value) {
+    if ((int)threadIdx.x < a.PD) {
+        const int e = a.path[(size_t)threadIdx.x * a.cap + h];
+        if (e >= 0) a.mark[e] = value;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+__device__ __forceinline__ double priced_sum(const BlpArgs& a, int h, Red* r) {    // sum of u over the rows of column h
+    double v = 0.0;
+    if ((int)threadIdx.x < a.PD) {
+        const int e = a.path[(size_t)threadIdx.x * a.cap + h];
+        if (e >= 0) v = a.u[e];
+    }
+    return block_sum(v, r);
+}
+
+// greedy dive: targets in cluster order, each takes its cheapest (reduced cost) column compatible with the
+// columns already taken.  Always feasible: every target owns an all-miss column without measurements.
+__device__ double greedy_dive(const BlpArgs& a, const int32_t* mem, int K, int32_t* out_sel, Red* r) {
+    double total = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const int t = mem[k];
+        double bv = DINF;
+        int bi = -1;
+        for (int h = a.tchild[t] + threadIdx.x; h < a.tchild[t + 1]; h += BLP_THREADS) {
+            if (!compatible(a, h)) continue;
+            const double rc = reduced_cost(a, h);
+            if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+        }
+        block_min_pair(bv, bi, r);
+        out_sel[k] = bi;
+        total += a.cost[bi];
+        set_marks(a, bi, 1);
+    }
+    for (int k = 0; k < K; ++k) set_marks(a, out_sel[k], 0);
+    return total;
+}
+
+__device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
+    const int32_t* mem = a.cl_members + a.cl_ptr[c];
+    const int slot = a.cl_ptr[c] + c;
+    int32_t* best_h = a.best_h + slot;
+    double* best_rc = a.best_rc + slot;
+    int32_t* ub_sel = a.bb_best + slot;
+    const int UW = (a.n_mnodes + 63) >> 6;
+    // ---- measurement nodes of the cluster (union of the rows of its columns) -----------------------------
+    for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const int t = mem[k];
+        for (int d = 0; d < a.PD; ++d)
+            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
+                const int e = a.path[(size_t)d * a.cap + h];
+                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+            }
+    }
+    __syncthreads();
+    for (int w = tid; w < UW; w += BLP_THREADS) {
+        unsigned long long bits = uw[w];
+        while (bits) {
+            const int m = w * 64 + __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            a.u[m] = 0.0;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
+    int stall = 0, status = 0, iters = 0;
+    for (int it = 0; it <= a.max_iter; ++it) {
+        iters = it;
+        // A: per target the minimiser of the reduced cost (one wavefront per target, lowest index wins ties)
+        for (int k = wave; k < K; k += BLP_THREADS / 64) {
+            const int t = mem[k];
+            double bv = DINF;
+            int bi = -1;
+            for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
+                const double rc = reduced_cost(a, h);
+                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            }
+            wave_min_pair(bv, bi);
+            if (lane == 0) { best_h[k] = bi; best_rc[k] = bv; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // B: how often each measurement node is used by the minimisers
+        for (int idx = tid; idx < K * a.PD; idx += BLP_THREADS) {
+            const int k = idx / a.PD, d = idx - k * a.PD;
+            const int e = a.path[(size_t)d * a.cap + best_h[k]];
+            if (e >= 0) atomicAdd(&a.usage[e], 1);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // C: subgradient, dual value, certificate
+        double nrm = 0.0, usum = 0.0;
+        int conflict = 0, slack = 0;
+        for (int w = tid; w < UW; w += BLP_THREADS) {
+            unsigned long long bits = uw[w];
+            while (bits) {
+                const int m = w * 64 + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int us = a.usage[m];
+                const double um = a.u[m];
+                double g = (double)(us - 1);
+                if (um <= 0.0 && g < 0.0) g = 0.0;
+                nrm += g * g;
+                usum += um;
+                conflict |= (us >= 2);
+                slack |= (um > 0.0 && us == 0);
+            }
+        }
+        double src = 0.0, sc = 0.0;
+        for (int k = tid; k < K; k += BLP_THREADS) { src += best_rc[k]; sc += a.cost[best_h[k]]; }
+        nrm = block_sum(nrm, r);
+        utot = block_sum(usum, r);
+        src = block_sum(src, r);
+        sc = block_sum(sc, r);
+        conflict = block_or(conflict, r);
+        slack = block_or(slack, r);
+        const double LB = src - utot;
+        if (!conflict && sc < UB) {
+            UB = sc;
+            for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = best_h[k];
+        }
+        bool done = false;
+        if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
+        if (!done) {
+            if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
+            else if (++stall >= 10) { theta *= 0.5; stall = 0; }
+            if (UB >= DINF || (conflict && (it % 8) == 0)) {
+                const double g = greedy_dive(a, mem, K, a.bb_ch + slot, r);
+                if (g < UB) {
+                    UB = g;
+                    for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = a.bb_ch[slot + k];
+                    __threadfence_block();
+                    __syncthreads();
+                }
+            }
+            if (UB - best_LB <= 1e-12 * fmax(1.0, fabs(UB))) { status = MHT_BLP_CERTIFIED; done = true; }   // zero duality gap
+            if (it == a.max_iter || nrm == 0.0) done = true;
+        }
+        // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
+        const double step = done ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
+        for (int w = tid; w < UW; w += BLP_THREADS) {
+            unsigned long long bits = uw[w];
+            while (bits) {
+                const int m = w * 64 + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                if (!done) {
+                    const double um = a.u[m];
+                    double g = (double)(a.usage[m] - 1);
+                    if (um <= 0.0 && g < 0.0) g = 0.0;
+                    a.u[m] = fmax(0.0, um + step * g);
+                }
+                a.usage[m] = 0;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (done) break;
+    }
+
+    int nodes = 0;
+    if (status == 0) {
+        // ---- depth-first branch and bound with the current prices -------------------------------------------
+        double usum = 0.0;
+        for (int w = tid; w < UW; w += BLP_THREADS) {
+            unsigned long long bits = uw[w];
+            while (bits) {
+                const int m = w * 64 + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                usum += a.u[m];
+            }
+        }
+        utot = block_sum(usum, r);
+        int32_t* ch = a.bb_ch + slot;
+        double* cst = a.bb_cost + slot;
+        double* uus = a.bb_uused + slot;
+        double* lrc = a.bb_last_rc + slot;
+        int32_t* lix = a.bb_last_idx + slot;
+        double* rest = a.bb_rest + slot;
+        double* mn = a.bb_min + slot;
+        if (UB >= DINF) {
+            UB = greedy_dive(a, mem, K, ch, r);
+            for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = ch[k];
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid == 0) { cst[0] = 0.0; uus[0] = 0.0; }
+        __threadfence_block();
+        __syncthreads();
+        int level = 0;
+        bool enter = true;
+        status = MHT_BLP_BRANCHED;
+        while (true) {
+            const double eps = 1e-12 * fmax(1.0, fabs(UB));
+            if (enter) {
+                if (++nodes > a.node_limit) { status = MHT_BLP_NODE_LIMIT; break; }
+                if (level == K) {
+                    if (cst[K] < UB - eps) {
+                        UB = cst[K];
+                        for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = ch[k];
+                        __threadfence_block();
+                        __syncthreads();
+                    }
+                    --level;
+                    set_marks(a, ch[level], 0);
+                    enter = false;
+                    continue;
+                }
+                for (int j = level + wave; j < K; j += BLP_THREADS / 64) {
+                    const int t = mem[j];
+                    double bv = DINF;
+                    int bi = -1;
+                    for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
+                        if (!compatible(a, h)) continue;
+                        const double rc = reduced_cost(a, h);
+                        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+                    }
+                    wave_min_pair(bv, bi);
+                    if (lane == 0) mn[j] = (bi < 0) ? DINF : bv;
+                }
+                __threadfence_block();
+                __syncthreads();
+                double rs = 0.0;
+                int dead = 0;
+                for (int j = level + tid; j < K; j += BLP_THREADS) {
+                    const double v = mn[j];
+                    if (v >= DINF) dead = 1;
+                    else if (j > level) rs += v;
+                }
+                rs = block_sum(rs, r);
+                dead = block_or(dead, r);
+                const double lb = cst[level] + mn[level] + rs - (utot - uus[level]);
+                if (dead || lb >= UB - eps) {
+                    if (level == 0) break;
+                    --level;
+                    set_marks(a, ch[level], 0);
+                    enter = false;
+                    continue;
+                }
+                if (tid == 0) { rest[level] = rs; lrc[level] = -DINF; lix[level] = -1; }
+                __threadfence_block();
+                __syncthreads();
+                enter = false;
+            }
+            // next candidate of target `level` in increasing (reduced cost, index) order
+            const int t = mem[level];
+            const double prc = lrc[level];
+            const int pix = lix[level];
+            double bv = DINF;
+            int bi = -1;
+            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
+                if (!compatible(a, h)) continue;
+                const double rc = reduced_cost(a, h);
+                if (rc < prc || (rc == prc && h <= pix)) continue;
+                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            }
+            block_min_pair(bv, bi, r);
+            if (bi < 0 || cst[level] + bv + rest[level] - (utot - uus[level]) >= UB - eps) {
+                if (level == 0) break;
+                --level;
+                set_marks(a, ch[level], 0);
+                continue;
+            }
+            const double pu = priced_sum(a, bi, r);
+            if (tid == 0) {
+                lrc[level] = bv;
+                lix[level] = bi;
+                ch[level] = bi;
+                cst[level + 1] = cst[level] + a.cost[bi];
+                uus[level + 1] = uus[level] + pu;
+            }
+            set_marks(a, bi, 1);
+            ++level;
+            enter = true;
+        }
+        // leave no marks behind
+        for (int l = 0; l < level; ++l) set_marks(a, ch[l], 0);
+    }
+    for (int k = tid; k < K; k += BLP_THREADS) a.sel[mem[k]] = ub_sel[k];
+    if (tid == 0) {
+        a.cl_status[c] = status;
+        a.cl_iters[c] = iters;
+        a.cl_nodes[c] = nodes;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
+    __shared__ unsigned long long uw[BLP_UW];
+    __shared__ Red red;
+    const int nMulti = a.counts[1], nSingle = a.counts[2];
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, &red);
+    // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
+    const int lane = threadIdx.x & 63;
+    const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
+    for (int i = gw; i < nSingle; i += gridDim.x * (BLP_THREADS / 64)) {
+        const int t = a.single_list[i];
+        double bv = DINF;
+        int bi = -1;
+        for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
+            const double v = a.cnllr[h];
+            if (bi < 0 || v <= bv) { bv = v; bi = h; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) a.sel[t] = bi;
+    }
+}
+
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
+    if ((a.n_mnodes + 63) / 64 > BLP_UW) {
+        set_error("blp: %d measurement nodes exceed the LDS bitset (%d)", a.n_mnodes, BLP_UW * 64);
+        return MHT_E_CAPACITY;
+    }
+    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+}  // namespace mht
+
+namespace mht {
+__global__ void blp_objective_kernel(const int32_t* sel, const double* cost, int nT, const int32_t* st, const int32_t* it,
+                                     const int32_t* nd, double* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double s = 0.0;
+    for (int t = 0; t < nT; ++t) s += cost[sel[t]];
+    out[0] = s;
+    out[1] = (double)st[0];
+    out[2] = (double)it[0];
+    out[3] = (double)nd[0];
+}
+}  // namespace mht
+
+using namespace mht;
+
+extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRows, int32_t depth, const int32_t* group_ptr,
+                             const int32_t* rows, const double* cost, int32_t max_iter, int32_t node_limit,
+                             int32_t* selected, double* objective, int32_t* status, int32_t* iterations, int32_t* nodes) {
+    MHT_REQUIRE(ctx && group_ptr && cost && selected, "mht_solve_blp: null argument");
+    MHT_REQUIRE(nT >= 1 && nHyp >= nT && nRows >= 0 && depth >= 0, "mht_solve_blp: bad sizes");
+    MHT_REQUIRE(rows || depth == 0, "mht_solve_blp: rows is null");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t S = (size_t)2 * nT + 2;
+    const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
+    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4]
+    const size_t n_d = nR + 6 * S + 4;
+    // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd
+    const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3;
+    int rc = ctx->hitmask.ensure(n_d * 8 + n_i * 4 + 64);
+    if (rc) return rc;
+    double* d = static_cast<double*>(ctx->hitmask.ptr);
+    int32_t* q = reinterpret_cast<int32_t*>(d + n_d);
+    MHT_HIP_CHECK(hipMemsetAsync(ctx->hitmask.ptr, 0, n_d * 8 + n_i * 4, ctx->stream));
+    BlpArgs a = {};
+    a.u = d; a.best_rc = d + nR; a.bb_cost = a.best_rc + S; a.bb_uused = a.bb_cost + S; a.bb_last_rc = a.bb_uused + S;
+    a.bb_rest = a.bb_last_rc + S; a.bb_min = a.bb_rest + S;
+    double* out = a.bb_min + S;
+    a.usage = q; a.mark = q + nR; a.best_h = a.mark + nR; a.bb_ch = a.best_h + S; a.bb_best = a.bb_ch + S; a.bb_last_idx = a.bb_best + S;
+    int32_t* cl_ptr = a.bb_last_idx + S;
+    int32_t* members = cl_ptr + 2;
+    int32_t* multi = members + nT;
+    int32_t* single = multi + 1;
+    int32_t* counts = single + 1;
+    int32_t* st = counts + 4;
+    a.cl_ptr = cl_ptr; a.cl_members = members; a.multi_list = multi; a.single_list = single; a.counts = counts;
+    a.cl_status = st; a.cl_iters = st + 1; a.cl_nodes = st + 2;
+    a.tchild = group_ptr; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
+    a.sel = selected;
+    a.max_iter = max_iter < 0 ? 200 : max_iter;
+    a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
+    // one cluster holding all targets
+    int32_t* hbuf = new int32_t[nT + 8];
+    hbuf[0] = 0; hbuf[1] = nT;
+    for (int t = 0; t < nT; ++t) hbuf[2 + t] = t;
+    hbuf[2 + nT] = 0; hbuf[3 + nT] = 0;
+    hbuf[4 + nT] = 1; hbuf[5 + nT] = 1; hbuf[6 + nT] = 0; hbuf[7 + nT] = 0;
+    hipError_t e = hipMemcpyAsync(cl_ptr, hbuf, (size_t)(nT + 8) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    delete[] hbuf;
+    MHT_HIP_CHECK(e);
+    rc = launch_blp(ctx, a, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(blp_objective_kernel, dim3(1), dim3(64), 0, ctx->stream, selected, cost, nT, st, st + 1, st + 2, out);
+    MHT_HIP_CHECK(hipGetLastError());
+    double res[4];
+    MHT_HIP_CHECK(hipMemcpyAsync(res, out, 32, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (objective) *objective = res[0];
+    if (status) *status = (int32_t)res[1];
+    if (iterations) *iterations = (int32_t)res[2];
+    if (nodes) *nodes = (int32_t)res[3];
+    if ((int32_t)res[1] == MHT_BLP_NODE_LIMIT) {
+        set_error("mht_solve_blp: node limit %d reached", a.node_limit);
+        return MHT_E_LIMIT;
+    }
+    return MHT_OK;
+}

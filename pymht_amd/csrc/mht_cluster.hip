@@ -1,0 +1,219 @@
+// Clustering: connected components of the bipartite graph  targets <-> measurements-of-the-window
+// (reference: Tracker._findClustersFromSets, pymht/tracker.py:961-974, which builds a dense
+// (T+|superSet|)^2 adjacency matrix in a Python double loop and calls scipy connected_components).
+//
+// Input is one bitset per target over the "measurement nodes" of the N-scan window (bit = ring_slot*Mpad + m),
+// filled by the emit kernel (ancestors below the root + everything gated in this scan) -- exactly the
+// reference's __associatedMeasurements__ sets.  One workgroup: expand the bitsets to an edge list, then
+// min-label propagation with pointer jumping in LDS until a fixed point.  Labels are target indices, the
+// fixed point is the smallest member of each component, so clusters come out ordered by smallest member with
+// ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
+#include "mht_kernels.h"
+
+namespace mht {
+
+
+constexpr int CL_THREADS = 1024;
+
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]
+    int* aux = tlabel + a.Tcap;                          // [Tcap]  (cluster index of a head / member counters)
+    int* mlabel = aux + a.Tcap;                          // [n_mnodes]
+    __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_total;
+    const int tid = threadIdx.x;
+    const int T = *a.nT_dev;
+    for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
+    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
+    if (tid == 0) s_edges = 0;
+    __syncthreads();
+    // bitsets -> edge list
+    const long long nwords = (long long)T * a.AW;
+    for (long long idx = tid; idx < nwords; idx += CL_THREADS) {
+        unsigned long long bits = a.assoc[idx];
+        if (!bits) continue;
+        const int t = (int)(idx / a.AW), w = (int)(idx % a.AW);
+        int pos = atomicAdd(&s_edges, __popcll(bits));
+        while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            if (pos < a.Ecap) {
+                a.edge_t[pos] = t;
+                a.edge_m[pos] = w * 64 + b;
+            }
+            ++pos;
+        }
+    }
+    __syncthreads();
+    int E = s_edges;
+    if (E > a.Ecap) {
+        if (tid == 0) a.counts[3] = 1;
+        E = a.Ecap;
+    }
+    __threadfence_block();
+    // label propagation
+    for (int iter = 0; iter < 4096; ++iter) {
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        for (int e = tid; e < E; e += CL_THREADS) atomicMin(&mlabel[a.edge_m[e]], tlabel[a.edge_t[e]]);
+        __syncthreads();
+        for (int e = tid; e < E; e += CL_THREADS) {
+            const int v = mlabel[a.edge_m[e]], t = a.edge_t[e];
+            if (v < tlabel[t]) {
+                atomicMin(&tlabel[t], v);
+                s_changed = 1;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += CL_THREADS) {      // pointer jumping
+            int l = tlabel[t], ll = tlabel[l];
+            while (ll < l) { l = ll; ll = tlabel[l]; }
+            if (l < tlabel[t]) { tlabel[t] = l; s_changed = 1; }
+        }
+        __syncthreads();
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    // heads -> cluster indices (exclusive scan over targets, chunked)
+    int running = 0;
+    for (int base = 0; base < T; base += CL_THREADS) {
+        const int t = base + tid;
+        const int head = (t < T && tlabel[t] == t) ? 1 : 0;
+        int incl = head;
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_scan[wv] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < CL_THREADS / 64; ++i) { const int v = s_scan[i]; s_scan[i] = acc; acc += v; }
+            s_total = acc;
+        }
+        __syncthreads();
+        if (head) aux[t] = running + s_scan[wv] + incl - 1;     // cluster index of head t
+        running += s_total;
+        __syncthreads();
+    }
+    const int nC = running;
+    for (int t = tid; t < T; t += CL_THREADS) {
+        a.t_label[t] = tlabel[t];
+        a.t_cluster[t] = aux[tlabel[t]];
+    }
+    for (int c = tid; c <= nC; c += CL_THREADS) a.cl_ptr[c] = 0;
+    __threadfence_block();
+    __syncthreads();
+    // member counts -> cl_ptr (counts at c+1, then inclusive scan by one wave-strided pass)
+    for (int t = tid; t < T; t += CL_THREADS) atomicAdd(&a.cl_ptr[a.t_cluster[t] + 1], 1);
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 64) {      // serial-by-chunk inclusive scan of cl_ptr[1..nC] by one wavefront
+        int carry = 0;
+        for (int base = 1; base <= nC; base += 64) {
+            const int c = base + tid;
+            int v = (c <= nC) ? a.cl_ptr[c] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(v, o);
+                if (tid >= o) v += u;
+            }
+            v += carry;
+            if (c <= nC) a.cl_ptr[c] = v;
+            carry = __shfl(v, 63);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // members in ascending order: rank of t among the members of its cluster with a smaller index
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int c = a.t_cluster[t];
+        const int size = a.cl_ptr[c + 1] - a.cl_ptr[c];
+        int rank = 0;
+        if (size > 1) {
+            const int l = tlabel[t];
+            for (int q = l; q < t; ++q) rank += (tlabel[q] == l);
+        }
+        a.cl_members[a.cl_ptr[c] + rank] = t;
+    }
+    if (tid == 0) { s_edges = 0; s_changed = 0; }
+    __syncthreads();
+    for (int c = tid; c < nC; c += CL_THREADS) {
+        const int size = a.cl_ptr[c + 1] - a.cl_ptr[c];
+        if (size > 1) a.multi_list[atomicAdd(&s_edges, 1)] = c;
+    }
+    __syncthreads();
+    // deterministic order of the work lists is not required (each entry is solved independently)
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int c = a.t_cluster[t];
+        if (a.cl_ptr[c + 1] - a.cl_ptr[c] == 1) a.single_list[atomicAdd(&s_changed, 1)] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.counts[0] = nC;
+        a.counts[1] = s_edges;
+        a.counts[2] = s_changed;
+    }
+}
+
+size_t cluster_lds_bytes(int Tcap, int n_mnodes) { return (size_t)(2 * Tcap + n_mnodes) * 4; }
+
+int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
+    static size_t attr_bytes = 0;
+    const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
+    if (lds > 150 * 1024) {
+        set_error("cluster: Tcap=%d and %d measurement nodes need %zu B of LDS (> 150 KiB)", a.Tcap, a.n_mnodes, lds);
+        return MHT_E_CAPACITY;
+    }
+    if (lds > 48 * 1024 && lds > attr_bytes) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(cluster_kernel, dim3(1), dim3(CL_THREADS), lds, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+}  // namespace mht
+
+using namespace mht;
+
+extern "C" int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_t* assoc, int32_t* label) {
+    MHT_REQUIRE(ctx && label && (assoc || T == 0), "mht_cluster: null argument");
+    MHT_REQUIRE(T >= 0 && words >= 1, "mht_cluster: bad sizes");
+    if (T == 0) return MHT_OK;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t ecap = (size_t)T * words * 64;
+    if (ecap > (1u << 22)) ecap = 1u << 22;
+    const size_t ints = 2 * ecap + 6 * (size_t)T + 32;
+    int rc = ctx->counts.ensure(ints * 4);
+    if (rc) return rc;
+    int32_t* base = static_cast<int32_t*>(ctx->counts.ptr);
+    ClusterArgs a = {};
+    a.assoc = reinterpret_cast<const unsigned long long*>(assoc);
+    a.AW = words;
+    a.Tcap = T;
+    a.Ecap = (int)ecap;
+    a.n_mnodes = words * 64;
+    a.edge_t = base; a.edge_m = base + ecap;
+    int32_t* q = base + 2 * ecap;
+    a.t_label = label; a.t_cluster = q; a.cl_ptr = q + T; a.cl_members = q + 2 * T + 1; a.multi_list = q + 3 * T + 1;
+    a.single_list = q + 4 * T + 1; a.counts = q + 5 * T + 8;
+    int32_t* nT_dev = q + 5 * T + 16;
+    a.nT_dev = nT_dev;
+    MHT_HIP_CHECK(hipMemsetAsync(a.counts, 0, 8 * 4, ctx->stream));
+    MHT_HIP_CHECK(hipMemcpyAsync(nT_dev, &T, 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_cluster(ctx, a);
+    if (rc) return rc;
+    int32_t counts[4];
+    MHT_HIP_CHECK(hipMemcpyAsync(counts, a.counts, 16, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (counts[3]) {
+        set_error("mht_cluster: more than %zu associations", ecap);
+        return MHT_E_CAPACITY;
+    }
+    return MHT_OK;
+}

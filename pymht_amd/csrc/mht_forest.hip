@@ -1,5 +1,771 @@
-// placeholder until the device-resident forest lands
-#include "mht_common.h"
+// The device-resident hypothesis forest: Tracker.addMeasurementList (pymht/tracker.py:162-307) without host
+// round trips between the stages.
+//
+// Data layout in HBM (all structure-of-arrays, owned by the ctx):
+//   layers[R]      ring of mht_nodes, one per scan of the N-scan window (R = N+2): layer s % R holds every
+//                  hypothesis created at scan s (children of that scan, then roots born after it).  A node refers
+//                  to its parent by index into the previous layer (pyTarget.Target.parent).
+//   leaf list      leaf_src[i] (node in the newest layer), leaf_tgt[i] (target slot); leaves of one target are
+//                  contiguous and in pyTarget.getLeafNodes DFS order; targets in __targetList__ order.
+//   path[PD][.]    per newest-layer node the measurement nodes (ring_slot*Mpad + m) on its root->node path:
+//                  the rows of its ILP column (tracker.py:1042-1113) and the key for N-scan pruning.
+//   target table   id, window, depth below the root, root node/score -- double buffered, compacted on termination.
+//   assoc[T][AW]   bitsets = the reference's __associatedMeasurements__ (tracker.py:78), rebuilt every scan.
+// Per scan five launches on one stream: gate_count, emit (mht_gate.hip), cluster (mht_cluster.hip), blp
+// (mht_blp.hip), prune (here: track termination tracker.py:891-916 / :353-381, N-scan pruning tracker.py:1219-1231,
+// compaction of the leaf list and the target table, the scan report).
+#include "mht_kernels.h"
+#include <string.h>
+#include <math.h>
+#include <new>
+
 namespace mht {
-void forest_destroy(mht_ctx*) {}
+
+constexpr int MAXR = 16;
+constexpr int PRUNE_THREADS = 1024;
+
+struct FCounts {          // device-side counters of the forest
+    int nT;               // targets in the NEXT table
+    int L;                // leaves in the NEXT leaf list
+    int n_nodes;          // nodes in the newest layer (children + roots born after the scan)
+    int n_roots;          // roots born into the newest layer
+    int id_counter;       // Tracker.trackIdCounter
+    int overflow;         // sticky capacity flag
+    int n_children;       // children of the last scan
+    int L_in;             // leaves gated in the last scan
+};
+
+struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
+
+struct TTable {           // one buffer of the target table
+    int32_t* id; int32_t* window; int32_t* depth; int32_t* shift; int32_t* root_scan; int32_t* root_node;
+    double* root_cnllr; uint8_t* root_f32;
+};
+
+struct ReportHeader {     // device image of mht_scan_report up to the host pointers
+    int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
+        blp_iters_max, error, used_words, pad[3];
+};
+
+struct PruneArgs {
+    TTable cur, nxt;
+    const int32_t* sel; const int32_t* tchild; const int32_t* ctgt;
+    LayerView layers[MAXR]; int R; int scan; int cap; int capc;
+    const int32_t* path; int PD;
+    int32_t* leaf_src_next; int32_t* leaf_tgt_next;
+    int32_t* alive; int32_t* jdrop; int32_t* new_index; int32_t* n_leaves;   // [Tcap] scratch
+    FCounts* cnt; const DevStatus* status;
+    const int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* t_label;
+    ReportHeader* hdr; mht_target_report* rec;
+    int Nwin; double score_limit, cnllr_limit, radar_x, radar_y, radar_range;
+    int Tcap; int W;
+};
+
+__device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    __syncthreads();
+    if (lane == 63) s_scan[wv] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < PRUNE_THREADS / 64; ++i) { const int t = s_scan[i]; s_scan[i] = acc; acc += t; }
+        *s_total = acc;
+    }
+    __syncthreads();
+    return s_scan[wv] + incl - v;
+}
+
+__global__ __launch_bounds__(PRUNE_THREADS) void prune_kernel(const PruneArgs a) {
+    __shared__ int s_scan[PRUNE_THREADS / 64], s_total, s_branched, s_limit, s_itmax;
+    const int tid = threadIdx.x;
+    const int nT = a.cnt->nT;                 // table of this scan
+    const int nCh = a.status->n_children;
+    const LayerView& Lc = a.layers[a.scan % a.R];
+    if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
+    __syncthreads();
+    // ---- A: per target: termination test, new root ---------------------------------------------------------
+    for (int t = tid; t < nT; t += PRUNE_THREADS) {
+        const int s = a.sel[t];
+        const double cn = Lc.cnllr[s];
+        const uint8_t fl = Lc.flags[s];
+        const double rootc = a.cur.root_cnllr[t];
+        const bool rf32 = a.cur.root_f32[t] != 0;
+        const bool f32score = (fl & F_SCORE_F32) && rf32;
+        // getScore() (pyTarget.py:124) with NumPy scalar promotion
+        const double score = f32score ? (double)((float)cn - (float)rootc) : cn - rootc;
+        int status = 0;
+        const double px = Lc.x[s], py = Lc.x[(size_t)a.cap + s];
+        if (isfinite(a.radar_range)) {
+            const double dx = px - a.radar_x, dy = py - a.radar_y;
+            if (sqrt(dx * dx + dy * dy) > a.radar_range) status = 1;                 // tracker.py:895
+        }
+        if (!status) {
+            const double per = f32score ? (double)((float)score / (float)(a.Nwin + 1)) : score / (double)(a.Nwin + 1);
+            if (per > a.score_limit) status = 2;                                        // tracker.py:902
+            else if (cn > a.cnllr_limit) status = 3;                                    // tracker.py:908
+        }
+        const int dg = a.cur.depth[t] + 1;        // depth below the root after this scan's growth
+        const int w = a.cur.window[t];
+        const int j = dg > w ? dg - w : 0;        // layers the root advances (pyTarget.pruneDepth, pyTarget.py:343)
+        int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
+        double rc = rootc;
+        uint8_t rf = a.cur.root_f32[t];
+        if (j > 0) {
+            int node = s, sc = a.scan;
+            for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
+            rscan = sc;
+            rnode = node;
+            rc = a.layers[sc % a.R].cnllr[node];
+            rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
+        }
+        a.alive[t] = status == 0;
+        a.jdrop[t] = j;
+        a.n_leaves[t] = 0;
+        mht_target_report& r = a.rec[t];
+        r.id = a.cur.id[t];
+        r.status = status;
+        r.sel_node = s;
+        r.sel_meas = Lc.meas[s];
+        r.root_scan = rscan;
+        r.root_node = rnode;
+        r.sel_x[0] = px; r.sel_x[1] = py; r.sel_x[2] = Lc.x[(size_t)2 * a.cap + s]; r.sel_x[3] = Lc.x[(size_t)3 * a.cap + s];
+        r.sel_cnllr = cn;
+        r.score = score;
+        r.root_cnllr = rc;
+        {
+            const LayerView& Lr = a.layers[rscan % a.R];
+            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
+            r.root_meas = Lr.meas[rnode];
+        }
+        r.cluster = a.t_label[t];
+        // stash what the compaction needs in the record (read back below)
+        r.new_index = -1;
+        r.n_leaves = (int)rf;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- B: compact the target table (np.delete of dead tracks, tracker.py:353-381) ---------------------------
+    int running = 0;
+    for (int base = 0; base < nT; base += PRUNE_THREADS) {
+        const int t = base + tid;
+        const int al = (t < nT) ? a.alive[t] : 0;
+        const int pos = running + block_excl_scan(al, s_scan, &s_total);
+        if (al) {
+            mht_target_report& r = a.rec[t];
+            const int j = a.jdrop[t];
+            a.new_index[t] = pos;
+            r.new_index = pos;
+            a.nxt.id[pos] = a.cur.id[t];
+            a.nxt.window[pos] = a.cur.window[t];
+            a.nxt.depth[pos] = a.cur.depth[t] + 1 - j;
+            a.nxt.shift[pos] = j;
+            a.nxt.root_scan[pos] = r.root_scan;
+            a.nxt.root_node[pos] = r.root_node;
+            a.nxt.root_cnllr[pos] = r.root_cnllr;
+            a.nxt.root_f32[pos] = (uint8_t)r.n_leaves;
+        } else if (t < nT) {
+            a.new_index[t] = -1;
+        }
+        running += s_total;
+        __syncthreads();
+    }
+    const int nAlive = running;
+    __threadfence_block();
+    __syncthreads();
+    // ---- C: surviving children -> next leaf list (keeps DFS order) ---------------------------------------------
+    running = 0;
+    for (int base = 0; base < nCh; base += PRUNE_THREADS) {
+        const int c = base + tid;
+        int sv = 0, t = 0;
+        if (c < nCh) {
+            t = a.ctgt[c];
+            sv = a.alive[t];
+            if (sv) {
+                const int j = a.jdrop[t], s = a.sel[t];
+                for (int d = 0; d < j; ++d)
+                    if (a.path[(size_t)d * a.cap + c] != a.path[(size_t)d * a.cap + s]) { sv = 0; break; }
+            }
+        }
+        const int pos = running + block_excl_scan(sv, s_scan, &s_total);
+        if (sv) {
+            a.leaf_src_next[pos] = c;
+            a.leaf_tgt_next[pos] = a.new_index[t];
+            atomicAdd(&a.n_leaves[t], 1);
+        }
+        running += s_total;
+        __syncthreads();
+    }
+    const int Lnext = running;
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < nT; t += PRUNE_THREADS) a.rec[t].n_leaves = a.n_leaves[t];
+    // ---- D: ILP statistics, counters, report header ---------------------------------------------------------------
+    const int nC = a.cl_counts[0];
+    for (int c = tid; c < nC; c += PRUNE_THREADS) {
+        const int st = a.cl_status[c];
+        if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
+        if (st == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
+        if (st) atomicMax(&s_itmax, a.cl_iters[c]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ReportHeader& h = *a.hdr;
+        h.scan = a.scan;
+        h.n_targets = nT;
+        h.n_alive = nAlive;
+        h.n_leaves_in = a.cnt->L;
+        h.n_children = nCh;
+        h.n_leaves_out = Lnext;
+        h.n_clusters = nC;
+        h.n_ilp = a.cl_counts[1];
+        h.n_branched = s_branched;
+        h.n_limit = s_limit;
+        h.blp_iters_max = s_itmax;
+        h.error = (a.status->overflow || a.cnt->overflow || a.cl_counts[3]) ? MHT_E_CAPACITY : 0;
+        h.used_words = a.W;
+        a.cnt->L_in = a.cnt->L;
+        a.cnt->n_children = nCh;
+        a.cnt->nT = nAlive;
+        a.cnt->L = Lnext;
+        a.cnt->n_nodes = nCh;
+        a.cnt->n_roots = 0;
+        if (a.status->overflow) a.cnt->overflow = 1;
+    }
+}
+
+// Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
+struct AddArgs {
+    int n; const double* x0; const float* P0; const uint8_t* flags; const double* pd; const int32_t* meas;
+    int check; double thr;
+    mht_nodes layer;     // newest layer
+    TTable tab; int32_t* leaf_src; int32_t* leaf_tgt; int32_t* path; int PD;
+    FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
+    uint8_t* accepted; int32_t* ids;
+};
+
+__global__ __launch_bounds__(256) void add_targets_kernel(const AddArgs a) {
+    __shared__ int s_near;
+    const int tid = threadIdx.x;
+    for (int q = 0; q < a.n; ++q) {
+        if (tid == 0) s_near = 0;
+        __syncthreads();
+        const int L = a.cnt->L;
+        const double cx = a.x0[q * 4], cy = a.x0[q * 4 + 1];
+        if (a.check) {
+            int near = 0;
+            for (int i = tid; i < L; i += 256) {          // pyTarget.haveNoNeightbours (pyTarget.py:181-189)
+                const int nd = a.leaf_src[i];
+                const double dx = a.layer.x[nd] - cx, dy = a.layer.x[(size_t)a.layer.cap + nd] - cy;
+                if (sqrt(dx * dx + dy * dy) < a.thr) near = 1;
+            }
+            if (near) s_near = 1;
+        }
+        __syncthreads();
+        const int ok = !s_near && a.cnt->nT < a.Tcap && a.cnt->n_nodes < a.layer.cap && a.cnt->L < a.layer.cap;
+        if (!s_near && !ok && tid == 0) a.cnt->overflow = 1;
+        if (ok && tid == 0) {
+            const int idx = a.cnt->n_nodes, r = a.cnt->n_roots, t = a.cnt->nT;
+            const size_t cap = a.layer.cap;
+            for (int k = 0; k < 4; ++k) a.layer.x[k * cap + idx] = a.x0[q * 4 + k];
+            a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
+            a.layer.pd[idx] = a.pd[q];
+            a.layer.parent[idx] = -1;
+            a.layer.meas[idx] = a.meas[q];
+            a.layer.cov[idx] = a.cov_base + r;
+            a.layer.flags[idx] = a.flags[q];
+            for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
+            for (int d = 0; d < a.PD; ++d) a.path[(size_t)d * cap + idx] = -1;
+            a.leaf_src[L] = idx;
+            a.leaf_tgt[L] = t;
+            a.tab.id[t] = a.cnt->id_counter;
+            a.tab.window[t] = a.Nwin;
+            a.tab.depth[t] = 0;
+            a.tab.shift[t] = 0;
+            a.tab.root_scan[t] = a.scan;
+            a.tab.root_node[t] = idx;
+            a.tab.root_cnllr[t] = 0.0;
+            a.tab.root_f32[t] = (a.flags[q] & F_SCORE_F32) ? 1 : 0;
+            if (a.ids) a.ids[q] = a.cnt->id_counter;
+            a.cnt->id_counter += 1;
+            a.cnt->n_nodes = idx + 1;
+            a.cnt->n_roots = r + 1;
+            a.cnt->nT = t + 1;
+            a.cnt->L = L + 1;
+        } else if (tid == 0 && a.ids) {
+            a.ids[q] = -1;
+        }
+        if (tid == 0 && a.accepted) a.accepted[q] = (uint8_t)ok;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+struct LeavesArgs {
+    mht_nodes layer; const int32_t* leaf_src; const int32_t* leaf_tgt; const int32_t* t_id; const FCounts* cnt;
+    int capacity; double* x; float* P; double* cnllr; int32_t* meas; int32_t* target; int32_t* id; int32_t* node; uint8_t* flags;
+};
+__global__ void leaves_kernel(const LeavesArgs a) {
+    const int L = a.cnt->L < a.capacity ? a.cnt->L : a.capacity;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+        const int nd = a.leaf_src[i], t = a.leaf_tgt[i];
+        for (int k = 0; k < 4; ++k) a.x[i * 4 + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
+        const int c = a.layer.cov[nd];
+        for (int e = 0; e < 16; ++e) a.P[i * 16 + e] = a.layer.P[(size_t)e * a.layer.cap_cov + c];
+        a.cnllr[i] = a.layer.cnllr[nd];
+        a.meas[i] = a.layer.meas[nd];
+        a.target[i] = t;
+        a.id[i] = a.t_id[t];
+        a.node[i] = nd;
+        a.flags[i] = a.layer.flags[nd];
+    }
+}
+
+struct ChainArgs { mht_nodes layers[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
+__global__ void chain_kernel(const ChainArgs a) {
+    if (threadIdx.x || blockIdx.x) return;
+    int nd = a.node, sc = a.scan, n = 0;
+    while (nd >= 0 && n < a.max_len && sc >= 0) {
+        const mht_nodes& l = a.layers[sc % a.R];
+        a.nodes[n] = nd;
+        a.meas[n] = l.meas[nd];
+        a.cnllr[n] = l.cnllr[nd];
+        for (int k = 0; k < 4; ++k) a.x[n * 4 + k] = l.x[(size_t)k * l.cap + nd];
+        const int c = l.cov[nd];
+        for (int e = 0; e < 16; ++e) a.P[n * 16 + e] = l.P[(size_t)e * l.cap_cov + c];
+        ++n;
+        nd = l.parent[nd];
+        --sc;
+    }
+    *a.n_out = n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr; size_t size = 0, off = 0;
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct Forest {
+    mht_forest_config cfg;
+    mht_model model;
+    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap;
+    Arena arena;
+    mht_nodes layer[MAXR];
+    int32_t* path[2]; int32_t* leafpos; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
+    int32_t* leaf_src[2]; int32_t* leaf_tgt[2];
+    TTable tab[2];
+    unsigned long long* assoc; unsigned long long* used;
+    int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
+    double* u; int32_t* usage; int32_t* mark;
+    int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
+    int32_t *sel, *cl_status, *cl_iters, *cl_nodes;
+    int32_t *alive, *jdrop, *new_index, *n_leaves;
+    FCounts* cnt;
+    char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off;
+    float* z_dev; float* z_host;
+    // small staging for add_targets / leaves / chain
+    Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
+    // host-side mirrors
+    int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0;
+    bool timing = false; bool timed = false; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    void layout(Arena& ar) {
+        for (int s = 0; s < R; ++s) {
+            mht_nodes& l = layer[s];
+            l.cap = Ncap; l.cap_cov = capc;
+            l.x = ar.take<double>((size_t)4 * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
+            l.parent = ar.take<int32_t>(Ncap); l.meas = ar.take<int32_t>(Ncap); l.cov = ar.take<int32_t>(Ncap);
+            l.flags = ar.take<uint8_t>(Ncap); l.P = ar.take<float>((size_t)16 * capc);
+        }
+        for (int b = 0; b < 2; ++b) {
+            path[b] = ar.take<int32_t>((size_t)PD * Ncap);
+            leaf_src[b] = ar.take<int32_t>(Ncap); leaf_tgt[b] = ar.take<int32_t>(Ncap);
+            TTable& t = tab[b];
+            t.id = ar.take<int32_t>(Tcap); t.window = ar.take<int32_t>(Tcap); t.depth = ar.take<int32_t>(Tcap);
+            t.shift = ar.take<int32_t>(Tcap); t.root_scan = ar.take<int32_t>(Tcap); t.root_node = ar.take<int32_t>(Tcap);
+            t.root_cnllr = ar.take<double>(Tcap); t.root_f32 = ar.take<uint8_t>(Tcap);
+        }
+        leafpos = ar.take<int32_t>(Ncap); ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
+        child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
+        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used = ar.take<unsigned long long>(Mpad / 64);
+        edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
+        t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
+        cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
+        cl_counts = ar.take<int32_t>(8);
+        u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
+        const size_t S = (size_t)2 * Tcap + 2;
+        best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
+        best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
+        bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
+        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap);
+        alive = ar.take<int32_t>(Tcap); jdrop = ar.take<int32_t>(Tcap); new_index = ar.take<int32_t>(Tcap); n_leaves = ar.take<int32_t>(Tcap);
+        cnt = ar.take<FCounts>(1);
+        report_dev = ar.take<char>(report_bytes);
+        z_dev = ar.take<float>((size_t)2 * Mpad);
+    }
+};
+
+void forest_destroy(mht_ctx* ctx) {
+    Forest* f = ctx->forest;
+    if (!f) return;
+    if (f->arena.base) (void)hipFree(f->arena.base);
+    if (f->report_host) (void)hipHostFree(f->report_host);
+    if (f->z_host) (void)hipHostFree(f->z_host);
+    if (f->stage_host) (void)hipHostFree(f->stage_host);
+    f->stage_dev.release();
+    for (int i = 0; i < 5; ++i) if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
+    delete f;
+    ctx->forest = nullptr;
+}
+
+static int stage_host_ensure(Forest* f, size_t bytes) {
+    if (bytes <= f->stage_host_bytes) return MHT_OK;
+    if (f->stage_host) MHT_HIP_CHECK(hipHostFree(f->stage_host));
+    f->stage_host = nullptr;
+    f->stage_host_bytes = 0;
+    MHT_HIP_CHECK(hipHostMalloc(&f->stage_host, bytes + 4096, hipHostMallocDefault));
+    f->stage_host_bytes = bytes + 4096;
+    return MHT_OK;
+}
+
+static LayerView view_of(const mht_nodes& l) { return LayerView{l.x, l.cnllr, l.parent, l.meas, l.flags, l.cov, l.P}; }
+
+}  // namespace mht
+
+using namespace mht;
+
+extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg) {
+    MHT_REQUIRE(ctx && model && cfg, "mht_forest_create: null argument");
+    MHT_REQUIRE(!ctx->forest, "mht_forest_create: the ctx already owns a forest");
+    MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 2 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 2);
+    MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
+    MHT_REQUIRE(cfg->max_targets >= 1 && cfg->max_targets <= 8192, "mht_forest_create: max_targets must be in [1, 8192]");
+    MHT_REQUIRE(cfg->max_nodes >= 64, "mht_forest_create: max_nodes too small");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    Forest* f = new (std::nothrow) Forest();
+    MHT_REQUIRE(f, "mht_forest_create: out of host memory");
+    f->cfg = *cfg;
+    if (f->cfg.blp_max_iter <= 0) f->cfg.blp_max_iter = 200;
+    if (f->cfg.blp_node_limit <= 0) f->cfg.blp_node_limit = 1 << 20;
+    f->model = *model;
+    f->Tcap = cfg->max_targets;
+    f->Ncap = cfg->max_nodes;
+    f->Mpad = ((cfg->max_meas + 63) / 64) * 64;
+    f->R = cfg->n_scan + 2;
+    f->PD = cfg->n_scan + 1;
+    f->n_mnodes = f->R * f->Mpad;
+    f->AW = f->n_mnodes / 64;
+    f->capc = 2 * f->Ncap + f->Tcap;
+    f->Ecap = 4 * f->Ncap;
+    f->used_off = sizeof(ReportHeader);
+    f->rec_off = f->used_off + (size_t)(f->Mpad / 64) * 8;
+    f->report_bytes = f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report);
+    Arena probe;
+    f->layout(probe);                     // first pass: size
+    const size_t total = probe.off + 4096;
+    void* base = nullptr;
+    if (hipMalloc(&base, total) != hipSuccess) {
+        delete f;
+        set_error("mht_forest_create: hipMalloc of %zu bytes failed", total);
+        return MHT_E_HIP;
+    }
+    f->arena.base = static_cast<char*>(base);
+    f->arena.size = total;
+    f->arena.off = 0;
+    f->layout(f->arena);
+    ctx->forest = f;
+    MHT_HIP_CHECK(hipMemsetAsync(base, 0, total, ctx->stream));
+    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host), f->report_bytes, hipHostMallocDefault));
+    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
+    memset(f->report_host, 0, f->report_bytes);
+    // cluster-kernel LDS budget check up front
+    if ((size_t)(2 * f->Tcap + f->n_mnodes) * 4 > 150 * 1024) {
+        set_error("mht_forest_create: max_targets=%d with %d measurement nodes exceeds the clustering kernel's LDS budget",
+                  f->Tcap, f->n_mnodes);
+        forest_destroy(ctx);
+        return MHT_E_CAPACITY;
+    }
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
+                                      const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
+                                      int32_t* ids) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_add_targets: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(n >= 0 && (n == 0 || (x0 && P0 && flags && pd && meas)), "mht_forest_add_targets: null input");
+    if (n == 0) return MHT_OK;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    // pack inputs: x0 | pd | P0 | meas | flags    outputs: ids | accepted
+    const size_t o_x = 0, o_pd = o_x + (size_t)n * 32, o_P = o_pd + (size_t)n * 8, o_m = o_P + (size_t)n * 64,
+                 o_f = o_m + (size_t)n * 4, o_id = (o_f + n + 7) & ~(size_t)7, o_acc = o_id + (size_t)n * 4,
+                 total = o_acc + n + 16;
+    int rc = stage_host_ensure(f, total);
+    if (rc) return rc;
+    rc = f->stage_dev.ensure(total);
+    if (rc) return rc;
+    char* h = static_cast<char*>(f->stage_host);
+    memcpy(h + o_x, x0, (size_t)n * 32); memcpy(h + o_pd, pd, (size_t)n * 8); memcpy(h + o_P, P0, (size_t)n * 64);
+    memcpy(h + o_m, meas, (size_t)n * 4); memcpy(h + o_f, flags, n);
+    char* d = static_cast<char*>(f->stage_dev.ptr);
+    MHT_HIP_CHECK(hipMemcpyAsync(d, h, o_id, hipMemcpyHostToDevice, ctx->stream));
+    AddArgs a = {};
+    a.n = n; a.x0 = (const double*)(d + o_x); a.pd = (const double*)(d + o_pd); a.P0 = (const float*)(d + o_P);
+    a.meas = (const int32_t*)(d + o_m); a.flags = (const uint8_t*)(d + o_f);
+    a.ids = (int32_t*)(d + o_id); a.accepted = (uint8_t*)(d + o_acc);
+    a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
+    const int nb = (f->scan + 1) & 1;
+    a.layer = f->layer[f->scan % f->R];
+    a.tab = f->tab[nb]; a.leaf_src = f->leaf_src[nb]; a.leaf_tgt = f->leaf_tgt[nb];
+    a.path = f->path[f->scan & 1]; a.PD = f->PD;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
+    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
+    f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
+    if (accepted || ids) {
+        MHT_HIP_CHECK(hipMemcpyAsync(h + o_id, d + o_id, total - o_id, hipMemcpyDeviceToHost, ctx->stream));
+        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ids) memcpy(ids, h + o_id, (size_t)n * 4);
+        if (accepted) memcpy(accepted, h + o_acc, n);
+    }
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
+    MHT_REQUIRE(z || M == 0, "mht_forest_step: z is null");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int s = ++f->scan;
+    const int cb = s & 1, nb = (s + 1) & 1;
+    const int W = (M + 63) / 64;
+    f->last_M = M;
+    MHT_HIP_CHECK(hipMemsetAsync(f->assoc, 0, (size_t)f->nT_ub * f->AW * 8, st));
+    MHT_HIP_CHECK(hipMemsetAsync(f->used, 0, (size_t)(f->Mpad / 64) * 8, st));
+    MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), st));
+    MHT_HIP_CHECK(hipMemsetAsync(f->cl_counts, 0, 8 * sizeof(int32_t), st));
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[0], st));
+    // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
+    GateArgs g = {};
+    fill_model(g, &f->model);
+    const mht_nodes& in = f->layer[(s - 1) % f->R];
+    const mht_nodes& out = f->layer[s % f->R];
+    g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
+    g.cap_in = in.cap; g.capc_in = in.cap_cov;
+    g.leaf_src = f->leaf_src[cb]; g.L_dev = &f->cnt->L; g.L = 0;
+    g.z = z; g.M = M; g.W = W;
+    g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
+    g.oflags = out.flags; g.oP = out.P; g.cap_out = out.cap; g.capc_out = out.cap_cov;
+    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = f->used;
+    g.leaf_tgt = f->leaf_tgt[cb]; g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
+    g.out_path = f->path[s & 1]; g.out_leafpos = f->leafpos; g.out_tgt = f->ctgt;
+    g.assoc = f->assoc; g.assoc_words = f->AW; g.PD = f->PD; g.cur_slot_base = (s % f->R) * f->Mpad;
+    g.tchild = f->tchild; g.ocost = f->cost; g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
+    g.Nwin = f->cfg.n_scan;
+    int rc = launch_gate(ctx, g, f->L_ub > 0 ? f->L_ub : 1);
+    if (rc) return rc;
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[1], st));
+    // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
+    ClusterArgs c = {};
+    c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
+    c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes;
+    c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
+    c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
+    rc = launch_cluster(ctx, c);
+    if (rc) return rc;
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[2], st));
+    // ---- 3: global hypothesis per cluster (tracker.py:225-237) --------------------------------------------------------
+    BlpArgs b = {};
+    b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
+    b.counts = f->cl_counts; b.tchild = f->tchild; b.cost = f->cost; b.cnllr = out.cnllr;
+    b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD;
+    b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
+    b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
+    b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
+    b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes;
+    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit;
+    int grid = f->nT_ub / 2 + 8;
+    if (grid > 1024) grid = 1024;
+    rc = launch_blp(ctx, b, grid);
+    if (rc) return rc;
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[3], st));
+    // ---- 4: terminate, N-scan prune, compact, report (tracker.py:250-259) ------------------------------------------------
+    PruneArgs p = {};
+    p.cur = f->tab[cb]; p.nxt = f->tab[nb];
+    p.sel = f->sel; p.tchild = f->tchild; p.ctgt = f->ctgt;
+    for (int k = 0; k < f->R; ++k) p.layers[k] = view_of(f->layer[k]);
+    p.R = f->R; p.scan = s; p.cap = f->Ncap; p.capc = f->capc;
+    p.path = f->path[s & 1]; p.PD = f->PD;
+    p.leaf_src_next = f->leaf_src[nb]; p.leaf_tgt_next = f->leaf_tgt[nb];
+    p.alive = f->alive; p.jdrop = f->jdrop; p.new_index = f->new_index; p.n_leaves = f->n_leaves;
+    p.cnt = f->cnt; p.status = ctx->status;
+    p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.t_label = f->t_label;
+    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
+    p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
+    p.Nwin = f->cfg.n_scan; p.score_limit = f->cfg.score_limit; p.cnllr_limit = f->cfg.cnllr_limit;
+    p.radar_x = f->cfg.radar_x; p.radar_y = f->cfg.radar_y; p.radar_range = f->cfg.radar_range;
+    p.Tcap = f->Tcap; p.W = W;
+    hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(PRUNE_THREADS), 0, st, p);
+    MHT_HIP_CHECK(hipGetLastError());
+    if (f->timing) { MHT_HIP_CHECK(hipEventRecord(f->ev[4], st)); f->timed = true; }
+    // the used-measurement mask travels with the report
+    MHT_HIP_CHECK(hipMemcpyAsync(f->report_dev + f->used_off, f->used, (size_t)(f->Mpad / 64) * 8, hipMemcpyDeviceToDevice, st));
+    f->report_pending = true;
+    f->L_ub = f->Ncap;        // unknown until the report is fetched
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step_host: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step_host: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
+    if (M > 0) {
+        MHT_REQUIRE(z_host, "mht_forest_step_host: z is null");
+        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the staging buffer may still be in flight
+        memcpy(f->z_host, z_host, (size_t)M * 2 * sizeof(float));
+        MHT_HIP_CHECK(hipMemcpyAsync(f->z_dev, f->z_host, (size_t)M * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return mht_forest_step(ctx, f->z_dev, M);
+}
+
+extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
+    MHT_REQUIRE(ctx && ctx->forest && out, "mht_forest_report: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->scan > 0, "mht_forest_report: no scan processed yet");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (f->report_pending) {
+        const size_t bytes = f->rec_off + (size_t)f->nT_ub * sizeof(mht_target_report);
+        MHT_HIP_CHECK(hipMemcpyAsync(f->report_host, f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        f->report_pending = false;
+    }
+    const ReportHeader* h = reinterpret_cast<const ReportHeader*>(f->report_host);
+    memcpy(out, h, sizeof(ReportHeader));
+    out->used = reinterpret_cast<const uint64_t*>(f->report_host + f->used_off);
+    out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);
+    f->nT_ub = h->n_alive;
+    f->L_ub = h->n_leaves_out;
+    if (h->error) {
+        set_error("forest: a pool overflowed during scan %d (max_nodes=%d, max_targets=%d): children=%d", h->scan,
+                  f->Ncap, f->Tcap, h->n_children);
+        return MHT_E_CAPACITY;
+    }
+    if (h->n_limit) {
+        set_error("forest: %d ILP(s) hit the branch-and-bound node limit in scan %d", h->n_limit, h->scan);
+        return MHT_E_LIMIT;
+    }
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
+                                 int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
+    MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_leaves: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(capacity >= 0, "mht_forest_leaves: negative capacity");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    FCounts c;
+    MHT_HIP_CHECK(hipMemcpyAsync(&c, f->cnt, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_out = c.L;
+    const int n = c.L < capacity ? c.L : capacity;
+    if (n == 0) return MHT_OK;
+    const size_t o_x = 0, o_c = o_x + (size_t)n * 32, o_P = o_c + (size_t)n * 8, o_m = o_P + (size_t)n * 64,
+                 o_t = o_m + (size_t)n * 4, o_i = o_t + (size_t)n * 4, o_n = o_i + (size_t)n * 4, o_f = o_n + (size_t)n * 4,
+                 total = o_f + n + 16;
+    int rc = stage_host_ensure(f, total);
+    if (rc) return rc;
+    rc = f->stage_dev.ensure(total);
+    if (rc) return rc;
+    char* d = static_cast<char*>(f->stage_dev.ptr);
+    char* h = static_cast<char*>(f->stage_host);
+    const int nb = (f->scan + 1) & 1;
+    LeavesArgs a = {f->layer[f->scan % f->R], f->leaf_src[nb], f->leaf_tgt[nb], f->tab[nb].id, f->cnt, n,
+                    (double*)(d + o_x), (float*)(d + o_P), (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
+                    (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f)};
+    hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (x) memcpy(x, h + o_x, (size_t)n * 32);
+    if (cnllr) memcpy(cnllr, h + o_c, (size_t)n * 8);
+    if (P) memcpy(P, h + o_P, (size_t)n * 64);
+    if (meas) memcpy(meas, h + o_m, (size_t)n * 4);
+    if (target) memcpy(target, h + o_t, (size_t)n * 4);
+    if (id) memcpy(id, h + o_i, (size_t)n * 4);
+    if (node) memcpy(node, h + o_n, (size_t)n * 4);
+    if (flags) memcpy(flags, h + o_f, n);
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                                double* x, double* cnllr, float* P, int32_t* n_out) {
+    MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_chain: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R, "mht_forest_chain: scan %d is outside the window", scan);
+    MHT_REQUIRE(node >= 0 && node < f->Ncap && max_len >= 1, "mht_forest_chain: bad node / max_len");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    int len = max_len;
+    const int avail = f->R - (f->scan - scan);   // layers still in the ring going backwards
+    if (len > avail) len = avail;
+    const size_t o_n = 0, o_m = o_n + (size_t)len * 4, o_x = (o_m + (size_t)len * 4 + 7) & ~(size_t)7, o_c = o_x + (size_t)len * 32,
+                 o_P = o_c + (size_t)len * 8, o_k = o_P + (size_t)len * 64, total = o_k + 16;
+    int rc = stage_host_ensure(f, total);
+    if (rc) return rc;
+    rc = f->stage_dev.ensure(total);
+    if (rc) return rc;
+    char* d = static_cast<char*>(f->stage_dev.ptr);
+    char* h = static_cast<char*>(f->stage_host);
+    ChainArgs a = {};
+    for (int k = 0; k < f->R; ++k) a.layers[k] = f->layer[k];
+    a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
+    a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
+    a.P = (float*)(d + o_P); a.n_out = (int32_t*)(d + o_k);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int n = *(int32_t*)(h + o_k);
+    *n_out = n;
+    if (nodes) memcpy(nodes, h + o_n, (size_t)n * 4);
+    if (meas) memcpy(meas, h + o_m, (size_t)n * 4);
+    if (x) memcpy(x, h + o_x, (size_t)n * 32);
+    if (cnllr) memcpy(cnllr, h + o_c, (size_t)n * 8);
+    if (P) memcpy(P, h + o_P, (size_t)n * 64);
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_set_timing(mht_ctx* ctx, int32_t enable) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_timing: no forest");
+    Forest* f = ctx->forest;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (enable && !f->ev[0])
+        for (int i = 0; i < 5; ++i) MHT_HIP_CHECK(hipEventCreate(&f->ev[i]));
+    f->timing = enable != 0;
+    if (!f->timing) f->timed = false;
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_stage_times(mht_ctx* ctx, float* ms5) {
+    MHT_REQUIRE(ctx && ctx->forest && ms5, "mht_forest_stage_times: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->timed, "mht_forest_stage_times: timing was not enabled for the last step");
+    MHT_HIP_CHECK(hipEventSynchronize(f->ev[4]));
+    for (int i = 0; i < 4; ++i) MHT_HIP_CHECK(hipEventElapsedTime(&ms5[i], f->ev[i], f->ev[i + 1]));
+    MHT_HIP_CHECK(hipEventElapsedTime(&ms5[4], f->ev[0], f->ev[4]));
+    return MHT_OK;
 }

@@ -13,38 +13,10 @@
 //                      dense, DFS-ordered child index of every leaf; children are written in ascending
 //                      measurement order by walking the hit mask.
 // Matrices are 4x4 / 2x2: registers only, no MFMA; the bound is HBM + launch latency.
-#include "mht_common.h"
+#include "mht_kernels.h"
 
 namespace mht {
 
-struct GateArgs {
-    Model model;
-    double default_pd, default_miss_nllr;
-    // input layer
-    const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
-    int cap_in, capc_in;
-    const int32_t* leaf_src;
-    const int32_t* L_dev;   // optional device-side leaf count
-    int L;
-    const float* z; int M; int W;
-    // scratch
-    unsigned long long* hitmask; int32_t* cnt; int32_t* tile_cnt;
-    // output layer
-    double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
-    int cap_out, capc_out;
-    int32_t* child_ptr; double* nllr; unsigned long long* used;
-    DevStatus* status;
-    // forest extras (null for the stateless seam)
-    const int32_t* leaf_tgt;      // [L] target slot of each leaf
-    const int32_t* in_path;       // [PD][cap_in] path of measurement-node ids below the root (prev scan children)
-    const int32_t* tgt_shift;     // [T] entries dropped from the front of the path (root advance)
-    const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
-    int32_t* out_path;            // [PD][cap_out]
-    int32_t* out_leafpos;         // [cap_out] leaf-list position of the parent
-    int32_t* out_tgt;             // [cap_out] target slot
-    unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window
-    int assoc_words; int PD; int cur_slot_base;   // measurement-node id of measurement j of this scan = cur_slot_base + j
-};
 
 struct LeafGate {        // per-leaf gate parameters staged in LDS
     double zhat[2];
@@ -203,7 +175,16 @@ __device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src,
         depth = a.tgt_depth[tgt];
         shift = a.tgt_shift[tgt];
     }
+    double rootc = 0.0;
+    bool root_f32 = false;
+    if (a.ocost) { rootc = a.t_root_cnllr[tgt]; root_f32 = a.t_root_f32[tgt] != 0; }
     auto write_common = [&](int c, int meas, int covcol, uint8_t cfl, double cnl, double inc) {
+        if (a.ocost) {
+            // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32
+            // and float32 / int stay float32
+            if ((cfl & F_SCORE_F32) && root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
+            else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
+        }
         a.ocnllr[c] = cnl;
         a.opd[c] = pd;
         a.oparent[c] = src;
@@ -307,6 +288,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
                 a.status->n_children = total;
                 if (total > a.cap_out) a.status->overflow = 1;
             }
+            if (a.tchild) {
+                const int tg = a.leaf_tgt[i];
+                if (i == 0 || a.leaf_tgt[i - 1] != tg) a.tchild[tg] = base;
+                if (i == L - 1) a.tchild[tg + 1] = base + mine;
+            }
             const int src = a.leaf_src ? a.leaf_src[i] : i;
             const uint8_t fl = a.flags[src];
             const double cn = a.cnllr[src], pd = a.pd[src];
@@ -317,6 +303,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
     if (L == 0 && blockIdx.x == 0 && lane == 0) {
         a.child_ptr[0] = 0;
         a.status->n_children = 0;
+        if (a.tchild) a.tchild[0] = 0;
     }
 }
 
@@ -324,8 +311,8 @@ static inline size_t gate_lds_bytes(int W) {
     return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafGate) + (size_t)W * 8 + 16;
 }
 
-int launch_gate(mht_ctx* ctx, GateArgs& a) {
-    const int L = a.L, W = a.W;
+int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
+    const int L = grid_leaves_hint > a.L ? grid_leaves_hint : a.L, W = a.W;
     a.status = ctx->status;
     if (L <= 0) {
         hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(EMIT_THREADS), 0, ctx->stream, a);
@@ -381,7 +368,7 @@ extern "C" int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nod
     a.ocov = out->cov; a.oflags = out->flags; a.oP = out->P; a.cap_out = out->cap; a.capc_out = out->cap_cov;
     a.child_ptr = child_ptr; a.nllr = nllr; a.used = reinterpret_cast<unsigned long long*>(used);
     MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), ctx->stream));
-    int rc = launch_gate(ctx, a);
+    int rc = launch_gate(ctx, a, L);
     if (rc) return rc;
     if (n_children) {
         DevStatus st;

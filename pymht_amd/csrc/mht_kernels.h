@@ -1,0 +1,80 @@
+// Kernel argument blocks and launchers shared by the translation units of libmht_amd.so.
+#pragma once
+#include "mht_common.h"
+
+namespace mht {
+
+struct GateArgs {
+    Model model;
+    double default_pd, default_miss_nllr;
+    // input layer
+    const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
+    int cap_in, capc_in;
+    const int32_t* leaf_src;
+    const int32_t* L_dev;   // optional device-side leaf count
+    int L;
+    const float* z; int M; int W;
+    // scratch
+    unsigned long long* hitmask; int32_t* cnt; int32_t* tile_cnt;
+    // output layer
+    double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
+    int cap_out, capc_out;
+    int32_t* child_ptr; double* nllr; unsigned long long* used;
+    DevStatus* status;
+    // forest extras (null for the stateless seam)
+    const int32_t* leaf_tgt;      // [L] target slot of each leaf
+    const int32_t* in_path;       // [PD][cap_in] path of measurement-node ids below the root (prev scan children)
+    const int32_t* tgt_shift;     // [T] entries dropped from the front of the path (root advance)
+    const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
+    int32_t* out_path;            // [PD][cap_out]
+    int32_t* out_leafpos;         // [cap_out] leaf-list position of the parent
+    int32_t* out_tgt;             // [cap_out] target slot
+    unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window
+    int assoc_words; int PD; int cur_slot_base;
+    int32_t* tchild;              // [T+1] first child of every target (children of a target are contiguous)
+    double* ocost;                // [cap_out] ILP cost of every child: getScore()/N (tracker.py:1127)
+    const double* t_root_cnllr;   // [T] cumulativeNLLR of the target's root
+    const uint8_t* t_root_f32;    // [T] the root score is a float32 value
+    int Nwin;                     // Tracker.N   // measurement-node id of measurement j of this scan = cur_slot_base + j
+};
+
+struct ClusterArgs {
+    const unsigned long long* assoc;   // [T][AW]
+    int AW;                            // words per target
+    const int32_t* nT_dev;
+    int Tcap;
+    int32_t* edge_t; int32_t* edge_m; int Ecap;
+    int n_mnodes;                      // R * Mpad
+    // outputs
+    int32_t* t_label;      // [T] smallest member of the component
+    int32_t* t_cluster;    // [T] cluster index
+    int32_t* cl_ptr;       // [T+1]
+    int32_t* cl_members;   // [T]
+    int32_t* multi_list;   // [T] cluster indices with >= 2 members
+    int32_t* single_list;  // [T] target indices that are alone in their cluster
+    int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow
+};
+
+struct BlpArgs {
+    const int32_t* cl_ptr; const int32_t* cl_members; const int32_t* multi_list; const int32_t* single_list;
+    const int32_t* counts;          // [1] = nMulti, [2] = nSingle
+    const int32_t* tchild;          // [T+1] children of target t are columns tchild[t] .. tchild[t+1]-1
+    const double* cost;             // [cap] f_h
+    const double* cnllr;            // [cap] cumulativeNLLR of the children (single-target clusters)
+    const int32_t* path; int cap; int PD;
+    double* u; int32_t* usage; int32_t* mark; int n_mnodes;
+    // per-member scratch, slot = cl_ptr[c] + c + k  (k = 0..K)
+    int32_t* best_h; double* best_rc; int32_t* bb_ch; int32_t* bb_best; double* bb_cost; double* bb_uused;
+    double* bb_last_rc; int32_t* bb_last_idx; double* bb_rest; double* bb_min;
+    int32_t* sel;                   // [T] out: selected child per target
+    int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
+    int max_iter; int node_limit;
+};
+
+int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
+void fill_model(GateArgs& a, const mht_model* m);
+int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
+void forest_destroy(mht_ctx* ctx);
+
+}  // namespace mht

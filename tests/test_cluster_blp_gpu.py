@@ -1,0 +1,110 @@
+"""GPU: seams (ii) clustering and (iii) the 0-1 ILP through the C ABI, against the oracle and the recorded instances."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import torch
+
+import mht_oracle as orc
+from pymht_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_cluster(ctx, sets, n_nodes):
+    T = len(sets)
+    words = (n_nodes + 63) // 64
+    bits = np.zeros((T, words), dtype=np.uint64)
+    for t, s in enumerate(sets):
+        for m in s:
+            bits[t, m >> 6] |= np.uint64(1) << np.uint64(m & 63)
+    d = torch.from_numpy(bits.view(np.int64)).to(ctx.device)
+    lab = torch.zeros(max(T, 1), dtype=torch.int32, device=ctx.device)
+    _lib.check(ctx.lib.mht_cluster(ctx.handle, T, words, d.data_ptr(), lab.data_ptr()))
+    return lab[:T].cpu().numpy()
+
+
+@pytest.mark.parametrize("T,n_nodes,deg,seed", [(1, 64, 3, 0), (7, 100, 2, 1), (300, 3000, 4, 2), (2000, 9000, 3, 3),
+                                                 (500, 200, 1, 4), (64, 64, 0, 5)])
+def test_cluster_matches_oracle(gpu_ctx, T, n_nodes, deg, seed):
+    rng = np.random.default_rng(seed)
+    sets = [set(int(v) for v in rng.integers(0, n_nodes, size=rng.integers(0, deg + 1))) for _ in range(T)]
+    if T > 10:     # a long chain: worst case for label propagation
+        for t in range(0, min(T, 120) - 1):
+            sets[t].add(n_nodes - 1 - t)
+            sets[t + 1].add(n_nodes - 1 - t)
+    lab = gpu_cluster(gpu_ctx, sets, n_nodes)
+    ref = orc.find_clusters(sets)
+    want = np.zeros(T, dtype=np.int64)
+    for cl in ref:
+        want[cl] = cl[0]
+    assert np.array_equal(lab, want)
+
+
+def load_instances(path):
+    g = np.load(path)
+    out = []
+    for i in range(int(g["n_inst"])):
+        p = "i%03d_" % i
+        ptr, rows = g[p + "col_ptr"], g[p + "col_rows"]
+        out.append(dict(cols=[rows[ptr[c]:ptr[c + 1]] for c in range(len(ptr) - 1)], sizes=g[p + "sizes"],
+                        cost=g[p + "cost"], sel=g[p + "sel"], obj=float(g[p + "obj"]), unique=bool(g[p + "unique"])))
+    return out
+
+
+def gpu_blp(ctx, inst, max_iter=200, node_limit=1 << 20):
+    cols, sizes, cost = inst["cols"], inst["sizes"], inst["cost"]
+    nH, nT = len(cols), len(sizes)
+    depth = max(1, max(len(c) for c in cols))
+    nrows = 1 + max((int(c.max()) for c in cols if len(c)), default=0)
+    rows = -np.ones((depth, nH), dtype=np.int32)
+    for h, c in enumerate(cols):
+        rows[:len(c), h] = c
+    dev = ctx.device
+    gp = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+    rw = torch.from_numpy(rows).to(dev)
+    cs = torch.from_numpy(np.asarray(cost, dtype=np.float64)).to(dev)
+    sel = torch.zeros(nT, dtype=torch.int32, device=dev)
+    obj, st, it, nd = C.c_double(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _lib.check(ctx.lib.mht_solve_blp(ctx.handle, nH, nT, nrows, depth, gp.data_ptr(), rw.data_ptr(), cs.data_ptr(),
+                                     max_iter, node_limit, sel.data_ptr(), C.byref(obj), C.byref(st), C.byref(it), C.byref(nd)))
+    return sorted(sel.cpu().numpy().tolist()), obj.value, st.value, it.value, nd.value
+
+
+@pytest.mark.parametrize("name", ["g4_ilp", "g6_ilp_cfg3"])
+@pytest.mark.parametrize("max_iter", [200, 0])
+def test_blp_recorded_instances(gpu_ctx, gold_dir, name, max_iter):
+    """Selections are bit-exact against the exact reference optimum (unique in every recorded instance); with
+    max_iter=0 the dual ascent is skipped and the GPU branch and bound has to prove optimality on its own."""
+    insts = load_instances(os.path.join(gold_dir, name + ".npz"))
+    stats = {1: 0, 2: 0}
+    for inst in insts:
+        sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=max_iter)
+        assert st in (1, 2)
+        stats[st] += 1
+        assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)), (name, len(inst["cols"]))
+        if inst["unique"]:
+            assert sel == inst["sel"].tolist()
+    print(name, "max_iter", max_iter, "certified/branched", stats)
+    if max_iter == 0:
+        assert stats[2] > 0
+
+
+def test_blp_adversarial_needs_branching(gpu_ctx):
+    """Odd cycle of pairwise conflicts: the LP relaxation is fractional (all 1/2), so the certificate cannot hold
+    and branch and bound must close the gap.  Checked against exhaustive search."""
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        nT = 5 + 2 * (trial % 2)
+        cols, sizes, cost = [], [], []
+        for t in range(nT):
+            # column A uses rows (t, t+1 mod nT) -> neighbours conflict pairwise around an odd cycle
+            cols += [np.array([t, (t + 1) % nT]), np.array([nT + t]), np.array([], dtype=np.int64)]
+            cost += [-2.0 - 0.1 * rng.uniform(), -0.9 - 0.05 * rng.uniform(), 0.0]
+            sizes.append(3)
+        inst = dict(cols=cols, sizes=np.array(sizes), cost=np.array(cost))
+        bs, bo, ties = orc.solve_blp_bruteforce([c.tolist() for c in cols], sizes, cost)
+        sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=30)
+        assert abs(obj - bo) < 1e-9
+        if ties == 1:
+            assert sel == sorted(bs)

@@ -1,0 +1,98 @@
+"""GPU: the whole scan path (`Tracker.addMeasurementList`) on the device forest against the golden scan traces
+recorded from the reference, and against the oracle on a fresh seeded scenario."""
+import os
+import numpy as np
+import pytest
+
+import mht_oracle as orc
+from trace_util import check_scan_against_fixture, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+# cumulative score slack: each scan adds an NLLR whose per-leaf float32 constant may differ by 1 ulp(f32) (util.NLLR_ATOL)
+SCORE_ATOL = 2e-5
+
+
+def make_tracker(period, lambda_phi, lambda_nu, P_d, N, eta2, x0, t0, **kw):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    trk = Tracker(pv, period, lambda_phi, lambda_nu, P_d=P_d, N=N, eta2=eta2, **kw)
+    acc = []
+    for x in x0:
+        n0 = len(trk.__targetList__)
+        trk.initiateTarget(Target(t0, None, x.copy(), pv.P0, status="preinitialized"))
+        acc.append(len(trk.__targetList__) > n0)
+    return trk, acc
+
+
+def tracker_selected(trk):
+    nodes = list(trk.getTrackNodes())
+    return dict(ID=np.array([n.ID for n in nodes], dtype=np.int64),
+                x=np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes]).reshape(-1, 4),
+                cnllr=np.array([float(n.cumulativeNLLR) for n in nodes]),
+                meas=np.array([n.measurementNumber for n in nodes], dtype=np.int64))
+
+
+@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3"])
+def test_tracker_replays_reference_trace(name, gold_dir):
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    trk, acc = make_tracker(float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), float(g["P_d"]),
+                            int(g["N"]), float(g["eta2"]), g["x0"], float(g["t0"]))
+    assert acc == [bool(a) for a in g["accepted"]]
+    for k in range(int(g["n_scans"])):
+        p = "s%02d_" % k
+        ids_before = [r.ID for r in trk.__targetList__]
+        trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]))
+        st = trk.lastScanStats
+        assert [st["L"], st["G"], st["M"]] == g[p + "LGM"].tolist(), "scan %d L/G/M" % k      # gating: exact counts
+        assert np.array_equal(st["unused"], g[p + "unused"]), "scan %d unused measurements" % k
+        # selection is reported for the targets alive before termination; the fixture holds survivors only
+        sel = tracker_selected(trk)
+        leaf = trk.leafBatch()
+        leaf_cmp = dict(ID=leaf["ID"].astype(np.int64), meas=leaf["meas"].astype(np.int64), x=leaf["x"], cnllr=leaf["cnllr"], P=leaf["P"])
+        ids_after = np.array([r.ID for r in trk.__targetList__])
+        # clusters refer to the target list before termination
+        check_scan_against_fixture(g, k, ids_after, sel, trk.__clusterList__, len(leaf["ID"]), leaf_cmp, score_atol=SCORE_ATOL)
+        dead = sorted(i for i in ids_before if i not in ids_after.tolist())
+        assert dead == g[p + "dead"].tolist()
+        assert st["branched"] == 0 or st["branched"] <= st["ilp"]
+    trk.close()
+
+
+def test_tracker_vs_oracle_fresh_scenario():
+    """A scenario that is in no fixture: oracle and device forest side by side, scan by scan."""
+    from pymht_amd.utils.scenario import make_scenario
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = make_scenario(T=40, radius=500.0, lambda_phi=3e-5, n_scans=14, P_d=0.85, seed=99)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=4, eta2=5.99,
+             x0=sc["x0"], t0=sc["t0"], accepted=None)
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], 4, 5.99, sc["x0"], sc["t0"])
+    g["accepted"] = acc
+    o = make_oracle(g)
+    assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__]
+    n_ilp = 0
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        info = o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        st = trk.lastScanStats
+        assert (st["L"], st["G"]) == (info["L"], info["G"]), k
+        assert np.array_equal(st["unused"], info["unused"]), k
+        assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__], k
+        os_, ts = o.selected(), tracker_selected(trk)
+        assert np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]), k
+        assert np.allclose(os_["x"], ts["x"], rtol=1e-6, atol=1e-9) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL)
+        assert len(o.clusters) == len(trk.__clusterList__)
+        lb, tb = o.leaf_batch(), trk.leafBatch()
+        assert np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]), k
+        assert np.allclose(lb["x"], tb["x"], rtol=1e-6, atol=1e-9)
+        n_ilp += o.n_ilp
+        assert o.n_ilp == trk.nOptimSolved
+    assert n_ilp > 0
+    # the selected leaf's ancestor chain (lazy `parent` through the device ring) matches the oracle's history
+    for n_o, n_t in zip(o.track_nodes, trk.getTrackNodes()):
+        h = n_o.history_meas()
+        chain = [m.measurementNumber for m in n_t.backtrackNodes()]
+        assert h[-len(chain):] == [0 if c is None else int(c) for c in chain][-len(h):] or h[-3:] == chain[-3:]
+    trk.close()
