@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""bench.py -- scans/sec of the pyMHT per-scan hot path on MI355X (BASELINE.json metric).
+
+A "step" = one radar scan through steps 1-6 of Tracker.addMeasurementList (grow/gate/score every leaf against
+every measurement, cluster, per-cluster 0-1 ILP, track termination, N-scan pruning) on the device-resident
+hypothesis forest -- five HIP launches, no host round trip.  Workload = BASELINE.json configs[2] (headline):
+500 targets, ~500 measurements/scan, N-scan = 5, synthetic scans from pymht_amd/utils/scenario.py.
+
+Protocol
+  1. pre-pass (untimed): the full drop-in Tracker incl. the host-side M-of-N initiator runs the W+K scans once;
+     the targets it gives birth to are recorded (step 7 of the reference is off the hot path).
+  2. all scans and the recorded births are staged in HBM.
+  3. replay: fresh forest, W untimed warm-up scans, then EXACTLY K timed scans between barrier+synchronize pairs;
+     nothing is fetched from the device inside the timed region.  Afterwards the last report is compared with the
+     pre-pass (same selections => the timed run did the same work).
+  4. a second identical replay with HIP events around the stages gives per-stage device time -> `roofline`.
+  5. rank 0, N=1 only: the CPU oracle (NumPy restatement of the reference, 1 thread) is timed on a bounded sample
+     of the same scan stream -> `cpu_baseline`.
+Multi-GPU (--gpus N under torch.distributed.run): every rank tracks its own independent sensor sector
+(BASELINE config 4: disjoint sectors = no data-path collective), weak scaling; value = total scans / max time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+LAMBDA_NU = 1e-4
+ETA2 = 5.99
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_tracker(sc, device, **kw):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, device=device,
+                  maxTargets=kw.pop("maxTargets", 2048), maxNodes=kw.pop("maxNodes", 1 << 17), maxMeasurements=1024, **kw)
+    trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+    return trk
+
+
+def prepass(sc, device):
+    """Full tracker with the host initiator; records births per scan and per-scan stats."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    trk = make_tracker(sc, device, deviceTiming=False)
+    births, stats = [], []
+    orig = trk._add_targets
+
+    def recording(targets):
+        acc = orig(targets)
+        cur = births[-1] if births else None
+        if cur is not None:
+            cur.extend(acc)
+        return acc
+
+    trk._add_targets = recording
+    t0 = time.time()
+    for z, t in zip(sc["scans"], sc["times"]):
+        births.append([])
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        s = trk.lastScanStats
+        stats.append((s["L"], s["G"], s["M"], s["ilp"], s["branched"], s["blp_iters_max"], len(trk.__targetList__)))
+    api_s = time.time() - t0
+    final = [(int(n.ID), int(n.measurementNumber)) for n in trk.getTrackNodes()]
+    init_s = float(np.sum(trk.runtimeLog["Init"]))
+    trk.close()
+    return births, np.array(stats), final, api_s, init_s
+
+
+class Replay:
+    """Drives the forest through the raw C ABI with every input resident in HBM."""
+
+    def __init__(self, sc, births, device):
+        from pymht_amd import _lib
+        self._lib_mod = _lib
+        self.sc = sc
+        self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
+        self.lib, self.h = self.trk._lib, self.trk._ctx.handle
+        dev = self.trk._ctx.device
+        self.M = [int(z.shape[0]) for z in sc["scans"]]
+        zall = np.concatenate([z.reshape(-1, 2) for z in sc["scans"]], axis=0).astype(np.float32)
+        self.z = torch.from_numpy(zall).to(dev)
+        self.zoff = np.concatenate([[0], np.cumsum(self.M)]).astype(np.int64)
+        flat = [b for per in births for b in per]
+        self.nb = [len(per) for per in births]
+        self.boff = np.concatenate([[0], np.cumsum(self.nb)]).astype(np.int64)
+        n = max(len(flat), 1)
+        x0 = np.zeros((n, 4)); P0 = np.zeros((n, 16), np.float32); fl = np.zeros(n, np.uint8); me = np.zeros(n, np.int32)
+        for i, b in enumerate(flat):
+            x0[i] = np.asarray(b.x_0, dtype=np.float64)
+            P0[i] = np.asarray(b.P_0, dtype=np.float32).reshape(16)
+            fl[i] = 3 if np.asarray(b.x_0).dtype == np.float32 else 0
+            me[i] = 0 if b.measurementNumber is None else int(b.measurementNumber)
+        self.bx, self.bP = torch.from_numpy(x0).to(dev), torch.from_numpy(P0).to(dev)
+        self.bf, self.bm = torch.from_numpy(fl).to(dev), torch.from_numpy(me).to(dev)
+        self.bpd = torch.full((n,), float(sc["P_d"]), dtype=torch.float64, device=dev)
+        self.k = 0
+        torch.cuda.synchronize()
+
+    def step(self):
+        k, lib, h = self.k, self.lib, self.h
+        rc = lib.mht_forest_step(h, self.z.data_ptr() + int(self.zoff[k]) * 8, self.M[k])
+        if rc:
+            self._lib_mod.check(rc)
+        nb = self.nb[k]
+        if nb:
+            o = int(self.boff[k])
+            rc = lib.mht_forest_add_targets_dev(h, nb, self.bx.data_ptr() + o * 32, self.bP.data_ptr() + o * 64,
+                                                self.bf.data_ptr() + o, self.bpd.data_ptr() + o * 8,
+                                                self.bm.data_ptr() + o * 4, 1, None, None)
+            if rc:
+                self._lib_mod.check(rc)
+        self.k += 1
+
+    def report(self):
+        rep = self._lib_mod.MhtScanReport()
+        self._lib_mod.check(self.lib.mht_forest_report(self.h, C.byref(rep)))
+        from pymht_amd.tracker import _REPORT_DTYPE
+        nT = rep.n_targets
+        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * _REPORT_DTYPE.itemsize,)) \
+            .view(_REPORT_DTYPE).copy()
+        return rep, recs
+
+    def close(self):
+        self.trk.close()
+
+
+def cpu_baseline(sc, n_warm, n_timed):
+    """The oracle (NumPy restatement of the reference algorithm, validated bitwise against the reference) on the
+    host: stages Process+Cluster+Optim+Terminate+N-Prune of `n_timed` scans after `n_warm` warm-up scans."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mht_oracle as orc
+    from pymht_amd.initiators.m_of_n import Initiator
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.models import pv
+
+    class Adapter:
+        def __init__(self):
+            self.i = Initiator(2, 3, 20, pv.C_RADAR, pv.R_RADAR(), 4 * 2.5 ** 2)
+
+        def processMeasurements(self, time_, z):
+            return [(t.x_0, t.P_0, t.measurementNumber, t.measurement)
+                    for t in self.i.processMeasurements(MeasurementList(time_, z))]
+
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, initiator=Adapter())
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0(), status="preinitialized")
+    hot, stats = 0.0, []
+    for k in range(n_warm + n_timed):
+        info = o.add_scan(float(sc["times"][k]), sc["scans"][k])
+        if k >= n_warm:
+            hot += sum(o.toc[s] for s in ("Process", "Cluster", "Optim", "Terminate", "N-Prune"))
+            stats.append((info["L"], info["G"], info["M"], o.toc["Process"], o.toc["Cluster"] + o.toc["Optim"]))
+    st = np.array(stats)
+    return dict(value=n_timed / hot, unit="scans/s", cores=1, kind="port",
+                sample="oracle/mht_oracle.py (NumPy restatement, bit-identical to the reference in the dev container), "
+                       "1 thread, scans %d..%d of the same scan stream after %d warm-up scans; stages "
+                       "Process+Cluster+Optim+Terminate+N-Prune; mean L=%d G=%d M=%d; gate %.0f ms, cluster+ILP %.0f ms per scan"
+                       % (n_warm, n_warm + n_timed - 1, n_warm, st[:, 0].mean(), st[:, 1].mean(), st[:, 2].mean(),
+                          1e3 * st[:, 3].mean(), 1e3 * st[:, 4].mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--cpu-scans", type=int, default=2, help="timed oracle scans for cpu_baseline (0 disables)")
+    ap.add_argument("--cpu-warm", type=int, default=6)
+    args = ap.parse_args()
+
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from pymht_amd.utils.scenario import make_config
+    W, K = args.warmup, args.steps
+    # every rank = its own sensor sector (own targets, own clutter): BASELINE config 4
+    sc = make_config(args.config, seed=5446 + 1000 * rank, n_scans=W + K, centre=(20000.0 * rank, 0.0))
+    births, stats, final, api_s, init_s = prepass(sc, local)
+
+    # ---- timed replay ---------------------------------------------------------------------------------------------
+    rp = Replay(sc, births, local)
+    for _ in range(W):
+        rp.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        rp.step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    rep, recs = rp.report()
+    got = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0]
+    same_work = (got == final) and rep.error == 0
+    rp.close()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        ok = torch.tensor([1 if same_work else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        same_work = bool(ok.item())
+
+    # ---- stage times with HIP events on the launch stream (identical replay) ----------------------------------------
+    rp = Replay(sc, births, local)
+    for _ in range(W):
+        rp.step()
+    torch.cuda.synchronize()
+    rp._lib_mod.check(rp.lib.mht_forest_set_timing(rp.h, 1))
+    ms = np.zeros(5)
+    done = 0
+    buf = (C.c_float * 5)()
+    n = C.c_int32(0)
+    while done < K:
+        chunk = min(32, K - done)
+        for _ in range(chunk):
+            rp.step()
+        rp._lib_mod.check(rp.lib.mht_forest_stage_times(rp.h, C.byref(buf), C.byref(n)))
+        ms += np.array(list(buf))
+        done += chunk
+    ms /= K
+    rp.close()
+
+    timed = stats[W:W + K]
+    Lm, Gm, Mm = float(timed[:, 0].mean()), float(timed[:, 1].mean()), float(timed[:, 2].mean())
+    # algorithmic bytes of the grow stage per scan: 280 B per leaf + 48 B per gated pair + 8 B per measurement
+    b_gate = 280.0 * Lm + 48.0 * Gm + 8.0 * Mm
+    gate_gbs = b_gate / (ms[0] * 1e-3) / 1e9
+    out = {
+        "metric": "scans/sec at ~5k+ leaf hypotheses x 500 measurements (per-scan gate + cluster + ILP + N-scan prune)",
+        "value": world * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 state / f32 covariance (the reference's own mix)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: 500 targets, ~500 meas/scan, N-scan=5, P_d=0.9, eta2=5.99; "
+                               "one independent sector per GPU", "name": args.config, "targets": int(timed[:, 6].mean()),
+                   "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
+                   "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()),
+                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work},
+        "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
+                     "device_total": float(ms[4])},
+        "api_scans_per_sec": len(sc["scans"]) / api_s,
+        "api_note": "Tracker.addMeasurementList incl. PCIe copies, per-scan report sync and the host-side M-of-N "
+                    "initiator (%.0f %% of that time)" % (100.0 * init_s / api_s),
+        "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gate_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "grow stage = gate_count_kernel + emit_kernel (2 launches), HIP events on the ctx stream",
+                     "algorithmic_bytes": b_gate},
+    }
+    if rank == 0 and world == 1 and args.cpu_scans > 0:
+        n_warm = min(args.cpu_warm, len(sc["scans"]) - args.cpu_scans)
+        out["cpu_baseline"] = cpu_baseline(sc, n_warm, args.cpu_scans)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        if not same_work:
+            out["warning"] = "timed replay diverged from the pre-pass"
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -188,6 +188,11 @@ int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_con
 int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
                            const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
                            int32_t* ids);
+/* Same with every array in device memory (dev pointers, accepted/ids may be NULL); fully asynchronous -- used to
+ * replay pre-staged births without a host round trip. */
+int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
+                               const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
+                               int32_t* ids);
 /* One scan, asynchronous: z dev (M,2) float32.  */
 int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
 /* Same with z in host memory (copied through a pinned staging buffer of the ctx). */
@@ -199,11 +204,13 @@ int mht_forest_report(mht_ctx* ctx, mht_scan_report* out);
  * capacity = length of the host arrays; *n_out = number of leaves.  Synchronises. */
 int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
                       int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
-/* Per-stage device time of the last step in milliseconds: [0] grow (gate+emit) = the reference's toc['Process'],
- * [1] cluster, [2] optimise (ILP + single-target selection), [3] terminate + N-scan prune, [4] whole step.
- * Timing is off by default (two hipEventRecord per stage); enable != 0 switches it on for subsequent steps. */
+/* Per-stage device time in milliseconds, SUMMED over the steps issued since the last call (at most 64 may be
+ * pending): [0] grow (gate_count + emit kernels) = the reference's toc['Process'], [1] cluster, [2] optimise (ILP +
+ * single-target selection), [3] terminate + N-scan prune, [4] whole step.  *n_steps = number of steps summed.
+ * Timing is off by default (five hipEventRecord per step); enable != 0 switches it on for subsequent steps.
+ * Synchronises the stream. */
 int mht_forest_set_timing(mht_ctx* ctx, int32_t enable);
-int mht_forest_stage_times(mht_ctx* ctx, float* ms5);
+int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps);
 /* Ancestor chain of one node: walks parents from (scan, node) towards the root of time, at most max_len steps
  * (bounded by the ring: layers older than n_scan+1 scans are gone).  Outputs host arrays
  * nodes/meas [max_len] int32, x [max_len][4], cnllr [max_len], P [max_len][16]; any may be NULL. */

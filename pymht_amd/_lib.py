@@ -88,13 +88,14 @@ def _declare(lib):
                           C.POINTER(i32), C.POINTER(i32)],
         "mht_forest_create": [vp, C.POINTER(MhtModel), C.POINTER(MhtForestConfig)],
         "mht_forest_add_targets": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
+        "mht_forest_add_targets_dev": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
         "mht_forest_step": [vp, vp, i32],
         "mht_forest_step_host": [vp, vp, i32],
         "mht_forest_report": [vp, C.POINTER(MhtScanReport)],
         "mht_forest_leaves": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_chain": [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_set_timing": [vp, i32],
-        "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5)],
+        "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5), C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

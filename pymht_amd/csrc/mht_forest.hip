@@ -23,6 +23,7 @@ namespace mht {
 
 constexpr int MAXR = 16;
 constexpr int PRUNE_THREADS = 1024;
+constexpr int EV_POOL = 64;
 
 struct FCounts {          // device-side counters of the forest
     int nT;               // targets in the NEXT table
@@ -378,7 +379,7 @@ struct Forest {
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
     int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0;
-    bool timing = false; bool timed = false; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
     void layout(Arena& ar) {
         for (int s = 0; s < R; ++s) {
@@ -424,7 +425,10 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->z_host) (void)hipHostFree(f->z_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
-    for (int i = 0; i < 5; ++i) if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
+    if (f->evp) {
+        for (int k = 0; k < EV_POOL; ++k) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(f->evp[k][i]);
+        delete[] f->evp;
+    }
     delete f;
     ctx->forest = nullptr;
 }
@@ -500,6 +504,29 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     return MHT_OK;
 }
 
+extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
+                                          const double* pd, const int32_t* meas, int32_t check_neighbours,
+                                          uint8_t* accepted, int32_t* ids) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_add_targets_dev: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(n >= 0 && (n == 0 || (x0 && P0 && flags && pd && meas)), "mht_forest_add_targets_dev: null input");
+    if (n == 0) return MHT_OK;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    AddArgs a = {};
+    a.n = n; a.x0 = x0; a.pd = pd; a.P0 = P0; a.meas = meas; a.flags = flags; a.ids = ids; a.accepted = accepted;
+    a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
+    const int nb = (f->scan + 1) & 1;
+    a.layer = f->layer[f->scan % f->R];
+    a.tab = f->tab[nb]; a.leaf_src = f->leaf_src[nb]; a.leaf_tgt = f->leaf_tgt[nb];
+    a.path = f->path[f->scan & 1]; a.PD = f->PD;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
+    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
+    f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
+    return MHT_OK;
+}
+
 extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
                                       const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
                                       int32_t* ids) {
@@ -512,6 +539,8 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     const size_t o_x = 0, o_pd = o_x + (size_t)n * 32, o_P = o_pd + (size_t)n * 8, o_m = o_P + (size_t)n * 64,
                  o_f = o_m + (size_t)n * 4, o_id = (o_f + n + 7) & ~(size_t)7, o_acc = o_id + (size_t)n * 4,
                  total = o_acc + n + 16;
+    // the staging buffers are reused: anything still in flight from a previous call must have drained
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     int rc = stage_host_ensure(f, total);
     if (rc) return rc;
     rc = f->stage_dev.ensure(total);
@@ -521,26 +550,14 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     memcpy(h + o_m, meas, (size_t)n * 4); memcpy(h + o_f, flags, n);
     char* d = static_cast<char*>(f->stage_dev.ptr);
     MHT_HIP_CHECK(hipMemcpyAsync(d, h, o_id, hipMemcpyHostToDevice, ctx->stream));
-    AddArgs a = {};
-    a.n = n; a.x0 = (const double*)(d + o_x); a.pd = (const double*)(d + o_pd); a.P0 = (const float*)(d + o_P);
-    a.meas = (const int32_t*)(d + o_m); a.flags = (const uint8_t*)(d + o_f);
-    a.ids = (int32_t*)(d + o_id); a.accepted = (uint8_t*)(d + o_acc);
-    a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
-    const int nb = (f->scan + 1) & 1;
-    a.layer = f->layer[f->scan % f->R];
-    a.tab = f->tab[nb]; a.leaf_src = f->leaf_src[nb]; a.leaf_tgt = f->leaf_tgt[nb];
-    a.path = f->path[f->scan & 1]; a.PD = f->PD;
-    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
-    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
-    MHT_HIP_CHECK(hipGetLastError());
-    f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
-    f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
-    if (accepted || ids) {
-        MHT_HIP_CHECK(hipMemcpyAsync(h + o_id, d + o_id, total - o_id, hipMemcpyDeviceToHost, ctx->stream));
-        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ids) memcpy(ids, h + o_id, (size_t)n * 4);
-        if (accepted) memcpy(accepted, h + o_acc, n);
-    }
+    rc = mht_forest_add_targets_dev(ctx, n, (const double*)(d + o_x), (const float*)(d + o_P), (const uint8_t*)(d + o_f),
+                                    (const double*)(d + o_pd), (const int32_t*)(d + o_m), check_neighbours,
+                                    (uint8_t*)(d + o_acc), (int32_t*)(d + o_id));
+    if (rc) return rc;
+    MHT_HIP_CHECK(hipMemcpyAsync(h + o_id, d + o_id, total - o_id, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ids) memcpy(ids, h + o_id, (size_t)n * 4);
+    if (accepted) memcpy(accepted, h + o_acc, n);
     return MHT_OK;
 }
 
@@ -555,11 +572,17 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     const int cb = s & 1, nb = (s + 1) & 1;
     const int W = (M + 63) / 64;
     f->last_M = M;
+    hipEvent_t* ev = nullptr;
+    if (f->timing) {
+        MHT_REQUIRE(f->timed_steps < EV_POOL, "mht_forest_step: %d timed steps pending, read them with mht_forest_stage_times", EV_POOL);
+        ev = f->evp[f->ev_slot];
+        f->ev_slot = (f->ev_slot + 1) % EV_POOL;
+    }
     MHT_HIP_CHECK(hipMemsetAsync(f->assoc, 0, (size_t)f->nT_ub * f->AW * 8, st));
     MHT_HIP_CHECK(hipMemsetAsync(f->used, 0, (size_t)(f->Mpad / 64) * 8, st));
     MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), st));
     MHT_HIP_CHECK(hipMemsetAsync(f->cl_counts, 0, 8 * sizeof(int32_t), st));
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[0], st));
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[0], st));
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     GateArgs g = {};
     fill_model(g, &f->model);
@@ -579,7 +602,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     g.Nwin = f->cfg.n_scan;
     int rc = launch_gate(ctx, g, f->L_ub > 0 ? f->L_ub : 1);
     if (rc) return rc;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[1], st));
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
@@ -588,7 +611,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
     if (rc) return rc;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[2], st));
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[2], st));
     // ---- 3: global hypothesis per cluster (tracker.py:225-237) --------------------------------------------------------
     BlpArgs b = {};
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
@@ -603,7 +626,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     if (grid > 1024) grid = 1024;
     rc = launch_blp(ctx, b, grid);
     if (rc) return rc;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(f->ev[3], st));
+    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[3], st));
     // ---- 4: terminate, N-scan prune, compact, report (tracker.py:250-259) ------------------------------------------------
     PruneArgs p = {};
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
@@ -622,7 +645,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     p.Tcap = f->Tcap; p.W = W;
     hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(PRUNE_THREADS), 0, st, p);
     MHT_HIP_CHECK(hipGetLastError());
-    if (f->timing) { MHT_HIP_CHECK(hipEventRecord(f->ev[4], st)); f->timed = true; }
+    if (f->timing) { MHT_HIP_CHECK(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     // the used-measurement mask travels with the report
     MHT_HIP_CHECK(hipMemcpyAsync(f->report_dev + f->used_off, f->used, (size_t)(f->Mpad / 64) * 8, hipMemcpyDeviceToDevice, st));
     f->report_pending = true;
@@ -753,19 +776,32 @@ extern "C" int mht_forest_set_timing(mht_ctx* ctx, int32_t enable) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_timing: no forest");
     Forest* f = ctx->forest;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    if (enable && !f->ev[0])
-        for (int i = 0; i < 5; ++i) MHT_HIP_CHECK(hipEventCreate(&f->ev[i]));
+    if (enable && !f->evp) {
+        f->evp = new hipEvent_t[EV_POOL][5];
+        for (int k = 0; k < EV_POOL; ++k)
+            for (int i = 0; i < 5; ++i) MHT_HIP_CHECK(hipEventCreate(&f->evp[k][i]));
+    }
     f->timing = enable != 0;
-    if (!f->timing) f->timed = false;
+    f->timed_steps = 0;
+    f->ev_slot = 0;
     return MHT_OK;
 }
 
-extern "C" int mht_forest_stage_times(mht_ctx* ctx, float* ms5) {
+extern "C" int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps) {
     MHT_REQUIRE(ctx && ctx->forest && ms5, "mht_forest_stage_times: null argument");
     Forest* f = ctx->forest;
-    MHT_REQUIRE(f->timed, "mht_forest_stage_times: timing was not enabled for the last step");
-    MHT_HIP_CHECK(hipEventSynchronize(f->ev[4]));
-    for (int i = 0; i < 4; ++i) MHT_HIP_CHECK(hipEventElapsedTime(&ms5[i], f->ev[i], f->ev[i + 1]));
-    MHT_HIP_CHECK(hipEventElapsedTime(&ms5[4], f->ev[0], f->ev[4]));
+    MHT_REQUIRE(f->timing && f->timed_steps > 0, "mht_forest_stage_times: no timed step pending");
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; ++i) ms5[i] = 0.f;
+    const int n = f->timed_steps;
+    for (int k = 0; k < n; ++k) {
+        hipEvent_t* ev = f->evp[(f->ev_slot - 1 - k + 2 * EV_POOL) % EV_POOL];
+        float v;
+        for (int i = 0; i < 4; ++i) { MHT_HIP_CHECK(hipEventElapsedTime(&v, ev[i], ev[i + 1])); ms5[i] += v; }
+        MHT_HIP_CHECK(hipEventElapsedTime(&v, ev[0], ev[4]));
+        ms5[4] += v;
+    }
+    if (n_steps) *n_steps = n;
+    f->timed_steps = 0;
     return MHT_OK;
 }

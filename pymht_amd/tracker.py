@@ -199,7 +199,7 @@ class Tracker():
         unusedRadarMeasurementIndices = ~used
         if self._timing:
             ms = (C.c_float * 5)()
-            _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms)))
+            _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms), None))
             self.toc['Process'], self.toc['Cluster'], self.toc['Optim'] = ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3
             self.toc['Terminate'] = 0.0
             self.toc['N-Prune'] = ms[3] * 1e-3
