@@ -16,20 +16,22 @@
 //      the Lagrangian bound (valid for any u >= 0), exact up to 1e-12 relative: BRANCHED.
 // The reference's LP relaxation is integral in >99 % of instances, so step 2 is rare; it keeps
 // the selection exact without any host fallback.
+//
+// Storage: a cluster whose columns / rows / members fit (<= 3072 columns, <= 1024 measurement nodes, <= 256 targets)
+// is copied into LDS once (costs, rows as dense local ids, prices, usage counters, marks) and every dual step runs
+// out of LDS; larger clusters run the same code on HBM scratch (L2 resident).
 #include "mht_kernels.h"
 
 namespace mht {
 
-
 constexpr int BLP_THREADS = 256;
 constexpr int BLP_UW = 512;       // words of the cluster's measurement-node bitset kept in LDS (32768 nodes)
 constexpr double DINF = 1.0e300;
+constexpr int L_MAXH = 3072, L_MAXR = 1024, L_MAXK = 256;
 
 struct Red {
     double d[BLP_THREADS / 64];
     int i[BLP_THREADS / 64];
-    double rd;
-    int ri;
 };
 
 __device__ __forceinline__ double block_sum(double v, Red* r) {
@@ -43,7 +45,6 @@ __device__ __forceinline__ double block_sum(double v, Red* r) {
     for (int w = 0; w < BLP_THREADS / 64; ++w) s += r->d[w];
     return s;
 }
-
 __device__ __forceinline__ int block_or(int v, Red* r) {
     v = __any(v) ? 1 : 0;
     __syncthreads();
@@ -54,7 +55,6 @@ __device__ __forceinline__ int block_or(int v, Red* r) {
     for (int w = 0; w < BLP_THREADS / 64; ++w) s |= r->i[w];
     return s;
 }
-
 // lexicographic (value, index) minimum; index -1 = none
 __device__ __forceinline__ void wave_min_pair(double& v, int& i) {
 #pragma unroll
@@ -79,138 +79,148 @@ __device__ __forceinline__ void block_min_pair(double& v, int& i, Red* r) {
     }
 }
 
-__device__ __forceinline__ double reduced_cost(const BlpArgs& a, int h) {
-    double rc = a.cost[h];
-    for (int d = 0; d < a.PD; ++d) {
-        const int e = a.path[(size_t)d * a.cap + h];
-        if (e >= 0) rc += a.u[e];
+// ---- storage policies -----------------------------------------------------------------------------------------
+// Columns are addressed by a policy-local index; rows by a policy-local id in [0, nrows()).
+struct GStore {      // HBM: column = global child index, row = global measurement-node id, row set = LDS bitset
+    const BlpArgs* a; const int32_t* mem; const unsigned long long* uw; int UW, PD; size_t cap;
+    int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
+    __device__ __forceinline__ int col_begin(int k) const { return a->tchild[mem[k]]; }
+    __device__ __forceinline__ int col_end(int k) const { return a->tchild[mem[k] + 1]; }
+    __device__ __forceinline__ double cost(int h) const { return a->cost[h]; }
+    __device__ __forceinline__ int ent(int d, int h) const { return a->path[(size_t)d * cap + h]; }
+    __device__ __forceinline__ double& u(int m) const { return a->u[m]; }
+    __device__ __forceinline__ int32_t& usage(int m) const { return a->usage[m]; }
+    __device__ __forceinline__ int32_t& mark(int m) const { return a->mark[m]; }
+    __device__ __forceinline__ int to_global(int h) const { return h; }
+    template <typename F> __device__ __forceinline__ void for_rows(F f) const {
+        for (int w = threadIdx.x; w < UW; w += BLP_THREADS) {
+            unsigned long long bits = uw[w];
+            while (bits) {
+                const int m = w * 64 + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                f(m);
+            }
+        }
+    }
+};
+struct LStore {      // LDS: column = dense local index, row = dense local id
+    double* costL; unsigned short* entL; double* uL; int32_t* usageL; int32_t* markL; int32_t* colb; int32_t* gbase;
+    int nH, nR, PD, K;
+    int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
+    __device__ __forceinline__ int col_begin(int k) const { return colb[k]; }
+    __device__ __forceinline__ int col_end(int k) const { return colb[k + 1]; }
+    __device__ __forceinline__ double cost(int h) const { return costL[h]; }
+    __device__ __forceinline__ int ent(int d, int h) const { const int e = entL[d * L_MAXH + h]; return e == 0xffff ? -1 : e; }
+    __device__ __forceinline__ double& u(int m) const { return uL[m]; }
+    __device__ __forceinline__ int32_t& usage(int m) const { return usageL[m]; }
+    __device__ __forceinline__ int32_t& mark(int m) const { return markL[m]; }
+    __device__ __forceinline__ int to_global(int h) const {       // member k with colb[k] <= h
+        int lo = 0, hi = K;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (colb[mid] <= h) lo = mid; else hi = mid; }
+        return gbase[lo] + (h - colb[lo]);
+    }
+    template <typename F> __device__ __forceinline__ void for_rows(F f) const {
+        for (int m = threadIdx.x; m < nR; m += BLP_THREADS) f(m);
+    }
+};
+
+template <typename S> __device__ __forceinline__ double reduced_cost(const S& s, int h) {
+    double rc = s.cost(h);
+    for (int d = 0; d < s.PD; ++d) {
+        const int e = s.ent(d, h);
+        if (e >= 0) rc += s.u(e);
     }
     return rc;
 }
-__device__ __forceinline__ bool compatible(const BlpArgs& a, int h) {
-    for (int d = 0; d < a.PD; ++d) {
-        const int e = a.path[(size_t)d * a.cap + h];
-        if (e >= 0 && a.mark[e]) return false;
+template <typename S> __device__ __forceinline__ bool compatible(const S& s, int h) {
+    for (int d = 0; d < s.PD; ++d) {
+        const int e = s.ent(d, h);
+        if (e >= 0 && s.mark(e)) return false;
     }
     return true;
 }
-__device__ __forceinline__ void set_marks(const BlpArgs& a, int h, int value) {
-    if ((int)threadIdx.x < a.PD) {
-        const int e = a.path[(size_t)threadIdx.x * a.cap + h];
-        if (e >= 0) a.mark[e] = value;
+template <typename S> __device__ __forceinline__ void set_marks(const S& s, int h, int value) {
+    if ((int)threadIdx.x < s.PD) {
+        const int e = s.ent(threadIdx.x, h);
+        if (e >= 0) s.mark(e) = value;
     }
     __threadfence_block();
     __syncthreads();
 }
-__device__ __forceinline__ double priced_sum(const BlpArgs& a, int h, Red* r) {    // sum of u over the rows of column h
+template <typename S> __device__ __forceinline__ double priced_sum(const S& s, int h, Red* r) {
     double v = 0.0;
-    if ((int)threadIdx.x < a.PD) {
-        const int e = a.path[(size_t)threadIdx.x * a.cap + h];
-        if (e >= 0) v = a.u[e];
+    if ((int)threadIdx.x < s.PD) {
+        const int e = s.ent(threadIdx.x, h);
+        if (e >= 0) v = s.u(e);
     }
     return block_sum(v, r);
 }
 
 // greedy dive: targets in cluster order, each takes its cheapest (reduced cost) column compatible with the
 // columns already taken.  Always feasible: every target owns an all-miss column without measurements.
-__device__ double greedy_dive(const BlpArgs& a, const int32_t* mem, int K, int32_t* out_sel, Red* r) {
+template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
     double total = 0.0;
     for (int k = 0; k < K; ++k) {
-        const int t = mem[k];
         double bv = DINF;
         int bi = -1;
-        for (int h = a.tchild[t] + threadIdx.x; h < a.tchild[t + 1]; h += BLP_THREADS) {
-            if (!compatible(a, h)) continue;
-            const double rc = reduced_cost(a, h);
+        for (int h = s.col_begin(k) + threadIdx.x; h < s.col_end(k); h += BLP_THREADS) {
+            if (!compatible(s, h)) continue;
+            const double rc = reduced_cost(s, h);
             if (bi < 0 || rc < bv) { bv = rc; bi = h; }
         }
         block_min_pair(bv, bi, r);
-        out_sel[k] = bi;
-        total += a.cost[bi];
-        set_marks(a, bi, 1);
+        if (threadIdx.x == 0) out_sel[k] = bi;
+        total += s.cost(bi);
+        set_marks(s, bi, 1);
     }
-    for (int k = 0; k < K; ++k) set_marks(a, out_sel[k], 0);
+    for (int k = 0; k < K; ++k) set_marks(s, out_sel[k], 0);
     return total;
 }
 
-__device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r) {
+// Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
+template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
-    const int32_t* mem = a.cl_members + a.cl_ptr[c];
-    const int slot = a.cl_ptr[c] + c;
-    int32_t* best_h = a.best_h + slot;
-    double* best_rc = a.best_rc + slot;
-    int32_t* ub_sel = a.bb_best + slot;
-    const int UW = (a.n_mnodes + 63) >> 6;
-    // ---- measurement nodes of the cluster (union of the rows of its columns) -----------------------------
-    for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
-    __syncthreads();
-    for (int k = 0; k < K; ++k) {
-        const int t = mem[k];
-        for (int d = 0; d < a.PD; ++d)
-            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
-                const int e = a.path[(size_t)d * a.cap + h];
-                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
-            }
-    }
-    __syncthreads();
-    for (int w = tid; w < UW; w += BLP_THREADS) {
-        unsigned long long bits = uw[w];
-        while (bits) {
-            const int m = w * 64 + __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            a.u[m] = 0.0;
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-
     double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
-    int stall = 0, status = 0, iters = 0;
+    int stall = 0;
+    status = 0; iters = 0; nodes = 0;
     for (int it = 0; it <= a.max_iter; ++it) {
         iters = it;
         // A: per target the minimiser of the reduced cost (one wavefront per target, lowest index wins ties)
         for (int k = wave; k < K; k += BLP_THREADS / 64) {
-            const int t = mem[k];
             double bv = DINF;
             int bi = -1;
-            for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
-                const double rc = reduced_cost(a, h);
+            for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+                const double rc = reduced_cost(s, h);
                 if (bi < 0 || rc < bv) { bv = rc; bi = h; }
             }
             wave_min_pair(bv, bi);
-            if (lane == 0) { best_h[k] = bi; best_rc[k] = bv; }
+            if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
         }
         __threadfence_block();
         __syncthreads();
         // B: how often each measurement node is used by the minimisers
-        for (int idx = tid; idx < K * a.PD; idx += BLP_THREADS) {
-            const int k = idx / a.PD, d = idx - k * a.PD;
-            const int e = a.path[(size_t)d * a.cap + best_h[k]];
-            if (e >= 0) atomicAdd(&a.usage[e], 1);
+        for (int idx = tid; idx < K * s.PD; idx += BLP_THREADS) {
+            const int k = idx / s.PD, d = idx - k * s.PD;
+            const int e = s.ent(d, s.best_h[k]);
+            if (e >= 0) atomicAdd(&s.usage(e), 1);
         }
         __threadfence_block();
         __syncthreads();
         // C: subgradient, dual value, certificate
         double nrm = 0.0, usum = 0.0;
         int conflict = 0, slack = 0;
-        for (int w = tid; w < UW; w += BLP_THREADS) {
-            unsigned long long bits = uw[w];
-            while (bits) {
-                const int m = w * 64 + __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                const int us = a.usage[m];
-                const double um = a.u[m];
-                double g = (double)(us - 1);
-                if (um <= 0.0 && g < 0.0) g = 0.0;
-                nrm += g * g;
-                usum += um;
-                conflict |= (us >= 2);
-                slack |= (um > 0.0 && us == 0);
-            }
-        }
+        s.for_rows([&](int m) {
+            const int us = s.usage(m);
+            const double um = s.u(m);
+            double g = (double)(us - 1);
+            if (um <= 0.0 && g < 0.0) g = 0.0;
+            nrm += g * g;
+            usum += um;
+            conflict |= (us >= 2);
+            slack |= (um > 0.0 && us == 0);
+        });
         double src = 0.0, sc = 0.0;
-        for (int k = tid; k < K; k += BLP_THREADS) { src += best_rc[k]; sc += a.cost[best_h[k]]; }
+        for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
         nrm = block_sum(nrm, r);
         utot = block_sum(usum, r);
         src = block_sum(src, r);
@@ -220,7 +230,9 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
         const double LB = src - utot;
         if (!conflict && sc < UB) {
             UB = sc;
-            for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = best_h[k];
+            for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
+            __threadfence_block();
+            __syncthreads();
         }
         bool done = false;
         if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
@@ -228,10 +240,10 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
             if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
             else if (++stall >= 10) { theta *= 0.5; stall = 0; }
             if (UB >= DINF || (conflict && (it % 8) == 0)) {
-                const double g = greedy_dive(a, mem, K, a.bb_ch + slot, r);
+                const double g = greedy_dive(s, K, s.ch, r);
                 if (g < UB) {
                     UB = g;
-                    for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = a.bb_ch[slot + k];
+                    for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.ch[k];
                     __threadfence_block();
                     __syncthreads();
                 }
@@ -241,144 +253,252 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
         }
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
         const double step = done ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
-        for (int w = tid; w < UW; w += BLP_THREADS) {
-            unsigned long long bits = uw[w];
-            while (bits) {
-                const int m = w * 64 + __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                if (!done) {
-                    const double um = a.u[m];
-                    double g = (double)(a.usage[m] - 1);
-                    if (um <= 0.0 && g < 0.0) g = 0.0;
-                    a.u[m] = fmax(0.0, um + step * g);
-                }
-                a.usage[m] = 0;
+        s.for_rows([&](int m) {
+            if (!done) {
+                const double um = s.u(m);
+                double g = (double)(s.usage(m) - 1);
+                if (um <= 0.0 && g < 0.0) g = 0.0;
+                s.u(m) = fmax(0.0, um + step * g);
             }
-        }
+            s.usage(m) = 0;
+        });
         __threadfence_block();
         __syncthreads();
         if (done) break;
     }
-
-    int nodes = 0;
-    if (status == 0) {
-        // ---- depth-first branch and bound with the current prices -------------------------------------------
-        double usum = 0.0;
-        for (int w = tid; w < UW; w += BLP_THREADS) {
-            unsigned long long bits = uw[w];
-            while (bits) {
-                const int m = w * 64 + __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                usum += a.u[m];
-            }
-        }
-        utot = block_sum(usum, r);
-        int32_t* ch = a.bb_ch + slot;
-        double* cst = a.bb_cost + slot;
-        double* uus = a.bb_uused + slot;
-        double* lrc = a.bb_last_rc + slot;
-        int32_t* lix = a.bb_last_idx + slot;
-        double* rest = a.bb_rest + slot;
-        double* mn = a.bb_min + slot;
-        if (UB >= DINF) {
-            UB = greedy_dive(a, mem, K, ch, r);
-            for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = ch[k];
-            __threadfence_block();
-            __syncthreads();
-        }
-        if (tid == 0) { cst[0] = 0.0; uus[0] = 0.0; }
+    if (status != 0) return;
+    // ---- depth-first branch and bound with the current prices ---------------------------------------------------
+    double usum = 0.0;
+    s.for_rows([&](int m) { usum += s.u(m); });
+    utot = block_sum(usum, r);
+    if (UB >= DINF) {
+        UB = greedy_dive(s, K, s.ch, r);
+        for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.ch[k];
         __threadfence_block();
         __syncthreads();
-        int level = 0;
-        bool enter = true;
-        status = MHT_BLP_BRANCHED;
-        while (true) {
-            const double eps = 1e-12 * fmax(1.0, fabs(UB));
-            if (enter) {
-                if (++nodes > a.node_limit) { status = MHT_BLP_NODE_LIMIT; break; }
-                if (level == K) {
-                    if (cst[K] < UB - eps) {
-                        UB = cst[K];
-                        for (int k = tid; k < K; k += BLP_THREADS) ub_sel[k] = ch[k];
-                        __threadfence_block();
-                        __syncthreads();
-                    }
-                    --level;
-                    set_marks(a, ch[level], 0);
-                    enter = false;
-                    continue;
+    }
+    if (tid == 0) { s.cst[0] = 0.0; s.uus[0] = 0.0; }
+    __threadfence_block();
+    __syncthreads();
+    int level = 0;
+    bool enter = true;
+    status = MHT_BLP_BRANCHED;
+    while (true) {
+        const double eps = 1e-12 * fmax(1.0, fabs(UB));
+        if (enter) {
+            if (++nodes > a.node_limit) { status = MHT_BLP_NODE_LIMIT; break; }
+            if (level == K) {
+                if (s.cst[K] < UB - eps) {
+                    UB = s.cst[K];
+                    for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.ch[k];
+                    __threadfence_block();
+                    __syncthreads();
                 }
-                for (int j = level + wave; j < K; j += BLP_THREADS / 64) {
-                    const int t = mem[j];
-                    double bv = DINF;
-                    int bi = -1;
-                    for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
-                        if (!compatible(a, h)) continue;
-                        const double rc = reduced_cost(a, h);
-                        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
-                    }
-                    wave_min_pair(bv, bi);
-                    if (lane == 0) mn[j] = (bi < 0) ? DINF : bv;
-                }
-                __threadfence_block();
-                __syncthreads();
-                double rs = 0.0;
-                int dead = 0;
-                for (int j = level + tid; j < K; j += BLP_THREADS) {
-                    const double v = mn[j];
-                    if (v >= DINF) dead = 1;
-                    else if (j > level) rs += v;
-                }
-                rs = block_sum(rs, r);
-                dead = block_or(dead, r);
-                const double lb = cst[level] + mn[level] + rs - (utot - uus[level]);
-                if (dead || lb >= UB - eps) {
-                    if (level == 0) break;
-                    --level;
-                    set_marks(a, ch[level], 0);
-                    enter = false;
-                    continue;
-                }
-                if (tid == 0) { rest[level] = rs; lrc[level] = -DINF; lix[level] = -1; }
-                __threadfence_block();
-                __syncthreads();
-                enter = false;
-            }
-            // next candidate of target `level` in increasing (reduced cost, index) order
-            const int t = mem[level];
-            const double prc = lrc[level];
-            const int pix = lix[level];
-            double bv = DINF;
-            int bi = -1;
-            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
-                if (!compatible(a, h)) continue;
-                const double rc = reduced_cost(a, h);
-                if (rc < prc || (rc == prc && h <= pix)) continue;
-                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
-            }
-            block_min_pair(bv, bi, r);
-            if (bi < 0 || cst[level] + bv + rest[level] - (utot - uus[level]) >= UB - eps) {
-                if (level == 0) break;
                 --level;
-                set_marks(a, ch[level], 0);
+                set_marks(s, s.ch[level], 0);
+                enter = false;
                 continue;
             }
-            const double pu = priced_sum(a, bi, r);
-            if (tid == 0) {
-                lrc[level] = bv;
-                lix[level] = bi;
-                ch[level] = bi;
-                cst[level + 1] = cst[level] + a.cost[bi];
-                uus[level + 1] = uus[level] + pu;
+            for (int j = level + wave; j < K; j += BLP_THREADS / 64) {
+                double bv = DINF;
+                int bi = -1;
+                for (int h = s.col_begin(j) + lane; h < s.col_end(j); h += 64) {
+                    if (!compatible(s, h)) continue;
+                    const double rc = reduced_cost(s, h);
+                    if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+                }
+                wave_min_pair(bv, bi);
+                if (lane == 0) s.mn[j] = (bi < 0) ? DINF : bv;
             }
-            set_marks(a, bi, 1);
-            ++level;
-            enter = true;
+            __threadfence_block();
+            __syncthreads();
+            double rs = 0.0;
+            int dead = 0;
+            for (int j = level + tid; j < K; j += BLP_THREADS) {
+                const double v = s.mn[j];
+                if (v >= DINF) dead = 1;
+                else if (j > level) rs += v;
+            }
+            rs = block_sum(rs, r);
+            dead = block_or(dead, r);
+            const double lb = s.cst[level] + s.mn[level] + rs - (utot - s.uus[level]);
+            if (dead || lb >= UB - eps) {
+                if (level == 0) break;
+                --level;
+                set_marks(s, s.ch[level], 0);
+                enter = false;
+                continue;
+            }
+            if (tid == 0) { s.rest[level] = rs; s.lrc[level] = -DINF; s.lix[level] = -1; }
+            __threadfence_block();
+            __syncthreads();
+            enter = false;
         }
-        // leave no marks behind
-        for (int l = 0; l < level; ++l) set_marks(a, ch[l], 0);
+        // next candidate of target `level` in increasing (reduced cost, index) order
+        const double prc = s.lrc[level];
+        const int pix = s.lix[level];
+        double bv = DINF;
+        int bi = -1;
+        for (int h = s.col_begin(level) + tid; h < s.col_end(level); h += BLP_THREADS) {
+            if (!compatible(s, h)) continue;
+            const double rc = reduced_cost(s, h);
+            if (rc < prc || (rc == prc && h <= pix)) continue;
+            if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+        }
+        block_min_pair(bv, bi, r);
+        if (bi < 0 || s.cst[level] + bv + s.rest[level] - (utot - s.uus[level]) >= UB - eps) {
+            if (level == 0) break;
+            --level;
+            set_marks(s, s.ch[level], 0);
+            continue;
+        }
+        const double pu = priced_sum(s, bi, r);
+        if (tid == 0) {
+            s.lrc[level] = bv;
+            s.lix[level] = bi;
+            s.ch[level] = bi;
+            s.cst[level + 1] = s.cst[level] + s.cost(bi);
+            s.uus[level + 1] = s.uus[level] + pu;
+        }
+        set_marks(s, bi, 1);
+        ++level;
+        enter = true;
     }
-    for (int k = tid; k < K; k += BLP_THREADS) a.sel[mem[k]] = ub_sel[k];
+    for (int l = 0; l < level; ++l) set_marks(s, s.ch[l], 0);     // leave no marks behind
+}
+
+// track termination test and N-scan prune depth for target t whose selected leaf is child s (forest mode)
+__device__ __forceinline__ void finish_target(const BlpArgs& a, int t, int s) {
+    if (!a.t_alive) return;
+    const double cn = a.cnllr[s];
+    const uint8_t fl = a.flags[s];
+    const double rootc = a.t_root_cnllr[t];
+    const bool f32score = (fl & F_SCORE_F32) && a.t_root_f32[t];
+    // getScore() (pyTarget.py:124) with NumPy scalar promotion: float32 - float32 stays float32
+    const double score = f32score ? (double)((float)cn - (float)rootc) : cn - rootc;
+    int status = 0;
+    if (isfinite(a.radar_range)) {
+        const double dx = a.x[s] - a.radar_x, dy = a.x[(size_t)a.cap + s] - a.radar_y;
+        if (sqrt(dx * dx + dy * dy) > a.radar_range) status = 1;                          // tracker.py:895
+    }
+    if (!status) {
+        const double per = f32score ? (double)((float)score / (float)(a.Nwin + 1)) : score / (double)(a.Nwin + 1);
+        if (per > a.score_limit) status = 2;                                                 // tracker.py:902
+        else if (cn > a.cnllr_limit) status = 3;                                             // tracker.py:908
+    }
+    const int dg = a.t_depth[t] + 1, w = a.t_window[t];
+    a.t_alive[t] = status;                 // 0 = alive, else the termination reason
+    a.t_jdrop[t] = dg > w ? dg - w : 0;    // layers the root advances (pyTarget.pruneDepth)
+    a.t_count[t] = 0;
+    a.t_firstsurv[t] = 0x7fffffff;
+    a.t_score[t] = score;
+}
+
+__device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds) {
+    const int tid = threadIdx.x;
+    const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
+    const int32_t* mem = a.cl_members + a.cl_ptr[c];
+    const int slot = a.cl_ptr[c] + c;
+    const int UW = (a.n_mnodes + 63) >> 6;
+    __shared__ int s_wbase[BLP_UW];
+    __shared__ int s_nR;
+    // ---- measurement nodes of the cluster (union of the rows of its columns) -----------------------------------
+    for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
+    __syncthreads();
+    int nH = 0;
+    for (int k = 0; k < K; ++k) {
+        const int t = mem[k];
+        nH += a.tchild[t + 1] - a.tchild[t];
+        for (int d = 0; d < a.PD; ++d)
+            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
+                const int e = a.path[(size_t)d * a.cap + h];
+                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+            }
+    }
+    __syncthreads();
+    if (tid < 64) {       // exclusive prefix of the popcounts: dense local row ids
+        int carry = 0;
+        for (int base = 0; base < UW; base += 64) {
+            const int w = base + tid;
+            const int pc = (w < UW) ? __popcll(uw[w]) : 0;
+            int incl = pc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (tid >= o) incl += v;
+            }
+            if (w < UW) s_wbase[w] = carry + incl - pc;
+            carry += __shfl(incl, 63);
+        }
+        if (tid == 0) s_nR = carry;
+    }
+    __syncthreads();
+    const int nR = s_nR;
+    int status, iters, nodes;
+    if (nH <= L_MAXH && nR <= L_MAXR && K <= L_MAXK && a.PD <= 8) {
+        // ---- LDS-resident solve ------------------------------------------------------------------------------
+        LStore s;
+        unsigned char* q = lds;
+        s.costL = reinterpret_cast<double*>(q); q += (size_t)L_MAXH * 8;
+        s.uL = reinterpret_cast<double*>(q); q += (size_t)L_MAXR * 8;
+        s.best_rc = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.cst = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.uus = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.lrc = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.rest = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.mn = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
+        s.usageL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
+        s.markL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
+        s.colb = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.gbase = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.best_h = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.ub_sel = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.ch = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.lix = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
+        s.entL = reinterpret_cast<unsigned short*>(q);
+        s.nH = nH; s.nR = nR; s.PD = a.PD; s.K = K;
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < K; ++k) { s.colb[k] = acc; s.gbase[k] = a.tchild[mem[k]]; acc += a.tchild[mem[k] + 1] - a.tchild[mem[k]]; }
+            s.colb[K] = acc;
+        }
+        for (int m = tid; m < nR; m += BLP_THREADS) { s.uL[m] = 0.0; s.usageL[m] = 0; s.markL[m] = 0; }
+        __syncthreads();
+        for (int k = 0; k < K; ++k) {
+            const int gb = s.gbase[k], lb = s.colb[k], n = s.colb[k + 1] - lb;
+            for (int j = tid; j < n; j += BLP_THREADS) {
+                s.costL[lb + j] = a.cost[gb + j];
+                for (int d = 0; d < a.PD; ++d) {
+                    const int e = a.path[(size_t)d * a.cap + gb + j];
+                    unsigned short v = 0xffff;
+                    if (e >= 0) v = (unsigned short)(s_wbase[e >> 6] + __popcll(uw[e >> 6] & ((1ull << (e & 63)) - 1ull)));
+                    s.entL[d * L_MAXH + lb + j] = v;
+                }
+            }
+        }
+        __syncthreads();
+        solve_core(a, s, K, r, status, iters, nodes);
+        for (int k = tid; k < K; k += BLP_THREADS) {
+            const int h = s.to_global(s.ub_sel[k]);
+            a.sel[mem[k]] = h;
+            finish_target(a, mem[k], h);
+        }
+    } else {
+        // ---- same code on HBM scratch ----------------------------------------------------------------------------
+        GStore s;
+        s.a = &a; s.mem = mem; s.uw = uw; s.UW = UW; s.PD = a.PD; s.cap = (size_t)a.cap;
+        s.best_h = a.best_h + slot; s.best_rc = a.best_rc + slot; s.ub_sel = a.bb_best + slot; s.ch = a.bb_ch + slot;
+        s.cst = a.bb_cost + slot; s.uus = a.bb_uused + slot; s.lrc = a.bb_last_rc + slot; s.lix = a.bb_last_idx + slot;
+        s.rest = a.bb_rest + slot; s.mn = a.bb_min + slot;
+        s.for_rows([&](int m) { a.u[m] = 0.0; });
+        __threadfence_block();
+        __syncthreads();
+        solve_core(a, s, K, r, status, iters, nodes);
+        for (int k = tid; k < K; k += BLP_THREADS) {
+            a.sel[mem[k]] = s.ub_sel[k];
+            finish_target(a, mem[k], s.ub_sel[k]);
+        }
+    }
     if (tid == 0) {
         a.cl_status[c] = status;
         a.cl_iters[c] = iters;
@@ -388,11 +508,15 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
     __syncthreads();
 }
 
+constexpr size_t BLP_LDS_BYTES = (size_t)L_MAXH * 8 + (size_t)L_MAXR * 8 + 6 * (size_t)(L_MAXK + 1) * 8 + 2 * (size_t)L_MAXR * 4 +
+                                 6 * (size_t)(L_MAXK + 1) * 4 + (size_t)8 * L_MAXH * 2 + 64;
+
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ unsigned long long uw[BLP_UW];
     __shared__ Red red;
     const int nMulti = a.counts[1], nSingle = a.counts[2];
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, &red);
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, &red, lds);
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
@@ -410,23 +534,29 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
             const int oi = __shfl_xor(bi, o);
             if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
         }
-        if (lane == 0) a.sel[t] = bi;
+        if (lane == 0) {
+            a.sel[t] = bi;
+            finish_target(a, t, bi);
+        }
     }
 }
 
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
+    static bool attr = false;
     if ((a.n_mnodes + 63) / 64 > BLP_UW) {
         set_error("blp: %d measurement nodes exceed the LDS bitset (%d)", a.n_mnodes, BLP_UW * 64);
         return MHT_E_CAPACITY;
     }
-    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), 0, ctx->stream, a);
+    if (!attr) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLP_LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), BLP_LDS_BYTES, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
 
-}  // namespace mht
-
-namespace mht {
 __global__ void blp_objective_kernel(const int32_t* sel, const double* cost, int nT, const int32_t* st, const int32_t* it,
                                      const int32_t* nd, double* out) {
     if (threadIdx.x || blockIdx.x) return;
@@ -445,7 +575,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
                              const int32_t* rows, const double* cost, int32_t max_iter, int32_t node_limit,
                              int32_t* selected, double* objective, int32_t* status, int32_t* iterations, int32_t* nodes) {
     MHT_REQUIRE(ctx && group_ptr && cost && selected, "mht_solve_blp: null argument");
-    MHT_REQUIRE(nT >= 1 && nHyp >= nT && nRows >= 0 && depth >= 0, "mht_solve_blp: bad sizes");
+    MHT_REQUIRE(nT >= 1 && nHyp >= nT && nRows >= 0 && depth >= 0 && depth <= MAXPD, "mht_solve_blp: bad sizes");
     MHT_REQUIRE(rows || depth == 0, "mht_solve_blp: rows is null");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t S = (size_t)2 * nT + 2;

@@ -14,51 +14,73 @@ namespace mht {
 
 
 constexpr int CL_THREADS = 1024;
+constexpr int CL_ELDS = 16384;     // edges kept in LDS (packed target<<16 | node); the rest spills to HBM scratch
+
+__device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArgs& a, int e) {
+    return e < CL_ELDS ? eL[e] : ((unsigned)a.edge_t[e - CL_ELDS] << 16) | (unsigned)a.edge_m[e - CL_ELDS];
+}
 
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]
-    int* aux = tlabel + a.Tcap;                          // [Tcap]  (cluster index of a head / member counters)
+    int* aux = tlabel + a.Tcap;                          // [Tcap]  cluster index of a head
     int* mlabel = aux + a.Tcap;                          // [n_mnodes]
+    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + a.n_mnodes);   // [CL_ELDS]
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_total;
     const int tid = threadIdx.x;
     const int T = *a.nT_dev;
     for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
-    if (tid == 0) s_edges = 0;
+    if (tid == 0) { s_edges = 0; a.counts[3] = 0; }
     __syncthreads();
-    // bitsets -> edge list
+    // bitsets -> edge list; the rows are cleared on the way (no memset between scans).  4 independent loads in
+    // flight per thread: the sweep is latency bound otherwise.
     const long long nwords = (long long)T * a.AW;
-    for (long long idx = tid; idx < nwords; idx += CL_THREADS) {
-        unsigned long long bits = a.assoc[idx];
-        if (!bits) continue;
-        const int t = (int)(idx / a.AW), w = (int)(idx % a.AW);
-        int pos = atomicAdd(&s_edges, __popcll(bits));
-        while (bits) {
-            const int b = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            if (pos < a.Ecap) {
-                a.edge_t[pos] = t;
-                a.edge_m[pos] = w * 64 + b;
+    unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
+    for (long long base = 0; base < nwords; base += 4LL * CL_THREADS) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long idx = base + (long long)q * CL_THREADS + tid;
+            v[q] = idx < nwords ? rows[idx] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned long long bits = v[q];
+            if (!bits) continue;
+            const long long idx = base + (long long)q * CL_THREADS + tid;
+            if (a.clear_rows) rows[idx] = 0ull;
+            const int t = (int)(idx / a.AW), w = (int)(idx % a.AW);
+            int pos = atomicAdd(&s_edges, __popcll(bits));
+            while (bits) {
+                const int b = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int m = w * 64 + b;
+                if (pos < CL_ELDS) eL[pos] = ((unsigned)t << 16) | (unsigned)m;
+                else if (pos - CL_ELDS < a.Ecap) { a.edge_t[pos - CL_ELDS] = t; a.edge_m[pos - CL_ELDS] = m; }
+                ++pos;
             }
-            ++pos;
         }
     }
+    __threadfence_block();
     __syncthreads();
     int E = s_edges;
-    if (E > a.Ecap) {
+    if (E > CL_ELDS + a.Ecap) {
         if (tid == 0) a.counts[3] = 1;
-        E = a.Ecap;
+        E = CL_ELDS + a.Ecap;
     }
-    __threadfence_block();
     // label propagation
     for (int iter = 0; iter < 4096; ++iter) {
         if (tid == 0) s_changed = 0;
         __syncthreads();
-        for (int e = tid; e < E; e += CL_THREADS) atomicMin(&mlabel[a.edge_m[e]], tlabel[a.edge_t[e]]);
+        for (int e = tid; e < E; e += CL_THREADS) {
+            const unsigned pk = cl_edge(eL, a, e);
+            atomicMin(&mlabel[pk & 0xffff], tlabel[pk >> 16]);
+        }
         __syncthreads();
         for (int e = tid; e < E; e += CL_THREADS) {
-            const int v = mlabel[a.edge_m[e]], t = a.edge_t[e];
+            const unsigned pk = cl_edge(eL, a, e);
+            const int v = mlabel[pk & 0xffff], t = (int)(pk >> 16);
             if (v < tlabel[t]) {
                 atomicMin(&tlabel[t], v);
                 s_changed = 1;
@@ -158,12 +180,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
 }
 
-size_t cluster_lds_bytes(int Tcap, int n_mnodes) { return (size_t)(2 * Tcap + n_mnodes) * 4; }
+size_t cluster_lds_bytes(int Tcap, int n_mnodes) { return (size_t)(2 * Tcap + n_mnodes + CL_ELDS) * 4; }
 
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
     static size_t attr_bytes = 0;
     const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
-    if (lds > 150 * 1024) {
+    if (lds > 150 * 1024 || a.n_mnodes > 65536 || a.Tcap > 65536) {
         set_error("cluster: Tcap=%d and %d measurement nodes need %zu B of LDS (> 150 KiB)", a.Tcap, a.n_mnodes, lds);
         return MHT_E_CAPACITY;
     }
@@ -197,6 +219,7 @@ extern "C" int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_
     a.AW = words;
     a.Tcap = T;
     a.Ecap = (int)ecap;
+    a.clear_rows = 0;
     a.n_mnodes = words * 64;
     a.edge_t = base; a.edge_m = base + ecap;
     int32_t* q = base + 2 * ecap;

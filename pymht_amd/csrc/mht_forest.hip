@@ -5,14 +5,14 @@
 //   layers[R]      ring of mht_nodes, one per scan of the N-scan window (R = N+2): layer s % R holds every
 //                  hypothesis created at scan s (children of that scan, then roots born after it).  A node refers
 //                  to its parent by index into the previous layer (pyTarget.Target.parent).
-//   leaf list      leaf_src[i] (node in the newest layer), leaf_tgt[i] (target slot); leaves of one target are
-//                  contiguous and in pyTarget.getLeafNodes DFS order; targets in __targetList__ order.
+//   leaves         implicit: target t owns the nodes first[t] .. first[t]+count-1 of the newest layer (contiguous, in
+//                  pyTarget.getLeafNodes DFS order); leaf_off[] is the prefix of the counts; targets in __targetList__ order.
 //   path[PD][.]    per newest-layer node the measurement nodes (ring_slot*Mpad + m) on its root->node path:
 //                  the rows of its ILP column (tracker.py:1042-1113) and the key for N-scan pruning.
 //   target table   id, window, depth below the root, root node/score -- double buffered, compacted on termination.
 //   assoc[T][AW]   bitsets = the reference's __associatedMeasurements__ (tracker.py:78), rebuilt every scan.
-// Per scan five launches on one stream: gate_count, emit (mht_gate.hip), cluster (mht_cluster.hip), blp
-// (mht_blp.hip), prune (here: track termination tracker.py:891-916 / :353-381, N-scan pruning tracker.py:1219-1231,
+// Per scan six launches on one stream, no memsets, no host round trip: gate_count, emit (mht_gate.hip), cluster
+// (mht_cluster.hip), blp (mht_blp.hip), survive + commit (here: track termination tracker.py:891-916 / :353-381, N-scan pruning tracker.py:1219-1231,
 // compaction of the leaf list and the target table, the scan report).
 #include "mht_kernels.h"
 #include <string.h>
@@ -41,25 +41,13 @@ struct LayerView { const double* x; const double* cnllr; const int32_t* parent; 
 struct TTable {           // one buffer of the target table
     int32_t* id; int32_t* window; int32_t* depth; int32_t* shift; int32_t* root_scan; int32_t* root_node;
     double* root_cnllr; uint8_t* root_f32;
+    int32_t* first;       // node index (newest layer) of the target's first leaf; its leaves are contiguous
+    int32_t* leaf_off;    // [T+1] exclusive prefix of the leaf counts
 };
 
 struct ReportHeader {     // device image of mht_scan_report up to the host pointers
     int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
         blp_iters_max, error, used_words, pad[3];
-};
-
-struct PruneArgs {
-    TTable cur, nxt;
-    const int32_t* sel; const int32_t* tchild; const int32_t* ctgt;
-    LayerView layers[MAXR]; int R; int scan; int cap; int capc;
-    const int32_t* path; int PD;
-    int32_t* leaf_src_next; int32_t* leaf_tgt_next;
-    int32_t* alive; int32_t* jdrop; int32_t* new_index; int32_t* n_leaves;   // [Tcap] scratch
-    FCounts* cnt; const DevStatus* status;
-    const int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* t_label;
-    ReportHeader* hdr; mht_target_report* rec;
-    int Nwin; double score_limit, cnllr_limit, radar_x, radar_y, radar_range;
-    int Tcap; int W;
 };
 
 __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total) {
@@ -82,131 +70,127 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total)
     return s_scan[wv] + incl - v;
 }
 
-__global__ __launch_bounds__(PRUNE_THREADS) void prune_kernel(const PruneArgs a) {
-    __shared__ int s_scan[PRUNE_THREADS / 64], s_total, s_branched, s_limit, s_itmax;
-    const int tid = threadIdx.x;
-    const int nT = a.cnt->nT;                 // table of this scan
+struct SurviveArgs {
+    const int32_t* ctgt; const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop;
+    int32_t* t_count; int32_t* t_firstsurv; const int32_t* path; int cap; const DevStatus* status;
+};
+
+// N-scan pruning, child side (pyTarget.pruneDepth -> _pruneAllHypothesisExceptThis, pyTarget.py:330-356): a new leaf
+// survives iff its target lives and it descends from the new root, i.e. shares the first `jdrop` path entries with the
+// selected leaf.  Survivors of a target are one contiguous DFS range: only (first, count) are recorded.
+__global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
     const int nCh = a.status->n_children;
-    const LayerView& Lc = a.layers[a.scan % a.R];
-    if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
-    __syncthreads();
-    // ---- A: per target: termination test, new root ---------------------------------------------------------
-    for (int t = tid; t < nT; t += PRUNE_THREADS) {
-        const int s = a.sel[t];
-        const double cn = Lc.cnllr[s];
-        const uint8_t fl = Lc.flags[s];
-        const double rootc = a.cur.root_cnllr[t];
-        const bool rf32 = a.cur.root_f32[t] != 0;
-        const bool f32score = (fl & F_SCORE_F32) && rf32;
-        // getScore() (pyTarget.py:124) with NumPy scalar promotion
-        const double score = f32score ? (double)((float)cn - (float)rootc) : cn - rootc;
-        int status = 0;
-        const double px = Lc.x[s], py = Lc.x[(size_t)a.cap + s];
-        if (isfinite(a.radar_range)) {
-            const double dx = px - a.radar_x, dy = py - a.radar_y;
-            if (sqrt(dx * dx + dy * dy) > a.radar_range) status = 1;                 // tracker.py:895
-        }
-        if (!status) {
-            const double per = f32score ? (double)((float)score / (float)(a.Nwin + 1)) : score / (double)(a.Nwin + 1);
-            if (per > a.score_limit) status = 2;                                        // tracker.py:902
-            else if (cn > a.cnllr_limit) status = 3;                                    // tracker.py:908
-        }
-        const int dg = a.cur.depth[t] + 1;        // depth below the root after this scan's growth
-        const int w = a.cur.window[t];
-        const int j = dg > w ? dg - w : 0;        // layers the root advances (pyTarget.pruneDepth, pyTarget.py:343)
-        int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
-        double rc = rootc;
-        uint8_t rf = a.cur.root_f32[t];
-        if (j > 0) {
-            int node = s, sc = a.scan;
-            for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
-            rscan = sc;
-            rnode = node;
-            rc = a.layers[sc % a.R].cnllr[node];
-            rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
-        }
-        a.alive[t] = status == 0;
-        a.jdrop[t] = j;
-        a.n_leaves[t] = 0;
-        mht_target_report& r = a.rec[t];
-        r.id = a.cur.id[t];
-        r.status = status;
-        r.sel_node = s;
-        r.sel_meas = Lc.meas[s];
-        r.root_scan = rscan;
-        r.root_node = rnode;
-        r.sel_x[0] = px; r.sel_x[1] = py; r.sel_x[2] = Lc.x[(size_t)2 * a.cap + s]; r.sel_x[3] = Lc.x[(size_t)3 * a.cap + s];
-        r.sel_cnllr = cn;
-        r.score = score;
-        r.root_cnllr = rc;
-        {
-            const LayerView& Lr = a.layers[rscan % a.R];
-            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
-            r.root_meas = Lr.meas[rnode];
-        }
-        r.cluster = a.t_label[t];
-        // stash what the compaction needs in the record (read back below)
-        r.new_index = -1;
-        r.n_leaves = (int)rf;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- B: compact the target table (np.delete of dead tracks, tracker.py:353-381) ---------------------------
-    int running = 0;
-    for (int base = 0; base < nT; base += PRUNE_THREADS) {
-        const int t = base + tid;
-        const int al = (t < nT) ? a.alive[t] : 0;
-        const int pos = running + block_excl_scan(al, s_scan, &s_total);
-        if (al) {
-            mht_target_report& r = a.rec[t];
-            const int j = a.jdrop[t];
-            a.new_index[t] = pos;
-            r.new_index = pos;
-            a.nxt.id[pos] = a.cur.id[t];
-            a.nxt.window[pos] = a.cur.window[t];
-            a.nxt.depth[pos] = a.cur.depth[t] + 1 - j;
-            a.nxt.shift[pos] = j;
-            a.nxt.root_scan[pos] = r.root_scan;
-            a.nxt.root_node[pos] = r.root_node;
-            a.nxt.root_cnllr[pos] = r.root_cnllr;
-            a.nxt.root_f32[pos] = (uint8_t)r.n_leaves;
-        } else if (t < nT) {
-            a.new_index[t] = -1;
-        }
-        running += s_total;
-        __syncthreads();
-    }
-    const int nAlive = running;
-    __threadfence_block();
-    __syncthreads();
-    // ---- C: surviving children -> next leaf list (keeps DFS order) ---------------------------------------------
-    running = 0;
-    for (int base = 0; base < nCh; base += PRUNE_THREADS) {
-        const int c = base + tid;
-        int sv = 0, t = 0;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x; base < nCh; base += gridDim.x * blockDim.x) {
+        const int c = base + threadIdx.x;
+        int sv = 0, t = -1;
         if (c < nCh) {
             t = a.ctgt[c];
-            sv = a.alive[t];
+            sv = a.t_status[t] == 0;
             if (sv) {
-                const int j = a.jdrop[t], s = a.sel[t];
+                const int j = a.t_jdrop[t], s = a.sel[t];
                 for (int d = 0; d < j; ++d)
                     if (a.path[(size_t)d * a.cap + c] != a.path[(size_t)d * a.cap + s]) { sv = 0; break; }
             }
         }
-        const int pos = running + block_excl_scan(sv, s_scan, &s_total);
-        if (sv) {
-            a.leaf_src_next[pos] = c;
-            a.leaf_tgt_next[pos] = a.new_index[t];
-            atomicAdd(&a.n_leaves[t], 1);
+        // wave-aggregated update: children of one target are contiguous, so most wavefronts see 1-3 targets
+        const int t0 = __shfl(t, 0);
+        const bool uniform = __all(t == t0 || c >= nCh);
+        if (uniform) {
+            const unsigned long long m = __ballot(sv);
+            if (m && lane == (int)(__ffsll((long long)m) - 1)) {
+                atomicAdd(&a.t_count[t], __popcll(m));
+                atomicMin(&a.t_firstsurv[t], c);
+            }
+        } else if (sv) {
+            atomicAdd(&a.t_count[t], 1);
+            atomicMin(&a.t_firstsurv[t], c);
         }
+    }
+}
+
+struct CommitArgs {
+    TTable cur, nxt;
+    const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
+    const double* t_score; const int32_t* t_label;
+    LayerView layers[MAXR]; int R; int scan; int cap;
+    int32_t* new_index;
+    FCounts* cnt; DevStatus* status;
+    int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters;
+    unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
+    ReportHeader* hdr; mht_target_report* rec;
+};
+
+// Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
+// roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
+__global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) {
+    __shared__ int s_scan[PRUNE_THREADS / 64], s_total, s_branched, s_limit, s_itmax;
+    const int tid = threadIdx.x;
+    const int nT = a.cnt->nT;
+    const int nCh = a.status->n_children;
+    const LayerView& Lc = a.layers[a.scan % a.R];
+    if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
+    __syncthreads();
+    int running = 0, lrun = 0;
+    for (int base = 0; base < nT; base += PRUNE_THREADS) {
+        const int t = base + tid;
+        const int al = (t < nT) ? (a.t_status[t] == 0) : 0;
+        const int cntl = al ? a.t_count[t] : 0;
+        const int pos = running + block_excl_scan(al, s_scan, &s_total);
         running += s_total;
         __syncthreads();
+        const int lpos = lrun + block_excl_scan(cntl, s_scan, &s_total);
+        lrun += s_total;
+        __syncthreads();
+        if (t < nT) {
+            const int s = a.sel[t];
+            const int j = a.t_jdrop[t];
+            const int dg = a.cur.depth[t] + 1;
+            int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
+            double rc = a.cur.root_cnllr[t];
+            uint8_t rf = a.cur.root_f32[t];
+            if (al && j > 0) {       // walk from the selected leaf up to the new root (pyTarget.py:343-356)
+                int node = s, sc = a.scan;
+                for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
+                rscan = sc;
+                rnode = node;
+                rc = a.layers[sc % a.R].cnllr[node];
+                rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
+            }
+            mht_target_report& r = a.rec[t];
+            r.id = a.cur.id[t];
+            r.status = a.t_status[t];
+            r.sel_node = s;
+            r.sel_meas = Lc.meas[s];
+            r.new_index = al ? pos : -1;
+            r.root_scan = rscan;
+            r.root_node = rnode;
+            r.n_leaves = cntl;
+            for (int k = 0; k < 4; ++k) r.sel_x[k] = Lc.x[(size_t)k * a.cap + s];
+            r.sel_cnllr = Lc.cnllr[s];
+            r.score = a.t_score[t];
+            r.root_cnllr = rc;
+            const LayerView& Lr = a.layers[rscan % a.R];
+            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
+            r.root_meas = Lr.meas[rnode];
+            r.cluster = a.t_label[t];
+            a.new_index[t] = al ? pos : -1;
+            if (al) {
+                a.nxt.id[pos] = a.cur.id[t];
+                a.nxt.window[pos] = a.cur.window[t];
+                a.nxt.depth[pos] = dg - j;
+                a.nxt.shift[pos] = j;
+                a.nxt.root_scan[pos] = rscan;
+                a.nxt.root_node[pos] = rnode;
+                a.nxt.root_cnllr[pos] = rc;
+                a.nxt.root_f32[pos] = rf;
+                a.nxt.first[pos] = a.t_firstsurv[t];
+                a.nxt.leaf_off[pos] = lpos;
+            }
+        }
     }
-    const int Lnext = running;
-    __threadfence_block();
-    __syncthreads();
-    for (int t = tid; t < nT; t += PRUNE_THREADS) a.rec[t].n_leaves = a.n_leaves[t];
-    // ---- D: ILP statistics, counters, report header ---------------------------------------------------------------
+    const int nAlive = running, Lnext = lrun;
+    // ILP statistics
     const int nC = a.cl_counts[0];
     for (int c = tid; c < nC; c += PRUNE_THREADS) {
         const int st = a.cl_status[c];
@@ -214,13 +198,23 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_kernel(const PruneArgs a)
         if (st == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
         if (st) atomicMax(&s_itmax, a.cl_iters[c]);
     }
+    // used-measurement bytes -> bit mask of the report; bytes cleared for the next scan
+    for (int w = tid; w < a.W; w += PRUNE_THREADS) {
+        unsigned long long bits = 0ull;
+        for (int b = 0; b < 64; ++b) {
+            const int jm = w * 64 + b;
+            if (jm < a.M && a.used_bytes[jm]) { bits |= 1ull << b; a.used_bytes[jm] = 0; }
+        }
+        a.used_words[w] = bits;
+    }
     __syncthreads();
     if (tid == 0) {
+        a.nxt.leaf_off[nAlive] = Lnext;
         ReportHeader& h = *a.hdr;
         h.scan = a.scan;
         h.n_targets = nT;
         h.n_alive = nAlive;
-        h.n_leaves_in = a.cnt->L;
+        h.n_leaves_in = a.cur.leaf_off[nT];
         h.n_children = nCh;
         h.n_leaves_out = Lnext;
         h.n_clusters = nC;
@@ -230,13 +224,15 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_kernel(const PruneArgs a)
         h.blp_iters_max = s_itmax;
         h.error = (a.status->overflow || a.cnt->overflow || a.cl_counts[3]) ? MHT_E_CAPACITY : 0;
         h.used_words = a.W;
-        a.cnt->L_in = a.cnt->L;
+        a.cnt->L_in = a.cur.leaf_off[nT];
         a.cnt->n_children = nCh;
         a.cnt->nT = nAlive;
         a.cnt->L = Lnext;
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;
         if (a.status->overflow) a.cnt->overflow = 1;
+        a.status->overflow = 0;      // per-scan status word is consumed here (no memset between scans)
+        a.status->n_children = 0;
     }
 }
 
@@ -245,83 +241,103 @@ struct AddArgs {
     int n; const double* x0; const float* P0; const uint8_t* flags; const double* pd; const int32_t* meas;
     int check; double thr;
     mht_nodes layer;     // newest layer
-    TTable tab; int32_t* leaf_src; int32_t* leaf_tgt; int32_t* path; int PD;
+    TTable tab; int32_t* path; int PD;
     FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
-    uint8_t* accepted; int32_t* ids;
+    uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
 };
 
-__global__ __launch_bounds__(256) void add_targets_kernel(const AddArgs a) {
-    __shared__ int s_near;
+// Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates.  The test against the existing leaves
+// (pyTarget.haveNoNeightbours, pyTarget.py:181-189) runs for all candidates in one parallel sweep; the candidates are
+// then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
+__global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
     const int tid = threadIdx.x;
-    for (int q = 0; q < a.n; ++q) {
-        if (tid == 0) s_near = 0;
-        __syncthreads();
-        const int L = a.cnt->L;
-        const double cx = a.x0[q * 4], cy = a.x0[q * 4 + 1];
-        if (a.check) {
-            int near = 0;
-            for (int i = tid; i < L; i += 256) {          // pyTarget.haveNoNeightbours (pyTarget.py:181-189)
-                const int nd = a.leaf_src[i];
-                const double dx = a.layer.x[nd] - cx, dy = a.layer.x[(size_t)a.layer.cap + nd] - cy;
-                if (sqrt(dx * dx + dy * dy) < a.thr) near = 1;
+    const int nT0 = a.cnt->nT, L0 = a.cnt->L;
+    for (int q = tid; q < a.n; q += 1024) a.near[q] = 0;
+    __syncthreads();
+    if (a.check) {
+        for (int i = tid; i < L0; i += 1024) {
+            // leaf i -> node: linear scan over targets is avoided by walking the ranges: (first, leaf_off) lookup
+            int lo = 0, hi = nT0;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
+            const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
+            const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
+            for (int q = 0; q < a.n; ++q) {
+                const double dx = lx - a.x0[q * 4], dy = ly - a.x0[q * 4 + 1];
+                if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
             }
-            if (near) s_near = 1;
         }
-        __syncthreads();
-        const int ok = !s_near && a.cnt->nT < a.Tcap && a.cnt->n_nodes < a.layer.cap && a.cnt->L < a.layer.cap;
-        if (!s_near && !ok && tid == 0) a.cnt->overflow = 1;
-        if (ok && tid == 0) {
-            const int idx = a.cnt->n_nodes, r = a.cnt->n_roots, t = a.cnt->nT;
-            const size_t cap = a.layer.cap;
-            for (int k = 0; k < 4; ++k) a.layer.x[k * cap + idx] = a.x0[q * 4 + k];
-            a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
-            a.layer.pd[idx] = a.pd[q];
-            a.layer.parent[idx] = -1;
-            a.layer.meas[idx] = a.meas[q];
-            a.layer.cov[idx] = a.cov_base + r;
-            a.layer.flags[idx] = a.flags[q];
-            for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
-            for (int d = 0; d < a.PD; ++d) a.path[(size_t)d * cap + idx] = -1;
-            a.leaf_src[L] = idx;
-            a.leaf_tgt[L] = t;
-            a.tab.id[t] = a.cnt->id_counter;
-            a.tab.window[t] = a.Nwin;
-            a.tab.depth[t] = 0;
-            a.tab.shift[t] = 0;
-            a.tab.root_scan[t] = a.scan;
-            a.tab.root_node[t] = idx;
-            a.tab.root_cnllr[t] = 0.0;
-            a.tab.root_f32[t] = (a.flags[q] & F_SCORE_F32) ? 1 : 0;
-            if (a.ids) a.ids[q] = a.cnt->id_counter;
-            a.cnt->id_counter += 1;
-            a.cnt->n_nodes = idx + 1;
-            a.cnt->n_roots = r + 1;
-            a.cnt->nT = t + 1;
-            a.cnt->L = L + 1;
-        } else if (tid == 0 && a.ids) {
-            a.ids[q] = -1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 0; q < a.n; ++q) {
+            int near = a.near[q];
+            if (a.check && !near) {           // against the candidates admitted in this call
+                const int r0 = a.cnt->n_roots;
+                for (int t = nT0; t < a.cnt->nT && !near; ++t) {
+                    const int nd = a.tab.first[t];
+                    const double dx = a.layer.x[nd] - a.x0[q * 4], dy = a.layer.x[(size_t)a.layer.cap + nd] - a.x0[q * 4 + 1];
+                    if (sqrt(dx * dx + dy * dy) < a.thr) near = 1;
+                }
+                (void)r0;
+            }
+            const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_nodes < a.layer.cap;
+            if (!near && !ok) a.cnt->overflow = 1;
+            if (ok) {
+                const int idx = a.cnt->n_nodes, r = a.cnt->n_roots, t = a.cnt->nT, L = a.cnt->L;
+                const size_t cap = a.layer.cap;
+                for (int k = 0; k < 4; ++k) a.layer.x[k * cap + idx] = a.x0[q * 4 + k];
+                a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
+                a.layer.pd[idx] = a.pd[q];
+                a.layer.parent[idx] = -1;
+                a.layer.meas[idx] = a.meas[q];
+                a.layer.cov[idx] = a.cov_base + r;
+                a.layer.flags[idx] = a.flags[q];
+                for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
+                for (int d = 0; d < a.PD; ++d) a.path[(size_t)d * cap + idx] = -1;
+                a.tab.id[t] = a.cnt->id_counter;
+                a.tab.window[t] = a.Nwin;
+                a.tab.depth[t] = 0;
+                a.tab.shift[t] = 0;
+                a.tab.root_scan[t] = a.scan;
+                a.tab.root_node[t] = idx;
+                a.tab.root_cnllr[t] = 0.0;
+                a.tab.root_f32[t] = (a.flags[q] & F_SCORE_F32) ? 1 : 0;
+                a.tab.first[t] = idx;
+                a.tab.leaf_off[t] = L;
+                a.tab.leaf_off[t + 1] = L + 1;
+                if (a.ids) a.ids[q] = a.cnt->id_counter;
+                a.cnt->id_counter += 1;
+                a.cnt->n_nodes = idx + 1;
+                a.cnt->n_roots = r + 1;
+                a.cnt->nT = t + 1;
+                a.cnt->L = L + 1;
+            } else if (a.ids) {
+                a.ids[q] = -1;
+            }
+            if (a.accepted) a.accepted[q] = (uint8_t)ok;
         }
-        if (tid == 0 && a.accepted) a.accepted[q] = (uint8_t)ok;
-        __threadfence_block();
-        __syncthreads();
     }
 }
 
 struct LeavesArgs {
-    mht_nodes layer; const int32_t* leaf_src; const int32_t* leaf_tgt; const int32_t* t_id; const FCounts* cnt;
+    mht_nodes layer; TTable tab; const FCounts* cnt;
     int capacity; double* x; float* P; double* cnllr; int32_t* meas; int32_t* target; int32_t* id; int32_t* node; uint8_t* flags;
 };
 __global__ void leaves_kernel(const LeavesArgs a) {
+    const int nT = a.cnt->nT;
     const int L = a.cnt->L < a.capacity ? a.cnt->L : a.capacity;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
-        const int nd = a.leaf_src[i], t = a.leaf_tgt[i];
+        int lo = 0, hi = nT;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
+        const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
         for (int k = 0; k < 4; ++k) a.x[i * 4 + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
         const int c = a.layer.cov[nd];
         for (int e = 0; e < 16; ++e) a.P[i * 16 + e] = a.layer.P[(size_t)e * a.layer.cap_cov + c];
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
-        a.id[i] = a.t_id[t];
+        a.id[i] = a.tab.id[t];
         a.node[i] = nd;
         a.flags[i] = a.layer.flags[nd];
     }
@@ -363,15 +379,14 @@ struct Forest {
     int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap;
     Arena arena;
     mht_nodes layer[MAXR];
-    int32_t* path[2]; int32_t* leafpos; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
-    int32_t* leaf_src[2]; int32_t* leaf_tgt[2];
+    int32_t* path[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
     TTable tab[2];
-    unsigned long long* assoc; unsigned long long* used;
+    unsigned long long* assoc; unsigned char* used_bytes;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes;
-    int32_t *alive, *jdrop, *new_index, *n_leaves;
+    int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     FCounts* cnt;
     char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off;
     float* z_dev; float* z_host;
@@ -391,15 +406,15 @@ struct Forest {
         }
         for (int b = 0; b < 2; ++b) {
             path[b] = ar.take<int32_t>((size_t)PD * Ncap);
-            leaf_src[b] = ar.take<int32_t>(Ncap); leaf_tgt[b] = ar.take<int32_t>(Ncap);
             TTable& t = tab[b];
             t.id = ar.take<int32_t>(Tcap); t.window = ar.take<int32_t>(Tcap); t.depth = ar.take<int32_t>(Tcap);
             t.shift = ar.take<int32_t>(Tcap); t.root_scan = ar.take<int32_t>(Tcap); t.root_node = ar.take<int32_t>(Tcap);
             t.root_cnllr = ar.take<double>(Tcap); t.root_f32 = ar.take<uint8_t>(Tcap);
+            t.first = ar.take<int32_t>(Tcap); t.leaf_off = ar.take<int32_t>((size_t)Tcap + 1);
         }
-        leafpos = ar.take<int32_t>(Ncap); ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
+        ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
         child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
-        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used = ar.take<unsigned long long>(Mpad / 64);
+        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes = ar.take<unsigned char>(Mpad);
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
@@ -410,7 +425,8 @@ struct Forest {
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
         sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap);
-        alive = ar.take<int32_t>(Tcap); jdrop = ar.take<int32_t>(Tcap); new_index = ar.take<int32_t>(Tcap); n_leaves = ar.take<int32_t>(Tcap);
+        t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
+        new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         cnt = ar.take<FCounts>(1);
         report_dev = ar.take<char>(report_bytes);
         z_dev = ar.take<float>((size_t)2 * Mpad);
@@ -517,10 +533,12 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
     const int nb = (f->scan + 1) & 1;
     a.layer = f->layer[f->scan % f->R];
-    a.tab = f->tab[nb]; a.leaf_src = f->leaf_src[nb]; a.leaf_tgt = f->leaf_tgt[nb];
+    a.tab = f->tab[nb];
     a.path = f->path[f->scan & 1]; a.PD = f->PD;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
-    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+    a.near = f->near;
+    MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
+    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
     f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
@@ -578,10 +596,8 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         ev = f->evp[f->ev_slot];
         f->ev_slot = (f->ev_slot + 1) % EV_POOL;
     }
-    MHT_HIP_CHECK(hipMemsetAsync(f->assoc, 0, (size_t)f->nT_ub * f->AW * 8, st));
-    MHT_HIP_CHECK(hipMemsetAsync(f->used, 0, (size_t)(f->Mpad / 64) * 8, st));
-    MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), st));
-    MHT_HIP_CHECK(hipMemsetAsync(f->cl_counts, 0, 8 * sizeof(int32_t), st));
+    // No memsets between scans: the association bitsets are cleared by the cluster kernel while it reads them, the
+    // status word and the used-measurement bytes by the commit kernel, the cluster counters by the cluster kernel.
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[0], st));
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     GateArgs g = {};
@@ -590,13 +606,14 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     const mht_nodes& out = f->layer[s % f->R];
     g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
     g.cap_in = in.cap; g.capc_in = in.cap_cov;
-    g.leaf_src = f->leaf_src[cb]; g.L_dev = &f->cnt->L; g.L = 0;
+    g.leaf_src = nullptr; g.L_dev = nullptr; g.L = 0;
+    g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
     g.z = z; g.M = M; g.W = W;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
     g.oflags = out.flags; g.oP = out.P; g.cap_out = out.cap; g.capc_out = out.cap_cov;
-    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = f->used;
-    g.leaf_tgt = f->leaf_tgt[cb]; g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
-    g.out_path = f->path[s & 1]; g.out_leafpos = f->leafpos; g.out_tgt = f->ctgt;
+    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = nullptr; g.used_bytes = f->used_bytes;
+    g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
+    g.out_path = f->path[s & 1]; g.out_tgt = f->ctgt;
     g.assoc = f->assoc; g.assoc_words = f->AW; g.PD = f->PD; g.cur_slot_base = (s % f->R) * f->Mpad;
     g.tchild = f->tchild; g.ocost = f->cost; g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
     g.Nwin = f->cfg.n_scan;
@@ -606,13 +623,13 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
-    c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes;
+    c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
     if (rc) return rc;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[2], st));
-    // ---- 3: global hypothesis per cluster (tracker.py:225-237) --------------------------------------------------------
+    // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
     BlpArgs b = {};
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
     b.counts = f->cl_counts; b.tchild = f->tchild; b.cost = f->cost; b.cnllr = out.cnllr;
@@ -622,32 +639,37 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes;
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit;
+    b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
+    b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
+    b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
+    b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
+    b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
     int grid = f->nT_ub / 2 + 8;
     if (grid > 1024) grid = 1024;
     rc = launch_blp(ctx, b, grid);
     if (rc) return rc;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[3], st));
-    // ---- 4: terminate, N-scan prune, compact, report (tracker.py:250-259) ------------------------------------------------
-    PruneArgs p = {};
+    // ---- 4: N-scan prune (tracker.py:256-259): surviving leaf ranges, then target table / roots / report --------------
+    SurviveArgs sv = {f->ctgt, f->sel, f->t_status, f->t_jdrop, f->t_count, f->t_firstsurv, f->path[s & 1], f->Ncap, ctx->status};
+    int sgrid = (f->L_ub > 0 ? 2 * f->L_ub + 255 : 256) / 256;
+    if (sgrid > 512) sgrid = 512;
+    hipLaunchKernelGGL(survive_kernel, dim3(sgrid), dim3(256), 0, st, sv);
+    MHT_HIP_CHECK(hipGetLastError());
+    CommitArgs p = {};
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
-    p.sel = f->sel; p.tchild = f->tchild; p.ctgt = f->ctgt;
+    p.sel = f->sel; p.t_status = f->t_status; p.t_jdrop = f->t_jdrop; p.t_count = f->t_count; p.t_firstsurv = f->t_firstsurv;
+    p.t_score = f->t_score; p.t_label = f->t_label;
     for (int k = 0; k < f->R; ++k) p.layers[k] = view_of(f->layer[k]);
-    p.R = f->R; p.scan = s; p.cap = f->Ncap; p.capc = f->capc;
-    p.path = f->path[s & 1]; p.PD = f->PD;
-    p.leaf_src_next = f->leaf_src[nb]; p.leaf_tgt_next = f->leaf_tgt[nb];
-    p.alive = f->alive; p.jdrop = f->jdrop; p.new_index = f->new_index; p.n_leaves = f->n_leaves;
+    p.R = f->R; p.scan = s; p.cap = f->Ncap;
+    p.new_index = f->new_index;
     p.cnt = f->cnt; p.status = ctx->status;
-    p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.t_label = f->t_label;
+    p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters;
+    p.used_bytes = f->used_bytes; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
     p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
-    p.Nwin = f->cfg.n_scan; p.score_limit = f->cfg.score_limit; p.cnllr_limit = f->cfg.cnllr_limit;
-    p.radar_x = f->cfg.radar_x; p.radar_y = f->cfg.radar_y; p.radar_range = f->cfg.radar_range;
-    p.Tcap = f->Tcap; p.W = W;
-    hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(PRUNE_THREADS), 0, st, p);
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(PRUNE_THREADS), 0, st, p);
     MHT_HIP_CHECK(hipGetLastError());
     if (f->timing) { MHT_HIP_CHECK(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
-    // the used-measurement mask travels with the report
-    MHT_HIP_CHECK(hipMemcpyAsync(f->report_dev + f->used_off, f->used, (size_t)(f->Mpad / 64) * 8, hipMemcpyDeviceToDevice, st));
     f->report_pending = true;
     f->L_ub = f->Ncap;        // unknown until the report is fetched
     return MHT_OK;
@@ -717,7 +739,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     char* d = static_cast<char*>(f->stage_dev.ptr);
     char* h = static_cast<char*>(f->stage_host);
     const int nb = (f->scan + 1) & 1;
-    LeavesArgs a = {f->layer[f->scan % f->R], f->leaf_src[nb], f->leaf_tgt[nb], f->tab[nb].id, f->cnt, n,
+    LeavesArgs a = {f->layer[f->scan % f->R], f->tab[nb], f->cnt, n,
                     (double*)(d + o_x), (float*)(d + o_P), (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
                     (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f)};
     hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);

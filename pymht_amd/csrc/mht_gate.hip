@@ -36,6 +36,17 @@ __device__ __forceinline__ void load_leaf(const GateArgs& a, int src, TS* xs, fl
     for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc_in + c];
 }
 
+// forest mode: position i in the implicit leaf list -> (target slot, node of the previous layer)
+__device__ __forceinline__ void locate_leaf(const int* off, const int32_t* first, int nT, int i, int& tgt, int& src) {
+    int lo = 0, hi = nT;                 // largest t with off[t] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    tgt = lo;
+    src = first[lo] + (i - off[lo]);
+}
+
 __device__ __forceinline__ void box_from_S(const float* S, double eta2, float zhx, float zhy, float& bx, float& by) {
     // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widen for float32 rounding of the
     // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test below decides, this only prunes.
@@ -53,17 +64,22 @@ __global__ __launch_bounds__(GATE_THREADS) void gate_count_kernel(const GateArgs
     LeafGate* lg = reinterpret_cast<LeafGate*>(zy + Mpad);
     unsigned long long* used_l = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);
     int* tile_total = reinterpret_cast<int*>(used_l + W);
+    int* off = tile_total + 4;            // [nT+1] forest mode
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = a.L_dev ? *a.L_dev : a.L;
+    const int nT = a.t_leaf_off ? *a.nT_dev : 0;
+    const int L = a.t_leaf_off ? a.t_leaf_off[nT] : a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     if ((int)blockIdx.x >= ntiles) return;
+    if (a.t_leaf_off)
+        for (int j = tid; j <= nT; j += GATE_THREADS) off[j] = a.t_leaf_off[j];
 
     for (int j = tid; j < Mpad; j += GATE_THREADS) {
         float2 v = (j < M) ? reinterpret_cast<const float2*>(a.z)[j] : make_float2(3.0e38f, 3.0e38f);
         zx[j] = v.x;
         zy[j] = v.y;
     }
+    __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (int w = tid; w < W; w += GATE_THREADS) used_l[w] = 0ull;
         if (tid == 0) *tile_total = 0;
@@ -73,7 +89,8 @@ __global__ __launch_bounds__(GATE_THREADS) void gate_count_kernel(const GateArgs
             LeafGate g;
             g.valid = i < L;
             if (g.valid) {
-                const int src = a.leaf_src ? a.leaf_src[i] : i;
+                int src = a.leaf_src ? a.leaf_src[i] : i, tg_unused;
+                if (a.t_leaf_off) locate_leaf(off, a.t_first, nT, i, tg_unused, src);
                 const uint8_t fl = a.flags[src];
                 float P[16];
                 float Pb[16], Ph[16], S[4];
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(GATE_THREADS) void gate_count_kernel(const GateArgs
 }
 
 template <typename TS>
-__device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src, uint8_t fl, int base, double cn, double pd) {
+__device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src, int tgt, uint8_t fl, int base, double cn, double pd) {
     TS xs[4];
     float P[16];
     load_leaf<TS>(a, src, xs, P);
@@ -169,11 +186,13 @@ __device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src,
     const TS eta2 = (TS)a.model.eta2;
     const size_t cap = a.cap_out;
     // forest extras: path of the parent leaf, shifted by the root advance of its target
-    int tgt = -1, depth = 0, shift = 0;
-    if (a.leaf_tgt) {
-        tgt = a.leaf_tgt[i];
+    int depth = 0, shift = 0;
+    int ppath[MAXPD];
+    if (tgt >= 0) {
         depth = a.tgt_depth[tgt];
         shift = a.tgt_shift[tgt];
+#pragma unroll
+        for (int d = 0; d < MAXPD; ++d) ppath[d] = (d < depth) ? a.in_path[(size_t)(d + shift) * a.cap_in + src] : -1;
     }
     double rootc = 0.0;
     bool root_f32 = false;
@@ -193,14 +212,15 @@ __device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src,
         a.oflags[c] = cfl;
         if (a.nllr) a.nllr[c] = inc;
         if (a.out_path) {
-            for (int d = 0; d < a.PD; ++d) {
-                int v = -1;
-                if (d < depth) v = a.in_path[(size_t)(d + shift) * a.cap_in + src];
-                else if (d == depth && meas > 0) v = a.cur_slot_base + meas - 1;
-                a.out_path[(size_t)d * cap + c] = v;
-            }
-            a.out_leafpos[c] = i;
+#pragma unroll
+            for (int d = 0; d < MAXPD; ++d)
+                if (d < a.PD) {
+                    int v = ppath[d];
+                    if (d == depth && meas > 0) v = a.cur_slot_base + meas - 1;
+                    a.out_path[(size_t)d * cap + c] = v;
+                }
             a.out_tgt[c] = tgt;
+            if (meas > 0) a.used_bytes[meas - 1] = 1;
         }
     };
     // missed-detection child (pyTarget.py:319-328)
@@ -246,10 +266,13 @@ __device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src,
     // association bitset of the target: ancestors below the root + everything gated now (tracker.py:255-258)
     if (a.assoc && tgt >= 0) {
         unsigned long long* row = a.assoc + (size_t)tgt * a.assoc_words;
-        for (int d = 0; d < depth; ++d) {
-            const int v = a.in_path[(size_t)(d + shift) * a.cap_in + src];
-            if (v >= 0) atomicOr(&row[v >> 6], 1ull << (v & 63));
-        }
+        // Every tree node with a real measurement is contributed exactly once: by the leaf reached from it through
+        // missed detections only, i.e. each leaf contributes the LAST real measurement on its path.
+        int last = -1;
+#pragma unroll
+        for (int d = 0; d < MAXPD; ++d)
+            if (d < depth && ppath[d] >= 0) last = ppath[d];
+        if (last >= 0) atomicOr(&row[last >> 6], 1ull << (last & 63));
         for (int w = 0; w < a.W; ++w) {
             const unsigned long long bits = a.hitmask[(size_t)i * a.W + w];
             if (bits) {
@@ -261,8 +284,15 @@ __device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src,
 }
 
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* off = reinterpret_cast<int*>(smem);
     const int lane = threadIdx.x;
-    const int L = a.L_dev ? *a.L_dev : a.L;
+    const int nT = a.t_leaf_off ? *a.nT_dev : 0;
+    const int L = a.t_leaf_off ? a.t_leaf_off[nT] : a.L;
+    if (a.t_leaf_off) {
+        for (int j = lane; j <= nT; j += EMIT_THREADS) off[j] = a.t_leaf_off[j];
+        __syncthreads();
+    }
     const int nblocks = (L + EMIT_THREADS - 1) / EMIT_THREADS;
     for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int i = blk * EMIT_THREADS + lane;
@@ -288,16 +318,16 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
                 a.status->n_children = total;
                 if (total > a.cap_out) a.status->overflow = 1;
             }
-            if (a.tchild) {
-                const int tg = a.leaf_tgt[i];
-                if (i == 0 || a.leaf_tgt[i - 1] != tg) a.tchild[tg] = base;
+            int src = a.leaf_src ? a.leaf_src[i] : i, tg = -1;
+            if (a.t_leaf_off) {
+                locate_leaf(off, a.t_first, nT, i, tg, src);
+                if (i == off[tg]) a.tchild[tg] = base;
                 if (i == L - 1) a.tchild[tg + 1] = base + mine;
             }
-            const int src = a.leaf_src ? a.leaf_src[i] : i;
             const uint8_t fl = a.flags[src];
             const double cn = a.cnllr[src], pd = a.pd[src];
-            if (fl & F_STATE_F32) emit_children<float>(a, i, src, fl, base, cn, pd);
-            else emit_children<double>(a, i, src, fl, base, cn, pd);
+            if (fl & F_STATE_F32) emit_children<float>(a, i, src, tg, fl, base, cn, pd);
+            else emit_children<double>(a, i, src, tg, fl, base, cn, pd);
         }
     }
     if (L == 0 && blockIdx.x == 0 && lane == 0) {
@@ -307,15 +337,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
     }
 }
 
-static inline size_t gate_lds_bytes(int W) {
-    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafGate) + (size_t)W * 8 + 16;
+static inline size_t gate_lds_bytes(int W, int Tcap) {
+    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafGate) + (size_t)W * 8 + 16 + (size_t)(Tcap + 1) * 4;
 }
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const int L = grid_leaves_hint > a.L ? grid_leaves_hint : a.L, W = a.W;
     a.status = ctx->status;
     if (L <= 0) {
-        hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(EMIT_THREADS), 0, ctx->stream, a);
+        hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(EMIT_THREADS), (size_t)((a.t_leaf_off ? a.Tcap : 0) + 1) * 4, ctx->stream, a);
         MHT_HIP_CHECK(hipGetLastError());
         return MHT_OK;
     }
@@ -328,11 +358,12 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     a.cnt = static_cast<int32_t*>(ctx->counts.ptr);
     a.tile_cnt = a.cnt + L;
     a.status = ctx->status;
-    const int gate_blocks = ntiles < 4096 ? ntiles : 4096;
-    hipLaunchKernelGGL(gate_count_kernel, dim3(gate_blocks), dim3(GATE_THREADS), gate_lds_bytes(W), ctx->stream, a);
+    const int Tl = a.t_leaf_off ? a.Tcap : 0;
+    const int gate_blocks = ntiles < 1024 ? ntiles : 1024;
+    hipLaunchKernelGGL(gate_count_kernel, dim3(gate_blocks), dim3(GATE_THREADS), gate_lds_bytes(W, Tl), ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     const int eblocks = (L + EMIT_THREADS - 1) / EMIT_THREADS;
-    hipLaunchKernelGGL(emit_kernel, dim3(eblocks < 4096 ? eblocks : 4096), dim3(EMIT_THREADS), 0, ctx->stream, a);
+    hipLaunchKernelGGL(emit_kernel, dim3(eblocks < 1024 ? eblocks : 1024), dim3(EMIT_THREADS), (size_t)(Tl + 1) * 4, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

@@ -21,14 +21,18 @@ struct GateArgs {
     int cap_out, capc_out;
     int32_t* child_ptr; double* nllr; unsigned long long* used;
     DevStatus* status;
-    // forest extras (null for the stateless seam)
-    const int32_t* leaf_tgt;      // [L] target slot of each leaf
+    // forest extras (null for the stateless seam).  In forest mode the leaves are implicit: target t owns the
+    // nodes t_first[t] .. of the previous layer and the leaf positions t_leaf_off[t] .. t_leaf_off[t+1]-1.
+    const int32_t* t_leaf_off;    // [T+1] exclusive prefix of the leaf counts; L = t_leaf_off[nT]
+    const int32_t* t_first;       // [T] node index of the target's first leaf
+    const int32_t* nT_dev;        // number of targets
+    int Tcap;
     const int32_t* in_path;       // [PD][cap_in] path of measurement-node ids below the root (prev scan children)
     const int32_t* tgt_shift;     // [T] entries dropped from the front of the path (root advance)
     const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
     int32_t* out_path;            // [PD][cap_out]
-    int32_t* out_leafpos;         // [cap_out] leaf-list position of the parent
     int32_t* out_tgt;             // [cap_out] target slot
+    unsigned char* used_bytes;    // [M] forest mode: byte j set iff measurement j was gated (plain stores, no atomics)
     unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window
     int assoc_words; int PD; int cur_slot_base;
     int32_t* tchild;              // [T+1] first child of every target (children of a target are contiguous)
@@ -45,6 +49,7 @@ struct ClusterArgs {
     int Tcap;
     int32_t* edge_t; int32_t* edge_m; int Ecap;
     int n_mnodes;                      // R * Mpad
+    int clear_rows;                    // zero the bitset rows while reading them (forest mode)
     // outputs
     int32_t* t_label;      // [T] smallest member of the component
     int32_t* t_cluster;    // [T] cluster index
@@ -62,13 +67,19 @@ struct BlpArgs {
     const double* cost;             // [cap] f_h
     const double* cnllr;            // [cap] cumulativeNLLR of the children (single-target clusters)
     const int32_t* path; int cap; int PD;
-    double* u; int32_t* usage; int32_t* mark; int n_mnodes;
+    double* u; int32_t* usage; int32_t* mark; int n_mnodes;       // HBM-path scratch, zero on entry and on exit
     // per-member scratch, slot = cl_ptr[c] + c + k  (k = 0..K)
     int32_t* best_h; double* best_rc; int32_t* bb_ch; int32_t* bb_best; double* bb_cost; double* bb_uused;
     double* bb_last_rc; int32_t* bb_last_idx; double* bb_rest; double* bb_min;
     int32_t* sel;                   // [T] out: selected child per target
     int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
     int max_iter; int node_limit;
+    // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
+    // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf
+    const double* x; const uint8_t* flags;        // newest layer (x: [4][cap])
+    const double* t_root_cnllr; const uint8_t* t_root_f32; const int32_t* t_depth; const int32_t* t_window;
+    int32_t* t_alive; int32_t* t_jdrop; int32_t* t_count; int32_t* t_firstsurv; double* t_score;
+    int Nwin; double score_limit, cnllr_limit, radar_x, radar_y, radar_range;
 };
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
