@@ -17,7 +17,9 @@ constexpr int CL_THREADS = 1024;
 constexpr int CL_ELDS = 16384;     // edges kept in LDS (packed target<<16 | node); the rest spills to HBM scratch
 
 __device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArgs& a, int e) {
-    return e < CL_ELDS ? eL[e] : ((unsigned)a.edge_t[e - CL_ELDS] << 16) | (unsigned)a.edge_m[e - CL_ELDS];
+    if (e < CL_ELDS) return eL[e];
+    if (a.edges_in) return a.edges_in[e];
+    return ((unsigned)a.edge_t[e - CL_ELDS] << 16) | (unsigned)a.edge_m[e - CL_ELDS];
 }
 
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
@@ -33,41 +35,50 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
     if (tid == 0) { s_edges = 0; a.counts[3] = 0; }
     __syncthreads();
-    // bitsets -> edge list; the rows are cleared on the way (no memset between scans).  4 independent loads in
-    // flight per thread: the sweep is latency bound otherwise.
-    const long long nwords = (long long)T * a.AW;
+    int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
-    for (long long base = 0; base < nwords; base += 4LL * CL_THREADS) {
-        unsigned long long v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long idx = base + (long long)q * CL_THREADS + tid;
-            v[q] = idx < nwords ? rows[idx] : 0ull;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned long long bits = v[q];
-            if (!bits) continue;
-            const long long idx = base + (long long)q * CL_THREADS + tid;
-            if (a.clear_rows) rows[idx] = 0ull;
-            const int t = (int)(idx / a.AW), w = (int)(idx % a.AW);
-            int pos = atomicAdd(&s_edges, __popcll(bits));
-            while (bits) {
-                const int b = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                const int m = w * 64 + b;
-                if (pos < CL_ELDS) eL[pos] = ((unsigned)t << 16) | (unsigned)m;
-                else if (pos - CL_ELDS < a.Ecap) { a.edge_t[pos - CL_ELDS] = t; a.edge_m[pos - CL_ELDS] = m; }
-                ++pos;
+    if (a.edges_in) {
+        // forest mode: grow_kernel already produced the deduplicated edge list
+        E = *a.edge_count;
+        if (E > a.Ecap) { if (tid == 0) a.counts[3] = 1; E = a.Ecap; }
+        for (int e = tid; e < E && e < CL_ELDS; e += CL_THREADS) eL[e] = a.edges_in[e];
+        __syncthreads();
+    } else {
+        // bitsets -> edge list; the rows are cleared on the way (no memset between scans).  4 independent loads in
+        // flight per thread: the sweep is latency bound otherwise.
+        const long long nwords = (long long)T * a.AW;
+        for (long long base = 0; base < nwords; base += 4LL * CL_THREADS) {
+            unsigned long long v[4];
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long idx = base + (long long)q * CL_THREADS + tid;
+                v[q] = idx < nwords ? rows[idx] : 0ull;
+            }
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned long long bits = v[q];
+                if (!bits) continue;
+                const long long idx = base + (long long)q * CL_THREADS + tid;
+                if (a.clear_rows) rows[idx] = 0ull;
+                const int t = (int)(idx / a.AW), w = (int)(idx % a.AW);
+                int pos = atomicAdd(&s_edges, __popcll(bits));
+                while (bits) {
+                    const int b = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const int m = w * 64 + b;
+                    if (pos < CL_ELDS) eL[pos] = ((unsigned)t << 16) | (unsigned)m;
+                    else if (pos - CL_ELDS < a.Ecap) { a.edge_t[pos - CL_ELDS] = t; a.edge_m[pos - CL_ELDS] = m; }
+                    ++pos;
+                }
             }
         }
-    }
-    __threadfence_block();
-    __syncthreads();
-    int E = s_edges;
-    if (E > CL_ELDS + a.Ecap) {
-        if (tid == 0) a.counts[3] = 1;
-        E = CL_ELDS + a.Ecap;
+        __threadfence_block();
+        __syncthreads();
+        E = s_edges;
+        if (E > CL_ELDS + a.Ecap) {
+            if (tid == 0) a.counts[3] = 1;
+            E = CL_ELDS + a.Ecap;
+        }
     }
     // label propagation
     for (int iter = 0; iter < 4096; ++iter) {
@@ -95,6 +106,13 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         __syncthreads();
         if (!s_changed) break;
         __syncthreads();
+    }
+    if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back
+        for (int e = tid; e < E; e += CL_THREADS) {
+            const unsigned pk = cl_edge(eL, a, e);
+            rows[(size_t)(pk >> 16) * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
+        }
+        if (tid == 0) { *a.edge_count = 0; *a.ticket_reset = 0; }
     }
     // heads -> cluster indices (exclusive scan over targets, chunked)
     int running = 0;

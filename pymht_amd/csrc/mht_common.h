@@ -39,6 +39,7 @@ struct Scratch {
         bytes = 0;
         size_t want = need + need / 2 + 4096;
         MHT_HIP_CHECK(hipMalloc(&ptr, want));
+        MHT_HIP_CHECK(hipMemset(ptr, 0, want));
         bytes = want;
         return MHT_OK;
     }
@@ -69,8 +70,9 @@ struct Forest;
 struct mht_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    mht::Scratch hitmask;    // [L][W] uint64
-    mht::Scratch counts;     // [L] int32 hits per leaf, then [ntiles] per-tile totals
+    mht::Scratch hitmask;    // stateless seams: look-back tile states / BLP scratch
+    mht::Scratch counts;     // stateless seams: tile ticket / clustering scratch
+    unsigned gate_epoch = 0;
     mht::DevStatus* status = nullptr;   // device
     mht::Forest* forest = nullptr;
 };

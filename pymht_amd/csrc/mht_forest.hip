@@ -199,13 +199,12 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
         if (st) atomicMax(&s_itmax, a.cl_iters[c]);
     }
     // used-measurement bytes -> bit mask of the report; bytes cleared for the next scan
-    for (int w = tid; w < a.W; w += PRUNE_THREADS) {
-        unsigned long long bits = 0ull;
-        for (int b = 0; b < 64; ++b) {
-            const int jm = w * 64 + b;
-            if (jm < a.M && a.used_bytes[jm]) { bits |= 1ull << b; a.used_bytes[jm] = 0; }
-        }
-        a.used_words[w] = bits;
+    for (int base = 0; base < a.W * 64; base += PRUNE_THREADS) {
+        const int jm = base + tid;
+        const int u = (jm < a.M) ? a.used_bytes[jm] : 0;
+        if (u) a.used_bytes[jm] = 0;
+        const unsigned long long bits = __ballot(u != 0);
+        if ((tid & 63) == 0 && jm < a.W * 64) a.used_words[jm >> 6] = bits;
     }
     __syncthreads();
     if (tid == 0) {
@@ -382,6 +381,7 @@ struct Forest {
     int32_t* path[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
     TTable tab[2];
     unsigned long long* assoc; unsigned char* used_bytes;
+    unsigned long long* tile_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
@@ -415,7 +415,9 @@ struct Forest {
         ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
         child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
         assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes = ar.take<unsigned char>(Mpad);
-        edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
+        edge_t = ar.take<int32_t>(64); edge_m = ar.take<int32_t>(64);
+        tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); edges = ar.take<unsigned>(Ecap);
+        edge_count = ar.take<int32_t>(4); ticket = edge_count + 1;
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8);
@@ -606,7 +608,9 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     const mht_nodes& out = f->layer[s % f->R];
     g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
     g.cap_in = in.cap; g.capc_in = in.cap_cov;
-    g.leaf_src = nullptr; g.L_dev = nullptr; g.L = 0;
+    g.leaf_src = nullptr; g.L = 0;
+    g.ticket = f->ticket; g.tile_state = f->tile_state; g.epoch = (unsigned)s;
+    g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->Ecap;
     g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
     g.z = z; g.M = M; g.W = W;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
@@ -624,6 +628,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);

@@ -1,30 +1,39 @@
-// Gate / update / score kernels: the L x M fan-out of every leaf hypothesis against every measurement
-// of a scan (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py, children of pyTarget.py:227-258).
+// grow_kernel: gate / update / score -- the L x M fan-out of every leaf hypothesis against every measurement
+// of a scan and the creation of the child hypotheses, ONE launch per scan
+// (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py; children: pyTarget.py:227-258, :319-328).
 //
-// Two launches per scan:
-//   gate_count_kernel  workgroup = 4 wavefronts, tile of 16 leaves.  Lanes 0..15 run predict+precalc
-//                      (one leaf per lane, SoA loads/stores are coalesced) and stage the gate parameters in
-//                      LDS; then each wavefront takes leaves of the tile and sweeps the scan 64 measurements
-//                      per step (scan staged in LDS once per workgroup): a cheap conservative float32
-//                      bounding-box test on all lanes, the exact reference-order NIS only on lanes that pass,
-//                      `__ballot` turns the outcome into one 64-bit hit-mask word per step.  No (L,M) tensor
-//                      is ever materialised (the reference builds a 40 MB z_tilde and a 20 MB NIS array).
-//   emit_kernel        one wavefront per 64 leaves, one leaf per lane: exclusive scan of (1 + hits) gives the
-//                      dense, DFS-ordered child index of every leaf; children are written in ascending
-//                      measurement order by walking the hit mask.
-// Matrices are 4x4 / 2x2: registers only, no MFMA; the bound is HBM + launch latency.
+// Workgroup = 4 wavefronts, tile = 16 consecutive leaves (tiles are handed out by an atomic ticket so that a
+// tile's predecessors are always running -- needed by the look-back below).
+//   phase 1  lanes 0..15: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
+//            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
+//            children need (x_bar, K, S^-1, z_hat, score constant) parked in LDS.
+//   phase 2  each wavefront takes leaves of the tile and sweeps the scan 64 measurements per step (scan staged in
+//            LDS once per workgroup): a cheap conservative float32 bounding-box test on all lanes, the exact
+//            reference-order NIS only on lanes that pass; `__ballot` turns the outcome into one 64-bit hit-mask word
+//            per step.  No (L,M) tensor is ever materialised (the reference builds a 40 MB z_tilde + a 20 MB NIS).
+//   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the
+//            number of children of ALL earlier leaves: single-pass decoupled look-back over per-tile
+//            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences).
+//   phase 4  one thread per child: k-th set bit of the hit mask -> measurement, x_hat = x_bar + K z_tilde,
+//            NLLR, cumulative score, ILP cost, root->leaf measurement path, target association bit + deduplicated
+//            (target, measurement-node) edge for the clustering kernel.  Consecutive threads write consecutive
+//            children: all SoA stores are coalesced.
+// The bound is HBM traffic + launch/dependency latency; the kernel moves
+// 280 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
 #include "mht_kernels.h"
 
 namespace mht {
 
-
-struct LeafGate {        // per-leaf gate parameters staged in LDS
+struct LeafLds {          // per-leaf results of phase 1/2 parked in LDS for phase 4
+    double xbar[4];
     double zhat[2];
+    double cn, pd;
+    float K[8];
     float sinv[4];
-    float bx, by;        // conservative half-widths of the gate's bounding box
-    float zhx, zhy;      // float32 copy of z_hat for the pre-filter
-    int f32state;
-    int valid;
+    float lnc, bx, by, zhx, zhy;
+    int src, tgt, cnt, base, depth, last_real;
+    int ppath[MAXPD];
+    unsigned char flags, f32state, valid, first_of_target;
 };
 
 template <typename TS>
@@ -49,108 +58,229 @@ __device__ __forceinline__ void locate_leaf(const int* off, const int32_t* first
 
 __device__ __forceinline__ void box_from_S(const float* S, double eta2, float zhx, float zhy, float& bx, float& by) {
     // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widen for float32 rounding of the
-    // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test below decides, this only prunes.
+    // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test decides, this only prunes.
     float rx = sqrtf((float)eta2 * fabsf(S[0])), ry = sqrtf((float)eta2 * fabsf(S[3]));
     bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;
     by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
 }
 
-__global__ __launch_bounds__(GATE_THREADS) void gate_count_kernel(const GateArgs a) {
+template <typename TS>
+__device__ __forceinline__ void phase1_leaf(const GateArgs& a, int i, int src, LeafLds& g) {
+    TS xs[4];
+    float P[16];
+    load_leaf<TS>(a, src, xs, P);
+    Predicted<TS> p;
+    predict_precalc<TS>(a.model, xs, P, p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.xbar[k] = (double)p.x_bar[k];
+    g.zhat[0] = (double)p.z_hat[0];
+    g.zhat[1] = (double)p.z_hat[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g.K[e] = p.K[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g.sinv[e] = p.S_inv[e];
+    g.lnc = nllr_const(p.S, a.model.lambda_ex, g.pd);
+    g.zhx = (float)g.zhat[0];
+    g.zhy = (float)g.zhat[1];
+    box_from_S(p.S, a.model.eta2, g.zhx, g.zhy, g.bx, g.by);
+    if (2 * i + 1 < a.capc_out) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            a.oP[(size_t)e * a.capc_out + 2 * i] = p.P_bar[e];
+            a.oP[(size_t)e * a.capc_out + 2 * i + 1] = p.P_hat[e];
+        }
+    } else {
+        a.status->overflow = 1;
+    }
+}
+
+// tile state word: [63:40] epoch (scan), [33:32] flag (1 = aggregate, 2 = inclusive prefix), [31:0] value
+__device__ __forceinline__ unsigned long long pack_state(unsigned epoch, unsigned flag, unsigned value) {
+    return ((unsigned long long)(epoch & 0xffffffu) << 40) | ((unsigned long long)flag << 32) | value;
+}
+
+template <typename TS>
+__device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, int i, int c, int k,
+                                           const unsigned long long* hw, const float2* z2, int& new_edge_node) {
+    const size_t cap = a.cap_out;
+    const uint8_t fl = g.flags;
+    int meas = 0, covcol = 2 * i;
+    double cnl, inc;
+    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
+    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = g.xbar[q];
+        inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
+        cnl = g.cn + inc;
+    } else {                 // (k-1)-th gated measurement in ascending index (pyTarget.py:242-254)
+        int need = k - 1, w = 0;
+        unsigned long long bits = hw[0];
+        while (true) {
+            const int pc = __popcll(bits);
+            if (need < pc) break;
+            need -= pc;
+            bits = hw[++w];
+        }
+        for (int q = 0; q < need; ++q) bits &= bits - 1;
+        const int j = w * 64 + __ffsll((long long)bits) - 1;
+        meas = j + 1;
+        covcol = 2 * i + 1;
+        const float2 m = z2[j];
+        TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
+        TS zt[2], nis, xh[4];
+        gate_pair<TS>(zh, g.sinv, m.x, m.y, (TS)a.model.eta2, zt, nis);
+        update_state<TS>(xb, g.K, zt, xh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = (double)xh[q];
+        const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19
+        inc = (double)tinc;
+        if (sizeof(TS) == 4 && (fl & F_SCORE_F32)) {          // float32 + float32 stays float32 (NumPy scalar rules)
+            cnl = (double)((float)g.cn + (float)tinc);
+            cfl |= F_SCORE_F32;
+        } else {
+            cnl = g.cn + inc;
+        }
+    }
+    a.ocnllr[c] = cnl;
+    a.opd[c] = g.pd;
+    a.oparent[c] = g.src;
+    a.omeas[c] = meas;
+    a.ocov[c] = covcol;
+    a.oflags[c] = cfl;
+    if (a.nllr) a.nllr[c] = inc;
+    if (a.out_path) {
+        const int tgt = g.tgt;
+        const double rootc = a.t_root_cnllr[tgt];
+        // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and
+        // float32 / int stay float32
+        if ((cfl & F_SCORE_F32) && a.t_root_f32[tgt]) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
+        else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
+#pragma unroll
+        for (int d = 0; d < MAXPD; ++d)
+            if (d < a.PD) {
+                int v = g.ppath[d];
+                if (d == g.depth && meas > 0) v = a.cur_slot_base + meas - 1;
+                a.out_path[(size_t)d * cap + c] = v;
+            }
+        a.out_tgt[c] = tgt;
+        // association of the target (tracker.py:255-258 / pyTarget.getMeasurementSet): the new measurement of a hit
+        // child; the miss child contributes the LAST real measurement on the parent's path (every tree node with a
+        // real measurement is contributed exactly once: by the leaf reached from it through misses only)
+        int node = -1;
+        if (meas > 0) {
+            node = a.cur_slot_base + meas - 1;
+            a.used_bytes[meas - 1] = 1;
+        } else {
+            node = g.last_real;
+        }
+        if (node >= 0) {
+            unsigned long long* row = a.assoc + (size_t)tgt * a.assoc_words;
+            const unsigned long long bit = 1ull << (node & 63);
+            const unsigned long long old = atomicOr(&row[node >> 6], bit);
+            if (!(old & bit)) new_edge_node = node;
+        }
+    }
+}
+
+__global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = a.M, W = a.W;
     const int Mpad = W * 64;
     float* zx = reinterpret_cast<float*>(smem);
     float* zy = zx + Mpad;
-    LeafGate* lg = reinterpret_cast<LeafGate*>(zy + Mpad);
-    unsigned long long* used_l = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);
-    int* tile_total = reinterpret_cast<int*>(used_l + W);
-    int* off = tile_total + 4;            // [nT+1] forest mode
+    LeafLds* lg = reinterpret_cast<LeafLds*>(zy + Mpad);
+    unsigned long long* hw = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);    // [GATE_TILE][W]
+    int* off = reinterpret_cast<int*>(hw + (size_t)GATE_TILE * W);                      // [nT+1] forest mode
+    __shared__ int s_tile, s_base, s_total, s_pref[GATE_TILE + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.t_leaf_off ? *a.nT_dev : 0;
     const int L = a.t_leaf_off ? a.t_leaf_off[nT] : a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
-    if ((int)blockIdx.x >= ntiles) return;
-    if (a.t_leaf_off)
-        for (int j = tid; j <= nT; j += GATE_THREADS) off[j] = a.t_leaf_off[j];
+    const float2* z2 = reinterpret_cast<const float2*>(a.z);
+    bool staged = false;
 
-    for (int j = tid; j < Mpad; j += GATE_THREADS) {
-        float2 v = (j < M) ? reinterpret_cast<const float2*>(a.z)[j] : make_float2(3.0e38f, 3.0e38f);
-        zx[j] = v.x;
-        zy[j] = v.y;
-    }
-    __syncthreads();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        for (int w = tid; w < W; w += GATE_THREADS) used_l[w] = 0ull;
-        if (tid == 0) *tile_total = 0;
-        // ---- phase 1: predict + precalc, one leaf per lane ------------------------------------------------
-        if (tid < GATE_TILE) {
-            const int i = tile * GATE_TILE + tid;
-            LeafGate g;
-            g.valid = i < L;
-            if (g.valid) {
-                int src = a.leaf_src ? a.leaf_src[i] : i, tg_unused;
-                if (a.t_leaf_off) locate_leaf(off, a.t_first, nT, i, tg_unused, src);
-                const uint8_t fl = a.flags[src];
-                float P[16];
-                float Pb[16], Ph[16], S[4];
-                if (fl & F_STATE_F32) {
-                    float xs[4];
-                    load_leaf<float>(a, src, xs, P);
-                    Predicted<float> p;
-                    predict_precalc<float>(a.model, xs, P, p);
-                    g.zhat[0] = p.z_hat[0]; g.zhat[1] = p.z_hat[1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { g.sinv[e] = p.S_inv[e]; S[e] = p.S[e]; }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { Pb[e] = p.P_bar[e]; Ph[e] = p.P_hat[e]; }
-                    g.f32state = 1;
-                } else {
-                    double xs[4];
-                    load_leaf<double>(a, src, xs, P);
-                    Predicted<double> p;
-                    predict_precalc<double>(a.model, xs, P, p);
-                    g.zhat[0] = p.z_hat[0]; g.zhat[1] = p.z_hat[1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { g.sinv[e] = p.S_inv[e]; S[e] = p.S[e]; }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { Pb[e] = p.P_bar[e]; Ph[e] = p.P_hat[e]; }
-                    g.f32state = 0;
-                }
-                g.zhx = (float)g.zhat[0];
-                g.zhy = (float)g.zhat[1];
-                box_from_S(S, a.model.eta2, g.zhx, g.zhy, g.bx, g.by);
-                if (2 * i + 1 < a.capc_out) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        a.oP[(size_t)e * a.capc_out + 2 * i] = Pb[e];
-                        a.oP[(size_t)e * a.capc_out + 2 * i + 1] = Ph[e];
-                    }
-                } else {
-                    a.status->overflow = 1;
+    while (true) {
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1);
+        __syncthreads();
+        const int tile = s_tile;
+        if (tile >= ntiles) {
+            if (tile == 0) {      // no leaves at all
+                if (tid == 0) {
+                    a.child_ptr[0] = 0;
+                    a.status->n_children = 0;
+                    if (a.tchild) a.tchild[0] = 0;
                 }
             }
-            lg[tid] = g;
+            break;
+        }
+        if (!staged) {
+            for (int j = tid; j < Mpad; j += GATE_THREADS) {
+                const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
+                zx[j] = v.x;
+                zy[j] = v.y;
+            }
+            if (a.t_leaf_off)
+                for (int j = tid; j <= nT; j += GATE_THREADS) off[j] = a.t_leaf_off[j];
+            staged = true;
+            __syncthreads();
+        }
+        // ---- phase 1: predict + precalc, one leaf per lane -----------------------------------------------------
+        if (tid < GATE_TILE) {
+            const int i = tile * GATE_TILE + tid;
+            LeafLds& g = lg[tid];
+            g.valid = i < L;
+            g.cnt = 0;
+            if (g.valid) {
+                int src = a.leaf_src ? a.leaf_src[i] : i, tgt = -1;
+                if (a.t_leaf_off) locate_leaf(off, a.t_first, nT, i, tgt, src);
+                g.src = src;
+                g.tgt = tgt;
+                g.first_of_target = (tgt >= 0 && i == off[tgt]);
+                const uint8_t fl = a.flags[src];
+                g.flags = fl;
+                g.f32state = (fl & F_STATE_F32) ? 1 : 0;
+                g.cn = a.cnllr[src];
+                g.pd = a.pd[src];
+                g.depth = 0;
+                g.last_real = -1;
+                if (tgt >= 0) {
+                    const int depth = a.tgt_depth[tgt], shift = a.tgt_shift[tgt];
+                    g.depth = depth;
+                    int last = -1;
+#pragma unroll
+                    for (int d = 0; d < MAXPD; ++d) {
+                        const int v = (d < depth) ? a.in_path[(size_t)(d + shift) * a.cap_in + src] : -1;
+                        g.ppath[d] = v;
+                        if (v >= 0) last = v;
+                    }
+                    g.last_real = last;
+                }
+                if (g.f32state) phase1_leaf<float>(a, i, src, g);
+                else phase1_leaf<double>(a, i, src, g);
+            }
         }
         __syncthreads();
-        // ---- phase 2: one wavefront per leaf, 64 measurements per step ----------------------------------------
+        // ---- phase 2: one wavefront per leaf, 64 measurements per step -----------------------------------------
         for (int t = wave; t < GATE_TILE; t += GATE_THREADS / 64) {
-            const LeafGate g = lg[t];
+            const LeafLds& g = lg[t];
             if (!g.valid) continue;
-            const int i = tile * GATE_TILE + t;
             unsigned long long myword = 0ull;
             int cnt = 0;
+            const float zhx = g.zhx, zhy = g.zhy, bx = g.bx, by = g.by;
+            const int f32s = g.f32state;
             for (int s = 0; s < W; ++s) {
                 const float mx = zx[s * 64 + lane], my = zy[s * 64 + lane];
-                const bool cand = (fabsf(mx - g.zhx) <= g.bx) && (fabsf(my - g.zhy) <= g.by);
+                const bool cand = (fabsf(mx - zhx) <= bx) && (fabsf(my - zhy) <= by);
                 bool hit = false;
                 if (cand) {
-                    if (g.f32state) {
+                    if (f32s) {
                         float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
                         hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
                     } else {
-                        double zt[2], nis;
-                        hit = gate_pair<double>(g.zhat, g.sinv, mx, my, a.model.eta2, zt, nis);
+                        double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
+                        hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
                     }
                 }
                 const unsigned long long word = __ballot(hit);
@@ -158,212 +288,132 @@ __global__ __launch_bounds__(GATE_THREADS) void gate_count_kernel(const GateArgs
                 cnt += __popcll(word);
             }
             if (lane < W) {
-                a.hitmask[(size_t)i * W + lane] = myword;
-                if (myword) atomicOr(&used_l[lane], myword);
+                hw[(size_t)t * W + lane] = myword;
+                if (a.used && myword) atomicOr(&a.used[lane], myword);      // stateless seam only
             }
+            if (lane == 0) lg[t].cnt = cnt;
+        }
+        __syncthreads();
+        // ---- phase 3: child offsets: in-tile prefix + decoupled look-back across tiles ------------------------------
+        if (wave == 0) {
+            int mine = (lane < GATE_TILE && lg[lane].valid) ? 1 + lg[lane].cnt : 0;
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < GATE_TILE; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane < GATE_TILE) s_pref[lane] = incl - mine;
+            const int total = __shfl(incl, GATE_TILE - 1);
             if (lane == 0) {
-                a.cnt[i] = cnt;
-                atomicAdd(tile_total, cnt);
+                s_pref[GATE_TILE] = total;
+                s_total = total;
+                __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, tile == 0 ? 2u : 1u, (unsigned)total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        __syncthreads();
-        if (tid == 0) a.tile_cnt[tile] = *tile_total;
-        if (a.used)
-            for (int w = tid; w < W; w += GATE_THREADS)
-                if (used_l[w]) atomicOr(&a.used[w], used_l[w]);
-        __syncthreads();
-    }
-}
-
-template <typename TS>
-__device__ __forceinline__ void emit_children(const GateArgs& a, int i, int src, int tgt, uint8_t fl, int base, double cn, double pd) {
-    TS xs[4];
-    float P[16];
-    load_leaf<TS>(a, src, xs, P);
-    Predicted<TS> p;
-    predict_precalc<TS>(a.model, xs, P, p);
-    const float lnc = nllr_const(p.S, a.model.lambda_ex, pd);
-    const TS eta2 = (TS)a.model.eta2;
-    const size_t cap = a.cap_out;
-    // forest extras: path of the parent leaf, shifted by the root advance of its target
-    int depth = 0, shift = 0;
-    int ppath[MAXPD];
-    if (tgt >= 0) {
-        depth = a.tgt_depth[tgt];
-        shift = a.tgt_shift[tgt];
+            int excl = 0;
+            if (tile > 0) {
+                int look = tile - 1;          // lane l inspects tile look - l
+                while (true) {
+                    const int tq = look - lane;
+                    unsigned long long st = 0ull;
+                    if (tq >= 0) st = __hip_atomic_load(&a.tile_state[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool fresh = tq >= 0 && (unsigned)(st >> 40) == (a.epoch & 0xffffffu) && ((st >> 32) & 3u) != 0;
+                    const bool incl_f = fresh && ((st >> 32) & 3u) == 2u;
+                    const unsigned long long ready = __ballot(fresh || tq < 0);
+                    const unsigned long long inclm = __ballot(incl_f);
+                    // usable prefix of lanes: all ready up to (and including) the first inclusive one
+                    int upto = 64;
+                    if (inclm) upto = __ffsll((long long)inclm);           // lanes [0, upto) are needed
+                    const unsigned long long need = upto >= 64 ? ~0ull : ((1ull << upto) - 1ull);
+                    if ((ready & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }
+                    int v = (lane < upto && tq >= 0) ? (int)(st & 0xffffffffu) : 0;
 #pragma unroll
-        for (int d = 0; d < MAXPD; ++d) ppath[d] = (d < depth) ? a.in_path[(size_t)(d + shift) * a.cap_in + src] : -1;
-    }
-    double rootc = 0.0;
-    bool root_f32 = false;
-    if (a.ocost) { rootc = a.t_root_cnllr[tgt]; root_f32 = a.t_root_f32[tgt] != 0; }
-    auto write_common = [&](int c, int meas, int covcol, uint8_t cfl, double cnl, double inc) {
-        if (a.ocost) {
-            // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32
-            // and float32 / int stay float32
-            if ((cfl & F_SCORE_F32) && root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
-            else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
-        }
-        a.ocnllr[c] = cnl;
-        a.opd[c] = pd;
-        a.oparent[c] = src;
-        a.omeas[c] = meas;
-        a.ocov[c] = covcol;
-        a.oflags[c] = cfl;
-        if (a.nllr) a.nllr[c] = inc;
-        if (a.out_path) {
-#pragma unroll
-            for (int d = 0; d < MAXPD; ++d)
-                if (d < a.PD) {
-                    int v = ppath[d];
-                    if (d == depth && meas > 0) v = a.cur_slot_base + meas - 1;
-                    a.out_path[(size_t)d * cap + c] = v;
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    excl += v;
+                    if (inclm || look - 63 <= 0) break;
+                    look -= 64;
                 }
-            a.out_tgt[c] = tgt;
-            if (meas > 0) a.used_bytes[meas - 1] = 1;
-        }
-    };
-    // missed-detection child (pyTarget.py:319-328)
-    {
-        const int c = base;
-        if (c < (int)cap) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.ox[(size_t)k * cap + c] = (double)p.x_bar[k];
-            const double inc = (pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - pd);
-            write_common(c, 0, 2 * i, (uint8_t)(fl & F_STATE_F32), cn + inc, inc);
-        }
-    }
-    // one child per gated measurement, ascending index (pyTarget.py:242-254)
-    int c = base + 1;
-    const float2* z2 = reinterpret_cast<const float2*>(a.z);
-    for (int w = 0; w < a.W; ++w) {
-        unsigned long long bits = a.hitmask[(size_t)i * a.W + w];
-        while (bits) {
-            const int b = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int j = w * 64 + b;
-            if (c < (int)cap) {
-                const float2 m = z2[j];
-                TS zt[2], nis, xh[4];
-                gate_pair<TS>(p.z_hat, p.S_inv, m.x, m.y, eta2, zt, nis);
-                update_state<TS>(p.x_bar, p.K, zt, xh);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a.ox[(size_t)k * cap + c] = (double)xh[k];
-                const TS inc = (TS)0.5 * nis + (TS)lnc;      // kalman.py:19
-                double cnl;
-                uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
-                if (sizeof(TS) == 4 && (fl & F_SCORE_F32)) {   // float32 + float32 stays float32 (NumPy scalar rules)
-                    cnl = (double)((float)cn + (float)inc);
-                    cfl |= F_SCORE_F32;
-                } else {
-                    cnl = cn + (double)inc;
-                }
-                write_common(c, j + 1, 2 * i + 1, cfl, cnl, (double)inc);
+                if (lane == 0)
+                    __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, 2u, (unsigned)(excl + total)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            ++c;
+            if (lane == 0) s_base = excl;
         }
-    }
-    // association bitset of the target: ancestors below the root + everything gated now (tracker.py:255-258)
-    if (a.assoc && tgt >= 0) {
-        unsigned long long* row = a.assoc + (size_t)tgt * a.assoc_words;
-        // Every tree node with a real measurement is contributed exactly once: by the leaf reached from it through
-        // missed detections only, i.e. each leaf contributes the LAST real measurement on its path.
-        int last = -1;
-#pragma unroll
-        for (int d = 0; d < MAXPD; ++d)
-            if (d < depth && ppath[d] >= 0) last = ppath[d];
-        if (last >= 0) atomicOr(&row[last >> 6], 1ull << (last & 63));
-        for (int w = 0; w < a.W; ++w) {
-            const unsigned long long bits = a.hitmask[(size_t)i * a.W + w];
-            if (bits) {
-                // measurement-node ids of this scan start at cur_slot_base (a multiple of 64)
-                atomicOr(&row[(a.cur_slot_base >> 6) + w], bits);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const GateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* off = reinterpret_cast<int*>(smem);
-    const int lane = threadIdx.x;
-    const int nT = a.t_leaf_off ? *a.nT_dev : 0;
-    const int L = a.t_leaf_off ? a.t_leaf_off[nT] : a.L;
-    if (a.t_leaf_off) {
-        for (int j = lane; j <= nT; j += EMIT_THREADS) off[j] = a.t_leaf_off[j];
         __syncthreads();
-    }
-    const int nblocks = (L + EMIT_THREADS - 1) / EMIT_THREADS;
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int i = blk * EMIT_THREADS + lane;
-        // children of all leaves before this block: (#leaves before) + (hits before), hits summed per gate tile
-        const int tiles_before = blk * (EMIT_THREADS / GATE_TILE);
-        int part = 0;
-        for (int t = lane; t < tiles_before; t += 64) part += a.tile_cnt[t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        const int mine = (i < L) ? 1 + a.cnt[i] : 0;
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        const int base = blk * EMIT_THREADS + part + incl - mine;
-        if (i < L) {
-            a.child_ptr[i] = base;
+        const int base = s_base, total = s_total;
+        if (tid < GATE_TILE && lg[tid].valid) {
+            const int i = tile * GATE_TILE + tid;
+            const int cb = base + s_pref[tid];
+            lg[tid].base = cb;
+            a.child_ptr[i] = cb;
+            if (a.tchild && lg[tid].first_of_target) a.tchild[lg[tid].tgt] = cb;
             if (i == L - 1) {
-                const int total = base + mine;
-                a.child_ptr[L] = total;
-                a.status->n_children = total;
-                if (total > a.cap_out) a.status->overflow = 1;
+                const int all = base + total;
+                a.child_ptr[L] = all;
+                a.status->n_children = all;
+                if (all > a.cap_out) a.status->overflow = 1;
+                if (a.tchild) a.tchild[lg[tid].tgt + 1] = all;
             }
-            int src = a.leaf_src ? a.leaf_src[i] : i, tg = -1;
-            if (a.t_leaf_off) {
-                locate_leaf(off, a.t_first, nT, i, tg, src);
-                if (i == off[tg]) a.tchild[tg] = base;
-                if (i == L - 1) a.tchild[tg + 1] = base + mine;
-            }
-            const uint8_t fl = a.flags[src];
-            const double cn = a.cnllr[src], pd = a.pd[src];
-            if (fl & F_STATE_F32) emit_children<float>(a, i, src, tg, fl, base, cn, pd);
-            else emit_children<double>(a, i, src, tg, fl, base, cn, pd);
         }
-    }
-    if (L == 0 && blockIdx.x == 0 && lane == 0) {
-        a.child_ptr[0] = 0;
-        a.status->n_children = 0;
-        if (a.tchild) a.tchild[0] = 0;
+        __syncthreads();
+        // ---- phase 4: one thread per child -----------------------------------------------------------------------------
+        for (int r = tid; r < ((total + 63) & ~63); r += GATE_THREADS) {
+            int new_node = -1, tgt = -1;
+            if (r < total) {
+                int l = 0;
+#pragma unroll
+                for (int q = 1; q < GATE_TILE; ++q) l += (s_pref[q] <= r) ? 1 : 0;     // leaf of child r
+                const LeafLds& g = lg[l];
+                const int k = r - s_pref[l];
+                const int c = base + r;
+                const int i = tile * GATE_TILE + l;
+                tgt = g.tgt;
+                if (c < a.cap_out) {
+                    if (g.f32state) emit_child<float>(a, g, i, c, k, hw + (size_t)l * W, z2, new_node);
+                    else emit_child<double>(a, g, i, c, k, hw + (size_t)l * W, z2, new_node);
+                }
+            }
+            if (a.edges) {          // wave-aggregated append of the new (target, measurement node) edges
+                const unsigned long long m = __ballot(new_node >= 0);
+                if (m) {
+                    int pos = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) pos = atomicAdd(a.edge_count, __popcll(m));
+                    pos = __shfl(pos, leader);
+                    if (new_node >= 0) {
+                        const int my = pos + __popcll(m & ((1ull << lane) - 1ull));
+                        if (my < a.edge_cap) a.edges[my] = ((unsigned)tgt << 16) | (unsigned)new_node;
+                    }
+                }
+            }
+        }
     }
 }
 
-static inline size_t gate_lds_bytes(int W, int Tcap) {
-    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafGate) + (size_t)W * 8 + 16 + (size_t)(Tcap + 1) * 4;
+static inline size_t grow_lds_bytes(int W, int Tcap) {
+    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(Tcap + 1) * 4 + 16;
 }
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const int L = grid_leaves_hint > a.L ? grid_leaves_hint : a.L, W = a.W;
     a.status = ctx->status;
-    if (L <= 0) {
-        hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(EMIT_THREADS), (size_t)((a.t_leaf_off ? a.Tcap : 0) + 1) * 4, ctx->stream, a);
-        MHT_HIP_CHECK(hipGetLastError());
-        return MHT_OK;
-    }
-    const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
-    int rc = ctx->hitmask.ensure((size_t)L * W * 8);
+    int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
+    if (ntiles < 1) ntiles = 1;
+    // tile states: epoch-tagged, never reset.  ticket: reset to zero by whoever consumes the scan (see callers).
+    int rc = ctx->hitmask.ensure(((size_t)ntiles + 8) * 8);
     if (rc) return rc;
-    rc = ctx->counts.ensure(((size_t)L + ntiles + 8) * 4);
-    if (rc) return rc;
-    a.hitmask = static_cast<unsigned long long*>(ctx->hitmask.ptr);
-    a.cnt = static_cast<int32_t*>(ctx->counts.ptr);
-    a.tile_cnt = a.cnt + L;
-    a.status = ctx->status;
+    if (!a.tile_state) a.tile_state = static_cast<unsigned long long*>(ctx->hitmask.ptr);
     const int Tl = a.t_leaf_off ? a.Tcap : 0;
-    const int gate_blocks = ntiles < 1024 ? ntiles : 1024;
-    hipLaunchKernelGGL(gate_count_kernel, dim3(gate_blocks), dim3(GATE_THREADS), gate_lds_bytes(W, Tl), ctx->stream, a);
-    MHT_HIP_CHECK(hipGetLastError());
-    const int eblocks = (L + EMIT_THREADS - 1) / EMIT_THREADS;
-    hipLaunchKernelGGL(emit_kernel, dim3(eblocks < 1024 ? eblocks : 1024), dim3(EMIT_THREADS), (size_t)(Tl + 1) * 4, ctx->stream, a);
+    const int blocks = ntiles < 2048 ? ntiles : 2048;
+    const size_t lds = grow_lds_bytes(W, Tl);
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && lds > attr_bytes) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grow_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(grow_kernel, dim3(blocks), dim3(GATE_THREADS), lds, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
@@ -393,13 +443,19 @@ extern "C" int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nod
     fill_model(a, model);
     a.x = in->x; a.cnllr = in->cnllr; a.pd = in->pd; a.cov = in->cov; a.flags = in->flags; a.P = in->P;
     a.cap_in = in->cap; a.capc_in = in->cap_cov;
-    a.leaf_src = leaf_src; a.L_dev = nullptr; a.L = L;
+    a.leaf_src = leaf_src; a.L = L;
     a.z = z; a.M = M; a.W = (M + 63) / 64;
     a.ox = out->x; a.ocnllr = out->cnllr; a.opd = out->pd; a.oparent = out->parent; a.omeas = out->meas;
     a.ocov = out->cov; a.oflags = out->flags; a.oP = out->P; a.cap_out = out->cap; a.capc_out = out->cap_cov;
     a.child_ptr = child_ptr; a.nllr = nllr; a.used = reinterpret_cast<unsigned long long*>(used);
+    // stateless use: a private ticket + epoch per call
+    a.epoch = ++ctx->gate_epoch;
+    int rc = ctx->counts.ensure(64);
+    if (rc) return rc;
+    a.ticket = static_cast<int32_t*>(ctx->counts.ptr);
+    MHT_HIP_CHECK(hipMemsetAsync(a.ticket, 0, 4, ctx->stream));
     MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), ctx->stream));
-    int rc = launch_gate(ctx, a, L);
+    rc = launch_gate(ctx, a, L);
     if (rc) return rc;
     if (n_children) {
         DevStatus st;

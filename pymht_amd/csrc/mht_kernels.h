@@ -10,12 +10,13 @@ struct GateArgs {
     // input layer
     const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
     int cap_in, capc_in;
-    const int32_t* leaf_src;
-    const int32_t* L_dev;   // optional device-side leaf count
-    int L;
+    const int32_t* leaf_src;      // stateless seam: explicit leaf list (or null = identity)
+    int L;                        // stateless seam: number of leaves
     const float* z; int M; int W;
-    // scratch
-    unsigned long long* hitmask; int32_t* cnt; int32_t* tile_cnt;
+    // cross-workgroup machinery of grow_kernel
+    int32_t* ticket;              // tile ticket counter (zero at launch)
+    unsigned long long* tile_state;   // [ntiles] epoch-tagged look-back words
+    unsigned epoch;
     // output layer
     double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
     int cap_out, capc_out;
@@ -32,14 +33,15 @@ struct GateArgs {
     const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
     int32_t* out_path;            // [PD][cap_out]
     int32_t* out_tgt;             // [cap_out] target slot
-    unsigned char* used_bytes;    // [M] forest mode: byte j set iff measurement j was gated (plain stores, no atomics)
-    unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window
-    int assoc_words; int PD; int cur_slot_base;
+    unsigned char* used_bytes;    // [M] byte j set iff measurement j was gated (plain stores, no atomics)
+    unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window (dedup filter)
+    int assoc_words; int PD; int cur_slot_base;   // measurement-node id of measurement j of this scan = cur_slot_base + j
+    unsigned* edges; int32_t* edge_count; int edge_cap;   // deduplicated (target<<16 | node) edges for the clustering
     int32_t* tchild;              // [T+1] first child of every target (children of a target are contiguous)
     double* ocost;                // [cap_out] ILP cost of every child: getScore()/N (tracker.py:1127)
     const double* t_root_cnllr;   // [T] cumulativeNLLR of the target's root
     const uint8_t* t_root_f32;    // [T] the root score is a float32 value
-    int Nwin;                     // Tracker.N   // measurement-node id of measurement j of this scan = cur_slot_base + j
+    int Nwin;                     // Tracker.N
 };
 
 struct ClusterArgs {
@@ -49,7 +51,10 @@ struct ClusterArgs {
     int Tcap;
     int32_t* edge_t; int32_t* edge_m; int Ecap;
     int n_mnodes;                      // R * Mpad
-    int clear_rows;                    // zero the bitset rows while reading them (forest mode)
+    int clear_rows;                    // zero the bitset rows while reading them
+    const unsigned* edges_in;          // forest mode: deduplicated edge list written by grow_kernel (skips the sweep)
+    int32_t* edge_count;               //   its length; reset to zero here
+    int32_t* ticket_reset;             //   grow_kernel's tile ticket, reset to zero here for the next scan
     // outputs
     int32_t* t_label;      // [T] smallest member of the component
     int32_t* t_cluster;    // [T] cluster index
