@@ -211,6 +211,10 @@ int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, doubl
  * Synchronises the stream. */
 int mht_forest_set_timing(mht_ctx* ctx, int32_t enable);
 int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps);
+/* Tooling: copy a named internal per-cluster array of the last step to the host ("cl_status", "cl_iters",
+ * "cl_nodes", "cl_time" [2 int32 per cluster: setup / total in 10 ns ticks], "cl_ptr", "cl_members", "multi_list",
+ * "cl_counts", "tchild").  Synchronises. */
+int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t bytes);
 /* Ancestor chain of one node: walks parents from (scan, node) towards the root of time, at most max_len steps
  * (bounded by the ring: layers older than n_scan+1 scans are gone).  Outputs host arrays
  * nodes/meas [max_len] int32, x [max_len][4], cnllr [max_len], P [max_len][16]; any may be NULL. */

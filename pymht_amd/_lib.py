@@ -94,6 +94,7 @@ def _declare(lib):
         "mht_forest_report": [vp, C.POINTER(MhtScanReport)],
         "mht_forest_leaves": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_chain": [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)],
+        "mht_forest_debug_read": [vp, C.c_char_p, vp, i64],
         "mht_forest_set_timing": [vp, i32],
         "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5), C.POINTER(i32)],
     }

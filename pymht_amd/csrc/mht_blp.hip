@@ -27,16 +27,35 @@ namespace mht {
 constexpr int BLP_THREADS = 256;
 constexpr int BLP_UW = 512;       // words of the cluster's measurement-node bitset kept in LDS (32768 nodes)
 constexpr double DINF = 1.0e300;
-constexpr int L_MAXH = 3072, L_MAXR = 1024, L_MAXK = 256;
+constexpr int L_MAXH = 2048, L_MAXR = 1024, L_MAXK = 256;
+constexpr int L_KPAD = L_MAXK + 4;   // member tables: (L_MAXK+4) * 4 and * 8 are multiples of 16 bytes
 
 struct Red {
     double d[BLP_THREADS / 64];
+    double q[BLP_THREADS / 64][4];
     int i[BLP_THREADS / 64];
 };
 
+// wave64 sum with DPP row shifts / row broadcasts (a handful of VALU ops instead of 12 LDS-crossbar permutes);
+// fixed summation order -> deterministic.  Result is valid in every lane.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_f64<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_f64<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_f64<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ double block_sum(double v, Red* r) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) r->d[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -55,14 +74,28 @@ __device__ __forceinline__ int block_or(int v, Red* r) {
     for (int w = 0; w < BLP_THREADS / 64; ++w) s |= r->i[w];
     return s;
 }
-// lexicographic (value, index) minimum; index -1 = none
+// lexicographic (value, index) minimum over the wavefront with DPP (index -1 = none); result valid in every lane
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void dpp_min_pair(double& v, int& i) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int ni = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    const double nv = __hiloint2double(nhi, nlo);
+    if (ni >= 0 && (i < 0 || nv < v || (nv == v && ni < i))) { v = nv; i = ni; }
+}
+__device__ __forceinline__ void row16_min_pair(double& v, int& i) {      // lane 15 of every 16-lane row gets the row minimum
+    dpp_min_pair<0x111, 0xf>(v, i);
+    dpp_min_pair<0x112, 0xf>(v, i);
+    dpp_min_pair<0x114, 0xf>(v, i);
+    dpp_min_pair<0x118, 0xf>(v, i);
+}
 __device__ __forceinline__ void wave_min_pair(double& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(i, o);
-        if (oi >= 0 && (i < 0 || ov < v || (ov == v && oi < i))) { v = ov; i = oi; }
-    }
+    row16_min_pair(v, i);
+    dpp_min_pair<0x142, 0xa>(v, i);      // row_bcast:15
+    dpp_min_pair<0x143, 0xc>(v, i);      // row_bcast:31 -> lane 63 holds the minimum
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63), lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    v = __hiloint2double(hi, lo);
+    i = __builtin_amdgcn_readlane(i, 63);
 }
 __device__ __forceinline__ void block_min_pair(double& v, int& i, Red* r) {
     wave_min_pair(v, i);
@@ -105,12 +138,13 @@ struct GStore {      // HBM: column = global child index, row = global measureme
 };
 struct LStore {      // LDS: column = dense local index, row = dense local id
     double* costL; unsigned short* entL; double* uL; int32_t* usageL; int32_t* markL; int32_t* colb; int32_t* gbase;
+    double* rcL; unsigned short* membL; unsigned long long* minkey;   // per-column reduced cost / member, per-member minimum key
     int nH, nR, PD, K;
     int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
     __device__ __forceinline__ int col_begin(int k) const { return colb[k]; }
     __device__ __forceinline__ int col_end(int k) const { return colb[k + 1]; }
     __device__ __forceinline__ double cost(int h) const { return costL[h]; }
-    __device__ __forceinline__ int ent(int d, int h) const { const int e = entL[d * L_MAXH + h]; return e == 0xffff ? -1 : e; }
+    __device__ __forceinline__ int ent(int d, int h) const { const int e = entL[h * 8 + d]; return e == nR ? -1 : e; }
     __device__ __forceinline__ double& u(int m) const { return uL[m]; }
     __device__ __forceinline__ int32_t& usage(int m) const { return usageL[m]; }
     __device__ __forceinline__ int32_t& mark(int m) const { return markL[m]; }
@@ -124,7 +158,10 @@ struct LStore {      // LDS: column = dense local index, row = dense local id
     }
 };
 
-template <typename S> __device__ __forceinline__ double reduced_cost(const S& s, int h) {
+// ---- column operations, generic (HBM policy) and specialised (LDS policy: one 16-byte record per column holds its
+//      <= 8 rows as dense ids, "no row" = the dummy row nR whose price / mark / usage are never non-zero, so all
+//      eight look-ups are unconditional and independent: two LDS round trips instead of 2*PD dependent ones) ----------
+__device__ __forceinline__ double reduced_cost(const GStore& s, int h) {
     double rc = s.cost(h);
     for (int d = 0; d < s.PD; ++d) {
         const int e = s.ent(d, h);
@@ -132,14 +169,14 @@ template <typename S> __device__ __forceinline__ double reduced_cost(const S& s,
     }
     return rc;
 }
-template <typename S> __device__ __forceinline__ bool compatible(const S& s, int h) {
+__device__ __forceinline__ bool compatible(const GStore& s, int h) {
     for (int d = 0; d < s.PD; ++d) {
         const int e = s.ent(d, h);
         if (e >= 0 && s.mark(e)) return false;
     }
     return true;
 }
-template <typename S> __device__ __forceinline__ void set_marks(const S& s, int h, int value) {
+__device__ __forceinline__ void set_marks(const GStore& s, int h, int value) {
     if ((int)threadIdx.x < s.PD) {
         const int e = s.ent(threadIdx.x, h);
         if (e >= 0) s.mark(e) = value;
@@ -147,28 +184,142 @@ template <typename S> __device__ __forceinline__ void set_marks(const S& s, int 
     __threadfence_block();
     __syncthreads();
 }
-template <typename S> __device__ __forceinline__ double priced_sum(const S& s, int h, Red* r) {
-    double v = 0.0;
+__device__ __forceinline__ double priced_part(const GStore& s, int h) {      // this thread's share of sum u over column h
     if ((int)threadIdx.x < s.PD) {
         const int e = s.ent(threadIdx.x, h);
-        if (e >= 0) v = s.u(e);
+        if (e >= 0) return s.u(e);
     }
-    return block_sum(v, r);
+    return 0.0;
+}
+__device__ __forceinline__ void add_usage(const GStore& s, int k, int d) {
+    const int e = s.ent(d, s.best_h[k]);
+    if (e >= 0) atomicAdd(&s.usage(e), 1);
 }
 
-// greedy dive: targets in cluster order, each takes its cheapest (reduced cost) column compatible with the
-// columns already taken.  Always feasible: every target owns an all-miss column without measurements.
-template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
-    double total = 0.0;
-    for (int k = 0; k < K; ++k) {
+struct Rows8 { unsigned short e[8]; };
+__device__ __forceinline__ Rows8 rows_of(const LStore& s, int h) {
+    const uint4 v = reinterpret_cast<const uint4*>(s.entL)[h];
+    Rows8 r;
+    r.e[0] = v.x & 0xffff; r.e[1] = v.x >> 16; r.e[2] = v.y & 0xffff; r.e[3] = v.y >> 16;
+    r.e[4] = v.z & 0xffff; r.e[5] = v.z >> 16; r.e[6] = v.w & 0xffff; r.e[7] = v.w >> 16;
+    return r;
+}
+__device__ __forceinline__ double reduced_cost(const LStore& s, int h) {
+    const Rows8 r = rows_of(s, h);
+    const double c = s.costL[h];
+    const double u0 = s.uL[r.e[0]], u1 = s.uL[r.e[1]], u2 = s.uL[r.e[2]], u3 = s.uL[r.e[3]];
+    const double u4 = s.uL[r.e[4]], u5 = s.uL[r.e[5]], u6 = s.uL[r.e[6]], u7 = s.uL[r.e[7]];
+    return ((((((((c + u0) + u1) + u2) + u3) + u4) + u5) + u6) + u7);
+}
+__device__ __forceinline__ bool compatible(const LStore& s, int h) {
+    const Rows8 r = rows_of(s, h);
+    const int m = s.markL[r.e[0]] | s.markL[r.e[1]] | s.markL[r.e[2]] | s.markL[r.e[3]] | s.markL[r.e[4]] | s.markL[r.e[5]] |
+                  s.markL[r.e[6]] | s.markL[r.e[7]];
+    return m == 0;
+}
+__device__ __forceinline__ void set_marks(const LStore& s, int h, int value) {
+    if (threadIdx.x < 8) {
+        const int e = s.entL[h * 8 + threadIdx.x];
+        if (e != s.nR) s.markL[e] = value;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double priced_part(const LStore& s, int h) {
+    return threadIdx.x < 8 ? s.uL[s.entL[h * 8 + threadIdx.x]] : 0.0;
+}
+__device__ __forceinline__ void add_usage(const LStore& s, int k, int d) {
+    const int e = s.entL[s.best_h[k] * 8 + d];
+    if (e != s.nR) atomicAdd(&s.usageL[e], 1);
+}
+template <typename S> __device__ __forceinline__ double priced_sum(const S& s, int h, Red* r) {
+    return block_sum(priced_part(s, h), r);
+}
+
+// per target the minimiser of the reduced cost (lowest column wins ties) -> best_h[k], best_rc[k]
+__device__ __forceinline__ void compute_minimisers(const GStore& s, int K, Red* r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += BLP_THREADS / 64) {
         double bv = DINF;
         int bi = -1;
-        for (int h = s.col_begin(k) + threadIdx.x; h < s.col_end(k); h += BLP_THREADS) {
-            if (!compatible(s, h)) continue;
+        for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
             const double rc = reduced_cost(s, h);
             if (bi < 0 || rc < bv) { bv = rc; bi = h; }
         }
-        block_min_pair(bv, bi, r);
+        wave_min_pair(bv, bi);
+        if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+__device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* r) {
+    // pass 1: one thread per column -> reduced cost in LDS; pass 2: 16 lanes per target scan its columns and reduce
+    // with four DPP row shifts (no atomics, no LDS-crossbar permutes)
+    for (int h = threadIdx.x; h < s.nH; h += BLP_THREADS) s.rcL[h] = reduced_cost(s, h);
+    __syncthreads();
+    const int row = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    for (int k = row; k < K; k += BLP_THREADS / 16) {
+        double bv = DINF;
+        int bi = -1;
+        for (int h = s.colb[k] + l16; h < s.colb[k + 1]; h += 16) {
+            const double rc = s.rcL[h];
+            if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+        }
+        row16_min_pair(bv, bi);
+        if (l16 == 15) { s.best_h[k] = bi; s.best_rc[k] = bv; }
+    }
+    __syncthreads();
+}
+
+// cheapest column of member k among those compatible with the marks (if need_compat) and lexicographically after
+// (prc, pix); returns (DINF, -1) if none.  Uniform result in every thread.
+__device__ __forceinline__ void argmin_member(const GStore& s, int k, bool need_compat, double prc, int pix, double& bv, int& bi, Red* r) {
+    bv = DINF;
+    bi = -1;
+    for (int h = s.col_begin(k) + threadIdx.x; h < s.col_end(k); h += BLP_THREADS) {
+        if (need_compat && !compatible(s, h)) continue;
+        const double rc = reduced_cost(s, h);
+        if (rc < prc || (rc == prc && h <= pix)) continue;
+        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+    }
+    block_min_pair(bv, bi, r);
+}
+__device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_compat, double prc, int pix, double& bv, int& bi, Red* r) {
+    bv = DINF;
+    bi = -1;
+    for (int h = s.col_begin(k) + threadIdx.x; h < s.col_end(k); h += BLP_THREADS) {
+        if (need_compat && !compatible(s, h)) continue;
+        const double rc = reduced_cost(s, h);
+        if (rc < prc || (rc == prc && h <= pix)) continue;
+        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+    }
+    block_min_pair(bv, bi, r);
+}
+
+// visiting order of the dive: targets by ascending minimal reduced cost (ties by index); identity for the HBM policy
+__device__ __forceinline__ int dive_member(const GStore& s, int K, int pos) { return pos; }
+__device__ __forceinline__ int dive_member(const LStore& s, int K, int pos) { return s.lix[pos]; }
+__device__ __forceinline__ void dive_order(const GStore& s, int K) {}
+__device__ __forceinline__ void dive_order(const LStore& s, int K) {      // rank sort of K <= 256 keys, one thread per target
+    for (int k = threadIdx.x; k < K; k += BLP_THREADS) {
+        const double v = s.best_rc[k];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) {
+            const double w = s.best_rc[j];
+            rank += (w < v || (w == v && j < k)) ? 1 : 0;
+        }
+        s.lix[rank] = k;
+    }
+    __syncthreads();
+}
+
+template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
+    double total = 0.0;
+    dive_order(s, K);
+    for (int pos = 0; pos < K; ++pos) {
+        const int k = dive_member(s, K, pos);
+        double bv;
+        int bi;
+        argmin_member(s, k, true, -DINF, -1, bv, bi, r);
         if (threadIdx.x == 0) out_sel[k] = bi;
         total += s.cost(bi);
         set_marks(s, bi, 1);
@@ -178,34 +329,24 @@ template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* 
 }
 
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
-template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes) {
+template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
     int stall = 0;
     status = 0; iters = 0; nodes = 0;
     for (int it = 0; it <= a.max_iter; ++it) {
         iters = it;
-        // A: per target the minimiser of the reduced cost (one wavefront per target, lowest index wins ties)
-        for (int k = wave; k < K; k += BLP_THREADS / 64) {
-            double bv = DINF;
-            int bi = -1;
-            for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
-                const double rc = reduced_cost(s, h);
-                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
-            }
-            wave_min_pair(bv, bi);
-            if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
-        }
-        __threadfence_block();
-        __syncthreads();
+        // A: per target the minimiser of the reduced cost (lowest column index wins ties)
+        compute_minimisers(s, K, r);
+        if (it == 0) stamp[1] = wall_clock64();
         // B: how often each measurement node is used by the minimisers
         for (int idx = tid; idx < K * s.PD; idx += BLP_THREADS) {
             const int k = idx / s.PD, d = idx - k * s.PD;
-            const int e = s.ent(d, s.best_h[k]);
-            if (e >= 0) atomicAdd(&s.usage(e), 1);
+            add_usage(s, k, d);
         }
         __threadfence_block();
         __syncthreads();
+        if (it == 0) stamp[2] = wall_clock64();
         // C: subgradient, dual value, certificate
         double nrm = 0.0, usum = 0.0;
         int conflict = 0, slack = 0;
@@ -221,12 +362,21 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         });
         double src = 0.0, sc = 0.0;
         for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
-        nrm = block_sum(nrm, r);
-        utot = block_sum(usum, r);
-        src = block_sum(src, r);
-        sc = block_sum(sc, r);
-        conflict = block_or(conflict, r);
-        slack = block_or(slack, r);
+        {   // one fused block reduction for the six quantities
+            const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
+            int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
+            __syncthreads();
+            if (lane == 0) { r->q[wave][0] = v0; r->q[wave][1] = v1; r->q[wave][2] = v2; r->q[wave][3] = v3; r->i[wave] = f; }
+            __syncthreads();
+            nrm = 0.0; utot = 0.0; src = 0.0; sc = 0.0; f = 0;
+#pragma unroll
+            for (int w = 0; w < BLP_THREADS / 64; ++w) {
+                nrm += r->q[w][0]; utot += r->q[w][1]; src += r->q[w][2]; sc += r->q[w][3]; f |= r->i[w];
+            }
+            conflict = f & 1;
+            slack = (f >> 1) & 1;
+        }
+        if (it == 0) stamp[3] = wall_clock64();
         const double LB = src - utot;
         if (!conflict && sc < UB) {
             UB = sc;
@@ -239,7 +389,7 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         if (!done) {
             if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
             else if (++stall >= 10) { theta *= 0.5; stall = 0; }
-            if (UB >= DINF || (conflict && (it % 8) == 0)) {
+            if (UB >= DINF || (conflict && (it % 4) == 0)) {
                 const double g = greedy_dive(s, K, s.ch, r);
                 if (g < UB) {
                     UB = g;
@@ -335,17 +485,9 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
             enter = false;
         }
         // next candidate of target `level` in increasing (reduced cost, index) order
-        const double prc = s.lrc[level];
-        const int pix = s.lix[level];
-        double bv = DINF;
-        int bi = -1;
-        for (int h = s.col_begin(level) + tid; h < s.col_end(level); h += BLP_THREADS) {
-            if (!compatible(s, h)) continue;
-            const double rc = reduced_cost(s, h);
-            if (rc < prc || (rc == prc && h <= pix)) continue;
-            if (bi < 0 || rc < bv) { bv = rc; bi = h; }
-        }
-        block_min_pair(bv, bi, r);
+        double bv;
+        int bi;
+        argmin_member(s, level, true, s.lrc[level], s.lix[level], bv, bi, r);
         if (bi < 0 || s.cst[level] + bv + s.rest[level] - (utot - s.uus[level]) >= UB - eps) {
             if (level == 0) break;
             --level;
@@ -400,20 +542,94 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
     const int32_t* mem = a.cl_members + a.cl_ptr[c];
     const int slot = a.cl_ptr[c] + c;
     const int UW = (a.n_mnodes + 63) >> 6;
-    __shared__ int s_wbase[BLP_UW];
-    __shared__ int s_nR;
-    // ---- measurement nodes of the cluster (union of the rows of its columns) -----------------------------------
+    const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = clock64();
+    // LDS carve: every block below is a multiple of 16 bytes and the dynamic segment starts at offset 0 (the kernel has
+    // no static __shared__), so the 16-byte column records stay aligned without integer round trips -- those would
+    // make the compiler lose the LDS address space and emit slow flat accesses.
+    LStore s;
+    unsigned char* q = lds;
+    int* s_wbase = reinterpret_cast<int*>(q); q += (size_t)BLP_UW * 4;
+    int* s_scal = reinterpret_cast<int*>(q); q += 16;
+    int& s_nR = s_scal[0];
+    int& s_nH = s_scal[1];
+    s.entL = reinterpret_cast<unsigned short*>(q); q += (size_t)L_MAXH * 16;
+    s.costL = reinterpret_cast<double*>(q); q += (size_t)L_MAXH * 8;
+    s.rcL = reinterpret_cast<double*>(q); q += (size_t)L_MAXH * 8;
+    s.uL = reinterpret_cast<double*>(q); q += (size_t)L_MAXR * 8;
+    s.minkey = reinterpret_cast<unsigned long long*>(q); q += (size_t)L_KPAD * 8;
+    s.best_rc = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.cst = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.uus = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.lrc = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.rest = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.mn = reinterpret_cast<double*>(q); q += (size_t)L_KPAD * 8;
+    s.usageL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
+    s.markL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
+    s.colb = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.gbase = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.best_h = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.ub_sel = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.ch = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.lix = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
+    s.membL = reinterpret_cast<unsigned short*>(q); q += (size_t)L_MAXH * 2;
+    const bool small_k = K <= L_MAXK;
     for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
-    __syncthreads();
-    int nH = 0;
-    for (int k = 0; k < K; ++k) {
-        const int t = mem[k];
-        nH += a.tchild[t + 1] - a.tchild[t];
-        for (int d = 0; d < a.PD; ++d)
-            for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
-                const int e = a.path[(size_t)d * a.cap + h];
-                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+    // column ranges of the members: one global round trip, then a wave scan
+    if (small_k) {
+        if (tid < 64) {
+            int carry = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int k = base + tid;
+                int gb = 0, n = 0;
+                if (k < K) { const int t = mem[k]; gb = a.tchild[t]; n = a.tchild[t + 1] - gb; }
+                int incl = n;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (tid >= o) incl += v;
+                }
+                if (k < K) { s.colb[k] = carry + incl - n; s.gbase[k] = gb; }
+                carry += __shfl(incl, 63);
             }
+            if (tid == 0) { s.colb[K] = carry; s_nH = carry; }
+        }
+    } else if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < K; ++k) acc += a.tchild[mem[k] + 1] - a.tchild[mem[k]];
+        s_nH = acc;
+    }
+    __syncthreads();
+    const int nH = s_nH;
+    const bool lds_cols = small_k && nH <= L_MAXH && a.PD <= 8;
+    s.nH = nH; s.PD = a.PD; s.K = K;
+    // ---- measurement nodes of the cluster (union of the rows of its columns); in the LDS case the columns are
+    //      copied in the same sweep: every thread issues the PD+1 loads of a column back to back (one round trip)
+    if (lds_cols) {
+        for (int h = tid; h < nH; h += BLP_THREADS) {
+            int lo = 0, hi = K;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= h) lo = mid; else hi = mid; }
+            const int g = s.gbase[lo] + (h - s.colb[lo]);
+            s.membL[h] = (unsigned short)lo;
+            s.costL[h] = a.cost[g];
+            int ev[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) ev[d] = (d < a.PD) ? a.path[(size_t)d * a.cap + g] : -1;      // all loads in flight
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                s.entL[h * 8 + d] = (unsigned short)(ev[d] < 0 ? 0xffff : ev[d]);     // global node id for now
+                if (ev[d] >= 0) atomicOr(&uw[ev[d] >> 6], 1ull << (ev[d] & 63));
+            }
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int t = mem[k];
+            for (int d = 0; d < a.PD; ++d)
+                for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
+                    const int e = a.path[(size_t)d * a.cap + h];
+                    if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+                }
+        }
     }
     __syncthreads();
     if (tid < 64) {       // exclusive prefix of the popcounts: dense local row ids
@@ -435,49 +651,26 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
     __syncthreads();
     const int nR = s_nR;
     int status, iters, nodes;
-    if (nH <= L_MAXH && nR <= L_MAXR && K <= L_MAXK && a.PD <= 8) {
-        // ---- LDS-resident solve ------------------------------------------------------------------------------
-        LStore s;
-        unsigned char* q = lds;
-        s.costL = reinterpret_cast<double*>(q); q += (size_t)L_MAXH * 8;
-        s.uL = reinterpret_cast<double*>(q); q += (size_t)L_MAXR * 8;
-        s.best_rc = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.cst = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.uus = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.lrc = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.rest = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.mn = reinterpret_cast<double*>(q); q += (size_t)(L_MAXK + 1) * 8;
-        s.usageL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
-        s.markL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXR * 4;
-        s.colb = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.gbase = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.best_h = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.ub_sel = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.ch = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.lix = reinterpret_cast<int32_t*>(q); q += (size_t)(L_MAXK + 1) * 4;
-        s.entL = reinterpret_cast<unsigned short*>(q);
-        s.nH = nH; s.nR = nR; s.PD = a.PD; s.K = K;
-        if (tid == 0) {
-            int acc = 0;
-            for (int k = 0; k < K; ++k) { s.colb[k] = acc; s.gbase[k] = a.tchild[mem[k]]; acc += a.tchild[mem[k] + 1] - a.tchild[mem[k]]; }
-            s.colb[K] = acc;
-        }
-        for (int m = tid; m < nR; m += BLP_THREADS) { s.uL[m] = 0.0; s.usageL[m] = 0; s.markL[m] = 0; }
-        __syncthreads();
-        for (int k = 0; k < K; ++k) {
-            const int gb = s.gbase[k], lb = s.colb[k], n = s.colb[k + 1] - lb;
-            for (int j = tid; j < n; j += BLP_THREADS) {
-                s.costL[lb + j] = a.cost[gb + j];
-                for (int d = 0; d < a.PD; ++d) {
-                    const int e = a.path[(size_t)d * a.cap + gb + j];
-                    unsigned short v = 0xffff;
-                    if (e >= 0) v = (unsigned short)(s_wbase[e >> 6] + __popcll(uw[e >> 6] & ((1ull << (e & 63)) - 1ull)));
-                    s.entL[d * L_MAXH + lb + j] = v;
-                }
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long t_setup = wall_clock64();
+    if (lds_cols && nR < L_MAXR) {
+        // ---- LDS-resident solve: global node ids -> dense local row ids (LDS only) --------------------------------
+        s.nR = nR;
+        for (int m = tid; m <= nR; m += BLP_THREADS) { s.uL[m] = 0.0; s.usageL[m] = 0; s.markL[m] = 0; }   // incl. dummy row nR
+        for (int h = tid; h < nH; h += BLP_THREADS) {       // one 16-byte record per thread: 8 independent rank look-ups
+            const Rows8 g8 = rows_of(s, h);
+            unsigned o[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const unsigned e = g8.e[d];
+                o[d] = (e == 0xffffu) ? (unsigned)nR
+                                      : (unsigned)(s_wbase[e >> 6] + __popcll(uw[e >> 6] & ((1ull << (e & 63)) - 1ull)));
             }
+            reinterpret_cast<uint4*>(s.entL)[h] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
         }
         __syncthreads();
-        solve_core(a, s, K, r, status, iters, nodes);
+        solve_core(a, s, K, r, status, iters, nodes, stamp);
+        stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
@@ -485,38 +678,47 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
         }
     } else {
         // ---- same code on HBM scratch ----------------------------------------------------------------------------
-        GStore s;
-        s.a = &a; s.mem = mem; s.uw = uw; s.UW = UW; s.PD = a.PD; s.cap = (size_t)a.cap;
-        s.best_h = a.best_h + slot; s.best_rc = a.best_rc + slot; s.ub_sel = a.bb_best + slot; s.ch = a.bb_ch + slot;
-        s.cst = a.bb_cost + slot; s.uus = a.bb_uused + slot; s.lrc = a.bb_last_rc + slot; s.lix = a.bb_last_idx + slot;
-        s.rest = a.bb_rest + slot; s.mn = a.bb_min + slot;
-        s.for_rows([&](int m) { a.u[m] = 0.0; });
+        GStore gs;
+        gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
+        gs.best_h = a.best_h + slot; gs.best_rc = a.best_rc + slot; gs.ub_sel = a.bb_best + slot; gs.ch = a.bb_ch + slot;
+        gs.cst = a.bb_cost + slot; gs.uus = a.bb_uused + slot; gs.lrc = a.bb_last_rc + slot; gs.lix = a.bb_last_idx + slot;
+        gs.rest = a.bb_rest + slot; gs.mn = a.bb_min + slot;
+        gs.for_rows([&](int m) { a.u[m] = 0.0; });
         __threadfence_block();
         __syncthreads();
-        solve_core(a, s, K, r, status, iters, nodes);
+        solve_core(a, gs, K, r, status, iters, nodes, stamp);
+        stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
-            a.sel[mem[k]] = s.ub_sel[k];
-            finish_target(a, mem[k], s.ub_sel[k]);
+            a.sel[mem[k]] = gs.ub_sel[k];
+            finish_target(a, mem[k], gs.ub_sel[k]);
         }
     }
     if (tid == 0) {
         a.cl_status[c] = status;
         a.cl_iters[c] = iters;
         a.cl_nodes[c] = nodes;
+        if (a.cl_time) {
+            a.cl_time[8 * c] = (int)(t_setup - t_begin);
+            a.cl_time[8 * c + 1] = (int)(wall_clock64() - t_begin);
+            for (int q = 1; q <= 4; ++q) a.cl_time[8 * c + 1 + q] = (int)(stamp[q] - t_begin);
+            a.cl_time[8 * c + 6] = (int)(clock64() - c_begin);
+        }
     }
     __threadfence_block();
     __syncthreads();
 }
 
-constexpr size_t BLP_LDS_BYTES = (size_t)L_MAXH * 8 + (size_t)L_MAXR * 8 + 6 * (size_t)(L_MAXK + 1) * 8 + 2 * (size_t)L_MAXR * 4 +
-                                 6 * (size_t)(L_MAXK + 1) * 4 + (size_t)8 * L_MAXH * 2 + 64;
+static_assert(sizeof(Red) <= 256, "Red must fit its LDS slot");
+constexpr size_t BLP_LDS_BYTES = (size_t)BLP_UW * 8 + 256 + (size_t)BLP_UW * 4 + 16 + (size_t)L_MAXH * 16 + (size_t)L_MAXH * 8 * 2 +
+                                 (size_t)L_MAXR * 8 + 7 * (size_t)L_KPAD * 8 + 2 * (size_t)L_MAXR * 4 + 6 * (size_t)L_KPAD * 4 +
+                                 (size_t)L_MAXH * 2;
 
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ unsigned long long uw[BLP_UW];
-    __shared__ Red red;
+    unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [BLP_UW]
+    Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to 256
     const int nMulti = a.counts[1], nSingle = a.counts[2];
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, &red, lds);
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)BLP_UW * 8 + 256);
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);

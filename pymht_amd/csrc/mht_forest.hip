@@ -381,11 +381,11 @@ struct Forest {
     int32_t* path[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
     TTable tab[2];
     unsigned long long* assoc; unsigned char* used_bytes;
-    unsigned long long* tile_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
+    unsigned long long* tile_state; unsigned long long* group_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
-    int32_t *sel, *cl_status, *cl_iters, *cl_nodes;
+    int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time;
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     FCounts* cnt;
     char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off;
@@ -416,7 +416,8 @@ struct Forest {
         child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
         assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes = ar.take<unsigned char>(Mpad);
         edge_t = ar.take<int32_t>(64); edge_m = ar.take<int32_t>(64);
-        tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); edges = ar.take<unsigned>(Ecap);
+        tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); group_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE / 64 + 8);
+        edges = ar.take<unsigned>(Ecap);
         edge_count = ar.take<int32_t>(4); ticket = edge_count + 1;
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
@@ -426,7 +427,7 @@ struct Forest {
         best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
-        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap);
+        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         cnt = ar.take<FCounts>(1);
@@ -609,7 +610,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
     g.cap_in = in.cap; g.capc_in = in.cap_cov;
     g.leaf_src = nullptr; g.L = 0;
-    g.ticket = f->ticket; g.tile_state = f->tile_state; g.epoch = (unsigned)s;
+    g.ticket = f->ticket; g.tile_state = f->tile_state; g.group_state = f->group_state; g.epoch = (unsigned)s;
     g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->Ecap;
     g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
     g.z = z; g.M = M; g.W = W;
@@ -642,7 +643,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
-    b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes;
+    b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit;
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
@@ -830,5 +831,29 @@ extern "C" int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps
     }
     if (n_steps) *n_steps = n;
     f->timed_steps = 0;
+    return MHT_OK;
+}
+
+// Development / tooling: copy a named internal array of the forest to the host (synchronises).
+extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t bytes) {
+    MHT_REQUIRE(ctx && ctx->forest && name && host && bytes > 0, "mht_forest_debug_read: bad argument");
+    Forest* f = ctx->forest;
+    const void* src = nullptr;
+    size_t avail = 0;
+    const size_t T = f->Tcap;
+    if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
+    else if (!strcmp(name, "cl_iters")) { src = f->cl_iters; avail = T * 4; }
+    else if (!strcmp(name, "cl_nodes")) { src = f->cl_nodes; avail = T * 4; }
+    else if (!strcmp(name, "cl_time")) { src = f->cl_time; avail = 8 * T * 4; }
+    else if (!strcmp(name, "cl_ptr")) { src = f->cl_ptr; avail = (T + 1) * 4; }
+    else if (!strcmp(name, "cl_members")) { src = f->cl_members; avail = T * 4; }
+    else if (!strcmp(name, "multi_list")) { src = f->multi_list; avail = T * 4; }
+    else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
+    else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
+    MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
+    MHT_REQUIRE((size_t)bytes <= avail, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    MHT_HIP_CHECK(hipMemcpyAsync(host, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHT_OK;
 }

@@ -2,8 +2,8 @@
 // of a scan and the creation of the child hypotheses, ONE launch per scan
 // (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py; children: pyTarget.py:227-258, :319-328).
 //
-// Workgroup = 4 wavefronts, tile = 16 consecutive leaves (tiles are handed out by an atomic ticket so that a
-// tile's predecessors are always running -- needed by the look-back below).
+// Workgroup = 4 wavefronts, tile = 16 consecutive leaves (tiles are mapped statically onto a
+// co-resident grid -- see the look-back below).
 //   phase 1  lanes 0..15: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
 //            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
 //            children need (x_bar, K, S^-1, z_hat, score constant) parked in LDS.
@@ -21,6 +21,7 @@
 // The bound is HBM traffic + launch/dependency latency; the kernel moves
 // 280 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
 #include "mht_kernels.h"
+#include <stdlib.h>
 
 namespace mht {
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     LeafLds* lg = reinterpret_cast<LeafLds*>(zy + Mpad);
     unsigned long long* hw = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);    // [GATE_TILE][W]
     int* off = reinterpret_cast<int*>(hw + (size_t)GATE_TILE * W);                      // [nT+1] forest mode
-    __shared__ int s_tile, s_base, s_total, s_pref[GATE_TILE + 1];
+    __shared__ int s_base, s_total, s_pref[GATE_TILE + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.t_leaf_off ? *a.nT_dev : 0;
@@ -200,21 +201,16 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     const float2* z2 = reinterpret_cast<const float2*>(a.z);
     bool staged = false;
 
-    while (true) {
+    // Tiles are mapped statically (tile = blockIdx + k*gridDim, increasing per workgroup).  The launcher keeps the
+    // grid small enough to be fully co-resident, so a workgroup spinning in the look-back only ever waits for tiles
+    // owned by workgroups that are running: no dependence on dispatch order, no shared ticket word to serialise on.
+    if (ntiles == 0 && blockIdx.x == 0 && tid == 0) {      // no leaves at all
+        a.child_ptr[0] = 0;
+        a.status->n_children = 0;
+        if (a.tchild) a.tchild[0] = 0;
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        if (tid == 0) s_tile = atomicAdd(a.ticket, 1);
-        __syncthreads();
-        const int tile = s_tile;
-        if (tile >= ntiles) {
-            if (tile == 0) {      // no leaves at all
-                if (tid == 0) {
-                    a.child_ptr[0] = 0;
-                    a.status->n_children = 0;
-                    if (a.tchild) a.tchild[0] = 0;
-                }
-            }
-            break;
-        }
         if (!staged) {
             for (int j = tid; j < Mpad; j += GATE_THREADS) {
                 const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
@@ -257,44 +253,57 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                     }
                     g.last_real = last;
                 }
-                if (g.f32state) phase1_leaf<float>(a, i, src, g);
-                else phase1_leaf<double>(a, i, src, g);
+                if (!(a.ablate & 8)) {
+                    if (g.f32state) phase1_leaf<float>(a, i, src, g);
+                    else phase1_leaf<double>(a, i, src, g);
+                }
             }
         }
         __syncthreads();
-        // ---- phase 2: one wavefront per leaf, 64 measurements per step -----------------------------------------
-        for (int t = wave; t < GATE_TILE; t += GATE_THREADS / 64) {
-            const LeafLds& g = lg[t];
-            if (!g.valid) continue;
-            unsigned long long myword = 0ull;
-            int cnt = 0;
-            const float zhx = g.zhx, zhy = g.zhy, bx = g.bx, by = g.by;
-            const int f32s = g.f32state;
-            for (int s = 0; s < W; ++s) {
-                const float mx = zx[s * 64 + lane], my = zy[s * 64 + lane];
-                const bool cand = (fabsf(mx - zhx) <= bx) && (fabsf(my - zhy) <= by);
-                bool hit = false;
-                if (cand) {
-                    if (f32s) {
-                        float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
-                        hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
-                    } else {
-                        double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
-                        hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
+        // ---- phase 2: thread = (leaf of the tile, measurement stream): 16 leaves x 16 interleaved streams ----------------
+        // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
+        // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
+        // reference-order NIS and sets its bit in the leaf's hit mask (LDS atomicOr; hits are rare: ~1 per leaf).
+        for (int w = tid; w < GATE_TILE * W; w += GATE_THREADS) hw[w] = 0ull;
+        __syncthreads();
+        if (!(a.ablate & 4)) {
+            const int l = tid & (GATE_TILE - 1), stream = tid / GATE_TILE;
+            const LeafLds& g = lg[l];
+            if (g.valid) {
+                const float zhx = g.zhx, zhy = g.zhy, bx = g.bx, by = g.by;
+                constexpr int NS = GATE_THREADS / GATE_TILE;       // 16 streams
+#pragma unroll 4
+                for (int j = stream; j < Mpad; j += NS) {
+                    const float mx = zx[j], my = zy[j];
+                    if ((fabsf(mx - zhx) <= bx) && (fabsf(my - zhy) <= by)) {
+                        bool hit;
+                        if (g.f32state) {
+                            float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
+                            hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
+                        } else {
+                            double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
+                            hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
+                        }
+                        if (hit) atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
                     }
                 }
-                const unsigned long long word = __ballot(hit);
-                if (lane == s) myword = word;
-                cnt += __popcll(word);
             }
-            if (lane < W) {
-                hw[(size_t)t * W + lane] = myword;
-                if (a.used && myword) atomicOr(&a.used[lane], myword);      // stateless seam only
-            }
-            if (lane == 0) lg[t].cnt = cnt;
         }
         __syncthreads();
-        // ---- phase 3: child offsets: in-tile prefix + decoupled look-back across tiles ------------------------------
+        for (int idx = tid; idx < GATE_TILE * W; idx += GATE_THREADS) {       // hits per leaf; stateless seam: used mask
+            const unsigned long long word = hw[idx];
+            if (word) {
+                atomicAdd(&lg[idx / W].cnt, __popcll(word));
+                if (a.used) atomicOr(&a.used[idx % W], word);
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: child offsets: in-tile prefix + two-level prefix across tiles -------------------------------------
+        // Every tile publishes its child count A[tile]; the last tile of each group of 64 also publishes the group sum
+        // S[group].  A tile's base = sum of S over earlier groups + sum of A over earlier tiles of its own group: two
+        // L2 round trips however many tiles there are (a chained look-back would serialise ~ntiles/64 hops here,
+        // because all tiles arrive at the same time).  Words carry {epoch, value} in one 64-bit agent-scope atomic:
+        // the data is the flag, stale epochs read as "not yet".
         if (wave == 0) {
             int mine = (lane < GATE_TILE && lg[lane].valid) ? 1 + lg[lane].cnt : 0;
             int incl = mine;
@@ -308,37 +317,47 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             if (lane == 0) {
                 s_pref[GATE_TILE] = total;
                 s_total = total;
-                __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, tile == 0 ? 2u : 1u, (unsigned)total),
+                s_base = 0;
+                __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, 1u, (unsigned)total),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            int excl = 0;
-            if (tile > 0) {
-                int look = tile - 1;          // lane l inspects tile look - l
-                while (true) {
-                    const int tq = look - lane;
-                    unsigned long long st = 0ull;
-                    if (tq >= 0) st = __hip_atomic_load(&a.tile_state[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool fresh = tq >= 0 && (unsigned)(st >> 40) == (a.epoch & 0xffffffu) && ((st >> 32) & 3u) != 0;
-                    const bool incl_f = fresh && ((st >> 32) & 3u) == 2u;
-                    const unsigned long long ready = __ballot(fresh || tq < 0);
-                    const unsigned long long inclm = __ballot(incl_f);
-                    // usable prefix of lanes: all ready up to (and including) the first inclusive one
-                    int upto = 64;
-                    if (inclm) upto = __ffsll((long long)inclm);           // lanes [0, upto) are needed
-                    const unsigned long long need = upto >= 64 ? ~0ull : ((1ull << upto) - 1ull);
-                    if ((ready & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }
-                    int v = (lane < upto && tq >= 0) ? (int)(st & 0xffffffffu) : 0;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                    excl += v;
-                    if (inclm || look - 63 <= 0) break;
-                    look -= 64;
+            if ((tile & 63) == 63) {          // group leader: sum of the 64 tiles of the group
+                int v = total;
+                if (lane < 63) {
+                    const int tq = tile - 63 + lane;
+                    unsigned long long st;
+                    do {
+                        st = __hip_atomic_load(&a.tile_state[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) __builtin_amdgcn_s_sleep(1);
+                    } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
+                    v = (int)(st & 0xffffffffu);
+                } else if (lane == 63) {
+                    v = total;
                 }
+                if (lane > 63) v = 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
                 if (lane == 0)
-                    __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, 2u, (unsigned)(excl + total)),
+                    __hip_atomic_store(&a.group_state[tile >> 6], pack_state(a.epoch, 1u, (unsigned)v),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (lane == 0) s_base = excl;
+        }
+        __syncthreads();
+        {
+            const int grp = tile >> 6, r = tile & 63;
+            int acc = 0;
+            for (int q = tid; q < ((a.ablate & 2) ? 0 : grp + r); q += GATE_THREADS) {
+                const unsigned long long* w = (q < grp) ? &a.group_state[q] : &a.tile_state[grp * 64 + (q - grp)];
+                unsigned long long st;
+                do {
+                    st = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) __builtin_amdgcn_s_sleep(1);
+                } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
+                acc += (int)(st & 0xffffffffu);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0 && acc) atomicAdd(&s_base, acc);
         }
         __syncthreads();
         const int base = s_base, total = s_total;
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
         }
         __syncthreads();
         // ---- phase 4: one thread per child -----------------------------------------------------------------------------
-        for (int r = tid; r < ((total + 63) & ~63); r += GATE_THREADS) {
+        for (int r = tid; r < ((a.ablate & 1) ? 0 : ((total + 63) & ~63)); r += GATE_THREADS) {
             int new_node = -1, tgt = -1;
             if (r < total) {
                 int l = 0;
@@ -391,6 +410,9 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     }
 }
 
+// co-residency bound of grow_kernel: <= 4 workgroups (16 wavefronts) per CU by registers (92 VGPRs) and LDS (< 40 KB)
+constexpr int GROW_MAX_BLOCKS = 1024;
+
 static inline size_t grow_lds_bytes(int W, int Tcap) {
     return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(Tcap + 1) * 4 + 16;
 }
@@ -401,11 +423,17 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     if (ntiles < 1) ntiles = 1;
     // tile states: epoch-tagged, never reset.  ticket: reset to zero by whoever consumes the scan (see callers).
-    int rc = ctx->hitmask.ensure(((size_t)ntiles + 8) * 8);
+    int rc = ctx->hitmask.ensure(((size_t)ntiles + ntiles / 64 + 16) * 8);
     if (rc) return rc;
-    if (!a.tile_state) a.tile_state = static_cast<unsigned long long*>(ctx->hitmask.ptr);
+    if (!a.tile_state) {
+        a.tile_state = static_cast<unsigned long long*>(ctx->hitmask.ptr);
+        a.group_state = a.tile_state + ntiles + 4;
+    }
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("MHT_GROW_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     const int Tl = a.t_leaf_off ? a.Tcap : 0;
-    const int blocks = ntiles < 2048 ? ntiles : 2048;
+    const int blocks = ntiles < GROW_MAX_BLOCKS ? ntiles : GROW_MAX_BLOCKS;
     const size_t lds = grow_lds_bytes(W, Tl);
     static size_t attr_bytes = 0;
     if (lds > 48 * 1024 && lds > attr_bytes) {
@@ -448,14 +476,9 @@ extern "C" int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nod
     a.ox = out->x; a.ocnllr = out->cnllr; a.opd = out->pd; a.oparent = out->parent; a.omeas = out->meas;
     a.ocov = out->cov; a.oflags = out->flags; a.oP = out->P; a.cap_out = out->cap; a.capc_out = out->cap_cov;
     a.child_ptr = child_ptr; a.nllr = nllr; a.used = reinterpret_cast<unsigned long long*>(used);
-    // stateless use: a private ticket + epoch per call
-    a.epoch = ++ctx->gate_epoch;
-    int rc = ctx->counts.ensure(64);
-    if (rc) return rc;
-    a.ticket = static_cast<int32_t*>(ctx->counts.ptr);
-    MHT_HIP_CHECK(hipMemsetAsync(a.ticket, 0, 4, ctx->stream));
+    a.epoch = ++ctx->gate_epoch;      // stateless use: a fresh look-back epoch per call
     MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), ctx->stream));
-    rc = launch_gate(ctx, a, L);
+    int rc = launch_gate(ctx, a, L);
     if (rc) return rc;
     if (n_children) {
         DevStatus st;

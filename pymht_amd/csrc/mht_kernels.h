@@ -15,8 +15,10 @@ struct GateArgs {
     const float* z; int M; int W;
     // cross-workgroup machinery of grow_kernel
     int32_t* ticket;              // tile ticket counter (zero at launch)
-    unsigned long long* tile_state;   // [ntiles] epoch-tagged look-back words
+    unsigned long long* tile_state;   // [ntiles] epoch-tagged child counts of the tiles
+    unsigned long long* group_state;  // [ntiles/64] epoch-tagged sums over groups of 64 tiles
     unsigned epoch;
+    int ablate;                   // development only (env MHT_GROW_ABLATE): knock out phases for timing experiments
     // output layer
     double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
     int cap_out, capc_out;
@@ -78,6 +80,7 @@ struct BlpArgs {
     double* bb_last_rc; int32_t* bb_last_idx; double* bb_rest; double* bb_min;
     int32_t* sel;                   // [T] out: selected child per target
     int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
+    int32_t* cl_time;               // [T][2] or null: wall-clock ticks (10 ns) spent in setup / in total, per cluster
     int max_iter; int node_limit;
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
     // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf
