@@ -203,7 +203,8 @@ def main():
     from pymht_amd.utils.scenario import make_config
     W, K = args.warmup, args.steps
     # every rank = its own sensor sector (own targets, own clutter): BASELINE config 4
-    sc = make_config(args.config, seed=5446 + 1000 * rank, n_scans=W + K, centre=(20000.0 * rank, 0.0))
+    from pymht_amd import parallel
+    sc = make_config(args.config, seed=parallel.sector_seed(5446, rank), n_scans=W + K, centre=parallel.sector_centre(rank))
     births, stats, final, api_s, init_s = prepass(sc, local)
 
     # ---- timed replay ---------------------------------------------------------------------------------------------
@@ -222,13 +223,11 @@ def main():
     got = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0]
     same_work = (got == final) and rep.error == 0
     rp.close()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        ok = torch.tensor([1 if same_work else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        same_work = bool(ok.item())
+    elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
+    # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
+    alive = [r for r in recs if int(r["status"]) == 0]
+    picture = parallel.gather_tracks([int(r["id"]) for r in alive], np.array([r["sel_x"] for r in alive]).reshape(-1, 4),
+                                     dist, device="cuda")
 
     # ---- stage times with HIP events on the launch stream (identical replay) ----------------------------------------
     rp = Replay(sc, births, local)
@@ -263,7 +262,7 @@ def main():
         "config": {"workload": "BASELINE configs[2]: 500 targets, ~500 meas/scan, N-scan=5, P_d=0.9, eta2=5.99; "
                                "one independent sector per GPU", "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
-                   "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()),
+                   "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),
                    "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},
