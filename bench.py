@@ -3,7 +3,8 @@
 
 A "step" = one radar scan through steps 1-6 of Tracker.addMeasurementList (grow/gate/score every leaf against
 every measurement, cluster, per-cluster 0-1 ILP, track termination, N-scan pruning) on the device-resident
-hypothesis forest -- five HIP launches, no host round trip.  Workload = BASELINE.json configs[2] (headline):
+hypothesis forest -- six HIP launches (grow, cluster, blp, survive, commit [+ add_targets when tracks are
+born]), no memsets, no host round trip.  Workload = BASELINE.json configs[2] (headline):
 500 targets, ~500 measurements/scan, N-scan = 5, synthetic scans from pymht_amd/utils/scenario.py.
 
 Protocol
@@ -178,8 +179,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg3")
-    ap.add_argument("--cpu-scans", type=int, default=2, help="timed oracle scans for cpu_baseline (0 disables)")
-    ap.add_argument("--cpu-warm", type=int, default=6)
+    ap.add_argument("--cpu-scans", type=int, default=16, help="timed oracle scans for cpu_baseline (0 disables)")
+    ap.add_argument("--cpu-warm", type=int, default=8)
     args = ap.parse_args()
 
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
@@ -271,7 +272,7 @@ def main():
                     "initiator (%.0f %% of that time)" % (100.0 * init_s / api_s),
         "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gate_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "grow stage = gate_count_kernel + emit_kernel (2 launches), HIP events on the ctx stream",
+                     "kernel": "grow_kernel (gate + update + score + child creation, 1 launch), HIP events on the ctx stream",
                      "algorithmic_bytes": b_gate},
     }
     if rank == 0 and world == 1 and args.cpu_scans > 0:
