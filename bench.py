@@ -83,11 +83,16 @@ def prepass(sc, device):
 class Replay:
     """Drives the forest through the raw C ABI with every input resident in HBM."""
 
-    def __init__(self, sc, births, device):
+    def __init__(self, sc, births, device, stream=None):
         from pymht_amd import _lib
         self._lib_mod = _lib
         self.sc = sc
-        self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
+        self.stream = stream
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
+        else:
+            self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
         self.lib, self.h = self.trk._lib, self.trk._ctx.handle
         dev = self.trk._ctx.device
         self.M = [int(z.shape[0]) for z in sc["scans"]]
@@ -176,9 +181,10 @@ def cpu_baseline(sc, n_warm, n_timed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--sectors", type=int, default=4, help="concurrent independent sectors per GPU for the multi_sector figure (0 disables)")
     ap.add_argument("--cpu-scans", type=int, default=16, help="timed oracle scans for cpu_baseline (0 disables)")
     ap.add_argument("--cpu-warm", type=int, default=8)
     args = ap.parse_args()
@@ -250,6 +256,41 @@ def main():
     ms /= K
     rp.close()
 
+    # ---- several independent sectors per GPU, one forest + HIP stream each (BASELINE config 4 on one device) -------
+    multi = None
+    if args.sectors > 1:
+        S = args.sectors
+        Km = min(K, 200)
+        scs, brs = [sc], [births]
+        for q in range(1, S):
+            sq = make_config(args.config, seed=parallel.sector_seed(5446, rank) + 17 * q, n_scans=W + Km,
+                             centre=(parallel.sector_centre(rank)[0], 20000.0 * q))
+            bq, _, _, _, _ = prepass(sq, local)
+            scs.append(sq)
+            brs.append(bq)
+        streams = [torch.cuda.Stream(device=local) for _ in range(S)]
+        rps = [Replay(scs[q], brs[q], local, stream=streams[q]) for q in range(S)]
+        for _ in range(W):
+            for r in rps:
+                r.step()
+        barrier()
+        tm0 = time.perf_counter()
+        for _ in range(Km):
+            for r in rps:
+                r.step()
+        torch.cuda.synchronize()
+        tm1 = time.perf_counter()
+        barrier()
+        okm = True
+        for r in rps:
+            repm, _ = r.report()
+            okm = okm and repm.error == 0
+            r.close()
+        tmulti, okm = parallel.reduce_clock(tm1 - tm0, okm, dist, device="cuda")
+        multi = {"sectors_per_gpu": S, "steps_per_sector": Km, "scans_per_sec": world * S * Km / tmulti,
+                 "ms_per_scan_aggregate": 1e3 * tmulti / (S * Km), "ok": okm,
+                 "note": "independent sectors on separate HIP streams of one GPU (the single-sector path is latency bound)"}
+
     timed = stats[W:W + K]
     Lm, Gm, Mm = float(timed[:, 0].mean()), float(timed[:, 1].mean()), float(timed[:, 2].mean())
     # algorithmic bytes of the grow stage per scan: 280 B per leaf + 48 B per gated pair + 8 B per measurement
@@ -267,6 +308,7 @@ def main():
                    "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},
+        "multi_sector": multi,
         "api_scans_per_sec": len(sc["scans"]) / api_s,
         "api_note": "Tracker.addMeasurementList incl. PCIe copies, per-scan report sync and the host-side M-of-N "
                     "initiator (%.0f %% of that time)" % (100.0 * init_s / api_s),

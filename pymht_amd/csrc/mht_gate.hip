@@ -211,6 +211,8 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
+        unsigned long long ts[7];
+        ts[0] = wall_clock64();
         if (!staged) {
             for (int j = tid; j < Mpad; j += GATE_THREADS) {
                 const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             staged = true;
             __syncthreads();
         }
+        ts[1] = wall_clock64();
         // ---- phase 1: predict + precalc, one leaf per lane -----------------------------------------------------
         if (tid < GATE_TILE) {
             const int i = tile * GATE_TILE + tid;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             }
         }
         __syncthreads();
+        ts[2] = wall_clock64();
         // ---- phase 2: thread = (leaf of the tile, measurement stream): 16 leaves x 16 interleaved streams ----------------
         // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
         // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             }
         }
         __syncthreads();
+        ts[3] = wall_clock64();
         // ---- phase 3: child offsets: in-tile prefix + two-level prefix across tiles -------------------------------------
         // Every tile publishes its child count A[tile]; the last tile of each group of 64 also publishes the group sum
         // S[group].  A tile's base = sum of S over earlier groups + sum of A over earlier tiles of its own group: two
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             if (lane == 0 && acc) atomicAdd(&s_base, acc);
         }
         __syncthreads();
+        ts[4] = wall_clock64();
         const int base = s_base, total = s_total;
         if (tid < GATE_TILE && lg[tid].valid) {
             const int i = tile * GATE_TILE + tid;
@@ -376,6 +382,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             }
         }
         __syncthreads();
+        ts[5] = wall_clock64();
         // ---- phase 4: one thread per child -----------------------------------------------------------------------------
         for (int r = tid; r < ((a.ablate & 1) ? 0 : ((total + 63) & ~63)); r += GATE_THREADS) {
             int new_node = -1, tgt = -1;
@@ -405,6 +412,17 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                         if (my < a.edge_cap) a.edges[my] = ((unsigned)tgt << 16) | (unsigned)new_node;
                     }
                 }
+            }
+        }
+        if (a.dbg) {
+            __syncthreads();
+            if (tid == 0) {
+                ts[6] = wall_clock64();
+                for (int q = 0; q < 6; ++q) {
+                    atomicAdd(&a.dbg[q], ts[q + 1] - ts[q]);
+                    atomicMax(&a.dbg[8 + q], ts[q + 1] - ts[q]);
+                }
+                atomicAdd(&a.dbg[6], 1ull);
             }
         }
     }

@@ -18,6 +18,7 @@ struct GateArgs {
     unsigned long long* tile_state;   // [ntiles] epoch-tagged child counts of the tiles
     unsigned long long* group_state;  // [ntiles/64] epoch-tagged sums over groups of 64 tiles
     unsigned epoch;
+    unsigned long long* dbg;      // development only: [8] summed wall-clock ticks per phase over all tiles, [8..15] max
     int ablate;                   // development only (env MHT_GROW_ABLATE): knock out phases for timing experiments
     // output layer
     double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
