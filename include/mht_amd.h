@@ -134,7 +134,7 @@ typedef struct mht_forest_config {
     int32_t max_nodes;    /* hypotheses per scan layer (children of one scan + roots born in it) */
     int32_t max_meas;     /* measurements per scan (<= 2048) */
     int32_t n_scan;       /* Tracker.N: N-scan window (tracker.py:112-114) */
-    int32_t blp_max_iter; /* dual-ascent steps before branch and bound (default 200 when <= 0) */
+    int32_t blp_max_iter; /* dual-ascent steps before branch and bound (200 when < 0; 0 = branch and bound only) */
     int32_t blp_node_limit; /* branch-and-bound node budget per cluster (default 1<<20 when <= 0) */
     double score_limit;   /* Tracker.scoreUpperLimit  (tracker.py:115) */
     double cnllr_limit;   /* Tracker.clnnrUpperLimit  (tracker.py:116) */

@@ -717,6 +717,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [BLP_UW]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to 256
+    if (a.status && a.status->overflow) return;
     const int nMulti = a.counts[1], nSingle = a.counts[2];
     for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)BLP_UW * 8 + 256);
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)

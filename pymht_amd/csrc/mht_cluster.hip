@@ -30,6 +30,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     unsigned* eL = reinterpret_cast<unsigned*>(mlabel + a.n_mnodes);   // [CL_ELDS]
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_total;
     const int tid = threadIdx.x;
+    if (a.status && a.status->overflow) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
     const int T = *a.nT_dev;
     for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;

@@ -80,6 +80,7 @@ struct SurviveArgs {
 // survives iff its target lives and it descends from the new root, i.e. shares the first `jdrop` path entries with the
 // selected leaf.  Survivors of a target are one contiguous DFS range: only (first, count) are recorded.
 __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
+    if (a.status->overflow) return;
     const int nCh = a.status->n_children;
     const int lane = threadIdx.x & 63;
     for (int base = blockIdx.x * blockDim.x; base < nCh; base += gridDim.x * blockDim.x) {
@@ -127,6 +128,16 @@ struct CommitArgs {
 __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) {
     __shared__ int s_scan[PRUNE_THREADS / 64], s_total, s_branched, s_limit, s_itmax;
     const int tid = threadIdx.x;
+    if (a.status->overflow || a.cnt->overflow) {        // void scan: report the error, leave the forest alone (it must be recreated)
+        if (tid == 0) {
+            ReportHeader& h = *a.hdr;
+            h.scan = a.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[a.cnt->nT];
+            h.n_children = a.status->n_children; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
+            h.blp_iters_max = 0; h.error = MHT_E_CAPACITY; h.used_words = 0;
+            a.cnt->overflow = 1;
+        }
+        return;
+    }
     const int nT = a.cnt->nT;
     const int nCh = a.status->n_children;
     const LayerView& Lc = a.layers[a.scan % a.R];
@@ -394,7 +405,7 @@ struct Forest {
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
-    int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0;
+    int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0; bool dead = false;
     bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
     void layout(Arena& ar) {
@@ -480,7 +491,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     Forest* f = new (std::nothrow) Forest();
     MHT_REQUIRE(f, "mht_forest_create: out of host memory");
     f->cfg = *cfg;
-    if (f->cfg.blp_max_iter <= 0) f->cfg.blp_max_iter = 200;
+    if (f->cfg.blp_max_iter < 0) f->cfg.blp_max_iter = 200;
     if (f->cfg.blp_node_limit <= 0) f->cfg.blp_node_limit = 1 << 20;
     f->model = *model;
     f->Tcap = cfg->max_targets;
@@ -588,6 +599,10 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     Forest* f = ctx->forest;
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
     MHT_REQUIRE(z || M == 0, "mht_forest_step: z is null");
+    if (f->dead) {
+        set_error("mht_forest_step: a pool overflowed in an earlier scan; create a new forest with larger max_nodes / max_targets");
+        return MHT_E_STATE;
+    }
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int s = ++f->scan;
@@ -631,7 +646,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.status = ctx->status;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
@@ -646,7 +661,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
-    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit;
+    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = ctx->status;
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
@@ -714,6 +729,7 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     f->nT_ub = h->n_alive;
     f->L_ub = h->n_leaves_out;
     if (h->error) {
+        f->dead = true;
         set_error("forest: a pool overflowed during scan %d (max_nodes=%d, max_targets=%d): children=%d", h->scan,
                   f->Ncap, f->Tcap, h->n_children);
         return MHT_E_CAPACITY;

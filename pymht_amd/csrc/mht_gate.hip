@@ -410,6 +410,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                     if (new_node >= 0) {
                         const int my = pos + __popcll(m & ((1ull << lane) - 1ull));
                         if (my < a.edge_cap) a.edges[my] = ((unsigned)tgt << 16) | (unsigned)new_node;
+                        else a.status->overflow = 1;
                     }
                 }
             }

@@ -54,6 +54,7 @@ struct ClusterArgs {
     int Tcap;
     int32_t* edge_t; int32_t* edge_m; int Ecap;
     int n_mnodes;                      // R * Mpad
+    const DevStatus* status;           // forest mode: per-scan status word (overflow => do nothing)
     int clear_rows;                    // zero the bitset rows while reading them
     const unsigned* edges_in;          // forest mode: deduplicated edge list written by grow_kernel (skips the sweep)
     int32_t* edge_count;               //   its length; reset to zero here
@@ -83,6 +84,7 @@ struct BlpArgs {
     int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
     int32_t* cl_time;               // [T][2] or null: wall-clock ticks (10 ns) spent in setup / in total, per cluster
     int max_iter; int node_limit;
+    const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
     // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf
     const double* x; const uint8_t* flags;        // newest layer (x: [4][cap])

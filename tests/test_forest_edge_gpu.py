@@ -1,0 +1,142 @@
+"""GPU: edge cases of the device forest through the Tracker API (empty and ragged inputs,
+terminations, capacity errors) and the exact branch-and-bound path inside the pipeline."""
+import numpy as np
+import pytest
+
+import mht_oracle as orc
+from trace_util import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(sc, N=3, **kw):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=5.99, **kw)
+    for x in sc["x0"]:
+        trk.initiateTarget(Target(sc["t0"], None, x.copy(), pv.P0))
+    return trk
+
+
+def _scenario(**kw):
+    from pymht_amd.utils.scenario import make_scenario
+    args = dict(T=30, radius=400.0, lambda_phi=3e-5, n_scans=8, P_d=0.85, seed=7)
+    args.update(kw)
+    return make_scenario(**args)
+
+
+def test_empty_scans_and_no_targets():
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.models import pv
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    trk = Tracker(pv, 2.5, 1e-5, 1e-4, P_d=0.9, N=3, useInitiator=False)
+    # no targets, no measurements
+    trk.addMeasurementList(MeasurementList(1002.5, np.zeros((0, 2), dtype=np.float32)))
+    assert trk.lastScanStats["L"] == 0 and len(trk.getTrackNodes()) == 0
+    # no targets, some measurements: nothing is gated, everything is unused
+    trk.addMeasurementList(MeasurementList(1005.0, np.random.default_rng(0).uniform(-50, 50, (7, 2)).astype(np.float32)))
+    assert trk.lastScanStats["unused"].all() and trk.lastScanStats["L"] == 0
+    trk.close()
+    # targets, but scans without measurements: every hypothesis gets exactly its missed-detection child
+    sc = _scenario(n_scans=3)
+    trk = _mk(sc, useInitiator=False)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0())
+    assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__]
+    for k in range(3):
+        z = np.zeros((0, 2), dtype=np.float32)
+        n_before = len(trk.__targetList__)
+        trk.addMeasurementList(MeasurementList(float(sc["times"][k]), z))
+        o.add_scan(float(sc["times"][k]), z)
+        st = trk.lastScanStats
+        assert st["G"] == 0 and st["L"] == n_before          # all-miss trees: one leaf per target alive before the scan
+        want = o.selected()
+        got = trk.getTrackNodes()
+        assert [int(g.ID) for g in got] == want["ID"].tolist()
+        # live oracle on this host's BLAS: last-bit differences are possible (the golden fixtures pin exact values)
+        assert np.allclose(np.array([g.x_0 for g in got]).reshape(-1, 4), want["x"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(np.array([g.cumulativeNLLR for g in got]), want["cnllr"], rtol=0, atol=2e-5)
+    trk.close()
+
+
+def test_range_termination_matches_oracle():
+    """Tracks leaving radarRange are terminated (tracker.py:895) -- the target list shrinks exactly like the oracle's."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=25, radius=300.0, n_scans=8, seed=21, sigma_v=20.0)
+    rng_ = 260.0
+    trk = _mk(sc, useInitiator=False, radarRange=rng_)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99, radarRange=rng_)
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0())
+    killed = 0
+    for z, t in zip(sc["scans"], sc["times"]):
+        info = o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__]
+        killed += len(info["dead"])
+    assert killed > 0 and any(n.status == "OutOfRange" for n in trk.__terminatedTargets__)
+    trk.close()
+
+
+def test_forced_branch_and_bound_inside_the_forest():
+    """blpMaxIter=0 switches the dual ascent off: every ILP with a conflict among the per-target minimisers has to be
+    proven optimal by the GPU branch and bound.  Selections must still equal the oracle's exact optimum."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    sc = make_config("cfg2", seed=11, n_scans=10)          # 50 targets in 700 m, ~200 measurements/scan: many contested ILPs
+    trk = _mk(sc, N=4, useInitiator=False, blpMaxIter=0)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=4, eta2=5.99)
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0())
+    branched = 0
+    for z, t in zip(sc["scans"], sc["times"]):
+        o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        want, got = o.selected(), trk.getTrackNodes()
+        assert [int(g.ID) for g in got] == want["ID"].tolist()
+        assert [int(g.measurementNumber) for g in got] == want["meas"].tolist()
+        branched += trk.lastScanStats["branched"]
+    assert branched > 0
+    trk.close()
+
+
+def test_capacity_overflow_is_reported_not_fatal():
+    from pymht_amd import _lib
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=40, radius=300.0, lambda_phi=8e-5, n_scans=8, seed=5)
+    trk = _mk(sc, N=5, useInitiator=False, maxNodes=128)
+    with pytest.raises(_lib.MhtError) as ei:
+        for z, t in zip(sc["scans"], sc["times"]):
+            trk.addMeasurementList(MeasurementList(float(t), z))
+    assert ei.value.code in (_lib.MHT_E_CAPACITY, _lib.MHT_E_STATE)
+    with pytest.raises(_lib.MhtError):       # the forest refuses further scans
+        trk.addMeasurementList(MeasurementList(float(sc["times"][-1]) + 2.5, sc["scans"][-1]))
+    trk.close()
+
+
+def test_api_rejections_and_views():
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(n_scans=6)
+    trk = _mk(sc, useInitiator=False)
+    with pytest.raises(NotImplementedError):
+        trk.addMeasurementList(MeasurementList(float(sc["times"][0]), sc["scans"][0]), aisList=[object()])
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0())
+    for z, t in zip(sc["scans"], sc["times"]):
+        o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+    assert set(trk.getRuntimeAverage()) >= {"Total", "Process", "Cluster", "Optim", "N-Prune"}
+    # lazy parent chains (device ring + committed root history) reproduce the oracle's measurement history
+    for n_o, n_t in zip(o.track_nodes, trk.getTrackNodes()):
+        chain = [0 if m.measurementNumber is None else int(m.measurementNumber) for m in n_t.backtrackNodes()]
+        assert chain == n_o.history_meas()
+        assert abs(float(n_t.getScore()) - float(n_o.score())) < 2e-5
+        assert n_t.P_0.shape == (4, 4) and np.allclose(n_t.P_0, np.asarray(n_o.P, dtype=np.float32), rtol=1e-6)
+    # leaves of every root, DFS order
+    for r_o, r_t in zip(o.targets, trk.__targetList__):
+        lo, lt = r_o.leaves(), r_t.getLeafNodes()
+        assert [l.meas for l in lo] == [l.measurementNumber for l in lt]
+    trk.close()
