@@ -27,11 +27,14 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]
     int* aux = tlabel + a.Tcap;                          // [Tcap]  cluster index of a head
     int* mlabel = aux + a.Tcap;                          // [n_mnodes]
-    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + a.n_mnodes);   // [CL_ELDS]
+    const int mslots = a.n_mnodes > 3 * a.Tcap + 2 ? a.n_mnodes : 3 * a.Tcap + 2;   // the slot is re-used for the cluster tables
+    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [CL_ELDS]
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_total;
     const int tid = threadIdx.x;
     if (a.status && a.status->overflow) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
     const int T = *a.nT_dev;
+    const unsigned long long t0 = wall_clock64();
+#define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
     if (tid == 0) { s_edges = 0; a.counts[3] = 0; }
@@ -81,7 +84,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             E = CL_ELDS + a.Ecap;
         }
     }
+    CL_STAMP(0);
     // label propagation
+    int iters_done = 0;
     for (int iter = 0; iter < 4096; ++iter) {
         if (tid == 0) s_changed = 0;
         __syncthreads();
@@ -105,9 +110,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             if (l < tlabel[t]) { tlabel[t] = l; s_changed = 1; }
         }
         __syncthreads();
+        ++iters_done;
         if (!s_changed) break;
         __syncthreads();
     }
+    CL_STAMP(1);
+    if (a.dbg && tid == 0) a.dbg[6] = iters_done;
     if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back
         for (int e = tid; e < E; e += CL_THREADS) {
             const unsigned pk = cl_edge(eL, a, e);
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
         if (tid == 0) { *a.edge_count = 0; *a.ticket_reset = 0; }
     }
+    CL_STAMP(2);
     // heads -> cluster indices (exclusive scan over targets, chunked)
     int running = 0;
     for (int base = 0; base < T; base += CL_THREADS) {
@@ -140,57 +149,81 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         __syncthreads();
     }
     const int nC = running;
+    CL_STAMP(3);
+    // cluster sizes and offsets in LDS (csize/cptr alias the measurement-label array, which is dead by now)
+    int* csize = mlabel;                 // [nC]
+    int* cptr = mlabel + a.Tcap;         // [nC+1]
+    int* mheads = mlabel + 2 * a.Tcap + 1;   // [<= nC] heads of the multi-target clusters
+    for (int c = tid; c < nC; c += CL_THREADS) csize[c] = 0;
+    if (tid == 0) { s_edges = 0; s_changed = 0; }
+    __syncthreads();
     for (int t = tid; t < T; t += CL_THREADS) {
         a.t_label[t] = tlabel[t];
         a.t_cluster[t] = aux[tlabel[t]];
+        atomicAdd(&csize[aux[tlabel[t]]], 1);
     }
-    for (int c = tid; c <= nC; c += CL_THREADS) a.cl_ptr[c] = 0;
-    __threadfence_block();
     __syncthreads();
-    // member counts -> cl_ptr (counts at c+1, then inclusive scan by one wave-strided pass)
-    for (int t = tid; t < T; t += CL_THREADS) atomicAdd(&a.cl_ptr[a.t_cluster[t] + 1], 1);
-    __threadfence_block();
-    __syncthreads();
-    if (tid < 64) {      // serial-by-chunk inclusive scan of cl_ptr[1..nC] by one wavefront
-        int carry = 0;
-        for (int base = 1; base <= nC; base += 64) {
-            const int c = base + tid;
-            int v = (c <= nC) ? a.cl_ptr[c] : 0;
+    running = 0;
+    for (int base = 0; base < nC; base += CL_THREADS) {       // exclusive scan of the sizes
+        const int c = base + tid;
+        const int v = (c < nC) ? csize[c] : 0;
+        int incl = v;
+        const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(v, o);
-                if (tid >= o) v += u;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_scan[wv] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < CL_THREADS / 64; ++i) { const int x = s_scan[i]; s_scan[i] = acc; acc += x; }
+            s_total = acc;
+        }
+        __syncthreads();
+        if (c < nC) {
+            const int p0 = running + s_scan[wv] + incl - v;
+            cptr[c] = p0;
+            a.cl_ptr[c] = p0;
+        }
+        running += s_total;
+        __syncthreads();
+    }
+    if (tid == 0) { cptr[nC] = running; a.cl_ptr[nC] = running; }
+    CL_STAMP(4);
+    // work lists: heads of multi-target clusters (solved by blp_kernel), targets alone in their cluster
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int c = aux[tlabel[t]];
+        if (csize[c] == 1) {
+            a.cl_members[cptr[c]] = t;
+            a.single_list[atomicAdd(&s_changed, 1)] = t;
+        } else if (tlabel[t] == t) {
+            const int pos = atomicAdd(&s_edges, 1);
+            mheads[pos] = t;
+            a.multi_list[pos] = c;
+        }
+    }
+    __syncthreads();
+    // members of every multi-target cluster in ascending order: one wavefront per cluster sweeps the labels
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int nM = s_edges;
+        for (int i = wv; i < nM; i += CL_THREADS / 64) {
+            const int l = mheads[i];
+            const int base = cptr[aux[l]];
+            int run = 0;
+            for (int t0 = l & ~63; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                const bool m = t < T && tlabel[t] == l;
+                const unsigned long long bal = __ballot(m);
+                if (m) a.cl_members[base + run + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+                run += __popcll(bal);
             }
-            v += carry;
-            if (c <= nC) a.cl_ptr[c] = v;
-            carry = __shfl(v, 63);
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    // members in ascending order: rank of t among the members of its cluster with a smaller index
-    for (int t = tid; t < T; t += CL_THREADS) {
-        const int c = a.t_cluster[t];
-        const int size = a.cl_ptr[c + 1] - a.cl_ptr[c];
-        int rank = 0;
-        if (size > 1) {
-            const int l = tlabel[t];
-            for (int q = l; q < t; ++q) rank += (tlabel[q] == l);
-        }
-        a.cl_members[a.cl_ptr[c] + rank] = t;
-    }
-    if (tid == 0) { s_edges = 0; s_changed = 0; }
-    __syncthreads();
-    for (int c = tid; c < nC; c += CL_THREADS) {
-        const int size = a.cl_ptr[c + 1] - a.cl_ptr[c];
-        if (size > 1) a.multi_list[atomicAdd(&s_edges, 1)] = c;
-    }
-    __syncthreads();
-    // deterministic order of the work lists is not required (each entry is solved independently)
-    for (int t = tid; t < T; t += CL_THREADS) {
-        const int c = a.t_cluster[t];
-        if (a.cl_ptr[c + 1] - a.cl_ptr[c] == 1) a.single_list[atomicAdd(&s_changed, 1)] = t;
-    }
+    CL_STAMP(5);
+    if (a.dbg && tid == 0) a.dbg[7] = E;
     __syncthreads();
     if (tid == 0) {
         a.counts[0] = nC;
@@ -199,7 +232,10 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
 }
 
-size_t cluster_lds_bytes(int Tcap, int n_mnodes) { return (size_t)(2 * Tcap + n_mnodes + CL_ELDS) * 4; }
+size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
+    const int mslots = n_mnodes > 3 * Tcap + 2 ? n_mnodes : 3 * Tcap + 2;
+    return (size_t)(2 * Tcap + mslots + CL_ELDS) * 4;
+}
 
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
     static size_t attr_bytes = 0;

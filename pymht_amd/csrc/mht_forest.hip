@@ -439,7 +439,7 @@ struct Forest {
         best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
-        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(16);
+        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         cnt = ar.take<FCounts>(1);
@@ -646,7 +646,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.status = ctx->status;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.status = ctx->status; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
@@ -869,6 +869,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = 16 * 8; }
+    else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
     MHT_REQUIRE((size_t)bytes <= avail, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));

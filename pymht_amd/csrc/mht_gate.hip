@@ -32,9 +32,10 @@ struct LeafLds {          // per-leaf results of phase 1/2 parked in LDS for pha
     float K[8];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
+    double rootc;
     int src, tgt, cnt, base, depth, last_real;
     int ppath[MAXPD];
-    unsigned char flags, f32state, valid, first_of_target;
+    unsigned char flags, f32state, valid, first_of_target, root_f32;
 };
 
 template <typename TS>
@@ -102,7 +103,7 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned epoch, unsigne
 
 template <typename TS>
 __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, int i, int c, int k,
-                                           const unsigned long long* hw, const float2* z2, int& new_edge_node) {
+                                           const unsigned long long* hw, const float* zx, const float* zy, int& new_edge_node) {
     const size_t cap = a.cap_out;
     const uint8_t fl = g.flags;
     int meas = 0, covcol = 2 * i;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
         const int j = w * 64 + __ffsll((long long)bits) - 1;
         meas = j + 1;
         covcol = 2 * i + 1;
-        const float2 m = z2[j];
+        const float2 m = make_float2(zx[j], zy[j]);
         TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
         TS zt[2], nis, xh[4];
         gate_pair<TS>(zh, g.sinv, m.x, m.y, (TS)a.model.eta2, zt, nis);
@@ -151,10 +152,10 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     if (a.nllr) a.nllr[c] = inc;
     if (a.out_path) {
         const int tgt = g.tgt;
-        const double rootc = a.t_root_cnllr[tgt];
+        const double rootc = g.rootc;
         // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and
         // float32 / int stay float32
-        if ((cfl & F_SCORE_F32) && a.t_root_f32[tgt]) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
+        if ((cfl & F_SCORE_F32) && g.root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
         else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
 #pragma unroll
         for (int d = 0; d < MAXPD; ++d)
@@ -191,12 +192,15 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     float* zy = zx + Mpad;
     LeafLds* lg = reinterpret_cast<LeafLds*>(zy + Mpad);
     unsigned long long* hw = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);    // [GATE_TILE][W]
-    int* off = reinterpret_cast<int*>(hw + (size_t)GATE_TILE * W);                      // [nT+1] forest mode
+    int* off = reinterpret_cast<int*>(hw + (size_t)GATE_TILE * W);                      // [Tcap+1] forest mode
+    int* tfirst = off + (a.Tcap + 1);                                                   // [Tcap] per-target tables staged once
+    unsigned char* tdepth = reinterpret_cast<unsigned char*>(tfirst + a.Tcap);          // [Tcap] (<= MAXPD)
+    unsigned char* tshift = tdepth + a.Tcap;
     __shared__ int s_base, s_total, s_pref[GATE_TILE + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nT = a.t_leaf_off ? *a.nT_dev : 0;
-    const int L = a.t_leaf_off ? a.t_leaf_off[nT] : a.L;
+    const int nT = a.t_leaf_off ? a.nT_dev[0] : 0;      // FCounts{nT, L, ...}: one round trip for both
+    const int L = a.t_leaf_off ? a.nT_dev[1] : a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     const float2* z2 = reinterpret_cast<const float2*>(a.z);
     bool staged = false;
@@ -220,7 +224,10 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                 zy[j] = v.y;
             }
             if (a.t_leaf_off)
-                for (int j = tid; j <= nT; j += GATE_THREADS) off[j] = a.t_leaf_off[j];
+                for (int j = tid; j <= nT; j += GATE_THREADS) {
+                    off[j] = a.t_leaf_off[j];
+                    if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
+                }
             staged = true;
             __syncthreads();
         }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
             g.cnt = 0;
             if (g.valid) {
                 int src = a.leaf_src ? a.leaf_src[i] : i, tgt = -1;
-                if (a.t_leaf_off) locate_leaf(off, a.t_first, nT, i, tgt, src);
+                if (a.t_leaf_off) locate_leaf(off, tfirst, nT, i, tgt, src);
                 g.src = src;
                 g.tgt = tgt;
                 g.first_of_target = (tgt >= 0 && i == off[tgt]);
@@ -244,9 +251,13 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                 g.pd = a.pd[src];
                 g.depth = 0;
                 g.last_real = -1;
+                g.rootc = 0.0;
+                g.root_f32 = 0;
                 if (tgt >= 0) {
-                    const int depth = a.tgt_depth[tgt], shift = a.tgt_shift[tgt];
+                    const int depth = tdepth[tgt], shift = tshift[tgt];
                     g.depth = depth;
+                    g.rootc = a.t_root_cnllr[tgt];
+                    g.root_f32 = a.t_root_f32[tgt];
                     int last = -1;
 #pragma unroll
                     for (int d = 0; d < MAXPD; ++d) {
@@ -396,8 +407,8 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
                 const int i = tile * GATE_TILE + l;
                 tgt = g.tgt;
                 if (c < a.cap_out) {
-                    if (g.f32state) emit_child<float>(a, g, i, c, k, hw + (size_t)l * W, z2, new_node);
-                    else emit_child<double>(a, g, i, c, k, hw + (size_t)l * W, z2, new_node);
+                    if (g.f32state) emit_child<float>(a, g, i, c, k, hw + (size_t)l * W, zx, zy, new_node);
+                    else emit_child<double>(a, g, i, c, k, hw + (size_t)l * W, zx, zy, new_node);
                 }
             }
             if (a.edges) {          // wave-aggregated append of the new (target, measurement node) edges
@@ -429,11 +440,8 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
     }
 }
 
-// co-residency bound of grow_kernel: <= 4 workgroups (16 wavefronts) per CU by registers (92 VGPRs) and LDS (< 40 KB)
-constexpr int GROW_MAX_BLOCKS = 1024;
-
 static inline size_t grow_lds_bytes(int W, int Tcap) {
-    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(Tcap + 1) * 4 + 16;
+    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(2 * Tcap + 1) * 4 + (size_t)2 * Tcap + 16;
 }
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
@@ -452,8 +460,13 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     if (ablate < 0) { const char* e = getenv("MHT_GROW_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
     const int Tl = a.t_leaf_off ? a.Tcap : 0;
-    const int blocks = ntiles < GROW_MAX_BLOCKS ? ntiles : GROW_MAX_BLOCKS;
     const size_t lds = grow_lds_bytes(W, Tl);
+    // the grid must be co-resident (see the tile prefix): <= 4 workgroups per CU by registers, fewer if LDS says so
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const int max_blocks = 256 * per_cu;
+    const int blocks = ntiles < max_blocks ? ntiles : max_blocks;
     static size_t attr_bytes = 0;
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grow_kernel),

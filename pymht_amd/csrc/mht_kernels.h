@@ -55,6 +55,7 @@ struct ClusterArgs {
     int32_t* edge_t; int32_t* edge_m; int Ecap;
     int n_mnodes;                      // R * Mpad
     const DevStatus* status;           // forest mode: per-scan status word (overflow => do nothing)
+    int32_t* dbg;                      // development only: [8] wall-clock ticks at phase boundaries
     int clear_rows;                    // zero the bitset rows while reading them
     const unsigned* edges_in;          // forest mode: deduplicated edge list written by grow_kernel (skips the sweep)
     int32_t* edge_count;               //   its length; reset to zero here
