@@ -74,6 +74,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total)
 struct SurviveArgs {
     const int32_t* ctgt; const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop;
     int32_t* t_count; int32_t* t_firstsurv; const int32_t* path; int cap; const DevStatus* status;
+    // per-target half (done here, in parallel with the child sweep, to keep the dependent parent walk off commit's
+    // critical path): new root of every target + the target's report record
+    TTable cur; LayerView layers[MAXR]; int R; int scan; const FCounts* cnt;
+    const double* t_score; const int32_t* t_label; mht_target_report* rec;
+    int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;   // [Tcap] walk results
 };
 
 // N-scan pruning, child side (pyTarget.pruneDepth -> _pruneAllHypothesisExceptThis, pyTarget.py:330-356): a new leaf
@@ -83,6 +88,45 @@ __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
     if (a.status->overflow) return;
     const int nCh = a.status->n_children;
     const int lane = threadIdx.x & 63;
+    // ---- target half: workgroups from the END of the grid take the targets, one thread each --------------------------
+    {
+        const int nT = a.cnt->nT;
+        const int t = (gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x;
+        if (t < nT) {
+            const LayerView& Lc = a.layers[a.scan % a.R];
+            const int s = a.sel[t];
+            const int st = a.t_status[t];
+            const int j = a.t_jdrop[t];
+            const int dg = a.cur.depth[t] + 1;
+            int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
+            double rc = a.cur.root_cnllr[t];
+            uint8_t rf = a.cur.root_f32[t];
+            if (st == 0 && j > 0) {       // walk from the selected leaf up to the new root (pyTarget.py:343-356)
+                int node = s, sc = a.scan;
+                for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
+                rscan = sc;
+                rnode = node;
+                rc = a.layers[sc % a.R].cnllr[node];
+                rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
+            }
+            a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
+            mht_target_report& r = a.rec[t];
+            r.id = a.cur.id[t];
+            r.status = st;
+            r.sel_node = s;
+            r.sel_meas = Lc.meas[s];
+            r.root_scan = rscan;
+            r.root_node = rnode;
+            for (int k = 0; k < 4; ++k) r.sel_x[k] = Lc.x[(size_t)k * a.cap + s];
+            r.sel_cnllr = Lc.cnllr[s];
+            r.score = a.t_score[t];
+            r.root_cnllr = rc;
+            const LayerView& Lr = a.layers[rscan % a.R];
+            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
+            r.root_meas = Lr.meas[rnode];
+            r.cluster = a.t_label[t];
+        }
+    }
     for (int base = blockIdx.x * blockDim.x; base < nCh; base += gridDim.x * blockDim.x) {
         const int c = base + threadIdx.x;
         int sv = 0, t = -1;
@@ -114,8 +158,8 @@ __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
 struct CommitArgs {
     TTable cur, nxt;
     const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
-    const double* t_score; const int32_t* t_label;
-    LayerView layers[MAXR]; int R; int scan; int cap;
+    const int32_t* w_root_scan; const int32_t* w_root_node; const double* w_root_cnllr; const uint8_t* w_root_f32;
+    int R; int scan; int cap;
     int32_t* new_index;
     FCounts* cnt; DevStatus* status;
     int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters;
@@ -140,7 +184,6 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
     }
     const int nT = a.cnt->nT;
     const int nCh = a.status->n_children;
-    const LayerView& Lc = a.layers[a.scan % a.R];
     if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
     __syncthreads();
     int running = 0, lrun = 0;
@@ -155,47 +198,20 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
         lrun += s_total;
         __syncthreads();
         if (t < nT) {
-            const int s = a.sel[t];
             const int j = a.t_jdrop[t];
-            const int dg = a.cur.depth[t] + 1;
-            int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
-            double rc = a.cur.root_cnllr[t];
-            uint8_t rf = a.cur.root_f32[t];
-            if (al && j > 0) {       // walk from the selected leaf up to the new root (pyTarget.py:343-356)
-                int node = s, sc = a.scan;
-                for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
-                rscan = sc;
-                rnode = node;
-                rc = a.layers[sc % a.R].cnllr[node];
-                rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
-            }
             mht_target_report& r = a.rec[t];
-            r.id = a.cur.id[t];
-            r.status = a.t_status[t];
-            r.sel_node = s;
-            r.sel_meas = Lc.meas[s];
             r.new_index = al ? pos : -1;
-            r.root_scan = rscan;
-            r.root_node = rnode;
             r.n_leaves = cntl;
-            for (int k = 0; k < 4; ++k) r.sel_x[k] = Lc.x[(size_t)k * a.cap + s];
-            r.sel_cnllr = Lc.cnllr[s];
-            r.score = a.t_score[t];
-            r.root_cnllr = rc;
-            const LayerView& Lr = a.layers[rscan % a.R];
-            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
-            r.root_meas = Lr.meas[rnode];
-            r.cluster = a.t_label[t];
             a.new_index[t] = al ? pos : -1;
             if (al) {
                 a.nxt.id[pos] = a.cur.id[t];
                 a.nxt.window[pos] = a.cur.window[t];
-                a.nxt.depth[pos] = dg - j;
+                a.nxt.depth[pos] = a.cur.depth[t] + 1 - j;
                 a.nxt.shift[pos] = j;
-                a.nxt.root_scan[pos] = rscan;
-                a.nxt.root_node[pos] = rnode;
-                a.nxt.root_cnllr[pos] = rc;
-                a.nxt.root_f32[pos] = rf;
+                a.nxt.root_scan[pos] = a.w_root_scan[t];
+                a.nxt.root_node[pos] = a.w_root_node[t];
+                a.nxt.root_cnllr[pos] = a.w_root_cnllr[t];
+                a.nxt.root_f32[pos] = a.w_root_f32[t];
                 a.nxt.first[pos] = a.t_firstsurv[t];
                 a.nxt.leaf_off[pos] = lpos;
             }
@@ -399,6 +415,7 @@ struct Forest {
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg;
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
+    int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
     char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off;
     float* z_dev; float* z_host;
@@ -442,6 +459,7 @@ struct Forest {
         sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
+        w_root_scan = ar.take<int32_t>(Tcap); w_root_node = ar.take<int32_t>(Tcap); w_root_cnllr = ar.take<double>(Tcap); w_root_f32 = ar.take<uint8_t>(Tcap);
         cnt = ar.take<FCounts>(1);
         report_dev = ar.take<char>(report_bytes);
         z_dev = ar.take<float>((size_t)2 * Mpad);
@@ -673,16 +691,23 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     if (rc) return rc;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259): surviving leaf ranges, then target table / roots / report --------------
-    SurviveArgs sv = {f->ctgt, f->sel, f->t_status, f->t_jdrop, f->t_count, f->t_firstsurv, f->path[s & 1], f->Ncap, ctx->status};
+    SurviveArgs sv = {};
+    sv.ctgt = f->ctgt; sv.sel = f->sel; sv.t_status = f->t_status; sv.t_jdrop = f->t_jdrop; sv.t_count = f->t_count;
+    sv.t_firstsurv = f->t_firstsurv; sv.path = f->path[s & 1]; sv.cap = f->Ncap; sv.status = ctx->status;
+    sv.cur = f->tab[cb];
+    for (int k = 0; k < f->R; ++k) sv.layers[k] = view_of(f->layer[k]);
+    sv.R = f->R; sv.scan = s; sv.cnt = f->cnt; sv.t_score = f->t_score; sv.t_label = f->t_label;
+    sv.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
+    sv.w_root_scan = f->w_root_scan; sv.w_root_node = f->w_root_node; sv.w_root_cnllr = f->w_root_cnllr; sv.w_root_f32 = f->w_root_f32;
     int sgrid = (f->L_ub > 0 ? 2 * f->L_ub + 255 : 256) / 256;
     if (sgrid > 512) sgrid = 512;
+    if (sgrid < (f->nT_ub + 255) / 256 + 1) sgrid = (f->nT_ub + 255) / 256 + 1;      // enough workgroups for the target half
     hipLaunchKernelGGL(survive_kernel, dim3(sgrid), dim3(256), 0, st, sv);
     MHT_HIP_CHECK(hipGetLastError());
     CommitArgs p = {};
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
     p.sel = f->sel; p.t_status = f->t_status; p.t_jdrop = f->t_jdrop; p.t_count = f->t_count; p.t_firstsurv = f->t_firstsurv;
-    p.t_score = f->t_score; p.t_label = f->t_label;
-    for (int k = 0; k < f->R; ++k) p.layers[k] = view_of(f->layer[k]);
+    p.w_root_scan = f->w_root_scan; p.w_root_node = f->w_root_node; p.w_root_cnllr = f->w_root_cnllr; p.w_root_f32 = f->w_root_f32;
     p.R = f->R; p.scan = s; p.cap = f->Ncap;
     p.new_index = f->new_index;
     p.cnt = f->cnt; p.status = ctx->status;
