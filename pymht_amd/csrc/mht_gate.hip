@@ -184,7 +184,7 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     }
 }
 
-__global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
+__global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = a.M, W = a.W;
     const int Mpad = W * 64;
@@ -428,13 +428,10 @@ __global__ __launch_bounds__(GATE_THREADS) void grow_kernel(const GateArgs a) {
         }
         if (a.dbg) {
             __syncthreads();
-            if (tid == 0) {
-                ts[6] = wall_clock64();
-                for (int q = 0; q < 6; ++q) {
-                    atomicAdd(&a.dbg[q], ts[q + 1] - ts[q]);
-                    atomicMax(&a.dbg[8 + q], ts[q + 1] - ts[q]);
-                }
-                atomicAdd(&a.dbg[6], 1ull);
+            if (tid == 0 && tile < 4000) {       // per-tile slots: no contention, stamps relative to the first tile's start are
+                ts[6] = wall_clock64();          // not available (no global clock origin), so absolute ticks are stored
+                for (int q = 0; q < 7; ++q) a.dbg[32 + (size_t)tile * 8 + q] = ts[q];
+                a.dbg[32 + (size_t)tile * 8 + 7] = (unsigned long long)blockIdx.x;
             }
         }
     }
@@ -466,6 +463,18 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
+    if (getenv("MHT_GROW_DEBUG")) {
+        static bool printed = false;
+        if (!printed) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, grow_kernel, GATE_THREADS, lds);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(grow_kernel));
+            fprintf(stderr, "[grow] occupancy API: %d workgroups/CU at %zu B dynamic LDS; static LDS %zu B, regs %d, local %zu B\n", nb, lds,
+                    (size_t)fa.sharedSizeBytes, fa.numRegs, (size_t)fa.localSizeBytes);
+            printed = true;
+        }
+    }
     const int blocks = ntiles < max_blocks ? ntiles : max_blocks;
     static size_t attr_bytes = 0;
     if (lds > 48 * 1024 && lds > attr_bytes) {

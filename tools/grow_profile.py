@@ -1,4 +1,4 @@
-"""Development aid: per-phase wall-clock of grow_kernel in forest mode on the headline config (MHT_GROW_DEBUG=1)."""
+"""Development aid: per-tile phase stamps of grow_kernel in forest mode on the headline config (MHT_GROW_DEBUG=1)."""
 import ctypes as C, os, sys
 os.environ["MHT_GROW_DEBUG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,15 +9,19 @@ from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 sc = make_config('cfg3', seed=5446, n_scans=14)
 trk = bench.make_tracker(sc, 0)
-prev = np.zeros(16, dtype=np.uint64)
-names = ['stage z/off', 'phase1 predict', 'phase2 fan-out', 'phase3 prefix', 'offsets', 'phase4 children']
+names = ['stage', 'phase1', 'phase2', 'prefix', 'offsets', 'phase4']
 for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     trk.addMeasurementList(MeasurementList(float(t), z))
-    a = np.zeros(16, dtype=np.uint64)
+    if k < 11: continue
+    a = np.zeros(32 + 8 * 4000, dtype=np.uint64)
     _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"grow_dbg", a.ctypes.data_as(C.c_void_p), a.nbytes))
-    d = a[:8].astype(np.int64) - prev[:8].astype(np.int64); prev = a
-    if k >= 9:
-        n = max(int(d[6]), 1)
-        print('scan %2d L=%d tiles=%d  grow stage %.1f us | mean us per tile: %s | sum %.1f' % (k, trk.lastScanStats['L'], n, 1e6 * trk.toc['Process'],
-              '  '.join('%s %.2f' % (nm, d[q] / n / 100.0) for q, nm in enumerate(names)), d[:6].sum() / n / 100.0))
-print('max us per phase over the run:', '  '.join('%s %.1f' % (nm, a[8 + q] / 100.0) for q, nm in enumerate(names)))
+    nt = (trk.lastScanStats['L'] + 15) // 16
+    ts = a[32:32 + 8 * nt].reshape(nt, 8).astype(np.int64)
+    t0 = ts[:, 0].min()
+    rel = (ts[:, :7] - t0) / 100.0
+    d = np.diff(rel, axis=1)
+    print('scan %d tiles=%d grow stage %.1f us; kernel span (first tile start -> last tile end) %.1f us' % (k, nt, 1e6 * trk.toc['Process'], rel[:, 6].max()))
+    print('   tile start: mean %.1f max %.1f | per-phase mean/max us: %s' % (rel[:, 0].mean(), rel[:, 0].max(),
+          '  '.join('%s %.1f/%.1f' % (n, d[:, q].mean(), d[:, q].max()) for q, n in enumerate(names))))
+    order = np.argsort(rel[:, 6])
+    print('   last tiles to finish:', [(int(i), round(float(rel[i, 0]), 1), round(float(rel[i, 6]), 1)) for i in order[-4:]])
