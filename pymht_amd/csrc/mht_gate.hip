@@ -106,15 +106,8 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
                                            const unsigned long long* hw, const float* zx, const float* zy, int& new_edge_node) {
     const size_t cap = a.cap_out;
     const uint8_t fl = g.flags;
-    int meas = 0, covcol = 2 * i;
-    double cnl, inc;
-    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
-    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = g.xbar[q];
-        inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
-        cnl = g.cn + inc;
-    } else {                 // (k-1)-th gated measurement in ascending index (pyTarget.py:242-254)
+    int meas = 0, covcol = 2 * i, j = -1;
+    if (k > 0) {             // (k-1)-th gated measurement in ascending index (pyTarget.py:242-254)
         int need = k - 1, w = 0;
         unsigned long long bits = hw[0];
         while (true) {
@@ -124,9 +117,31 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
             bits = hw[++w];
         }
         for (int q = 0; q < need; ++q) bits &= bits - 1;
-        const int j = w * 64 + __ffsll((long long)bits) - 1;
+        j = w * 64 + __ffsll((long long)bits) - 1;
         meas = j + 1;
         covcol = 2 * i + 1;
+    }
+    // association of the target (tracker.py:255-258 / pyTarget.getMeasurementSet), issued FIRST so that the round trip
+    // of the returning atomic overlaps the arithmetic and the stores below: a hit child contributes its measurement;
+    // the miss child contributes the LAST real measurement on the parent's path (every tree node with a real measurement
+    // is contributed exactly once: by the leaf reached from it through misses only).
+    int node = -1;
+    unsigned long long old = 0ull, bit = 0ull;
+    if (a.out_path) {
+        node = meas > 0 ? a.cur_slot_base + meas - 1 : g.last_real;
+        if (node >= 0) {
+            bit = 1ull << (node & 63);
+            old = atomicOr(&a.assoc[(size_t)g.tgt * a.assoc_words + (node >> 6)], bit);
+        }
+    }
+    double cnl, inc;
+    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
+    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = g.xbar[q];
+        inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
+        cnl = g.cn + inc;
+    } else {
         const float2 m = make_float2(zx[j], zy[j]);
         TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
         TS zt[2], nis, xh[4];
@@ -151,7 +166,6 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     a.oflags[c] = cfl;
     if (a.nllr) a.nllr[c] = inc;
     if (a.out_path) {
-        const int tgt = g.tgt;
         const double rootc = g.rootc;
         // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and
         // float32 / int stay float32
@@ -164,23 +178,9 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
                 if (d == g.depth && meas > 0) v = a.cur_slot_base + meas - 1;
                 a.out_path[(size_t)d * cap + c] = v;
             }
-        a.out_tgt[c] = tgt;
-        // association of the target (tracker.py:255-258 / pyTarget.getMeasurementSet): the new measurement of a hit
-        // child; the miss child contributes the LAST real measurement on the parent's path (every tree node with a
-        // real measurement is contributed exactly once: by the leaf reached from it through misses only)
-        int node = -1;
-        if (meas > 0) {
-            node = a.cur_slot_base + meas - 1;
-            a.used_bytes[meas - 1] = 1;
-        } else {
-            node = g.last_real;
-        }
-        if (node >= 0) {
-            unsigned long long* row = a.assoc + (size_t)tgt * a.assoc_words;
-            const unsigned long long bit = 1ull << (node & 63);
-            const unsigned long long old = atomicOr(&row[node >> 6], bit);
-            if (!(old & bit)) new_edge_node = node;
-        }
+        a.out_tgt[c] = g.tgt;
+        if (meas > 0) a.used_bytes[meas - 1] = 1;
+        if (node >= 0 && !(old & bit)) new_edge_node = node;
     }
 }
 
