@@ -18,7 +18,6 @@ constexpr int CL_ELDS = 16384;     // edges kept in LDS (packed target<<16 | nod
 
 __device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArgs& a, int e) {
     if (e < CL_ELDS) return eL[e];
-    if (a.edges_in) return a.edges_in[e];
     return ((unsigned)a.edge_t[e - CL_ELDS] << 16) | (unsigned)a.edge_m[e - CL_ELDS];
 }
 
@@ -42,10 +41,32 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
     if (a.edges_in) {
-        // forest mode: grow_kernel already produced the deduplicated edge list
-        E = *a.edge_count;
-        if (E > a.Ecap) { if (tid == 0) a.counts[3] = 1; E = a.Ecap; }
-        for (int e = tid; e < E && e < CL_ELDS; e += CL_THREADS) eL[e] = a.edges_in[e];
+        // forest mode: grow_kernel already produced the deduplicated edge list, in EDGE_SEGS counted segments
+        __shared__ int s_segoff[EDGE_SEGS + 1];
+        if (tid < 64) {
+            int n = a.edge_count[tid];
+            if (n > a.seg_cap) { n = a.seg_cap; a.counts[3] = 1; }
+            int incl = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (tid >= o) incl += v;
+            }
+            s_segoff[tid] = incl - n;
+            if (tid == 63) s_segoff[64] = incl;
+        }
+        __syncthreads();
+        E = s_segoff[EDGE_SEGS];
+        if (E > CL_ELDS + a.Ecap) { if (tid == 0) a.counts[3] = 1; E = CL_ELDS + a.Ecap; }
+        // flat gather: thread -> dense edge index -> (segment, offset) by binary search over the 65 offsets
+        for (int e = tid; e < E; e += CL_THREADS) {
+            int lo = 0, hi = EDGE_SEGS;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_segoff[mid] <= e) lo = mid; else hi = mid; }
+            const unsigned pk = a.edges_in[(size_t)lo * a.seg_cap + (e - s_segoff[lo])];
+            if (e < CL_ELDS) eL[e] = pk;
+            else { a.edge_t[e - CL_ELDS] = (int)(pk >> 16); a.edge_m[e - CL_ELDS] = (int)(pk & 0xffff); }
+        }
+        __threadfence_block();
         __syncthreads();
     } else {
         // bitsets -> edge list; the rows are cleared on the way (no memset between scans).  4 independent loads in
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             const unsigned pk = cl_edge(eL, a, e);
             rows[(size_t)(pk >> 16) * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
         }
-        if (tid == 0) { *a.edge_count = 0; *a.ticket_reset = 0; }
+        if (tid < EDGE_SEGS) a.edge_count[tid] = 0;
     }
     CL_STAMP(2);
     // heads -> cluster indices (exclusive scan over targets, chunked)

@@ -403,7 +403,7 @@ struct Arena {
 struct Forest {
     mht_forest_config cfg;
     mht_model model;
-    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap;
+    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap, SegCap;
     Arena arena;
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
@@ -444,10 +444,10 @@ struct Forest {
         ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
         child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
         assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes = ar.take<unsigned char>(Mpad);
-        edge_t = ar.take<int32_t>(64); edge_m = ar.take<int32_t>(64);
+        edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
         tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); group_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE / 64 + 8);
-        edges = ar.take<unsigned>(Ecap);
-        edge_count = ar.take<int32_t>(4); ticket = edge_count + 1;
+        edges = ar.take<unsigned>((size_t)EDGE_SEGS * SegCap);
+        edge_count = ar.take<int32_t>(EDGE_SEGS + 4); ticket = edge_count + EDGE_SEGS;
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8);
@@ -520,7 +520,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->n_mnodes = f->R * f->Mpad;
     f->AW = f->n_mnodes / 64;
     f->capc = 2 * f->Ncap + f->Tcap;
-    f->Ecap = 4 * f->Ncap;
+    f->Ecap = 4 * f->Ncap;              // edges the clustering kernel can take beyond its LDS list (spill arrays)
+    f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
     f->used_off = sizeof(ReportHeader);
     f->rec_off = f->used_off + (size_t)(f->Mpad / 64) * 8;
     f->report_bytes = f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report);
@@ -645,7 +646,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     g.cap_in = in.cap; g.capc_in = in.cap_cov;
     g.leaf_src = nullptr; g.L = 0;
     g.ticket = f->ticket; g.tile_state = f->tile_state; g.group_state = f->group_state; g.epoch = (unsigned)s;
-    g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->Ecap;
+    g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
     g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
     g.z = z; g.M = M; g.W = W;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
@@ -664,7 +665,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.status = ctx->status; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.seg_cap = f->SegCap; c.status = ctx->status; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);

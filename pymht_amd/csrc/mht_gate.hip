@@ -416,11 +416,14 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 if (m) {
                     int pos = 0;
                     const int leader = __ffsll((long long)m) - 1;
-                    if (lane == leader) pos = atomicAdd(a.edge_count, __popcll(m));
+                    // 64 edge segments with their own counters (segment = workgroup & 63): all workgroups reach this point
+                    // within a few microseconds of each other and one counter word saturates at ~88 atomics/us
+                    const int seg = blockIdx.x & (EDGE_SEGS - 1);
+                    if (lane == leader) pos = atomicAdd(&a.edge_count[seg], __popcll(m));
                     pos = __shfl(pos, leader);
                     if (new_node >= 0) {
                         const int my = pos + __popcll(m & ((1ull << lane) - 1ull));
-                        if (my < a.edge_cap) a.edges[my] = ((unsigned)tgt << 16) | (unsigned)new_node;
+                        if (my < a.edge_cap) a.edges[(size_t)seg * a.edge_cap + my] = ((unsigned)tgt << 16) | (unsigned)new_node;
                         else a.status->overflow = 1;
                     }
                 }

@@ -39,7 +39,7 @@ struct GateArgs {
     unsigned char* used_bytes;    // [M] byte j set iff measurement j was gated (plain stores, no atomics)
     unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window (dedup filter)
     int assoc_words; int PD; int cur_slot_base;   // measurement-node id of measurement j of this scan = cur_slot_base + j
-    unsigned* edges; int32_t* edge_count; int edge_cap;   // deduplicated (target<<16 | node) edges for the clustering
+    unsigned* edges; int32_t* edge_count; int edge_cap;   // deduplicated (target<<16 | node) edges: [EDGE_SEGS][edge_cap], counts [EDGE_SEGS]
     int32_t* tchild;              // [T+1] first child of every target (children of a target are contiguous)
     double* ocost;                // [cap_out] ILP cost of every child: getScore()/N (tracker.py:1127)
     const double* t_root_cnllr;   // [T] cumulativeNLLR of the target's root
@@ -58,7 +58,8 @@ struct ClusterArgs {
     int32_t* dbg;                      // development only: [8] wall-clock ticks at phase boundaries
     int clear_rows;                    // zero the bitset rows while reading them
     const unsigned* edges_in;          // forest mode: deduplicated edge list written by grow_kernel (skips the sweep)
-    int32_t* edge_count;               //   its length; reset to zero here
+    int32_t* edge_count;               //   [EDGE_SEGS] segment lengths; reset to zero here
+    int seg_cap;                       //   segment stride
     int32_t* ticket_reset;             //   grow_kernel's tile ticket, reset to zero here for the next scan
     // outputs
     int32_t* t_label;      // [T] smallest member of the component
