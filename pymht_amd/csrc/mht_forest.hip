@@ -101,6 +101,12 @@ __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
             int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
             double rc = a.cur.root_cnllr[t];
             uint8_t rf = a.cur.root_f32[t];
+            // everything that does not depend on the walk is fetched first so that its latency overlaps the walk's
+            mht_target_report& r = a.rec[t];
+            const int id = a.cur.id[t], smeas = Lc.meas[s];
+            const double sx0 = Lc.x[s], sx1 = Lc.x[(size_t)a.cap + s], sx2 = Lc.x[(size_t)2 * a.cap + s], sx3 = Lc.x[(size_t)3 * a.cap + s];
+            const double scn = Lc.cnllr[s], sscore = a.t_score[t];
+            const int lab = a.t_label[t];
             if (st == 0 && j > 0) {       // walk from the selected leaf up to the new root (pyTarget.py:343-356)
                 int node = s, sc = a.scan;
                 for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
@@ -110,21 +116,20 @@ __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
                 rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
             }
             a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
-            mht_target_report& r = a.rec[t];
-            r.id = a.cur.id[t];
+            r.id = id;
             r.status = st;
             r.sel_node = s;
-            r.sel_meas = Lc.meas[s];
+            r.sel_meas = smeas;
             r.root_scan = rscan;
             r.root_node = rnode;
-            for (int k = 0; k < 4; ++k) r.sel_x[k] = Lc.x[(size_t)k * a.cap + s];
-            r.sel_cnllr = Lc.cnllr[s];
-            r.score = a.t_score[t];
+            r.sel_x[0] = sx0; r.sel_x[1] = sx1; r.sel_x[2] = sx2; r.sel_x[3] = sx3;
+            r.sel_cnllr = scn;
+            r.score = sscore;
             r.root_cnllr = rc;
             const LayerView& Lr = a.layers[rscan % a.R];
             for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
             r.root_meas = Lr.meas[rnode];
-            r.cluster = a.t_label[t];
+            r.cluster = lab;
         }
     }
     for (int base = blockIdx.x * blockDim.x; base < nCh; base += gridDim.x * blockDim.x) {
