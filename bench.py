@@ -75,7 +75,7 @@ def prepass(sc, device):
         births.append([])
         trk.addMeasurementList(MeasurementList(float(t), z))
         s = trk.lastScanStats
-        stats.append((s["L"], s["G"], s["M"], s["ilp"], s["branched"], s["blp_iters_max"], len(trk.__targetList__)))
+        stats.append((s["L"], s["G"], s["M"], s["ilp"], s["branched"], s["blp_iters_max"], trk.nTargets))
     api_s = time.time() - t0
     final = [(int(n.ID), int(n.measurementNumber)) for n in trk.getTrackNodes()]
     init_s = float(np.sum(trk.runtimeLog["Init"]))

@@ -66,14 +66,9 @@ class Tracker():
         self.mergeThreshold = 4 * (model.sigmaR_RADAR_tracker ** 2)
         self.initiator = m_of_n.Initiator(self.M_required, self.N_checks, self.maxSpeedMS, self.C, self.R_RADAR,
                                           self.mergeThreshold)
-        # Tracker storage (tracker.py:74-84)
-        self.__targetList__ = []
-        self.__targetWindowSize__ = []
+        # Tracker storage (tracker.py:74-84): the forest lives on the device; the host keeps flat NumPy tables and
+        # builds `Target` views only when somebody looks (properties __targetList__, __trackNodes__, ... below)
         self.__scanHistory__ = []
-        self.__associatedMeasurements__ = []
-        self.__trackNodes__ = np.empty(0, dtype=np.dtype(object))
-        self.__terminatedTargets__ = []
-        self.__clusterList__ = []
         self.__aisHistory__ = []
         self.trackIdCounter = 0
         # Timing and logging (tracker.py:86-101)
@@ -117,9 +112,16 @@ class Tracker():
         _lib.check(self._lib.mht_forest_create(self._ctx.handle, C.byref(self._model), C.byref(cfg)))
         self._timing = bool(kwargs.get('deviceTiming', True))
         _lib.check(self._lib.mht_forest_set_timing(self._ctx.handle, int(self._timing)))
-        self._history = {}          # Target.ID -> list of committed root views (oldest first)
-        self._roots = []            # root views, target-list order
-        self._last_report = None
+        # host mirror of the target list (one row per target, target-list order)
+        self._tbl = dict(id=np.zeros(0, np.int64), root_scan=np.zeros(0, np.int64), root_node=np.zeros(0, np.int64),
+                         root_meas=np.zeros(0, np.int64), root_x=np.zeros((0, 4)), root_cnllr=np.zeros(0),
+                         root_time=np.zeros(0), f32=np.zeros(0, bool))
+        self._sel = None            # report records of the live targets after the last scan (selected leaves)
+        self._labels = np.zeros(0, np.int64)
+        self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
+        self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
+        self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
+        self._views = {}            # cache of lazily built views, dropped at every scan
         self.lastScanStats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -150,24 +152,24 @@ class Tracker():
         _lib.check(self._lib.mht_forest_add_targets(self._ctx.handle, n, p(x0), p(P0), p(flags), p(pd), p(meas), 1,
                                                     p(acc), p(ids)))
         scan = len(self.__scanHistory__)
-        out = []
-        for q, t in enumerate(targets):
-            if not acc[q]:
-                log.debug("Discarded an initial target: " + str(t))
-                continue
-            v = DeviceTarget(t.time, scan, t.x_0, t.P_0, ID=int(ids[q]), P_d=self.default_P_d,
-                             measurementNumber=t.measurementNumber, measurement=t.measurement, status=t.status,
-                             cumulativeNLLR=t.cumulativeNLLR)
-            v.isRoot = True
-            v._tracker = self
-            self.trackIdCounter = int(ids[q]) + 1
-            self.__targetList__.append(v)
-            self._roots.append(v)
-            self.__associatedMeasurements__.append(set())
-            self.__trackNodes__ = np.append(self.__trackNodes__, v)
-            self.__targetWindowSize__.append(self.N)
-            self._history[v.ID] = [v]
-            out.append(v)
+        ok = acc.astype(bool)
+        out = [t for t, a in zip(targets, ok) if a]
+        if not out:
+            return out
+        tb = self._tbl
+        tb["id"] = np.concatenate([tb["id"], ids[ok].astype(np.int64)])
+        tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(len(out), scan, np.int64)])
+        tb["root_node"] = np.concatenate([tb["root_node"], np.full(len(out), -1, np.int64)])
+        tb["root_meas"] = np.concatenate([tb["root_meas"], meas[ok].astype(np.int64)])
+        tb["root_x"] = np.concatenate([tb["root_x"], x0[ok]], axis=0)
+        tb["root_cnllr"] = np.concatenate([tb["root_cnllr"], np.zeros(len(out))])
+        tb["root_time"] = np.concatenate([tb["root_time"], np.array([float(t.time) for t in out])])
+        tb["f32"] = np.concatenate([tb["f32"], f32[ok]])
+        for t, i in zip(out, ids[ok]):
+            self._birth[int(i)] = (t.time, scan, t.x_0, t.P_0, t.measurementNumber, t.measurement, t.status)
+            t.ID = int(i)
+        self.trackIdCounter = int(ids[ok].max()) + 1
+        self._views.clear()
         return out
 
     # ------------------------------------------------------------------------------------------------
@@ -207,7 +209,7 @@ class Tracker():
         self.toc['ILP-Prune'] = 0.0
         self.toc['DynN'] = 0.0
         self.nOptimSolved = rep.n_ilp
-        self._apply_report(recs, rep, scanTime, scanNumber, z)
+        self._apply_report(recs, scanTime, scanNumber, z)
         # 7 -- Initiate new tracks (tracker.py:264-278), host side
         self.tic['Init'] = time.time()
         if self.useInitiator:
@@ -228,54 +230,139 @@ class Tracker():
                                   branched=rep.n_branched, blp_iters_max=rep.blp_iters_max,
                                   unused=unusedRadarMeasurementIndices)
 
-    def _apply_report(self, recs, rep, scanTime, scanNumber, z):
-        """Rebuild the host-side views (__trackNodes__, __targetList__, clusters, terminated list) from the report."""
-        nT = len(recs)
-        # clusters: group by label, ordered by label, members ascending (tracker.py:972-974)
-        labels = recs["cluster"] if nT else np.zeros(0, dtype=np.int32)
-        self.__clusterList__ = [np.where(labels == lab)[0] for lab in np.unique(labels)]
-        track_nodes, roots, windows, assoc = [], [], [], []
-        for t in range(nT):
-            r = recs[t]
-            old_root = self._roots[t]
-            m = int(r["sel_meas"])
-            node = DeviceTarget(scanTime, scanNumber, np.array(r["sel_x"]), self.P_0, ID=int(r["id"]),
-                                P_d=self.default_P_d, measurementNumber=m,
-                                measurement=(z[m - 1] if m > 0 else None), cumulativeNLLR=float(r["sel_cnllr"]),
-                                status=_STATUS_TAG[int(r["status"])])
-            node._tracker, node._node = self, int(r["sel_node"])
-            node._lazy_parent = self._make_parent_loader(int(r["id"]))
-            node._score = float(r["score"])
-            if int(r["status"]) != 0:
-                log.info("Terminating track %d (%s)" % (int(r["id"]), node.status))
-                self.__terminatedTargets__.append(node)
-                continue
-            if int(r["root_scan"]) != old_root.scanNumber:
-                old_root.isRoot = False
-                rm = int(r["root_meas"])
-                root = DeviceTarget(self.__scanHistory__[int(r["root_scan"]) - 1].time if r["root_scan"] > 0 else old_root.time,
-                                    int(r["root_scan"]), np.array(r["root_x"]), self.P_0, ID=int(r["id"]),
-                                    P_d=self.default_P_d, measurementNumber=rm, cumulativeNLLR=float(r["root_cnllr"]))
-                root._tracker, root._node, root.isRoot = self, int(r["root_node"]), True
-                root.parent = old_root
-                self._history[root.ID].append(root)
+    def _apply_report(self, recs, scanTime, scanNumber, z):
+        """Fold the scan report into the host tables (vectorised; no per-target Python objects are created here)."""
+        tb = self._tbl
+        self._views.clear()
+        self._labels = recs["cluster"].astype(np.int64) if len(recs) else np.zeros(0, np.int64)
+        alive = recs["status"] == 0
+        if (~alive).any():
+            self._dead_chunks.append((recs[~alive].copy(), scanTime, scanNumber, z))
+        live = recs[alive]
+        moved = live["root_scan"] != tb["root_scan"][alive]
+        if moved.any():      # the root of these targets advanced: commit the new root to the history
+            m = live[moved]
+            rs = m["root_scan"].astype(np.int64)
+            times = np.array([self.__scanHistory__[k - 1].time if k >= 1 else 0.0 for k in rs])
+            self._history.append(dict(id=m["id"].astype(np.int64), scan=rs, node=m["root_node"].astype(np.int64),
+                                      meas=m["root_meas"].astype(np.int64), x=m["root_x"].copy(),
+                                      cnllr=m["root_cnllr"].copy(), time=times))
+            root_time = tb["root_time"][alive].copy()
+            root_time[moved] = times
+        else:
+            root_time = tb["root_time"][alive]
+        self._tbl = dict(id=live["id"].astype(np.int64), root_scan=live["root_scan"].astype(np.int64),
+                         root_node=live["root_node"].astype(np.int64), root_meas=live["root_meas"].astype(np.int64),
+                         root_x=live["root_x"].copy(), root_cnllr=live["root_cnllr"].copy(), root_time=root_time,
+                         f32=tb["f32"][alive])
+        self._sel = (live, scanTime, scanNumber, z)
+
+    # ---- lazily built views (the reference's attributes, tracker.py:74-84) -----------------------------------------
+    def _node_view(self, r, scanTime, scanNumber, z):
+        m = int(r["sel_meas"])
+        node = DeviceTarget(scanTime, scanNumber, np.array(r["sel_x"]), self.P_0, ID=int(r["id"]), P_d=self.default_P_d,
+                            measurementNumber=m, measurement=(z[m - 1] if m > 0 else None),
+                            cumulativeNLLR=float(r["sel_cnllr"]), status=_STATUS_TAG[int(r["status"])])
+        node._tracker, node._node = self, int(r["sel_node"])
+        node._lazy_parent = self._make_parent_loader(int(r["id"]))
+        return node
+
+    @property
+    def __trackNodes__(self):
+        v = self._views.get("track")
+        if v is None:
+            v = np.empty(len(self._tbl["id"]), dtype=np.dtype(object))
+            if self._sel is not None and len(self._sel[0]) == len(v):
+                live, scanTime, scanNumber, z = self._sel
+                for i in range(len(live)):
+                    v[i] = self._node_view(live[i], scanTime, scanNumber, z)
+                n0 = len(live)
             else:
-                root = old_root
-            track_nodes.append(node)
-            roots.append(root)
-            windows.append(self.N)
-            assoc.append(None)
-        self._roots = roots
-        self.__targetList__ = list(roots)
-        self.__targetWindowSize__ = windows
-        self.__associatedMeasurements__ = assoc
-        arr = np.empty(len(track_nodes), dtype=np.dtype(object))
-        for i, n in enumerate(track_nodes):
-            arr[i] = n
-        self.__trackNodes__ = arr
-        self._last_report = recs
+                n0 = 0 if self._sel is None else len(self._sel[0])
+                if self._sel is not None:
+                    live, scanTime, scanNumber, z = self._sel
+                    for i in range(n0):
+                        v[i] = self._node_view(live[i], scanTime, scanNumber, z)
+            roots = self.__targetList__
+            for i in range(n0, len(v)):      # targets born after the last scan: their node is the root itself
+                v[i] = roots[i]
+            self._views["track"] = v
+        return v
+
+    @property
+    def __targetList__(self):
+        v = self._views.get("roots")
+        if v is None:
+            tb = self._tbl
+            v = []
+            for i in range(len(tb["id"])):
+                tid = int(tb["id"][i])
+                b = self._birth.get(tid)
+                if b is not None and int(tb["root_scan"][i]) == b[1]:      # still the root it was born with
+                    root = DeviceTarget(b[0], b[1], b[2], b[3], ID=tid, P_d=self.default_P_d, measurementNumber=b[4],
+                                        measurement=b[5], status=b[6])
+                else:
+                    root = DeviceTarget(float(tb["root_time"][i]), int(tb["root_scan"][i]), tb["root_x"][i].copy(), self.P_0,
+                                        ID=tid, P_d=self.default_P_d, measurementNumber=int(tb["root_meas"][i]),
+                                        cumulativeNLLR=float(tb["root_cnllr"][i]))
+                    root._lazy_parent = self._history_parent_loader(tid)
+                root.isRoot, root._tracker, root._node = True, self, int(tb["root_node"][i])
+                v.append(root)
+            self._views["roots"] = v
+        return v
+
+    @property
+    def __clusterList__(self):
+        return [np.where(self._labels == lab)[0] for lab in np.unique(self._labels)]
+
+    @property
+    def __terminatedTargets__(self):
+        out = []
+        for recs, scanTime, scanNumber, z in self._dead_chunks:
+            for r in recs:
+                out.append(self._node_view(r, scanTime, scanNumber, z))
+        return out
+
+    @property
+    def __targetWindowSize__(self):
+        return [self.N] * len(self._tbl["id"])
+
+    @property
+    def __associatedMeasurements__(self):
+        """The association sets live on the device as (target, measurement node) edges; the host view is rebuilt from
+        the leaves' ancestor chains on demand (slow path, for inspection only)."""
+        return [root.getMeasurementSet() if root.trackHypotheses is not None else set() for root in self.__targetList__]
 
     # ------------------------------------------------------------------------------------------------
+    def _history_chain(self, target_id):
+        """Committed roots of one track, oldest first, as Target views linked through `parent`."""
+        b = self._birth.get(target_id)
+        chain = []
+        if b is not None:
+            first = DeviceTarget(b[0], b[1], b[2], b[3], ID=target_id, P_d=self.default_P_d, measurementNumber=b[4],
+                                 measurement=b[5], status=b[6])
+            first._tracker = self
+            chain.append(first)
+        for ch in self._history:
+            for k in np.where(ch["id"] == target_id)[0]:
+                sc = int(ch["scan"][k])
+                zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
+                m = int(ch["meas"][k])
+                v = DeviceTarget(float(ch["time"][k]), sc, ch["x"][k].copy(), self.P_0, ID=target_id, P_d=self.default_P_d,
+                                 measurementNumber=m, measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
+                                 cumulativeNLLR=float(ch["cnllr"][k]))
+                v._tracker, v._node = self, int(ch["node"][k])
+                v.parent = chain[-1] if chain else None
+                chain.append(v)
+        return chain
+
+    def _history_parent_loader(self, target_id):
+        def load(view):
+            chain = self._history_chain(target_id)
+            older = [c for c in chain if c.scanNumber < view.scanNumber]
+            return older[-1] if older else None
+        return load
+
     def _make_parent_loader(self, target_id):
         def load(view):
             # ancestors inside the device window, then the committed root history kept on the host
@@ -291,13 +378,14 @@ class Tracker():
                 return None
             _lib.check(self._lib.mht_forest_chain(self._ctx.handle, view.scanNumber, view._node, n_max, p(nodes), p(meas),
                                                   p(x), p(cn), p(P), C.byref(n)))
-            hist = self._history.get(target_id, [])
-            root = hist[-1] if hist else None
+            i = int(np.where(self._tbl["id"] == target_id)[0][0]) if (self._tbl["id"] == target_id).any() else -1
+            root_scan = int(self._tbl["root_scan"][i]) if i >= 0 else -1
             view.P_0 = P[0].reshape(4, 4).copy()
             prev = view
             for k in range(1, n.value):
                 sc = view.scanNumber - k
-                if root is not None and sc == root.scanNumber and int(nodes[k]) == root._node:
+                if sc == root_scan:          # reached the current root: continue with the committed history
+                    root = self.__targetList__[i]
                     prev._parent, prev._lazy_parent = root, None
                     return view._parent
                 zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
@@ -335,6 +423,9 @@ class Tracker():
         t = self.__scanHistory__[-1].time if scan else root.time
         out = []
         for i in np.where(snap["ID"] == root.ID)[0]:
+            if int(snap["node"][i]) == root._node and root.scanNumber == scan:
+                out.append(root)
+                continue
             v = DeviceTarget(t, scan, snap["x"][i].copy(), snap["P"][i].copy(), ID=root.ID, P_d=self.default_P_d,
                              measurementNumber=int(snap["meas"][i]), cumulativeNLLR=float(snap["cnllr"][i]))
             v._tracker, v._node = self, int(snap["node"][i])
@@ -343,6 +434,11 @@ class Tracker():
         return out
 
     # ------------------------------------------------------------------------------------------------
+    @property
+    def nTargets(self):
+        """len(__targetList__) without building the views."""
+        return len(self._tbl["id"])
+
     def getTrackNodes(self):
         return self.__trackNodes__
 
