@@ -73,7 +73,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total)
 
 struct SurviveArgs {
     const int32_t* ctgt; const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop;
-    int32_t* t_count; int32_t* t_firstsurv; const int32_t* path; int cap; const DevStatus* status;
+    int32_t* t_count; int32_t* t_firstsurv; const int32_t* path; const int32_t* apath; int cap; const DevStatus* status;
     // per-target half (done here, in parallel with the child sweep, to keep the dependent parent walk off commit's
     // critical path): new root of every target + the target's report record
     TTable cur; LayerView layers[MAXR]; int R; int scan; const FCounts* cnt;
@@ -107,14 +107,16 @@ __global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
             const double sx0 = Lc.x[s], sx1 = Lc.x[(size_t)a.cap + s], sx2 = Lc.x[(size_t)2 * a.cap + s], sx3 = Lc.x[(size_t)3 * a.cap + s];
             const double scn = Lc.cnllr[s], sscore = a.t_score[t];
             const int lab = a.t_label[t];
-            if (st == 0 && j > 0) {       // walk from the selected leaf up to the new root (pyTarget.py:343-356)
-                int node = s, sc = a.scan;
-                for (int k = 0; k < dg - j; ++k) { node = a.layers[sc % a.R].parent[node]; --sc; }
+            if (st == 0 && j > 0) {       // new root = the selected leaf's ancestor j levels below the old root
+                // (pyTarget.pruneDepth, pyTarget.py:343-356); the ancestor table makes it one lookup instead of a parent walk
+                const int sc = rscan + j;
+                const int node = a.apath[(size_t)(j - 1) * a.cap + s];
                 rscan = sc;
                 rnode = node;
                 rc = a.layers[sc % a.R].cnllr[node];
                 rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
             }
+            (void)dg;
             a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
             r.id = id;
             r.status = st;
@@ -273,7 +275,7 @@ struct AddArgs {
     int n; const double* x0; const float* P0; const uint8_t* flags; const double* pd; const int32_t* meas;
     int check; double thr;
     mht_nodes layer;     // newest layer
-    TTable tab; int32_t* path; int PD;
+    TTable tab; int32_t* path; int32_t* apath; int PD;
     FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
 };
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.layer.cov[idx] = a.cov_base + r;
                 a.layer.flags[idx] = a.flags[q];
                 for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
-                for (int d = 0; d < a.PD; ++d) a.path[(size_t)d * cap + idx] = -1;
+                for (int d = 0; d < a.PD; ++d) { a.path[(size_t)d * cap + idx] = -1; a.apath[(size_t)d * cap + idx] = -1; }
                 a.tab.id[t] = a.cnt->id_counter;
                 a.tab.window[t] = a.Nwin;
                 a.tab.depth[t] = 0;
@@ -411,7 +413,7 @@ struct Forest {
     int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap, SegCap;
     Arena arena;
     mht_nodes layer[MAXR];
-    int32_t* path[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
+    int32_t* path[2]; int32_t* apath[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
     TTable tab[2];
     unsigned long long* assoc; unsigned char* used_bytes;
     unsigned long long* tile_state; unsigned long long* group_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
@@ -440,6 +442,7 @@ struct Forest {
         }
         for (int b = 0; b < 2; ++b) {
             path[b] = ar.take<int32_t>((size_t)PD * Ncap);
+            apath[b] = ar.take<int32_t>((size_t)PD * Ncap);
             TTable& t = tab[b];
             t.id = ar.take<int32_t>(Tcap); t.window = ar.take<int32_t>(Tcap); t.depth = ar.take<int32_t>(Tcap);
             t.shift = ar.take<int32_t>(Tcap); t.root_scan = ar.take<int32_t>(Tcap); t.root_node = ar.take<int32_t>(Tcap);
@@ -573,7 +576,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     const int nb = (f->scan + 1) & 1;
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb];
-    a.path = f->path[f->scan & 1]; a.PD = f->PD;
+    a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->PD;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
     a.near = f->near;
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
@@ -659,6 +662,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = nullptr; g.used_bytes = f->used_bytes;
     g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
     g.out_path = f->path[s & 1]; g.out_tgt = f->ctgt;
+    g.in_apath = f->apath[(s - 1) & 1]; g.out_apath = f->apath[s & 1];
     g.assoc = f->assoc; g.assoc_words = f->AW; g.PD = f->PD; g.cur_slot_base = (s % f->R) * f->Mpad;
     g.tchild = f->tchild; g.ocost = f->cost; g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
     g.Nwin = f->cfg.n_scan;
@@ -699,7 +703,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     // ---- 4: N-scan prune (tracker.py:256-259): surviving leaf ranges, then target table / roots / report --------------
     SurviveArgs sv = {};
     sv.ctgt = f->ctgt; sv.sel = f->sel; sv.t_status = f->t_status; sv.t_jdrop = f->t_jdrop; sv.t_count = f->t_count;
-    sv.t_firstsurv = f->t_firstsurv; sv.path = f->path[s & 1]; sv.cap = f->Ncap; sv.status = ctx->status;
+    sv.t_firstsurv = f->t_firstsurv; sv.path = f->path[s & 1]; sv.apath = f->apath[s & 1]; sv.cap = f->Ncap; sv.status = ctx->status;
     sv.cur = f->tab[cb];
     for (int k = 0; k < f->R; ++k) sv.layers[k] = view_of(f->layer[k]);
     sv.R = f->R; sv.scan = s; sv.cnt = f->cnt; sv.t_score = f->t_score; sv.t_label = f->t_label;

@@ -35,6 +35,7 @@ struct LeafLds {          // per-leaf results of phase 1/2 parked in LDS for pha
     double rootc;
     int src, tgt, cnt, base, depth, last_real;
     int ppath[MAXPD];
+    int apath[MAXPD];
     unsigned char flags, f32state, valid, first_of_target, root_f32;
 };
 
@@ -177,6 +178,7 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
                 int v = g.ppath[d];
                 if (d == g.depth && meas > 0) v = a.cur_slot_base + meas - 1;
                 a.out_path[(size_t)d * cap + c] = v;
+                a.out_apath[(size_t)d * cap + c] = (d == g.depth) ? c : g.apath[d];
             }
         a.out_tgt[c] = g.tgt;
         if (meas > 0) a.used_bytes[meas - 1] = 1;
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                     for (int d = 0; d < MAXPD; ++d) {
                         const int v = (d < depth) ? a.in_path[(size_t)(d + shift) * a.cap_in + src] : -1;
                         g.ppath[d] = v;
+                        g.apath[d] = (d < depth) ? a.in_apath[(size_t)(d + shift) * a.cap_in + src] : -1;
                         if (v >= 0) last = v;
                     }
                     g.last_real = last;

@@ -35,6 +35,8 @@ struct GateArgs {
     const int32_t* tgt_shift;     // [T] entries dropped from the front of the path (root advance)
     const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
     int32_t* out_path;            // [PD][cap_out]
+    const int32_t* in_apath;      // [PD][cap_in] node index of the ancestor at depth d+1 below the root (own layer each)
+    int32_t* out_apath;           // [PD][cap_out]
     int32_t* out_tgt;             // [cap_out] target slot
     unsigned char* used_bytes;    // [M] byte j set iff measurement j was gated (plain stores, no atomics)
     unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window (dedup filter)
