@@ -21,6 +21,7 @@
 // is copied into LDS once (costs, rows as dense local ids, prices, usage counters, marks) and every dual step runs
 // out of LDS; larger clusters run the same code on HBM scratch (L2 resident).
 #include "mht_kernels.h"
+#include <stdlib.h>
 
 namespace mht {
 
@@ -601,7 +602,7 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
     }
     __syncthreads();
     const int nH = s_nH;
-    const bool lds_cols = small_k && nH <= L_MAXH && a.PD <= 8;
+    const bool lds_cols = small_k && nH <= L_MAXH && a.PD <= 8 && !a.force_hbm;
     s.nH = nH; s.PD = a.PD; s.K = K;
     // ---- measurement nodes of the cluster (union of the rows of its columns); in the LDS case the columns are
     //      copied in the same sweep: every thread issues the PD+1 loads of a column back to back (one round trip)
@@ -809,6 +810,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
+    { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     // one cluster holding all targets
     int32_t* hbuf = new int32_t[nT + 8];
     hbuf[0] = 0; hbuf[1] = nT;

@@ -690,6 +690,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = ctx->status;
+    { const char* e = getenv("MHT_BLP_FORCE_HBM"); b.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;

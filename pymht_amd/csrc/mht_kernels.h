@@ -88,6 +88,7 @@ struct BlpArgs {
     int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
     int32_t* cl_time;               // [T][2] or null: wall-clock ticks (10 ns) spent in setup / in total, per cluster
     int max_iter; int node_limit;
+    int force_hbm;                  // testing: run every cluster through the HBM storage policy (as oversized clusters do)
     const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
     // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf

@@ -25,7 +25,8 @@ def gpu_cluster(ctx, sets, n_nodes):
 
 
 @pytest.mark.parametrize("T,n_nodes,deg,seed", [(1, 64, 3, 0), (7, 100, 2, 1), (300, 3000, 4, 2), (2000, 9000, 3, 3),
-                                                 (500, 200, 1, 4), (64, 64, 0, 5)])
+                                                 (500, 200, 1, 4), (64, 64, 0, 5),
+                                                 (3000, 9000, 9, 6)])       # > 16384 edges: the LDS edge list spills to HBM
 def test_cluster_matches_oracle(gpu_ctx, T, n_nodes, deg, seed):
     rng = np.random.default_rng(seed)
     sets = [set(int(v) for v in rng.integers(0, n_nodes, size=rng.integers(0, deg + 1))) for _ in range(T)]
@@ -108,3 +109,17 @@ def test_blp_adversarial_needs_branching(gpu_ctx):
         assert abs(obj - bo) < 1e-9
         if ties == 1:
             assert sel == sorted(bs)
+
+
+def test_blp_hbm_storage_policy(gpu_ctx, gold_dir, monkeypatch):
+    """Clusters that do not fit LDS run the same solver on HBM scratch; MHT_BLP_FORCE_HBM=1 sends every cluster there.
+    Recorded instances (dual ascent and branch and bound) and a whole scan trace must still match bit for bit."""
+    monkeypatch.setenv("MHT_BLP_FORCE_HBM", "1")
+    for name in ("g4_ilp", "g6_ilp_cfg3"):
+        for max_iter in (200, 0):
+            for inst in load_instances(os.path.join(gold_dir, name + ".npz"))[::3]:
+                sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=max_iter)
+                assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj))
+                assert sel == inst["sel"].tolist()
+    from test_tracker_gpu import test_tracker_replays_reference_trace
+    test_tracker_replays_reference_trace("g3b_trace_cfg2", gold_dir)
