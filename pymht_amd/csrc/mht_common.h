@@ -50,8 +50,8 @@ struct Scratch {
     }
 };
 
-constexpr int GATE_TILE = 16;    // leaves per workgroup of the gate kernel
-constexpr int GATE_THREADS = 256;
+constexpr int GATE_TILE = 32;    // leaves per workgroup tile of grow_kernel
+constexpr int GATE_THREADS = 512;
 constexpr int EMIT_THREADS = 64;  // one wavefront, one leaf per lane
 constexpr int MAX_MEAS = 4096;    // 64 hit-mask words per leaf, one per lane
 constexpr int EDGE_SEGS = 64;      // the (target, measurement) edge list is written in 64 independently counted segments

@@ -2,7 +2,7 @@
 // of a scan and the creation of the child hypotheses, ONE launch per scan
 // (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py; children: pyTarget.py:227-258, :319-328).
 //
-// Workgroup = 4 wavefronts, tile = 16 consecutive leaves (tiles are mapped statically onto a
+// Workgroup = 8 wavefronts, tile = 32 consecutive leaves (tiles are mapped statically onto a
 // co-resident grid -- see the look-back below).
 //   phase 1  lanes 0..15: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
 //            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
         }
         __syncthreads();
         ts[2] = wall_clock64();
-        // ---- phase 2: thread = (leaf of the tile, measurement stream): 16 leaves x 16 interleaved streams ----------------
+        // ---- phase 2: thread = (leaf of the tile, measurement stream): 32 leaves x 16 interleaved streams ----------------
         // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
         // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
         // reference-order NIS and sets its bit in the leaf's hit mask (LDS atomicOr; hits are rare: ~1 per leaf).
@@ -466,7 +466,8 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const size_t lds = grow_lds_bytes(W, Tl);
     // the grid must be co-resident (see the tile prefix): <= 4 workgroups per CU by registers, fewer if LDS says so
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    if (per_cu > 4) per_cu = 4;
+    const int by_regs = 16 / (GATE_THREADS / 64);     // 4 wavefronts per SIMD at 128 registers = 16 per CU
+    if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;
     const int max_blocks = 256 * per_cu;
     if (getenv("MHT_GROW_DEBUG")) {
