@@ -28,14 +28,13 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     int* mlabel = aux + a.Tcap;                          // [n_mnodes]
     const int mslots = a.n_mnodes > 3 * a.Tcap + 2 ? a.n_mnodes : 3 * a.Tcap + 2;   // the slot is re-used for the cluster tables
     unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [CL_ELDS]
-    __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_total;
+    __shared__ int s_edges, s_changed, s_big, s_scan[CL_THREADS / 64], s_total;
     const int tid = threadIdx.x;
     if (a.status && a.status->overflow) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
     const int T = *a.nT_dev;
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
-    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
     if (tid == 0) { s_edges = 0; a.counts[3] = 0; }
     __syncthreads();
     int E;
@@ -106,35 +105,40 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
     }
     CL_STAMP(0);
-    // label propagation
-    int iters_done = 0;
-    for (int iter = 0; iter < 4096; ++iter) {
-        if (tid == 0) s_changed = 0;
-        __syncthreads();
-        for (int e = tid; e < E; e += CL_THREADS) {
-            const unsigned pk = cl_edge(eL, a, e);
-            atomicMin(&mlabel[pk & 0xffff], tlabel[pk >> 16]);
+    // connected components by lock-free union-find in LDS: vertices = targets (0..T-1) and measurement nodes (mlabel[]
+    // doubles as their parent array, value = vertex id, T + m).  Every edge hooks the larger root under the smaller one
+    // with atomicCAS; targets have the smaller ids, so the root of a component is its smallest target -- the label the
+    // reference's scipy labelling + np.where ordering implies (tracker.py:972-974).  One pass over the edges, one
+    // compression pass: no iteration to a fixed point.
+    int iters_done = 1;
+    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = T + m;
+    __syncthreads();
+    auto parent_of = [&](int v) -> int { return v < T ? tlabel[v] : mlabel[v - T]; };
+    auto find_root = [&](int v) -> int {
+        int p = parent_of(v);
+        while (p != v) { v = p; p = parent_of(v); }
+        return v;
+    };
+    for (int e = tid; e < E; e += CL_THREADS) {
+        const unsigned pk = cl_edge(eL, a, e);
+        int ra = find_root((int)(pk >> 16)), rb = find_root(T + (int)(pk & 0xffff));
+        while (ra != rb) {
+            if (ra > rb) { const int tmp = ra; ra = rb; rb = tmp; }      // ra < rb: hook rb under ra
+            int* slot = rb < T ? &tlabel[rb] : &mlabel[rb - T];
+            const int old = atomicCAS(slot, rb, ra);
+            if (old == rb) break;
+            rb = find_root(old);          // somebody else moved rb meanwhile: retry from its new root
+            ra = find_root(ra);
         }
-        __syncthreads();
-        for (int e = tid; e < E; e += CL_THREADS) {
-            const unsigned pk = cl_edge(eL, a, e);
-            const int v = mlabel[pk & 0xffff], t = (int)(pk >> 16);
-            if (v < tlabel[t]) {
-                atomicMin(&tlabel[t], v);
-                s_changed = 1;
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < T; t += CL_THREADS) {      // pointer jumping
-            int l = tlabel[t], ll = tlabel[l];
-            while (ll < l) { l = ll; ll = tlabel[l]; }
-            if (l < tlabel[t]) { tlabel[t] = l; s_changed = 1; }
-        }
-        __syncthreads();
-        ++iters_done;
-        if (!s_changed) break;
-        __syncthreads();
     }
+    __syncthreads();
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int r = find_root(t);
+        aux[t] = r;                       // stash: writing tlabel here would race with other threads' find_root
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = aux[t];
+    __syncthreads();
     CL_STAMP(1);
     if (a.dbg && tid == 0) a.dbg[6] = iters_done;
     if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     int* cptr = mlabel + a.Tcap;         // [nC+1]
     int* mheads = mlabel + 2 * a.Tcap + 1;   // [<= nC] heads of the multi-target clusters
     for (int c = tid; c < nC; c += CL_THREADS) csize[c] = 0;
-    if (tid == 0) { s_edges = 0; s_changed = 0; }
+    if (tid == 0) { s_edges = 0; s_changed = 0; s_big = 0; }
     __syncthreads();
     for (int t = tid; t < T; t += CL_THREADS) {
         a.t_label[t] = tlabel[t];
@@ -213,24 +217,49 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
     if (tid == 0) { cptr[nC] = running; a.cl_ptr[nC] = running; }
     CL_STAMP(4);
-    // work lists: heads of multi-target clusters (solved by blp_kernel), targets alone in their cluster
+    // per-cluster linked lists of the non-head members (push order is arbitrary, the lists are sorted below)
+    // (the three tables live in the LDS edge list, which is dead by now; 3*Tcap <= CL_ELDS is checked at launch)
+    int* lhead = reinterpret_cast<int*>(eL);   // [T] first list element of the cluster headed by t, -1 = none
+    int* lnext = lhead + a.Tcap;               // [T]
+    int* tmp = lnext + a.Tcap;                 // [T] scratch: every cluster owns the segment [cptr[c], cptr[c+1])
+    for (int t = tid; t < T; t += CL_THREADS) lhead[t] = -1;
+    __syncthreads();
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int r = tlabel[t];
+        if (r != t) lnext[t] = atomicExch(&lhead[r], t);
+    }
+    __syncthreads();
+    // work lists: heads of multi-target clusters (solved by blp_kernel), targets alone in their cluster; the members of a
+    // multi-target cluster are collected by its head, sorted ascending (insertion sort in LDS: clusters are small) and
+    // written out; clusters with more than 64 members are left to the wavefront sweep below
     for (int t = tid; t < T; t += CL_THREADS) {
         const int c = aux[tlabel[t]];
-        if (csize[c] == 1) {
+        const int K = csize[c];
+        if (K == 1) {
             a.cl_members[cptr[c]] = t;
             a.single_list[atomicAdd(&s_changed, 1)] = t;
         } else if (tlabel[t] == t) {
-            const int pos = atomicAdd(&s_edges, 1);
-            mheads[pos] = t;
-            a.multi_list[pos] = c;
+            a.multi_list[atomicAdd(&s_edges, 1)] = c;
+            if (K <= 64) {
+                int* seg = tmp + cptr[c];
+                seg[0] = t;                               // the head is the smallest member
+                int n = 1;
+                for (int q = lhead[t]; q >= 0 && n < K; q = lnext[q]) {
+                    int pos = n++;
+                    while (pos > 1 && seg[pos - 1] > q) { seg[pos] = seg[pos - 1]; --pos; }
+                    seg[pos] = q;
+                }
+                for (int k = 0; k < K; ++k) a.cl_members[cptr[c] + k] = seg[k];
+            } else {
+                mheads[atomicAdd(&s_big, 1)] = t;
+            }
         }
     }
     __syncthreads();
-    // members of every multi-target cluster in ascending order: one wavefront per cluster sweeps the labels
-    {
+    {   // big clusters: one wavefront per cluster sweeps the labels in ascending order
         const int lane = tid & 63, wv = tid >> 6;
-        const int nM = s_edges;
-        for (int i = wv; i < nM; i += CL_THREADS / 64) {
+        const int nB = s_big;
+        for (int i = wv; i < nB; i += CL_THREADS / 64) {
             const int l = mheads[i];
             const int base = cptr[aux[l]];
             int run = 0;
@@ -261,7 +290,7 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
     static size_t attr_bytes = 0;
     const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
-    if (lds > 150 * 1024 || a.n_mnodes > 65536 || a.Tcap > 65536) {
+    if (lds > 150 * 1024 || a.n_mnodes > 65536 || 3 * a.Tcap > CL_ELDS) {
         set_error("cluster: Tcap=%d and %d measurement nodes need %zu B of LDS (> 150 KiB)", a.Tcap, a.n_mnodes, lds);
         return MHT_E_CAPACITY;
     }
