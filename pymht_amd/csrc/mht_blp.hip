@@ -296,6 +296,109 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
     block_min_pair(bv, bi, r);
 }
 
+// ---- dual coordinate ascent (LDS policy) -------------------------------------------------------------------------
+// The conflicts of MHT clusters are mostly local: a few targets whose cheapest leaves want the same measurement node.
+// Along the single price u_m the dual function is piecewise linear and its maximiser is known in closed form: with the
+// users' regrets r_t = (cheapest column of t avoiding m) - (cheapest column of t) sorted r1 >= r2 >= ..., any increase
+// in (r2, r1) makes every user but the highest bidder leave m strictly -- an auction step.  Rows are repriced together
+// only when no target takes part in two of them (every target nominates the lowest conflicted row of its minimiser; a
+// row is active iff all its users nominated it), so the step is a block-coordinate ascent: the dual bound never
+// decreases.  Priced rows nobody uses any more are lowered to just below the cheapest taker.  Nothing here affects
+// exactness: the certificate (no conflict, no priced-but-unused row) is what proves optimality, and clusters that are
+// not certified after CA_ROUNDS fall through to the subgradient steps and the branch and bound.
+constexpr int CA_ROUNDS = 8;
+__device__ __forceinline__ bool coord_capable(const GStore&) { return false; }
+__device__ __forceinline__ bool coord_capable(const LStore&) { return true; }
+__device__ __forceinline__ void coordinate_step(const GStore&, int, bool, bool) {}
+__device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool conflict, bool slack) {
+    const int tid = threadIdx.x;
+    if (conflict) {
+        // nominations (lix = nominated row or -1; markL counts the nominations of a row)
+        for (int k = tid; k < K; k += BLP_THREADS) {
+            const Rows8 e8 = rows_of(s, s.best_h[k]);
+            int act = 0x7fffffff;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const int e = e8.e[d];
+                if (e != s.nR && s.usageL[e] >= 2 && e < act) act = e;
+            }
+            s.lix[k] = (act == 0x7fffffff) ? -1 : act;
+            if (act != 0x7fffffff) atomicAdd(&s.markL[act], 1);
+        }
+        __syncthreads();
+        // regrets of the users of active rows: 16 lanes per target scan its columns
+        const int row = tid >> 4, l16 = tid & 15;
+        for (int k0 = 0; k0 < K; k0 += BLP_THREADS / 16) {
+            const int k = k0 + row;
+            const int m = (k < K) ? s.lix[k] : -1;
+            const bool active = m >= 0 && s.markL[m] == s.usageL[m];
+            double alt = DINF;
+            int ai = -1;
+            if (active)
+                for (int h = s.colb[k] + l16; h < s.colb[k + 1]; h += 16) {
+                    const Rows8 e8 = rows_of(s, h);
+                    bool has = false;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) has |= (e8.e[d] == m);
+                    const double rc = s.rcL[h];
+                    if (!has && (ai < 0 || rc < alt)) { alt = rc; ai = h; }
+                }
+            row16_min_pair(alt, ai);
+            if (l16 == 15 && k < K) s.mn[k] = active ? ((ai < 0 ? DINF : alt) - s.best_rc[k]) : -1.0;
+        }
+        __syncthreads();
+        // price increase of every active row, written by its lowest-index user
+        for (int k = tid; k < K; k += BLP_THREADS) {
+            const int m = s.lix[k];
+            if (m < 0 || s.mn[k] < 0.0) continue;
+            double r1 = -1.0, r2 = -1.0;
+            bool lowest = true;
+            for (int j = 0; j < K; ++j)
+                if (s.lix[j] == m) {
+                    if (j < k) lowest = false;
+                    const double v = s.mn[j];
+                    if (v > r1) { r2 = r1; r1 = v; }
+                    else if (v > r2) r2 = v;
+                }
+            if (lowest && r2 >= 0.0 && r2 < DINF) s.uL[m] += r2 + 0.5 * fmin(r1 - r2, 1.0);
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += BLP_THREADS)
+            if (s.lix[k] >= 0) s.markL[s.lix[k]] = 0;
+        __syncthreads();
+    }
+    if (slack) {
+        // priced rows without a user: markL[m] <- float bits of the smallest gap (rounded up) any column containing m has to
+        // its target's minimum; a target that was repriced above blocks the row for this round (gap 0)
+        const unsigned INF_BITS = 0x7f800000u;
+        for (int m = tid; m < s.nR; m += BLP_THREADS)
+            if (s.uL[m] > 0.0 && s.usageL[m] == 0) s.markL[m] = (int)INF_BITS;
+        __syncthreads();
+        for (int h = tid; h < s.nH; h += BLP_THREADS) {
+            const Rows8 e8 = rows_of(s, h);
+            const int k = s.membL[h];
+            const bool busy = conflict && s.lix[k] >= 0 && s.mn[k] >= 0.0;
+            const double gap = busy ? 0.0 : s.rcL[h] - s.best_rc[k];
+            float gf = (float)gap;
+            if ((double)gf < gap) gf = __uint_as_float(__float_as_uint(gf) + 1u);      // round up (gap >= 0)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const int e = e8.e[d];
+                if (e != s.nR && s.markL[e] != 0) atomicMin(reinterpret_cast<unsigned*>(&s.markL[e]), __float_as_uint(gf));
+            }
+        }
+        __syncthreads();
+        for (int m = tid; m < s.nR; m += BLP_THREADS)
+            if (s.uL[m] > 0.0 && s.usageL[m] == 0) {
+                const unsigned b = (unsigned)s.markL[m];
+                const double g = (b == INF_BITS) ? DINF : (double)__uint_as_float(b);
+                s.uL[m] = fmax(0.0, s.uL[m] - (g * (1.0 + 9.5367431640625e-7) + 1e-9));
+                s.markL[m] = 0;
+            }
+        __syncthreads();
+    }
+}
+
 // visiting order of the dive: targets by ascending minimal reduced cost (ties by index); identity for the HBM policy
 __device__ __forceinline__ int dive_member(const GStore& s, int K, int pos) { return pos; }
 __device__ __forceinline__ int dive_member(const LStore& s, int K, int pos) { return s.lix[pos]; }
@@ -387,7 +490,9 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         }
         bool done = false;
         if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
-        if (!done) {
+        const bool coord = coord_capable(s) && it < CA_ROUNDS && it < a.max_iter;
+        if (!done && coord) coordinate_step(s, K, conflict != 0, slack != 0);
+        if (!done && !coord) {
             if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
             else if (++stall >= 10) { theta *= 0.5; stall = 0; }
             if (UB >= DINF || (conflict && (it % 4) == 0)) {
@@ -403,9 +508,9 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
             if (it == a.max_iter || nrm == 0.0) done = true;
         }
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
-        const double step = done ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
+        const double step = (done || coord) ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
         s.for_rows([&](int m) {
-            if (!done) {
+            if (!done && !coord) {
                 const double um = s.u(m);
                 double g = (double)(s.usage(m) - 1);
                 if (um <= 0.0 && g < 0.0) g = 0.0;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
             ReportHeader& h = *a.hdr;
             h.scan = a.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[a.cnt->nT];
             h.n_children = a.status->n_children; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
-            h.blp_iters_max = 0; h.error = MHT_E_CAPACITY; h.used_words = 0;
+            h.blp_iters_max = 0; h.error = (a.status->overflow == 2) ? MHT_E_HIP : MHT_E_CAPACITY; h.used_words = 0;
             a.cnt->overflow = 1;
         }
         return;
@@ -764,6 +764,12 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);
     f->nT_ub = h->n_alive;
     f->L_ub = h->n_leaves_out;
+    if (h->error == MHT_E_HIP) {
+        f->dead = true;
+        set_error("forest: grow_kernel stalled in scan %d waiting for a tile that was never dispatched (GPU shared with another "
+                  "resident grid?); the forest must be recreated", h->scan);
+        return MHT_E_HIP;
+    }
     if (h->error) {
         f->dead = true;
         set_error("forest: a pool overflowed during scan %d (max_nodes=%d, max_targets=%d): children=%d", h->scan,

@@ -186,6 +186,8 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     }
 }
 
+constexpr int SPIN_LIMIT = 1 << 23;     // look-back watchdog: x ~0.1 us per poll
+
 __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = a.M, W = a.W;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     int* tfirst = off + (a.Tcap + 1);                                                   // [Tcap] per-target tables staged once
     unsigned char* tdepth = reinterpret_cast<unsigned char*>(tfirst + a.Tcap);          // [Tcap] (<= MAXPD)
     unsigned char* tshift = tdepth + a.Tcap;
-    __shared__ int s_base, s_total, s_pref[GATE_TILE + 1];
+    __shared__ int s_base, s_total, s_stall, s_pref[GATE_TILE + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.t_leaf_off ? a.nT_dev[0] : 0;      // FCounts{nT, L, ...}: one round trip for both
@@ -208,8 +210,11 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     bool staged = false;
 
     // Tiles are mapped statically (tile = blockIdx + k*gridDim, increasing per workgroup).  The launcher keeps the
-    // grid small enough to be fully co-resident, so a workgroup spinning in the look-back only ever waits for tiles
-    // owned by workgroups that are running: no dependence on dispatch order, no shared ticket word to serialise on.
+    // grid small enough to be fully co-resident on an otherwise idle GPU, so a workgroup spinning in the look-back only
+    // ever waits for tiles owned by workgroups that are running: no shared ticket word to serialise on.  If another
+    // resident grid (a second stream / process) takes the slots, a multi-round grid could wait for a workgroup that is
+    // not dispatched yet; the spins are bounded (SPIN_LIMIT, ~1 s) and a stall voids the scan with a loud error
+    // instead of hanging the device.
     if (ntiles == 0 && blockIdx.x == 0 && tid == 0) {      // no leaves at all
         a.child_ptr[0] = 0;
         a.status->n_children = 0;
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 s_pref[GATE_TILE] = total;
                 s_total = total;
                 s_base = 0;
+                s_stall = 0;
                 __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, 1u, (unsigned)total),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -345,9 +351,13 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 if (lane < 63) {
                     const int tq = tile - 63 + lane;
                     unsigned long long st;
+                    int spins = 0;
                     do {
                         st = __hip_atomic_load(&a.tile_state[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) __builtin_amdgcn_s_sleep(1);
+                        if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > SPIN_LIMIT) { s_stall = 1; break; }
+                        }
                     } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
                     v = (int)(st & 0xffffffffu);
                 } else if (lane == 63) {
@@ -368,9 +378,13 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             for (int q = tid; q < ((a.ablate & 2) ? 0 : grp + r); q += GATE_THREADS) {
                 const unsigned long long* w = (q < grp) ? &a.group_state[q] : &a.tile_state[grp * 64 + (q - grp)];
                 unsigned long long st;
+                int spins = 0;
                 do {
                     st = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) __builtin_amdgcn_s_sleep(1);
+                    if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > SPIN_LIMIT) { s_stall = 1; break; }
+                    }
                 } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
                 acc += (int)(st & 0xffffffffu);
             }
@@ -379,6 +393,10 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             if (lane == 0 && acc) atomicAdd(&s_base, acc);
         }
         __syncthreads();
+        if (s_stall) {      // watchdog: a tile this one depends on never published (its workgroup is not resident): void scan
+            if (tid == 0) a.status->overflow = 2;
+            return;
+        }
         ts[4] = wall_clock64();
         const int base = s_base, total = s_total;
         if (tid < GATE_TILE && lg[tid].valid) {
@@ -533,6 +551,10 @@ extern "C" int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nod
         MHT_HIP_CHECK(hipMemcpyAsync(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *n_children = st.n_children;
+        if (st.overflow == 2) {
+            set_error("mht_gate_scan: grow_kernel stalled waiting for a tile that was never dispatched (GPU shared with another resident grid?)");
+            return MHT_E_HIP;
+        }
         if (st.overflow) {
             set_error("mht_gate_scan: output layer too small (need cap >= %d, cap_cov >= %d)", st.n_children, 2 * L);
             return MHT_E_CAPACITY;
