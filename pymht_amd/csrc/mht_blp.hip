@@ -253,6 +253,25 @@ __device__ __forceinline__ void compute_minimisers(const GStore& s, int K, Red* 
     __syncthreads();
 }
 __device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* r) {
+    if (K <= BLP_THREADS / 64) {
+        // small cluster: one wavefront per target, reduced costs computed in the same sweep (kept in rcL for the
+        // coordinate step), DPP reduction: a single phase
+        const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (k < K) {
+            const int hb = s.colb[k], he = s.colb[k + 1];
+            double bv = DINF;
+            int bi = -1;
+            for (int h = hb + lane; h < he; h += 64) {
+                const double rc = reduced_cost(s, h);
+                s.rcL[h] = rc;
+                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            }
+            wave_min_pair(bv, bi);
+            if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
+        }
+        __syncthreads();
+        return;
+    }
     // pass 1: one thread per column -> reduced cost in LDS; pass 2: 16 lanes per target scan its columns and reduce
     // with four DPP row shifts (no atomics, no LDS-crossbar permutes)
     for (int h = threadIdx.x; h < s.nH; h += BLP_THREADS) s.rcL[h] = reduced_cost(s, h);
@@ -261,7 +280,9 @@ __device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* 
     for (int k = row; k < K; k += BLP_THREADS / 16) {
         double bv = DINF;
         int bi = -1;
-        for (int h = s.colb[k] + l16; h < s.colb[k + 1]; h += 16) {
+        const int hb = s.colb[k], he = s.colb[k + 1];
+#pragma unroll 2
+        for (int h = hb + l16; h < he; h += 16) {
             const double rc = s.rcL[h];
             if (bi < 0 || rc < bv) { bv = rc; bi = h; }
         }
@@ -310,41 +331,64 @@ constexpr int CA_ROUNDS = 8;
 __device__ __forceinline__ bool coord_capable(const GStore&) { return false; }
 __device__ __forceinline__ bool coord_capable(const LStore&) { return true; }
 __device__ __forceinline__ void coordinate_step(const GStore&, int, bool, bool) {}
+__device__ __forceinline__ void nominate(const GStore&, int) {}
+// every target nominates the lowest conflicted row of its minimiser (lix = row or -1; markL counts nominations).
+// Runs in the same phase as the certificate flags (both only need the usage counters).
+__device__ __forceinline__ void nominate(const LStore& s, int K) {
+    for (int k = threadIdx.x; k < K; k += BLP_THREADS) {
+        const Rows8 e8 = rows_of(s, s.best_h[k]);
+        int us[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) us[d] = s.usageL[e8.e[d]];      // dummy row nR: usage 0
+        int act = 0x7fffffff;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (us[d] >= 2 && (int)e8.e[d] < act) act = e8.e[d];
+        s.lix[k] = (act == 0x7fffffff) ? -1 : act;
+        if (act != 0x7fffffff) atomicAdd(&s.markL[act], 1);
+    }
+}
+// cheapest column of target k that avoids row m, by `G` cooperating lanes (G = 16: DPP row; G = 64: wavefront)
+template <int G> __device__ __forceinline__ double regret_of(const LStore& s, int k, int m, bool active, int l) {
+    double alt = DINF;
+    int ai = -1;
+    if (active) {
+        const int hb = s.colb[k], he = s.colb[k + 1];
+#pragma unroll 2
+        for (int h = hb + l; h < he; h += G) {
+            const uint4 v = reinterpret_cast<const uint4*>(s.entL)[h];
+            const double rc = s.rcL[h];
+            const unsigned mm = (unsigned)m, m2 = mm | (mm << 16);
+            // does any of the eight 16-bit row ids equal m?
+            const unsigned x0 = v.x ^ m2, x1 = v.y ^ m2, x2 = v.z ^ m2, x3 = v.w ^ m2;
+            const bool has = !(x0 & 0xffffu) || !(x0 >> 16) || !(x1 & 0xffffu) || !(x1 >> 16) ||
+                             !(x2 & 0xffffu) || !(x2 >> 16) || !(x3 & 0xffffu) || !(x3 >> 16);
+            if (!has && (ai < 0 || rc < alt)) { alt = rc; ai = h; }
+        }
+    }
+    if (G == 64) wave_min_pair(alt, ai);
+    else row16_min_pair(alt, ai);
+    return ai < 0 ? DINF : alt;
+}
 __device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool conflict, bool slack) {
     const int tid = threadIdx.x;
     if (conflict) {
-        // nominations (lix = nominated row or -1; markL counts the nominations of a row)
-        for (int k = tid; k < K; k += BLP_THREADS) {
-            const Rows8 e8 = rows_of(s, s.best_h[k]);
-            int act = 0x7fffffff;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const int e = e8.e[d];
-                if (e != s.nR && s.usageL[e] >= 2 && e < act) act = e;
-            }
-            s.lix[k] = (act == 0x7fffffff) ? -1 : act;
-            if (act != 0x7fffffff) atomicAdd(&s.markL[act], 1);
-        }
-        __syncthreads();
-        // regrets of the users of active rows: 16 lanes per target scan its columns
-        const int row = tid >> 4, l16 = tid & 15;
-        for (int k0 = 0; k0 < K; k0 += BLP_THREADS / 16) {
-            const int k = k0 + row;
+        // regrets of the users of active rows (mn[k] = regret, -1 = target not taking part)
+        if (K <= BLP_THREADS / 64) {
+            const int k = tid >> 6, lane = tid & 63;
             const int m = (k < K) ? s.lix[k] : -1;
             const bool active = m >= 0 && s.markL[m] == s.usageL[m];
-            double alt = DINF;
-            int ai = -1;
-            if (active)
-                for (int h = s.colb[k] + l16; h < s.colb[k + 1]; h += 16) {
-                    const Rows8 e8 = rows_of(s, h);
-                    bool has = false;
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) has |= (e8.e[d] == m);
-                    const double rc = s.rcL[h];
-                    if (!has && (ai < 0 || rc < alt)) { alt = rc; ai = h; }
-                }
-            row16_min_pair(alt, ai);
-            if (l16 == 15 && k < K) s.mn[k] = active ? ((ai < 0 ? DINF : alt) - s.best_rc[k]) : -1.0;
+            const double alt = regret_of<64>(s, k, m, active, lane);
+            if (lane == 0 && k < K) s.mn[k] = active ? alt - s.best_rc[k] : -1.0;
+        } else {
+            const int row = tid >> 4, l16 = tid & 15;
+            for (int k0 = 0; k0 < K; k0 += BLP_THREADS / 16) {
+                const int k = k0 + row;
+                const int m = (k < K) ? s.lix[k] : -1;
+                const bool active = m >= 0 && s.markL[m] == s.usageL[m];
+                const double alt = regret_of<16>(s, k, m, active, l16);
+                if (l16 == 15 && k < K) s.mn[k] = active ? alt - s.best_rc[k] : -1.0;
+            }
         }
         __syncthreads();
         // price increase of every active row, written by its lowest-index user
@@ -353,19 +397,23 @@ __device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool con
             if (m < 0 || s.mn[k] < 0.0) continue;
             double r1 = -1.0, r2 = -1.0;
             bool lowest = true;
-            for (int j = 0; j < K; ++j)
-                if (s.lix[j] == m) {
+            for (int j = 0; j < K; ++j) {
+                const int mj = s.lix[j];
+                const double v = s.mn[j];
+                if (mj == m) {
                     if (j < k) lowest = false;
-                    const double v = s.mn[j];
                     if (v > r1) { r2 = r1; r1 = v; }
                     else if (v > r2) r2 = v;
                 }
+            }
             if (lowest && r2 >= 0.0 && r2 < DINF) s.uL[m] += r2 + 0.5 * fmin(r1 - r2, 1.0);
         }
-        __syncthreads();
-        for (int k = tid; k < K; k += BLP_THREADS)
-            if (s.lix[k] >= 0) s.markL[s.lix[k]] = 0;
-        __syncthreads();
+        if (slack) {      // the slack pass re-uses markL: clear the nomination counters first
+            __syncthreads();
+            for (int k = tid; k < K; k += BLP_THREADS)
+                if (s.lix[k] >= 0) s.markL[s.lix[k]] = 0;
+            __syncthreads();
+        }
     }
     if (slack) {
         // priced rows without a user: markL[m] <- float bits of the smallest gap (rounded up) any column containing m has to
@@ -466,6 +514,8 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         });
         double src = 0.0, sc = 0.0;
         for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
+        const bool coord = coord_capable(s) && it < CA_ROUNDS && it < a.max_iter;
+        if (coord) nominate(s, K);      // needs the usage counters only; published by the reduction's barriers
         {   // one fused block reduction for the six quantities
             const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
             int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
@@ -490,7 +540,6 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         }
         bool done = false;
         if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
-        const bool coord = coord_capable(s) && it < CA_ROUNDS && it < a.max_iter;
         if (!done && coord) coordinate_step(s, K, conflict != 0, slack != 0);
         if (!done && !coord) {
             if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
@@ -517,6 +566,7 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
                 s.u(m) = fmax(0.0, um + step * g);
             }
             s.usage(m) = 0;
+            if (coord) s.mark(m) = 0;      // nomination counters
         });
         __threadfence_block();
         __syncthreads();
