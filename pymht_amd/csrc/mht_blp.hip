@@ -666,17 +666,42 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
 }
 
 // track termination test and N-scan prune depth for target t whose selected leaf is child s (forest mode)
-__device__ __forceinline__ void finish_target(const BlpArgs& a, int t, int s) {
-    if (!a.t_alive) return;
+// ---- forest epilogue: track termination, N-scan prune decision, new root, report record, surviving leaf range -------
+// (tracker.py:891-916, pyTarget.py:343-356).  It is latency-, not throughput-bound (a handful of dependent look-ups per
+// target), so it is arranged in as few dependent load levels as possible: what depends only on the target is fetched
+// before the selection is known (TgtPre), the layers of the ring are addressed arithmetically (no pointer table), and
+// survival is decided with ONE ancestor-table look-up per child (child descends from the new root <=> its ancestor at the
+// root's depth IS the new root) instead of comparing path prefixes.
+struct TgtPre { int j, rscan, rnode, id, lab, cb, ce; double rootc; uint8_t rootf; };
+__device__ __forceinline__ TgtPre load_target(const BlpArgs& a, int t) {
+    TgtPre p;
+    const int dg = a.t_depth[t] + 1, w = a.t_window[t];
+    p.j = dg > w ? dg - w : 0;             // layers the root advances (pyTarget.pruneDepth)
+    p.rscan = a.t_root_scan[t]; p.rnode = a.t_root_node[t]; p.id = a.t_id[t]; p.lab = a.t_label[t];
+    p.cb = a.tchild[t]; p.ce = a.tchild[t + 1];
+    p.rootc = a.t_root_cnllr[t]; p.rootf = a.t_root_f32[t];
+    return p;
+}
+template <typename T> __device__ __forceinline__ const T* ring_ptr(const T* base0, size_t stride, int k) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base0) + (size_t)k * stride);
+}
+constexpr int KEY_DEAD = -1, KEY_ALL = -2;
+// Returns the survival key of the target: KEY_DEAD (terminated), KEY_ALL (alive, root stays) or the node index of the
+// new root (children whose ancestor table holds it at level j-1 survive).
+__device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, const TgtPre& p, bool store) {
+    const int kc = a.scan % a.R;
     const double cn = a.cnllr[s];
     const uint8_t fl = a.flags[s];
-    const double rootc = a.t_root_cnllr[t];
-    const bool f32score = (fl & F_SCORE_F32) && a.t_root_f32[t];
+    const int smeas = ring_ptr(a.ring0.meas, a.ring_stride, kc)[s];
+    const double sx0 = a.x[s], sx1 = a.x[(size_t)a.cap + s], sx2 = a.x[(size_t)2 * a.cap + s], sx3 = a.x[(size_t)3 * a.cap + s];
+    const int j = p.j;
+    const int anc = (j > 0) ? a.apath[(size_t)(j - 1) * a.cap + s] : -1;
+    const bool f32score = (fl & F_SCORE_F32) && p.rootf;
     // getScore() (pyTarget.py:124) with NumPy scalar promotion: float32 - float32 stays float32
-    const double score = f32score ? (double)((float)cn - (float)rootc) : cn - rootc;
+    const double score = f32score ? (double)((float)cn - (float)p.rootc) : cn - p.rootc;
     int status = 0;
     if (isfinite(a.radar_range)) {
-        const double dx = a.x[s] - a.radar_x, dy = a.x[(size_t)a.cap + s] - a.radar_y;
+        const double dx = sx0 - a.radar_x, dy = sx1 - a.radar_y;
         if (sqrt(dx * dx + dy * dy) > a.radar_range) status = 1;                          // tracker.py:895
     }
     if (!status) {
@@ -684,15 +709,80 @@ __device__ __forceinline__ void finish_target(const BlpArgs& a, int t, int s) {
         if (per > a.score_limit) status = 2;                                                 // tracker.py:902
         else if (cn > a.cnllr_limit) status = 3;                                             // tracker.py:908
     }
-    const int dg = a.t_depth[t] + 1, w = a.t_window[t];
-    a.t_alive[t] = status;                 // 0 = alive, else the termination reason
-    a.t_jdrop[t] = dg > w ? dg - w : 0;    // layers the root advances (pyTarget.pruneDepth)
-    a.t_count[t] = 0;
-    a.t_firstsurv[t] = 0x7fffffff;
-    a.t_score[t] = score;
+    int rscan = p.rscan, rnode = p.rnode;
+    double rc = p.rootc;
+    uint8_t rf = p.rootf;
+    if (status == 0 && j > 0) {       // new root = the selected leaf's ancestor j levels below the old root
+        rscan += j;
+        rnode = anc;
+        const int kn = rscan % a.R;
+        rc = ring_ptr(a.ring0.cnllr, a.ring_stride, kn)[rnode];
+        rf = (ring_ptr(a.ring0.flags, a.ring_stride, kn)[rnode] & F_SCORE_F32) ? 1 : 0;
+    }
+    const int kr = rscan % a.R;
+    const double* rx = ring_ptr(a.ring0.x, a.ring_stride, kr);
+    const double rx0 = rx[rnode], rx1 = rx[(size_t)a.cap + rnode], rx2 = rx[(size_t)2 * a.cap + rnode], rx3 = rx[(size_t)3 * a.cap + rnode];
+    const int rmeas = ring_ptr(a.ring0.meas, a.ring_stride, kr)[rnode];
+    if (store) {
+        a.t_alive[t] = status;                 // 0 = alive, else the termination reason
+        a.t_jdrop[t] = j;
+        a.t_score[t] = score;
+        a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
+        mht_target_report& r = a.rec[t];
+        r.id = p.id;
+        r.status = status;
+        r.sel_node = s;
+        r.sel_meas = smeas;
+        r.root_scan = rscan;
+        r.root_node = rnode;
+        r.sel_x[0] = sx0; r.sel_x[1] = sx1; r.sel_x[2] = sx2; r.sel_x[3] = sx3;
+        r.sel_cnllr = cn;
+        r.score = score;
+        r.root_cnllr = rc;
+        r.root_x[0] = rx0; r.root_x[1] = rx1; r.root_x[2] = rx2; r.root_x[3] = rx3;
+        r.root_meas = rmeas;
+        r.cluster = p.lab;
+    }
+    return status ? KEY_DEAD : (j > 0 ? anc : KEY_ALL);
 }
 
-__device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds) {
+// N-scan pruning, child side (pyTarget.pruneDepth -> _pruneAllHypothesisExceptThis, pyTarget.py:330-356).  Survivors of a
+// target are one contiguous DFS range: only (first, count) are recorded.  One wavefront per target; `va0` is the
+// ancestor entry of the lane's child in the first chunk, fetched by the caller before the key was known.
+__device__ __forceinline__ int sweep_prefetch(const BlpArgs& a, int j, int cb, int ce, int lane) {
+    return (j > 0 && cb + lane < ce) ? a.apath[(size_t)(j - 1) * a.cap + cb + lane] : -1;
+}
+__device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, int cb, int ce, int key, int va0, int lane) {
+    int count = 0, first = 0x7fffffff;
+    if (key == KEY_ALL) {
+        count = ce - cb;
+        if (count > 0) first = cb;
+    } else if (key != KEY_DEAD) {
+        for (int c0 = cb; c0 < ce; c0 += 64) {
+            const int c = c0 + lane;
+            const int v = (c0 == cb) ? va0 : (c < ce ? a.apath[(size_t)(j - 1) * a.cap + c] : -1);
+            const unsigned long long m = __ballot(c < ce && v == key);
+            if (m && first == 0x7fffffff) first = c0 + __ffsll((long long)m) - 1;
+            count += __popcll(m);
+        }
+    }
+    if (lane == 0) { a.t_count[t] = count; a.t_firstsurv[t] = first; }
+}
+
+// surviving leaf ranges of the members of a cluster: one wavefront per target; key[k] = survival key from finish_target
+__device__ __forceinline__ void prune_members(const BlpArgs& a, const int32_t* mem, int K, const int32_t* key) {
+    if (!a.t_alive) return;
+    __threadfence_block();
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x >> 6; k < K; k += BLP_THREADS / 64) {
+        const int t = mem[k];
+        const int j = a.t_jdrop[t], cb = a.tchild[t], ce = a.tchild[t + 1];
+        sweep_survivors(a, t, j, cb, ce, key[k], sweep_prefetch(a, j, cb, ce, lane), lane);
+    }
+}
+
+__device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds) {
     const int tid = threadIdx.x;
     const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
     const int32_t* mem = a.cl_members + a.cl_ptr[c];
@@ -700,6 +790,9 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
     const int UW = (a.n_mnodes + 63) >> 6;
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = clock64();
+    TgtPre pre = {};      // per-member data of the prune epilogue, fetched now so that its latency hides behind the solve
+    const bool pre_ok = a.t_alive && K <= BLP_THREADS;
+    if (pre_ok && tid < K) pre = load_target(a, mem[tid]);
     // LDS carve: every block below is a multiple of 16 bytes and the dynamic segment starts at offset 0 (the kernel has
     // no static __shared__), so the 16-byte column records stay aligned without integer round trips -- those would
     // make the compiler lose the LDS address space and emit slow flat accesses.
@@ -830,7 +923,30 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
-            finish_target(a, mem[k], h);
+            if (a.t_alive) {
+                const TgtPre q = pre_ok ? pre : load_target(a, mem[k]);
+                s.ch[k] = finish_target(a, mem[k], h, q, true);
+                s.ub_sel[k] = q.j;             // the solver's tables are free now: prune depth, survivor count, first survivor
+                s.lix[k] = 0;
+                s.best_h[k] = 0x7fffffff;
+            }
+        }
+        if (a.t_alive) {
+            // surviving leaf ranges: one thread per column (= child), one ancestor look-up each, LDS counters per member
+            __syncthreads();
+            for (int h = tid; h < nH; h += BLP_THREADS) {
+                const int m = s.membL[h];
+                const int key = s.ch[m];
+                if (key == KEY_DEAD) continue;
+                const int g = s.gbase[m] + (h - s.colb[m]);
+                const bool sv = key == KEY_ALL || a.apath[(size_t)(s.ub_sel[m] - 1) * a.cap + g] == key;
+                if (sv) { atomicAdd(&s.lix[m], 1); atomicMin(&s.best_h[m], g); }
+            }
+            __syncthreads();
+            for (int k = tid; k < K; k += BLP_THREADS) {
+                a.t_count[mem[k]] = s.lix[k];
+                a.t_firstsurv[mem[k]] = s.best_h[k];
+            }
         }
     } else {
         // ---- same code on HBM scratch ----------------------------------------------------------------------------
@@ -845,9 +961,11 @@ __device__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, R
         solve_core(a, gs, K, r, status, iters, nodes, stamp);
         stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
-            a.sel[mem[k]] = gs.ub_sel[k];
-            finish_target(a, mem[k], gs.ub_sel[k]);
+            const int h = gs.ub_sel[k];
+            a.sel[mem[k]] = h;
+            if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
         }
+        prune_members(a, mem, K, gs.ch);
     }
     if (tid == 0) {
         a.cl_status[c] = status;
@@ -881,21 +999,27 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
     for (int i = gw; i < nSingle; i += gridDim.x * (BLP_THREADS / 64)) {
         const int t = a.single_list[i];
+        TgtPre pre = {};
+        int cb, ce;
+        if (a.t_alive) { pre = load_target(a, t); cb = pre.cb; ce = pre.ce; }
+        else { cb = a.tchild[t]; ce = a.tchild[t + 1]; }
         double bv = DINF;
         int bi = -1;
-        for (int h = a.tchild[t] + lane; h < a.tchild[t + 1]; h += 64) {
+        for (int h = cb + lane; h < ce; h += 64) {
             const double v = a.cnllr[h];
             if (bi < 0 || v <= bv) { bv = v; bi = h; }
         }
+        const int va0 = a.t_alive ? sweep_prefetch(a, pre.j, cb, ce, lane) : -1;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ov = __shfl_xor(bv, o);
             const int oi = __shfl_xor(bi, o);
             if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
         }
-        if (lane == 0) {
-            a.sel[t] = bi;
-            finish_target(a, t, bi);
+        if (lane == 0) a.sel[t] = bi;
+        if (a.t_alive) {      // wave-uniform: every lane evaluates the (broadcast) look-ups, lane 0 stores
+            const int key = finish_target(a, t, bi, pre, lane == 0);
+            sweep_survivors(a, t, pre.j, cb, ce, key, va0, lane);
         }
     }
 }

@@ -71,97 +71,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total)
     return s_scan[wv] + incl - v;
 }
 
-struct SurviveArgs {
-    const int32_t* ctgt; const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop;
-    int32_t* t_count; int32_t* t_firstsurv; const int32_t* path; const int32_t* apath; int cap; const DevStatus* status;
-    // per-target half (done here, in parallel with the child sweep, to keep the dependent parent walk off commit's
-    // critical path): new root of every target + the target's report record
-    TTable cur; LayerView layers[MAXR]; int R; int scan; const FCounts* cnt;
-    const double* t_score; const int32_t* t_label; mht_target_report* rec;
-    int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;   // [Tcap] walk results
-};
-
-// N-scan pruning, child side (pyTarget.pruneDepth -> _pruneAllHypothesisExceptThis, pyTarget.py:330-356): a new leaf
-// survives iff its target lives and it descends from the new root, i.e. shares the first `jdrop` path entries with the
-// selected leaf.  Survivors of a target are one contiguous DFS range: only (first, count) are recorded.
-__global__ __launch_bounds__(256) void survive_kernel(const SurviveArgs a) {
-    if (a.status->overflow) return;
-    const int nCh = a.status->n_children;
-    const int lane = threadIdx.x & 63;
-    // ---- target half: workgroups from the END of the grid take the targets, one thread each --------------------------
-    {
-        const int nT = a.cnt->nT;
-        const int t = (gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x;
-        if (t < nT) {
-            const LayerView& Lc = a.layers[a.scan % a.R];
-            const int s = a.sel[t];
-            const int st = a.t_status[t];
-            const int j = a.t_jdrop[t];
-            const int dg = a.cur.depth[t] + 1;
-            int rscan = a.cur.root_scan[t], rnode = a.cur.root_node[t];
-            double rc = a.cur.root_cnllr[t];
-            uint8_t rf = a.cur.root_f32[t];
-            // everything that does not depend on the walk is fetched first so that its latency overlaps the walk's
-            mht_target_report& r = a.rec[t];
-            const int id = a.cur.id[t], smeas = Lc.meas[s];
-            const double sx0 = Lc.x[s], sx1 = Lc.x[(size_t)a.cap + s], sx2 = Lc.x[(size_t)2 * a.cap + s], sx3 = Lc.x[(size_t)3 * a.cap + s];
-            const double scn = Lc.cnllr[s], sscore = a.t_score[t];
-            const int lab = a.t_label[t];
-            if (st == 0 && j > 0) {       // new root = the selected leaf's ancestor j levels below the old root
-                // (pyTarget.pruneDepth, pyTarget.py:343-356); the ancestor table makes it one lookup instead of a parent walk
-                const int sc = rscan + j;
-                const int node = a.apath[(size_t)(j - 1) * a.cap + s];
-                rscan = sc;
-                rnode = node;
-                rc = a.layers[sc % a.R].cnllr[node];
-                rf = (a.layers[sc % a.R].flags[node] & F_SCORE_F32) ? 1 : 0;
-            }
-            (void)dg;
-            a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
-            r.id = id;
-            r.status = st;
-            r.sel_node = s;
-            r.sel_meas = smeas;
-            r.root_scan = rscan;
-            r.root_node = rnode;
-            r.sel_x[0] = sx0; r.sel_x[1] = sx1; r.sel_x[2] = sx2; r.sel_x[3] = sx3;
-            r.sel_cnllr = scn;
-            r.score = sscore;
-            r.root_cnllr = rc;
-            const LayerView& Lr = a.layers[rscan % a.R];
-            for (int k = 0; k < 4; ++k) r.root_x[k] = Lr.x[(size_t)k * a.cap + rnode];
-            r.root_meas = Lr.meas[rnode];
-            r.cluster = lab;
-        }
-    }
-    for (int base = blockIdx.x * blockDim.x; base < nCh; base += gridDim.x * blockDim.x) {
-        const int c = base + threadIdx.x;
-        int sv = 0, t = -1;
-        if (c < nCh) {
-            t = a.ctgt[c];
-            sv = a.t_status[t] == 0;
-            if (sv) {
-                const int j = a.t_jdrop[t], s = a.sel[t];
-                for (int d = 0; d < j; ++d)
-                    if (a.path[(size_t)d * a.cap + c] != a.path[(size_t)d * a.cap + s]) { sv = 0; break; }
-            }
-        }
-        // wave-aggregated update: children of one target are contiguous, so most wavefronts see 1-3 targets
-        const int t0 = __shfl(t, 0);
-        const bool uniform = __all(t == t0 || c >= nCh);
-        if (uniform) {
-            const unsigned long long m = __ballot(sv);
-            if (m && lane == (int)(__ffsll((long long)m) - 1)) {
-                atomicAdd(&a.t_count[t], __popcll(m));
-                atomicMin(&a.t_firstsurv[t], c);
-            }
-        } else if (sv) {
-            atomicAdd(&a.t_count[t], 1);
-            atomicMin(&a.t_firstsurv[t], c);
-        }
-    }
-}
-
 struct CommitArgs {
     TTable cur, nxt;
     const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
@@ -547,6 +456,22 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->arena.off = 0;
     f->layout(f->arena);
     ctx->forest = f;
+    {   // the prune epilogue addresses layer k of the ring arithmetically: all layers must be laid out identically
+        const ptrdiff_t stride = reinterpret_cast<const char*>(f->layer[1].x) - reinterpret_cast<const char*>(f->layer[0].x);
+        bool ok = true;
+        for (int k = 1; k < f->R; ++k) {
+            const mht_nodes &l0 = f->layer[0], &lk = f->layer[k];
+            ok = ok && reinterpret_cast<const char*>(lk.x) - reinterpret_cast<const char*>(l0.x) == k * stride &&
+                 reinterpret_cast<const char*>(lk.cnllr) - reinterpret_cast<const char*>(l0.cnllr) == k * stride &&
+                 reinterpret_cast<const char*>(lk.meas) - reinterpret_cast<const char*>(l0.meas) == k * stride &&
+                 reinterpret_cast<const char*>(lk.flags) - reinterpret_cast<const char*>(l0.flags) == k * stride;
+        }
+        if (!ok) {
+            forest_destroy(ctx);
+            set_error("mht_forest_create: internal error, ring layers are not equally spaced");
+            return MHT_E_INVALID;
+        }
+    }
     MHT_HIP_CHECK(hipMemsetAsync(base, 0, total, ctx->stream));
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host), f->report_bytes, hipHostMallocDefault));
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
@@ -693,6 +618,12 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); b.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
+    b.apath = f->apath[s & 1]; b.R = f->R; b.scan = s;
+    b.ring0 = RingLayer{f->layer[0].x, f->layer[0].cnllr, f->layer[0].meas, f->layer[0].flags};
+    b.ring_stride = (size_t)(reinterpret_cast<const char*>(f->layer[1].x) - reinterpret_cast<const char*>(f->layer[0].x));   // layers are laid out identically, back to back
+    b.t_id = f->tab[cb].id; b.t_root_scan = f->tab[cb].root_scan; b.t_root_node = f->tab[cb].root_node; b.t_label = f->t_label;
+    b.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
+    b.w_root_scan = f->w_root_scan; b.w_root_node = f->w_root_node; b.w_root_cnllr = f->w_root_cnllr; b.w_root_f32 = f->w_root_f32;
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
@@ -702,19 +633,6 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     if (rc) return rc;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259): surviving leaf ranges, then target table / roots / report --------------
-    SurviveArgs sv = {};
-    sv.ctgt = f->ctgt; sv.sel = f->sel; sv.t_status = f->t_status; sv.t_jdrop = f->t_jdrop; sv.t_count = f->t_count;
-    sv.t_firstsurv = f->t_firstsurv; sv.path = f->path[s & 1]; sv.apath = f->apath[s & 1]; sv.cap = f->Ncap; sv.status = ctx->status;
-    sv.cur = f->tab[cb];
-    for (int k = 0; k < f->R; ++k) sv.layers[k] = view_of(f->layer[k]);
-    sv.R = f->R; sv.scan = s; sv.cnt = f->cnt; sv.t_score = f->t_score; sv.t_label = f->t_label;
-    sv.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
-    sv.w_root_scan = f->w_root_scan; sv.w_root_node = f->w_root_node; sv.w_root_cnllr = f->w_root_cnllr; sv.w_root_f32 = f->w_root_f32;
-    int sgrid = (f->L_ub > 0 ? 2 * f->L_ub + 255 : 256) / 256;
-    if (sgrid > 512) sgrid = 512;
-    if (sgrid < (f->nT_ub + 255) / 256 + 1) sgrid = (f->nT_ub + 255) / 256 + 1;      // enough workgroups for the target half
-    hipLaunchKernelGGL(survive_kernel, dim3(sgrid), dim3(256), 0, st, sv);
-    MHT_HIP_CHECK(hipGetLastError());
     CommitArgs p = {};
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
     p.sel = f->sel; p.t_status = f->t_status; p.t_jdrop = f->t_jdrop; p.t_count = f->t_count; p.t_firstsurv = f->t_firstsurv;

@@ -73,6 +73,8 @@ struct ClusterArgs {
     int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow
 };
 
+struct RingLayer { const double* x; const double* cnllr; const int32_t* meas; const uint8_t* flags; };   // one layer of the node ring
+
 struct BlpArgs {
     const int32_t* cl_ptr; const int32_t* cl_members; const int32_t* multi_list; const int32_t* single_list;
     const int32_t* counts;          // [1] = nMulti, [2] = nSingle
@@ -96,6 +98,12 @@ struct BlpArgs {
     const double* t_root_cnllr; const uint8_t* t_root_f32; const int32_t* t_depth; const int32_t* t_window;
     int32_t* t_alive; int32_t* t_jdrop; int32_t* t_count; int32_t* t_firstsurv; double* t_score;
     int Nwin; double score_limit, cnllr_limit, radar_x, radar_y, radar_range;
+    // N-scan prune per target (pyTarget.pruneDepth, pyTarget.py:343-356), done by whoever selected the target's leaf:
+    // new root (ancestor table look-up), the target's report record, the surviving leaf range (first, count)
+    const int32_t* apath; int R; int scan;
+    RingLayer ring0; size_t ring_stride;      // layer k of the ring: every array of ring0 advanced by k * ring_stride BYTES
+    const int32_t* t_id; const int32_t* t_root_scan; const int32_t* t_root_node; const int32_t* t_label;
+    mht_target_report* rec; int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
 };
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
