@@ -205,8 +205,9 @@ int mht_forest_report(mht_ctx* ctx, mht_scan_report* out);
 int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
                       int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
 /* Per-stage device time in milliseconds, SUMMED over the steps issued since the last call (at most 64 may be
- * pending): [0] grow (gate_count + emit kernels) = the reference's toc['Process'], [1] cluster, [2] optimise (ILP +
- * single-target selection), [3] terminate + N-scan prune, [4] whole step.  *n_steps = number of steps summed.
+ * pending): [0] grow kernel = the reference's toc['Process'], [1] cluster, [2] optimise (ILP + single-target selection,
+ * incl. the per-target termination test / prune decision / surviving leaf ranges), [3] commit (target-table compaction,
+ * next leaf ranges, report), [4] whole step.  *n_steps = number of steps summed.
  * Timing is off by default (five hipEventRecord per step); enable != 0 switches it on for subsequent steps.
  * Synchronises the stream. */
 int mht_forest_set_timing(mht_ctx* ctx, int32_t enable);

@@ -11,9 +11,10 @@
 //                  the rows of its ILP column (tracker.py:1042-1113) and the key for N-scan pruning.
 //   target table   id, window, depth below the root, root node/score -- double buffered, compacted on termination.
 //   assoc[T][AW]   bitsets = the reference's __associatedMeasurements__ (tracker.py:78), rebuilt every scan.
-// Per scan six launches on one stream, no memsets, no host round trip: gate_count, emit (mht_gate.hip), cluster
-// (mht_cluster.hip), blp (mht_blp.hip), survive + commit (here: track termination tracker.py:891-916 / :353-381, N-scan pruning tracker.py:1219-1231,
-// compaction of the leaf list and the target table, the scan report).
+// Per scan four launches on one stream, no memsets, no host round trip: grow (mht_gate.hip), cluster (mht_cluster.hip),
+// blp (mht_blp.hip: selection + per target the termination test tracker.py:891-916, the N-scan prune decision
+// pyTarget.py:343-356, the new root, the report record and the surviving leaf range) and commit (here: compaction of
+// the target table tracker.py:353-381 / :1219-1231, next scan's leaf ranges, the scan report).
 #include "mht_kernels.h"
 #include <string.h>
 #include <math.h>

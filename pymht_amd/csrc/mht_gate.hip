@@ -186,6 +186,16 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     }
 }
 
+// per-phase wall-clock stamps of every tile (tools/grow_profile.py): compiled in only with -DMHT_GROW_STAMPS, they cost
+// SGPRs (-> spills) and an LDS/SMEM drain per stamp
+#ifdef MHT_GROW_STAMPS
+#define GROW_STAMP_DECL unsigned long long ts[7]
+#define GROW_STAMP(k) ts[k] = wall_clock64()
+#else
+#define GROW_STAMP_DECL
+#define GROW_STAMP(k)
+#endif
+
 constexpr int SPIN_LIMIT = 1 << 23;     // look-back watchdog: x ~0.1 us per poll
 
 __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a) {
@@ -207,38 +217,43 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     const int L = a.t_leaf_off ? a.nT_dev[1] : a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     const float2* z2 = reinterpret_cast<const float2*>(a.z);
-    bool staged = false;
 
-    // Tiles are mapped statically (tile = blockIdx + k*gridDim, increasing per workgroup).  The launcher keeps the
-    // grid small enough to be fully co-resident on an otherwise idle GPU, so a workgroup spinning in the look-back only
-    // ever waits for tiles owned by workgroups that are running: no shared ticket word to serialise on.  If another
-    // resident grid (a second stream / process) takes the slots, a multi-round grid could wait for a workgroup that is
-    // not dispatched yet; the spins are bounded (SPIN_LIMIT, ~1 s) and a stall voids the scan with a loud error
+    // One tile per workgroup.  Static mapping (tile = blockIdx) whenever the whole grid is co-resident: a workgroup spinning
+    // in the look-back then only waits for workgroups that are running, and nothing serialises on a shared word.  A grid
+    // larger than the machine takes tile numbers from a ticket counter instead: whoever holds tile t is running and
+    // every tile < t was handed to a workgroup that started earlier, so the look-back cannot wait for an undispatched
+    // workgroup whatever the dispatch order.  (Looping over tiles inside a workgroup was measurably worse: everything
+    // loop invariant got hoisted, the kernel hit the 128-register budget and spilled 32 B of scratch per thread at
+    // entry -- ~7 MB of HBM writes per launch; without the loop it needs 80 registers and no scratch.)  Spins are
+    // bounded (SPIN_LIMIT, ~1 s): should another resident grid starve this one, the scan is voided with a loud error
     // instead of hanging the device.
     if (ntiles == 0 && blockIdx.x == 0 && tid == 0) {      // no leaves at all
         a.child_ptr[0] = 0;
         a.status->n_children = 0;
         if (a.tchild) a.tchild[0] = 0;
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int tile = blockIdx.x;
+    if (tile < ntiles && ntiles > a.max_resident) {      // (workgroups beyond the last tile leave without a ticket)
+        if (tid == 0) s_base = atomicAdd(a.ticket, 1);
         __syncthreads();
-        unsigned long long ts[7];
-        ts[0] = wall_clock64();
-        if (!staged) {
-            for (int j = tid; j < Mpad; j += GATE_THREADS) {
-                const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
-                zx[j] = v.x;
-                zy[j] = v.y;
-            }
-            if (a.t_leaf_off)
-                for (int j = tid; j <= nT; j += GATE_THREADS) {
-                    off[j] = a.t_leaf_off[j];
-                    if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
-                }
-            staged = true;
-            __syncthreads();
+        tile = s_base;
+        __syncthreads();
+    }
+    if (tile < ntiles) {
+        GROW_STAMP_DECL;
+        GROW_STAMP(0);
+        for (int j = tid; j < Mpad; j += GATE_THREADS) {
+            const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
+            zx[j] = v.x;
+            zy[j] = v.y;
         }
-        ts[1] = wall_clock64();
+        if (a.t_leaf_off)
+            for (int j = tid; j <= nT; j += GATE_THREADS) {
+                off[j] = a.t_leaf_off[j];
+                if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
+            }
+        __syncthreads();
+        GROW_STAMP(1);
         // ---- phase 1: predict + precalc, one leaf per lane -----------------------------------------------------
         if (tid < GATE_TILE) {
             const int i = tile * GATE_TILE + tid;
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             }
         }
         __syncthreads();
-        ts[2] = wall_clock64();
+        GROW_STAMP(2);
         // ---- phase 2: thread = (leaf of the tile, measurement stream): 32 leaves x 16 interleaved streams ----------------
         // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
         // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             }
         }
         __syncthreads();
-        ts[3] = wall_clock64();
+        GROW_STAMP(3);
         // ---- phase 3: child offsets: in-tile prefix + two-level prefix across tiles -------------------------------------
         // Every tile publishes its child count A[tile]; the last tile of each group of 64 also publishes the group sum
         // S[group].  A tile's base = sum of S over earlier groups + sum of A over earlier tiles of its own group: two
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             if (tid == 0) a.status->overflow = 2;
             return;
         }
-        ts[4] = wall_clock64();
+        GROW_STAMP(4);
         const int base = s_base, total = s_total;
         if (tid < GATE_TILE && lg[tid].valid) {
             const int i = tile * GATE_TILE + tid;
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             }
         }
         __syncthreads();
-        ts[5] = wall_clock64();
+        GROW_STAMP(5);
         // ---- phase 4: one thread per child -----------------------------------------------------------------------------
         for (int r = tid; r < ((a.ablate & 1) ? 0 : ((total + 63) & ~63)); r += GATE_THREADS) {
             int new_node = -1, tgt = -1;
@@ -450,6 +465,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 }
             }
         }
+#ifdef MHT_GROW_STAMPS
         if (a.dbg) {
             __syncthreads();
             if (tid == 0 && tile < 4000) {       // per-tile slots: no contention, stamps relative to the first tile's start are
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 a.dbg[32 + (size_t)tile * 8 + 7] = (unsigned long long)blockIdx.x;
             }
         }
+#endif
     }
 }
 
@@ -500,7 +517,12 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
             printed = true;
         }
     }
-    const int blocks = ntiles < max_blocks ? ntiles : max_blocks;
+    const int blocks = ntiles;
+    a.max_resident = max_blocks;                      // more tiles than that: dynamic tile numbers (see grow_kernel)
+    if (ntiles > max_blocks && !a.ticket) {           // stateless seam: ticket word behind the tile states, zeroed per call
+        a.ticket = reinterpret_cast<int32_t*>(a.group_state + ntiles / 64 + 4);
+        MHT_HIP_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(int32_t), ctx->stream));
+    }
     static size_t attr_bytes = 0;
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grow_kernel),

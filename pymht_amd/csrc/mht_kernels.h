@@ -15,6 +15,7 @@ struct GateArgs {
     const float* z; int M; int W;
     // cross-workgroup machinery of grow_kernel
     int32_t* ticket;              // tile ticket counter (zero at launch)
+    int max_resident;             // workgroups that are co-resident; with more tiles than that they are numbered by the ticket
     unsigned long long* tile_state;   // [ntiles] epoch-tagged child counts of the tiles
     unsigned long long* group_state;  // [ntiles/64] epoch-tagged sums over groups of 64 tiles
     unsigned epoch;

@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pymht_amd.device import Context, NodeLayer, make_model
 from pymht_amd import _lib
-sys.path.insert(0, 'oracle'); import mht_oracle as orc
-g = np.load('tests/golden/g5_headline.npz')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle')); import mht_oracle as orc
+g = np.load(os.path.join(ROOT, 'tests/golden/g5_headline.npz'))
 reps = [int(v) for v in sys.argv[1:]] or [1, 4, 16, 64, 256]
 ctx = Context(0); dev = ctx.device
 model = make_model(orc.model_Phi(2.5), orc.model_Q(2.5), orc.model_C(), orc.model_R(), 5.99, float(g['lambda_ex']), 0.9)
