@@ -486,7 +486,12 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
     double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
     int stall = 0;
     status = 0; iters = 0; nodes = 0;
-    for (int it = 0; it <= a.max_iter; ++it) {
+    // dual iterations: the LDS policy does its coordinate-ascent rounds and then goes straight to the branch and bound (the
+    // ascent is monotone, so its prices give a tight Lagrangian bound; on the rare clusters it does not certify -- two
+    // near-duplicate tracks sharing a measurement in every scan of the window zig-zag geometrically -- subgradient steps took
+    // up to ~100 more iterations where the branch and bound needs ~10 nodes); the HBM policy has subgradient steps only.
+    const int it_cap = coord_capable(s) ? (a.max_iter < CA_ROUNDS ? a.max_iter : CA_ROUNDS) : a.max_iter;
+    for (int it = 0; it <= it_cap; ++it) {
         iters = it;
         // A: per target the minimiser of the reduced cost (lowest column index wins ties)
         compute_minimisers(s, K, r);
@@ -514,7 +519,7 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         });
         double src = 0.0, sc = 0.0;
         for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
-        const bool coord = coord_capable(s) && it < CA_ROUNDS && it < a.max_iter;
+        const bool coord = coord_capable(s) && it < it_cap;
         if (coord) nominate(s, K);      // needs the usage counters only; published by the reduction's barriers
         {   // one fused block reduction for the six quantities
             const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
@@ -554,7 +559,7 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
                 }
             }
             if (UB - best_LB <= 1e-12 * fmax(1.0, fabs(UB))) { status = MHT_BLP_CERTIFIED; done = true; }   // zero duality gap
-            if (it == a.max_iter || nrm == 0.0) done = true;
+            if (it == it_cap || nrm == 0.0) done = true;
         }
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
         const double step = (done || coord) ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;

@@ -64,9 +64,11 @@ def test_gate_headline_shape_checksums(gpu_ctx, gold_dir):
     assert np.allclose(r["nllr"][-64:], g["nllr_tail"], rtol=0, atol=NLLR_ATOL)
 
 
-@pytest.mark.parametrize("n,M,seed", [(1, 0, 1), (0, 5, 2), (3, 1, 3), (700, 64, 4), (65, 65, 5), (129, 1000, 6), (33, 4096, 7)])
+@pytest.mark.parametrize("n,M,seed", [(1, 0, 1), (0, 5, 2), (3, 1, 3), (700, 64, 4), (65, 65, 5), (129, 1000, 6), (33, 4096, 7),
+                                      (20011, 48, 8)])      # > 512 tiles: more workgroups than are co-resident -> ticket-numbered tiles
 def test_gate_vs_oracle_random_shapes(gpu_ctx, n, M, seed):
-    """Edge shapes (empty scan, empty batch, ragged tiles, M at word boundaries, maximum M) vs the oracle."""
+    """Edge shapes (empty scan, empty batch, ragged tiles, M at word boundaries, maximum M, a grid larger than the machine)
+    vs the oracle."""
     rng = np.random.default_rng(seed)
     A, Q, Cm, R = orc.model_Phi(2.5), orc.model_Q(2.5), orc.model_C(), orc.model_R()
     gm = dict(A=A, Q=Q, C=Cm, R=R, eta2=5.99, lambda_ex=1.2e-4)
