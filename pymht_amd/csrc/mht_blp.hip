@@ -326,8 +326,9 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 // row is active iff all its users nominated it), so the step is a block-coordinate ascent: the dual bound never
 // decreases.  Priced rows nobody uses any more are lowered to just below the cheapest taker.  Nothing here affects
 // exactness: the certificate (no conflict, no priced-but-unused row) is what proves optimality, and clusters that are
-// not certified after CA_ROUNDS fall through to the subgradient steps and the branch and bound.
-constexpr int CA_ROUNDS = 8;
+// not certified after CA_ROUNDS go to the branch and bound.
+constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
+constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
 __device__ __forceinline__ bool coord_capable(const GStore&) { return false; }
 __device__ __forceinline__ bool coord_capable(const LStore&) { return true; }
 __device__ __forceinline__ void coordinate_step(const GStore&, int, bool, bool) {}
@@ -490,7 +491,8 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
     // ascent is monotone, so its prices give a tight Lagrangian bound; on the rare clusters it does not certify -- two
     // near-duplicate tracks sharing a measurement in every scan of the window zig-zag geometrically -- subgradient steps took
     // up to ~100 more iterations where the branch and bound needs ~10 nodes); the HBM policy has subgradient steps only.
-    const int it_cap = coord_capable(s) ? (a.max_iter < CA_ROUNDS ? a.max_iter : CA_ROUNDS) : a.max_iter;
+    const int ca_rounds = (K == 2) ? CA_ROUNDS_PAIR : CA_ROUNDS;
+    const int it_cap = coord_capable(s) ? (a.max_iter < ca_rounds ? a.max_iter : ca_rounds) : a.max_iter;
     for (int it = 0; it <= it_cap; ++it) {
         iters = it;
         // A: per target the minimiser of the reduced cost (lowest column index wins ties)

@@ -34,10 +34,11 @@ def test_kalman_kernels_bitwise(gold_dir):
         assert np.allclose(np.concatenate(r["nllr"]), k("nllr"), rtol=0, atol=5e-7)
 
 
-def test_blp_exact_matches_recorded_and_bruteforce(gold_dir):
-    g = np.load(os.path.join(gold_dir, "g4_ilp.npz"))
+@pytest.mark.parametrize("name,least", [("g4_ilp", 50), ("g7_ilp_hard", 30)])
+def test_blp_exact_matches_recorded_and_bruteforce(gold_dir, name, least):
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
     n = int(g["n_inst"])
-    assert n >= 50
+    assert n >= least
     for i in range(n):
         p = "i%03d_" % i
         ptr, rows = g[p + "col_ptr"], g[p + "col_rows"]
