@@ -1032,15 +1032,14 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
 }
 
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
-    static bool attr = false;
     if ((a.n_mnodes + 63) / 64 > BLP_UW) {
         set_error("blp: %d measurement nodes exceed the LDS bitset (%d)", a.n_mnodes, BLP_UW * 64);
         return MHT_E_CAPACITY;
     }
-    if (!attr) {
+    if (ctx->lds_attr_blp < BLP_LDS_BYTES) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLP_LDS_BYTES));
-        attr = true;
+        ctx->lds_attr_blp = BLP_LDS_BYTES;
     }
     hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), BLP_LDS_BYTES, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());

@@ -288,7 +288,7 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
 }
 
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
-    static size_t attr_bytes = 0;
+    size_t& attr_bytes = ctx->lds_attr_cluster;
     const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
     if (lds > 150 * 1024 || a.n_mnodes > 65536 || 3 * a.Tcap > CL_ELDS) {
         set_error("cluster: Tcap=%d and %d measurement nodes need %zu B of LDS (> 150 KiB)", a.Tcap, a.n_mnodes, lds);

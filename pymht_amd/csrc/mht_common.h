@@ -76,4 +76,6 @@ struct mht_ctx {
     unsigned gate_epoch = 0;
     mht::DevStatus* status = nullptr;   // device
     mht::Forest* forest = nullptr;
+    // dynamic-LDS limits already raised with hipFuncSetAttribute (per context: the attribute is per device)
+    size_t lds_attr_gate = 0, lds_attr_cluster = 0, lds_attr_blp = 0;
 };

@@ -523,7 +523,7 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
         a.ticket = reinterpret_cast<int32_t*>(a.group_state + ntiles / 64 + 4);
         MHT_HIP_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(int32_t), ctx->stream));
     }
-    static size_t attr_bytes = 0;
+    size_t& attr_bytes = ctx->lds_attr_gate;
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grow_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
