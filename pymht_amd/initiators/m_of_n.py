@@ -182,9 +182,7 @@ class Initiator:
         now = mlist.time
         z = np.array(mlist.measurements, ndmin=2, dtype=np.float32)[unused]
         seeds = np.array([s.value for s in self.initiators], ndmin=2, dtype=np.float32)
-        d = np.empty((n1, n2, 2))
-        for i in range(n1):
-            d[i] = z - seeds[i]
+        d = (z[None, :, :] - seeds[:, None, :]).astype(np.float64)      # float32 differences stored as float64, like the reference
         dist = np.linalg.norm(d, axis=2)
         pairs = gnn_assign(dist, self.v_max * (now - self.initiators[0].timestamp))
         taken = {unused[j] for _, j in pairs}

@@ -69,6 +69,7 @@ class Tracker():
         # Tracker storage (tracker.py:74-84): the forest lives on the device; the host keeps flat NumPy tables and
         # builds `Target` views only when somebody looks (properties __targetList__, __trackNodes__, ... below)
         self.__scanHistory__ = []
+        self._scan_times = np.zeros(256)     # time of scan k at index k (index 0 = before the first scan); grows by doubling
         self.__aisHistory__ = []
         self.trackIdCounter = 0
         # Timing and logging (tracker.py:86-101)
@@ -182,6 +183,9 @@ class Tracker():
         self.tic.clear()
         self.toc.clear()
         self.__scanHistory__.append(scanList)
+        if len(self.__scanHistory__) >= len(self._scan_times):
+            self._scan_times = np.concatenate([self._scan_times, np.zeros(len(self._scan_times))])
+        self._scan_times[len(self.__scanHistory__)] = float(scanList.time)
         self.__aisHistory__.append(aisList)
         scanTime = scanList.time
         scanNumber = len(self.__scanHistory__)
@@ -243,7 +247,7 @@ class Tracker():
         if moved.any():      # the root of these targets advanced: commit the new root to the history
             m = live[moved]
             rs = m["root_scan"].astype(np.int64)
-            times = np.array([self.__scanHistory__[k - 1].time if k >= 1 else 0.0 for k in rs])
+            times = self._scan_times[np.maximum(rs, 0)]
             self._history.append(dict(id=m["id"].astype(np.int64), scan=rs, node=m["root_node"].astype(np.int64),
                                       meas=m["root_meas"].astype(np.int64), x=m["root_x"].copy(),
                                       cnllr=m["root_cnllr"].copy(), time=times))
