@@ -14,28 +14,32 @@ namespace mht {
 
 
 constexpr int CL_THREADS = 1024;
-constexpr int CL_ELDS = 16384;     // edges kept in LDS (packed target<<16 | node); the rest spills to HBM scratch
+constexpr int CL_ELDS_MAX = 16384; // edges kept in LDS (packed target<<16 | node), fewer if the tables need the room (ClusterArgs::elds);
+                                   // the rest spills to HBM scratch
 
 __device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArgs& a, int e) {
-    if (e < CL_ELDS) return eL[e];
-    return ((unsigned)a.edge_t[e - CL_ELDS] << 16) | (unsigned)a.edge_m[e - CL_ELDS];
+    if (e < a.elds) return eL[e];
+    return ((unsigned)a.edge_t[e - a.elds] << 16) | (unsigned)a.edge_m[e - a.elds];
 }
 
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]
-    int* aux = tlabel + a.Tcap;                          // [Tcap]  cluster index of a head
-    int* mlabel = aux + a.Tcap;                          // [n_mnodes]
-    const int mslots = a.n_mnodes > 3 * a.Tcap + 2 ? a.n_mnodes : 3 * a.Tcap + 2;   // the slot is re-used for the cluster tables
-    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [CL_ELDS]
-    __shared__ int s_edges, s_changed, s_big, s_scan[CL_THREADS / 64], s_total;
+    int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]  union-find parent of a target
+    int* lab = tlabel + a.Tcap;                          // [Tcap]  final label = smallest target of the component
+    int* cnt = lab + a.Tcap;                             // [Tcap]  by head: members of its cluster
+    int* fill = cnt + a.Tcap;                            // [Tcap]  by head: member slots handed out
+    int* mlabel = fill + a.Tcap;                         // [n_mnodes] union-find parent of a measurement node
+    const int mslots = a.n_mnodes > 2 * a.Tcap ? a.n_mnodes : 2 * a.Tcap;   // re-used for the cluster tables afterwards
+    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [a.elds]
+    __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_scan2[CL_THREADS / 64], s_total, s_total2;
     const int tid = threadIdx.x;
     if (a.status && a.status->overflow) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
     const int T = *a.nT_dev;
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
-    for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = t;
-    if (tid == 0) { s_edges = 0; a.counts[3] = 0; }
+    for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
+    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = T + m;
+    if (tid == 0) { s_edges = 0; s_changed = 0; a.counts[3] = 0; }
     __syncthreads();
     int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
@@ -56,14 +60,14 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
         __syncthreads();
         E = s_segoff[EDGE_SEGS];
-        if (E > CL_ELDS + a.Ecap) { if (tid == 0) a.counts[3] = 1; E = CL_ELDS + a.Ecap; }
+        if (E > a.elds + a.Ecap) { if (tid == 0) a.counts[3] = 1; E = a.elds + a.Ecap; }
         // flat gather: thread -> dense edge index -> (segment, offset) by binary search over the 65 offsets
         for (int e = tid; e < E; e += CL_THREADS) {
             int lo = 0, hi = EDGE_SEGS;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_segoff[mid] <= e) lo = mid; else hi = mid; }
             const unsigned pk = a.edges_in[(size_t)lo * a.seg_cap + (e - s_segoff[lo])];
-            if (e < CL_ELDS) eL[e] = pk;
-            else { a.edge_t[e - CL_ELDS] = (int)(pk >> 16); a.edge_m[e - CL_ELDS] = (int)(pk & 0xffff); }
+            if (e < a.elds) eL[e] = pk;
+            else { a.edge_t[e - a.elds] = (int)(pk >> 16); a.edge_m[e - a.elds] = (int)(pk & 0xffff); }
         }
         __threadfence_block();
         __syncthreads();
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                     const int b = __ffsll((long long)bits) - 1;
                     bits &= bits - 1;
                     const int m = w * 64 + b;
-                    if (pos < CL_ELDS) eL[pos] = ((unsigned)t << 16) | (unsigned)m;
-                    else if (pos - CL_ELDS < a.Ecap) { a.edge_t[pos - CL_ELDS] = t; a.edge_m[pos - CL_ELDS] = m; }
+                    if (pos < a.elds) eL[pos] = ((unsigned)t << 16) | (unsigned)m;
+                    else if (pos - a.elds < a.Ecap) { a.edge_t[pos - a.elds] = t; a.edge_m[pos - a.elds] = m; }
                     ++pos;
                 }
             }
@@ -99,9 +103,9 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         __threadfence_block();
         __syncthreads();
         E = s_edges;
-        if (E > CL_ELDS + a.Ecap) {
+        if (E > a.elds + a.Ecap) {
             if (tid == 0) a.counts[3] = 1;
-            E = CL_ELDS + a.Ecap;
+            E = a.elds + a.Ecap;
         }
     }
     CL_STAMP(0);
@@ -111,8 +115,6 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     // reference's scipy labelling + np.where ordering implies (tracker.py:972-974).  One pass over the edges, one
     // compression pass: no iteration to a fixed point.
     int iters_done = 1;
-    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = T + m;
-    __syncthreads();
     auto parent_of = [&](int v) -> int { return v < T ? tlabel[v] : mlabel[v - T]; };
     auto find_root = [&](int v) -> int {
         int p = parent_of(v);
@@ -121,7 +123,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     };
     for (int e = tid; e < E; e += CL_THREADS) {
         const unsigned pk = cl_edge(eL, a, e);
-        int ra = find_root((int)(pk >> 16)), rb = find_root(T + (int)(pk & 0xffff));
+        const int et = (int)(pk >> 16), em = (int)(pk & 0xffff);
+        // most measurement nodes belong to one target only: the first edge of a node claims it with a single CAS
+        // (node still its own root -> child of that target); only further edges of the node need the generic union
+        if (atomicCAS(&mlabel[em], T + em, et) == T + em) continue;
+        int ra = find_root(et), rb = find_root(T + em);
         while (ra != rb) {
             if (ra > rb) { const int tmp = ra; ra = rb; rb = tmp; }      // ra < rb: hook rb under ra
             int* slot = rb < T ? &tlabel[rb] : &mlabel[rb - T];
@@ -134,143 +140,87 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     __syncthreads();
     for (int t = tid; t < T; t += CL_THREADS) {
         const int r = find_root(t);
-        aux[t] = r;                       // stash: writing tlabel here would race with other threads' find_root
+        lab[t] = r;                       // (writing tlabel here would race with other threads' find_root)
+        atomicAdd(&cnt[r], 1);
     }
-    __syncthreads();
-    for (int t = tid; t < T; t += CL_THREADS) tlabel[t] = aux[t];
-    __syncthreads();
-    CL_STAMP(1);
-    if (a.dbg && tid == 0) a.dbg[6] = iters_done;
-    if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back
+    if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back (edge list still intact)
         for (int e = tid; e < E; e += CL_THREADS) {
             const unsigned pk = cl_edge(eL, a, e);
             rows[(size_t)(pk >> 16) * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
         }
         if (tid < EDGE_SEGS) a.edge_count[tid] = 0;
     }
+    __syncthreads();
+    CL_STAMP(1);
+    if (a.dbg && tid == 0) a.dbg[6] = iters_done;
     CL_STAMP(2);
-    // heads -> cluster indices (exclusive scan over targets, chunked)
-    int running = 0;
+    // heads -> cluster index (scan of the head flags) and cluster offset (scan of the head's member count), one pass
+    int* cidx = mlabel;                  // [T] by head; the measurement parents are dead by now
+    int* cstart = mlabel + a.Tcap;       // [T] by head
+    int running = 0, running2 = 0;
     for (int base = 0; base < T; base += CL_THREADS) {
         const int t = base + tid;
-        const int head = (t < T && tlabel[t] == t) ? 1 : 0;
-        int incl = head;
+        const int head = (t < T && lab[t] == t) ? 1 : 0;
+        const int sz = head ? cnt[t] : 0;
+        int incl = head, incl2 = sz;
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
+            const int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
+            if (lane >= o) { incl += v; incl2 += v2; }
         }
-        if (lane == 63) s_scan[wv] = incl;
+        if (lane == 63) { s_scan[wv] = incl; s_scan2[wv] = incl2; }
         __syncthreads();
         if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < CL_THREADS / 64; ++i) { const int v = s_scan[i]; s_scan[i] = acc; acc += v; }
-            s_total = acc;
+            int acc = 0, acc2 = 0;
+            for (int i = 0; i < CL_THREADS / 64; ++i) {
+                const int v = s_scan[i], v2 = s_scan2[i];
+                s_scan[i] = acc; s_scan2[i] = acc2;
+                acc += v; acc2 += v2;
+            }
+            s_total = acc; s_total2 = acc2;
         }
         __syncthreads();
-        if (head) aux[t] = running + s_scan[wv] + incl - 1;     // cluster index of head t
-        running += s_total;
-        __syncthreads();
-    }
-    const int nC = running;
-    CL_STAMP(3);
-    // cluster sizes and offsets in LDS (csize/cptr alias the measurement-label array, which is dead by now)
-    int* csize = mlabel;                 // [nC]
-    int* cptr = mlabel + a.Tcap;         // [nC+1]
-    int* mheads = mlabel + 2 * a.Tcap + 1;   // [<= nC] heads of the multi-target clusters
-    for (int c = tid; c < nC; c += CL_THREADS) csize[c] = 0;
-    if (tid == 0) { s_edges = 0; s_changed = 0; s_big = 0; }
-    __syncthreads();
-    for (int t = tid; t < T; t += CL_THREADS) {
-        a.t_label[t] = tlabel[t];
-        a.t_cluster[t] = aux[tlabel[t]];
-        atomicAdd(&csize[aux[tlabel[t]]], 1);
-    }
-    __syncthreads();
-    running = 0;
-    for (int base = 0; base < nC; base += CL_THREADS) {       // exclusive scan of the sizes
-        const int c = base + tid;
-        const int v = (c < nC) ? csize[c] : 0;
-        int incl = v;
-        const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
-        }
-        if (lane == 63) s_scan[wv] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < CL_THREADS / 64; ++i) { const int x = s_scan[i]; s_scan[i] = acc; acc += x; }
-            s_total = acc;
-        }
-        __syncthreads();
-        if (c < nC) {
-            const int p0 = running + s_scan[wv] + incl - v;
-            cptr[c] = p0;
+        if (head) {
+            const int c = running + s_scan[wv] + incl - 1, p0 = running2 + s_scan2[wv] + incl2 - sz;
+            cidx[t] = c;
+            cstart[t] = p0;
             a.cl_ptr[c] = p0;
         }
         running += s_total;
+        running2 += s_total2;
         __syncthreads();
     }
-    if (tid == 0) { cptr[nC] = running; a.cl_ptr[nC] = running; }
+    const int nC = running;
+    if (tid == 0) a.cl_ptr[nC] = running2;
+    CL_STAMP(3);
     CL_STAMP(4);
-    // per-cluster linked lists of the non-head members (push order is arbitrary, the lists are sorted below)
-    // (the three tables live in the LDS edge list, which is dead by now; 3*Tcap <= CL_ELDS is checked at launch)
-    int* lhead = reinterpret_cast<int*>(eL);   // [T] first list element of the cluster headed by t, -1 = none
-    int* lnext = lhead + a.Tcap;               // [T]
-    int* tmp = lnext + a.Tcap;                 // [T] scratch: every cluster owns the segment [cptr[c], cptr[c+1])
-    for (int t = tid; t < T; t += CL_THREADS) lhead[t] = -1;
-    __syncthreads();
+    // work lists (heads of multi-target clusters -> blp_kernel's ILPs, targets alone in their cluster) and the member lists
+    // in ascending target order: every member takes a slot of its cluster's segment with an LDS atomic (arbitrary order),
+    // then finds its rank by counting the smaller members -- O(cluster size) per thread, all targets in parallel.
+    // (the scratch lives in the LDS edge list, which is dead by now; Tcap <= elds is checked at launch)
+    int* tmp = reinterpret_cast<int*>(eL);     // [T] every cluster owns the segment [cstart, cstart + cnt)
     for (int t = tid; t < T; t += CL_THREADS) {
-        const int r = tlabel[t];
-        if (r != t) lnext[t] = atomicExch(&lhead[r], t);
-    }
-    __syncthreads();
-    // work lists: heads of multi-target clusters (solved by blp_kernel), targets alone in their cluster; the members of a
-    // multi-target cluster are collected by its head, sorted ascending (insertion sort in LDS: clusters are small) and
-    // written out; clusters with more than 64 members are left to the wavefront sweep below
-    for (int t = tid; t < T; t += CL_THREADS) {
-        const int c = aux[tlabel[t]];
-        const int K = csize[c];
+        const int h = lab[t];
+        const int c = cidx[h], base = cstart[h], K = cnt[h];
+        a.t_label[t] = h;
+        a.t_cluster[t] = c;
         if (K == 1) {
-            a.cl_members[cptr[c]] = t;
+            a.cl_members[base] = t;
             a.single_list[atomicAdd(&s_changed, 1)] = t;
-        } else if (tlabel[t] == t) {
-            a.multi_list[atomicAdd(&s_edges, 1)] = c;
-            if (K <= 64) {
-                int* seg = tmp + cptr[c];
-                seg[0] = t;                               // the head is the smallest member
-                int n = 1;
-                for (int q = lhead[t]; q >= 0 && n < K; q = lnext[q]) {
-                    int pos = n++;
-                    while (pos > 1 && seg[pos - 1] > q) { seg[pos] = seg[pos - 1]; --pos; }
-                    seg[pos] = q;
-                }
-                for (int k = 0; k < K; ++k) a.cl_members[cptr[c] + k] = seg[k];
-            } else {
-                mheads[atomicAdd(&s_big, 1)] = t;
-            }
+        } else {
+            tmp[base + atomicAdd(&fill[h], 1)] = t;
+            if (h == t) a.multi_list[atomicAdd(&s_edges, 1)] = c;
         }
     }
     __syncthreads();
-    {   // big clusters: one wavefront per cluster sweeps the labels in ascending order
-        const int lane = tid & 63, wv = tid >> 6;
-        const int nB = s_big;
-        for (int i = wv; i < nB; i += CL_THREADS / 64) {
-            const int l = mheads[i];
-            const int base = cptr[aux[l]];
-            int run = 0;
-            for (int t0 = l & ~63; t0 < T; t0 += 64) {
-                const int t = t0 + lane;
-                const bool m = t < T && tlabel[t] == l;
-                const unsigned long long bal = __ballot(m);
-                if (m) a.cl_members[base + run + __popcll(bal & ((1ull << lane) - 1ull))] = t;
-                run += __popcll(bal);
-            }
-        }
+    for (int t = tid; t < T; t += CL_THREADS) {
+        const int h = lab[t];
+        const int base = cstart[h], K = cnt[h];
+        if (K == 1) continue;
+        int rank = 0;
+        for (int i = 0; i < K; ++i) rank += (tmp[base + i] < t) ? 1 : 0;
+        a.cl_members[base + rank] = t;
     }
     CL_STAMP(5);
     if (a.dbg && tid == 0) a.dbg[7] = E;
@@ -282,16 +232,28 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
 }
 
+constexpr size_t CL_LDS_BUDGET = 150 * 1024;
+// LDS edge-list capacity for a given table size: what is left of the budget, at most CL_ELDS_MAX; < Tcap = does not fit
+int cluster_elds(int Tcap, int n_mnodes) {
+    const size_t mslots = n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap;
+    const size_t tables = ((size_t)4 * Tcap + mslots) * 4;
+    if (tables >= CL_LDS_BUDGET) return 0;
+    const size_t room = (CL_LDS_BUDGET - tables) / 4;
+    return (int)(room < (size_t)CL_ELDS_MAX ? room : (size_t)CL_ELDS_MAX);
+}
 size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
-    const int mslots = n_mnodes > 3 * Tcap + 2 ? n_mnodes : 3 * Tcap + 2;
-    return (size_t)(2 * Tcap + mslots + CL_ELDS) * 4;
+    const size_t mslots = n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap;
+    return ((size_t)4 * Tcap + mslots + (size_t)cluster_elds(Tcap, n_mnodes)) * 4;
 }
 
-int launch_cluster(mht_ctx* ctx, const ClusterArgs& a) {
+int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in) {
+    ClusterArgs a = a_in;
     size_t& attr_bytes = ctx->lds_attr_cluster;
+    a.elds = cluster_elds(a.Tcap, a.n_mnodes);
     const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
-    if (lds > 150 * 1024 || a.n_mnodes > 65536 || 3 * a.Tcap > CL_ELDS) {
-        set_error("cluster: Tcap=%d and %d measurement nodes need %zu B of LDS (> 150 KiB)", a.Tcap, a.n_mnodes, lds);
+    if (a.elds < a.Tcap || a.elds < 1024 || a.n_mnodes > 65536) {
+        set_error("cluster: Tcap=%d and %d measurement nodes do not fit the clustering kernel's LDS budget (%zu KiB)", a.Tcap, a.n_mnodes,
+                  CL_LDS_BUDGET / 1024);
         return MHT_E_CAPACITY;
     }
     if (lds > 48 * 1024 && lds > attr_bytes) {

@@ -478,7 +478,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
     memset(f->report_host, 0, f->report_bytes);
     // cluster-kernel LDS budget check up front
-    if ((size_t)(2 * f->Tcap + f->n_mnodes) * 4 > 150 * 1024) {
+    if (cluster_elds(f->Tcap, f->n_mnodes) < f->Tcap || cluster_elds(f->Tcap, f->n_mnodes) < 1024) {
         set_error("mht_forest_create: max_targets=%d with %d measurement nodes exceeds the clustering kernel's LDS budget",
                   f->Tcap, f->n_mnodes);
         forest_destroy(ctx);

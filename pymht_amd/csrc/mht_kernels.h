@@ -56,6 +56,7 @@ struct ClusterArgs {
     const int32_t* nT_dev;
     int Tcap;
     int32_t* edge_t; int32_t* edge_m; int Ecap;
+    int elds;                          // edges kept in LDS (set by launch_cluster); the rest spills to edge_t / edge_m
     int n_mnodes;                      // R * Mpad
     const DevStatus* status;           // forest mode: per-scan status word (overflow => do nothing)
     int32_t* dbg;                      // development only: [8] wall-clock ticks at phase boundaries
@@ -110,6 +111,8 @@ struct BlpArgs {
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 void fill_model(GateArgs& a, const mht_model* m);
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
+size_t cluster_lds_bytes(int Tcap, int n_mnodes);
+int cluster_elds(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
 void forest_destroy(mht_ctx* ctx);
 
