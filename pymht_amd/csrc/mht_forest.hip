@@ -24,7 +24,7 @@
 namespace mht {
 
 constexpr int MAXR = 16;
-constexpr int PRUNE_THREADS = 1024;
+constexpr int PRUNE_THREADS = 512;
 constexpr int EV_POOL = 64;
 
 struct FCounts {          // device-side counters of the forest
@@ -52,26 +52,6 @@ struct ReportHeader {     // device image of mht_scan_report up to the host poin
         blp_iters_max, error, used_words, pad[3];
 };
 
-__device__ __forceinline__ int block_excl_scan(int v, int* s_scan, int* s_total) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(incl, o);
-        if (lane >= o) incl += u;
-    }
-    __syncthreads();
-    if (lane == 63) s_scan[wv] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < PRUNE_THREADS / 64; ++i) { const int t = s_scan[i]; s_scan[i] = acc; acc += t; }
-        *s_total = acc;
-    }
-    __syncthreads();
-    return s_scan[wv] + incl - v;
-}
-
 struct CommitArgs {
     TTable cur, nxt;
     const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
@@ -87,7 +67,7 @@ struct CommitArgs {
 // Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
 // roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
 __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) {
-    __shared__ int s_scan[PRUNE_THREADS / 64], s_total, s_branched, s_limit, s_itmax;
+    __shared__ int s_scan[PRUNE_THREADS / 64], s_scan2[PRUNE_THREADS / 64], s_total, s_total2, s_branched, s_limit, s_itmax;
     const int tid = threadIdx.x;
     if (a.status->overflow || a.cnt->overflow) {        // void scan: report the error, leave the forest alone (it must be recreated)
         if (tid == 0) {
@@ -101,42 +81,65 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
     }
     const int nT = a.cnt->nT;
     const int nCh = a.status->n_children;
+    // everything below that does not depend on the scans is fetched first, so its latency overlaps their barriers
+    const int nC = a.cl_counts[0], n_ilp = a.cl_counts[1], e_over = a.cl_counts[3], L_in = a.cur.leaf_off[nT];
     if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
-    __syncthreads();
     int running = 0, lrun = 0;
     for (int base = 0; base < nT; base += PRUNE_THREADS) {
         const int t = base + tid;
-        const int al = (t < nT) ? (a.t_status[t] == 0) : 0;
-        const int cntl = al ? a.t_count[t] : 0;
-        const int pos = running + block_excl_scan(al, s_scan, &s_total);
+        const bool in = t < nT;
+        const int al = in ? (a.t_status[t] == 0) : 0;
+        const int cntl = in ? a.t_count[t] : 0, j = in ? a.t_jdrop[t] : 0, first = in ? a.t_firstsurv[t] : 0;
+        const int id = in ? a.cur.id[t] : 0, win = in ? a.cur.window[t] : 0, dep = in ? a.cur.depth[t] : 0;
+        const int rs = in ? a.w_root_scan[t] : 0, rn = in ? a.w_root_node[t] : 0;
+        const double rc = in ? a.w_root_cnllr[t] : 0.0;
+        const uint8_t rf = in ? a.w_root_f32[t] : 0;
+        const int leaves = al ? cntl : 0;
+        // one block scan for both the compacted target index and the leaf offset
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = al, incl2 = leaves;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o), u2 = __shfl_up(incl2, o);
+            if (lane >= o) { incl += u; incl2 += u2; }
+        }
+        if (lane == 63) { s_scan[wv] = incl; s_scan2[wv] = incl2; }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, acc2 = 0;
+            for (int i = 0; i < PRUNE_THREADS / 64; ++i) {
+                const int v = s_scan[i], v2 = s_scan2[i];
+                s_scan[i] = acc; s_scan2[i] = acc2;
+                acc += v; acc2 += v2;
+            }
+            s_total = acc; s_total2 = acc2;
+        }
+        __syncthreads();
+        const int pos = running + s_scan[wv] + incl - al, lpos = lrun + s_scan2[wv] + incl2 - leaves;
         running += s_total;
-        __syncthreads();
-        const int lpos = lrun + block_excl_scan(cntl, s_scan, &s_total);
-        lrun += s_total;
-        __syncthreads();
-        if (t < nT) {
-            const int j = a.t_jdrop[t];
+        lrun += s_total2;
+        if (in) {
             mht_target_report& r = a.rec[t];
             r.new_index = al ? pos : -1;
-            r.n_leaves = cntl;
+            r.n_leaves = leaves;
             a.new_index[t] = al ? pos : -1;
             if (al) {
-                a.nxt.id[pos] = a.cur.id[t];
-                a.nxt.window[pos] = a.cur.window[t];
-                a.nxt.depth[pos] = a.cur.depth[t] + 1 - j;
+                a.nxt.id[pos] = id;
+                a.nxt.window[pos] = win;
+                a.nxt.depth[pos] = dep + 1 - j;
                 a.nxt.shift[pos] = j;
-                a.nxt.root_scan[pos] = a.w_root_scan[t];
-                a.nxt.root_node[pos] = a.w_root_node[t];
-                a.nxt.root_cnllr[pos] = a.w_root_cnllr[t];
-                a.nxt.root_f32[pos] = a.w_root_f32[t];
-                a.nxt.first[pos] = a.t_firstsurv[t];
+                a.nxt.root_scan[pos] = rs;
+                a.nxt.root_node[pos] = rn;
+                a.nxt.root_cnllr[pos] = rc;
+                a.nxt.root_f32[pos] = rf;
+                a.nxt.first[pos] = first;
                 a.nxt.leaf_off[pos] = lpos;
             }
         }
+        if (base + PRUNE_THREADS < nT) __syncthreads();      // s_scan is re-used by the next chunk
     }
     const int nAlive = running, Lnext = lrun;
     // ILP statistics
-    const int nC = a.cl_counts[0];
     for (int c = tid; c < nC; c += PRUNE_THREADS) {
         const int st = a.cl_status[c];
         if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
@@ -158,17 +161,17 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
         h.scan = a.scan;
         h.n_targets = nT;
         h.n_alive = nAlive;
-        h.n_leaves_in = a.cur.leaf_off[nT];
+        h.n_leaves_in = L_in;
         h.n_children = nCh;
         h.n_leaves_out = Lnext;
         h.n_clusters = nC;
-        h.n_ilp = a.cl_counts[1];
+        h.n_ilp = n_ilp;
         h.n_branched = s_branched;
         h.n_limit = s_limit;
         h.blp_iters_max = s_itmax;
-        h.error = (a.status->overflow || a.cnt->overflow || a.cl_counts[3]) ? MHT_E_CAPACITY : 0;
+        h.error = (a.status->overflow || a.cnt->overflow || e_over) ? MHT_E_CAPACITY : 0;
         h.used_words = a.W;
-        a.cnt->L_in = a.cur.leaf_off[nT];
+        a.cnt->L_in = L_in;
         a.cnt->n_children = nCh;
         a.cnt->nT = nAlive;
         a.cnt->L = Lnext;
