@@ -252,6 +252,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 off[j] = a.t_leaf_off[j];
                 if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
             }
+        for (int w = tid; w < GATE_TILE * W; w += GATE_THREADS) hw[w] = 0ull;      // hit masks of phase 2
         __syncthreads();
         GROW_STAMP(1);
         // ---- phase 1: predict + precalc, one leaf per lane -----------------------------------------------------
@@ -302,8 +303,6 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
         // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
         // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
         // reference-order NIS and sets its bit in the leaf's hit mask (LDS atomicOr; hits are rare: ~1 per leaf).
-        for (int w = tid; w < GATE_TILE * W; w += GATE_THREADS) hw[w] = 0ull;
-        __syncthreads();
         if (!(a.ablate & 4)) {
             const int l = tid & (GATE_TILE - 1), stream = tid / GATE_TILE;
             const LeafLds& g = lg[l];
@@ -328,14 +327,11 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < GATE_TILE * W; idx += GATE_THREADS) {       // hits per leaf; stateless seam: used mask
-            const unsigned long long word = hw[idx];
-            if (word) {
-                atomicAdd(&lg[idx / W].cnt, __popcll(word));
-                if (a.used) atomicOr(&a.used[idx % W], word);
+        if (a.used)                                                           // stateless seam: used-measurement mask
+            for (int idx = tid; idx < GATE_TILE * W; idx += GATE_THREADS) {
+                const unsigned long long word = hw[idx];
+                if (word) atomicOr(&a.used[idx % W], word);
             }
-        }
-        __syncthreads();
         GROW_STAMP(3);
         // ---- phase 3: child offsets: in-tile prefix + two-level prefix across tiles -------------------------------------
         // Every tile publishes its child count A[tile]; the last tile of each group of 64 also publishes the group sum
@@ -344,7 +340,11 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
         // because all tiles arrive at the same time).  Words carry {epoch, value} in one 64-bit agent-scope atomic:
         // the data is the flag, stale epochs read as "not yet".
         if (wave == 0) {
-            int mine = (lane < GATE_TILE && lg[lane].valid) ? 1 + lg[lane].cnt : 0;
+            int hits = 0;                                                     // hits of this lane's leaf (no separate counting phase)
+            if (lane < GATE_TILE)
+                for (int w = 0; w < W; ++w) hits += __popcll(hw[(size_t)lane * W + w]);
+            if (lane < GATE_TILE) lg[lane].cnt = hits;
+            int mine = (lane < GATE_TILE && lg[lane].valid) ? 1 + hits : 0;
             int incl = mine;
 #pragma unroll
             for (int o = 1; o < GATE_TILE; o <<= 1) {

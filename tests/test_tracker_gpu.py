@@ -13,6 +13,19 @@ pytestmark = pytest.mark.gpu
 SCORE_ATOL = 2e-5
 
 
+def states_close(a, b, rel=1e-6):
+    """The north star's state tolerance against a LIVE oracle (another host's BLAS kernels may differ in the last bit, one
+    float32 ulp for initiator-born float32 chains): 1e-6 relative to the largest component of each state vector -- a
+    velocity near zero carries the rounding of the ~1e2..1e3 m positions it was differenced from."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    if a.size == 0:
+        return True
+    scale = np.maximum(np.abs(a).max(axis=1, keepdims=True), 1.0)
+    return bool(np.all(np.abs(a - b) <= rel * scale))
+
+
 def make_tracker(period, lambda_phi, lambda_nu, P_d, N, eta2, x0, t0, **kw):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
@@ -61,14 +74,22 @@ def test_tracker_replays_reference_trace(name, gold_dir):
     trk.close()
 
 
-def test_tracker_vs_oracle_fresh_scenario():
-    """A scenario that is in no fixture: oracle and device forest side by side, scan by scan."""
+@pytest.mark.parametrize("N,P_d,period,eta2,lam,seed", [
+    (4, 0.85, 2.5, 5.99, 3e-5, 99),
+    (1, 0.95, 2.5, 5.99, 3e-5, 7),        # window of one scan: the root advances every scan
+    (2, 0.60, 1.0, 9.21, 2e-5, 8),        # low detection probability, wide gate, fast radar
+    (6, 0.90, 4.0, 4.61, 4e-5, 9),        # slow radar, narrow gate
+    (8, 0.80, 2.5, 5.99, 1.5e-5, 10),     # paths of 9 rows: every cluster takes the ILP kernel's HBM policy
+])
+def test_tracker_vs_oracle_fresh_scenario(N, P_d, period, eta2, lam, seed):
+    """Scenarios that are in no fixture (other windows, detection probabilities, radar periods, gate sizes): oracle and device
+    forest side by side, scan by scan."""
     from pymht_amd.utils.scenario import make_scenario
     from pymht_amd.utils.classDefinitions import MeasurementList
-    sc = make_scenario(T=40, radius=500.0, lambda_phi=3e-5, n_scans=14, P_d=0.85, seed=99)
-    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=4, eta2=5.99,
+    sc = make_scenario(T=40, radius=500.0, lambda_phi=lam, n_scans=14, P_d=P_d, period=period, seed=seed)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2,
              x0=sc["x0"], t0=sc["t0"], accepted=None)
-    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], 4, 5.99, sc["x0"], sc["t0"])
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], N, eta2, sc["x0"], sc["t0"])
     g["accepted"] = acc
     o = make_oracle(g)
     assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__]
@@ -82,14 +103,14 @@ def test_tracker_vs_oracle_fresh_scenario():
         assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__], k
         os_, ts = o.selected(), tracker_selected(trk)
         assert np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]), k
-        assert np.allclose(os_["x"], ts["x"], rtol=1e-6, atol=1e-9) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL)
+        assert states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL), k
         assert len(o.clusters) == len(trk.__clusterList__)
         lb, tb = o.leaf_batch(), trk.leafBatch()
         assert np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]), k
-        assert np.allclose(lb["x"], tb["x"], rtol=1e-6, atol=1e-9)
+        assert states_close(lb["x"], tb["x"]), k
         n_ilp += o.n_ilp
         assert o.n_ilp == trk.nOptimSolved
-    assert n_ilp > 0
+    assert n_ilp > 0 or N == 1
     # the selected leaf's ancestor chain (lazy `parent` through the device ring) matches the oracle's history
     for n_o, n_t in zip(o.track_nodes, trk.getTrackNodes()):
         h = n_o.history_meas()
