@@ -67,6 +67,13 @@ def load(build_if_missing=True):
                 raise
     if not os.path.exists(LIB_PATH):
         raise ImportError("libmht_amd.so is missing (%s); run `python -m pymht_amd.build`" % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  If libmht_amd.so is loaded first it pulls in
+    # /opt/rocm's copy, a later `import torch` then brings a second runtime into the process and one of the two reports
+    # "no ROCm-capable device".  Importing torch first makes both resolve to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.mht_last_error.restype = C.c_char_p
     lib.mht_abi_version.restype = C.c_int

@@ -26,7 +26,8 @@ def build_library(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc] + FLAGS + srcs + ["-o", LIB]
+    extra = os.environ.get("MHT_EXTRA_HIPCC_FLAGS", "").split()      # development: e.g. -DMHT_GROW_STAMPS (tools/grow_profile.py)
+    cmd = [hipcc] + FLAGS + extra + srcs + ["-o", LIB]
     if verbose:
         print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

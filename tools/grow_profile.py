@@ -1,4 +1,5 @@
-"""Development aid: per-tile phase stamps of grow_kernel in forest mode on the headline config (MHT_GROW_DEBUG=1)."""
+"""Development aid: per-tile phase stamps of grow_kernel in forest mode on the headline config.  Needs a library built with
+MHT_EXTRA_HIPCC_FLAGS=-DMHT_GROW_STAMPS (python -m pymht_amd.build --force); rebuild without it afterwards."""
 import ctypes as C, os, sys
 os.environ["MHT_GROW_DEBUG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +16,7 @@ for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     if k < 11: continue
     a = np.zeros(32 + 8 * 4000, dtype=np.uint64)
     _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"grow_dbg", a.ctypes.data_as(C.c_void_p), a.nbytes))
-    nt = (trk.lastScanStats['L'] + 15) // 16
+    nt = (trk.lastScanStats["L"] + 31) // 32
     ts = a[32:32 + 8 * nt].reshape(nt, 8).astype(np.int64)
     t0 = ts[:, 0].min()
     rel = (ts[:, :7] - t0) / 100.0
