@@ -22,15 +22,32 @@ def _stale():
 
 
 def build_library(force=False, verbose=True):
+    """Compile the library if it is missing or older than its sources.  Safe under concurrent callers (one process per
+    GPU all importing the package at once): an exclusive file lock serialises them, the second one finds a fresh library;
+    the output is written to a temporary file and renamed, so a reader never sees a half-written .so."""
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    extra = os.environ.get("MHT_EXTRA_HIPCC_FLAGS", "").split()      # development: e.g. -DMHT_GROW_STAMPS (tools/grow_profile.py)
-    cmd = [hipcc] + FLAGS + extra + srcs + ["-o", LIB]
-    if verbose:
-        print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            hipcc = os.environ.get("HIPCC", "hipcc")
+            srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+            extra = os.environ.get("MHT_EXTRA_HIPCC_FLAGS", "").split()      # development: e.g. -DMHT_GROW_STAMPS (tools/grow_profile.py)
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc] + FLAGS + extra + srcs + ["-o", tmp]
+            if verbose:
+                print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
