@@ -989,18 +989,19 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     __syncthreads();
 }
 
-static_assert(sizeof(Red) <= 256, "Red must fit its LDS slot");
-constexpr size_t BLP_LDS_BYTES = (size_t)BLP_UW * 8 + 256 + (size_t)BLP_UW * 4 + 16 + (size_t)L_MAXH * 16 + (size_t)L_MAXH * 8 * 2 +
+constexpr size_t RED_SLOT = 512;      // LDS bytes reserved for the reduction scratch (multiple of 16)
+static_assert(sizeof(Red) <= RED_SLOT, "Red must fit its LDS slot");
+constexpr size_t BLP_LDS_BYTES = (size_t)BLP_UW * 8 + RED_SLOT + (size_t)BLP_UW * 4 + 16 + (size_t)L_MAXH * 16 + (size_t)L_MAXH * 8 * 2 +
                                  (size_t)L_MAXR * 8 + 7 * (size_t)L_KPAD * 8 + 2 * (size_t)L_MAXR * 4 + 6 * (size_t)L_KPAD * 4 +
                                  (size_t)L_MAXH * 2;
 
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [BLP_UW]
-    Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to 256
+    Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to RED_SLOT
     if (a.status && a.status->overflow) return;
     const int nMulti = a.counts[1], nSingle = a.counts[2];
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)BLP_UW * 8 + 256);
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)BLP_UW * 8 + RED_SLOT);
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
