@@ -862,19 +862,38 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     // ---- measurement nodes of the cluster (union of the rows of its columns); in the LDS case the columns are
     //      copied in the same sweep: every thread issues the PD+1 loads of a column back to back (one round trip)
     if (lds_cols) {
-        for (int h = tid; h < nH; h += BLP_THREADS) {
-            int lo = 0, hi = K;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= h) lo = mid; else hi = mid; }
-            const int g = s.gbase[lo] + (h - s.colb[lo]);
-            s.membL[h] = (unsigned short)lo;
-            s.costL[h] = a.cost[g];
-            int ev[8];
+        // two columns per thread and pass: all 2 x (PD + 1) global loads are issued before the first is consumed, so a
+        // cluster of up to 512 columns is copied in ONE global round trip (the loop is latency, not bandwidth, bound)
+        for (int h0 = tid; h0 < nH; h0 += 2 * BLP_THREADS) {
+            int g[2], ev[2][8];
+            double cs[2];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) ev[d] = (d < a.PD) ? a.path[(size_t)d * a.cap + g] : -1;      // all loads in flight
+            for (int q = 0; q < 2; ++q) {
+                const int h = h0 + q * BLP_THREADS;
+                g[q] = -1;
+                if (h < nH) {
+                    int lo = 0, hi = K;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= h) lo = mid; else hi = mid; }
+                    g[q] = s.gbase[lo] + (h - s.colb[lo]);
+                    s.membL[h] = (unsigned short)lo;
+                }
+            }
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                s.entL[h * 8 + d] = (unsigned short)(ev[d] < 0 ? 0xffff : ev[d]);     // global node id for now
-                if (ev[d] >= 0) atomicOr(&uw[ev[d] >> 6], 1ull << (ev[d] & 63));
+            for (int q = 0; q < 2; ++q) {
+                cs[q] = (g[q] >= 0) ? a.cost[g[q]] : 0.0;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) ev[q][d] = (g[q] >= 0 && d < a.PD) ? a.path[(size_t)d * a.cap + g[q]] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int h = h0 + q * BLP_THREADS;
+                if (g[q] < 0) continue;
+                s.costL[h] = cs[q];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    s.entL[h * 8 + d] = (unsigned short)(ev[q][d] < 0 ? 0xffff : ev[q][d]);     // global node id for now
+                    if (ev[q][d] >= 0) atomicOr(&uw[ev[q][d] >> 6], 1ull << (ev[q][d] & 63));
+                }
             }
         }
     } else {
