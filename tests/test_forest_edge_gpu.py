@@ -140,3 +140,28 @@ def test_api_rejections_and_views():
         lo, lt = r_o.leaves(), r_t.getLeafNodes()
         assert [l.meas for l in lo] == [l.measurementNumber for l in lt]
     trk.close()
+
+
+def test_many_targets_multi_chunk_paths():
+    """1500 targets / ~1600 measurements per scan: more targets than one pass of the single-workgroup kernels covers (cluster
+    scans 1024 per pass, commit 512), several hundred clusters -- against the oracle, scan by scan."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=1500, radius=9000.0, lambda_phi=1e-6, n_scans=4, seed=21)
+    trk = _mk(sc, N=3, useInitiator=False, maxTargets=2048, maxMeasurements=2048)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)
+    for x0 in sc["x0"]:
+        o.initiate_target(sc["t0"], x0.copy(), orc.model_P0())
+    assert trk.nTargets == len(o.targets) > 1400
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        info = o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        st = trk.lastScanStats
+        assert (st["L"], st["G"]) == (info["L"], info["G"]), k
+        assert np.array_equal(st["unused"], info["unused"]), k
+        want = o.selected()
+        sel = trk._sel[0]
+        assert sel["id"].tolist() == want["ID"].tolist(), k
+        assert sel["sel_meas"].tolist() == want["meas"].tolist(), k
+        assert len(o.clusters) == st["clusters"], k
+        assert len(trk.leafBatch()["ID"]) == len(o.leaf_batch()["ID"]), k
+    trk.close()
