@@ -77,7 +77,8 @@ def prepass(sc, device):
         s = trk.lastScanStats
         stats.append((s["L"], s["G"], s["M"], s["ilp"], s["branched"], s["blp_iters_max"], trk.nTargets))
     api_s = time.time() - t0
-    final = [(int(n.ID), int(n.measurementNumber)) for n in trk.getTrackNodes()]
+    live = trk._sel[0]      # selected leaf of every target that survived the last scan (tracks born by that scan's initiator excluded)
+    final = [(int(i), int(m)) for i, m in zip(live["id"], live["sel_meas"])]
     init_s = float(np.sum(trk.runtimeLog["Init"]))
     trk.close()
     return births, np.array(stats), final, api_s, init_s

@@ -343,6 +343,8 @@ struct Forest {
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
     int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0; bool dead = false;
+    int nT_ub_step = 0;      // upper bound of the number of targets of the last launched scan (rows of its report)
+    int births_since_step = 0;   // candidates added after the last launched scan (they are not in its report)
     bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
     void layout(Arena& ar) {
@@ -513,6 +515,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     MHT_HIP_CHECK(hipGetLastError());
     f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
     f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
+    f->births_since_step += n;
     return MHT_OK;
 }
 
@@ -563,6 +566,8 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     hipStream_t st = ctx->stream;
     const int s = ++f->scan;
     const int cb = s & 1, nb = (s + 1) & 1;
+    f->nT_ub_step = f->nT_ub;
+    f->births_since_step = 0;
     const int W = (M + 63) / 64;
     f->last_M = M;
     hipEvent_t* ev = nullptr;
@@ -675,7 +680,7 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     MHT_REQUIRE(f->scan > 0, "mht_forest_report: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     if (f->report_pending) {
-        const size_t bytes = f->rec_off + (size_t)f->nT_ub * sizeof(mht_target_report);
+        const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
         MHT_HIP_CHECK(hipMemcpyAsync(f->report_host, f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         f->report_pending = false;
@@ -684,8 +689,9 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     memcpy(out, h, sizeof(ReportHeader));
     out->used = reinterpret_cast<const uint64_t*>(f->report_host + f->used_off);
     out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);
-    f->nT_ub = h->n_alive;
-    f->L_ub = h->n_leaves_out;
+    // tighten the host-side bounds; targets added since that scan was launched are not in its report
+    f->nT_ub = h->n_alive + f->births_since_step < f->Tcap ? h->n_alive + f->births_since_step : f->Tcap;
+    f->L_ub = h->n_leaves_out + f->births_since_step < f->Ncap ? h->n_leaves_out + f->births_since_step : f->Ncap;
     if (h->error == MHT_E_HIP) {
         f->dead = true;
         set_error("forest: grow_kernel stalled in scan %d waiting for a tile that was never dispatched (GPU shared with another "

@@ -165,3 +165,40 @@ def test_many_targets_multi_chunk_paths():
         assert len(o.clusters) == st["clusters"], k
         assert len(trk.leafBatch()["ID"]) == len(o.leaf_batch()["ID"]), k
     trk.close()
+
+
+def test_report_after_births_raw_abi():
+    """C-ABI call order step -> add_targets -> report (what a streaming host does): the report of the scan has the rows of the
+    targets that took part in it, and the targets added in between show up, with their ids, in the next report."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.tracker import _REPORT_DTYPE
+    sc = _scenario(T=30, n_scans=3, seed=11)
+    trk = _mk(sc, N=3, useInitiator=False)
+    lib, h = trk._lib, trk._ctx.handle
+    n0 = trk.nTargets
+
+    def report():
+        rep = _lib.MhtScanReport()
+        _lib.check(lib.mht_forest_report(h, C.byref(rep)))
+        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(rep.n_targets * _REPORT_DTYPE.itemsize,)) \
+            .view(_REPORT_DTYPE).copy()
+        return rep, recs
+
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    z = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in sc["scans"]]
+    _lib.check(lib.mht_forest_step_host(h, p(z[0]), len(z[0])))
+    x0 = np.array([[5000.0, 5000.0, 1.0, -2.0], [-5000.0, 4000.0, 0.0, 3.0]])          # far from everything: both are accepted
+    P0 = np.tile(np.asarray(orc.model_P0(), dtype=np.float32).reshape(1, 16), (2, 1))
+    fl, pd, me = np.zeros(2, np.uint8), np.full(2, 0.85), np.zeros(2, np.int32)
+    acc, ids = np.zeros(2, np.uint8), np.zeros(2, np.int32)
+    _lib.check(lib.mht_forest_add_targets(h, 2, p(x0), p(P0), p(fl), p(pd), p(me), 1, p(acc), p(ids)))
+    assert acc.tolist() == [1, 1] and ids.tolist() == [n0, n0 + 1]
+    rep, recs = report()
+    assert rep.scan == 1 and rep.n_targets == n0 and recs["id"].tolist() == list(range(n0))
+    _lib.check(lib.mht_forest_step_host(h, p(z[1]), len(z[1])))
+    rep, recs = report()
+    assert rep.scan == 2 and rep.n_targets == rep.n_alive + int((recs["status"] != 0).sum())
+    assert recs["id"][-2:].tolist() == [n0, n0 + 1]
+    assert np.allclose(recs["sel_x"][-2:, 0:2], x0[:, 0:2] + 2.5 * x0[:, 2:4])          # nothing gated out there: the miss hypothesis
+    trk.close()
