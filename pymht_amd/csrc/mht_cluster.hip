@@ -149,6 +149,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             rows[(size_t)(pk >> 16) * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
         }
         if (tid < EDGE_SEGS) a.edge_count[tid] = 0;
+        if (tid == 0 && a.ticket_reset) *a.ticket_reset = 0;      // grow_kernel's tile ticket (used when its grid is not co-resident)
     }
     __syncthreads();
     CL_STAMP(1);

@@ -202,3 +202,27 @@ def test_report_after_births_raw_abi():
     assert recs["id"][-2:].tolist() == [n0, n0 + 1]
     assert np.allclose(recs["sel_x"][-2:, 0:2], x0[:, 0:2] + 2.5 * x0[:, 2:4])          # nothing gated out there: the miss hypothesis
     trk.close()
+
+
+def test_deep_window_ticket_numbered_tiles():
+    """200 targets with a 7-scan window: > 20 k leaves = more grow tiles than workgroups are co-resident, so the forest's
+    grow kernel numbers its tiles by the ticket counter; 8-row ILP columns.  Against the oracle, scan by scan."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=200, radius=3000.0, lambda_phi=1.5e-6, n_scans=10, P_d=0.9, seed=31)
+    trk = _mk(sc, N=7, useInitiator=False)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=7, eta2=5.99)
+    for x0 in sc["x0"]:
+        o.initiate_target(sc["t0"], x0.copy(), orc.model_P0())
+    Lmax = 0
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        info = o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        st = trk.lastScanStats
+        Lmax = max(Lmax, st["L"])
+        assert (st["L"], st["G"]) == (info["L"], info["G"]), k
+        assert np.array_equal(st["unused"], info["unused"]), k
+        want = o.selected()
+        sel = trk._sel[0]
+        assert sel["id"].tolist() == want["ID"].tolist() and sel["sel_meas"].tolist() == want["meas"].tolist(), k
+    assert Lmax > 512 * 32, Lmax          # the regime this test is about
+    trk.close()
