@@ -59,7 +59,7 @@ struct CommitArgs {
     int R; int scan; int cap;
     int32_t* new_index;
     FCounts* cnt; DevStatus* status;
-    int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters;
+    int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
     unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
     ReportHeader* hdr; mht_target_report* rec;
 };
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
     }
     const int nAlive = running, Lnext = lrun;
     // ILP statistics
-    for (int c = tid; c < nC; c += PRUNE_THREADS) {
+    for (int i = tid; i < n_ilp; i += PRUNE_THREADS) {      // only this scan's ILPs: the entries of other clusters are stale
+        const int c = a.multi_list[i];
         const int st = a.cl_status[c];
         if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
         if (st == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
@@ -649,7 +650,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     p.R = f->R; p.scan = s; p.cap = f->Ncap;
     p.new_index = f->new_index;
     p.cnt = f->cnt; p.status = ctx->status;
-    p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters;
+    p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
     p.used_bytes = f->used_bytes; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
     p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
