@@ -226,3 +226,34 @@ def test_deep_window_ticket_numbered_tiles():
         assert sel["id"].tolist() == want["ID"].tolist() and sel["sel_meas"].tolist() == want["meas"].tolist(), k
     assert Lmax > 512 * 32, Lmax          # the regime this test is about
     trk.close()
+
+
+def test_two_trackers_interleaved_share_nothing():
+    """Two trackers in one process on the same GPU, scans interleaved: each must behave exactly as it does alone (contexts
+    share no device state: scratch, counters, LDS attributes, error strings)."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+
+    def digest(trk):
+        sel = trk._sel[0]
+        st = trk.lastScanStats
+        return (st["L"], st["G"], st["ilp"], sel["id"].tolist(), sel["sel_meas"].tolist(), float(sel["sel_cnllr"].sum()))
+
+    scA = _scenario(T=40, radius=500.0, lambda_phi=3e-5, n_scans=10, seed=41)
+    scB = _scenario(T=25, radius=300.0, lambda_phi=6e-5, n_scans=10, P_d=0.7, seed=42)
+    alone = []
+    for sc, N in ((scA, 3), (scB, 5)):
+        trk = _mk(sc, N=N)
+        out = []
+        for z, t in zip(sc["scans"], sc["times"]):
+            trk.addMeasurementList(MeasurementList(float(t), z))
+            out.append(digest(trk))
+        trk.close()
+        alone.append(out)
+    ta, tb = _mk(scA, N=3), _mk(scB, N=5)
+    for k in range(10):
+        ta.addMeasurementList(MeasurementList(float(scA["times"][k]), scA["scans"][k]))
+        tb.addMeasurementList(MeasurementList(float(scB["times"][k]), scB["scans"][k]))
+        assert digest(ta) == alone[0][k], k
+        assert digest(tb) == alone[1][k], k
+    ta.close()
+    tb.close()
