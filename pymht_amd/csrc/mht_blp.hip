@@ -329,10 +329,95 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 // not certified after CA_ROUNDS go to the branch and bound.
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
-__device__ __forceinline__ bool coord_capable(const GStore&) { return false; }
-__device__ __forceinline__ bool coord_capable(const LStore&) { return true; }
-__device__ __forceinline__ void coordinate_step(const GStore&, int, bool, bool) {}
-__device__ __forceinline__ void nominate(const GStore&, int) {}
+__device__ __forceinline__ bool bb_after_rounds(const GStore&) { return false; }     // large clusters: subgradient steps in between
+__device__ __forceinline__ bool bb_after_rounds(const LStore&) { return true; }
+// HBM policy: the same round on global scratch.  Regrets are reduced per row with two 64-bit atomicMax (the value displaced from
+// the row's top slot is pushed into the second slot: after all users the two slots hold the two largest regrets), so the round
+// stays O(columns) for clusters of any size.
+__device__ __forceinline__ void nominate(const GStore& s, int K) {
+    for (int k = threadIdx.x; k < K; k += BLP_THREADS) {
+        const int h = s.best_h[k];
+        int act = 0x7fffffff;
+        for (int d = 0; d < s.PD; ++d) {
+            const int e = s.ent(d, h);
+            if (e >= 0 && s.usage(e) >= 2 && e < act) act = e;
+        }
+        s.lix[k] = (act == 0x7fffffff) ? -1 : act;
+        if (act != 0x7fffffff) atomicAdd(&s.mark(act), 1);
+    }
+}
+__device__ __forceinline__ void coordinate_step(const GStore& s, int K, bool conflict, bool slack) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlpArgs& a = *s.a;
+    if (conflict) {
+        for (int k = wave; k < K; k += BLP_THREADS / 64) {          // one wavefront per member: cheapest column avoiding its row
+            const int m = s.lix[k];
+            const bool active = m >= 0 && s.mark(m) == s.usage(m);
+            double alt = DINF;
+            int ai = -1;
+            if (active)
+                for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+                    bool has = false;
+                    for (int d = 0; d < s.PD; ++d) has |= (s.ent(d, h) == m);
+                    if (has) continue;
+                    const double rc = reduced_cost(s, h);
+                    if (ai < 0 || rc < alt) { alt = rc; ai = h; }
+                }
+            wave_min_pair(alt, ai);
+            const double reg = active ? ((ai < 0 ? DINF : alt) - s.best_rc[k]) : -1.0;
+            if (lane == 0) {
+                s.mn[k] = reg;
+                if (active) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(reg < 0.0 ? 0.0 : reg);
+                    const unsigned long long old = atomicMax(&a.row_a[m], key);
+                    atomicMax(&a.row_b[m], old < key ? old : key);
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        s.for_rows([&](int m) {
+            if (s.usage(m) >= 2 && s.mark(m) == s.usage(m)) {      // active row: its users left their two largest regrets
+                const double r1 = __longlong_as_double((long long)a.row_a[m]), r2 = __longlong_as_double((long long)a.row_b[m]);
+                if (r2 < DINF) s.u(m) += r2 + 0.5 * fmin(r1 - r2, 1.0);
+                a.row_a[m] = 0ull;
+                a.row_b[m] = 0ull;
+            }
+        });
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (slack) {
+        s.for_rows([&](int m) { if (s.u(m) > 0.0 && s.usage(m) == 0) a.row_a[m] = ~0ull; });
+        __threadfence_block();
+        __syncthreads();
+        for (int k = wave; k < K; k += BLP_THREADS / 64) {
+            const bool busy = conflict && s.lix[k] >= 0 && s.mn[k] >= 0.0;
+            const double brc = s.best_rc[k];
+            for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+                double gap = -1.0;
+                for (int d = 0; d < s.PD; ++d) {
+                    const int e = s.ent(d, h);
+                    if (e < 0 || !(s.u(e) > 0.0 && s.usage(e) == 0)) continue;
+                    if (gap < 0.0) { gap = busy ? 0.0 : reduced_cost(s, h) - brc; if (gap < 0.0) gap = 0.0; }
+                    atomicMin(&a.row_a[e], (unsigned long long)__double_as_longlong(gap));
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        s.for_rows([&](int m) {
+            if (s.u(m) > 0.0 && s.usage(m) == 0) {
+                const unsigned long long b = a.row_a[m];
+                const double g = (b == ~0ull) ? DINF : __longlong_as_double((long long)b);
+                s.u(m) = fmax(0.0, s.u(m) - (g * (1.0 + 9.5367431640625e-7) + 1e-9));
+                a.row_a[m] = 0ull;
+            }
+        });
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 // every target nominates the lowest conflicted row of its minimiser (lix = row or -1; markL counts nominations).
 // Runs in the same phase as the certificate flags (both only need the usage counters).
 __device__ __forceinline__ void nominate(const LStore& s, int K) {
@@ -465,7 +550,7 @@ __device__ __forceinline__ void dive_order(const LStore& s, int K) {      // ran
     __syncthreads();
 }
 
-template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
+template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
     double total = 0.0;
     dive_order(s, K);
     for (int pos = 0; pos < K; ++pos) {
@@ -482,7 +567,7 @@ template <typename S> __device__ double greedy_dive(const S& s, int K, int32_t* 
 }
 
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
-template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp) {
+template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
     int stall = 0;
@@ -490,9 +575,11 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
     // dual iterations: the LDS policy does its coordinate-ascent rounds and then goes straight to the branch and bound (the
     // ascent is monotone, so its prices give a tight Lagrangian bound; on the rare clusters it does not certify -- two
     // near-duplicate tracks sharing a measurement in every scan of the window zig-zag geometrically -- subgradient steps took
-    // up to ~100 more iterations where the branch and bound needs ~10 nodes); the HBM policy has subgradient steps only.
+    // up to ~100 more iterations where the branch and bound needs ~10 nodes); the HBM policy (large clusters, where a branch and
+    // bound could explode) continues with subgradient steps up to max_iter before it branches.
     const int ca_rounds = (K == 2) ? CA_ROUNDS_PAIR : CA_ROUNDS;
-    const int it_cap = coord_capable(s) ? (a.max_iter < ca_rounds ? a.max_iter : ca_rounds) : a.max_iter;
+    const int ca_end = a.max_iter < ca_rounds ? a.max_iter : ca_rounds;        // rounds [0, ca_end) are coordinate rounds
+    const int it_cap = bb_after_rounds(s) ? ca_end : a.max_iter;
     for (int it = 0; it <= it_cap; ++it) {
         iters = it;
         // A: per target the minimiser of the reduced cost (lowest column index wins ties)
@@ -521,7 +608,7 @@ template <typename S> __device__ void solve_core(const BlpArgs& a, const S& s, i
         });
         double src = 0.0, sc = 0.0;
         for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
-        const bool coord = coord_capable(s) && it < it_cap;
+        const bool coord = it < ca_end;
         if (coord) nominate(s, K);      // needs the usage counters only; published by the reduction's barriers
         {   // one fused block reduction for the six quantities
             const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
@@ -1089,8 +1176,8 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t S = (size_t)2 * nT + 2;
     const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
-    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4]
-    const size_t n_d = nR + 6 * S + 4;
+    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4] row_a[nR] row_b[nR] (64-bit words)
+    const size_t n_d = nR + 6 * S + 4 + 2 * nR;
     // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd
     const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3;
     int rc = ctx->hitmask.ensure(n_d * 8 + n_i * 4 + 64);
@@ -1102,6 +1189,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.u = d; a.best_rc = d + nR; a.bb_cost = a.best_rc + S; a.bb_uused = a.bb_cost + S; a.bb_last_rc = a.bb_uused + S;
     a.bb_rest = a.bb_last_rc + S; a.bb_min = a.bb_rest + S;
     double* out = a.bb_min + S;
+    a.row_a = reinterpret_cast<unsigned long long*>(out + 4); a.row_b = a.row_a + nR;
     a.usage = q; a.mark = q + nR; a.best_h = a.mark + nR; a.bb_ch = a.best_h + S; a.bb_best = a.bb_ch + S; a.bb_last_idx = a.bb_best + S;
     int32_t* cl_ptr = a.bb_last_idx + S;
     int32_t* members = cl_ptr + 2;
