@@ -1,0 +1,50 @@
+"""CPU (cross-compile only): register / scratch budget of the hot kernels.  Twice this round a harmless-looking change made
+the compiler stop inlining a device function or hoist loop invariants, and the kernel silently started to spill or to pass
+its argument struct through scratch memory (1.6 us slower per ILP cluster; 7 MB of extra HBM writes per grow launch).
+The compiler's own resource report is checked here so that this cannot come back unnoticed."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pymht_amd", "csrc")
+
+# kernel -> (max scratch bytes per lane, max VGPRs).  grow_kernel must stay at <= 128 registers: 4 wavefronts per SIMD keep two
+# of its 512-thread workgroups per CU resident, which the look-back of its tile prefix relies on.
+BUDGET = {
+    "mht_gate.hip": {"grow_kernel": (0, 128)},
+    "mht_blp.hip": {"blp_kernel": (32, 256)},
+    "mht_cluster.hip": {"cluster_kernel": (0, 128)},
+    "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 64)},
+}
+
+
+@pytest.mark.parametrize("src", sorted(BUDGET))
+def test_scratch_and_register_budget(src, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from pymht_amd.build import FLAGS
+    flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [hipcc] + flags + ["-c", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"),
+                             os.path.join(CSRC, src), "-o", str(tmp_path / "o.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stderr
+    found = {}
+    for m in re.finditer(r"Function Name: (\S+)", text):
+        seg = text[m.end():m.end() + 4000]
+        nxt = seg.find("Function Name:")
+        seg = seg if nxt < 0 else seg[:nxt]
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", seg).group(1))
+        vgpr = int(re.search(r"VGPRs: (\d+)", seg).group(1))
+        found[m.group(1)] = (scratch, vgpr)
+    for kern, (max_scratch, max_vgpr) in BUDGET[src].items():
+        hits = [v for k, v in found.items() if kern in k]
+        assert hits, "kernel %s not found in the compiler report of %s" % (kern, src)
+        scratch, vgpr = hits[0]
+        assert scratch <= max_scratch, "%s uses %d B of scratch per lane (budget %d): a device function stopped being inlined or registers spill" % (kern, scratch, max_scratch)
+        assert vgpr <= max_vgpr, "%s needs %d VGPRs (budget %d)" % (kern, vgpr, max_vgpr)
