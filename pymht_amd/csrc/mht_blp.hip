@@ -610,7 +610,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
         const bool coord = it < ca_end;
         if (coord) nominate(s, K);      // needs the usage counters only; published by the reduction's barriers
-        {   // one fused block reduction for the six quantities
+        {   // one fused block reduction for the four sums and the two flags
             const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
             int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
             __syncthreads();

@@ -2,12 +2,14 @@
 // (reference: Tracker._findClustersFromSets, pymht/tracker.py:961-974, which builds a dense
 // (T+|superSet|)^2 adjacency matrix in a Python double loop and calls scipy connected_components).
 //
-// Input is one bitset per target over the "measurement nodes" of the N-scan window (bit = ring_slot*Mpad + m),
-// filled by the emit kernel (ancestors below the root + everything gated in this scan) -- exactly the
-// reference's __associatedMeasurements__ sets.  One workgroup: expand the bitsets to an edge list, then
-// min-label propagation with pointer jumping in LDS until a fixed point.  Labels are target indices, the
-// fixed point is the smallest member of each component, so clusters come out ordered by smallest member with
-// ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
+// The vertices on the measurement side are the "measurement nodes" of the N-scan window (id = ring_slot*Mpad + m); the
+// edges are the reference's __associatedMeasurements__ sets.  In the forest grow_kernel hands over a de-duplicated
+// (target, node) edge list in 64 counted segments (the per-target bitsets only serve as its de-duplication filter and are
+// cleared here through that list); the stateless seam mht_cluster expands bitsets into the edge list first.
+// One workgroup, everything in LDS, nine barrier-separated phases: gather the edges; lock-free union-find (labels are
+// target indices, a component's root is its smallest target); path compression + member counts; one dual block scan for
+// cluster index and cluster offset; slot + rank for the ascending member lists.  Clusters come out ordered by smallest
+// member with ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
 #include "mht_kernels.h"
 
 namespace mht {

@@ -2,22 +2,23 @@
 // of a scan and the creation of the child hypotheses, ONE launch per scan
 // (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py; children: pyTarget.py:227-258, :319-328).
 //
-// Workgroup = 8 wavefronts, tile = 32 consecutive leaves (tiles are mapped statically onto a
-// co-resident grid -- see the look-back below).
-//   phase 1  lanes 0..15: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
+// Workgroup = 8 wavefronts = ONE tile of 32 consecutive leaves (tile = blockIdx while the grid is co-resident, ticket-
+// numbered beyond that -- see the look-back below).
+//   phase 1  lanes 0..31: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
 //            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
-//            children need (x_bar, K, S^-1, z_hat, score constant) parked in LDS.
-//   phase 2  each wavefront takes leaves of the tile and sweeps the scan 64 measurements per step (scan staged in
-//            LDS once per workgroup): a cheap conservative float32 bounding-box test on all lanes, the exact
-//            reference-order NIS only on lanes that pass; `__ballot` turns the outcome into one 64-bit hit-mask word
-//            per step.  No (L,M) tensor is ever materialised (the reference builds a 40 MB z_tilde + a 20 MB NIS).
-//   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the
-//            number of children of ALL earlier leaves: single-pass decoupled look-back over per-tile
-//            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences).
+//            children need (x_bar, K, S^-1, z_hat, score constant, path + ancestor entries) parked in LDS.
+//   phase 2  thread = (leaf of the tile, one of 16 interleaved measurement streams): a cheap conservative float32
+//            bounding-box test per pair (scan staged in LDS once per workgroup), the exact reference-order NIS only on
+//            pairs that pass; hits set bits in the leaf's hit mask (LDS atomicOr).  No (L,M) tensor is ever materialised
+//            (the reference builds a 40 MB z_tilde + a 20 MB NIS).
+//   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the number of
+//            children of ALL earlier leaves: every tile publishes its count, every 64th tile a group sum, as
+//            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences); a tile's
+//            base = group sums of earlier groups + counts of the earlier tiles of its own group: two L2 round trips.
 //   phase 4  one thread per child: k-th set bit of the hit mask -> measurement, x_hat = x_bar + K z_tilde,
-//            NLLR, cumulative score, ILP cost, root->leaf measurement path, target association bit + deduplicated
-//            (target, measurement-node) edge for the clustering kernel.  Consecutive threads write consecutive
-//            children: all SoA stores are coalesced.
+//            NLLR, cumulative score, ILP cost, root->leaf measurement path, ancestor table, target association bit +
+//            deduplicated (target, measurement-node) edge for the clustering kernel.  Consecutive threads write
+//            consecutive children: all SoA stores are coalesced.
 // The bound is HBM traffic + launch/dependency latency; the kernel moves
 // 280 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
 #include "mht_kernels.h"
