@@ -24,6 +24,10 @@ extern "C" int mht_create(mht_ctx** out, int device, void* stream) {
     MHT_HIP_CHECK(hipSetDevice(device));
     mht_ctx* ctx = new mht_ctx();
     ctx->device = device;
+    {   // compute units of THIS device (a partitioned MI355X exposes fewer than 256): bounds the co-resident grid of grow_kernel
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
     ctx->stream = static_cast<hipStream_t>(stream);
     if (hipMalloc(reinterpret_cast<void**>(&ctx->status), sizeof(mht::DevStatus)) != hipSuccess) {
         delete ctx;

@@ -70,6 +70,7 @@ struct Forest;
 
 struct mht_ctx {
     int device = 0;
+    int n_cu = 256;          // compute units of the device (queried in mht_create)
     hipStream_t stream = nullptr;
     mht::Scratch hitmask;    // stateless seams: look-back tile states / BLP scratch
     mht::Scratch counts;     // stateless seams: tile ticket / clustering scratch

@@ -505,7 +505,7 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const int by_regs = 16 / (GATE_THREADS / 64);     // 4 wavefronts per SIMD at 128 registers = 16 per CU
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;
-    const int max_blocks = 256 * per_cu;
+    const int max_blocks = ctx->n_cu * per_cu;
     if (getenv("MHT_GROW_DEBUG")) {
         static bool printed = false;
         if (!printed) {
