@@ -371,7 +371,8 @@ struct Forest {
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
         tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); group_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE / 64 + 8);
         edges = ar.take<unsigned>((size_t)EDGE_SEGS * SegCap);
-        edge_count = ar.take<int32_t>(EDGE_SEGS + 4); ticket = edge_count + EDGE_SEGS;
+        edge_count = ar.take<int32_t>(EDGE_SEGS + 4);
+        ticket = ar.take<int32_t>(64) + 32;      // a cache line of its own: the edge counters next door are hammered by atomics
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8);
