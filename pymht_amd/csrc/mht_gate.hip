@@ -7,10 +7,10 @@
 //   phase 1  lanes 0..31: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
 //            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
 //            children need (x_bar, K, S^-1, z_hat, score constant, path + ancestor entries) parked in LDS.
-//   phase 2  thread = (leaf of the tile, one of 16 interleaved measurement streams): a cheap conservative float32
-//            bounding-box test per pair (scan staged in LDS once per workgroup), the exact reference-order NIS only on
-//            pairs that pass; hits set bits in the leaf's hit mask (LDS atomicOr).  No (L,M) tensor is ever materialised
-//            (the reference builds a 40 MB z_tilde + a 20 MB NIS).
+//   phase 2  the scan (staged in LDS once per workgroup) is cut down to the measurements inside one of <= 4 bounding boxes
+//            (one per run of leaves of the same target); thread = (leaf, candidate): the leaf's own conservative float32
+//            box, the exact reference-order NIS only on pairs that pass; hits set bits in the leaf's hit mask (LDS
+//            atomicOr).  No (L,M) tensor is ever materialised (the reference builds a 40 MB z_tilde + a 20 MB NIS).
 //   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the number of
 //            children of ALL earlier leaves: every tile publishes its count, every 64th tile a group sum, as
 //            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences); a tile's
@@ -96,6 +96,12 @@ __device__ __forceinline__ void phase1_leaf(const GateArgs& a, int i, int src, L
     } else {
         a.status->overflow = 1;
     }
+}
+
+// monotone map float -> int (for LDS atomicMin/atomicMax on float keys)
+__device__ __forceinline__ int sortable(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : (i ^ 0x7fffffff);
 }
 
 // tile state word: [63:40] epoch (scan), [33:32] flag (1 = aggregate, 2 = inclusive prefix), [31:0] value
@@ -211,7 +217,9 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     int* tfirst = off + (a.Tcap + 1);                                                   // [Tcap] per-target tables staged once
     unsigned char* tdepth = reinterpret_cast<unsigned char*>(tfirst + a.Tcap);          // [Tcap] (<= MAXPD)
     unsigned char* tshift = tdepth + a.Tcap;
+    unsigned short* cand = reinterpret_cast<unsigned short*>(tshift + a.Tcap + ((2 * a.Tcap) & 1));   // [Mpad] phase-2 candidates
     __shared__ int s_base, s_total, s_stall, s_pref[GATE_TILE + 1];
+    __shared__ int s_box[4][4], s_ncand;      // up to 4 target segments per tile: {min x, max x, min y, max y} as sortable ints
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.t_leaf_off ? a.nT_dev[0] : 0;      // FCounts{nT, L, ...}: one round trip for both
@@ -254,6 +262,8 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
             }
         for (int w = tid; w < GATE_TILE * W; w += GATE_THREADS) hw[w] = 0ull;      // hit masks of phase 2
+        if (tid < 16) s_box[tid >> 2][tid & 3] = (tid & 1) ? (int)0x80000000 : 0x7fffffff;
+        if (tid == 16) s_ncand = 0;
         __syncthreads();
         GROW_STAMP(1);
         // ---- phase 1: predict + precalc, one leaf per lane -----------------------------------------------------
@@ -297,33 +307,68 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                     else phase1_leaf<double>(a, i, src, g);
                 }
             }
+            // bounding boxes of the gates, one per run of leaves of the same target (the leaves of a target sit within a few
+            // hundred metres of each other, targets do not): the scan is first cut down to the measurements inside one of
+            // the <= 4 boxes, only those are tested per leaf
+            const int tg = g.valid ? g.tgt : -2, tp = __shfl_up(tg, 1);
+            const float pzx = __shfl_up(g.zhx, 1), pzy = __shfl_up(g.zhy, 1), pbx = __shfl_up(g.bx, 1), pby = __shfl_up(g.by, 1);
+            // stateless seam (no target table): a run ends where the predicted measurement jumps by more than a few gate widths
+            const bool jump = tg == -1 && (fabsf(g.zhx - pzx) > 8.0f * (g.bx + pbx) || fabsf(g.zhy - pzy) > 8.0f * (g.by + pby));
+            const bool head = g.valid && (tid == 0 || tg != tp || jump);
+            const unsigned long long hb = __ballot(head);
+            int seg = __popcll(hb & ((2ull << tid) - 1ull)) - 1;
+            if (seg > 3) seg = 3;
+            if (g.valid && seg >= 0) {
+                float lox = g.zhx - g.bx, hix = g.zhx + g.bx, loy = g.zhy - g.by, hiy = g.zhy + g.by;
+                lox -= fabsf(lox) * 2.4e-7f + 1e-30f; hix += fabsf(hix) * 2.4e-7f + 1e-30f;      // outward: a superset of the leaf's own box
+                loy -= fabsf(loy) * 2.4e-7f + 1e-30f; hiy += fabsf(hiy) * 2.4e-7f + 1e-30f;
+                atomicMin(&s_box[seg][0], sortable(lox)); atomicMax(&s_box[seg][1], sortable(hix));
+                atomicMin(&s_box[seg][2], sortable(loy)); atomicMax(&s_box[seg][3], sortable(hiy));
+            }
         }
         __syncthreads();
         GROW_STAMP(2);
-        // ---- phase 2: thread = (leaf of the tile, measurement stream): 32 leaves x 16 interleaved streams ----------------
-        // Each thread sweeps M/16 measurements for ONE leaf: four VALU ops per pair on the conservative float32 box,
-        // independent iterations (unrolled for ILP), scan read from LDS.  A pair that passes the box gets the exact
-        // reference-order NIS and sets its bit in the leaf's hit mask (LDS atomicOr; hits are rare: ~1 per leaf).
+        // ---- phase 2: (a) every thread tests measurements against the segment boxes and appends the survivors to a candidate
+        //      list (wave ballot + one LDS atomic per wavefront; the order is irrelevant, hits are recorded by measurement
+        //      index); (b) thread = (leaf, candidate): the leaf's own conservative float32 box, then the exact reference-order
+        //      NIS, hits set bits in the leaf's hit mask (LDS atomicOr; ~1 hit per leaf).  No (L, M) sweep per leaf.
         if (!(a.ablate & 4)) {
-            const int l = tid & (GATE_TILE - 1), stream = tid / GATE_TILE;
-            const LeafLds& g = lg[l];
-            if (g.valid) {
-                const float zhx = g.zhx, zhy = g.zhy, bx = g.bx, by = g.by;
-                constexpr int NS = GATE_THREADS / GATE_TILE;       // 16 streams
-#pragma unroll 4
-                for (int j = stream; j < Mpad; j += NS) {
-                    const float mx = zx[j], my = zy[j];
-                    if ((fabsf(mx - zhx) <= bx) && (fabsf(my - zhy) <= by)) {
-                        bool hit;
-                        if (g.f32state) {
-                            float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
-                            hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
-                        } else {
-                            double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
-                            hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
-                        }
-                        if (hit) atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
+            int bxs[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bxs[q][e] = s_box[q][e];
+            for (int j0 = 0; j0 < Mpad; j0 += GATE_THREADS) {
+                const int j = j0 + tid;
+                bool in = false;
+                if (j < Mpad) {
+                    const int kx = sortable(zx[j]), ky = sortable(zy[j]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) in |= (kx >= bxs[q][0]) && (kx <= bxs[q][1]) && (ky >= bxs[q][2]) && (ky <= bxs[q][3]);
+                }
+                const unsigned long long bal = __ballot(in);
+                int wbase = 0;
+                if (lane == 0 && bal) wbase = atomicAdd(&s_ncand, __popcll(bal));
+                wbase = __shfl(wbase, 0);
+                if (in) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            }
+            __syncthreads();
+            const int nc = s_ncand;
+            for (int w = tid; w < GATE_TILE * nc; w += GATE_THREADS) {
+                const int l = w & (GATE_TILE - 1), j = cand[w / GATE_TILE];
+                const LeafLds& g = lg[l];
+                if (!g.valid) continue;
+                const float mx = zx[j], my = zy[j];
+                if ((fabsf(mx - g.zhx) <= g.bx) && (fabsf(my - g.zhy) <= g.by)) {
+                    bool hit;
+                    if (g.f32state) {
+                        float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
+                        hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
+                    } else {
+                        double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
+                        hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
                     }
+                    if (hit) atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
                 }
             }
         }
@@ -480,7 +525,8 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
 }
 
 static inline size_t grow_lds_bytes(int W, int Tcap) {
-    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(2 * Tcap + 1) * 4 + (size_t)2 * Tcap + 16;
+    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(2 * Tcap + 1) * 4 + (size_t)2 * Tcap + 16 +
+           (size_t)W * 64 * 2 + 2;      // + candidate list
 }
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
