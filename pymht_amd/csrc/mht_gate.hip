@@ -293,11 +293,21 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                     g.rootc = a.t_root_cnllr[tgt];
                     g.root_f32 = a.t_root_f32[tgt];
                     int last = -1;
+                    // unconditional loads (clamped row, result masked afterwards): with a branch per level the 2 x depth
+                    // look-ups went out one after the other -- 3.5 us of the critical path instead of one round trip
+                    int pv[MAXPD], av[MAXPD];
 #pragma unroll
                     for (int d = 0; d < MAXPD; ++d) {
-                        const int v = (d < depth) ? a.in_path[(size_t)(d + shift) * a.cap_in + src] : -1;
+                        const int row = (d < depth) ? d + shift : 0;
+                        const bool on = d < a.PD;             // uniform: levels beyond the window are never read
+                        pv[d] = on ? a.in_path[(size_t)row * a.cap_in + src] : -1;
+                        av[d] = on ? a.in_apath[(size_t)row * a.cap_in + src] : -1;
+                    }
+#pragma unroll
+                    for (int d = 0; d < MAXPD; ++d) {
+                        const int v = (d < depth) ? pv[d] : -1;
                         g.ppath[d] = v;
-                        g.apath[d] = (d < depth) ? a.in_apath[(size_t)(d + shift) * a.cap_in + src] : -1;
+                        g.apath[d] = (d < depth) ? av[d] : -1;
                         if (v >= 0) last = v;
                     }
                     g.last_real = last;
