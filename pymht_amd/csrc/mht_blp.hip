@@ -966,10 +966,14 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                cs[q] = (g[q] >= 0) ? a.cost[g[q]] : 0.0;
+            for (int q = 0; q < 2; ++q) {      // unconditional loads (clamped index), masked afterwards: no branch between them
+                const int gq = g[q] >= 0 ? g[q] : 0;
+                cs[q] = a.cost[gq];
 #pragma unroll
-                for (int d = 0; d < 8; ++d) ev[q][d] = (g[q] >= 0 && d < a.PD) ? a.path[(size_t)d * a.cap + g[q]] : -1;
+                for (int d = 0; d < 8; ++d) {
+                    const int v = (d < a.PD) ? a.path[(size_t)d * a.cap + gq] : -1;
+                    ev[q][d] = g[q] >= 0 ? v : -1;
+                }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {

@@ -88,12 +88,13 @@ __global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs 
     for (int base = 0; base < nT; base += PRUNE_THREADS) {
         const int t = base + tid;
         const bool in = t < nT;
-        const int al = in ? (a.t_status[t] == 0) : 0;
-        const int cntl = in ? a.t_count[t] : 0, j = in ? a.t_jdrop[t] : 0, first = in ? a.t_firstsurv[t] : 0;
-        const int id = in ? a.cur.id[t] : 0, win = in ? a.cur.window[t] : 0, dep = in ? a.cur.depth[t] : 0;
-        const int rs = in ? a.w_root_scan[t] : 0, rn = in ? a.w_root_node[t] : 0;
-        const double rc = in ? a.w_root_cnllr[t] : 0.0;
-        const uint8_t rf = in ? a.w_root_f32[t] : 0;
+        const int tc = in ? t : 0;      // clamped: the ten look-ups go out together, without a branch each
+        const int al = in && (a.t_status[tc] == 0);
+        const int cntl = a.t_count[tc], j = a.t_jdrop[tc], first = a.t_firstsurv[tc];
+        const int id = a.cur.id[tc], win = a.cur.window[tc], dep = a.cur.depth[tc];
+        const int rs = a.w_root_scan[tc], rn = a.w_root_node[tc];
+        const double rc = a.w_root_cnllr[tc];
+        const uint8_t rf = a.w_root_f32[tc];
         const int leaves = al ? cntl : 0;
         // one block scan for both the compacted target index and the leaf offset
         const int lane = tid & 63, wv = tid >> 6;
