@@ -64,12 +64,25 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         E = s_segoff[EDGE_SEGS];
         if (E > a.elds + a.Ecap) { if (tid == 0) a.counts[3] = 1; E = a.elds + a.Ecap; }
         // flat gather: thread -> dense edge index -> (segment, offset) by binary search over the 65 offsets
-        for (int e = tid; e < E; e += CL_THREADS) {
-            int lo = 0, hi = EDGE_SEGS;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_segoff[mid] <= e) lo = mid; else hi = mid; }
-            const unsigned pk = a.edges_in[(size_t)lo * a.seg_cap + (e - s_segoff[lo])];
-            if (e < a.elds) eL[e] = pk;
-            else { a.edge_t[e - a.elds] = (int)(pk >> 16); a.edge_m[e - a.elds] = (int)(pk & 0xffff); }
+        // four edges per thread and pass: the four global loads are issued before the first result is stored (the loop is
+        // latency bound: one round trip per pass)
+        for (int e0 = tid; e0 < E; e0 += 4 * CL_THREADS) {
+            unsigned pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * CL_THREADS;
+                const int ec = e < E ? e : 0;
+                int lo = 0, hi = EDGE_SEGS;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_segoff[mid] <= ec) lo = mid; else hi = mid; }
+                pk[q] = a.edges_in[(size_t)lo * a.seg_cap + (ec - s_segoff[lo])];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * CL_THREADS;
+                if (e >= E) continue;
+                if (e < a.elds) eL[e] = pk[q];
+                else { a.edge_t[e - a.elds] = (int)(pk[q] >> 16); a.edge_m[e - a.elds] = (int)(pk[q] & 0xffff); }
+            }
         }
         __threadfence_block();
         __syncthreads();
