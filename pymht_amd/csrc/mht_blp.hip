@@ -789,7 +789,8 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
     const int smeas = ring_ptr(a.ring0.meas, a.ring_stride, kc)[s];
     const double sx0 = a.x[s], sx1 = a.x[(size_t)a.cap + s], sx2 = a.x[(size_t)2 * a.cap + s], sx3 = a.x[(size_t)3 * a.cap + s];
     const int j = p.j;
-    const int anc = (j > 0) ? a.apath[(size_t)(j - 1) * a.cap + s] : -1;
+    const int anc_l = a.apath[(size_t)(j > 0 ? j - 1 : 0) * a.cap + s];      // unconditional (clamped row): one batch with the loads above
+    const int anc = (j > 0) ? anc_l : -1;
     const bool f32score = (fl & F_SCORE_F32) && p.rootf;
     // getScore() (pyTarget.py:124) with NumPy scalar promotion: float32 - float32 stays float32
     const double score = f32score ? (double)((float)cn - (float)p.rootc) : cn - p.rootc;
@@ -804,19 +805,17 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
         else if (cn > a.cnllr_limit) status = 3;                                             // tracker.py:908
     }
     int rscan = p.rscan, rnode = p.rnode;
-    double rc = p.rootc;
-    uint8_t rf = p.rootf;
-    if (status == 0 && j > 0) {       // new root = the selected leaf's ancestor j levels below the old root
-        rscan += j;
-        rnode = anc;
-        const int kn = rscan % a.R;
-        rc = ring_ptr(a.ring0.cnllr, a.ring_stride, kn)[rnode];
-        rf = (ring_ptr(a.ring0.flags, a.ring_stride, kn)[rnode] & F_SCORE_F32) ? 1 : 0;
-    }
+    const bool moved = status == 0 && j > 0;      // new root = the selected leaf's ancestor j levels below the old root
+    if (moved) { rscan += j; rnode = anc; }
+    // the (new or old) root's record: seven look-ups in one batch, none behind a branch
     const int kr = rscan % a.R;
     const double* rx = ring_ptr(a.ring0.x, a.ring_stride, kr);
+    const double rc_l = ring_ptr(a.ring0.cnllr, a.ring_stride, kr)[rnode];
+    const uint8_t rf_l = ring_ptr(a.ring0.flags, a.ring_stride, kr)[rnode];
     const double rx0 = rx[rnode], rx1 = rx[(size_t)a.cap + rnode], rx2 = rx[(size_t)2 * a.cap + rnode], rx3 = rx[(size_t)3 * a.cap + rnode];
     const int rmeas = ring_ptr(a.ring0.meas, a.ring_stride, kr)[rnode];
+    const double rc = moved ? rc_l : p.rootc;
+    const uint8_t rf = moved ? (uint8_t)((rf_l & F_SCORE_F32) ? 1 : 0) : p.rootf;
     if (store) {
         a.t_alive[t] = status;                 // 0 = alive, else the termination reason
         a.t_jdrop[t] = j;
