@@ -69,10 +69,10 @@ __device__ __forceinline__ void box_from_S(const float* S, double eta2, float zh
 }
 
 template <typename TS>
-__device__ __forceinline__ void phase1_leaf(const GateArgs& a, int i, int src, LeafLds& g) {
+__device__ __forceinline__ void phase1_leaf(const GateArgs& a, int i, const double* xd, const float* P, LeafLds& g) {
     TS xs[4];
-    float P[16];
-    load_leaf<TS>(a, src, xs, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xs[k] = (TS)xd[k];
     Predicted<TS> p;
     predict_precalc<TS>(a.model, xs, P, p);
 #pragma unroll
@@ -278,43 +278,57 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 g.src = src;
                 g.tgt = tgt;
                 g.first_of_target = (tgt >= 0 && i == off[tgt]);
+                // Two load batches only -- (A) everything addressed by the leaf or its target, (B) the covariance column that
+                // A's `cov` names.  All of A is issued before anything is consumed and nothing sits behind a branch: target
+                // look-ups use a clamped index and are masked afterwards (the stateless seam has no target table).
+                const bool forest = tgt >= 0;
+                const int tgc = forest ? tgt : 0;
+                const int depth = forest ? tdepth[tgc] : 0, shift = forest ? tshift[tgc] : 0;
                 const uint8_t fl = a.flags[src];
-                g.flags = fl;
-                g.f32state = (fl & F_STATE_F32) ? 1 : 0;
-                g.cn = a.cnllr[src];
-                g.pd = a.pd[src];
-                g.depth = 0;
-                g.last_real = -1;
-                g.rootc = 0.0;
-                g.root_f32 = 0;
-                if (tgt >= 0) {
-                    const int depth = tdepth[tgt], shift = tshift[tgt];
-                    g.depth = depth;
-                    g.rootc = a.t_root_cnllr[tgt];
-                    g.root_f32 = a.t_root_f32[tgt];
-                    int last = -1;
-                    // unconditional loads (clamped row, result masked afterwards): with a branch per level the 2 x depth
-                    // look-ups went out one after the other -- 3.5 us of the critical path instead of one round trip
-                    int pv[MAXPD], av[MAXPD];
+                const double cn = a.cnllr[src], pd = a.pd[src];
+                const int covc = a.cov[src];
+                double xd[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap_in + src];
+                double rootc = 0.0;
+                uint8_t rootf = 0;
+                int pv[MAXPD], av[MAXPD];
+                if (a.t_leaf_off) {                       // uniform
+                    rootc = a.t_root_cnllr[tgc];
+                    rootf = a.t_root_f32[tgc];
 #pragma unroll
                     for (int d = 0; d < MAXPD; ++d) {
                         const int row = (d < depth) ? d + shift : 0;
-                        const bool on = d < a.PD;             // uniform: levels beyond the window are never read
+                        const bool on = d < a.PD;         // uniform: levels beyond the window are never read
                         pv[d] = on ? a.in_path[(size_t)row * a.cap_in + src] : -1;
                         av[d] = on ? a.in_apath[(size_t)row * a.cap_in + src] : -1;
                     }
+                } else {
 #pragma unroll
-                    for (int d = 0; d < MAXPD; ++d) {
-                        const int v = (d < depth) ? pv[d] : -1;
-                        g.ppath[d] = v;
-                        g.apath[d] = (d < depth) ? av[d] : -1;
-                        if (v >= 0) last = v;
-                    }
-                    g.last_real = last;
+                    for (int d = 0; d < MAXPD; ++d) { pv[d] = -1; av[d] = -1; }
                 }
+                float P[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc_in + covc];
+                g.flags = fl;
+                g.f32state = (fl & F_STATE_F32) ? 1 : 0;
+                g.cn = cn;
+                g.pd = pd;
+                g.depth = depth;
+                g.rootc = forest ? rootc : 0.0;
+                g.root_f32 = forest ? rootf : 0;
+                int last = -1;
+#pragma unroll
+                for (int d = 0; d < MAXPD; ++d) {
+                    const int v = (forest && d < depth) ? pv[d] : -1;
+                    g.ppath[d] = v;
+                    g.apath[d] = (forest && d < depth) ? av[d] : -1;
+                    if (v >= 0) last = v;
+                }
+                g.last_real = last;
                 if (!(a.ablate & 8)) {
-                    if (g.f32state) phase1_leaf<float>(a, i, src, g);
-                    else phase1_leaf<double>(a, i, src, g);
+                    if (g.f32state) phase1_leaf<float>(a, i, xd, P, g);
+                    else phase1_leaf<double>(a, i, xd, P, g);
                 }
             }
             // bounding boxes of the gates, one per run of leaves of the same target (the leaves of a target sit within a few
