@@ -37,7 +37,7 @@ LAMBDA_NU = 1e-4
 ETA2 = 5.99
 # HBM bytes per grow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
 # workload, steady-state scans): profiles/r01_pmc_hbm_traffic.txt.  Keyed by config name; None = not profiled.
-PMC_TRAFFIC_BYTES = {"cfg3": (3111 + 6164) * 1024}
+PMC_TRAFFIC_BYTES = {"cfg3": (3274 + 6164) * 1024}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
 
 
