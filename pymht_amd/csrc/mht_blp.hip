@@ -346,7 +346,7 @@ __device__ __forceinline__ void nominate(const GStore& s, int K) {
         if (act != 0x7fffffff) atomicAdd(&s.mark(act), 1);
     }
 }
-__device__ __forceinline__ void coordinate_step(const GStore& s, int K, bool conflict, bool slack) {
+__device__ __forceinline__ bool coordinate_step(const GStore& s, int K, bool conflict, bool slack) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const BlpArgs& a = *s.a;
     if (conflict) {
@@ -417,6 +417,7 @@ __device__ __forceinline__ void coordinate_step(const GStore& s, int K, bool con
         __threadfence_block();
         __syncthreads();
     }
+    return false;
 }
 // every target nominates the lowest conflicted row of its minimiser (lix = row or -1; markL counts nominations).
 // Runs in the same phase as the certificate flags (both only need the usage counters).
@@ -456,7 +457,7 @@ template <int G> __device__ __forceinline__ double regret_of(const LStore& s, in
     else row16_min_pair(alt, ai);
     return ai < 0 ? DINF : alt;
 }
-__device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool conflict, bool slack) {
+__device__ __forceinline__ bool coordinate_step(const LStore& s, int K, bool conflict, bool slack) {
     const int tid = threadIdx.x;
     if (conflict) {
         // regrets of the users of active rows (mn[k] = regret, -1 = target not taking part)
@@ -493,6 +494,10 @@ __device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool con
                 }
             }
             if (lowest && r2 >= 0.0 && r2 < DINF) s.uL[m] += r2 + 0.5 * fmin(r1 - r2, 1.0);
+        }
+        if (!slack) {     // nobody reads the usage / nomination counters any more: reset them here, not in a phase of their own
+            for (int m = tid; m < s.nR; m += BLP_THREADS) { s.usageL[m] = 0; s.markL[m] = 0; }
+            return true;
         }
         if (slack) {      // the slack pass re-uses markL: clear the nomination counters first
             __syncthreads();
@@ -531,6 +536,7 @@ __device__ __forceinline__ void coordinate_step(const LStore& s, int K, bool con
             }
         __syncthreads();
     }
+    return false;
 }
 
 // visiting order of the dive: targets by ascending minimal reduced cost (ties by index); identity for the HBM policy
@@ -593,48 +599,74 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         __threadfence_block();
         __syncthreads();
         if (it == 0) stamp[2] = wall_clock64();
-        // C: subgradient, dual value, certificate
-        double nrm = 0.0, usum = 0.0;
-        int conflict = 0, slack = 0;
-        s.for_rows([&](int m) {
-            const int us = s.usage(m);
-            const double um = s.u(m);
-            double g = (double)(us - 1);
-            if (um <= 0.0 && g < 0.0) g = 0.0;
-            nrm += g * g;
-            usum += um;
-            conflict |= (us >= 2);
-            slack |= (um > 0.0 && us == 0);
-        });
-        double src = 0.0, sc = 0.0;
-        for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
+        // C: certificate flags; the subgradient rounds also need the dual value and the subgradient norm
         const bool coord = it < ca_end;
-        if (coord) nominate(s, K);      // needs the usage counters only; published by the reduction's barriers
-        {   // one fused block reduction for the four sums and the two flags
-            const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
-            int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
-            __syncthreads();
-            if (lane == 0) { r->q[wave][0] = v0; r->q[wave][1] = v1; r->q[wave][2] = v2; r->q[wave][3] = v3; r->i[wave] = f; }
-            __syncthreads();
-            nrm = 0.0; utot = 0.0; src = 0.0; sc = 0.0; f = 0;
-#pragma unroll
-            for (int w = 0; w < BLP_THREADS / 64; ++w) {
-                nrm += r->q[w][0]; utot += r->q[w][1]; src += r->q[w][2]; sc += r->q[w][3]; f |= r->i[w];
-            }
-            conflict = f & 1;
-            slack = (f >> 1) & 1;
-        }
-        if (it == 0) stamp[3] = wall_clock64();
-        const double LB = src - utot;
-        if (!conflict && sc < UB) {
-            UB = sc;
-            for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
+        double nrm = 0.0, usum = 0.0, LB = 0.0;
+        int conflict = 0, slack = 0;
+        if (coord) {
+            // coordinate round: only "is some row over-used" / "is some priced row unused"; nominations ride along (they
+            // need the usage counters only).  r->i was last read several barriers ago: one barrier suffices.
+            s.for_rows([&](int m) {
+                const int us = s.usage(m);
+                conflict |= (us >= 2);
+                slack |= (s.u(m) > 0.0 && us == 0);
+            });
+            nominate(s, K);
+            const int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
+            if (lane == 0) r->i[wave] = f;
             __threadfence_block();
             __syncthreads();
+            int ff = 0;
+#pragma unroll
+            for (int w = 0; w < BLP_THREADS / 64; ++w) ff |= r->i[w];
+            conflict = ff & 1;
+            slack = (ff >> 1) & 1;
+            if (it == 0) stamp[3] = wall_clock64();
+            if (!conflict) {        // the minimisers are a feasible selection (and optimal if no priced row is unused)
+                for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
+                __threadfence_block();
+                __syncthreads();
+            }
+        } else {
+            s.for_rows([&](int m) {
+                const int us = s.usage(m);
+                const double um = s.u(m);
+                double g = (double)(us - 1);
+                if (um <= 0.0 && g < 0.0) g = 0.0;
+                nrm += g * g;
+                usum += um;
+                conflict |= (us >= 2);
+                slack |= (um > 0.0 && us == 0);
+            });
+            double src = 0.0, sc = 0.0;
+            for (int k = tid; k < K; k += BLP_THREADS) { src += s.best_rc[k]; sc += s.cost(s.best_h[k]); }
+            {   // one fused block reduction for the four sums and the two flags
+                const double v0 = wave_sum(nrm), v1 = wave_sum(usum), v2 = wave_sum(src), v3 = wave_sum(sc);
+                int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
+                __syncthreads();
+                if (lane == 0) { r->q[wave][0] = v0; r->q[wave][1] = v1; r->q[wave][2] = v2; r->q[wave][3] = v3; r->i[wave] = f; }
+                __syncthreads();
+                nrm = 0.0; utot = 0.0; src = 0.0; sc = 0.0; f = 0;
+#pragma unroll
+                for (int w = 0; w < BLP_THREADS / 64; ++w) {
+                    nrm += r->q[w][0]; utot += r->q[w][1]; src += r->q[w][2]; sc += r->q[w][3]; f |= r->i[w];
+                }
+                conflict = f & 1;
+                slack = (f >> 1) & 1;
+            }
+            if (it == 0) stamp[3] = wall_clock64();
+            LB = src - utot;
+            if (!conflict && sc < UB) {
+                UB = sc;
+                for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
+                __threadfence_block();
+                __syncthreads();
+            }
         }
         bool done = false;
         if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
-        if (!done && coord) coordinate_step(s, K, conflict != 0, slack != 0);
+        bool counters_reset = false;
+        if (!done && coord) counters_reset = coordinate_step(s, K, conflict != 0, slack != 0);
         if (!done && !coord) {
             if (LB > best_LB + 1e-12) { best_LB = LB; stall = 0; }
             else if (++stall >= 10) { theta *= 0.5; stall = 0; }
@@ -652,16 +684,17 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         }
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
         const double step = (done || coord) ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
-        s.for_rows([&](int m) {
-            if (!done && !coord) {
-                const double um = s.u(m);
-                double g = (double)(s.usage(m) - 1);
-                if (um <= 0.0 && g < 0.0) g = 0.0;
-                s.u(m) = fmax(0.0, um + step * g);
-            }
-            s.usage(m) = 0;
-            if (coord) s.mark(m) = 0;      // nomination counters
-        });
+        if (!counters_reset)
+            s.for_rows([&](int m) {
+                if (!done && !coord) {
+                    const double um = s.u(m);
+                    double g = (double)(s.usage(m) - 1);
+                    if (um <= 0.0 && g < 0.0) g = 0.0;
+                    s.u(m) = fmax(0.0, um + step * g);
+                }
+                s.usage(m) = 0;
+                if (coord) s.mark(m) = 0;      // nomination counters
+            });
         __threadfence_block();
         __syncthreads();
         if (done) break;
