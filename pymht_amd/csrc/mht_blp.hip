@@ -268,6 +268,10 @@ __device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* 
             }
             wave_min_pair(bv, bi);
             if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
+            if (lane < 8 && bi >= 0) {                      // usage of the minimiser's rows right here: no phase of its own
+                const int e = s.entL[bi * 8 + lane];
+                if (e != s.nR) atomicAdd(&s.usageL[e], 1);
+            }
         }
         __syncthreads();
         return;
@@ -329,6 +333,8 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 // not certified after CA_ROUNDS go to the branch and bound.
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
+__device__ __forceinline__ bool usage_counted_by_minimisers(const GStore&, int) { return false; }
+__device__ __forceinline__ bool usage_counted_by_minimisers(const LStore&, int K) { return K <= BLP_THREADS / 64; }
 __device__ __forceinline__ bool bb_after_rounds(const GStore&) { return false; }     // large clusters: subgradient steps in between
 __device__ __forceinline__ bool bb_after_rounds(const LStore&) { return true; }
 // HBM policy: the same round on global scratch.  Regrets are reduced per row with two 64-bit atomicMax (the value displaced from
@@ -592,12 +598,14 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         compute_minimisers(s, K, r);
         if (it == 0) stamp[1] = wall_clock64();
         // B: how often each measurement node is used by the minimisers
-        for (int idx = tid; idx < K * s.PD; idx += BLP_THREADS) {
-            const int k = idx / s.PD, d = idx - k * s.PD;
-            add_usage(s, k, d);
+        if (!usage_counted_by_minimisers(s, K)) {
+            for (int idx = tid; idx < K * s.PD; idx += BLP_THREADS) {
+                const int k = idx / s.PD, d = idx - k * s.PD;
+                add_usage(s, k, d);
+            }
+            __threadfence_block();
+            __syncthreads();
         }
-        __threadfence_block();
-        __syncthreads();
         if (it == 0) stamp[2] = wall_clock64();
         // C: certificate flags; the subgradient rounds also need the dual value and the subgradient norm
         const bool coord = it < ca_end;
