@@ -218,18 +218,30 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) {
-        for (int q = 0; q < a.n; ++q) {
-            int near = a.near[q];
-            if (a.check && !near) {           // against the candidates admitted in this call
-                const int r0 = a.cnt->n_roots;
-                for (int t = nT0; t < a.cnt->nT && !near; ++t) {
-                    const int nd = a.tab.first[t];
-                    const double dx = a.layer.x[nd] - a.x0[q * 4], dy = a.layer.x[(size_t)a.layer.cap + nd] - a.x0[q * 4 + 1];
-                    if (sqrt(dx * dx + dy * dy) < a.thr) near = 1;
-                }
-                (void)r0;
+    // Sequential admission like the reference (a candidate is also tested against the candidates admitted before it in this
+    // call), but the test of one candidate against the admitted ones is spread over the workgroup: a batch of 500 initial
+    // targets took 33 ms with one thread walking the O(n^2) pairs.
+    __shared__ int s_near, s_nadm;
+    __shared__ int s_adm[2048];                 // candidate indices admitted so far (chunked if more)
+    if (tid == 0) s_nadm = 0;
+    __syncthreads();
+    for (int q = 0; q < a.n; ++q) {
+        if (tid == 0) s_near = a.near[q];
+        __syncthreads();
+        if (a.check && !s_near) {
+            const double qx = a.x0[q * 4], qy = a.x0[q * 4 + 1];
+            const int na = s_nadm;
+            int hit = 0;
+            for (int i = tid; i < na; i += 1024) {
+                const int pc = s_adm[i & 2047];
+                const double dx = a.x0[pc * 4] - qx, dy = a.x0[pc * 4 + 1] - qy;
+                if (sqrt(dx * dx + dy * dy) < a.thr) hit = 1;
             }
+            if (hit) s_near = 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int near = s_near;
             const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_nodes < a.layer.cap;
             if (!near && !ok) a.cnt->overflow = 1;
             if (ok) {
@@ -261,11 +273,14 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.cnt->n_roots = r + 1;
                 a.cnt->nT = t + 1;
                 a.cnt->L = L + 1;
+                s_adm[s_nadm & 2047] = q;
+                s_nadm += 1;
             } else if (a.ids) {
                 a.ids[q] = -1;
             }
             if (a.accepted) a.accepted[q] = (uint8_t)ok;
         }
+        __syncthreads();
     }
 }
 
@@ -516,8 +531,16 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
     a.near = f->near;
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
-    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
-    MHT_HIP_CHECK(hipGetLastError());
+    // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
+    // earlier chunks are leaves of the forest by then and are tested as such
+    for (int c0 = 0; c0 < n; c0 += 2048) {
+        AddArgs ac = a;
+        ac.n = n - c0 < 2048 ? n - c0 : 2048;
+        ac.x0 = x0 + (size_t)c0 * 4; ac.pd = pd + c0; ac.P0 = P0 + (size_t)c0 * 16; ac.meas = meas + c0; ac.flags = flags + c0;
+        ac.ids = ids ? ids + c0 : nullptr; ac.accepted = accepted ? accepted + c0 : nullptr;
+        hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, ac);
+        MHT_HIP_CHECK(hipGetLastError());
+    }
     f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
     f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
     f->births_since_step += n;
