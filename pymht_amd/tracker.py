@@ -128,9 +128,10 @@ class Tracker():
     # ------------------------------------------------------------------------------------------------
     def preInitialize(self, simList):
         """tracker.py:139-145: one root per ground-truth object of simList[0]."""
-        for initialTarget in simList[0]:
-            self.initiateTarget(Target(initialTarget.time, None, initialTarget.cartesianState(), self.P_0,
-                                       status=preinitializedTag))
+        # one batch: the device admits the candidates sequentially (each is tested against the leaves and against the
+        # candidates admitted before it), exactly like calling initiateTarget one by one
+        self._add_targets([Target(initialTarget.time, None, initialTarget.cartesianState(), self.P_0, status=preinitializedTag)
+                           for initialTarget in simList[0]])
 
     def initiateTarget(self, newTarget):
         """tracker.py:147-160.  The neighbour test (pyTarget.py:181-189) runs on the device against the current

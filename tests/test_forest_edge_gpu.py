@@ -257,3 +257,35 @@ def test_two_trackers_interleaved_share_nothing():
         assert digest(tb) == alone[1][k], k
     ta.close()
     tb.close()
+
+
+def test_preinitialize_batch_equals_one_by_one():
+    """Tracker.preInitialize(simList) (tracker.py:139-145) admits the ground-truth objects of simList[0] in one device batch;
+    the result must equal initiateTarget called one by one, including the rejection of objects closer than the merge threshold to
+    an earlier one."""
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+
+    class SimTarget:                                  # what the reference's simulator hands over: .time, .cartesianState()
+        def __init__(self, t, x):
+            self.time, self._x = t, x
+
+        def cartesianState(self):
+            return self._x
+
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-300, 300, size=(60, 2)), rng.normal(0, 5, size=(60, 2))], axis=1)
+    xs[7, 0:2] = xs[3, 0:2] + [1.0, -2.0]              # too close to an earlier one: rejected
+    xs[41, 0:2] = xs[40, 0:2] + [0.5, 0.5]
+    a = Tracker(pv, 2.5, 1e-5, 1e-4, P_d=0.9, N=3)
+    a.preInitialize([[SimTarget(1000.0, x.copy()) for x in xs]])
+    b = Tracker(pv, 2.5, 1e-5, 1e-4, P_d=0.9, N=3)
+    for x in xs:
+        b.initiateTarget(Target(1000.0, None, x.copy(), pv.P0, status="preinitialized"))
+    assert a.nTargets == b.nTargets and 40 < a.nTargets <= 58             # (a few random placements are too close as well)
+    la, lb = a.leafBatch(), b.leafBatch()
+    assert np.array_equal(la["ID"], lb["ID"]) and np.array_equal(la["x"], lb["x"]) and np.array_equal(la["P"], lb["P"])
+    assert [r.ID for r in a.__targetList__] == list(range(a.nTargets))
+    a.close()
+    b.close()
