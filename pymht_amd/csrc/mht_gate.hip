@@ -104,9 +104,11 @@ __device__ __forceinline__ int sortable(float f) {
     return i >= 0 ? i : (i ^ 0x7fffffff);
 }
 
-// tile state word: [63:40] epoch (scan), [33:32] flag (1 = aggregate, 2 = inclusive prefix), [31:0] value
+// tile state word: [63:32] epoch (the scan number, all 32 bits: a 24-bit tag would repeat after 16.7 M scans -- a quarter of an
+// hour at replay speed -- and a stale word of a tile index that was last used that long ago would read as ready), [31:0] value
 __device__ __forceinline__ unsigned long long pack_state(unsigned epoch, unsigned flag, unsigned value) {
-    return ((unsigned long long)(epoch & 0xffffffu) << 40) | ((unsigned long long)flag << 32) | value;
+    (void)flag;
+    return ((unsigned long long)epoch << 32) | value;
 }
 
 template <typename TS>
@@ -439,11 +441,11 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                     int spins = 0;
                     do {
                         st = __hip_atomic_load(&a.tile_state[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) {
+                        if ((unsigned)(st >> 32) != a.epoch) {
                             __builtin_amdgcn_s_sleep(1);
                             if (++spins > SPIN_LIMIT) { s_stall = 1; break; }
                         }
-                    } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
+                    } while ((unsigned)(st >> 32) != a.epoch);
                     v = (int)(st & 0xffffffffu);
                 } else if (lane == 63) {
                     v = total;
@@ -466,11 +468,11 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 int spins = 0;
                 do {
                     st = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(st >> 40) != (a.epoch & 0xffffffu)) {
+                    if ((unsigned)(st >> 32) != a.epoch) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > SPIN_LIMIT) { s_stall = 1; break; }
                     }
-                } while ((unsigned)(st >> 40) != (a.epoch & 0xffffffu));
+                } while ((unsigned)(st >> 32) != a.epoch);
                 acc += (int)(st & 0xffffffffu);
             }
 #pragma unroll
