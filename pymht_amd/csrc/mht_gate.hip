@@ -14,7 +14,8 @@
 //   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the number of
 //            children of ALL earlier leaves: every tile publishes its count, every 64th tile a group sum, as
 //            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences); a tile's
-//            base = group sums of earlier groups + counts of the earlier tiles of its own group: two L2 round trips.
+//            base = group sums of earlier groups + counts of the earlier tiles of its own group: two L2 round trips
+//            (<= 512 tiles: all earlier counts directly, one word per thread: one round trip).
 //   phase 4  one thread per child: k-th set bit of the hit mask -> measurement, x_hat = x_bar + K z_tilde,
 //            NLLR, cumulative score, ILP cost, root->leaf measurement path, ancestor table, target association bit +
 //            deduplicated (target, measurement-node) edge for the clustering kernel.  Consecutive threads write
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 __hip_atomic_store(&a.tile_state[tile], pack_state(a.epoch, 1u, (unsigned)total),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if ((tile & 63) == 63) {          // group leader: sum of the 64 tiles of the group
+            if ((tile & 63) == 63 && ntiles > GATE_THREADS) {          // group leader: sum of the 64 tiles of the group (two-hop mode only)
                 int v = total;
                 if (lane < 63) {
                     const int tq = tile - 63 + lane;
@@ -460,10 +461,14 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
         }
         __syncthreads();
         {
+            // few tiles (the co-resident case): read every earlier tile's count directly -- one hop instead of two (group
+            // sums are published only after their leader has seen its 63 tiles); many tiles: group sums + own group
+            const bool direct = ntiles <= GATE_THREADS;
             const int grp = tile >> 6, r = tile & 63;
+            const int nread = (a.ablate & 2) ? 0 : (direct ? tile : grp + r);
             int acc = 0;
-            for (int q = tid; q < ((a.ablate & 2) ? 0 : grp + r); q += GATE_THREADS) {
-                const unsigned long long* w = (q < grp) ? &a.group_state[q] : &a.tile_state[grp * 64 + (q - grp)];
+            for (int q = tid; q < nread; q += GATE_THREADS) {
+                const unsigned long long* w = direct ? &a.tile_state[q] : ((q < grp) ? &a.group_state[q] : &a.tile_state[grp * 64 + (q - grp)]);
                 unsigned long long st;
                 int spins = 0;
                 do {
