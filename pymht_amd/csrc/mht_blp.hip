@@ -335,8 +335,13 @@ constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bo
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
 __device__ __forceinline__ bool usage_counted_by_minimisers(const GStore&, int) { return false; }
 __device__ __forceinline__ bool usage_counted_by_minimisers(const LStore&, int K) { return K <= BLP_THREADS / 64; }
-__device__ __forceinline__ bool bb_after_rounds(const GStore&) { return false; }     // large clusters: subgradient steps in between
-__device__ __forceinline__ bool bb_after_rounds(const LStore&) { return true; }
+// Branch and bound right after the coordinate rounds only where it is cheap and cannot explode: clusters of <= 4 targets.
+// Larger clusters go on with subgradient steps (up to max_iter) first: their branch and bound needs good prices (a 68-target
+// scenario ran into the node limit with the prices of 16 coordinate rounds).
+__device__ __forceinline__ int coordinate_rounds(const GStore&, int) { return 0; }       // giant clusters: subgradient steps only
+__device__ __forceinline__ int coordinate_rounds(const LStore&, int K) { return K == 2 ? CA_ROUNDS_PAIR : CA_ROUNDS; }
+__device__ __forceinline__ bool bb_after_rounds(const GStore&, int) { return false; }
+__device__ __forceinline__ bool bb_after_rounds(const LStore&, int K) { return K <= 4; }
 // HBM policy: the same round on global scratch.  Regrets are reduced per row with two 64-bit atomicMax (the value displaced from
 // the row's top slot is pushed into the second slot: after all users the two slots hold the two largest regrets), so the round
 // stays O(columns) for clusters of any size.
@@ -589,11 +594,19 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     // near-duplicate tracks sharing a measurement in every scan of the window zig-zag geometrically -- subgradient steps took
     // up to ~100 more iterations where the branch and bound needs ~10 nodes); the HBM policy (large clusters, where a branch and
     // bound could explode) continues with subgradient steps up to max_iter before it branches.
-    const int ca_rounds = (K == 2) ? CA_ROUNDS_PAIR : CA_ROUNDS;
+    const int ca_rounds = coordinate_rounds(s, K);
     const int ca_end = a.max_iter < ca_rounds ? a.max_iter : ca_rounds;        // rounds [0, ca_end) are coordinate rounds
-    const int it_cap = bb_after_rounds(s) ? ca_end : a.max_iter;
+    const int it_cap = bb_after_rounds(s, K) ? ca_end : a.max_iter;
     for (int it = 0; it <= it_cap; ++it) {
         iters = it;
+        if (it == ca_end && ca_end > 0 && !bb_after_rounds(s, K)) {
+            // a larger cluster that the coordinate rounds did not certify: the subgradient steps start from zero prices, as
+            // they always did (from the rounds' prices they converged worse: a 29-target / 18 k-column cluster then ran
+            // its branch and bound into the node limit)
+            s.for_rows([&](int m) { s.u(m) = 0.0; });
+            __threadfence_block();
+            __syncthreads();
+        }
         // A: per target the minimiser of the reduced cost (lowest column index wins ties)
         compute_minimisers(s, K, r);
         if (it == 0) stamp[1] = wall_clock64();
@@ -689,6 +702,8 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             }
             if (UB - best_LB <= 1e-12 * fmax(1.0, fabs(UB))) { status = MHT_BLP_CERTIFIED; done = true; }   // zero duality gap
             if (it == it_cap || nrm == 0.0) done = true;
+            if (theta < 1.0 / 16.0) done = true;      // the dual bound has stalled through four step halvings: no certificate is
+                                                      // coming (duality gap), hand over to the branch and bound now
         }
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
         const double step = (done || coord) ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;

@@ -125,3 +125,13 @@ def test_blp_hbm_storage_policy(gpu_ctx, gold_dir, monkeypatch):
                 assert sel == inst["sel"].tolist()
     from test_tracker_gpu import test_tracker_replays_reference_trace
     test_tracker_replays_reference_trace("g3b_trace_cfg2", gold_dir)
+
+
+def test_blp_giant_cluster_without_certificate(gpu_ctx, gold_dir):
+    """29 targets / 17 935 columns from a dense scenario (tests/golden/g9_ilp_giant.npz): too large for the LDS policy, no dual
+    certificate exists, the subgradient phase stalls and the branch and bound has to close it -- exactly and well inside the
+    node limit (an earlier solver version exhausted it here)."""
+    inst = load_instances(os.path.join(gold_dir, "g9_ilp_giant.npz"))[0]
+    sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=200)
+    assert st == 2 and 0 < nd < 20000, (st, it, nd)
+    assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
