@@ -342,94 +342,9 @@ __device__ __forceinline__ int coordinate_rounds(const GStore&, int) { return 0;
 __device__ __forceinline__ int coordinate_rounds(const LStore&, int K) { return K == 2 ? CA_ROUNDS_PAIR : CA_ROUNDS; }
 __device__ __forceinline__ bool bb_after_rounds(const GStore&, int) { return false; }
 __device__ __forceinline__ bool bb_after_rounds(const LStore&, int K) { return K <= 4; }
-// HBM policy: the same round on global scratch.  Regrets are reduced per row with two 64-bit atomicMax (the value displaced from
-// the row's top slot is pushed into the second slot: after all users the two slots hold the two largest regrets), so the round
-// stays O(columns) for clusters of any size.
-__device__ __forceinline__ void nominate(const GStore& s, int K) {
-    for (int k = threadIdx.x; k < K; k += BLP_THREADS) {
-        const int h = s.best_h[k];
-        int act = 0x7fffffff;
-        for (int d = 0; d < s.PD; ++d) {
-            const int e = s.ent(d, h);
-            if (e >= 0 && s.usage(e) >= 2 && e < act) act = e;
-        }
-        s.lix[k] = (act == 0x7fffffff) ? -1 : act;
-        if (act != 0x7fffffff) atomicAdd(&s.mark(act), 1);
-    }
-}
-__device__ __forceinline__ bool coordinate_step(const GStore& s, int K, bool conflict, bool slack) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BlpArgs& a = *s.a;
-    if (conflict) {
-        for (int k = wave; k < K; k += BLP_THREADS / 64) {          // one wavefront per member: cheapest column avoiding its row
-            const int m = s.lix[k];
-            const bool active = m >= 0 && s.mark(m) == s.usage(m);
-            double alt = DINF;
-            int ai = -1;
-            if (active)
-                for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
-                    bool has = false;
-                    for (int d = 0; d < s.PD; ++d) has |= (s.ent(d, h) == m);
-                    if (has) continue;
-                    const double rc = reduced_cost(s, h);
-                    if (ai < 0 || rc < alt) { alt = rc; ai = h; }
-                }
-            wave_min_pair(alt, ai);
-            const double reg = active ? ((ai < 0 ? DINF : alt) - s.best_rc[k]) : -1.0;
-            if (lane == 0) {
-                s.mn[k] = reg;
-                if (active) {
-                    const unsigned long long key = (unsigned long long)__double_as_longlong(reg < 0.0 ? 0.0 : reg);
-                    const unsigned long long old = atomicMax(&a.row_a[m], key);
-                    atomicMax(&a.row_b[m], old < key ? old : key);
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        s.for_rows([&](int m) {
-            if (s.usage(m) >= 2 && s.mark(m) == s.usage(m)) {      // active row: its users left their two largest regrets
-                const double r1 = __longlong_as_double((long long)a.row_a[m]), r2 = __longlong_as_double((long long)a.row_b[m]);
-                if (r2 < DINF) s.u(m) += r2 + 0.5 * fmin(r1 - r2, 1.0);
-                a.row_a[m] = 0ull;
-                a.row_b[m] = 0ull;
-            }
-        });
-        __threadfence_block();
-        __syncthreads();
-    }
-    if (slack) {
-        s.for_rows([&](int m) { if (s.u(m) > 0.0 && s.usage(m) == 0) a.row_a[m] = ~0ull; });
-        __threadfence_block();
-        __syncthreads();
-        for (int k = wave; k < K; k += BLP_THREADS / 64) {
-            const bool busy = conflict && s.lix[k] >= 0 && s.mn[k] >= 0.0;
-            const double brc = s.best_rc[k];
-            for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
-                double gap = -1.0;
-                for (int d = 0; d < s.PD; ++d) {
-                    const int e = s.ent(d, h);
-                    if (e < 0 || !(s.u(e) > 0.0 && s.usage(e) == 0)) continue;
-                    if (gap < 0.0) { gap = busy ? 0.0 : reduced_cost(s, h) - brc; if (gap < 0.0) gap = 0.0; }
-                    atomicMin(&a.row_a[e], (unsigned long long)__double_as_longlong(gap));
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        s.for_rows([&](int m) {
-            if (s.u(m) > 0.0 && s.usage(m) == 0) {
-                const unsigned long long b = a.row_a[m];
-                const double g = (b == ~0ull) ? DINF : __longlong_as_double((long long)b);
-                s.u(m) = fmax(0.0, s.u(m) - (g * (1.0 + 9.5367431640625e-7) + 1e-9));
-                a.row_a[m] = 0ull;
-            }
-        });
-        __threadfence_block();
-        __syncthreads();
-    }
-    return false;
-}
+// HBM policy (giant clusters): no coordinate rounds (coordinate_rounds() is 0 there), these are never executed
+__device__ __forceinline__ void nominate(const GStore&, int) {}
+__device__ __forceinline__ bool coordinate_step(const GStore&, int, bool, bool) { return false; }
 // every target nominates the lowest conflicted row of its minimiser (lix = row or -1; markL counts nominations).
 // Runs in the same phase as the certificate flags (both only need the usage counters).
 __device__ __forceinline__ void nominate(const LStore& s, int K) {
@@ -1235,8 +1150,8 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t S = (size_t)2 * nT + 2;
     const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
-    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4] row_a[nR] row_b[nR] (64-bit words)
-    const size_t n_d = nR + 6 * S + 4 + 2 * nR;
+    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4]
+    const size_t n_d = nR + 6 * S + 4;
     // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd
     const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3;
     int rc = ctx->hitmask.ensure(n_d * 8 + n_i * 4 + 64);
@@ -1248,7 +1163,6 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.u = d; a.best_rc = d + nR; a.bb_cost = a.best_rc + S; a.bb_uused = a.bb_cost + S; a.bb_last_rc = a.bb_uused + S;
     a.bb_rest = a.bb_last_rc + S; a.bb_min = a.bb_rest + S;
     double* out = a.bb_min + S;
-    a.row_a = reinterpret_cast<unsigned long long*>(out + 4); a.row_b = a.row_a + nR;
     a.usage = q; a.mark = q + nR; a.best_h = a.mark + nR; a.bb_ch = a.best_h + S; a.bb_best = a.bb_ch + S; a.bb_last_idx = a.bb_best + S;
     int32_t* cl_ptr = a.bb_last_idx + S;
     int32_t* members = cl_ptr + 2;

@@ -85,7 +85,6 @@ struct BlpArgs {
     const double* cnllr;            // [cap] cumulativeNLLR of the children (single-target clusters)
     const int32_t* path; int cap; int PD;
     double* u; int32_t* usage; int32_t* mark; int n_mnodes;       // HBM-path scratch, zero on entry and on exit
-    unsigned long long* row_a; unsigned long long* row_b;          // HBM-path scratch [n_mnodes] each: per-row top-2 keys of a coordinate round, zero on entry and on exit
     // per-member scratch, slot = cl_ptr[c] + c + k  (k = 0..K)
     int32_t* best_h; double* best_rc; int32_t* bb_ch; int32_t* bb_best; double* bb_cost; double* bb_uused;
     double* bb_last_rc; int32_t* bb_last_idx; double* bb_rest; double* bb_min;
