@@ -28,10 +28,11 @@ for case in range(n_cases):
         o = make_oracle(g)
         ok = True
         for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
-            if time.time() - t0 > 15 or (k > 0 and st["L"] > 4000): print(desc, 'stopped after scan', k, '(the oracle gets slow beyond this size)'); break
+            if time.time() - t0 > 15 or (k > 0 and st["L"] > 2000): print(desc, 'stopped after scan', k, '(the oracle gets slow beyond this size)'); break
             info = o.add_scan(float(t), z)
             trk.addMeasurementList(MeasurementList(float(t), z))
             st = trk.lastScanStats
+            if trk.toc['Total'] > 0.2: print(desc, 'SLOW scan', k, '%.2f s' % trk.toc['Total'], 'L', st['L'], 'ilp', st['ilp'], 'branched', st['branched'], 'iters', st['blp_iters_max'], flush=True)
             os_, ts = o.selected(), tracker_selected(trk)
             lb, tb = o.leaf_batch(), trk.leafBatch()
             checks = [(st["L"], st["G"]) == (info["L"], info["G"]), np.array_equal(st["unused"], info["unused"]),
