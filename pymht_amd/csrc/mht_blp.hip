@@ -12,8 +12,9 @@
 //      reduced cost f_h + sum u.  If the minimisers are conflict-free and every priced node is used exactly once
 //      (complementary slackness) the primal cost equals the dual bound: CERTIFIED optimal.  Projected subgradient
 //      steps (Polyak step length, upper bound from a greedy dive) move the prices otherwise.
-//   2. If the certificate is not reached in max_iter steps: depth-first branch and bound over the targets with
-//      the Lagrangian bound (valid for any u >= 0), exact up to 1e-12 relative: BRANCHED.
+//   2. If the certificate is not reached: depth-first branch and bound over the targets (hot ones first) with the
+//      Lagrangian bound (valid for any u >= 0); the top levels re-optimise the prices of their residual problem and solve a
+//      node outright when its minimisers certify.  Exact up to 1e-12 relative: BRANCHED.
 // The reference's LP relaxation is integral in >99 % of instances, so step 2 is rare; it keeps
 // the selection exact without any host fallback.
 //
@@ -331,6 +332,7 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 // decreases.  Priced rows nobody uses any more are lowered to just below the cheapest taker.  Nothing here affects
 // exactness: the certificate (no conflict, no priced-but-unused row) is what proves optimality, and clusters that are
 // not certified after CA_ROUNDS go to the branch and bound.
+constexpr int BB_NODE_STEPS = 4;   // subgradient steps per such node
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
 __device__ __forceinline__ bool usage_counted_by_minimisers(const GStore&, int) { return false; }
@@ -638,17 +640,69 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         if (done) break;
     }
     if (status != 0) return;
-    // ---- depth-first branch and bound with the current prices ---------------------------------------------------
-    double usum = 0.0;
-    s.for_rows([&](int m) { usum += s.u(m); });
-    utot = block_sum(usum, r);
-    if (UB >= DINF) {
+    // ---- depth-first branch and bound -------------------------------------------------------------------------------
+    // Positions 0..K-1 of the search are the cluster's targets in "hot first" order (ord[]): targets whose minimiser touches
+    // an over-used or a priced row come first, the decisions that matter sit at the top of the tree.  At the first
+    // BB_RE_LEVELS levels a node does not just evaluate the Lagrangian bound with the prices it inherits: it takes a few
+    // subgradient steps on ITS residual problem (remaining targets, rows not blocked by the fixed columns) and checks the
+    // certificate there -- conflict-free minimisers that use every priced free row are an optimal completion, the node is
+    // solved without descending.  A static bound needs ~10^6 nodes on a 34-target cluster with an LP gap of 0.6 spread over 5
+    // targets; this needs ~50 (HiGHS, on the host: branch on the fractional targets, re-optimise at every node -- same idea).
+    // Any prices >= 0 give a valid bound, so exactness does not depend on the steps; the candidates of a level are enumerated
+    // in (reduced cost, index) order under the prices of that node, which are restored (snapshot in HBM) whenever the search
+    // returns to the level.
+    if (UB >= DINF) {      // (before best_rc is re-used below: the dive orders the targets by it)
         UB = greedy_dive(s, K, s.ch, r);
         for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.ch[k];
         __threadfence_block();
         __syncthreads();
     }
-    if (tid == 0) { s.cst[0] = 0.0; s.uus[0] = 0.0; }
+    int32_t* ord = reinterpret_cast<int32_t*>(s.best_rc);       // position -> member (best_rc is dead from here on)
+    int32_t* bh = s.best_h;                                      // position -> minimiser column of the current node
+    {   // hot-first order: minimisers and usage under the final prices
+        compute_minimisers(s, K, r);
+        if (!usage_counted_by_minimisers(s, K)) {
+            for (int idx = tid; idx < K * s.PD; idx += BLP_THREADS) add_usage(s, idx / s.PD, idx % s.PD);
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int k = tid; k < K; k += BLP_THREADS) {
+            int hot = 0;
+            const int h = s.best_h[k];
+            for (int d = 0; d < s.PD; ++d) {
+                const int e = s.ent(d, h);
+                if (e >= 0 && (s.usage(e) >= 2 || s.u(e) > 0.0)) ++hot;
+            }
+            s.lix[k] = hot;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int k = tid; k < K; k += BLP_THREADS) {           // rank sort: more hot rows first, ties by member index
+            const int hk = s.lix[k];
+            int rank = 0;
+            for (int j = 0; j < K; ++j) { const int hj = s.lix[j]; rank += (hj > hk || (hj == hk && j < k)) ? 1 : 0; }
+            ord[rank] = k;
+        }
+        s.for_rows([&](int m) { s.usage(m) = 0; });
+        __threadfence_block();
+        __syncthreads();
+    }
+    // snapshot slot for the re-optimised prices (a small shared pool: branching clusters are rare); none free or none
+    // configured -> plain static-bound search
+    int slot = -1;
+    if (a.bb_snap && a.bb_busy) {
+        if (tid == 0) {
+            int got = -1;
+            for (int i = 0; i < BB_SLOTS && got < 0; ++i)
+                if (atomicCAS(&a.bb_busy[i], 0, 1) == 0) got = i;
+            r->i[0] = got;
+        }
+        __syncthreads();
+        slot = r->i[0];
+        __syncthreads();
+    }
+    double* snap = slot >= 0 ? a.bb_snap + (size_t)slot * BB_RE_LEVELS * a.bb_snap_rows : nullptr;
+    if (tid == 0) s.cst[0] = 0.0;
     __threadfence_block();
     __syncthreads();
     int level = 0;
@@ -661,7 +715,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             if (level == K) {
                 if (s.cst[K] < UB - eps) {
                     UB = s.cst[K];
-                    for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.ch[k];
+                    for (int p = tid; p < K; p += BLP_THREADS) s.ub_sel[ord[p]] = s.ch[p];
                     __threadfence_block();
                     __syncthreads();
                 }
@@ -670,64 +724,150 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                 enter = false;
                 continue;
             }
-            for (int j = level + wave; j < K; j += BLP_THREADS / 64) {
-                double bv = DINF;
-                int bi = -1;
-                for (int h = s.col_begin(j) + lane; h < s.col_end(j); h += 64) {
-                    if (!compatible(s, h)) continue;
-                    const double rc = reduced_cost(s, h);
-                    if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            const int rounds = (snap && level < BB_RE_LEVELS) ? BB_NODE_STEPS : 0;
+            bool pruned = false;
+            double rs_all = 0.0, usumU = 0.0, best_lb = -DINF;
+            int best_rd = -1;
+            bool final_eval = false;          // one more evaluation under the restored best prices, no step after it
+            double* sl = snap ? snap + (size_t)(level < BB_RE_LEVELS ? level : 0) * a.bb_snap_rows : nullptr;
+            for (int rd = 0; rd <= rounds + 1; ++rd) {
+                // minimisers of the remaining targets among the columns compatible with the fixed ones
+                for (int p = level + wave; p < K; p += BLP_THREADS / 64) {
+                    const int k = ord[p];
+                    double bv = DINF;
+                    int bi = -1;
+                    for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+                        if (!compatible(s, h)) continue;
+                        const double rc = reduced_cost(s, h);
+                        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+                    }
+                    wave_min_pair(bv, bi);
+                    if (lane == 0) { s.mn[p] = (bi < 0) ? DINF : bv; bh[p] = bi; }
                 }
-                wave_min_pair(bv, bi);
-                if (lane == 0) s.mn[j] = (bi < 0) ? DINF : bv;
+                __threadfence_block();
+                __syncthreads();
+                double rs = 0.0, cs = 0.0;
+                int dead = 0;
+                for (int p = level + tid; p < K; p += BLP_THREADS) {
+                    const double v = s.mn[p];
+                    if (v >= DINF) dead = 1;
+                    else { rs += v; cs += s.cost(bh[p]); }
+                }
+                dead = block_or(dead, r);
+                if (dead) { pruned = true; break; }
+                int conflict = 0, slack = 0;
+                double nrm = 0.0, us = 0.0;
+                if (rounds > 0) {          // usage of the free rows by these minimisers
+                    for (int idx = tid; idx < (K - level) * s.PD; idx += BLP_THREADS) {
+                        const int p = level + idx / s.PD, d = idx % s.PD;
+                        const int e = s.ent(d, bh[p]);
+                        if (e >= 0) atomicAdd(&s.usage(e), 1);
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                s.for_rows([&](int m) {
+                    if (s.mark(m)) return;                      // blocked by a fixed column: not part of the residual problem
+                    const double um = s.u(m);
+                    us += um;
+                    if (rounds > 0) {
+                        const int ug = s.usage(m);
+                        double g = (double)(ug - 1);
+                        if (um <= 0.0 && g < 0.0) g = 0.0;
+                        nrm += g * g;
+                        conflict |= (ug >= 2);
+                        slack |= (um > 0.0 && ug == 0);
+                    }
+                });
+                rs_all = block_sum(rs, r);
+                usumU = block_sum(us, r);
+                const double lb = s.cst[level] + rs_all - usumU;
+                bool stop = false;
+                if (rounds > 0 && !final_eval && lb > best_lb) {       // keep the best prices of the node (a Polyak step with a loose
+                    best_lb = lb;                                      // upper bound can overshoot badly)
+                    best_rd = rd;
+                    s.for_rows([&](int m) { sl[m] = s.u(m); });
+                }
+                if (rounds > 0) {
+                    const double csum = block_sum(cs, r);
+                    nrm = block_sum(nrm, r);
+                    conflict = block_or(conflict, r);
+                    slack = block_or(slack, r);
+                    if (!conflict) {                            // the minimisers complete the fixed columns feasibly
+                        const double cand = s.cst[level] + csum;
+                        if (cand < UB - eps) {
+                            UB = cand;
+                            for (int p = tid; p < K; p += BLP_THREADS) s.ub_sel[ord[p]] = (p < level) ? s.ch[p] : bh[p];
+                            __threadfence_block();
+                            __syncthreads();
+                        }
+                        if (!slack) { pruned = true; stop = true; }      // ... and optimally: the node is solved
+                    }
+                }
+                if (!stop && lb >= UB - 1e-12 * fmax(1.0, fabs(UB))) { pruned = true; stop = true; }
+                const bool step_on = !stop && !final_eval && rd < rounds && nrm > 0.0;
+                // no further step: if the last evaluated prices are not the node's best, go back to those and evaluate once more
+                const bool redo = !stop && !final_eval && !step_on && rounds > 0 && best_rd != rd;
+                if (rounds > 0) {          // subgradient step on the free rows / restore of the best prices; counters back to zero
+                    const double step = step_on ? fmax(UB - lb, 1e-6) / nrm : 0.0;
+                    s.for_rows([&](int m) {
+                        if (redo) {
+                            s.u(m) = sl[m];
+                        } else if (!s.mark(m) && step_on) {
+                            const double um = s.u(m);
+                            double g = (double)(s.usage(m) - 1);
+                            if (um <= 0.0 && g < 0.0) g = 0.0;
+                            s.u(m) = fmax(0.0, um + step * g);
+                        }
+                        s.usage(m) = 0;
+                    });
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                if (redo) { final_eval = true; continue; }
+                if (stop || !step_on) break;
             }
-            __threadfence_block();
-            __syncthreads();
-            double rs = 0.0;
-            int dead = 0;
-            for (int j = level + tid; j < K; j += BLP_THREADS) {
-                const double v = s.mn[j];
-                if (v >= DINF) dead = 1;
-                else if (j > level) rs += v;
-            }
-            rs = block_sum(rs, r);
-            dead = block_or(dead, r);
-            const double lb = s.cst[level] + s.mn[level] + rs - (utot - s.uus[level]);
-            if (dead || lb >= UB - eps) {
+            if (pruned) {
                 if (level == 0) break;
                 --level;
                 set_marks(s, s.ch[level], 0);
                 enter = false;
                 continue;
             }
-            if (tid == 0) { s.rest[level] = rs; s.lrc[level] = -DINF; s.lix[level] = -1; }
+            // (sl holds the node's prices -- the best of its rounds -- for the returns from its children)
+            if (tid == 0) { s.rest[level] = rs_all - s.mn[level]; s.uus[level] = usumU; s.lrc[level] = -DINF; s.lix[level] = -1; }
             __threadfence_block();
             __syncthreads();
             enter = false;
+        } else if (snap && level + 1 < BB_RE_LEVELS) {
+            // back from a child that re-optimised the prices: restore this node's
+            const double* slr = snap + (size_t)level * a.bb_snap_rows;
+            s.for_rows([&](int m) { s.u(m) = slr[m]; });
+            __threadfence_block();
+            __syncthreads();
         }
-        // next candidate of target `level` in increasing (reduced cost, index) order
+        // next candidate of the target at this level in increasing (reduced cost, index) order under the node's prices
         double bv;
         int bi;
-        argmin_member(s, level, true, s.lrc[level], s.lix[level], bv, bi, r);
-        if (bi < 0 || s.cst[level] + bv + s.rest[level] - (utot - s.uus[level]) >= UB - eps) {
+        argmin_member(s, ord[level], true, s.lrc[level], s.lix[level], bv, bi, r);
+        if (bi < 0 || s.cst[level] + bv + s.rest[level] - s.uus[level] >= UB - eps) {
             if (level == 0) break;
             --level;
             set_marks(s, s.ch[level], 0);
             continue;
         }
-        const double pu = priced_sum(s, bi, r);
         if (tid == 0) {
             s.lrc[level] = bv;
             s.lix[level] = bi;
             s.ch[level] = bi;
             s.cst[level + 1] = s.cst[level] + s.cost(bi);
-            s.uus[level + 1] = s.uus[level] + pu;
         }
         set_marks(s, bi, 1);
         ++level;
         enter = true;
     }
     for (int l = 0; l < level; ++l) set_marks(s, s.ch[l], 0);     // leave no marks behind
+    if (slot >= 0 && tid == 0) atomicExch(&a.bb_busy[slot], 0);
 }
 
 // track termination test and N-scan prune depth for target t whose selected leaf is child s (forest mode)
@@ -1150,10 +1290,11 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t S = (size_t)2 * nT + 2;
     const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
-    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4]
-    const size_t n_d = nR + 6 * S + 4;
-    // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd
-    const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3;
+    // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4] snapshots[BB_SLOTS][BB_RE_LEVELS][snap_rows]
+    const size_t snap_rows = nR > (size_t)L_MAXR ? nR : (size_t)L_MAXR;
+    const size_t n_d = nR + 6 * S + 4 + (size_t)BB_SLOTS * BB_RE_LEVELS * snap_rows;
+    // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd busy[BB_SLOTS]
+    const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3 + BB_SLOTS;
     int rc = ctx->hitmask.ensure(n_d * 8 + n_i * 4 + 64);
     if (rc) return rc;
     double* d = static_cast<double*>(ctx->hitmask.ptr);
@@ -1163,6 +1304,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.u = d; a.best_rc = d + nR; a.bb_cost = a.best_rc + S; a.bb_uused = a.bb_cost + S; a.bb_last_rc = a.bb_uused + S;
     a.bb_rest = a.bb_last_rc + S; a.bb_min = a.bb_rest + S;
     double* out = a.bb_min + S;
+    a.bb_snap = out + 4; a.bb_snap_rows = (int)snap_rows;
     a.usage = q; a.mark = q + nR; a.best_h = a.mark + nR; a.bb_ch = a.best_h + S; a.bb_best = a.bb_ch + S; a.bb_last_idx = a.bb_best + S;
     int32_t* cl_ptr = a.bb_last_idx + S;
     int32_t* members = cl_ptr + 2;
@@ -1172,6 +1314,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     int32_t* st = counts + 4;
     a.cl_ptr = cl_ptr; a.cl_members = members; a.multi_list = multi; a.single_list = single; a.counts = counts;
     a.cl_status = st; a.cl_iters = st + 1; a.cl_nodes = st + 2;
+    a.bb_busy = st + 3;
     a.tchild = group_ptr; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;

@@ -75,6 +75,11 @@ struct ClusterArgs {
     int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow
 };
 
+// branch and bound of blp_kernel: the first BB_RE_LEVELS levels re-optimise the prices of their residual problem and keep a
+// snapshot of them in HBM; BB_SLOTS snapshot sets are shared by the workgroups of a launch (clusters that branch are rare)
+constexpr int BB_RE_LEVELS = 12;
+constexpr int BB_SLOTS = 8;
+
 struct RingLayer { const double* x; const double* cnllr; const int32_t* meas; const uint8_t* flags; };   // one layer of the node ring
 
 struct BlpArgs {
@@ -85,6 +90,9 @@ struct BlpArgs {
     const double* cnllr;            // [cap] cumulativeNLLR of the children (single-target clusters)
     const int32_t* path; int cap; int PD;
     double* u; int32_t* usage; int32_t* mark; int n_mnodes;       // HBM-path scratch, zero on entry and on exit
+    // branch and bound with re-optimised prices: snapshot pool [slots][levels][bb_snap_rows] and its busy flags (zero = free);
+    // null = static-bound search
+    double* bb_snap; int32_t* bb_busy; int bb_snap_rows;
     // per-member scratch, slot = cl_ptr[c] + c + k  (k = 0..K)
     int32_t* best_h; double* best_rc; int32_t* bb_ch; int32_t* bb_best; double* bb_cost; double* bb_uused;
     double* bb_last_rc; int32_t* bb_last_idx; double* bb_rest; double* bb_min;
