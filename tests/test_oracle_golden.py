@@ -53,6 +53,17 @@ def test_blp_exact_matches_recorded_and_bruteforce(gold_dir, name, least):
             assert abs(bo - obj) < 1e-9 and (ties > 1 or sorted(bs) == sel)
 
 
+def test_blp_exact_survives_the_instance_that_crashes_highs_presolve():
+    """Two targets (3 and 6 hypotheses, two of them with no measurement at all) over 4 measurements: HiGHS' presolve
+    segfaults on it (scipy 1.15.3); the oracle's exact solver must not use presolve.  From fuzz seed 60123."""
+    cols = [[], [0], [0, 1], [], [1], [2], [3], [1, 3], [2, 3]]
+    cost = [2.3077111646945614, -1.3412485884187602, -4.352695628825843, 2.3077111646945614, -0.8355870679930426,
+            -2.410760657117973, -2.5942404715584617, -6.632188665582252, -7.556655319126575]
+    sel, obj = orc.solve_blp_exact(cols, [3, 6], cost, 4)
+    bs, bo, ties = orc.solve_blp_bruteforce(cols, [3, 6], cost)
+    assert sel == sorted(bs) == [2, 8] and ties == 1 and abs(obj - bo) < 1e-12
+
+
 @pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2"])
 def test_scan_trace_replay(gold_dir, name):
     """Replays the recorded scans through OracleTracker and compares every scan with what the reference did."""
