@@ -1,0 +1,181 @@
+// Target side of a scan's end (shared by mht_forest.hip and mht_gate.hip): the compaction of the target table after track
+// termination + N-scan pruning (tracker.py:353-381, :1219-1231), the next scan's leaf ranges, the scan report.  It runs either
+// as commit_kernel (when the host needs the result now: report, births) or, deferred, in workgroup 0 of the NEXT scan's
+// grow_kernel, whose tiles derive the same tables for themselves in LDS (grow_kernel, "deferred commit").
+#pragma once
+#include "mht_kernels.h"
+
+namespace mht {
+
+constexpr int PRUNE_THREADS = 512;
+
+struct FCounts {          // device-side counters of the forest
+    int nT;               // targets in the NEXT table
+    int L;                // leaves in the NEXT leaf list
+    int n_nodes;          // nodes in the newest layer (children + roots born after the scan)
+    int n_roots;          // roots born into the newest layer
+    int id_counter;       // Tracker.trackIdCounter
+    int overflow;         // sticky capacity flag
+    int n_children;       // children of the last scan
+    int L_in;             // leaves gated in the last scan
+    int nTv[2];           // nT by table version: nTv[s & 1] = targets in the table scan s runs on.  The tiles of a grow_kernel that
+                          // carries the previous scan's commit read the OLD count here while that commit rewrites nT
+};
+
+struct TTable {           // one buffer of the target table
+    int32_t* id; int32_t* window; int32_t* depth; int32_t* shift; int32_t* root_scan; int32_t* root_node;
+    double* root_cnllr; uint8_t* root_f32;
+    int32_t* first;       // node index (newest layer) of the target's first leaf; its leaves are contiguous
+    int32_t* leaf_off;    // [T+1] exclusive prefix of the leaf counts
+};
+
+struct ReportHeader {     // device image of mht_scan_report up to the host pointers
+    int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
+        blp_iters_max, error, used_words, pad[3];
+};
+
+struct CommitArgs {
+    TTable cur, nxt;
+    const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
+    const int32_t* w_root_scan; const int32_t* w_root_node; const double* w_root_cnllr; const uint8_t* w_root_f32;
+    int R; int scan; int cap; int Tcap;
+    int vnext;            // version index of the table this commit produces: (scan + 1) & 1
+    int32_t* new_index;
+    FCounts* cnt; DevStatus* status;
+    int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
+    unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
+    ReportHeader* hdr; mht_target_report* rec;
+};
+
+// Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
+// roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
+__device__ __forceinline__ void commit_body(const CommitArgs& a) {
+    __shared__ int s_scan[PRUNE_THREADS / 64], s_scan2[PRUNE_THREADS / 64], s_total, s_total2, s_branched, s_limit, s_itmax;
+    const int tid = threadIdx.x;
+    // first round trip, everything at once: the scalars and the first chunk of per-target look-ups (index clamped by the
+    // table's capacity; entries beyond the real count are masked afterwards)
+    const int s_over = a.status->overflow, c_over = a.cnt->overflow, nT = a.cnt->nT, nCh = a.status->n_children;
+    const int nC = a.cl_counts[0], n_ilp = a.cl_counts[1], e_over = a.cl_counts[3];
+    const int tcl = tid < a.Tcap ? tid : 0;
+    int v_st = a.t_status[tcl], v_cnt = a.t_count[tcl], v_j = a.t_jdrop[tcl], v_first = a.t_firstsurv[tcl];
+    int v_id = a.cur.id[tcl], v_win = a.cur.window[tcl], v_dep = a.cur.depth[tcl];
+    int v_rs = a.w_root_scan[tcl], v_rn = a.w_root_node[tcl];
+    double v_rc = a.w_root_cnllr[tcl];
+    uint8_t v_rf = a.w_root_f32[tcl];
+    if (s_over || c_over) {        // void scan: report the error, leave the forest alone (it must be recreated)
+        if (tid == 0) {
+            ReportHeader& h = *a.hdr;
+            h.scan = a.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[nT];
+            h.n_children = nCh; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
+            h.blp_iters_max = 0; h.error = (s_over == 2) ? MHT_E_HIP : MHT_E_CAPACITY; h.used_words = 0;
+            a.cnt->overflow = 1;
+        }
+        return;
+    }
+    const int L_in = a.cur.leaf_off[nT];      // (only needed at the very end)
+    if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
+    int running = 0, lrun = 0;
+    for (int base = 0; base < nT; base += PRUNE_THREADS) {
+        const int t = base + tid;
+        const bool in = t < nT;
+        if (base > 0) {                 // further chunks (more than 512 targets): clamped, the look-ups go out together
+            const int tc = in ? t : 0;
+            v_st = a.t_status[tc]; v_cnt = a.t_count[tc]; v_j = a.t_jdrop[tc]; v_first = a.t_firstsurv[tc];
+            v_id = a.cur.id[tc]; v_win = a.cur.window[tc]; v_dep = a.cur.depth[tc];
+            v_rs = a.w_root_scan[tc]; v_rn = a.w_root_node[tc]; v_rc = a.w_root_cnllr[tc]; v_rf = a.w_root_f32[tc];
+        }
+        const int al = in && (v_st == 0);
+        const int cntl = v_cnt, j = v_j, first = v_first, id = v_id, win = v_win, dep = v_dep, rs = v_rs, rn = v_rn;
+        const double rc = v_rc;
+        const uint8_t rf = v_rf;
+        const int leaves = al ? cntl : 0;
+        // one block scan for both the compacted target index and the leaf offset
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = al, incl2 = leaves;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o), u2 = __shfl_up(incl2, o);
+            if (lane >= o) { incl += u; incl2 += u2; }
+        }
+        if (lane == 63) { s_scan[wv] = incl; s_scan2[wv] = incl2; }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, acc2 = 0;
+            for (int i = 0; i < PRUNE_THREADS / 64; ++i) {
+                const int v = s_scan[i], v2 = s_scan2[i];
+                s_scan[i] = acc; s_scan2[i] = acc2;
+                acc += v; acc2 += v2;
+            }
+            s_total = acc; s_total2 = acc2;
+        }
+        __syncthreads();
+        const int pos = running + s_scan[wv] + incl - al, lpos = lrun + s_scan2[wv] + incl2 - leaves;
+        running += s_total;
+        lrun += s_total2;
+        if (in) {
+            mht_target_report& r = a.rec[t];
+            r.new_index = al ? pos : -1;
+            r.n_leaves = leaves;
+            a.new_index[t] = al ? pos : -1;
+            if (al) {
+                a.nxt.id[pos] = id;
+                a.nxt.window[pos] = win;
+                a.nxt.depth[pos] = dep + 1 - j;
+                a.nxt.shift[pos] = j;
+                a.nxt.root_scan[pos] = rs;
+                a.nxt.root_node[pos] = rn;
+                a.nxt.root_cnllr[pos] = rc;
+                a.nxt.root_f32[pos] = rf;
+                a.nxt.first[pos] = first;
+                a.nxt.leaf_off[pos] = lpos;
+            }
+        }
+        if (base + PRUNE_THREADS < nT) __syncthreads();      // s_scan is re-used by the next chunk
+    }
+    const int nAlive = running, Lnext = lrun;
+    // ILP statistics
+    for (int i = tid; i < n_ilp; i += PRUNE_THREADS) {      // only this scan's ILPs: the entries of other clusters are stale
+        const int c = a.multi_list[i];
+        const int st = a.cl_status[c];
+        if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
+        if (st == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
+        if (st) atomicMax(&s_itmax, a.cl_iters[c]);
+    }
+    // used-measurement bytes -> bit mask of the report; bytes cleared for the next scan
+    for (int base = 0; base < a.W * 64; base += PRUNE_THREADS) {
+        const int jm = base + tid;
+        const int u = (jm < a.M) ? a.used_bytes[jm] : 0;
+        if (u) a.used_bytes[jm] = 0;
+        const unsigned long long bits = __ballot(u != 0);
+        if ((tid & 63) == 0 && jm < a.W * 64) a.used_words[jm >> 6] = bits;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.nxt.leaf_off[nAlive] = Lnext;
+        ReportHeader& h = *a.hdr;
+        h.scan = a.scan;
+        h.n_targets = nT;
+        h.n_alive = nAlive;
+        h.n_leaves_in = L_in;
+        h.n_children = nCh;
+        h.n_leaves_out = Lnext;
+        h.n_clusters = nC;
+        h.n_ilp = n_ilp;
+        h.n_branched = s_branched;
+        h.n_limit = s_limit;
+        h.blp_iters_max = s_itmax;
+        h.error = e_over ? MHT_E_CAPACITY : 0;
+        h.used_words = a.W;
+        a.cnt->L_in = L_in;
+        a.cnt->n_children = nCh;
+        a.cnt->nT = nAlive;
+        a.cnt->nTv[a.vnext] = nAlive;
+        a.cnt->L = Lnext;
+        a.cnt->n_nodes = nCh;
+        a.cnt->n_roots = 0;
+        // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a
+        // commit that rides in the next grow_kernel must not touch what that kernel's tiles are reading)
+    }
+}
+
+}  // namespace mht

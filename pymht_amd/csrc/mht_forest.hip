@@ -16,6 +16,7 @@
 // pyTarget.py:343-356, the new root, the report record and the surviving leaf range) and commit (here: compaction of
 // the target table tracker.py:353-381 / :1219-1231, next scan's leaf ranges, the scan report).
 #include "mht_kernels.h"
+#include "mht_commit.h"
 #include <string.h>
 #include <math.h>
 #include <new>
@@ -24,166 +25,11 @@
 namespace mht {
 
 constexpr int MAXR = 16;
-constexpr int PRUNE_THREADS = 512;
 constexpr int EV_POOL = 64;
-
-struct FCounts {          // device-side counters of the forest
-    int nT;               // targets in the NEXT table
-    int L;                // leaves in the NEXT leaf list
-    int n_nodes;          // nodes in the newest layer (children + roots born after the scan)
-    int n_roots;          // roots born into the newest layer
-    int id_counter;       // Tracker.trackIdCounter
-    int overflow;         // sticky capacity flag
-    int n_children;       // children of the last scan
-    int L_in;             // leaves gated in the last scan
-};
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
 
-struct TTable {           // one buffer of the target table
-    int32_t* id; int32_t* window; int32_t* depth; int32_t* shift; int32_t* root_scan; int32_t* root_node;
-    double* root_cnllr; uint8_t* root_f32;
-    int32_t* first;       // node index (newest layer) of the target's first leaf; its leaves are contiguous
-    int32_t* leaf_off;    // [T+1] exclusive prefix of the leaf counts
-};
-
-struct ReportHeader {     // device image of mht_scan_report up to the host pointers
-    int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
-        blp_iters_max, error, used_words, pad[3];
-};
-
-struct CommitArgs {
-    TTable cur, nxt;
-    const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
-    const int32_t* w_root_scan; const int32_t* w_root_node; const double* w_root_cnllr; const uint8_t* w_root_f32;
-    int R; int scan; int cap;
-    int32_t* new_index;
-    FCounts* cnt; DevStatus* status;
-    int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
-    unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
-    ReportHeader* hdr; mht_target_report* rec;
-};
-
-// Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
-// roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
-__global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) {
-    __shared__ int s_scan[PRUNE_THREADS / 64], s_scan2[PRUNE_THREADS / 64], s_total, s_total2, s_branched, s_limit, s_itmax;
-    const int tid = threadIdx.x;
-    if (a.status->overflow || a.cnt->overflow) {        // void scan: report the error, leave the forest alone (it must be recreated)
-        if (tid == 0) {
-            ReportHeader& h = *a.hdr;
-            h.scan = a.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[a.cnt->nT];
-            h.n_children = a.status->n_children; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
-            h.blp_iters_max = 0; h.error = (a.status->overflow == 2) ? MHT_E_HIP : MHT_E_CAPACITY; h.used_words = 0;
-            a.cnt->overflow = 1;
-        }
-        return;
-    }
-    const int nT = a.cnt->nT;
-    const int nCh = a.status->n_children;
-    // everything below that does not depend on the scans is fetched first, so its latency overlaps their barriers
-    const int nC = a.cl_counts[0], n_ilp = a.cl_counts[1], e_over = a.cl_counts[3], L_in = a.cur.leaf_off[nT];
-    if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
-    int running = 0, lrun = 0;
-    for (int base = 0; base < nT; base += PRUNE_THREADS) {
-        const int t = base + tid;
-        const bool in = t < nT;
-        const int tc = in ? t : 0;      // clamped: the ten look-ups go out together, without a branch each
-        const int al = in && (a.t_status[tc] == 0);
-        const int cntl = a.t_count[tc], j = a.t_jdrop[tc], first = a.t_firstsurv[tc];
-        const int id = a.cur.id[tc], win = a.cur.window[tc], dep = a.cur.depth[tc];
-        const int rs = a.w_root_scan[tc], rn = a.w_root_node[tc];
-        const double rc = a.w_root_cnllr[tc];
-        const uint8_t rf = a.w_root_f32[tc];
-        const int leaves = al ? cntl : 0;
-        // one block scan for both the compacted target index and the leaf offset
-        const int lane = tid & 63, wv = tid >> 6;
-        int incl = al, incl2 = leaves;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o), u2 = __shfl_up(incl2, o);
-            if (lane >= o) { incl += u; incl2 += u2; }
-        }
-        if (lane == 63) { s_scan[wv] = incl; s_scan2[wv] = incl2; }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, acc2 = 0;
-            for (int i = 0; i < PRUNE_THREADS / 64; ++i) {
-                const int v = s_scan[i], v2 = s_scan2[i];
-                s_scan[i] = acc; s_scan2[i] = acc2;
-                acc += v; acc2 += v2;
-            }
-            s_total = acc; s_total2 = acc2;
-        }
-        __syncthreads();
-        const int pos = running + s_scan[wv] + incl - al, lpos = lrun + s_scan2[wv] + incl2 - leaves;
-        running += s_total;
-        lrun += s_total2;
-        if (in) {
-            mht_target_report& r = a.rec[t];
-            r.new_index = al ? pos : -1;
-            r.n_leaves = leaves;
-            a.new_index[t] = al ? pos : -1;
-            if (al) {
-                a.nxt.id[pos] = id;
-                a.nxt.window[pos] = win;
-                a.nxt.depth[pos] = dep + 1 - j;
-                a.nxt.shift[pos] = j;
-                a.nxt.root_scan[pos] = rs;
-                a.nxt.root_node[pos] = rn;
-                a.nxt.root_cnllr[pos] = rc;
-                a.nxt.root_f32[pos] = rf;
-                a.nxt.first[pos] = first;
-                a.nxt.leaf_off[pos] = lpos;
-            }
-        }
-        if (base + PRUNE_THREADS < nT) __syncthreads();      // s_scan is re-used by the next chunk
-    }
-    const int nAlive = running, Lnext = lrun;
-    // ILP statistics
-    for (int i = tid; i < n_ilp; i += PRUNE_THREADS) {      // only this scan's ILPs: the entries of other clusters are stale
-        const int c = a.multi_list[i];
-        const int st = a.cl_status[c];
-        if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
-        if (st == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
-        if (st) atomicMax(&s_itmax, a.cl_iters[c]);
-    }
-    // used-measurement bytes -> bit mask of the report; bytes cleared for the next scan
-    for (int base = 0; base < a.W * 64; base += PRUNE_THREADS) {
-        const int jm = base + tid;
-        const int u = (jm < a.M) ? a.used_bytes[jm] : 0;
-        if (u) a.used_bytes[jm] = 0;
-        const unsigned long long bits = __ballot(u != 0);
-        if ((tid & 63) == 0 && jm < a.W * 64) a.used_words[jm >> 6] = bits;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        a.nxt.leaf_off[nAlive] = Lnext;
-        ReportHeader& h = *a.hdr;
-        h.scan = a.scan;
-        h.n_targets = nT;
-        h.n_alive = nAlive;
-        h.n_leaves_in = L_in;
-        h.n_children = nCh;
-        h.n_leaves_out = Lnext;
-        h.n_clusters = nC;
-        h.n_ilp = n_ilp;
-        h.n_branched = s_branched;
-        h.n_limit = s_limit;
-        h.blp_iters_max = s_itmax;
-        h.error = (a.status->overflow || a.cnt->overflow || e_over) ? MHT_E_CAPACITY : 0;
-        h.used_words = a.W;
-        a.cnt->L_in = L_in;
-        a.cnt->n_children = nCh;
-        a.cnt->nT = nAlive;
-        a.cnt->L = Lnext;
-        a.cnt->n_nodes = nCh;
-        a.cnt->n_roots = 0;
-        if (a.status->overflow) a.cnt->overflow = 1;
-        a.status->overflow = 0;      // per-scan status word is consumed here (no memset between scans)
-        a.status->n_children = 0;
-    }
-}
+__global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) { commit_body(a); }
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
 struct AddArgs {
@@ -192,6 +38,7 @@ struct AddArgs {
     mht_nodes layer;     // newest layer
     TTable tab; int32_t* path; int32_t* apath; int PD;
     FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
+    int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
 };
 
@@ -272,6 +119,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.cnt->n_nodes = idx + 1;
                 a.cnt->n_roots = r + 1;
                 a.cnt->nT = t + 1;
+                a.cnt->nTv[a.vidx] = t + 1;
                 a.cnt->L = L + 1;
                 s_adm[s_nadm & 2047] = q;
                 s_nadm += 1;
@@ -345,7 +193,9 @@ struct Forest {
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
     TTable tab[2];
-    unsigned long long* assoc; unsigned char* used_bytes;
+    unsigned long long* assoc;
+    unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
+    DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
     unsigned long long* tile_state; unsigned long long* group_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
     double* u; int32_t* usage; int32_t* mark;
@@ -362,6 +212,9 @@ struct Forest {
     int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0; bool dead = false;
     int nT_ub_step = 0;      // upper bound of the number of targets of the last launched scan (rows of its report)
     int births_since_step = 0;   // candidates added after the last launched scan (they are not in its report)
+    // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
+    // on its own by whoever needs the committed state first (report, births, exports)
+    bool commit_pending = false; CommitArgs pending = {};
     bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
     void layout(Arena& ar) {
@@ -383,7 +236,8 @@ struct Forest {
         }
         ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
         child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
-        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes = ar.take<unsigned char>(Mpad);
+        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
+        status2 = ar.take<DevStatus>(2);
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
         tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); group_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE / 64 + 8);
         edges = ar.take<unsigned>((size_t)EDGE_SEGS * SegCap);
@@ -432,6 +286,15 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
     f->stage_host_bytes = 0;
     MHT_HIP_CHECK(hipHostMalloc(&f->stage_host, bytes + 4096, hipHostMallocDefault));
     f->stage_host_bytes = bytes + 4096;
+    return MHT_OK;
+}
+
+// runs the pending commit now (see Forest::commit_pending)
+static int flush_commit(mht_ctx* ctx, Forest* f) {
+    if (!f->commit_pending) return MHT_OK;
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(PRUNE_THREADS), 0, ctx->stream, f->pending);
+    MHT_HIP_CHECK(hipGetLastError());
+    f->commit_pending = false;
     return MHT_OK;
 }
 
@@ -522,12 +385,13 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     MHT_REQUIRE(n >= 0 && (n == 0 || (x0 && P0 && flags && pd && meas)), "mht_forest_add_targets_dev: null input");
     if (n == 0) return MHT_OK;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     AddArgs a = {};
     a.n = n; a.x0 = x0; a.pd = pd; a.P0 = P0; a.meas = meas; a.flags = flags; a.ids = ids; a.accepted = accepted;
     a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
     const int nb = (f->scan + 1) & 1;
     a.layer = f->layer[f->scan % f->R];
-    a.tab = f->tab[nb];
+    a.tab = f->tab[nb]; a.vidx = nb;
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->PD;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
     a.near = f->near;
@@ -606,7 +470,10 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         f->ev_slot = (f->ev_slot + 1) % EV_POOL;
     }
     // No memsets between scans: the association bitsets are cleared by the cluster kernel while it reads them, the
-    // status word and the used-measurement bytes by the commit kernel, the cluster counters by the cluster kernel.
+    // used-measurement bytes by the commit, the other parity's status word and the cluster counters by the cluster kernel.
+    DevStatus* st_cur = f->status2 + (s & 1);
+    DevStatus* st_prev = f->status2 + ((s - 1) & 1);
+    const bool fused = f->commit_pending;      // the previous scan's commit rides in this scan's grow_kernel
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[0], st));
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     GateArgs g = {};
@@ -619,25 +486,35 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     g.ticket = f->ticket; g.tile_state = f->tile_state; g.group_state = f->group_state; g.epoch = (unsigned)s;
     g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
     g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
+    g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;
+    if (fused) {      // tables of the scan before, still uncommitted: the tiles compact them for themselves
+        const int pb = (s - 1) & 1;
+        g.fused = 1;
+        g.nT_dev = &f->cnt->nTv[pb];
+        g.p_status = f->t_status; g.p_count = f->t_count; g.p_jdrop = f->t_jdrop; g.p_firstsurv = f->t_firstsurv;
+        g.p_depth = f->tab[pb].depth; g.t_root_cnllr = f->w_root_cnllr; g.t_root_f32 = f->w_root_f32;
+    }
     g.z = z; g.M = M; g.W = W;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
     g.oflags = out.flags; g.oP = out.P; g.cap_out = out.cap; g.capc_out = out.cap_cov;
-    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = nullptr; g.used_bytes = f->used_bytes;
+    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = nullptr; g.used_bytes = f->used_bytes[s & 1];
     g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
     g.out_path = f->path[s & 1]; g.out_tgt = f->ctgt;
     g.in_apath = f->apath[(s - 1) & 1]; g.out_apath = f->apath[s & 1];
     g.assoc = f->assoc; g.assoc_words = f->AW; g.PD = f->PD; g.cur_slot_base = (s % f->R) * f->Mpad;
-    g.tchild = f->tchild; g.ocost = f->cost; g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
+    g.tchild = f->tchild; g.ocost = f->cost;
+    if (!fused) { g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32; }
     g.Nwin = f->cfg.n_scan;
     g.dbg = getenv("MHT_GROW_DEBUG") ? f->grow_dbg : nullptr;
-    int rc = launch_gate(ctx, g, f->L_ub > 0 ? f->L_ub : 1);
+    int rc = launch_gate(ctx, g, f->L_ub > 0 ? f->L_ub : 1, fused ? &f->pending : nullptr);
     if (rc) return rc;
+    f->commit_pending = false;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     ClusterArgs c = {};
     c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.seg_cap = f->SegCap; c.status = ctx->status; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.seg_cap = f->SegCap; c.status = st_cur; c.status_other = st_prev; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
@@ -653,7 +530,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
-    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = ctx->status;
+    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = st_cur;
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); b.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
@@ -676,15 +553,18 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
     p.sel = f->sel; p.t_status = f->t_status; p.t_jdrop = f->t_jdrop; p.t_count = f->t_count; p.t_firstsurv = f->t_firstsurv;
     p.w_root_scan = f->w_root_scan; p.w_root_node = f->w_root_node; p.w_root_cnllr = f->w_root_cnllr; p.w_root_f32 = f->w_root_f32;
-    p.R = f->R; p.scan = s; p.cap = f->Ncap;
+    p.R = f->R; p.scan = s; p.cap = f->Ncap; p.Tcap = f->Tcap; p.vnext = nb;
     p.new_index = f->new_index;
-    p.cnt = f->cnt; p.status = ctx->status;
+    p.cnt = f->cnt; p.status = st_cur;
     p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
-    p.used_bytes = f->used_bytes; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
+    p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
     p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(PRUNE_THREADS), 0, st, p);
-    MHT_HIP_CHECK(hipGetLastError());
+    // deferred: workgroup 0 of the next scan's grow_kernel runs it, unless somebody needs the committed state before that
+    // (flush_commit).  One launch and one kernel boundary less per scan; with timing on, its time shows up in the next
+    // scan's "gate" stage and the "prune" stage reads zero.
+    f->pending = p;
+    f->commit_pending = true;
     if (f->timing) { MHT_HIP_CHECK(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     f->report_pending = true;
     f->L_ub = f->Ncap;        // unknown until the report is fetched
@@ -710,6 +590,7 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     MHT_REQUIRE(f->scan > 0, "mht_forest_report: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     if (f->report_pending) {
+        { const int rc = flush_commit(ctx, f); if (rc) return rc; }
         const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
         MHT_HIP_CHECK(hipMemcpyAsync(f->report_host, f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -747,6 +628,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     Forest* f = ctx->forest;
     MHT_REQUIRE(capacity >= 0, "mht_forest_leaves: negative capacity");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     FCounts c;
     MHT_HIP_CHECK(hipMemcpyAsync(&c, f->cnt, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -788,6 +670,7 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R, "mht_forest_chain: scan %d is outside the window", scan);
     MHT_REQUIRE(node >= 0 && node < f->Ncap && max_len >= 1, "mht_forest_chain: bad node / max_len");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     int len = max_len;
     const int avail = f->R - (f->scan - scan);   // layers still in the ring going backwards
     if (len > avail) len = avail;
@@ -873,6 +756,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
     MHT_REQUIRE((size_t)bytes <= avail, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     MHT_HIP_CHECK(hipMemcpyAsync(host, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHT_OK;

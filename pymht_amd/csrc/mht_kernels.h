@@ -48,7 +48,17 @@ struct GateArgs {
     const double* t_root_cnllr;   // [T] cumulativeNLLR of the target's root
     const uint8_t* t_root_f32;    // [T] the root score is a float32 value
     int Nwin;                     // Tracker.N
+    // Deferred commit (forest mode).  fused = 1: the target-side commit of the PREVIOUS scan has not run; workgroup 0 of this
+    // launch runs it (CommitArgs, second kernel argument) while every tile derives the compacted target table it needs
+    // -- leaf ranges, depth, shift, old slot -- in LDS from that scan's per-target results (p_*), indexed by old slot.
+    // nT_dev then points at the old table's target count and t_root_cnllr / t_root_f32 at the old-slot root arrays.
+    int fused;
+    const int32_t* p_status; const int32_t* p_count; const int32_t* p_jdrop; const int32_t* p_firstsurv; const int32_t* p_depth;
+    const DevStatus* prev_status;     // forest mode: status word of the previous scan (overflow there voids this scan too)
+    const int32_t* sticky_overflow;   // forest mode: FCounts::overflow
 };
+
+struct CommitArgs;
 
 struct ClusterArgs {
     const unsigned long long* assoc;   // [T][AW]
@@ -59,6 +69,7 @@ struct ClusterArgs {
     int elds;                          // edges kept in LDS (set by launch_cluster); the rest spills to edge_t / edge_m
     int n_mnodes;                      // R * Mpad
     const DevStatus* status;           // forest mode: per-scan status word (overflow => do nothing)
+    DevStatus* status_other;           // forest mode: the other parity's status word, cleared here for the scan after this one
     int32_t* dbg;                      // development only: [8] wall-clock ticks at phase boundaries
     int clear_rows;                    // zero the bitset rows while reading them
     const unsigned* edges_in;          // forest mode: deduplicated edge list written by grow_kernel (skips the sweep)
@@ -116,7 +127,7 @@ struct BlpArgs {
     mht_target_report* rec; int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
 };
 
-int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
+int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArgs* commit = nullptr);
 void fill_model(GateArgs& a, const mht_model* m);
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);

@@ -289,3 +289,60 @@ def test_preinitialize_batch_equals_one_by_one():
     assert [r.ID for r in a.__targetList__] == list(range(a.nTargets))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("T,N,radius,lam,n_scans,kw", [
+    (60, 3, 500.0, 3e-5, 12, {}),                                                          # dense clusters, one tile chunk
+    (200, 7, 3000.0, 1.5e-6, 10, {}),                                                      # > 512 tiles: ticket-numbered tiles
+    (700, 3, 6000.0, 1e-6, 6, dict(maxTargets=1024, maxMeasurements=1024)),                # > 512 targets: chunked compaction
+])
+def test_deferred_commit_equals_immediate_commit(T, N, radius, lam, n_scans, kw):
+    """A scan's target-side commit runs inside the NEXT scan's grow_kernel unless the host asks for the committed state first.
+    Both orders must leave the same forest: tracker A reports after every scan (commit_kernel on its own every time), tracker B
+    steps through the C ABI without looking (deferred commits), with births in the middle (they force one commit), and is
+    compared at the end: report rows, used-measurement mask and the complete leaf list."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.tracker import _REPORT_DTYPE
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=T, radius=radius, lambda_phi=lam, n_scans=n_scans, seed=5)
+    A = _mk(sc, N=N, useInitiator=False, **kw)
+    B = _mk(sc, N=N, useInitiator=False, **kw)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    x0 = np.array([[radius * 3, radius * 3, 1.0, -2.0], [-radius * 3, radius * 2, 0.0, 3.0]])          # far from everything
+    P0 = np.tile(np.asarray(orc.model_P0(), dtype=np.float32).reshape(1, 16), (2, 1))
+    fl, pd, me = np.zeros(2, np.uint8), np.full(2, 0.85), np.zeros(2, np.int32)
+
+    def births(trk):
+        acc, ids = np.zeros(2, np.uint8), np.zeros(2, np.int32)
+        _lib.check(trk._lib.mht_forest_add_targets(trk._ctx.handle, 2, p(x0), p(P0), p(fl), p(pd), p(me), 1, p(acc), p(ids)))
+        assert acc.tolist() == [1, 1]
+        return ids.tolist()
+
+    def report(trk):
+        rep = _lib.MhtScanReport()
+        _lib.check(trk._lib.mht_forest_report(trk._ctx.handle, C.byref(rep)))
+        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(rep.n_targets * _REPORT_DTYPE.itemsize,)) \
+            .view(_REPORT_DTYPE).copy()
+        used = np.ctypeslib.as_array(C.cast(rep.used, C.POINTER(C.c_uint64)), shape=(rep.used_words,)).copy()
+        hdr = (rep.scan, rep.n_targets, rep.n_alive, rep.n_leaves_in, rep.n_children, rep.n_leaves_out, rep.n_clusters, rep.n_ilp)
+        return hdr, recs, used
+
+    z = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in sc["scans"]]
+    mid = n_scans // 2
+    for k in range(n_scans):
+        _lib.check(A._lib.mht_forest_step_host(A._ctx.handle, p(z[k]), len(z[k])))
+        ra = report(A)
+        _lib.check(B._lib.mht_forest_step_host(B._ctx.handle, p(z[k]), len(z[k])))
+        if k == mid:
+            assert births(A) == births(B)
+    hb, rb, ub = report(B)
+    assert ra[0] == hb, (ra[0], hb)
+    assert ra[1].tobytes() == rb.tobytes()
+    assert np.array_equal(ra[2], ub)
+    la, lb = A.leafBatch(), B.leafBatch()
+    assert len(la["ID"]) == hb[5] > 0
+    for key in la:
+        assert np.array_equal(la[key], lb[key]), key
+    A.close()
+    B.close()
