@@ -3,8 +3,9 @@
 
 A "step" = one radar scan through steps 1-6 of Tracker.addMeasurementList (grow/gate/score every leaf against
 every measurement, cluster, per-cluster 0-1 ILP, track termination, N-scan pruning) on the device-resident
-hypothesis forest -- four HIP launches (grow, cluster, blp incl. the per-target prune epilogue, commit [+ add_targets
-when tracks are born]), no memsets, no host round trip.  Workload = BASELINE.json configs[2] (headline):
+hypothesis forest -- three HIP launches (grow, cluster, blp incl. the per-target prune epilogue; the target-side commit of a
+scan rides in the next scan's grow launch [+ commit and add_targets launches when tracks are born]), no memsets, no host
+round trip.  stage_ms therefore shows the commit inside "gate"; "prune" is what two back-to-back event records cost.  Workload = BASELINE.json configs[2] (headline):
 500 targets, ~500 measurements/scan, N-scan = 5, synthetic scans from pymht_amd/utils/scenario.py.
 
 Protocol

@@ -11,10 +11,12 @@
 //                  the rows of its ILP column (tracker.py:1042-1113) and the key for N-scan pruning.
 //   target table   id, window, depth below the root, root node/score -- double buffered, compacted on termination.
 //   assoc[T][AW]   bitsets = the reference's __associatedMeasurements__ (tracker.py:78), rebuilt every scan.
-// Per scan four launches on one stream, no memsets, no host round trip: grow (mht_gate.hip), cluster (mht_cluster.hip),
+// Per scan three launches on one stream, no memsets, no host round trip: grow (mht_gate.hip), cluster (mht_cluster.hip),
 // blp (mht_blp.hip: selection + per target the termination test tracker.py:891-916, the N-scan prune decision
-// pyTarget.py:343-356, the new root, the report record and the surviving leaf range) and commit (here: compaction of
-// the target table tracker.py:353-381 / :1219-1231, next scan's leaf ranges, the scan report).
+// pyTarget.py:343-356, the new root, the report record and the surviving leaf range).  The target-side commit
+// (mht_commit.h: compaction of the target table tracker.py:353-381 / :1219-1231, next scan's leaf ranges, the scan report)
+// is deferred: it rides in workgroup 0 of the next scan's grow launch, or runs as commit_kernel when the host asks for the
+// committed state first (report, births, exports) -- see Forest::commit_pending.
 #include "mht_kernels.h"
 #include "mht_commit.h"
 #include <string.h>

@@ -3,7 +3,7 @@
 Same constructor, `preInitialize`, `initiateTarget`, `addMeasurementList(scanList, aisList=AisMessageList(), **kw)`,
 `getTrackNodes`, `getRuntimeAverage`, `runtimeLog`/`toc` keys and double-underscore attributes as the reference
 (pymht/tracker.py:39-307).  Steps 1-6 of a scan (grow, cluster, optimise, terminate, N-scan
-prune) run as four HIP launches on the device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h);
+prune) run as three HIP launches (+ one for the report) on the device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h);
 the host sees one report per scan.  Step 7 (M-of-N initiation, off the hot path) stays on the host.
 
 Not supported (raise): AIS fusion (`aisList` non-empty; tracker.py:417-552), `dynamicWindow`, `pruneSimilar`.

@@ -11,13 +11,22 @@ from pymht_amd.utils.classDefinitions import MeasurementList
 sc = make_config('cfg3', seed=5446, n_scans=14)
 trk = bench.make_tracker(sc, 0)
 names = ['stage', 'phase1', 'phase2', 'prefix', 'offsets', 'phase4']
+raw = len(sys.argv) > 1 and sys.argv[1] == 'raw'      # raw: step through the C ABI without reports -> deferred commits (replay mode)
 for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
-    trk.addMeasurementList(MeasurementList(float(t), z))
+    if raw and k >= 10:
+        zz = np.ascontiguousarray(z, dtype=np.float32)
+        _lib.check(trk._lib.mht_forest_step_host(trk._ctx.handle, zz.ctypes.data_as(C.c_void_p), len(zz)))
+        trk.lastScanStats = dict(L=13000)
+        trk.toc = dict(Process=0.0)
+    else:
+        trk.addMeasurementList(MeasurementList(float(t), z))
     if k < 11: continue
     a = np.zeros(32 + 8 * 4000, dtype=np.uint64)
     _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"grow_dbg", a.ctypes.data_as(C.c_void_p), a.nbytes))
     nt = (trk.lastScanStats["L"] + 31) // 32
     ts = a[32:32 + 8 * nt].reshape(nt, 8).astype(np.int64)
+    ts = ts[np.abs(ts[:, 0] - np.median(ts[:, 0])) < 5000]      # raw mode: L is not known, drop stale rows of earlier scans
+    nt = len(ts)
     t0 = ts[:, 0].min()
     rel = (ts[:, :7] - t0) / 100.0
     d = np.diff(rel, axis=1)
