@@ -346,3 +346,58 @@ def test_deferred_commit_equals_immediate_commit(T, N, radius, lam, n_scans, kw)
         assert np.array_equal(la[key], lb[key]), key
     A.close()
     B.close()
+
+
+def test_deferred_commit_edge_cases_raw_abi():
+    """Deferred commits (no report between scans) with (a) no targets at all, (b) targets that all die while nobody looks,
+    (c) a pool overflow in the middle: the overflow voids every later scan and surfaces in the first report asked for."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.models import pv
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def step(trk, z):
+        z = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 2)
+        _lib.check(trk._lib.mht_forest_step_host(trk._ctx.handle, p(z), len(z)))
+
+    def report(trk):
+        rep = _lib.MhtScanReport()
+        rc = trk._lib.mht_forest_report(trk._ctx.handle, C.byref(rep))
+        return rc, rep
+
+    # (a) an empty forest stepped three times
+    trk = Tracker(pv, 2.5, 1e-5, 1e-4, P_d=0.9, N=3, useInitiator=False)
+    rng = np.random.default_rng(1)
+    for k in range(3):
+        step(trk, rng.uniform(-50, 50, (5, 2)))
+    rc, rep = report(trk)
+    assert rc == 0 and (rep.scan, rep.n_targets, rep.n_alive, rep.n_leaves_in, rep.n_children) == (3, 0, 0, 0, 0)
+    trk.close()
+    # (b) two targets whose score limit kills them after a few empty scans, nobody looking in between
+    sc = _scenario(T=2, n_scans=12, seed=3)
+    ref = _mk(sc, N=3, useInitiator=False)
+    trk = _mk(sc, N=3, useInitiator=False)
+    empty = np.zeros((0, 2), dtype=np.float32)
+    alive = []
+    for k in range(12):
+        step(ref, empty)
+        rc, rep = report(ref)
+        assert rc == 0
+        alive.append(rep.n_alive)
+        step(trk, empty)
+    assert alive[0] == 2 and alive[-1] == 0, alive          # they do die on the way
+    rc, rep = report(trk)
+    assert rc == 0 and (rep.scan, rep.n_targets, rep.n_alive, rep.n_leaves_out) == (12, 0, 0, 0)
+    ref.close()
+    trk.close()
+    # (c) overflow while nobody looks
+    sc = _scenario(T=40, radius=300.0, lambda_phi=8e-5, n_scans=8, seed=5)
+    trk = _mk(sc, N=5, useInitiator=False, maxNodes=128)
+    for z in sc["scans"]:
+        step(trk, z)
+    rc, rep = report(trk)
+    assert rc in (_lib.MHT_E_CAPACITY, _lib.MHT_E_STATE), rc
+    with pytest.raises(_lib.MhtError):       # the forest refuses further scans
+        step(trk, sc["scans"][-1])
+    trk.close()
