@@ -193,7 +193,10 @@ int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const floa
 int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
                                const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
                                int32_t* ids);
-/* One scan, asynchronous: z dev (M,2) float32.  */
+/* One scan, asynchronous: z dev (M,2) float32.  Three launches (grow, cluster, ILP + prune decisions); the target-side commit
+ * of the scan (compacted target table, next leaf ranges, the report) is deferred: it rides in the next step's first launch,
+ * or runs as a launch of its own as soon as the report, new targets or an export are asked for.  Either order leaves the same
+ * forest (tests/test_forest_edge_gpu.py).  */
 int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
 /* Same with z in host memory (copied through a pinned staging buffer of the ctx). */
 int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M);
