@@ -16,6 +16,8 @@ namespace mht {
 
 
 constexpr int CL_THREADS = 1024;
+static_assert(CL_THREADS / 16 == EDGE_SEGS, "speculative gather: 16 threads per edge segment");
+constexpr int CL_SPEC = 128;       // edges per segment fetched speculatively in the first round trip (CL_THREADS / 64 threads x 8)
 constexpr int CL_ELDS_MAX = 16384; // edges kept in LDS (packed target<<16 | node), fewer if the tables need the room (ClusterArgs::elds);
                                    // the rest spills to HBM scratch
 
@@ -35,9 +37,21 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [a.elds]
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_scan2[CL_THREADS / 64], s_total, s_total2;
     const int tid = threadIdx.x;
-    if (a.status && a.status->overflow) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
-    if (a.status_other && tid == 0) a.status_other->overflow = 0;      // the scan after this one starts from a clean word
+    // First round trip, everything at once: the status word, the target count, the 64 segment lengths and -- speculatively --
+    // the first CL_SPEC edges of every segment (16 threads per segment; a segment holds ~55 edges on the headline config, its
+    // capacity is >= 1024, so the loads are always in bounds; what lies beyond a segment's length is masked below).
+    const int s_over = a.status ? a.status->overflow : 0;
     const int T = *a.nT_dev;
+    int my_n = 0;
+    unsigned spec[CL_SPEC / 16];
+    if (a.edges_in) {
+        if (tid < EDGE_SEGS) my_n = a.edge_count[tid];
+        const int sg = tid >> 4, l16 = tid & 15;
+#pragma unroll
+        for (int q = 0; q < CL_SPEC / 16; ++q) spec[q] = a.edges_in[(size_t)sg * a.seg_cap + l16 + 16 * q];
+    }
+    if (s_over) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
+    if (a.status_other && tid == 0) a.status_other->overflow = 0;      // the scan after this one starts from a clean word
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
@@ -48,10 +62,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
     if (a.edges_in) {
         // forest mode: grow_kernel already produced the deduplicated edge list, in EDGE_SEGS counted segments
-        __shared__ int s_segoff[EDGE_SEGS + 1];
+        __shared__ int s_segoff[EDGE_SEGS + 1], s_long;
         if (tid < 64) {
-            int n = a.edge_count[tid];
+            int n = my_n;
             if (n > a.seg_cap) { n = a.seg_cap; a.counts[3] = 1; }
+            const int any_long = __any(n > CL_SPEC) ? 1 : 0;
+            if (tid == 0) s_long = any_long;
             int incl = n;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -64,11 +80,24 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         __syncthreads();
         E = s_segoff[EDGE_SEGS];
         if (E > a.elds + a.Ecap) { if (tid == 0) a.counts[3] = 1; E = a.elds + a.Ecap; }
-        // flat gather: thread -> dense edge index -> (segment, offset) by binary search over the 65 offsets
-        // four edges per thread and pass: the four global loads are issued before the first result is stored (the loop is
-        // latency bound: one round trip per pass)
-        for (int e0 = tid; e0 < E; e0 += 4 * CL_THREADS) {
+        {   // the speculative loads: entry l16 + 16 q of segment sg, if the segment is that long
+            const int sg = tid >> 4, l16 = tid & 15;
+            const int sb = s_segoff[sg], sn = s_segoff[sg + 1] - sb;
+#pragma unroll
+            for (int q = 0; q < CL_SPEC / 16; ++q) {
+                const int idx = l16 + 16 * q, e = sb + idx;
+                if (idx < sn && e < E) {
+                    if (e < a.elds) eL[e] = spec[q];
+                    else { a.edge_t[e - a.elds] = (int)(spec[q] >> 16); a.edge_m[e - a.elds] = (int)(spec[q] & 0xffff); }
+                }
+            }
+        }
+        // segments longer than CL_SPEC (rare): flat gather of the rest: thread -> dense edge index -> (segment, offset) by
+        // binary search over the 65 offsets, four edges per thread and pass (the four global loads are issued before the
+        // first result is stored: one round trip per pass)
+        for (int e0 = tid; e0 < (s_long ? E : 0); e0 += 4 * CL_THREADS) {
             unsigned pk[4];
+            bool rest[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = e0 + q * CL_THREADS;
@@ -76,11 +105,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
                 int lo = 0, hi = EDGE_SEGS;
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_segoff[mid] <= ec) lo = mid; else hi = mid; }
                 pk[q] = a.edges_in[(size_t)lo * a.seg_cap + (ec - s_segoff[lo])];
+                rest[q] = ec - s_segoff[lo] >= CL_SPEC;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = e0 + q * CL_THREADS;
-                if (e >= E) continue;
+                if (e >= E || !rest[q]) continue;
                 if (e < a.elds) eL[e] = pk[q];
                 else { a.edge_t[e - a.elds] = (int)(pk[q] >> 16); a.edge_m[e - a.elds] = (int)(pk[q] & 0xffff); }
             }
