@@ -18,6 +18,7 @@ namespace mht {
 constexpr int CL_THREADS = 1024;
 static_assert(CL_THREADS / 16 == EDGE_SEGS, "speculative gather: 16 threads per edge segment");
 constexpr int CL_SPEC = 128;       // edges per segment fetched speculatively in the first round trip (CL_THREADS / 64 threads x 8)
+constexpr int CL_PEND_MAX = 4096;  // (owner, user) target pairs waiting for their union (ClusterArgs::pcap); more are united straight away
 constexpr int CL_ELDS_MAX = 16384; // edges kept in LDS (packed target<<16 | node), fewer if the tables need the room (ClusterArgs::elds);
                                    // the rest spills to HBM scratch
 
@@ -32,9 +33,11 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     int* lab = tlabel + a.Tcap;                          // [Tcap]  final label = smallest target of the component
     int* cnt = lab + a.Tcap;                             // [Tcap]  by head: members of its cluster
     int* fill = cnt + a.Tcap;                            // [Tcap]  by head: member slots handed out
-    int* mlabel = fill + a.Tcap;                         // [n_mnodes] union-find parent of a measurement node
+    int* mlabel = fill + a.Tcap;                         // [n_mnodes] smallest target that uses the measurement node
     const int mslots = a.n_mnodes > 2 * a.Tcap ? a.n_mnodes : 2 * a.Tcap;   // re-used for the cluster tables afterwards
     unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [a.elds]
+    unsigned* pend = eL + a.elds;                                  // [a.pcap] (owner << 16 | user) pairs still to be united
+    __shared__ int s_pend;
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_scan2[CL_THREADS / 64], s_total, s_total2;
     const int tid = threadIdx.x;
     // First round trip, everything at once: the status word, the target count, the 64 segment lengths and -- speculatively --
@@ -55,8 +58,8 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
-    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = T + m;
-    if (tid == 0) { s_edges = 0; s_changed = 0; a.counts[3] = 0; }
+    for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
+    if (tid == 0) { s_edges = 0; s_changed = 0; s_pend = 0; a.counts[3] = 0; }
     __syncthreads();
     int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
@@ -155,32 +158,62 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         }
     }
     CL_STAMP(0);
-    // connected components by lock-free union-find in LDS: vertices = targets (0..T-1) and measurement nodes (mlabel[]
-    // doubles as their parent array, value = vertex id, T + m).  Every edge hooks the larger root under the smaller one
-    // with atomicCAS; targets have the smaller ids, so the root of a component is its smallest target -- the label the
-    // reference's scipy labelling + np.where ordering implies (tracker.py:972-974).  One pass over the edges, one
-    // compression pass: no iteration to a fixed point.
+    // Connected components.  Pass A: every measurement node learns its smallest user (one fire-and-forget LDS atomicMin per
+    // edge; most nodes have a single user and are done).  Pass B: every other user of a node must end up in its owner's
+    // component: those (owner, user) pairs are compacted into a list (ballot + one LDS atomic per wavefront) and united, one
+    // pair per thread, by a lock-free union-find over the TARGETS only (hook the larger root under the smaller with
+    // atomicCAS) -- the root of a component is its smallest target, the label the reference's scipy labelling + np.where
+    // ordering implies (tracker.py:972-974).  Running the unions straight from the edge loop made every wavefront wait, in
+    // every pass, for its few lanes on the slow path; compacted, the slow path runs once, fully occupied.
     int iters_done = 1;
-    auto parent_of = [&](int v) -> int { return v < T ? tlabel[v] : mlabel[v - T]; };
     auto find_root = [&](int v) -> int {
-        int p = parent_of(v);
-        while (p != v) { v = p; p = parent_of(v); }
+        int p = tlabel[v];
+        while (p != v) { v = p; p = tlabel[v]; }
         return v;
     };
-    for (int e = tid; e < E; e += CL_THREADS) {
-        const unsigned pk = cl_edge(eL, a, e);
-        const int et = (int)(pk >> 16), em = (int)(pk & 0xffff);
-        // most measurement nodes belong to one target only: the first edge of a node claims it with a single CAS
-        // (node still its own root -> child of that target); only further edges of the node need the generic union
-        if (atomicCAS(&mlabel[em], T + em, et) == T + em) continue;
-        int ra = find_root(et), rb = find_root(T + em);
+    auto unite = [&](int x, int y) {
+        int ra = find_root(x), rb = find_root(y);
         while (ra != rb) {
             if (ra > rb) { const int tmp = ra; ra = rb; rb = tmp; }      // ra < rb: hook rb under ra
-            int* slot = rb < T ? &tlabel[rb] : &mlabel[rb - T];
-            const int old = atomicCAS(slot, rb, ra);
+            const int old = atomicCAS(&tlabel[rb], rb, ra);
             if (old == rb) break;
             rb = find_root(old);          // somebody else moved rb meanwhile: retry from its new root
             ra = find_root(ra);
+        }
+    };
+    for (int e = tid; e < E; e += CL_THREADS) {
+        const unsigned pk = cl_edge(eL, a, e);
+        atomicMin(&mlabel[pk & 0xffff], (int)(pk >> 16));
+    }
+    __syncthreads();
+    if (tid == 0) s_edges = 0;      // (the stateless seam counted its edges here; from now on it counts the multi-target clusters)
+    for (int e0 = 0; e0 < E; e0 += CL_THREADS) {
+        const int e = e0 + tid;
+        int owner = -1, et = -1;
+        if (e < E) {
+            const unsigned pk = cl_edge(eL, a, e);
+            et = (int)(pk >> 16);
+            owner = mlabel[pk & 0xffff];
+        }
+        const bool foreign = owner != et;      // owner < et
+        const unsigned long long fm = __ballot(foreign);
+        if (fm) {
+            const int lane = tid & 63, leader = __ffsll((long long)fm) - 1;
+            int pos = 0;
+            if (lane == leader) pos = atomicAdd(&s_pend, __popcll(fm));
+            pos = __shfl(pos, leader) + __popcll(fm & ((1ull << lane) - 1ull));
+            if (foreign) {
+                if (pos < a.pcap) pend[pos] = ((unsigned)owner << 16) | (unsigned)et;
+                else unite(owner, et);          // list full (huge graphs): straight from here
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int np = s_pend < a.pcap ? s_pend : a.pcap;
+        for (int i = tid; i < np; i += CL_THREADS) {
+            const unsigned pr = pend[i];
+            unite((int)(pr >> 16), (int)(pr & 0xffff));
         }
     }
     __syncthreads();
@@ -280,23 +313,33 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
 }
 
 constexpr size_t CL_LDS_BUDGET = 150 * 1024;
-// LDS edge-list capacity for a given table size: what is left of the budget, at most CL_ELDS_MAX; < Tcap = does not fit
-int cluster_elds(int Tcap, int n_mnodes) {
+// LDS carve for a given table size: the pending-pair list gets a quarter of what the tables leave (at most CL_PEND_MAX), the
+// edge list the rest (at most CL_ELDS_MAX); elds < Tcap = does not fit
+static void cluster_carve(int Tcap, int n_mnodes, int& elds, int& pcap) {
     const size_t mslots = n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap;
     const size_t tables = ((size_t)4 * Tcap + mslots) * 4;
-    if (tables >= CL_LDS_BUDGET) return 0;
+    elds = 0; pcap = 0;
+    if (tables >= CL_LDS_BUDGET) return;
     const size_t room = (CL_LDS_BUDGET - tables) / 4;
-    return (int)(room < (size_t)CL_ELDS_MAX ? room : (size_t)CL_ELDS_MAX);
+    pcap = (int)(room / 4 < (size_t)CL_PEND_MAX ? room / 4 : (size_t)CL_PEND_MAX);
+    elds = (int)(room - pcap < (size_t)CL_ELDS_MAX ? room - pcap : (size_t)CL_ELDS_MAX);
+}
+int cluster_elds(int Tcap, int n_mnodes) {
+    int elds, pcap;
+    cluster_carve(Tcap, n_mnodes, elds, pcap);
+    return elds;
 }
 size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
     const size_t mslots = n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap;
-    return ((size_t)4 * Tcap + mslots + (size_t)cluster_elds(Tcap, n_mnodes)) * 4;
+    int elds, pcap;
+    cluster_carve(Tcap, n_mnodes, elds, pcap);
+    return ((size_t)4 * Tcap + mslots + (size_t)elds + (size_t)pcap) * 4;
 }
 
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in) {
     ClusterArgs a = a_in;
     size_t& attr_bytes = ctx->lds_attr_cluster;
-    a.elds = cluster_elds(a.Tcap, a.n_mnodes);
+    cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap);
     const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
     if (a.elds < a.Tcap || a.elds < 1024 || a.n_mnodes > 65536) {
         set_error("cluster: Tcap=%d and %d measurement nodes do not fit the clustering kernel's LDS budget (%zu KiB)", a.Tcap, a.n_mnodes,

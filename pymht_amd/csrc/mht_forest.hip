@@ -370,7 +370,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     // cluster-kernel LDS budget check up front
     if (cluster_elds(f->Tcap, f->n_mnodes) < f->Tcap || cluster_elds(f->Tcap, f->n_mnodes) < 1024) {
         set_error("mht_forest_create: max_targets=%d and (n_scan+2) x max_meas = %d measurement nodes do not fit the clustering "
-                  "kernel's LDS budget (16*max_targets + 4*nodes + 4*max(1024, max_targets) <= 150 KiB): lower max_targets / max_meas",
+                  "kernel's LDS budget (150 KiB: 16 B per target + 4 B per node, and three quarters of the rest must hold max(1024, max_targets) edges): lower max_targets / max_meas",
                   f->Tcap, f->n_mnodes);
         forest_destroy(ctx);
         return MHT_E_CAPACITY;

@@ -67,6 +67,7 @@ struct ClusterArgs {
     int Tcap;
     int32_t* edge_t; int32_t* edge_m; int Ecap;
     int elds;                          // edges kept in LDS (set by launch_cluster); the rest spills to edge_t / edge_m
+    int pcap;                          // capacity of the LDS list of target pairs to unite (set by launch_cluster)
     int n_mnodes;                      // R * Mpad
     const DevStatus* status;           // forest mode: per-scan status word (overflow => do nothing)
     DevStatus* status_other;           // forest mode: the other parity's status word, cleared here for the scan after this one
