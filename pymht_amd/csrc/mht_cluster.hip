@@ -181,19 +181,66 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             ra = find_root(ra);
         }
     };
-    for (int e = tid; e < E; e += CL_THREADS) {
+    // (a thread keeps its first four edges -- all of them up to 4096 edges -- in registers across both passes: with sixteen
+    // wavefronts on one LDS every access counts, not only the dependent ones)
+    constexpr unsigned NO_EDGE = 0xffffffffu;
+    unsigned pkr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * CL_THREADS;
+        pkr[q] = e < E ? cl_edge(eL, a, e) : NO_EDGE;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (pkr[q] != NO_EDGE) atomicMin(&mlabel[pkr[q] & 0xffff], (int)(pkr[q] >> 16));
+    for (int e = tid + 4 * CL_THREADS; e < E; e += CL_THREADS) {
         const unsigned pk = cl_edge(eL, a, e);
         atomicMin(&mlabel[pk & 0xffff], (int)(pk >> 16));
     }
     __syncthreads();
     if (tid == 0) s_edges = 0;      // (the stateless seam counted its edges here; from now on it counts the multi-target clusters)
-    for (int e0 = 0; e0 < E; e0 += CL_THREADS) {
+    {
+        // pass B for the edges in registers: one list reservation per wavefront for all four
+        const int lane = tid & 63;
+        int owner[4];
+        unsigned long long fm[4];
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) owner[q] = (pkr[q] != NO_EDGE) ? mlabel[pkr[q] & 0xffff] : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fm[q] = __ballot(pkr[q] != NO_EDGE && owner[q] != (int)(pkr[q] >> 16));
+            total += __popcll(fm[q]);
+        }
+        if (a.edges_in && a.clear_rows) {      // clear the dedup bitsets for the next scan (forest mode), while the edge is at hand
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (pkr[q] != NO_EDGE) rows[(size_t)(pkr[q] >> 16) * a.AW + ((pkr[q] & 0xffff) >> 6)] = 0ull;
+        }
+        if (total) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_pend, total);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((fm[q] >> lane) & 1ull) {
+                    const int pos = base + __popcll(fm[q] & ((1ull << lane) - 1ull));
+                    const int et = (int)(pkr[q] >> 16);
+                    if (pos < a.pcap) pend[pos] = ((unsigned)owner[q] << 16) | (unsigned)et;
+                    else unite(owner[q], et);          // list full (huge graphs): straight from here
+                }
+                base += __popcll(fm[q]);
+            }
+        }
+    }
+    for (int e0 = 4 * CL_THREADS; e0 < E; e0 += CL_THREADS) {      // more than 4096 edges: the rest, one at a time
         const int e = e0 + tid;
         int owner = -1, et = -1;
         if (e < E) {
             const unsigned pk = cl_edge(eL, a, e);
             et = (int)(pk >> 16);
             owner = mlabel[pk & 0xffff];
+            if (a.edges_in && a.clear_rows) rows[(size_t)et * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
         }
         const bool foreign = owner != et;      // owner < et
         const unsigned long long fm = __ballot(foreign);
@@ -204,7 +251,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
             pos = __shfl(pos, leader) + __popcll(fm & ((1ull << lane) - 1ull));
             if (foreign) {
                 if (pos < a.pcap) pend[pos] = ((unsigned)owner << 16) | (unsigned)et;
-                else unite(owner, et);          // list full (huge graphs): straight from here
+                else unite(owner, et);
             }
         }
     }
@@ -222,11 +269,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         lab[t] = r;                       // (writing tlabel here would race with other threads' find_root)
         atomicAdd(&cnt[r], 1);
     }
-    if (a.edges_in) {      // clear the dedup bitsets for the next scan and hand the counters back (edge list still intact)
-        for (int e = tid; e < E; e += CL_THREADS) {
-            const unsigned pk = cl_edge(eL, a, e);
-            rows[(size_t)(pk >> 16) * a.AW + ((pk & 0xffff) >> 6)] = 0ull;
-        }
+    if (a.edges_in) {      // hand the counters back (the dedup bitsets were cleared in pass B)
         if (tid < EDGE_SEGS) a.edge_count[tid] = 0;
         if (tid == 0 && a.ticket_reset) *a.ticket_reset = 0;      // grow_kernel's tile ticket (used when its grid is not co-resident)
     }
