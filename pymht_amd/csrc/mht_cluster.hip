@@ -6,9 +6,10 @@
 // edges are the reference's __associatedMeasurements__ sets.  In the forest grow_kernel hands over a de-duplicated
 // (target, node) edge list in 64 counted segments (the per-target bitsets only serve as its de-duplication filter and are
 // cleared here through that list); the stateless seam mht_cluster expands bitsets into the edge list first.
-// One workgroup, everything in LDS, nine barrier-separated phases: gather the edges; lock-free union-find (labels are
-// target indices, a component's root is its smallest target); path compression + member counts; one dual block scan for
-// cluster index and cluster offset; slot + rank for the ascending member lists.  Clusters come out ordered by smallest
+// One workgroup, everything in LDS, ten barrier-separated phases: gather the edges (one global round trip, speculative);
+// every node learns its smallest user; the other users are united with it (lock-free union-find over the targets, a
+// component's root is its smallest target); root search + member counts; one dual block scan for cluster index and cluster
+// offset; slot + rank for the ascending member lists.  Clusters come out ordered by smallest
 // member with ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
 #include "mht_kernels.h"
 
