@@ -37,8 +37,8 @@ import torch  # noqa: E402
 LAMBDA_NU = 1e-4
 ETA2 = 5.99
 # HBM bytes per grow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
-# workload, steady-state scans): profiles/r01r_pmc_hbm_traffic.txt.  Keyed by config name; None = not profiled.
-PMC_TRAFFIC_BYTES = {"cfg3": (3331 + 6204) * 1024}
+# workload, steady-state scans): profiles/r01s_pmc_hbm_traffic.txt.  Keyed by config name; None = not profiled.
+PMC_TRAFFIC_BYTES = {"cfg3": (3331 + 6205) * 1024}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
 
 
@@ -331,7 +331,7 @@ def main():
                     "initiator (%.0f %% of that time)" % (100.0 * init_s / api_s),
         "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gate_gbs / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(args.config),
-                     "traffic_source": "profiles/r01r_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
+                     "traffic_source": "profiles/r01s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
                      "kernel": "grow_kernel (gate + update + score + child creation, 1 launch), HIP events on the ctx stream",
                      "algorithmic_bytes": b_gate},
     }
