@@ -76,6 +76,27 @@ __device__ __forceinline__ int block_or(int v, Red* r) {
     for (int w = 0; w < BLP_THREADS / 64; ++w) s |= r->i[w];
     return s;
 }
+// minimum of a value over a 16-lane row (result in lane 15 of the row) / the wavefront (result in every lane): three VALU
+// ops per step where the (value, index) pair needs a dozen
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void dpp_min_value(double& v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    v = fmin(v, __hiloint2double(nhi, nlo));
+}
+__device__ __forceinline__ double row16_min_value(double v) {
+    dpp_min_value<0x111, 0xf>(v);
+    dpp_min_value<0x112, 0xf>(v);
+    dpp_min_value<0x114, 0xf>(v);
+    dpp_min_value<0x118, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_min_value(double v) {
+    v = row16_min_value(v);
+    dpp_min_value<0x142, 0xa>(v);      // row_bcast:15
+    dpp_min_value<0x143, 0xc>(v);      // row_bcast:31 -> lane 63 holds the minimum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 // lexicographic (value, index) minimum over the wavefront with DPP (index -1 = none); result valid in every lane
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ void dpp_min_pair(double& v, int& i) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -262,12 +283,30 @@ __device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* 
             const int hb = s.colb[k], he = s.colb[k + 1];
             double bv = DINF;
             int bi = -1;
-            for (int h = hb + lane; h < he; h += 64) {
-                const double rc = reduced_cost(s, h);
-                s.rcL[h] = rc;
-                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            for (int h = hb + lane; h < he; h += 128) {      // two columns in flight per lane
+                const int h1 = h + 64, h1c = h1 < he ? h1 : h;
+                const double rc0 = reduced_cost(s, h), rc1 = reduced_cost(s, h1c);
+                s.rcL[h] = rc0;
+                if (bi < 0 || rc0 < bv) { bv = rc0; bi = h; }
+                if (h1 < he) {
+                    s.rcL[h1] = rc1;
+                    if (rc1 < bv) { bv = rc1; bi = h1; }
+                }
             }
-            wave_min_pair(bv, bi);
+            {   // (value, lowest index) minimum: the value by DPP, the index from the lanes that hold it (one lane unless
+                // costs tie exactly)
+                const double gmin = wave_min_value(bi >= 0 ? bv : DINF);
+                unsigned long long mk = __ballot(bi >= 0 && bv == gmin);
+                int gi = -1;
+                while (mk) {
+                    const int src = __ffsll((long long)mk) - 1;
+                    const int cand = __builtin_amdgcn_readlane(bi, src);
+                    if (gi < 0 || cand < gi) gi = cand;
+                    mk &= mk - 1;
+                }
+                bv = gmin;
+                bi = gi;
+            }
             if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
             if (lane < 8 && bi >= 0) {                      // usage of the minimiser's rows right here: no phase of its own
                 const int e = s.entL[bi * 8 + lane];
@@ -365,25 +404,24 @@ __device__ __forceinline__ void nominate(const LStore& s, int K) {
 }
 // cheapest column of target k that avoids row m, by `G` cooperating lanes (G = 16: DPP row; G = 64: wavefront)
 template <int G> __device__ __forceinline__ double regret_of(const LStore& s, int k, int m, bool active, int l) {
-    double alt = DINF;
-    int ai = -1;
+    double alt = DINF;      // only the value matters: DINF = no column avoids m
     if (active) {
         const int hb = s.colb[k], he = s.colb[k + 1];
-#pragma unroll 2
-        for (int h = hb + l; h < he; h += G) {
-            const uint4 v = reinterpret_cast<const uint4*>(s.entL)[h];
-            const double rc = s.rcL[h];
-            const unsigned mm = (unsigned)m, m2 = mm | (mm << 16);
-            // does any of the eight 16-bit row ids equal m?
+        const unsigned mm = (unsigned)m, m2 = mm | (mm << 16);
+        auto has_row = [&](const uint4& v) -> bool {      // does any of the eight 16-bit row ids equal m?
             const unsigned x0 = v.x ^ m2, x1 = v.y ^ m2, x2 = v.z ^ m2, x3 = v.w ^ m2;
-            const bool has = !(x0 & 0xffffu) || !(x0 >> 16) || !(x1 & 0xffffu) || !(x1 >> 16) ||
-                             !(x2 & 0xffffu) || !(x2 >> 16) || !(x3 & 0xffffu) || !(x3 >> 16);
-            if (!has && (ai < 0 || rc < alt)) { alt = rc; ai = h; }
+            return !(x0 & 0xffffu) || !(x0 >> 16) || !(x1 & 0xffffu) || !(x1 >> 16) ||
+                   !(x2 & 0xffffu) || !(x2 >> 16) || !(x3 & 0xffffu) || !(x3 >> 16);
+        };
+        for (int h = hb + l; h < he; h += 2 * G) {      // two columns in flight per lane
+            const int h1 = h + G, h1c = h1 < he ? h1 : h;
+            const uint4 v0 = reinterpret_cast<const uint4*>(s.entL)[h], v1 = reinterpret_cast<const uint4*>(s.entL)[h1c];
+            const double rc0 = s.rcL[h], rc1 = s.rcL[h1c];
+            if (!has_row(v0)) alt = fmin(alt, rc0);
+            if (h1 < he && !has_row(v1)) alt = fmin(alt, rc1);
         }
     }
-    if (G == 64) wave_min_pair(alt, ai);
-    else row16_min_pair(alt, ai);
-    return ai < 0 ? DINF : alt;
+    return (G == 64) ? wave_min_value(alt) : row16_min_value(alt);
 }
 __device__ __forceinline__ bool coordinate_step(const LStore& s, int K, bool conflict, bool slack) {
     const int tid = threadIdx.x;
