@@ -505,6 +505,45 @@ __device__ __forceinline__ bool coordinate_step(const LStore& s, int K, bool con
     return false;
 }
 
+// Two-target clusters (the most common kind) whose minimisers collide: the optimum straight away, by enumeration.  Every column
+// gets the bit mask of its (dense) rows; thread i holds column i of the first target and walks the columns of the second
+// (broadcast LDS reads): min cost[i] + cost[j] over pairs with disjoint masks, ties to the lowest (i, j).  n0 x n1 is a few
+// thousand pairs -- about one dual round's time, where the rounds needed 1-6 of them (near-duplicate tracks zig-zag).
+// Needs <= 64 rows; returns false (nothing touched but rcL) if that does not hold.
+__device__ __forceinline__ bool enumerate_pair(const GStore&, Red*) { return false; }
+__device__ __forceinline__ bool enumerate_pair(const LStore& s, Red* r) {
+    if (s.nR > 64) return false;
+    const int tid = threadIdx.x;
+    const int b0 = s.colb[0], b1 = s.colb[1], n0 = b1 - b0, n1 = s.colb[2] - b1;
+    unsigned long long* mk = reinterpret_cast<unsigned long long*>(s.rcL);      // the reduced costs are dead until the next sweep
+    for (int h = tid; h < s.nH; h += BLP_THREADS) {
+        const Rows8 e = rows_of(s, h);
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if ((int)e.e[d] != s.nR) m |= 1ull << e.e[d];
+        mk[h] = m;
+    }
+    __syncthreads();
+    double bv = DINF;
+    int bi = -1;
+    for (int i = tid; i < n0; i += BLP_THREADS) {
+        const double c0 = s.costL[b0 + i];
+        const unsigned long long m0 = mk[b0 + i];
+#pragma unroll 4
+        for (int j = 0; j < n1; ++j) {
+            const double v = c0 + s.costL[b1 + j];
+            if ((m0 & mk[b1 + j]) == 0ull && v < bv) { bv = v; bi = i * n1 + j; }
+        }
+    }
+    block_min_pair(bv, bi, r);
+    if (bi < 0) return false;          // (cannot happen: the missed-detection columns have no rows)
+    if (tid == 0) { s.ub_sel[0] = b0 + bi / n1; s.ub_sel[1] = b1 + bi % n1; }
+    __threadfence_block();
+    __syncthreads();
+    return true;
+}
+
 // visiting order of the dive: targets by ascending minimal reduced cost (ties by index); identity for the HBM policy
 __device__ __forceinline__ int dive_member(const GStore& s, int K, int pos) { return pos; }
 __device__ __forceinline__ int dive_member(const LStore& s, int K, int pos) { return s.lix[pos]; }
@@ -641,6 +680,13 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         }
         bool done = false;
         if (!conflict && !slack) { status = MHT_BLP_CERTIFIED; done = true; }
+        // a pair that one coordinate round did not settle (near-duplicate tracks: the prices zig-zag for several rounds and may
+        // end in the branch and bound): exact by enumeration, optimal like a certificate.  (Pairs that settle in one round are
+        // cheaper that way: the enumeration costs about one round.)
+        if (!done && coord && it == 1 && K == 2 && enumerate_pair(s, r)) {
+            status = MHT_BLP_CERTIFIED;
+            break;
+        }
         bool counters_reset = false;
         if (!done && coord) counters_reset = coordinate_step(s, K, conflict != 0, slack != 0);
         if (!done && !coord) {
