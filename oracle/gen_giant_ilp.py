@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE (development container only): tests/golden/g9_ilp_giant.npz (two instances).
+"""TEST INFRASTRUCTURE (development container only): tests/golden/g9_ilp_giant.npz (three instances).
 
 (1) One 0-1 ILP of the giant-component regime: 29 targets / 17 935 columns (too large for the ILP kernel's LDS policy), recorded from
 the oracle (pinned bit for bit against the reference by oracle/gen_golden.py) on a dense scenario found by tools/fuzz_parity.py
@@ -7,6 +7,8 @@ has to finish by branch and bound; an earlier version ran into the node limit he
 (gen_golden.gen_g4).
 (2) The instance with a wide LP gap (fuzz seed 40002, scan 3: 34 targets, 3 039 columns, LP optimum -48.178 vs ILP optimum -47.593,
 five fractional targets): a depth-first search with a static Lagrangian bound needs ~10^6 nodes on it.
+(3) Fuzz seed 90266, scan 4: 43 targets / 9 531 columns (HBM policy), 67 objects inside a 231 m radius without clutter: the branch
+and bound needed 260 k nodes while it re-optimised the prices on its first 12 levels only.
 The fixture holds numbers only.
 
 Run:  python oracle/gen_giant_ilp.py          (~1 minute)
@@ -59,4 +61,4 @@ def largest_ilp(seed, scan):
 
 if __name__ == "__main__":
     import gen_golden
-    gen_golden.gen_g4([largest_ilp(20025, 4), largest_ilp(40002, 2)], name="g9_ilp_giant")
+    gen_golden.gen_g4([largest_ilp(20025, 4), largest_ilp(40002, 2), largest_ilp(90266, 4)], name="g9_ilp_giant")

@@ -639,10 +639,14 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArg
     a.fused = commit ? 1 : 0;
     int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     if (ntiles < 1) ntiles = 1;
-    // tile states: epoch-tagged, never reset.  ticket: reset to zero by whoever consumes the scan (see callers).
-    int rc = ctx->hitmask.ensure(((size_t)ntiles + ntiles / 64 + 16) * 8);
-    if (rc) return rc;
+    // tile states: epoch-tagged; the forest owns its arrays and never resets them (ticket: reset to zero by whoever consumes
+    // the scan, see callers).  The stateless seam borrows the ctx scratch, which mht_solve_blp also uses and which may just have
+    // been reallocated: whatever is in there could pass for a tile state of this epoch, so it is cleared on every call.
     if (!a.tile_state) {
+        const size_t bytes = ((size_t)ntiles + ntiles / 64 + 16) * 8;
+        int rc = ctx->hitmask.ensure(bytes);
+        if (rc) return rc;
+        MHT_HIP_CHECK(hipMemsetAsync(ctx->hitmask.ptr, 0, bytes, ctx->stream));
         a.tile_state = static_cast<unsigned long long*>(ctx->hitmask.ptr);
         a.group_state = a.tile_state + ntiles + 4;
     }
@@ -671,10 +675,8 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArg
     }
     const int blocks = ntiles + a.fused;              // + the workgroup that runs the deferred commit
     a.max_resident = max_blocks - a.fused;                    // more tiles than that: dynamic tile numbers (see grow_kernel)
-    if (ntiles > max_blocks && !a.ticket) {           // stateless seam: ticket word behind the tile states, zeroed per call
+    if (ntiles > max_blocks && !a.ticket)             // stateless seam: ticket word behind the tile states (cleared above)
         a.ticket = reinterpret_cast<int32_t*>(a.group_state + ntiles / 64 + 4);
-        MHT_HIP_CHECK(hipMemsetAsync(a.ticket, 0, sizeof(int32_t), ctx->stream));
-    }
     size_t& attr_bytes = ctx->lds_attr_gate;
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grow_kernel),

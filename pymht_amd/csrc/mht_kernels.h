@@ -89,7 +89,7 @@ struct ClusterArgs {
 
 // branch and bound of blp_kernel: the first BB_RE_LEVELS levels re-optimise the prices of their residual problem and keep a
 // snapshot of them in HBM; BB_SLOTS snapshot sets are shared by the workgroups of a launch (clusters that branch are rare)
-constexpr int BB_RE_LEVELS = 12;
+constexpr int BB_RE_LEVELS = 32;
 constexpr int BB_SLOTS = 8;
 
 struct RingLayer { const double* x; const double* cnllr; const int32_t* meas; const uint8_t* flags; };   // one layer of the node ring
