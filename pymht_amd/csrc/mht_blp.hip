@@ -141,9 +141,9 @@ struct GStore {      // HBM: column = global child index, row = global measureme
     const BlpArgs* a; const int32_t* mem; const unsigned long long* uw; int UW, PD; size_t cap;
     int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
     __device__ __forceinline__ int col_begin(int k) const { return a->tchild[mem[k]]; }
-    __device__ __forceinline__ int col_end(int k) const { return a->tchild[mem[k] + 1]; }
+    __device__ __forceinline__ int col_end(int k) const { return a->tcend[mem[k]]; }
     __device__ __forceinline__ double cost(int h) const { return a->cost[h]; }
-    __device__ __forceinline__ int ent(int d, int h) const { return a->path[(size_t)d * cap + h]; }
+    __device__ __forceinline__ int ent(int d, int h) const { return a->pds ? a->path[(size_t)h * a->pds + d] : a->path[(size_t)d * cap + h]; }
     __device__ __forceinline__ double& u(int m) const { return a->u[m]; }
     __device__ __forceinline__ int32_t& usage(int m) const { return a->usage[m]; }
     __device__ __forceinline__ int32_t& mark(int m) const { return a->mark[m]; }
@@ -967,7 +967,7 @@ __device__ __forceinline__ TgtPre load_target(const BlpArgs& a, int t) {
     const int dg = a.t_depth[t] + 1, w = a.t_window[t];
     p.j = dg > w ? dg - w : 0;             // layers the root advances (pyTarget.pruneDepth)
     p.rscan = a.t_root_scan[t]; p.rnode = a.t_root_node[t]; p.id = a.t_id[t]; p.lab = a.t_label[t];
-    p.cb = a.tchild[t]; p.ce = a.tchild[t + 1];
+    p.cb = a.tchild[t]; p.ce = a.tcend[t];
     p.rootc = a.t_root_cnllr[t]; p.rootf = a.t_root_f32[t];
     return p;
 }
@@ -984,7 +984,7 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
     const int smeas = ring_ptr(a.ring0.meas, a.ring_stride, kc)[s];
     const double sx0 = a.x[s], sx1 = a.x[(size_t)a.cap + s], sx2 = a.x[(size_t)2 * a.cap + s], sx3 = a.x[(size_t)3 * a.cap + s];
     const int j = p.j;
-    const int anc_l = a.apath[(size_t)(j > 0 ? j - 1 : 0) * a.cap + s];      // unconditional (clamped row): one batch with the loads above
+    const int anc_l = a.apath[(size_t)s * a.pds + (j > 0 ? j - 1 : 0)];      // unconditional (clamped level): one batch with the loads above
     const int anc = (j > 0) ? anc_l : -1;
     const bool f32score = (fl & F_SCORE_F32) && p.rootf;
     // getScore() (pyTarget.py:124) with NumPy scalar promotion: float32 - float32 stays float32
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
 // target are one contiguous DFS range: only (first, count) are recorded.  One wavefront per target; `va0` is the
 // ancestor entry of the lane's child in the first chunk, fetched by the caller before the key was known.
 __device__ __forceinline__ int sweep_prefetch(const BlpArgs& a, int j, int cb, int ce, int lane) {
-    return (j > 0 && cb + lane < ce) ? a.apath[(size_t)(j - 1) * a.cap + cb + lane] : -1;
+    return (j > 0 && cb + lane < ce) ? a.apath[(size_t)(cb + lane) * a.pds + (j - 1)] : -1;
 }
 __device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, int cb, int ce, int key, int va0, int lane) {
     int count = 0, first = 0x7fffffff;
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, 
     } else if (key != KEY_DEAD) {
         for (int c0 = cb; c0 < ce; c0 += 64) {
             const int c = c0 + lane;
-            const int v = (c0 == cb) ? va0 : (c < ce ? a.apath[(size_t)(j - 1) * a.cap + c] : -1);
+            const int v = (c0 == cb) ? va0 : (c < ce ? a.apath[(size_t)c * a.pds + (j - 1)] : -1);
             const unsigned long long m = __ballot(c < ce && v == key);
             if (m && first == 0x7fffffff) first = c0 + __ffsll((long long)m) - 1;
             count += __popcll(m);
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void prune_members(const BlpArgs& a, const int32_t* m
     const int lane = threadIdx.x & 63;
     for (int k = threadIdx.x >> 6; k < K; k += BLP_THREADS / 64) {
         const int t = mem[k];
-        const int j = a.t_jdrop[t], cb = a.tchild[t], ce = a.tchild[t + 1];
+        const int j = a.t_jdrop[t], cb = a.tchild[t], ce = a.tcend[t];
         sweep_survivors(a, t, j, cb, ce, key[k], sweep_prefetch(a, j, cb, ce, lane), lane);
     }
 }
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             for (int base = 0; base < K; base += 64) {
                 const int k = base + tid;
                 int gb = 0, n = 0;
-                if (k < K) { const int t = mem[k]; gb = a.tchild[t]; n = a.tchild[t + 1] - gb; }
+                if (k < K) { const int t = mem[k]; gb = a.tchild[t]; n = a.tcend[t] - gb; }
                 int incl = n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -1133,7 +1133,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         }
     } else if (tid == 0) {
         int acc = 0;
-        for (int k = 0; k < K; ++k) acc += a.tchild[mem[k] + 1] - a.tchild[mem[k]];
+        for (int k = 0; k < K; ++k) acc += a.tcend[mem[k]] - a.tchild[mem[k]];
         s_nH = acc;
     }
     __syncthreads();
@@ -1163,10 +1163,18 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             for (int q = 0; q < 2; ++q) {      // unconditional loads (clamped index), masked afterwards: no branch between them
                 const int gq = g[q] >= 0 ? g[q] : 0;
                 cs[q] = a.cost[gq];
+                if (a.pds) {      // forest: one 32-byte record per column (entries beyond PD are -1)
+                    const int4* rec = reinterpret_cast<const int4*>(a.path + (size_t)gq * a.pds);
+                    const int4 r0 = rec[0], r1 = rec[1];
+                    const int rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    const int v = (d < a.PD) ? a.path[(size_t)d * a.cap + gq] : -1;
-                    ev[q][d] = g[q] >= 0 ? v : -1;
+                    for (int d = 0; d < 8; ++d) ev[q][d] = g[q] >= 0 ? rv[d] : -1;
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const int v = (d < a.PD) ? a.path[(size_t)d * a.cap + gq] : -1;
+                        ev[q][d] = g[q] >= 0 ? v : -1;
+                    }
                 }
             }
 #pragma unroll
@@ -1185,8 +1193,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         for (int k = 0; k < K; ++k) {
             const int t = mem[k];
             for (int d = 0; d < a.PD; ++d)
-                for (int h = a.tchild[t] + tid; h < a.tchild[t + 1]; h += BLP_THREADS) {
-                    const int e = a.path[(size_t)d * a.cap + h];
+                for (int h = a.tchild[t] + tid; h < a.tcend[t]; h += BLP_THREADS) {
+                    const int e = a.pds ? a.path[(size_t)h * a.pds + d] : a.path[(size_t)d * a.cap + h];
                     if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
                 }
         }
@@ -1250,7 +1258,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 const int key = s.ch[m];
                 if (key == KEY_DEAD) continue;
                 const int g = s.gbase[m] + (h - s.colb[m]);
-                const bool sv = key == KEY_ALL || a.apath[(size_t)(s.ub_sel[m] - 1) * a.cap + g] == key;
+                const bool sv = key == KEY_ALL || a.apath[(size_t)g * a.pds + (s.ub_sel[m] - 1)] == key;
                 if (sv) { atomicAdd(&s.lix[m], 1); atomicMin(&s.best_h[m], g); }
             }
             __syncthreads();
@@ -1314,7 +1322,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
         TgtPre pre = {};
         int cb, ce;
         if (a.t_alive) { pre = load_target(a, t); cb = pre.cb; ce = pre.ce; }
-        else { cb = a.tchild[t]; ce = a.tchild[t + 1]; }
+        else { cb = a.tchild[t]; ce = a.tcend[t]; }
         double bv = DINF;
         int bi = -1;
         for (int h = cb + lane; h < ce; h += 64) {
@@ -1399,7 +1407,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.cl_ptr = cl_ptr; a.cl_members = members; a.multi_list = multi; a.single_list = single; a.counts = counts;
     a.cl_status = st; a.cl_iters = st + 1; a.cl_nodes = st + 2;
     a.bb_busy = st + 3;
-    a.tchild = group_ptr; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
+    a.tchild = group_ptr; a.tcend = group_ptr + 1; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
         for (int q = 0; q < CL_SPEC / 16; ++q) spec[q] = a.edges_in[(size_t)sg * a.seg_cap + l16 + 16 * q];
     }
     if (s_over) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
-    if (a.status_other && tid == 0) a.status_other->overflow = 0;      // the scan after this one starts from a clean word
+    if (a.status_other && tid == 0) { a.status_other->overflow = 0; a.status_other->n_children = 0; }      // the scan after this one starts from a clean word
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     if (a.edges_in) {      // hand the counters back (the dedup bitsets were cleared in pass B)
         if (tid < EDGE_SEGS) a.edge_count[tid] = 0;
         if (tid == 0 && a.ticket_reset) *a.ticket_reset = 0;      // grow_kernel's tile ticket (used when its grid is not co-resident)
+        if (a.alloc_reset && tid >= 64 && tid < 64 + FG_REGIONS) a.alloc_reset[(tid - 64) * 32] = 0u;      // fgrow_kernel's child counters
     }
     __syncthreads();
     CL_STAMP(1);

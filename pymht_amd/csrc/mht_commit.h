@@ -7,7 +7,7 @@
 
 namespace mht {
 
-constexpr int PRUNE_THREADS = 512;
+constexpr int COMMIT_THREADS = 512;   // commit_kernel (standalone); fgrow_kernel runs the same body with its own width
 
 struct FCounts {          // device-side counters of the forest
     int nT;               // targets in the NEXT table
@@ -49,8 +49,18 @@ struct CommitArgs {
 
 // Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
 // roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
-__device__ __forceinline__ void commit_body(const CommitArgs& a) {
-    __shared__ int s_scan[PRUNE_THREADS / 64], s_scan2[PRUNE_THREADS / 64], s_total, s_total2, s_branched, s_limit, s_itmax;
+// NT = threads of the workgroup; `sm` = 2 * NT / 64 + 8 ints of LDS scratch (handed in by the kernel: a static __shared__
+// here would shift the dynamic LDS base of the kernels this is inlined into off its 16-byte alignment).
+template <int NT>
+__device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
+    constexpr int PRUNE_THREADS = NT;
+    int* s_scan = sm;
+    int* s_scan2 = sm + NT / 64;
+    int& s_total = sm[2 * (NT / 64)];
+    int& s_total2 = sm[2 * (NT / 64) + 1];
+    int& s_branched = sm[2 * (NT / 64) + 2];
+    int& s_limit = sm[2 * (NT / 64) + 3];
+    int& s_itmax = sm[2 * (NT / 64) + 4];
     const int tid = threadIdx.x;
     // first round trip, everything at once: the scalars and the first chunk of per-target look-ups (index clamped by the
     // table's capacity; entries beyond the real count are masked afterwards)
@@ -172,7 +182,7 @@ __device__ __forceinline__ void commit_body(const CommitArgs& a) {
         a.cnt->nTv[a.vnext] = nAlive;
         a.cnt->L = Lnext;
         a.cnt->n_nodes = nCh;
-        a.cnt->n_roots = 0;
+        a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a
         // commit that rides in the next grow_kernel must not touch what that kernel's tiles are reading)
     }

@@ -56,6 +56,9 @@ constexpr int EMIT_THREADS = 64;  // one wavefront, one leaf per lane
 constexpr int MAX_MEAS = 4096;    // 64 hit-mask words per leaf, one per lane
 constexpr int EDGE_SEGS = 64;      // the (target, measurement) edge list is written in 64 independently counted segments
 constexpr int MAXPD = 15;         // longest root->leaf path kept per hypothesis (N-scan window + 1)
+constexpr int FG_THREADS = 256;   // fgrow_kernel: one workgroup per target
+constexpr int FG_CAP = 64;        //   leaves of a target handled per pass (more: chunks, two passes)
+constexpr int FG_REGIONS = 8;     //   regions of the node index space, one child counter each (one per XCD)
 
 // device-side status word of a ctx (sticky until read)
 struct DevStatus {
@@ -78,5 +81,5 @@ struct mht_ctx {
     mht::DevStatus* status = nullptr;   // device
     mht::Forest* forest = nullptr;
     // dynamic-LDS limits already raised with hipFuncSetAttribute (per context: the attribute is per device)
-    size_t lds_attr_gate = 0, lds_attr_cluster = 0, lds_attr_blp = 0;
+    size_t lds_attr_gate = 0, lds_attr_cluster = 0, lds_attr_blp = 0, lds_attr_fgrow = 0;
 };

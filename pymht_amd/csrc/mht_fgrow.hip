@@ -1,0 +1,537 @@
+// fgrow_kernel: the grow stage of the device-resident forest -- gate / update / score of every leaf hypothesis against every
+// measurement of a scan and the creation of the child hypotheses (reference: Tracker._growTarget / _processLeafNodes,
+// pymht/tracker.py:309-351, :383-398, :804-889; children pyTarget.py:227-258, :319-328), ONE launch per scan.
+//
+// Round-2 design (the stateless seam mht_gate_scan keeps the tile/look-back kernel of mht_gate.hip):
+//   * one WORKGROUP PER TARGET (the leaves of a target are one contiguous node range of the previous layer, 32 of them at
+//     N-scan 5): no leaf -> target search, one gate bounding box, every per-target quantity is a scalar, and -- because all
+//     leaves of a target are in ONE workgroup -- the target's association set is de-duplicated in an LDS bitset (no global
+//     bitset, no returning atomic per child).  Targets with more than FG_CAP leaves are processed in chunks (two passes:
+//     count, then emit).
+//   * children are NOT placed by a device-wide prefix over all leaves any more (a look-back every tile waited 3.7 us in):
+//     the children of a target only have to be contiguous and in DFS order AMONG THEMSELVES (pyTarget.getLeafNodes), so a
+//     workgroup takes its block with one returning atomicAdd on the child counter of its XCD's region of the (sparse) node
+//     index space -- eight regions, neighbours in memory were written through the same L2.  tchild[t] / tcend[t] give the
+//     block; nothing downstream needs a dense numbering.
+//   * the measurement-independent covariance chain P -> P_bar, S, S^-1, K, P_hat (kalman.py:62, :90-93; ~700 dependent VALU
+//     operations per leaf) is off the critical path: "chain" workgroups of the same launch compute, per leaf and per
+//     hit/miss, the child's covariance and ITS gains (S^-1, K, score constant, gate half-axes) one scan ahead into the gain
+//     table G of the new layer, so a target workgroup only forms x_bar = A x, z_hat = C x_bar and looks its gains up.
+//   * launch = [commit of the previous scan (deferred, workgroup 0)] + one workgroup per target slot + chain workgroups.
+// Algorithmic bytes of the stage: 280 B per leaf + 48 B per gated pair + 8 B per measurement.
+#include "mht_kernels.h"
+#include "mht_commit.h"
+
+namespace mht {
+
+struct FLeaf {            // per-leaf results of phase 1 parked in LDS for the later phases (one chunk = FG_CAP leaves)
+    double xbar[4];
+    double zhat[2];
+    double cn, pd;
+    float K[8];
+    float sinv[4];
+    float lnc, bx, by, zhx, zhy;
+    int src, last_real, cnt;
+    unsigned char flags, f32state, valid, pad;
+};
+static_assert(sizeof(FLeaf) % 8 == 0, "FLeaf must keep 8-byte alignment in LDS");
+
+struct TInfo { int alive, first, cnt, depth, shift; };
+typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
+
+// what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
+// loads go out unconditionally (one round trip), dead or out-of-range slots are masked afterwards
+__device__ __forceinline__ TInfo target_info(const FGrowArgs& a, int t, int nT) {
+    TInfo r;
+    const int tc = (t < a.Tcap) ? t : 0;
+    if (a.fused) {      // the previous scan's commit has not run: its per-target results, indexed by old slot
+        const int st = a.p_status[tc], cnt = a.p_count[tc], j = a.p_jdrop[tc], first = a.p_firstsurv[tc], dep = a.p_depth[tc];
+        r.alive = (t < nT) && st == 0;
+        r.first = first; r.cnt = cnt; r.depth = dep + 1 - j; r.shift = j;
+    } else {
+        const int first = a.t_first[tc], o0 = a.t_leaf_off[tc], o1 = a.t_leaf_off[tc + 1], dep = a.t_depth[tc], sh = a.t_shift[tc];
+        r.alive = t < nT;
+        r.first = first; r.cnt = o1 - o0; r.depth = dep; r.shift = sh;
+    }
+    if (!r.alive) r.cnt = 0;
+    return r;
+}
+
+__device__ __forceinline__ int fg_sortable(float f) {      // monotone map float -> int
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : (i ^ 0x7fffffff);
+}
+
+// ---- chain workgroups: the covariance chain one scan ahead ---------------------------------------------------------------
+// Wavefront = (target, hit/miss); lane = leaf.  For leaf `src` (node of the previous layer, covariance P = Pin[cov[src]]):
+//   full chain from P -> P_bar, P_hat; the child's covariance Pc = hit ? P_hat : P_bar goes to column 2*src+hit of the new
+//   layer's pool (exactly the sharing of the reference: one ndarray for all hit children, pyTarget.py:246), and the gains the
+//   child will need when IT is a leaf next scan -- S^-1, K, ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from
+//   predict(Pc) -- go to row 2*src+hit of the gain table.
+__device__ __forceinline__ void gains_record(const Model& m, const CovChain& c, double pd, float4* g) {
+    const float lnc = nllr_const(c.S, m.lambda_ex, pd);
+    const float rx = sqrtf((float)m.eta2 * fabsf(c.S[0])), ry = sqrtf((float)m.eta2 * fabsf(c.S[3]));
+    g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
+    g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
+    g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
+    g[3] = make_float4(lnc, rx, ry, 0.f);
+}
+
+__device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nT = a.nT_dev[0];
+    const int po = a.prev_status->overflow, so = *a.sticky_overflow;
+    const int t = cb * (FG_THREADS / 128) + (wave >> 1), h = wave & 1;
+    const TInfo ti = target_info(a, t, nT);
+    if (po || so) return;
+    for (int c0 = 0; c0 < ti.cnt; c0 += 64) {
+        const int l = c0 + lane;
+        if (l >= ti.cnt) break;
+        const int src = ti.first + l;
+        const int covc = a.cov[src];
+        const double pd = a.pd[src];
+        float P[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc + covc];
+        CovChain c;
+        cov_chain(a.model, P, c, true);
+        float Pc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Pc[e] = h ? c.P_hat[e] : c.P_bar[e];
+        const int col = 2 * src + h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a.oP[(size_t)e * a.capc + col] = Pc[e];
+        CovChain g;
+        cov_chain(a.model, Pc, g, false);
+        float4 rec[4];
+        gains_record(a.model, g, pd, rec);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.G_out[(size_t)col * 4 + q] = rec[q];
+    }
+}
+
+// ---- target workgroups ---------------------------------------------------------------------------------------------------
+template <typename TS, typename ARGS>
+__device__ __forceinline__ void fg_emit_child(const ARGS& a, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
+                                              const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
+                                              double rootc, int root_f32) {
+    const size_t cap = a.cap;
+    const uint8_t fl = g.flags;
+    int meas = 0, hit = 0, j = -1;
+    if (k > 0) {             // (k-1)-th gated measurement in ascending index (pyTarget.py:242-254)
+        int need = k - 1, w = 0;
+        unsigned long long bits = hwl[0];
+        while (true) {
+            const int pc = __popcll(bits);
+            if (need < pc) break;
+            need -= pc;
+            bits = hwl[++w];
+        }
+        for (int q = 0; q < need; ++q) bits &= bits - 1;
+        j = w * 64 + __ffsll((long long)bits) - 1;
+        meas = j + 1;
+        hit = 1;
+    }
+    double cnl, inc;
+    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
+    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = g.xbar[q];
+        inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
+        cnl = g.cn + inc;
+    } else {
+        const float mx = zx[j], my = zy[j];
+        TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
+        TS zt[2], nis, xh[4];
+        gate_pair<TS>(zh, g.sinv, mx, my, (TS)a.model.eta2, zt, nis);
+        update_state<TS>(xb, g.K, zt, xh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = (double)xh[q];
+        const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19
+        inc = (double)tinc;
+        if (sizeof(TS) == 4 && (fl & F_SCORE_F32)) {          // float32 + float32 stays float32 (NumPy scalar rules)
+            cnl = (double)((float)g.cn + (float)tinc);
+            cfl |= F_SCORE_F32;
+        } else {
+            cnl = g.cn + inc;
+        }
+        a.used_bytes[j] = 1;
+    }
+    a.ocnllr[c] = cnl;
+    a.opd[c] = g.pd;
+    a.oparent[c] = g.src;
+    a.omeas[c] = meas;
+    a.ocov[c] = 2 * g.src + hit;
+    a.oflags[c] = cfl;
+    // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and float32 / int stay
+    // float32
+    if ((cfl & F_SCORE_F32) && root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
+    else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
+    // path / ancestor records of the child: the parent's entries from the new root on (d + shift), its own at level `depth`
+    const int* pl = s_pp + l * a.pds;
+    const int* al = s_ap + l * a.pds;
+    int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * a.pds);
+    int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * a.pds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q * 4 < a.pds) {
+            int pe[4], ae[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = q * 4 + e;
+                const int src_i = (d < depth) ? d + shift : 0;
+                const int pvv = pl[src_i], avv = al[src_i];
+                pe[e] = (d < depth) ? pvv : ((d == depth && meas > 0) ? a.cur_slot_base + meas - 1 : -1);
+                ae[e] = (d < depth) ? avv : ((d == depth) ? c : -1);
+            }
+            po[q] = make_int4(pe[0], pe[1], pe[2], pe[3]);
+            ao[q] = make_int4(ae[0], ae[1], ae[2], ae[3]);
+        }
+}
+
+__device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = a.M, W = a.W, Mpad = W * 64, AW = a.AW;
+    // LDS carve (every block a multiple of 16 bytes)
+    float* zx = reinterpret_cast<float*>(smem);
+    float* zy = zx + Mpad;
+    FLeaf* lg = reinterpret_cast<FLeaf*>(zy + Mpad);                                        // [FG_CAP]
+    int* s_pp = reinterpret_cast<int*>(lg + FG_CAP);                                        // [FG_CAP][pds] path records of the leaves
+    int* s_ap = s_pp + a.pds * FG_CAP;                                                      // [FG_CAP][pds] ancestor records
+    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + a.pds * FG_CAP);  // [FG_CAP][W] hit masks
+    unsigned long long* tb = hw + (size_t)FG_CAP * W;                                       // [AW] association bitset of the target
+    int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [FG_CAP + 1]
+    int* s_misc = s_pref + FG_CAP + 4;                                                      // [16]
+    unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 16);                  // [Mpad]
+    int& s_ncand = s_misc[0];
+    int& s_base = s_misc[1];
+    int& s_ebase = s_misc[2];
+    int& s_total = s_misc[3];
+    int* s_box = s_misc + 4;          // [4] sortable ints: min x, max x, min y, max y
+    int* s_red = s_misc + 8;          // [4] per-wave partials
+
+    // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
+    const int nT = a.nT_dev[0];
+    const int po = a.prev_status->overflow, so = *a.sticky_overflow;
+    const TInfo ti = target_info(a, t, nT);
+    const int tc = (t < a.Tcap) ? t : 0;
+    const double rootc = a.t_root_cnllr[tc];
+    const int root_f32 = a.t_root_f32[tc];
+    int acc = 0;
+    if (a.fused)          // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
+        for (int i = tid; i < t; i += FG_THREADS) acc += (a.p_status[i] == 0) ? 1 : 0;
+    const float2* z2 = reinterpret_cast<const float2*>(a.z);
+    for (int j = tid; j < Mpad; j += FG_THREADS) {
+        const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
+        zx[j] = v.x;
+        zy[j] = v.y;
+    }
+    if (po || so) {          // a scan that overflowed its pools voids every scan after it
+        if (t == 0 && tid == 0) a.status->overflow = po ? po : 1;
+        return;
+    }
+    if (!ti.alive) return;
+    for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_red[wave] = acc;
+    __syncthreads();
+    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+    const int depth0 = ti.depth, shift0 = ti.shift, cnt = ti.cnt, first = ti.first;
+    const int curw = a.cur_slot_base >> 6;      // first word of this scan's measurement nodes in the association bitset
+
+    // ---- the target's children: count, take a block of the node index space, emit -------------------------------------------
+    // (a target with more than FG_CAP leaves runs the chunk loop twice: pass 0 only counts, pass 1 emits)
+    const bool two_pass = cnt > FG_CAP;
+    int total = 0, run = 0, base = 0;
+    for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
+        for (int c0 = 0; c0 < cnt; c0 += FG_CAP) {
+            // (the loops exist for targets with more than FG_CAP leaves only.  The kernel arguments are re-read through an opaque
+            // kernarg pointer in every iteration: otherwise every address and every uniform predicate of the unrolled body is
+            // hoisted in front of the loops and held in registers across them -- +100 VGPRs, ~400 spilled SGPRs)
+            int depth = __builtin_amdgcn_readfirstlane(depth0), shift = __builtin_amdgcn_readfirstlane(shift0);
+            asm volatile("" : "+s"(depth), "+s"(shift));
+            KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // (FGrowArgs is the first kernel argument)
+            asm volatile("" : "+s"(ap));
+            const auto& a = *ap;
+            // ---- phases 1 + 2 of one chunk: predict (gains looked up), gate ---------------------------------------------------------
+            auto phase12 = [&](int c0, int depth, int shift) {
+                const int n = (cnt - c0 < FG_CAP) ? cnt - c0 : FG_CAP;
+                for (int w = tid; w < FG_CAP * W; w += FG_THREADS) hw[w] = 0ull;
+                if (tid == 0) s_ncand = 0;
+                if (wave == 0) {
+                    FLeaf& g = lg[lane];
+                    const bool valid = lane < n;
+                    const int src = first + c0 + (valid ? lane : 0);
+                    // batch A: everything addressed by the leaf; nothing sits behind a branch
+                    const uint8_t fl = a.flags[src];
+                    const double cn = a.cnllr[src], pd = a.pd[src];
+                    const int covc = a.cov[src];
+                    double xd[4];
+        #pragma unroll
+                    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+                    // the leaf's path / ancestor records (pds ints each: 2 or 4 x 16 bytes)
+                    const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * a.pds);
+                    const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * a.pds);
+                    int4 pq[4], aq[4];
+        #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = q * 4 < a.pds;          // uniform
+                        pq[q] = on ? prec[q] : make_int4(-1, -1, -1, -1);
+                        aq[q] = on ? arec[q] : make_int4(-1, -1, -1, -1);
+                    }
+                    // batch B: the gains of the leaf's covariance column
+                    float4 gr[4];
+        #pragma unroll
+                    for (int q = 0; q < 4; ++q) gr[q] = a.G_in[(size_t)covc * 4 + q];
+                    g.valid = valid;
+                    g.cnt = 0;
+                    g.src = src;
+                    g.flags = fl;
+                    g.f32state = (fl & F_STATE_F32) ? 1 : 0;
+                    g.cn = cn;
+                    g.pd = pd;
+                    // records parked raw (the root advance `shift` is applied when they are read back); last real measurement on the path
+                    int last = -1;
+        #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q * 4 < a.pds) {
+                            reinterpret_cast<int4*>(s_pp + lane * a.pds)[q] = pq[q];
+                            reinterpret_cast<int4*>(s_ap + lane * a.pds)[q] = aq[q];
+                            const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
+        #pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = q * 4 + e;
+                                if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
+                            }
+                        }
+                    g.last_real = last;
+                    if (valid && last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));
+                    Model mdl;          // (only A and C are used: uniform registers)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+                    if (g.f32state) {
+                        float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
+                        state_predict<float>(mdl, xs, xb, zh);
+        #pragma unroll
+                        for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
+                        g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
+                    } else {
+                        double xb[4], zh[2];
+                        state_predict<double>(mdl, xd, xb, zh);
+        #pragma unroll
+                        for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
+                        g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
+                    }
+                    g.sinv[0] = gr[0].x; g.sinv[1] = gr[0].y; g.sinv[2] = gr[0].z; g.sinv[3] = gr[0].w;
+                    g.K[0] = gr[1].x; g.K[1] = gr[1].y; g.K[2] = gr[1].z; g.K[3] = gr[1].w;
+                    g.K[4] = gr[2].x; g.K[5] = gr[2].y; g.K[6] = gr[2].z; g.K[7] = gr[2].w;
+                    g.lnc = gr[3].x;
+                    const float zhx = (float)g.zhat[0], zhy = (float)g.zhat[1];
+                    const float rx = gr[3].y, ry = gr[3].z;
+                    // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widened for the float32 rounding of the
+                    // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test decides, this only prunes
+                    const float bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;
+                    const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
+                    g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by;
+                    // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first cut
+                    // down to the measurements inside it
+                    float lox = zhx - bx, hix = zhx + bx, loy = zhy - by, hiy = zhy + by;
+                    lox -= fabsf(lox) * 2.4e-7f + 1e-30f; hix += fabsf(hix) * 2.4e-7f + 1e-30f;      // outward: a superset of the leaf's own box
+                    loy -= fabsf(loy) * 2.4e-7f + 1e-30f; hiy += fabsf(hiy) * 2.4e-7f + 1e-30f;
+                    int b0 = valid ? fg_sortable(lox) : 0x7fffffff, b1 = valid ? fg_sortable(hix) : (int)0x80000000;
+                    int b2 = valid ? fg_sortable(loy) : 0x7fffffff, b3 = valid ? fg_sortable(hiy) : (int)0x80000000;
+        #pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        b0 = min(b0, __shfl_xor(b0, o)); b1 = max(b1, __shfl_xor(b1, o));
+                        b2 = min(b2, __shfl_xor(b2, o)); b3 = max(b3, __shfl_xor(b3, o));
+                    }
+                    if (lane == 0) { s_box[0] = b0; s_box[1] = b1; s_box[2] = b2; s_box[3] = b3; }
+                }
+                __syncthreads();
+                // phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront)
+                const int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3];
+                for (int j0 = 0; j0 < Mpad; j0 += FG_THREADS) {
+                    const int j = j0 + tid;
+                    bool in = false;
+                    if (j < Mpad) {
+                        const int kx = fg_sortable(zx[j]), ky = fg_sortable(zy[j]);
+                        in = (kx >= x0) && (kx <= x1) && (ky >= y0) && (ky <= y1);
+                    }
+                    const unsigned long long bal = __ballot(in);
+                    int wbase = 0;
+                    if (lane == 0 && bal) wbase = atomicAdd(&s_ncand, __popcll(bal));
+                    wbase = __shfl(wbase, 0);
+                    if (in) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+                }
+                __syncthreads();
+                // phase 2 (b): thread = (leaf, candidate): the leaf's own conservative float32 box, then the exact reference-order NIS
+                const int nc = s_ncand;
+                for (int w = tid; w < FG_CAP * nc; w += FG_THREADS) {
+                    const int l = w & (FG_CAP - 1), j = cand[w / FG_CAP];
+                    const FLeaf& g = lg[l];
+                    if (!g.valid) continue;
+                    const float mx = zx[j], my = zy[j];
+                    if ((fabsf(mx - g.zhx) <= g.bx) && (fabsf(my - g.zhy) <= g.by)) {
+                        bool hit;
+                        if (g.f32state) {
+                            float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
+                            hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
+                        } else {
+                            double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
+                            hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
+                        }
+                        if (hit) {
+                            atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
+                            atomicOr(&tb[curw + (j >> 6)], 1ull << (j & 63));
+                        }
+                    }
+                }
+                __syncthreads();
+                // child counts of the chunk: 1 (missed detection) + hits per leaf, exclusive prefix in s_pref
+                if (wave == 0) {
+                    int hits = 0;
+                    for (int w = 0; w < W; ++w) hits += __popcll(hw[(size_t)lane * W + w]);
+                    const int mine = (lane < n) ? 1 + hits : 0;
+                    int incl = mine;
+        #pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_up(incl, o);
+                        if (lane >= o) incl += v;
+                    }
+                    s_pref[lane] = incl - mine;
+                    if (lane == 63) { s_pref[FG_CAP] = incl; s_total = incl; }
+                }
+                __syncthreads();
+            };
+
+            // ---- phase 4 of one chunk: one thread per child, children of the chunk at base .. base + total - 1 ---------------------
+            auto emit = [&](int base, int depth, int shift) {
+                const int total = s_pref[FG_CAP];
+                for (int r = tid; r < total; r += FG_THREADS) {
+                    int lo = 0, hi = FG_CAP;                 // leaf of child r: largest l with s_pref[l] <= r
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= r) lo = mid; else hi = mid;
+                    }
+                    const int l = lo, k = r - s_pref[l], c = base + r;
+                    const FLeaf& g = lg[l];
+                    if (g.f32state) fg_emit_child<float>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                }
+            };
+
+            phase12(c0, depth, shift);
+            if (pass == 0) {
+                total += s_total;
+                __syncthreads();
+                continue;
+            }
+            if (c0 == 0) {
+                if (!two_pass) total = s_total;
+                // edges of the clustering graph: the set bits of the association bitset (complete here: the current scan's hits
+                // and every leaf's last real measurement; with two passes the count pass has seen all chunks)
+                int ne = 0;
+                if (wave == 1) {
+                    for (int w = lane; w < AW; w += 64) ne += __popcll(tb[w]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+                }
+                if (tid == 64) {
+                    const int seg = blockIdx.x & (EDGE_SEGS - 1);
+                    const int e0 = atomicAdd(&a.edge_count[seg], ne);
+                    s_ebase = e0;
+                    if (e0 + ne > a.edge_cap) a.status->overflow = 1;
+                }
+                if (tid == 0) {
+                    // one returning atomic per target: a block of this XCD's region of the node index space (next region if full)
+                    int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
+                    int b = -1;
+                    for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
+                        const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)total);
+                        if (old + (unsigned)total <= (unsigned)a.region_cap) b = r * a.region_cap + (int)old;
+                        else r = (r + 1) & (FG_REGIONS - 1);
+                    }
+                    if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
+                    s_base = b;
+                    atomicAdd(&a.status->n_children, total);
+                    a.tchild[pos] = b < 0 ? 0 : b;
+                    a.tcend[pos] = b < 0 ? 0 : b + total;
+                }
+                __syncthreads();
+                base = s_base;
+                if (base < 0) return;
+                if (wave == 3) {      // edge list: (target << 16 | node) for every set bit
+                    const int seg = blockIdx.x & (EDGE_SEGS - 1);
+                    int eb = s_ebase;
+                    for (int w0 = 0; w0 < AW; w0 += 64) {
+                        const int w = w0 + lane;
+                        unsigned long long bits = (w < AW) ? tb[w] : 0ull;
+                        const int pc = __popcll(bits);
+                        int incl = pc;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int v = __shfl_up(incl, o);
+                            if (lane >= o) incl += v;
+                        }
+                        int my = eb + incl - pc;
+                        while (bits) {
+                            const int bpos = __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            if (my < a.edge_cap) a.edges[(size_t)seg * a.edge_cap + my] = ((unsigned)pos << 16) | (unsigned)(w * 64 + bpos);
+                            ++my;
+                        }
+                        eb += __shfl(incl, 63);
+                    }
+                }
+            }
+            emit(base + run, depth, shift);
+            run += s_total;
+            if (c0 + FG_CAP < cnt) __syncthreads();      // the chunk tables are re-used
+        }
+    }
+}
+
+__global__ __launch_bounds__(FG_THREADS) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid = blockIdx.x;
+    if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
+        if (bid == 0) { commit_body<FG_THREADS>(cm, reinterpret_cast<int*>(smem)); return; }
+        bid -= 1;
+    }
+    if (bid >= a.n_main) { chain_part(a, bid - a.n_main); return; }
+    target_part(a, bid, smem);
+}
+
+static inline size_t fgrow_lds_bytes(int W, int pds, int AW) {
+    size_t b = (size_t)2 * W * 64 * 4 + (size_t)FG_CAP * sizeof(FLeaf) + (size_t)2 * pds * FG_CAP * 4 + (size_t)FG_CAP * W * 8 + (size_t)AW * 8 +
+               (size_t)(FG_CAP + 4) * 4 + 64 + (size_t)W * 64 * 2;
+    if (b < 256) b = 256;      // the commit workgroup keeps its scan partials here
+    return (b + 15) & ~(size_t)15;
+}
+
+int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs* commit) {
+    a.fused = commit ? 1 : 0;
+    int n_main = n_targets_ub < 1 ? 1 : n_targets_ub;
+    if (n_main > a.Tcap) n_main = a.Tcap;
+    a.n_main = n_main;
+    const int per = FG_THREADS / 128;                       // targets per chain workgroup (two wavefronts each: miss, hit)
+    const int n_chain = (n_main + per - 1) / per;
+    const size_t lds = fgrow_lds_bytes(a.W, a.pds, a.AW);
+    if (lds > 64 * 1024) {
+        set_error("fgrow: %zu bytes of LDS per workgroup (max_meas / window too large)", lds);
+        return MHT_E_CAPACITY;
+    }
+    size_t& attr_bytes = ctx->lds_attr_fgrow;
+    if (lds > 48 * 1024 && lds > attr_bytes) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(fgrow_kernel, dim3(a.fused + n_main + n_chain), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{});
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+}  // namespace mht

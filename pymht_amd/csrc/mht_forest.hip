@@ -31,7 +31,10 @@ constexpr int EV_POOL = 64;
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
 
-__global__ __launch_bounds__(PRUNE_THREADS) void commit_kernel(const CommitArgs a) { commit_body(a); }
+__global__ __launch_bounds__(COMMIT_THREADS) void commit_kernel(const CommitArgs a) {
+    __shared__ int s_commit[2 * (COMMIT_THREADS / 64) + 8];
+    commit_body<COMMIT_THREADS>(a, s_commit);
+}
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
 struct AddArgs {
@@ -42,6 +45,7 @@ struct AddArgs {
     FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
     int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
+    Model model; float4* G; int root_base;   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
 };
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates.  The test against the existing leaves
@@ -49,7 +53,7 @@ struct AddArgs {
 // then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
 __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
     const int tid = threadIdx.x;
-    const int nT0 = a.cnt->nT, L0 = a.cnt->L;
+    const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
     for (int q = tid; q < a.n; q += 1024) a.near[q] = 0;
     __syncthreads();
     if (a.check) {
@@ -89,12 +93,14 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
             if (hit) s_near = 1;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {   // (admission is sequential like the reference's loop)
             const int near = s_near;
-            const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_nodes < a.layer.cap;
+            const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_roots < a.Tcap;
             if (!near && !ok) a.cnt->overflow = 1;
             if (ok) {
-                const int idx = a.cnt->n_nodes, r = a.cnt->n_roots, t = a.cnt->nT, L = a.cnt->L;
+                // roots born into a layer live at its end (node root_base + r): the children of a scan are spread over the regions
+                // of the node index space below it (fgrow_kernel)
+                const int r = a.cnt->n_roots, idx = a.root_base + r, t = a.cnt->nT, L = a.cnt->L;
                 const size_t cap = a.layer.cap;
                 for (int k = 0; k < 4; ++k) a.layer.x[k * cap + idx] = a.x0[q * 4 + k];
                 a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.layer.cov[idx] = a.cov_base + r;
                 a.layer.flags[idx] = a.flags[q];
                 for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
-                for (int d = 0; d < a.PD; ++d) { a.path[(size_t)d * cap + idx] = -1; a.apath[(size_t)d * cap + idx] = -1; }
+                for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
                 a.tab.id[t] = a.cnt->id_counter;
                 a.tab.window[t] = a.Nwin;
                 a.tab.depth[t] = 0;
@@ -118,7 +124,6 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.tab.leaf_off[t + 1] = L + 1;
                 if (a.ids) a.ids[q] = a.cnt->id_counter;
                 a.cnt->id_counter += 1;
-                a.cnt->n_nodes = idx + 1;
                 a.cnt->n_roots = r + 1;
                 a.cnt->nT = t + 1;
                 a.cnt->nTv[a.vidx] = t + 1;
@@ -131,6 +136,21 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
             if (a.accepted) a.accepted[q] = (uint8_t)ok;
         }
         __syncthreads();
+    }
+    // gains of the admitted roots (what fgrow_kernel's chain workgroups compute for every other node one scan ahead)
+    for (int k = tid; k < s_nadm; k += 1024) {
+        const int q = s_adm[k & 2047];
+        float P[16];
+        for (int e = 0; e < 16; ++e) P[e] = a.P0[q * 16 + e];
+        CovChain c;
+        cov_chain(a.model, P, c, false);
+        const float lnc = nllr_const(c.S, a.model.lambda_ex, a.pd[q]);
+        const float rx = sqrtf((float)a.model.eta2 * fabsf(c.S[0])), ry = sqrtf((float)a.model.eta2 * fabsf(c.S[3]));
+        float4* g = a.G + (size_t)(a.cov_base + r0 + k) * 4;
+        g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
+        g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
+        g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
+        g[3] = make_float4(lnc, rx, ry, 0.f);
     }
 }
 
@@ -193,12 +213,14 @@ struct Forest {
     int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap, SegCap;
     Arena arena;
     mht_nodes layer[MAXR];
-    int32_t* path[2]; int32_t* apath[2]; int32_t* ctgt; double* cost; int32_t* child_ptr; int32_t* tchild;
+    int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
+    int pds = 8;                      // ints per path / ancestor record (8 or 16)
+    float4* G[2];                     // gain tables by scan parity: row = covariance column (fgrow_kernel)
+    unsigned* alloc; int region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
     TTable tab[2];
-    unsigned long long* assoc;
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
-    unsigned long long* tile_state; unsigned long long* group_state; unsigned* edges; int32_t* edge_count; int32_t* ticket;
+    unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
@@ -212,6 +234,7 @@ struct Forest {
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
     int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0; bool dead = false;
+    int nT_ub_prev = 0;      // ... of the scan before it (grid of a grow launch that carries that scan's commit)
     int nT_ub_step = 0;      // upper bound of the number of targets of the last launched scan (rows of its report)
     int births_since_step = 0;   // candidates added after the last launched scan (they are not in its report)
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
@@ -228,23 +251,23 @@ struct Forest {
             l.flags = ar.take<uint8_t>(Ncap); l.P = ar.take<float>((size_t)16 * capc);
         }
         for (int b = 0; b < 2; ++b) {
-            path[b] = ar.take<int32_t>((size_t)PD * Ncap);
-            apath[b] = ar.take<int32_t>((size_t)PD * Ncap);
+            path[b] = ar.take<int32_t>((size_t)pds * Ncap);
+            apath[b] = ar.take<int32_t>((size_t)pds * Ncap);
             TTable& t = tab[b];
             t.id = ar.take<int32_t>(Tcap); t.window = ar.take<int32_t>(Tcap); t.depth = ar.take<int32_t>(Tcap);
             t.shift = ar.take<int32_t>(Tcap); t.root_scan = ar.take<int32_t>(Tcap); t.root_node = ar.take<int32_t>(Tcap);
             t.root_cnllr = ar.take<double>(Tcap); t.root_f32 = ar.take<uint8_t>(Tcap);
             t.first = ar.take<int32_t>(Tcap); t.leaf_off = ar.take<int32_t>((size_t)Tcap + 1);
         }
-        ctgt = ar.take<int32_t>(Ncap); cost = ar.take<double>(Ncap);
-        child_ptr = ar.take<int32_t>((size_t)Ncap + 1); tchild = ar.take<int32_t>((size_t)Tcap + 1);
-        assoc = ar.take<unsigned long long>((size_t)Tcap * AW); used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
+        cost = ar.take<double>(Ncap);
+        tchild = ar.take<int32_t>((size_t)Tcap + 1); tcend = ar.take<int32_t>((size_t)Tcap + 1);
+        G[0] = ar.take<float4>((size_t)4 * capc); G[1] = ar.take<float4>((size_t)4 * capc);
+        alloc = ar.take<unsigned>((size_t)FG_REGIONS * 32);
+        used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
         status2 = ar.take<DevStatus>(2);
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
-        tile_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE + 8); group_state = ar.take<unsigned long long>((size_t)Ncap / GATE_TILE / 64 + 8);
         edges = ar.take<unsigned>((size_t)EDGE_SEGS * SegCap);
         edge_count = ar.take<int32_t>(EDGE_SEGS + 4);
-        ticket = ar.take<int32_t>(64) + 32;      // a cache line of its own: the edge counters next door are hammered by atomics
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8);
@@ -294,7 +317,7 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
 // runs the pending commit now (see Forest::commit_pending)
 static int flush_commit(mht_ctx* ctx, Forest* f) {
     if (!f->commit_pending) return MHT_OK;
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(PRUNE_THREADS), 0, ctx->stream, f->pending);
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending);
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
     return MHT_OK;
@@ -312,7 +335,9 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 2 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 2);
     MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
     MHT_REQUIRE(cfg->max_targets >= 1 && cfg->max_targets <= 8192, "mht_forest_create: max_targets must be in [1, 8192]");
-    MHT_REQUIRE(cfg->max_nodes >= 64, "mht_forest_create: max_nodes too small");
+    MHT_REQUIRE(cfg->max_nodes >= 2 * cfg->max_targets + 512, "mht_forest_create: max_nodes must be at least 2 * max_targets + 512");
+    MHT_REQUIRE((cfg->n_scan + 2) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,
+                "mht_forest_create: (n_scan + 2) x max_meas = %d measurement nodes exceed the 16 bits of an edge record", (cfg->n_scan + 2) * (((cfg->max_meas + 63) / 64) * 64));
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     Forest* f = new (std::nothrow) Forest();
     MHT_REQUIRE(f, "mht_forest_create: out of host memory");
@@ -330,6 +355,10 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->capc = 2 * f->Ncap + f->Tcap;
     f->Ecap = 4 * f->Ncap;              // edges the clustering kernel can take beyond its LDS list (spill arrays)
     f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
+    f->region_cap = (f->Ncap - f->Tcap) / FG_REGIONS;
+    f->root_base = FG_REGIONS * f->region_cap;
+    f->pds = f->PD <= 8 ? 8 : 16;
+
     f->used_off = sizeof(ReportHeader);
     f->rec_off = f->used_off + (size_t)(f->Mpad / 64) * 8;
     f->report_bytes = f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report);
@@ -394,9 +423,10 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     const int nb = (f->scan + 1) & 1;
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb]; a.vidx = nb;
-    a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->PD;
+    a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
     a.near = f->near;
+    fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
@@ -461,6 +491,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     hipStream_t st = ctx->stream;
     const int s = ++f->scan;
     const int cb = s & 1, nb = (s + 1) & 1;
+    f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
     f->nT_ub_step = f->nT_ub;
     f->births_since_step = 0;
     const int W = (M + 63) / 64;
@@ -478,45 +509,51 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     const bool fused = f->commit_pending;      // the previous scan's commit rides in this scan's grow_kernel
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[0], st));
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
-    GateArgs g = {};
-    fill_model(g, &f->model);
     const mht_nodes& in = f->layer[(s - 1) % f->R];
     const mht_nodes& out = f->layer[s % f->R];
-    g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
-    g.cap_in = in.cap; g.capc_in = in.cap_cov;
-    g.leaf_src = nullptr; g.L = 0;
-    g.ticket = f->ticket; g.tile_state = f->tile_state; g.group_state = f->group_state; g.epoch = (unsigned)s;
-    g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
-    g.t_leaf_off = f->tab[cb].leaf_off; g.t_first = f->tab[cb].first; g.nT_dev = &f->cnt->nT; g.Tcap = f->Tcap;
-    g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;
-    if (fused) {      // tables of the scan before, still uncommitted: the tiles compact them for themselves
-        const int pb = (s - 1) & 1;
-        g.fused = 1;
-        g.nT_dev = &f->cnt->nTv[pb];
-        g.p_status = f->t_status; g.p_count = f->t_count; g.p_jdrop = f->t_jdrop; g.p_firstsurv = f->t_firstsurv;
-        g.p_depth = f->tab[pb].depth; g.t_root_cnllr = f->w_root_cnllr; g.t_root_f32 = f->w_root_f32;
+    int rc;
+    {
+        FGrowArgs g = {};
+        fill_model_only(g.model, &f->model);
+        g.default_pd = f->model.default_pd; g.default_miss_nllr = f->model.default_miss_nllr;
+        g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
+        g.cap = f->Ncap; g.capc = f->capc;
+        g.G_in = f->G[(s - 1) & 1]; g.G_out = f->G[s & 1];
+        g.in_path = f->path[(s - 1) & 1]; g.in_apath = f->apath[(s - 1) & 1]; g.pds = f->pds;
+        g.z = z; g.M = M; g.W = W;
+        g.Tcap = f->Tcap;
+        if (fused) {      // tables of the scan before, still uncommitted
+            const int pb = (s - 1) & 1;
+            g.nT_dev = &f->cnt->nTv[pb];
+            g.p_status = f->t_status; g.p_count = f->t_count; g.p_jdrop = f->t_jdrop; g.p_firstsurv = f->t_firstsurv;
+            g.p_depth = f->tab[pb].depth; g.t_root_cnllr = f->w_root_cnllr; g.t_root_f32 = f->w_root_f32;
+        } else {
+            g.nT_dev = &f->cnt->nT;
+            g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
+        }
+        g.t_first = f->tab[cb].first; g.t_leaf_off = f->tab[cb].leaf_off; g.t_depth = f->tab[cb].depth; g.t_shift = f->tab[cb].shift;
+        g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
+        g.oflags = out.flags; g.oP = out.P;
+        g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
+        g.tchild = f->tchild; g.tcend = f->tcend;
+        g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
+        g.alloc = f->alloc; g.region_cap = f->region_cap;
+        g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
+        g.used_bytes = f->used_bytes[s & 1];
+        g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;
+        // one workgroup per slot of the table the scan runs on: the uncommitted one (targets before the last scan's
+        // terminations) when the commit rides along, else the committed one
+        rc = launch_fgrow(ctx, g, fused ? f->nT_ub_prev : f->nT_ub, fused ? &f->pending : nullptr);
+        if (rc) return rc;
     }
-    g.z = z; g.M = M; g.W = W;
-    g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
-    g.oflags = out.flags; g.oP = out.P; g.cap_out = out.cap; g.capc_out = out.cap_cov;
-    g.child_ptr = f->child_ptr; g.nllr = nullptr; g.used = nullptr; g.used_bytes = f->used_bytes[s & 1];
-    g.in_path = f->path[(s - 1) & 1]; g.tgt_shift = f->tab[cb].shift; g.tgt_depth = f->tab[cb].depth;
-    g.out_path = f->path[s & 1]; g.out_tgt = f->ctgt;
-    g.in_apath = f->apath[(s - 1) & 1]; g.out_apath = f->apath[s & 1];
-    g.assoc = f->assoc; g.assoc_words = f->AW; g.PD = f->PD; g.cur_slot_base = (s % f->R) * f->Mpad;
-    g.tchild = f->tchild; g.ocost = f->cost;
-    if (!fused) { g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32; }
-    g.Nwin = f->cfg.n_scan;
-    g.dbg = getenv("MHT_GROW_DEBUG") ? f->grow_dbg : nullptr;
-    int rc = launch_gate(ctx, g, f->L_ub > 0 ? f->L_ub : 1, fused ? &f->pending : nullptr);
-    if (rc) return rc;
     f->commit_pending = false;
     if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     ClusterArgs c = {};
-    c.assoc = f->assoc; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
-    c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 1;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = f->ticket; c.seg_cap = f->SegCap; c.status = st_cur; c.status_other = st_prev; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
+    c.assoc = nullptr; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
+    c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 0;
+    c.alloc_reset = f->alloc;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = nullptr; c.seg_cap = f->SegCap; c.status = st_cur; c.status_other = st_prev; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     rc = launch_cluster(ctx, c);
@@ -525,8 +562,8 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
     BlpArgs b = {};
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
-    b.counts = f->cl_counts; b.tchild = f->tchild; b.cost = f->cost; b.cnllr = out.cnllr;
-    b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD;
+    b.counts = f->cl_counts; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
+    b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD; b.pds = f->pds;
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
     b.bb_snap = f->bb_snap; b.bb_busy = f->bb_busy; b.bb_snap_rows = f->bb_snap_rows;
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;

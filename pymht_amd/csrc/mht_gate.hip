@@ -229,7 +229,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
     if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it, the tiles follow from workgroup 1
-        if (bid == 0) { commit_body(cm); return; }
+        if (bid == 0) { __shared__ int s_commit[2 * (GATE_THREADS / 64) + 8]; commit_body<GATE_THREADS>(cm, s_commit); return; }
         bid -= 1;
     }
     // First round trip, everything at once: the scalars that decide what this workgroup does, the first slice of the scan
@@ -688,12 +688,16 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArg
     return MHT_OK;
 }
 
+void fill_model_only(Model& o, const mht_model* m) {
+    for (int i = 0; i < 16; ++i) { o.A[i] = m->A[i]; o.Q[i] = m->Q[i]; }
+    for (int i = 0; i < 8; ++i) o.C[i] = m->C[i];
+    for (int i = 0; i < 4; ++i) o.R[i] = m->R[i];
+    o.eta2 = m->eta2;
+    o.lambda_ex = m->lambda_ex;
+}
+
 void fill_model(GateArgs& a, const mht_model* m) {
-    for (int i = 0; i < 16; ++i) { a.model.A[i] = m->A[i]; a.model.Q[i] = m->Q[i]; }
-    for (int i = 0; i < 8; ++i) a.model.C[i] = m->C[i];
-    for (int i = 0; i < 4; ++i) a.model.R[i] = m->R[i];
-    a.model.eta2 = m->eta2;
-    a.model.lambda_ex = m->lambda_ex;
+    fill_model_only(a.model, m);
     a.default_pd = m->default_pd;
     a.default_miss_nllr = m->default_miss_nllr;
 }

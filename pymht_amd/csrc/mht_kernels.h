@@ -60,6 +60,41 @@ struct GateArgs {
 
 struct CommitArgs;
 
+// fgrow_kernel (mht_fgrow.hip): the grow stage of the forest, one workgroup per target + covariance-chain workgroups
+struct FGrowArgs {
+    Model model;
+    double default_pd, default_miss_nllr;
+    // input layer (the previous scan's nodes); cap / capc are the same for every layer of the ring
+    const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
+    int cap, capc;
+    const float4* G_in;            // [capc][4] gains by covariance column of the input layer (written one scan ahead)
+    const int32_t* in_path;        // [cap][pds] measurement nodes below the root, one record per node of the input layer
+    const int32_t* in_apath;       // [cap][pds] ancestor node per level
+    int pds;                       // ints per record: 8 (PD <= 8) or 16
+    const float* z; int M; int W;
+    // the target table this scan runs on.  fused = 1: the commit of the previous scan has not run (it rides in workgroup 0):
+    // the per-target results of that scan (p_*), indexed by old slot, stand in for the compacted table
+    int fused;
+    const int32_t* nT_dev;
+    int Tcap;
+    const int32_t* p_status; const int32_t* p_count; const int32_t* p_jdrop; const int32_t* p_firstsurv; const int32_t* p_depth;
+    const int32_t* t_first; const int32_t* t_leaf_off; const int32_t* t_depth; const int32_t* t_shift;
+    const double* t_root_cnllr; const uint8_t* t_root_f32;      // by slot of the table named above
+    // output layer
+    double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
+    float4* G_out;
+    int32_t* out_path; int32_t* out_apath; double* ocost;
+    int32_t* tchild; int32_t* tcend;      // [T] children of (compacted) target t: tchild[t] .. tcend[t]-1
+    int PD; int Nwin; int cur_slot_base; int AW;
+    unsigned* alloc;               // [FG_REGIONS][32] child counter of every region (a cache line each), zero at launch
+    int region_cap;                // node indices per region; region r = [r * region_cap, (r+1) * region_cap)
+    unsigned* edges; int32_t* edge_count; int edge_cap;
+    unsigned char* used_bytes;
+    DevStatus* status;             // this scan's status word: n_children is accumulated here
+    const DevStatus* prev_status; const int32_t* sticky_overflow;
+    int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
+};
+
 struct ClusterArgs {
     const unsigned long long* assoc;   // [T][AW]
     int AW;                            // words per target
@@ -77,6 +112,7 @@ struct ClusterArgs {
     int32_t* edge_count;               //   [EDGE_SEGS] segment lengths; reset to zero here
     int seg_cap;                       //   segment stride
     int32_t* ticket_reset;             //   grow_kernel's tile ticket, reset to zero here for the next scan
+    unsigned* alloc_reset;             //   fgrow_kernel's child counters [FG_REGIONS][32], reset to zero here for the next scan
     // outputs
     int32_t* t_label;      // [T] smallest member of the component
     int32_t* t_cluster;    // [T] cluster index
@@ -97,10 +133,13 @@ struct RingLayer { const double* x; const double* cnllr; const int32_t* meas; co
 struct BlpArgs {
     const int32_t* cl_ptr; const int32_t* cl_members; const int32_t* multi_list; const int32_t* single_list;
     const int32_t* counts;          // [1] = nMulti, [2] = nSingle
-    const int32_t* tchild;          // [T+1] children of target t are columns tchild[t] .. tchild[t+1]-1
+    const int32_t* tchild;          // [T] children of target t are columns tchild[t] .. tcend[t]-1
+    const int32_t* tcend;           // [T] (the stateless seam passes group_ptr and group_ptr + 1)
     const double* cost;             // [cap] f_h
     const double* cnllr;            // [cap] cumulativeNLLR of the children (single-target clusters)
     const int32_t* path; int cap; int PD;
+    int pds;                        // 0: path = [PD][cap] rows (stateless seam); else: one record of pds ints per column, path[h * pds + d],
+                                    // entries beyond PD = -1 (forest; apath has the same layout)
     double* u; int32_t* usage; int32_t* mark; int n_mnodes;       // HBM-path scratch, zero on entry and on exit
     // branch and bound with re-optimised prices: snapshot pool [slots][levels][bb_snap_rows] and its busy flags (zero = free);
     // null = static-bound search
@@ -129,7 +168,9 @@ struct BlpArgs {
 };
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArgs* commit = nullptr);
+int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs* commit);
 void fill_model(GateArgs& a, const mht_model* m);
+void fill_model_only(Model& o, const mht_model* m);
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);

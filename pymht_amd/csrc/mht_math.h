@@ -97,10 +97,17 @@ MHT_HD void inv2(const float* s, float* out) {
     }
 }
 
-template <typename TS>
-MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predicted<TS>& o) {
-    // kalman.py:61  x_bar = A.dot(x.T).T      (A promoted to the state dtype)
-    gemm_chain<TS, float, TS, 4, 4, 1>(m.A, x, o.x_bar);
+// The measurement-independent covariance chain of one hypothesis (kalman.py:62, :90-93): P -> P_bar, S, S^-1, K, P_hat.
+// All float32, like the reference's model matrices; `with_phat` = false stops after K (the gains of a node whose children's
+// covariance is not needed yet).
+struct CovChain {
+    float P_bar[16];
+    float P_hat[16];
+    float K[8];      // 4x2
+    float S[4];
+    float S_inv[4];
+};
+MHT_HD void cov_chain(const Model& m, const float* P, CovChain& o, bool with_phat = true) {
     // kalman.py:62  P_bar = matmul(matmul(A, P), A.T) + Q
     float AP[16], At[16], APA[16];
 #pragma unroll
@@ -111,8 +118,6 @@ MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predict
     gemm_chain<float, float, float, 4, 4, 4>(AP, At, APA);
 #pragma unroll
     for (int i = 0; i < 16; ++i) o.P_bar[i] = APA[i] + m.Q[i];
-    // kalman.py:89  z_hat = C.dot(x_bar.T).T
-    gemm_chain<TS, float, TS, 2, 4, 1>(m.C, o.x_bar, o.z_hat);
     // kalman.py:90  S = matmul(matmul(C, P_bar), C.T) + R
     float Ct[8], CP[8], CPC[4];
 #pragma unroll
@@ -129,12 +134,33 @@ MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predict
     float PCt[8];
     gemm_chain<float, float, float, 4, 4, 2>(o.P_bar, Ct, PCt);
     gemm_chain<float, float, float, 4, 2, 2>(PCt, o.S_inv, o.K);
+    if (!with_phat) return;
     // kalman.py:93  P_hat = P_bar - matmul(K.dot(C), P_bar)
     float KC[16], KCP[16];
     gemm_chain<float, float, float, 4, 2, 4>(o.K, m.C, KC);
     gemm_chain<float, float, float, 4, 4, 4>(KC, o.P_bar, KCP);
 #pragma unroll
     for (int i = 0; i < 16; ++i) o.P_hat[i] = o.P_bar[i] - KCP[i];
+}
+
+// kalman.py:61 / :89  x_bar = A.dot(x.T).T (A promoted to the state dtype), z_hat = C.dot(x_bar.T).T
+template <typename TS>
+MHT_HD void state_predict(const Model& m, const TS* x, TS* x_bar, TS* z_hat) {
+    gemm_chain<TS, float, TS, 4, 4, 1>(m.A, x, x_bar);
+    gemm_chain<TS, float, TS, 2, 4, 1>(m.C, x_bar, z_hat);
+}
+
+template <typename TS>
+MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predicted<TS>& o) {
+    state_predict<TS>(m, x, o.x_bar, o.z_hat);
+    CovChain c;
+    cov_chain(m, P, c);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o.P_bar[i] = c.P_bar[i]; o.P_hat[i] = c.P_hat[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.K[i] = c.K[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.S[i] = c.S[i]; o.S_inv[i] = c.S_inv[i]; }
 }
 
 // kalman.py:19  ln( lambda_ex * sqrt(det(2 pi S)) / P_d ), evaluated in f32 exactly as NumPy evaluates it for an

@@ -106,7 +106,7 @@ def test_capacity_overflow_is_reported_not_fatal():
     from pymht_amd import _lib
     from pymht_amd.utils.classDefinitions import MeasurementList
     sc = _scenario(T=40, radius=300.0, lambda_phi=8e-5, n_scans=8, seed=5)
-    trk = _mk(sc, N=5, useInitiator=False, maxNodes=128)
+    trk = _mk(sc, N=5, useInitiator=False, maxTargets=64, maxNodes=1024)
     with pytest.raises(_lib.MhtError) as ei:
         for z, t in zip(sc["scans"], sc["times"]):
             trk.addMeasurementList(MeasurementList(float(t), z))
@@ -292,8 +292,8 @@ def test_preinitialize_batch_equals_one_by_one():
 
 
 @pytest.mark.parametrize("T,N,radius,lam,n_scans,kw", [
-    (60, 3, 500.0, 3e-5, 12, {}),                                                          # dense clusters, one tile chunk
-    (200, 7, 3000.0, 1.5e-6, 10, {}),                                                      # > 512 tiles: ticket-numbered tiles
+    (60, 3, 500.0, 3e-5, 12, {}),                                                          # dense clusters
+    (200, 7, 3000.0, 1.5e-6, 10, {}),                                                      # N = 7: targets with > 64 leaves (chunked, two passes)
     (700, 3, 6000.0, 1e-6, 6, dict(maxTargets=1024, maxMeasurements=1024)),                # > 512 targets: chunked compaction
 ])
 def test_deferred_commit_equals_immediate_commit(T, N, radius, lam, n_scans, kw):
@@ -338,12 +338,17 @@ def test_deferred_commit_equals_immediate_commit(T, N, radius, lam, n_scans, kw)
             assert births(A) == births(B)
     hb, rb, ub = report(B)
     assert ra[0] == hb, (ra[0], hb)
-    assert ra[1].tobytes() == rb.tobytes()
+    # node indices (sel_node, root_node) are handles: a target's children take their block of the node index space with an
+    # atomic, so the numbering differs from run to run; everything else must be identical
+    for name in _REPORT_DTYPE.names:
+        if name not in ("sel_node", "root_node"):
+            assert np.array_equal(ra[1][name], rb[name]), name
     assert np.array_equal(ra[2], ub)
     la, lb = A.leafBatch(), B.leafBatch()
     assert len(la["ID"]) == hb[5] > 0
     for key in la:
-        assert np.array_equal(la[key], lb[key]), key
+        if key != "node":
+            assert np.array_equal(la[key], lb[key]), key
     A.close()
     B.close()
 
@@ -393,7 +398,7 @@ def test_deferred_commit_edge_cases_raw_abi():
     trk.close()
     # (c) overflow while nobody looks
     sc = _scenario(T=40, radius=300.0, lambda_phi=8e-5, n_scans=8, seed=5)
-    trk = _mk(sc, N=5, useInitiator=False, maxNodes=128)
+    trk = _mk(sc, N=5, useInitiator=False, maxTargets=64, maxNodes=1024)
     for z in sc["scans"]:
         step(trk, z)
     rc, rep = report(trk)
