@@ -57,7 +57,7 @@ constexpr int MAX_MEAS = 4096;    // 64 hit-mask words per leaf, one per lane
 constexpr int EDGE_SEGS = 64;      // the (target, measurement) edge list is written in 64 independently counted segments
 constexpr int MAXPD = 15;         // longest root->leaf path kept per hypothesis (N-scan window + 1)
 constexpr int FG_THREADS = 256;   // fgrow_kernel: one workgroup per target
-constexpr int FG_CAP = 64;        //   leaves of a target handled per pass (more: chunks, two passes)
+constexpr int FG_CAP = 96;        //   leaves of a target handled per pass, one per lane of two wavefronts (more: chunks, two passes)
 constexpr int FG_REGIONS = 8;     //   regions of the node index space, one child counter each (one per XCD)
 
 // device-side status word of a ctx (sticky until read)

@@ -31,12 +31,13 @@ struct FLeaf {            // per-leaf results of phase 1 parked in LDS for the l
     float K[8];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
-    int src, last_real, cnt;
+    int src;
     unsigned char flags, f32state, valid, pad;
 };
 static_assert(sizeof(FLeaf) % 8 == 0, "FLeaf must keep 8-byte alignment in LDS");
 
 struct TInfo { int alive, first, cnt, depth, shift; };
+constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128;     // targets per chain workgroup: wavefront = (target, hit/miss)
 typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
 
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
@@ -62,6 +63,13 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
     return i >= 0 ? i : (i ^ 0x7fffffff);
 }
 
+// per-phase wall-clock stamps (tools/grow_profile.py): compiled in only with -DMHT_GROW_STAMPS
+#ifdef MHT_GROW_STAMPS
+#define FG_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define FG_STAMP(k)
+#endif
+
 // ---- chain workgroups: the covariance chain one scan ahead ---------------------------------------------------------------
 // Wavefront = (target, hit/miss); lane = leaf.  For leaf `src` (node of the previous layer, covariance P = Pin[cov[src]]):
 //   full chain from P -> P_bar, P_hat; the child's covariance Pc = hit ? P_hat : P_bar goes to column 2*src+hit of the new
@@ -81,12 +89,12 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
-    const int t = cb * (FG_THREADS / 128) + (wave >> 1), h = wave & 1;
+    // wavefront = (target, hit/miss), lane = leaf: two targets per workgroup
+    const int t = cb * FG_CHAIN_TARGETS + (wave >> 1), h = wave & 1;
     const TInfo ti = target_info(a, t, nT);
     if (po || so) return;
-    for (int c0 = 0; c0 < ti.cnt; c0 += 64) {
-        const int l = c0 + lane;
-        if (l >= ti.cnt) break;
+    FG_STAMP(0);
+    for (int l = lane; l < ti.cnt; l += 64) {
         const int src = ti.first + l;
         const int covc = a.cov[src];
         const double pd = a.pd[src];
@@ -108,6 +116,7 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) a.G_out[(size_t)col * 4 + q] = rec[q];
     }
+    FG_STAMP(1);
 }
 
 // ---- target workgroups ---------------------------------------------------------------------------------------------------
@@ -201,15 +210,16 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + a.pds * FG_CAP);  // [FG_CAP][W] hit masks
     unsigned long long* tb = hw + (size_t)FG_CAP * W;                                       // [AW] association bitset of the target
     int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [FG_CAP + 1]
-    int* s_misc = s_pref + FG_CAP + 4;                                                      // [16]
-    unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 16);                  // [Mpad]
+    int* s_misc = s_pref + FG_CAP + 4;                                                      // [32]
+    unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
     int& s_ncand = s_misc[0];
     int& s_base = s_misc[1];
     int& s_ebase = s_misc[2];
     int& s_total = s_misc[3];
-    int* s_box = s_misc + 4;          // [4] sortable ints: min x, max x, min y, max y
-    int* s_red = s_misc + 8;          // [4] per-wave partials
+    int* s_red = s_misc + 4;          // [4] per-wave partials of the alive prefix
+    int* s_boxp = s_misc + 8;         // [2][4] per-wave gate boxes as sortable ints: min x, max x, min y, max y
 
+    FG_STAMP(0);
     // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
     const int nT = a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
@@ -234,14 +244,13 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) s_red[wave] = acc;
-    __syncthreads();
-    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+    if (lane == 0) s_red[wave] = acc;      // (summed behind the first barrier below: nothing needs the index before the allocation)
     const int depth0 = ti.depth, shift0 = ti.shift, cnt = ti.cnt, first = ti.first;
     const int curw = a.cur_slot_base >> 6;      // first word of this scan's measurement nodes in the association bitset
 
     // ---- the target's children: count, take a block of the node index space, emit -------------------------------------------
-    // (a target with more than FG_CAP leaves runs the chunk loop twice: pass 0 only counts, pass 1 emits)
+    // A chunk = FG_CAP leaves, one per lane of wavefronts 0 and 1.  A target with more leaves runs the chunk loop twice: pass 0
+    // only counts, pass 1 emits.
     const bool two_pass = cnt > FG_CAP;
     int total = 0, run = 0, base = 0;
     for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
@@ -254,125 +263,134 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
             KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // (FGrowArgs is the first kernel argument)
             asm volatile("" : "+s"(ap));
             const auto& a = *ap;
-            // ---- phases 1 + 2 of one chunk: predict (gains looked up), gate ---------------------------------------------------------
-            auto phase12 = [&](int c0, int depth, int shift) {
-                const int n = (cnt - c0 < FG_CAP) ? cnt - c0 : FG_CAP;
-                for (int w = tid; w < FG_CAP * W; w += FG_THREADS) hw[w] = 0ull;
-                if (tid == 0) s_ncand = 0;
-                if (wave == 0) {
-                    FLeaf& g = lg[lane];
-                    const bool valid = lane < n;
-                    const int src = first + c0 + (valid ? lane : 0);
-                    // batch A: everything addressed by the leaf; nothing sits behind a branch
-                    const uint8_t fl = a.flags[src];
-                    const double cn = a.cnllr[src], pd = a.pd[src];
-                    const int covc = a.cov[src];
-                    double xd[4];
-        #pragma unroll
-                    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
-                    // the leaf's path / ancestor records (pds ints each: 2 or 4 x 16 bytes)
-                    const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * a.pds);
-                    const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * a.pds);
-                    int4 pq[4], aq[4];
-        #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool on = q * 4 < a.pds;          // uniform
-                        pq[q] = on ? prec[q] : make_int4(-1, -1, -1, -1);
-                        aq[q] = on ? arec[q] : make_int4(-1, -1, -1, -1);
-                    }
-                    // batch B: the gains of the leaf's covariance column
-                    float4 gr[4];
-        #pragma unroll
-                    for (int q = 0; q < 4; ++q) gr[q] = a.G_in[(size_t)covc * 4 + q];
-                    g.valid = valid;
-                    g.cnt = 0;
-                    g.src = src;
-                    g.flags = fl;
-                    g.f32state = (fl & F_STATE_F32) ? 1 : 0;
-                    g.cn = cn;
-                    g.pd = pd;
-                    // records parked raw (the root advance `shift` is applied when they are read back); last real measurement on the path
-                    int last = -1;
-        #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q * 4 < a.pds) {
-                            reinterpret_cast<int4*>(s_pp + lane * a.pds)[q] = pq[q];
-                            reinterpret_cast<int4*>(s_ap + lane * a.pds)[q] = aq[q];
-                            const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
-        #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int i = q * 4 + e;
-                                if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
-                            }
+            const int n = (cnt - c0 < FG_CAP) ? cnt - c0 : FG_CAP;
+            const bool first_emit = (pass == 1 && c0 == 0);
+            // ---- phase 1: predict, one leaf per lane of wavefronts 0 and 1; the gains come from the table -----------------------
+            for (int w = tid; w < FG_CAP * W; w += FG_THREADS) hw[w] = 0ull;
+            if (tid == 0) s_ncand = 0;
+            int last = -1;
+            if (wave < 2) {          // (both wavefronts whole: the box reduction below runs over all their lanes)
+                const bool keep = tid < FG_CAP;
+                FLeaf g;
+                const bool valid = tid < n;
+                const int src = first + c0 + (valid ? tid : 0);
+                // batch A: everything addressed by the leaf; nothing sits behind a branch
+                const uint8_t fl = a.flags[src];
+                const double cn = a.cnllr[src], pd = a.pd[src];
+                const int covc = a.cov[src];
+                double xd[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+                // the leaf's path / ancestor records (pds ints each: 2 or 4 x 16 bytes)
+                const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * a.pds);
+                const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * a.pds);
+                int4 pq[4], aq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool on = q * 4 < a.pds;          // uniform
+                    pq[q] = on ? prec[q] : make_int4(-1, -1, -1, -1);
+                    aq[q] = on ? arec[q] : make_int4(-1, -1, -1, -1);
+                }
+                // batch B: the gains of the leaf's covariance column
+                float4 gr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gr[q] = a.G_in[(size_t)covc * 4 + q];
+                g.valid = valid;
+                g.src = src;
+                g.flags = fl;
+                g.f32state = (fl & F_STATE_F32) ? 1 : 0;
+                g.cn = cn;
+                g.pd = pd;
+                // records parked raw (the root advance `shift` is applied when they are read back); last real measurement on the path
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q * 4 < a.pds) {
+                        if (keep) {
+                            reinterpret_cast<int4*>(s_pp + tid * a.pds)[q] = pq[q];
+                            reinterpret_cast<int4*>(s_ap + tid * a.pds)[q] = aq[q];
                         }
-                    g.last_real = last;
-                    if (valid && last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));
-                    Model mdl;          // (only A and C are used: uniform registers)
+                        const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = q * 4 + e;
+                            if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
+                        }
+                    }
+                if (!valid) last = -1;
+                Model mdl;          // (only A and C are used: uniform registers)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
-                    if (g.f32state) {
-                        float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
-                        state_predict<float>(mdl, xs, xb, zh);
-        #pragma unroll
-                        for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
-                        g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
-                    } else {
-                        double xb[4], zh[2];
-                        state_predict<double>(mdl, xd, xb, zh);
-        #pragma unroll
-                        for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
-                        g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
-                    }
-                    g.sinv[0] = gr[0].x; g.sinv[1] = gr[0].y; g.sinv[2] = gr[0].z; g.sinv[3] = gr[0].w;
-                    g.K[0] = gr[1].x; g.K[1] = gr[1].y; g.K[2] = gr[1].z; g.K[3] = gr[1].w;
-                    g.K[4] = gr[2].x; g.K[5] = gr[2].y; g.K[6] = gr[2].z; g.K[7] = gr[2].w;
-                    g.lnc = gr[3].x;
-                    const float zhx = (float)g.zhat[0], zhy = (float)g.zhat[1];
-                    const float rx = gr[3].y, ry = gr[3].z;
-                    // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widened for the float32 rounding of the
-                    // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test decides, this only prunes
-                    const float bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;
-                    const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
-                    g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by;
-                    // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first cut
-                    // down to the measurements inside it
-                    float lox = zhx - bx, hix = zhx + bx, loy = zhy - by, hiy = zhy + by;
-                    lox -= fabsf(lox) * 2.4e-7f + 1e-30f; hix += fabsf(hix) * 2.4e-7f + 1e-30f;      // outward: a superset of the leaf's own box
-                    loy -= fabsf(loy) * 2.4e-7f + 1e-30f; hiy += fabsf(hiy) * 2.4e-7f + 1e-30f;
-                    int b0 = valid ? fg_sortable(lox) : 0x7fffffff, b1 = valid ? fg_sortable(hix) : (int)0x80000000;
-                    int b2 = valid ? fg_sortable(loy) : 0x7fffffff, b3 = valid ? fg_sortable(hiy) : (int)0x80000000;
-        #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        b0 = min(b0, __shfl_xor(b0, o)); b1 = max(b1, __shfl_xor(b1, o));
-                        b2 = min(b2, __shfl_xor(b2, o)); b3 = max(b3, __shfl_xor(b3, o));
-                    }
-                    if (lane == 0) { s_box[0] = b0; s_box[1] = b1; s_box[2] = b2; s_box[3] = b3; }
+                for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+                if (g.f32state) {
+                    float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
+                    state_predict<float>(mdl, xs, xb, zh);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
+                    g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
+                } else {
+                    double xb[4], zh[2];
+                    state_predict<double>(mdl, xd, xb, zh);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
+                    g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
                 }
-                __syncthreads();
-                // phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront)
-                const int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3];
-                for (int j0 = 0; j0 < Mpad; j0 += FG_THREADS) {
-                    const int j = j0 + tid;
-                    bool in = false;
-                    if (j < Mpad) {
-                        const int kx = fg_sortable(zx[j]), ky = fg_sortable(zy[j]);
-                        in = (kx >= x0) && (kx <= x1) && (ky >= y0) && (ky <= y1);
-                    }
-                    const unsigned long long bal = __ballot(in);
-                    int wbase = 0;
-                    if (lane == 0 && bal) wbase = atomicAdd(&s_ncand, __popcll(bal));
-                    wbase = __shfl(wbase, 0);
-                    if (in) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+                g.sinv[0] = gr[0].x; g.sinv[1] = gr[0].y; g.sinv[2] = gr[0].z; g.sinv[3] = gr[0].w;
+                g.K[0] = gr[1].x; g.K[1] = gr[1].y; g.K[2] = gr[1].z; g.K[3] = gr[1].w;
+                g.K[4] = gr[2].x; g.K[5] = gr[2].y; g.K[6] = gr[2].z; g.K[7] = gr[2].w;
+                g.lnc = gr[3].x;
+                const float zhx = (float)g.zhat[0], zhy = (float)g.zhat[1];
+                const float rx = gr[3].y, ry = gr[3].z;
+                // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widened for the float32 rounding of the
+                // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test decides, this only prunes
+                const float bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;
+                const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
+                g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by;
+                g.pad = 0;
+                if (keep) lg[tid] = g;
+                // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first
+                // cut down to the measurements inside it
+                float lox = zhx - bx, hix = zhx + bx, loy = zhy - by, hiy = zhy + by;
+                lox -= fabsf(lox) * 2.4e-7f + 1e-30f; hix += fabsf(hix) * 2.4e-7f + 1e-30f;      // outward: a superset of the leaf's own box
+                loy -= fabsf(loy) * 2.4e-7f + 1e-30f; hiy += fabsf(hiy) * 2.4e-7f + 1e-30f;
+                int b0 = valid ? fg_sortable(lox) : 0x7fffffff, b1 = valid ? fg_sortable(hix) : (int)0x80000000;
+                int b2 = valid ? fg_sortable(loy) : 0x7fffffff, b3 = valid ? fg_sortable(hiy) : (int)0x80000000;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    b0 = min(b0, __shfl_xor(b0, o)); b1 = max(b1, __shfl_xor(b1, o));
+                    b2 = min(b2, __shfl_xor(b2, o)); b3 = max(b3, __shfl_xor(b3, o));
                 }
-                __syncthreads();
-                // phase 2 (b): thread = (leaf, candidate): the leaf's own conservative float32 box, then the exact reference-order NIS
+                if (lane == 0) { s_boxp[wave * 4] = b0; s_boxp[wave * 4 + 1] = b1; s_boxp[wave * 4 + 2] = b2; s_boxp[wave * 4 + 3] = b3; }
+            }
+            __syncthreads();
+            FG_STAMP(2);
+            // ---- phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront) -----
+            if (last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));      // (the bitset was cleared in front of the barrier)
+            const int x0 = min(s_boxp[0], s_boxp[4]), x1 = max(s_boxp[1], s_boxp[5]);
+            const int y0 = min(s_boxp[2], s_boxp[6]), y1 = max(s_boxp[3], s_boxp[7]);
+            for (int j0 = 0; j0 < Mpad; j0 += FG_THREADS) {
+                const int j = j0 + tid;
+                bool in = false;
+                if (j < Mpad) {
+                    const int kx = fg_sortable(zx[j]), ky = fg_sortable(zy[j]);
+                    in = (kx >= x0) && (kx <= x1) && (ky >= y0) && (ky <= y1);
+                }
+                const unsigned long long bal = __ballot(in);
+                int wbase = 0;
+                if (lane == 0 && bal) wbase = atomicAdd(&s_ncand, __popcll(bal));
+                wbase = __shfl(wbase, 0);
+                if (in) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+            }
+            __syncthreads();
+            FG_STAMP(3);
+            // ---- phase 2 (b): thread = (leaf, candidate): the leaf's own conservative float32 box, then the exact reference-order NIS
+            {
                 const int nc = s_ncand;
-                for (int w = tid; w < FG_CAP * nc; w += FG_THREADS) {
-                    const int l = w & (FG_CAP - 1), j = cand[w / FG_CAP];
+                const int sh = (n > 1) ? 32 - __clz(n - 1) : 0;      // leaves padded to a power of two
+                for (int w = tid; w < (nc << sh); w += FG_THREADS) {
+                    const int l = w & ((1 << sh) - 1), j = cand[w >> sh];
+                    if (l >= n) continue;
                     const FLeaf& g = lg[l];
-                    if (!g.valid) continue;
                     const float mx = zx[j], my = zy[j];
                     if ((fabsf(mx - g.zhx) <= g.bx) && (fabsf(my - g.zhy) <= g.by)) {
                         bool hit;
@@ -389,81 +407,71 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                         }
                     }
                 }
-                __syncthreads();
-                // child counts of the chunk: 1 (missed detection) + hits per leaf, exclusive prefix in s_pref
-                if (wave == 0) {
-                    int hits = 0;
-                    for (int w = 0; w < W; ++w) hits += __popcll(hw[(size_t)lane * W + w]);
-                    const int mine = (lane < n) ? 1 + hits : 0;
-                    int incl = mine;
-        #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int v = __shfl_up(incl, o);
-                        if (lane >= o) incl += v;
-                    }
-                    s_pref[lane] = incl - mine;
-                    if (lane == 63) { s_pref[FG_CAP] = incl; s_total = incl; }
-                }
-                __syncthreads();
-            };
-
-            // ---- phase 4 of one chunk: one thread per child, children of the chunk at base .. base + total - 1 ---------------------
-            auto emit = [&](int base, int depth, int shift) {
-                const int total = s_pref[FG_CAP];
-                for (int r = tid; r < total; r += FG_THREADS) {
-                    int lo = 0, hi = FG_CAP;                 // leaf of child r: largest l with s_pref[l] <= r
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= r) lo = mid; else hi = mid;
-                    }
-                    const int l = lo, k = r - s_pref[l], c = base + r;
-                    const FLeaf& g = lg[l];
-                    if (g.f32state) fg_emit_child<float>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                }
-            };
-
-            phase12(c0, depth, shift);
-            if (pass == 0) {
-                total += s_total;
-                __syncthreads();
-                continue;
             }
-            if (c0 == 0) {
-                if (!two_pass) total = s_total;
-                // edges of the clustering graph: the set bits of the association bitset (complete here: the current scan's hits
-                // and every leaf's last real measurement; with two passes the count pass has seen all chunks)
-                int ne = 0;
-                if (wave == 1) {
-                    for (int w = lane; w < AW; w += 64) ne += __popcll(tb[w]);
+            __syncthreads();
+            FG_STAMP(4);
+            // ---- child counts (1 missed detection + hits per leaf), exclusive prefix, and -- before the first emission -- the
+            //      target's block of the node index space and its slice of the edge list: wavefront 0 / wavefront 1
+            if (wave == 0) {
+                int h0 = 0, h1 = 0;
+                const int l1 = (lane + 64 < FG_CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
+                for (int w = 0; w < W; ++w) { h0 += __popcll(hw[(size_t)lane * W + w]); h1 += __popcll(hw[(size_t)l1 * W + w]); }
+                const int m0 = (lane < n) ? 1 + h0 : 0, m1 = (lane + 64 < n) ? 1 + h1 : 0;
+                int i0 = m0, i1 = m1;
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v0 = __shfl_up(i0, o), v1 = __shfl_up(i1, o);
+                    if (lane >= o) { i0 += v0; i1 += v1; }
                 }
-                if (tid == 64) {
+                const int t0 = __shfl(i0, 63);
+                i1 += t0;
+                s_pref[lane] = i0 - m0;
+                if (lane + 64 < FG_CAP) s_pref[64 + lane] = i1 - m1;
+                const int chunk_total = __shfl(i1, 63);
+                if (lane == 63) { s_pref[FG_CAP] = chunk_total; s_total = chunk_total; }
+                if (first_emit && lane == 0) {
+                    const int tot = two_pass ? total : chunk_total;
+                    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                    // one returning atomic per target: a block of this XCD's region of the node index space (next region if full)
+                    int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
+                    int b = -1;
+                    for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
+                        const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)tot);
+                        if (old + (unsigned)tot <= (unsigned)a.region_cap) b = r * a.region_cap + (int)old;
+                        else r = (r + 1) & (FG_REGIONS - 1);
+                    }
+                    if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
+                    s_base = b;
+                    atomicAdd(&a.status->n_children, tot);
+                    a.tchild[pos] = b < 0 ? 0 : b;
+                    a.tcend[pos] = b < 0 ? 0 : b + tot;
+                }
+            } else if (wave == 1 && first_emit) {
+                // edges of the clustering graph = set bits of the association bitset (complete here: every leaf's last real
+                // measurement and the hits; with two passes the count pass has seen all chunks)
+                int ne = 0;
+                for (int w = lane; w < AW; w += 64) ne += __popcll(tb[w]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+                if (lane == 0) {
                     const int seg = blockIdx.x & (EDGE_SEGS - 1);
                     const int e0 = atomicAdd(&a.edge_count[seg], ne);
                     s_ebase = e0;
                     if (e0 + ne > a.edge_cap) a.status->overflow = 1;
                 }
-                if (tid == 0) {
-                    // one returning atomic per target: a block of this XCD's region of the node index space (next region if full)
-                    int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
-                    int b = -1;
-                    for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
-                        const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)total);
-                        if (old + (unsigned)total <= (unsigned)a.region_cap) b = r * a.region_cap + (int)old;
-                        else r = (r + 1) & (FG_REGIONS - 1);
-                    }
-                    if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
-                    s_base = b;
-                    atomicAdd(&a.status->n_children, total);
-                    a.tchild[pos] = b < 0 ? 0 : b;
-                    a.tcend[pos] = b < 0 ? 0 : b + total;
-                }
+            }
+            __syncthreads();
+            FG_STAMP(5);
+            if (pass == 0) {
+                total += s_total;
                 __syncthreads();
+                continue;
+            }
+            if (first_emit) {
                 base = s_base;
                 if (base < 0) return;
                 if (wave == 3) {      // edge list: (target << 16 | node) for every set bit
+                    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     const int seg = blockIdx.x & (EDGE_SEGS - 1);
                     int eb = s_ebase;
                     for (int w0 = 0; w0 < AW; w0 += 64) {
@@ -487,14 +495,29 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                     }
                 }
             }
-            emit(base + run, depth, shift);
-            run += s_total;
+            // ---- phase 4: one thread per child, children of the chunk at base + run .. ---------------------------------------------
+            {
+                const int ctot = s_pref[FG_CAP];
+                for (int r = tid; r < ctot; r += FG_THREADS) {
+                    int lo = 0, hi = FG_CAP;                 // leaf of child r: largest l with s_pref[l] <= r
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= r) lo = mid; else hi = mid;
+                    }
+                    const int l = lo, k = r - s_pref[l], c = base + run + r;
+                    const FLeaf& g = lg[l];
+                    if (g.f32state) fg_emit_child<float>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                }
+                run += ctot;
+            }
             if (c0 + FG_CAP < cnt) __syncthreads();      // the chunk tables are re-used
         }
     }
+    FG_STAMP(7);
 }
 
-__global__ __launch_bounds__(FG_THREADS) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
+__global__ __launch_bounds__(FG_THREADS, 4) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = blockIdx.x;
     if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(FG_THREADS) void fgrow_kernel(const FGrowArgs a, co
 
 static inline size_t fgrow_lds_bytes(int W, int pds, int AW) {
     size_t b = (size_t)2 * W * 64 * 4 + (size_t)FG_CAP * sizeof(FLeaf) + (size_t)2 * pds * FG_CAP * 4 + (size_t)FG_CAP * W * 8 + (size_t)AW * 8 +
-               (size_t)(FG_CAP + 4) * 4 + 64 + (size_t)W * 64 * 2;
+               (size_t)(FG_CAP + 4) * 4 + 128 + (size_t)W * 64 * 2;
     if (b < 256) b = 256;      // the commit workgroup keeps its scan partials here
     return (b + 15) & ~(size_t)15;
 }
@@ -517,10 +540,9 @@ int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs*
     int n_main = n_targets_ub < 1 ? 1 : n_targets_ub;
     if (n_main > a.Tcap) n_main = a.Tcap;
     a.n_main = n_main;
-    const int per = FG_THREADS / 128;                       // targets per chain workgroup (two wavefronts each: miss, hit)
-    const int n_chain = (n_main + per - 1) / per;
+    const int n_chain = (n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
     const size_t lds = fgrow_lds_bytes(a.W, a.pds, a.AW);
-    if (lds > 64 * 1024) {
+    if (lds > 150 * 1024) {
         set_error("fgrow: %zu bytes of LDS per workgroup (max_meas / window too large)", lds);
         return MHT_E_CAPACITY;
     }

@@ -240,6 +240,7 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {};
+    bool debug = false;      // MHT_GROW_DEBUG set at creation: phase stamps (with -DMHT_GROW_STAMPS), forced storage policies
     bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
     void layout(Arena& ar) {
@@ -278,7 +279,7 @@ struct Forest {
         best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
-        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32 + 8 * 4000);
+        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32 + 16 * 4000);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         w_root_scan = ar.take<int32_t>(Tcap); w_root_node = ar.take<int32_t>(Tcap); w_root_cnllr = ar.take<double>(Tcap); w_root_f32 = ar.take<uint8_t>(Tcap);
@@ -357,6 +358,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
     f->region_cap = (f->Ncap - f->Tcap) / FG_REGIONS;
     f->root_base = FG_REGIONS * f->region_cap;
+    f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
     f->pds = f->PD <= 8 ? 8 : 16;
 
     f->used_off = sizeof(ReportHeader);
@@ -541,6 +543,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
         g.used_bytes = f->used_bytes[s & 1];
         g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;
+        g.dbg = f->debug ? f->grow_dbg : nullptr;
         // one workgroup per slot of the table the scan runs on: the uncommitted one (targets before the last scan's
         // terminations) when the commit rides along, else the committed one
         rc = launch_fgrow(ctx, g, fused ? f->nT_ub_prev : f->nT_ub, fused ? &f->pending : nullptr);
@@ -790,7 +793,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "multi_list")) { src = f->multi_list; avail = T * 4; }
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
-    else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 8 * 4000) * 8; }
+    else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
     MHT_REQUIRE((size_t)bytes <= avail, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);

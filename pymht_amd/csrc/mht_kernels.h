@@ -93,6 +93,7 @@ struct FGrowArgs {
     DevStatus* status;             // this scan's status word: n_children is accumulated here
     const DevStatus* prev_status; const int32_t* sticky_overflow;
     int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
+    unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][8] wall-clock ticks at phase boundaries
 };
 
 struct ClusterArgs {
