@@ -51,7 +51,7 @@ def make_tracker(sc, device, **kw):
     from pymht_amd.pyTarget import Target
     from pymht_amd.models import pv
     trk = Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, device=device,
-                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2048"))), maxNodes=kw.pop("maxNodes", 1 << 17), maxMeasurements=1024, **kw)
+                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2048"))), maxNodes=kw.pop("maxNodes", int(os.environ.get("MHT_BENCH_MAXN", str(1 << 19)))), maxMeasurements=1024, **kw)
     trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
     return trk
 

@@ -24,7 +24,7 @@
 
 namespace mht {
 
-struct FLeaf {            // per-leaf results of phase 1 parked in LDS for the later phases (one chunk = FG_CAP leaves)
+struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in LDS for the later phases (one chunk = FG_CAP leaves)
     double xbar[4];
     double zhat[2];
     double cn, pd;
@@ -34,9 +34,10 @@ struct FLeaf {            // per-leaf results of phase 1 parked in LDS for the l
     int src;
     unsigned char flags, f32state, valid, pad;
 };
-static_assert(sizeof(FLeaf) % 8 == 0, "FLeaf must keep 8-byte alignment in LDS");
+static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesses");
 
 struct TInfo { int alive, first, cnt, depth, shift; };
+constexpr int FG_MAP = 1024;                          // entries of the child -> leaf table of a chunk (more children: binary search)
 constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128;     // targets per chain workgroup: wavefront = (target, hit/miss)
 typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
 
@@ -66,8 +67,10 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
 // per-phase wall-clock stamps (tools/grow_profile.py): compiled in only with -DMHT_GROW_STAMPS
 #ifdef MHT_GROW_STAMPS
 #define FG_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 8 + (k)] = wall_clock64(); } while (0)
+#define FG_STAMPX(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define FG_STAMP(k)
+#define FG_STAMPX(k)
 #endif
 
 // ---- chain workgroups: the covariance chain one scan ahead ---------------------------------------------------------------
@@ -120,8 +123,12 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
 }
 
 // ---- target workgroups ---------------------------------------------------------------------------------------------------
+// One child, one ROLE: the four wavefronts of the workgroup all walk the children (lane = child) and each does a quarter of
+// the work -- role 0: x[0..1], cumulativeNLLR; 1: x[2..3], P_d, parent; 2: measurement number, covariance column, flags, ILP
+// cost, used-measurement byte; 3: path and ancestor records.  (One wavefront doing everything was a ~1500-instruction serial
+// stream, 2.9 us; what every role needs -- which hit, z_tilde, NIS, the score -- is recomputed by each.)
 template <typename TS, typename ARGS>
-__device__ __forceinline__ void fg_emit_child(const ARGS& a, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
+__device__ __forceinline__ void fg_emit_child(const ARGS& a, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
                                               double rootc, int root_f32) {
     const size_t cap = a.cap;
@@ -141,61 +148,88 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FLeaf& g, int
         meas = j + 1;
         hit = 1;
     }
-    double cnl, inc;
-    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
-    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
+    FG_STAMPX(2);
+    if (role == 3 || role < 0) {
+        // path / ancestor records of the child: the parent's entries from the new root on (d + shift), its own at level `depth`
+        const int* pl = s_pp + l * a.pds;
+        const int* al = s_ap + l * a.pds;
+        int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * a.pds);
+        int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * a.pds);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = g.xbar[q];
-        inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
+        for (int q = 0; q < 4; ++q)
+            if (q * 4 < a.pds) {
+                int pe[4], ae[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = q * 4 + e;
+                    const int src_i = (d < depth) ? d + shift : 0;
+                    const int pvv = pl[src_i], avv = al[src_i];
+                    pe[e] = (d < depth) ? pvv : ((d == depth && meas > 0) ? a.cur_slot_base + meas - 1 : -1);
+                    ae[e] = (d < depth) ? avv : ((d == depth) ? c : -1);
+                }
+                po[q] = make_int4(pe[0], pe[1], pe[2], pe[3]);
+                ao[q] = make_int4(ae[0], ae[1], ae[2], ae[3]);
+            }
+        if (role == 3) return;
+    }
+    FG_STAMPX(3);
+    double cnl;
+    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
+    TS zt[2] = {(TS)0, (TS)0};
+    if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
+        const double inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
         cnl = g.cn + inc;
     } else {
         const float mx = zx[j], my = zy[j];
-        TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
-        TS zt[2], nis, xh[4];
+        TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, nis;
         gate_pair<TS>(zh, g.sinv, mx, my, (TS)a.model.eta2, zt, nis);
-        update_state<TS>(xb, g.K, zt, xh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = (double)xh[q];
         const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19
-        inc = (double)tinc;
         if (sizeof(TS) == 4 && (fl & F_SCORE_F32)) {          // float32 + float32 stays float32 (NumPy scalar rules)
             cnl = (double)((float)g.cn + (float)tinc);
             cfl |= F_SCORE_F32;
         } else {
-            cnl = g.cn + inc;
+            cnl = g.cn + (double)tinc;
         }
-        a.used_bytes[j] = 1;
     }
-    a.ocnllr[c] = cnl;
-    a.opd[c] = g.pd;
-    a.oparent[c] = g.src;
+    FG_STAMPX(4);
+    if (role < 0) {          // (all four state components)
+        double xo[4] = {g.xbar[0], g.xbar[1], g.xbar[2], g.xbar[3]};
+        if (k > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xo[i] = (double)update_component<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.ox[(size_t)i * cap + c] = xo[i];
+        a.ocnllr[c] = cnl;
+        a.opd[c] = g.pd;
+        a.oparent[c] = g.src;
+    } else if (role < 2) {          // two state components each
+        const int i0 = 2 * role, i1 = 2 * role + 1;
+        double x0 = g.xbar[i0], x1 = g.xbar[i1];
+        if (k > 0) {
+            x0 = (double)update_component<TS>((TS)g.xbar[i0], g.K[i0 * 2], g.K[i0 * 2 + 1], zt);
+            x1 = (double)update_component<TS>((TS)g.xbar[i1], g.K[i1 * 2], g.K[i1 * 2 + 1], zt);
+        }
+        a.ox[(size_t)i0 * cap + c] = x0;
+        a.ox[(size_t)i1 * cap + c] = x1;
+        if (role == 0) {
+            a.ocnllr[c] = cnl;
+        } else {
+            a.opd[c] = g.pd;
+            a.oparent[c] = g.src;
+        }
+        return;
+    }
+    FG_STAMPX(5);
     a.omeas[c] = meas;
     a.ocov[c] = 2 * g.src + hit;
     a.oflags[c] = cfl;
+    if (k > 0) a.used_bytes[j] = 1;
     // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and float32 / int stay
     // float32
     if ((cfl & F_SCORE_F32) && root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
     else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
-    // path / ancestor records of the child: the parent's entries from the new root on (d + shift), its own at level `depth`
-    const int* pl = s_pp + l * a.pds;
-    const int* al = s_ap + l * a.pds;
-    int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * a.pds);
-    int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * a.pds);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (q * 4 < a.pds) {
-            int pe[4], ae[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int d = q * 4 + e;
-                const int src_i = (d < depth) ? d + shift : 0;
-                const int pvv = pl[src_i], avv = al[src_i];
-                pe[e] = (d < depth) ? pvv : ((d == depth && meas > 0) ? a.cur_slot_base + meas - 1 : -1);
-                ae[e] = (d < depth) ? avv : ((d == depth) ? c : -1);
-            }
-            po[q] = make_int4(pe[0], pe[1], pe[2], pe[3]);
-            ao[q] = make_int4(ae[0], ae[1], ae[2], ae[3]);
-        }
+    FG_STAMPX(6);
 }
 
 __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned char* smem) {
@@ -212,6 +246,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [FG_CAP + 1]
     int* s_misc = s_pref + FG_CAP + 4;                                                      // [32]
     unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
+    unsigned char* s_map = reinterpret_cast<unsigned char*>(cand + Mpad);                   // [FG_MAP] leaf of the chunk's r-th child
     int& s_ncand = s_misc[0];
     int& s_base = s_misc[1];
     int& s_ebase = s_misc[2];
@@ -241,6 +276,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
         return;
     }
     if (!ti.alive) return;
+    FG_STAMP(1);
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -427,18 +463,26 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                 i1 += t0;
                 s_pref[lane] = i0 - m0;
                 if (lane + 64 < FG_CAP) s_pref[64 + lane] = i1 - m1;
+                for (int q = 0, p = i0 - m0; q < m0 && p < FG_MAP; ++q, ++p) s_map[p] = (unsigned char)lane;          // child -> leaf
+                for (int q = 0, p = i1 - m1; q < m1 && p < FG_MAP; ++q, ++p) s_map[p] = (unsigned char)(lane + 64);
                 const int chunk_total = __shfl(i1, 63);
                 if (lane == 63) { s_pref[FG_CAP] = chunk_total; s_total = chunk_total; }
                 if (first_emit && lane == 0) {
                     const int tot = two_pass ? total : chunk_total;
                     const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
-                    // one returning atomic per target: a block of this XCD's region of the node index space (next region if full)
-                    int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
+                    // the target's block of the node index space: its slot's own static block (no atomic: nothing downstream needs a
+                    // dense numbering, the index space is sized for 288 GB of HBM) or, for a target with more children than that, a
+                    // piece of this XCD's region of the overflow area (one returning atomic; next region if full)
                     int b = -1;
-                    for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
-                        const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)tot);
-                        if (old + (unsigned)tot <= (unsigned)a.region_cap) b = r * a.region_cap + (int)old;
-                        else r = (r + 1) & (FG_REGIONS - 1);
+                    if (tot <= a.block_cap) {
+                        b = t * a.block_cap;
+                    } else {
+                        int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
+                        for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
+                            const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)tot);
+                            if (old + (unsigned)tot <= (unsigned)a.region_cap) b = a.over_base + r * a.region_cap + (int)old;
+                            else r = (r + 1) & (FG_REGIONS - 1);
+                        }
                     }
                     if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
                     s_base = b;
@@ -470,7 +514,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
             if (first_emit) {
                 base = s_base;
                 if (base < 0) return;
-                if (wave == 3) {      // edge list: (target << 16 | node) for every set bit
+                if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
                     const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     const int seg = blockIdx.x & (EDGE_SEGS - 1);
                     int eb = s_ebase;
@@ -495,19 +539,36 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                     }
                 }
             }
-            // ---- phase 4: one thread per child, children of the chunk at base + run .. ---------------------------------------------
+            // ---- phase 4: lane = child, wavefront = role; children of the chunk at base + run .. --------------------------------------
+            FG_STAMP(6);
+            // ---- phase 4: one thread per child; children of the chunk at base + run .. ------------------------------------------------
             {
                 const int ctot = s_pref[FG_CAP];
                 for (int r = tid; r < ctot; r += FG_THREADS) {
-                    int lo = 0, hi = FG_CAP;                 // leaf of child r: largest l with s_pref[l] <= r
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= r) lo = mid; else hi = mid;
+                    int l;
+                    if (r < FG_MAP) {
+                        l = s_map[r];                        // child -> leaf table written with the counts
+                    } else {                                 // (more children than the table holds: search the prefix)
+                        int lo = 0, hi = FG_CAP;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_pref[mid] <= r) lo = mid; else hi = mid;
+                        }
+                        l = lo;
                     }
-                    const int l = lo, k = r - s_pref[l], c = base + run + r;
-                    const FLeaf& g = lg[l];
-                    if (g.f32state) fg_emit_child<float>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double>(a, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    const int k = r - s_pref[l], c = base + run + r;
+                    // the leaf's record and the child's path / ancestor sources in ONE batch of wide LDS reads (field-by-field reads
+                    // behind the branches below were ~40 dependent LDS round trips per child: 2 us)
+                    FG_STAMPX(1);
+                    FLeaf g;
+                    {
+                        const uint4* srcq = reinterpret_cast<const uint4*>(lg + l);
+                        uint4* dstq = reinterpret_cast<uint4*>(&g);
+#pragma unroll
+                        for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
+                    }
+                    if (g.f32state) fg_emit_child<float>(a, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double>(a, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                 }
                 run += ctot;
             }
@@ -517,7 +578,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     FG_STAMP(7);
 }
 
-__global__ __launch_bounds__(FG_THREADS, 4) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = blockIdx.x;
     if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
@@ -530,7 +591,7 @@ __global__ __launch_bounds__(FG_THREADS, 4) void fgrow_kernel(const FGrowArgs a,
 
 static inline size_t fgrow_lds_bytes(int W, int pds, int AW) {
     size_t b = (size_t)2 * W * 64 * 4 + (size_t)FG_CAP * sizeof(FLeaf) + (size_t)2 * pds * FG_CAP * 4 + (size_t)FG_CAP * W * 8 + (size_t)AW * 8 +
-               (size_t)(FG_CAP + 4) * 4 + 128 + (size_t)W * 64 * 2;
+               (size_t)(FG_CAP + 4) * 4 + 128 + (size_t)W * 64 * 2 + FG_MAP;
     if (b < 256) b = 256;      // the commit workgroup keeps its scan partials here
     return (b + 15) & ~(size_t)15;
 }

@@ -216,7 +216,7 @@ struct Forest {
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
     int pds = 8;                      // ints per path / ancestor record (8 or 16)
     float4* G[2];                     // gain tables by scan parity: row = covariance column (fgrow_kernel)
-    unsigned* alloc; int region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
+    unsigned* alloc; int block_cap = 0, over_base = 0, region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
     TTable tab[2];
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
@@ -356,8 +356,17 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->capc = 2 * f->Ncap + f->Tcap;
     f->Ecap = 4 * f->Ncap;              // edges the clustering kernel can take beyond its LDS list (spill arrays)
     f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
-    f->region_cap = (f->Ncap - f->Tcap) / FG_REGIONS;
-    f->root_base = FG_REGIONS * f->region_cap;
+    {   // node index space of a layer: [static block per target slot | overflow area in FG_REGIONS regions | roots born into the layer]
+        const long long usable = (long long)f->Ncap - f->Tcap;
+        long long bc = usable * 3 / 4 / f->Tcap;
+        if (bc > 256) bc = 256;
+        if (bc < 16) bc = 0;          // (tiny pools: everything through the overflow counters)
+        if (const char* e = getenv("MHT_BLOCK_CAP")) bc = atoi(e) < bc ? atoi(e) : bc;      // development: 0 = no static blocks
+        f->block_cap = (int)bc;
+        f->over_base = f->Tcap * f->block_cap;
+        f->region_cap = (int)((usable - f->over_base) / FG_REGIONS);
+        f->root_base = f->over_base + FG_REGIONS * f->region_cap;
+    }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
     f->pds = f->PD <= 8 ? 8 : 16;
 
@@ -539,7 +548,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
         g.tchild = f->tchild; g.tcend = f->tcend;
         g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
-        g.alloc = f->alloc; g.region_cap = f->region_cap;
+        g.alloc = f->alloc; g.block_cap = f->block_cap; g.over_base = f->over_base; g.region_cap = f->region_cap;
         g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
         g.used_bytes = f->used_bytes[s & 1];
         g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;

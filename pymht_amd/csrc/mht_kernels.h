@@ -87,7 +87,8 @@ struct FGrowArgs {
     int32_t* tchild; int32_t* tcend;      // [T] children of (compacted) target t: tchild[t] .. tcend[t]-1
     int PD; int Nwin; int cur_slot_base; int AW;
     unsigned* alloc;               // [FG_REGIONS][32] child counter of every region (a cache line each), zero at launch
-    int region_cap;                // node indices per region; region r = [r * region_cap, (r+1) * region_cap)
+    int block_cap;                 // node indices of the static block of every target slot: slot t owns [t * block_cap, (t+1) * block_cap)
+    int over_base, region_cap;     // overflow area behind the static blocks: region r = over_base + [r * region_cap, (r+1) * region_cap)
     unsigned* edges; int32_t* edge_count; int edge_cap;
     unsigned char* used_bytes;
     DevStatus* status;             // this scan's status word: n_children is accumulated here

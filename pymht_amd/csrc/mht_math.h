@@ -191,15 +191,17 @@ MHT_HD bool gate_pair(const TS* z_hat, const float* S_inv, float zx, float zy, T
     return nis <= eta2;
 }
 
-// kalman.py:43-52  x_hat = x_bar + K z_tilde
+// kalman.py:43-52  x_hat = x_bar + K z_tilde   (one component / all four)
+template <typename TS>
+MHT_HD TS update_component(TS x_bar_i, float k0, float k1, const TS* zt) {
+    TS acc = (TS)k0 * zt[0];
+    acc = fmaT((TS)k1, zt[1], acc);
+    return x_bar_i + acc;
+}
 template <typename TS>
 MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        TS acc = (TS)K[i * 2] * zt[0];
-        acc = fmaT((TS)K[i * 2 + 1], zt[1], acc);
-        x_hat[i] = x_bar[i] + acc;
-    }
+    for (int i = 0; i < 4; ++i) x_hat[i] = update_component<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt);
 }
 
 // Node flags (one byte per hypothesis)

@@ -99,7 +99,7 @@ class Tracker():
         self._model = make_model(self.A, self.Q, self.C, self.R_RADAR, self.eta2, self.lambda_ex, self.default_P_d)
         cfg = _lib.MhtForestConfig()
         cfg.max_targets = int(kwargs.get('maxTargets', 2048))
-        cfg.max_nodes = int(kwargs.get('maxNodes', 1 << 17))
+        cfg.max_nodes = int(kwargs.get('maxNodes', 1 << 19))
         cfg.max_meas = int(kwargs.get('maxMeasurements', 2048))
         cfg.n_scan = int(N)
         cfg.blp_max_iter = int(kwargs.get('blpMaxIter', 200))

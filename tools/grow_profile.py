@@ -10,8 +10,8 @@ from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 sc = make_config('cfg3', seed=5446, n_scans=14)
 trk = bench.make_tracker(sc, 0, maxTargets=int(os.environ.get("MHT_PROF_MAXT", "640")))
-names = ['rt1+phase1', 'cands', 'pairs', 'counts+alloc', 'emit']
-COLS = [0, 2, 3, 4, 5, 7]
+names = ['rt1', 'phase1', 'cands', 'pairs', 'counts+alloc', 'edges(w1)', 'emit']
+COLS = [0, 1, 2, 3, 4, 5, 6, 7]
 raw = len(sys.argv) > 1 and sys.argv[1] == 'raw'      # raw: step through the C ABI without reports -> deferred commits (replay mode)
 for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     if raw and k >= 10:
@@ -33,6 +33,11 @@ for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     d = np.diff(rel[:, COLS], axis=1)
     print('scan %d: %d target workgroups, span (first start -> last end) %.1f us; start mean %.1f max %.1f' % (k, len(main), rel[:, 7].max(), rel[:, 0].mean(), rel[:, 0].max()))
     print('   per-phase mean/max us: ' + '  '.join('%s %.1f/%.1f' % (n, d[:, q].mean(), d[:, q].max()) for q, n in enumerate(names)))
+    wx = ts[:, 8:16]
+    wx = wx[(wx[:, 6] > 0) & (wx[:, 1] > 0) & (np.abs(wx[:, 1] - np.median(main[:, 0])) < 5000)]
+    if len(wx):
+        dx = np.diff(wx[:, 1:7], axis=1) / 100.0
+        print('   emit detail (thread 0): ' + '  '.join('%s %.2f/%.2f' % (nm, dx[:, q].mean(), dx[:, q].max()) for q, nm in enumerate(['ldsbatch+decode', 'path recs', 'score', 'x stores', 'rest'])))
     if len(chain):
         rc = (chain - t0) / 100.0
         print('   %d chain workgroups: start mean %.1f max %.1f, end mean %.1f max %.1f, duration mean %.1f max %.1f' % (
