@@ -45,6 +45,8 @@ struct CommitArgs {
     int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
     unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
     ReportHeader* hdr; mht_target_report* rec;
+    unsigned long long* hint;      // host-mapped word or null: {scan, targets alive after it}, so that the host can size the next grids
+                                   // without fetching a report
 };
 
 // Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
@@ -181,6 +183,7 @@ __device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
         a.cnt->nT = nAlive;
         a.cnt->nTv[a.vnext] = nAlive;
         a.cnt->L = Lnext;
+        if (a.hint) __hip_atomic_store(a.hint, ((unsigned long long)(unsigned)a.scan << 32) | (unsigned)nAlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a

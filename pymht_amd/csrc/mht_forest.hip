@@ -240,6 +240,22 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {};
+    // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
+    // since that scan this bounds the current target count (targets only disappear otherwise)
+    unsigned long long* hint_host = nullptr; unsigned long long* hint_dev = nullptr;
+    long long births_cum = 0; long long births_issue[64] = {};      // births issued so far / before step s was issued (ring by s % 64)
+    int targets_ub(int s_table) const {      // upper bound of the targets in the table scan `s_table` runs on
+        int ub = nT_ub;
+        if (hint_host) {
+            const unsigned long long h = *reinterpret_cast<volatile unsigned long long*>(hint_host);
+            const int k = (int)(h >> 32), na = (int)(h & 0xffffffffu);
+            if (k >= 1 && k < s_table && s_table - k < 60) {
+                const long long b = na + (births_issue[s_table % 64] - births_issue[k % 64]);
+                if (b < ub) ub = (int)b;
+            }
+        }
+        return ub;
+    }
     bool debug = false;      // MHT_GROW_DEBUG set at creation: phase stamps (with -DMHT_GROW_STAMPS), forced storage policies
     bool timing = false; int timed_steps = 0; int ev_slot = 0; hipEvent_t (*evp)[5] = nullptr;   // pool of EV_POOL event sets
 
@@ -295,6 +311,7 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->arena.base) (void)hipFree(f->arena.base);
     if (f->report_host) (void)hipHostFree(f->report_host);
     if (f->z_host) (void)hipHostFree(f->z_host);
+    if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->evp) {
@@ -407,6 +424,9 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host), f->report_bytes, hipHostMallocDefault));
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
     memset(f->report_host, 0, f->report_bytes);
+    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
+    memset(f->hint_host, 0, 64);
+    MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
     // cluster-kernel LDS budget check up front
     if (cluster_elds(f->Tcap, f->n_mnodes) < f->Tcap || cluster_elds(f->Tcap, f->n_mnodes) < 1024) {
         set_error("mht_forest_create: max_targets=%d and (n_scan+2) x max_meas = %d measurement nodes do not fit the clustering "
@@ -452,6 +472,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
     f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
     f->births_since_step += n;
+    f->births_cum += n;
     return MHT_OK;
 }
 
@@ -502,8 +523,9 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     hipStream_t st = ctx->stream;
     const int s = ++f->scan;
     const int cb = s & 1, nb = (s + 1) & 1;
+    f->births_issue[s % 64] = f->births_cum;
     f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
-    f->nT_ub_step = f->nT_ub;
+    f->nT_ub_step = f->targets_ub(s);
     f->births_since_step = 0;
     const int W = (M + 63) / 64;
     f->last_M = M;
@@ -555,7 +577,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         g.dbg = f->debug ? f->grow_dbg : nullptr;
         // one workgroup per slot of the table the scan runs on: the uncommitted one (targets before the last scan's
         // terminations) when the commit rides along, else the committed one
-        rc = launch_fgrow(ctx, g, fused ? f->nT_ub_prev : f->nT_ub, fused ? &f->pending : nullptr);
+        rc = launch_fgrow(ctx, g, fused ? f->nT_ub_prev : f->nT_ub_step, fused ? &f->pending : nullptr);
         if (rc) return rc;
     }
     f->commit_pending = false;
@@ -594,7 +616,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
-    int grid = f->nT_ub / 2 + 8;
+    int grid = f->nT_ub_step / 2 + 8;
     if (grid > 1024) grid = 1024;
     rc = launch_blp(ctx, b, grid);
     if (rc) return rc;
@@ -609,7 +631,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     p.cnt = f->cnt; p.status = st_cur;
     p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
     p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
-    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
+    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev); p.hint = f->hint_dev;
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
     // deferred: workgroup 0 of the next scan's grow_kernel runs it, unless somebody needs the committed state before that
     // (flush_commit).  One launch and one kernel boundary less per scan; with timing on, its time shows up in the next
