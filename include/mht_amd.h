@@ -225,6 +225,20 @@ int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t by
 int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                      double* x, double* cnllr, float* P, int32_t* n_out);
 
+/* ---- a group of independent sectors on one device (BASELINE config 4: four sensor sectors = four independent Tracker
+ * instances, pymht/tracker.py:39-137; nothing in tracker.py:162-307 couples two Tracker objects) -------------------------------
+ * The members' forests step TOGETHER with one launch per stage (grow, cluster, ILP) for the whole group: a single sector is a
+ * chain of dependent round trips that leaves most of the GPU idle, S sectors cost about one such chain.  Results are exactly
+ * those of stepping every member with mht_forest_step (tests/test_sectors_gpu.py).
+ *   ctxs   n contexts (1 <= n <= 32) that own a forest each; same device, same stream, same forest configuration
+ *   z      host array of n device pointers, z[i] = member i's scan, dev (M[i],2) float32
+ *   M      host array of n measurement counts
+ * After a group step every per-forest call (mht_forest_report, _add_targets*, _leaves, ...) works on the members as usual. */
+typedef struct mht_group mht_group;
+int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs);
+int mht_group_step(mht_group* g, const float* const* z, const int32_t* M);
+int mht_group_destroy(mht_group* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,9 @@ def _declare(lib):
         "mht_forest_debug_read": [vp, C.c_char_p, vp, i64],
         "mht_forest_set_timing": [vp, i32],
         "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5), C.POINTER(i32)],
+        "mht_group_create": [C.POINTER(vp), i32, C.POINTER(vp)],
+        "mht_group_step": [vp, C.POINTER(vp), C.POINTER(i32)],
+        "mht_group_destroy": [vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

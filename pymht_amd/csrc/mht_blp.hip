@@ -978,7 +978,7 @@ constexpr int KEY_DEAD = -1, KEY_ALL = -2;
 // Returns the survival key of the target: KEY_DEAD (terminated), KEY_ALL (alive, root stays) or the node index of the
 // new root (children whose ancestor table holds it at level j-1 survive).
 __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, const TgtPre& p, bool store) {
-    const int kc = a.scan % a.R;
+    const int kc = a.kc;
     const double cn = a.cnllr[s];
     const uint8_t fl = a.flags[s];
     const int smeas = ring_ptr(a.ring0.meas, a.ring_stride, kc)[s];
@@ -1307,8 +1307,7 @@ constexpr size_t BLP_LDS_BYTES = (size_t)BLP_UW * 8 + RED_SLOT + (size_t)BLP_UW 
                                  (size_t)L_MAXR * 8 + 7 * (size_t)L_KPAD * 8 + 2 * (size_t)L_MAXR * 4 + 6 * (size_t)L_KPAD * 4 +
                                  (size_t)L_MAXH * 2;
 
-__global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [BLP_UW]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to RED_SLOT
     if (a.status && a.status->overflow) return;
@@ -1342,6 +1341,29 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
             sweep_survivors(a, t, pre.j, cb, ce, key, va0, lane);
         }
     }
+}
+
+__global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    blp_body(a, lds);
+}
+// a group of sectors per launch: blockIdx.y = sector, its argument block is read from HBM (written once, at group creation)
+__global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    BlpArgs a;
+    load_args(a, static_cast<const BlpArgs*>(av.p[blockIdx.y]));
+    blp_body(a, lds);
+}
+
+int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x) {
+    static bool attr = false;
+    if (!attr) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLP_LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL(blp_batch_kernel, dim3(grid_x, n_sectors), dim3(BLP_THREADS), BLP_LDS_BYTES, ctx->stream, av);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
 }
 
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {

@@ -28,8 +28,7 @@ __device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArg
     return ((unsigned)a.edge_t[e - a.elds] << 16) | (unsigned)a.edge_m[e - a.elds];
 }
 
-__global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char* smem) {
     int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]  union-find parent of a target
     int* lab = tlabel + a.Tcap;                          // [Tcap]  final label = smallest target of the component
     int* cnt = lab + a.Tcap;                             // [Tcap]  by head: members of its cluster
@@ -357,6 +356,18 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     }
 }
 
+__global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cluster_body(a, smem);
+}
+// a group of sectors per launch: blockIdx.y = sector, its argument block is read from HBM (two variants by scan parity)
+__global__ __launch_bounds__(CL_THREADS) void cluster_batch_kernel(const PBatch av) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ClusterArgs a;
+    load_args(a, static_cast<const ClusterArgs*>(av.p[blockIdx.y]));
+    cluster_body(a, smem);
+}
+
 constexpr size_t CL_LDS_BUDGET = 150 * 1024;
 // LDS carve for a given table size: the pending-pair list gets a quarter of what the tables leave (at most CL_PEND_MAX), the
 // edge list the rest (at most CL_ELDS_MAX); elds < Tcap = does not fit
@@ -397,6 +408,21 @@ int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in) {
         attr_bytes = lds;
     }
     hipLaunchKernelGGL(cluster_kernel, dim3(1), dim3(CL_THREADS), lds, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+// the LDS carve (elds, pcap) of a forest's argument block, as launch_cluster sets it
+void cluster_prepare(ClusterArgs& a) { cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap); }
+
+int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes) {
+    const size_t lds = cluster_lds_bytes(Tcap, n_mnodes);
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && lds > attr_bytes) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(cluster_batch_kernel, dim3(1, n_sectors), dim3(CL_THREADS), lds, ctx->stream, av);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

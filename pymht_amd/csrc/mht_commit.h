@@ -34,16 +34,18 @@ struct ReportHeader {     // device image of mht_scan_report up to the host poin
         blp_iters_max, error, used_words, pad[3];
 };
 
+struct CommitDyn { int scan, M, W; };      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
+
 struct CommitArgs {
     TTable cur, nxt;
     const int32_t* sel; const int32_t* t_status; const int32_t* t_jdrop; const int32_t* t_count; const int32_t* t_firstsurv;
     const int32_t* w_root_scan; const int32_t* w_root_node; const double* w_root_cnllr; const uint8_t* w_root_f32;
-    int R; int scan; int cap; int Tcap;
+    int R; int cap; int Tcap;      // (the scan number and the size of its scan, M / W = ceil(M/64), travel separately: CommitDyn)
     int vnext;            // version index of the table this commit produces: (scan + 1) & 1
     int32_t* new_index;
     FCounts* cnt; DevStatus* status;
     int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
-    unsigned char* used_bytes; unsigned long long* used_words; int M; int W;
+    unsigned char* used_bytes; unsigned long long* used_words;
     ReportHeader* hdr; mht_target_report* rec;
     unsigned long long* hint;      // host-mapped word or null: {scan, targets alive after it}, so that the host can size the next grids
                                    // without fetching a report
@@ -53,8 +55,8 @@ struct CommitArgs {
 // roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
 // NT = threads of the workgroup; `sm` = 2 * NT / 64 + 8 ints of LDS scratch (handed in by the kernel: a static __shared__
 // here would shift the dynamic LDS base of the kernels this is inlined into off its 16-byte alignment).
-template <int NT>
-__device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
+template <int NT, typename CARGS>
+__device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn, int* sm) {
     constexpr int PRUNE_THREADS = NT;
     int* s_scan = sm;
     int* s_scan2 = sm + NT / 64;
@@ -77,7 +79,7 @@ __device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
     if (s_over || c_over) {        // void scan: report the error, leave the forest alone (it must be recreated)
         if (tid == 0) {
             ReportHeader& h = *a.hdr;
-            h.scan = a.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[nT];
+            h.scan = dyn.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[nT];
             h.n_children = nCh; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
             h.blp_iters_max = 0; h.error = (s_over == 2) ? MHT_E_HIP : MHT_E_CAPACITY; h.used_words = 0;
             a.cnt->overflow = 1;
@@ -154,18 +156,18 @@ __device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
         if (st) atomicMax(&s_itmax, a.cl_iters[c]);
     }
     // used-measurement bytes -> bit mask of the report; bytes cleared for the next scan
-    for (int base = 0; base < a.W * 64; base += PRUNE_THREADS) {
+    for (int base = 0; base < dyn.W * 64; base += PRUNE_THREADS) {
         const int jm = base + tid;
-        const int u = (jm < a.M) ? a.used_bytes[jm] : 0;
+        const int u = (jm < dyn.M) ? a.used_bytes[jm] : 0;
         if (u) a.used_bytes[jm] = 0;
         const unsigned long long bits = __ballot(u != 0);
-        if ((tid & 63) == 0 && jm < a.W * 64) a.used_words[jm >> 6] = bits;
+        if ((tid & 63) == 0 && jm < dyn.W * 64) a.used_words[jm >> 6] = bits;
     }
     __syncthreads();
     if (tid == 0) {
         a.nxt.leaf_off[nAlive] = Lnext;
         ReportHeader& h = *a.hdr;
-        h.scan = a.scan;
+        h.scan = dyn.scan;
         h.n_targets = nT;
         h.n_alive = nAlive;
         h.n_leaves_in = L_in;
@@ -177,13 +179,13 @@ __device__ __forceinline__ void commit_body(const CommitArgs& a, int* sm) {
         h.n_limit = s_limit;
         h.blp_iters_max = s_itmax;
         h.error = e_over ? MHT_E_CAPACITY : 0;
-        h.used_words = a.W;
+        h.used_words = dyn.W;
         a.cnt->L_in = L_in;
         a.cnt->n_children = nCh;
         a.cnt->nT = nAlive;
         a.cnt->nTv[a.vnext] = nAlive;
         a.cnt->L = Lnext;
-        if (a.hint) __hip_atomic_store(a.hint, ((unsigned long long)(unsigned)a.scan << 32) | (unsigned)nAlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.hint) __hip_atomic_store(a.hint, ((unsigned long long)(unsigned)dyn.scan << 32) | (unsigned)nAlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a

@@ -69,6 +69,17 @@ struct DevStatus {
 
 struct Forest;
 
+// Copy an argument block that lives in HBM (written once by the host) into registers through the CONSTANT address space: scalar
+// loads, shared by the whole wavefront (batched launches: blockIdx.y picks the sector's block).
+template <typename T>
+__device__ __forceinline__ void load_args(T& dst, const T* src) {
+    static_assert(sizeof(T) % 4 == 0, "argument blocks are copied dword-wise");
+    const __attribute__((address_space(4))) unsigned* s = (const __attribute__((address_space(4))) unsigned*)src;
+    unsigned* d = reinterpret_cast<unsigned*>(&dst);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = s[i];
+}
+
 }  // namespace mht
 
 struct mht_ctx {

@@ -43,10 +43,11 @@ typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the ke
 
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
 // loads go out unconditionally (one round trip), dead or out-of-range slots are masked afterwards
-__device__ __forceinline__ TInfo target_info(const FGrowArgs& a, int t, int nT) {
+template <typename ARGS>
+__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT) {
     TInfo r;
     const int tc = (t < a.Tcap) ? t : 0;
-    if (a.fused) {      // the previous scan's commit has not run: its per-target results, indexed by old slot
+    if (d.fused) {      // the previous scan's commit has not run: its per-target results, indexed by old slot
         const int st = a.p_status[tc], cnt = a.p_count[tc], j = a.p_jdrop[tc], first = a.p_firstsurv[tc], dep = a.p_depth[tc];
         r.alive = (t < nT) && st == 0;
         r.first = first; r.cnt = cnt; r.depth = dep + 1 - j; r.shift = j;
@@ -66,8 +67,8 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
 
 // per-phase wall-clock stamps (tools/grow_profile.py): compiled in only with -DMHT_GROW_STAMPS
 #ifdef MHT_GROW_STAMPS
-#define FG_STAMP(k) do { if (a.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 8 + (k)] = wall_clock64(); } while (0)
-#define FG_STAMPX(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 8 + (k)] = wall_clock64(); } while (0)
+#define FG_STAMP(k) do { if (d.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < 3900) d.dbg[32 + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 8 + (k)] = wall_clock64(); } while (0)
+#define FG_STAMPX(k) do { if (d.dbg && threadIdx.x == 0 && blockIdx.x < 3900) d.dbg[32 + (size_t)blockIdx.x * 16 + 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define FG_STAMP(k)
 #define FG_STAMPX(k)
@@ -88,13 +89,14 @@ __device__ __forceinline__ void gains_record(const Model& m, const CovChain& c, 
     g[3] = make_float4(lnc, rx, ry, 0.f);
 }
 
-__device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
+template <typename ARGS>
+__device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
     // wavefront = (target, hit/miss), lane = leaf: two targets per workgroup
     const int t = cb * FG_CHAIN_TARGETS + (wave >> 1), h = wave & 1;
-    const TInfo ti = target_info(a, t, nT);
+    const TInfo ti = target_info(a, d, t, nT);
     if (po || so) return;
     FG_STAMP(0);
     for (int l = lane; l < ti.cnt; l += 64) {
@@ -104,8 +106,16 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
         float P[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc + covc];
+        Model mdl;          // (uniform registers)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
+        mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
         CovChain c;
-        cov_chain(a.model, P, c, true);
+        cov_chain(mdl, P, c, true);
         float Pc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) Pc[e] = h ? c.P_hat[e] : c.P_bar[e];
@@ -113,9 +123,9 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) a.oP[(size_t)e * a.capc + col] = Pc[e];
         CovChain g;
-        cov_chain(a.model, Pc, g, false);
+        cov_chain(mdl, Pc, g, false);
         float4 rec[4];
-        gains_record(a.model, g, pd, rec);
+        gains_record(mdl, g, pd, rec);
 #pragma unroll
         for (int q = 0; q < 4; ++q) a.G_out[(size_t)col * 4 + q] = rec[q];
     }
@@ -128,7 +138,7 @@ __device__ __forceinline__ void chain_part(const FGrowArgs& a, int cb) {
 // cost, used-measurement byte; 3: path and ancestor records.  (One wavefront doing everything was a ~1500-instruction serial
 // stream, 2.9 us; what every role needs -- which hit, z_tilde, NIS, the score -- is recomputed by each.)
 template <typename TS, typename ARGS>
-__device__ __forceinline__ void fg_emit_child(const ARGS& a, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
+__device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
                                               double rootc, int root_f32) {
     const size_t cap = a.cap;
@@ -232,9 +242,10 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, int role, const FLe
     FG_STAMPX(6);
 }
 
-__device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned char* smem) {
+__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem) {
+    const auto& a = *ap0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = a.M, W = a.W, Mpad = W * 64, AW = a.AW;
+    const int M = d.M, W = d.W, Mpad = W * 64, AW = a.AW;
     // LDS carve (every block a multiple of 16 bytes)
     float* zx = reinterpret_cast<float*>(smem);
     float* zy = zx + Mpad;
@@ -258,14 +269,14 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
     const int nT = a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
-    const TInfo ti = target_info(a, t, nT);
+    const TInfo ti = target_info(a, d, t, nT);
     const int tc = (t < a.Tcap) ? t : 0;
     const double rootc = a.t_root_cnllr[tc];
     const int root_f32 = a.t_root_f32[tc];
     int acc = 0;
-    if (a.fused)          // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
+    if (d.fused)          // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
         for (int i = tid; i < t; i += FG_THREADS) acc += (a.p_status[i] == 0) ? 1 : 0;
-    const float2* z2 = reinterpret_cast<const float2*>(a.z);
+    const float2* z2 = reinterpret_cast<const float2*>(d.z);
     for (int j = tid; j < Mpad; j += FG_THREADS) {
         const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
         zx[j] = v.x;
@@ -291,12 +302,12 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     int total = 0, run = 0, base = 0;
     for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
         for (int c0 = 0; c0 < cnt; c0 += FG_CAP) {
-            // (the loops exist for targets with more than FG_CAP leaves only.  The kernel arguments are re-read through an opaque
-            // kernarg pointer in every iteration: otherwise every address and every uniform predicate of the unrolled body is
+            // (the loops exist for targets with more than FG_CAP leaves only.  The argument block is re-read through an opaque
+            // pointer in every iteration: otherwise every address and every uniform predicate of the unrolled body is
             // hoisted in front of the loops and held in registers across them -- +100 VGPRs, ~400 spilled SGPRs)
             int depth = __builtin_amdgcn_readfirstlane(depth0), shift = __builtin_amdgcn_readfirstlane(shift0);
             asm volatile("" : "+s"(depth), "+s"(shift));
-            KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // (FGrowArgs is the first kernel argument)
+            KArgs ap = ap0;
             asm volatile("" : "+s"(ap));
             const auto& a = *ap;
             const int n = (cnt - c0 < FG_CAP) ? cnt - c0 : FG_CAP;
@@ -469,7 +480,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                 if (lane == 63) { s_pref[FG_CAP] = chunk_total; s_total = chunk_total; }
                 if (first_emit && lane == 0) {
                     const int tot = two_pass ? total : chunk_total;
-                    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                    const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     // the target's block of the node index space: its slot's own static block (no atomic: nothing downstream needs a
                     // dense numbering, the index space is sized for 288 GB of HBM) or, for a target with more children than that, a
                     // piece of this XCD's region of the overflow area (one returning atomic; next region if full)
@@ -515,7 +526,7 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
                 base = s_base;
                 if (base < 0) return;
                 if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
-                    const int pos = a.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                    const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     const int seg = blockIdx.x & (EDGE_SEGS - 1);
                     int eb = s_ebase;
                     for (int w0 = 0; w0 < AW; w0 += 64) {
@@ -567,8 +578,8 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (g.f32state) fg_emit_child<float>(a, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double>(a, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    if (g.f32state) fg_emit_child<float>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                 }
                 run += ctot;
             }
@@ -578,31 +589,42 @@ __device__ __forceinline__ void target_part(const FGrowArgs& a, int t, unsigned 
     FG_STAMP(7);
 }
 
-__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <typename CARGS>
+__device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
-    if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
-        if (bid == 0) { commit_body<FG_THREADS>(cm, reinterpret_cast<int*>(smem)); return; }
+    if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
+        if (bid == 0) { commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, reinterpret_cast<int*>(smem)); return; }
         bid -= 1;
     }
-    if (bid >= a.n_main) { chain_part(a, bid - a.n_main); return; }
-    target_part(a, bid, smem);
+    if (bid >= d.n_main) { chain_part(*ap, d, bid - d.n_main); return; }
+    target_part(ap, d, bid, smem);
 }
 
-static inline size_t fgrow_lds_bytes(int W, int pds, int AW) {
+// one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fgrow_body((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+}
+
+// a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
+// repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
+typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_batch_kernel(const FBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int y = blockIdx.y;
+    const FDyn d = b.d[y];
+    if ((int)blockIdx.x >= d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS) return;
+    fgrow_body((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
+}
+
+size_t fgrow_lds_bytes(int W, int pds, int AW) {
     size_t b = (size_t)2 * W * 64 * 4 + (size_t)FG_CAP * sizeof(FLeaf) + (size_t)2 * pds * FG_CAP * 4 + (size_t)FG_CAP * W * 8 + (size_t)AW * 8 +
                (size_t)(FG_CAP + 4) * 4 + 128 + (size_t)W * 64 * 2 + FG_MAP;
     if (b < 256) b = 256;      // the commit workgroup keeps its scan partials here
     return (b + 15) & ~(size_t)15;
 }
 
-int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs* commit) {
-    a.fused = commit ? 1 : 0;
-    int n_main = n_targets_ub < 1 ? 1 : n_targets_ub;
-    if (n_main > a.Tcap) n_main = a.Tcap;
-    a.n_main = n_main;
-    const int n_chain = (n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
-    const size_t lds = fgrow_lds_bytes(a.W, a.pds, a.AW);
+static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
     if (lds > 150 * 1024) {
         set_error("fgrow: %zu bytes of LDS per workgroup (max_meas / window too large)", lds);
         return MHT_E_CAPACITY;
@@ -610,11 +632,38 @@ int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs*
     size_t& attr_bytes = ctx->lds_attr_fgrow;
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
-    hipLaunchKernelGGL(fgrow_kernel, dim3(a.fused + n_main + n_chain), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{});
+    return MHT_OK;
+}
+
+// grid of one sector: [commit] + one workgroup per target slot + chain workgroups
+static inline int fgrow_grid(const FDyn& d) { return d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS; }
+
+void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused) {
+    d.fused = fused ? 1 : 0;
+    int n_main = n_targets_ub < 1 ? 1 : n_targets_ub;
+    if (n_main > Tcap) n_main = Tcap;
+    d.n_main = n_main;
+}
+
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit) {
+    fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
+    const size_t lds = fgrow_lds_bytes(d.W, a.pds, a.AW);
+    { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(fgrow_kernel, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
+
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds) {
+    { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(fgrow_batch_kernel, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+int fgrow_grid_of(const FDyn& d) { return fgrow_grid(d); }
 
 }  // namespace mht

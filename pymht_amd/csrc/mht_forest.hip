@@ -31,9 +31,9 @@ constexpr int EV_POOL = 64;
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
 
-__global__ __launch_bounds__(COMMIT_THREADS) void commit_kernel(const CommitArgs a) {
+__global__ __launch_bounds__(COMMIT_THREADS) void commit_kernel(const CommitArgs a, const CommitDyn dyn) {
     __shared__ int s_commit[2 * (COMMIT_THREADS / 64) + 8];
-    commit_body<COMMIT_THREADS>(a, s_commit);
+    commit_body<COMMIT_THREADS>(a, dyn, s_commit);
 }
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
@@ -239,7 +239,8 @@ struct Forest {
     int births_since_step = 0;   // candidates added after the last launched scan (they are not in its report)
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
-    bool commit_pending = false; CommitArgs pending = {};
+    bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
+    bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
     // since that scan this bounds the current target count (targets only disappear otherwise)
     unsigned long long* hint_host = nullptr; unsigned long long* hint_dev = nullptr;
@@ -335,7 +336,7 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
 // runs the pending commit now (see Forest::commit_pending)
 static int flush_commit(mht_ctx* ctx, Forest* f) {
     if (!f->commit_pending) return MHT_OK;
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending);
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending, f->pending_dyn);
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
     return MHT_OK;
@@ -385,6 +386,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
         f->root_base = f->over_base + FG_REGIONS * f->region_cap;
     }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
+    { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     f->pds = f->PD <= 8 ? 8 : 16;
 
     f->used_off = sizeof(ReportHeader);
@@ -510,91 +512,62 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     return MHT_OK;
 }
 
-extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
-    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
-    Forest* f = ctx->forest;
-    MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
-    MHT_REQUIRE(z || M == 0, "mht_forest_step: z is null");
-    if (f->dead) {
-        set_error("mht_forest_step: a pool overflowed in an earlier scan; create a new forest with larger max_nodes / max_targets");
-        return MHT_E_STATE;
-    }
-    MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const int s = ++f->scan;
-    const int cb = s & 1, nb = (s + 1) & 1;
-    f->births_issue[s % 64] = f->births_cum;
-    f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
-    f->nT_ub_step = f->targets_ub(s);
-    f->births_since_step = 0;
-    const int W = (M + 63) / 64;
-    f->last_M = M;
-    hipEvent_t* ev = nullptr;
-    if (f->timing) {
-        MHT_REQUIRE(f->timed_steps < EV_POOL, "mht_forest_step: %d timed steps pending, read them with mht_forest_stage_times", EV_POOL);
-        ev = f->evp[f->ev_slot];
-        f->ev_slot = (f->ev_slot + 1) % EV_POOL;
-    }
-    // No memsets between scans: the association bitsets are cleared by the cluster kernel while it reads them, the
-    // used-measurement bytes by the commit, the other parity's status word and the cluster counters by the cluster kernel.
-    DevStatus* st_cur = f->status2 + (s & 1);
-    DevStatus* st_prev = f->status2 + ((s - 1) & 1);
-    const bool fused = f->commit_pending;      // the previous scan's commit rides in this scan's grow_kernel
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[0], st));
-    // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
+// ---- argument blocks of a scan's launches ------------------------------------------------------------------------------
+// Everything in them depends on the scan number s only through s % R (ring layer) and s & 1 (double-buffered tables): they repeat
+// with period 2R.  What really changes per scan -- the scan's measurements, the grid, the scan number in the report -- travels
+// separately (FDyn, CommitDyn), so that a group of sectors can keep its blocks in HBM (mht_group_*).
+namespace mht {
+
+static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
+    g = FGrowArgs{};
+    const int cb = s & 1;
     const mht_nodes& in = f->layer[(s - 1) % f->R];
     const mht_nodes& out = f->layer[s % f->R];
-    int rc;
-    {
-        FGrowArgs g = {};
-        fill_model_only(g.model, &f->model);
-        g.default_pd = f->model.default_pd; g.default_miss_nllr = f->model.default_miss_nllr;
-        g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
-        g.cap = f->Ncap; g.capc = f->capc;
-        g.G_in = f->G[(s - 1) & 1]; g.G_out = f->G[s & 1];
-        g.in_path = f->path[(s - 1) & 1]; g.in_apath = f->apath[(s - 1) & 1]; g.pds = f->pds;
-        g.z = z; g.M = M; g.W = W;
-        g.Tcap = f->Tcap;
-        if (fused) {      // tables of the scan before, still uncommitted
-            const int pb = (s - 1) & 1;
-            g.nT_dev = &f->cnt->nTv[pb];
-            g.p_status = f->t_status; g.p_count = f->t_count; g.p_jdrop = f->t_jdrop; g.p_firstsurv = f->t_firstsurv;
-            g.p_depth = f->tab[pb].depth; g.t_root_cnllr = f->w_root_cnllr; g.t_root_f32 = f->w_root_f32;
-        } else {
-            g.nT_dev = &f->cnt->nT;
-            g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
-        }
-        g.t_first = f->tab[cb].first; g.t_leaf_off = f->tab[cb].leaf_off; g.t_depth = f->tab[cb].depth; g.t_shift = f->tab[cb].shift;
-        g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
-        g.oflags = out.flags; g.oP = out.P;
-        g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
-        g.tchild = f->tchild; g.tcend = f->tcend;
-        g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
-        g.alloc = f->alloc; g.block_cap = f->block_cap; g.over_base = f->over_base; g.region_cap = f->region_cap;
-        g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
-        g.used_bytes = f->used_bytes[s & 1];
-        g.status = st_cur; g.prev_status = st_prev; g.sticky_overflow = &f->cnt->overflow;
-        g.dbg = f->debug ? f->grow_dbg : nullptr;
-        // one workgroup per slot of the table the scan runs on: the uncommitted one (targets before the last scan's
-        // terminations) when the commit rides along, else the committed one
-        rc = launch_fgrow(ctx, g, fused ? f->nT_ub_prev : f->nT_ub_step, fused ? &f->pending : nullptr);
-        if (rc) return rc;
+    fill_model_only(g.model, &f->model);
+    g.default_pd = f->model.default_pd; g.default_miss_nllr = f->model.default_miss_nllr;
+    g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
+    g.cap = f->Ncap; g.capc = f->capc;
+    g.G_in = f->G[(s - 1) & 1]; g.G_out = f->G[s & 1];
+    g.in_path = f->path[(s - 1) & 1]; g.in_apath = f->apath[(s - 1) & 1]; g.pds = f->pds;
+    g.Tcap = f->Tcap;
+    if (fused) {      // tables of the scan before, still uncommitted
+        const int pb = (s - 1) & 1;
+        g.nT_dev = &f->cnt->nTv[pb];
+        g.p_status = f->t_status; g.p_count = f->t_count; g.p_jdrop = f->t_jdrop; g.p_firstsurv = f->t_firstsurv;
+        g.p_depth = f->tab[pb].depth; g.t_root_cnllr = f->w_root_cnllr; g.t_root_f32 = f->w_root_f32;
+    } else {
+        g.nT_dev = &f->cnt->nT;
+        g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
     }
-    f->commit_pending = false;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[1], st));
-    // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
-    ClusterArgs c = {};
+    g.t_first = f->tab[cb].first; g.t_leaf_off = f->tab[cb].leaf_off; g.t_depth = f->tab[cb].depth; g.t_shift = f->tab[cb].shift;
+    g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
+    g.oflags = out.flags; g.oP = out.P;
+    g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
+    g.tchild = f->tchild; g.tcend = f->tcend;
+    g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
+    g.alloc = f->alloc; g.block_cap = f->block_cap; g.over_base = f->over_base; g.region_cap = f->region_cap;
+    g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
+    g.used_bytes = f->used_bytes[s & 1];
+    g.status = f->status2 + (s & 1); g.prev_status = f->status2 + ((s - 1) & 1); g.sticky_overflow = &f->cnt->overflow;
+}
+
+static void fill_cluster(const Forest* f, int s, ClusterArgs& c) {
+    c = ClusterArgs{};
     c.assoc = nullptr; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 0;
     c.alloc_reset = f->alloc;
-    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = nullptr; c.seg_cap = f->SegCap; c.status = st_cur; c.status_other = st_prev; c.dbg = reinterpret_cast<int32_t*>(f->grow_dbg) + 16;
+    c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = nullptr; c.seg_cap = f->SegCap;
+    c.status = f->status2 + (s & 1); c.status_other = f->status2 + ((s - 1) & 1);
+    c.dbg = f->debug ? reinterpret_cast<int32_t*>(f->grow_dbg) + 16 : nullptr;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
-    rc = launch_cluster(ctx, c);
-    if (rc) return rc;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[2], st));
-    // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
-    BlpArgs b = {};
+    cluster_prepare(c);
+}
+
+static void fill_blp(const Forest* f, int s, BlpArgs& b) {
+    b = BlpArgs{};
+    const int cb = s & 1;
+    const mht_nodes& out = f->layer[s % f->R];
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
     b.counts = f->cl_counts; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD; b.pds = f->pds;
@@ -603,11 +576,11 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
-    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = st_cur;
-    { const char* e = getenv("MHT_BLP_FORCE_HBM"); b.force_hbm = (e && e[0] == '1') ? 1 : 0; }
+    b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = f->status2 + (s & 1);
+    b.force_hbm = f->force_hbm ? 1 : 0;
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
-    b.apath = f->apath[s & 1]; b.R = f->R; b.scan = s;
+    b.apath = f->apath[s & 1]; b.R = f->R; b.kc = s % f->R;
     b.ring0 = RingLayer{f->layer[0].x, f->layer[0].cnllr, f->layer[0].meas, f->layer[0].flags};
     b.ring_stride = (size_t)(reinterpret_cast<const char*>(f->layer[1].x) - reinterpret_cast<const char*>(f->layer[0].x));   // layers are laid out identically, back to back
     b.t_id = f->tab[cb].id; b.t_root_scan = f->tab[cb].root_scan; b.t_root_node = f->tab[cb].root_node; b.t_label = f->t_label;
@@ -616,32 +589,241 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
-    int grid = f->nT_ub_step / 2 + 8;
-    if (grid > 1024) grid = 1024;
-    rc = launch_blp(ctx, b, grid);
-    if (rc) return rc;
-    if (f->timing) MHT_HIP_CHECK(hipEventRecord(ev[3], st));
-    // ---- 4: N-scan prune (tracker.py:256-259): surviving leaf ranges, then target table / roots / report --------------
-    CommitArgs p = {};
+}
+
+// N-scan prune (tracker.py:256-259), target side: surviving leaf ranges -> target table / roots / report, for scan s
+static void fill_commit(const Forest* f, int s, CommitArgs& p) {
+    p = CommitArgs{};
+    const int cb = s & 1, nb = (s + 1) & 1;
     p.cur = f->tab[cb]; p.nxt = f->tab[nb];
     p.sel = f->sel; p.t_status = f->t_status; p.t_jdrop = f->t_jdrop; p.t_count = f->t_count; p.t_firstsurv = f->t_firstsurv;
     p.w_root_scan = f->w_root_scan; p.w_root_node = f->w_root_node; p.w_root_cnllr = f->w_root_cnllr; p.w_root_f32 = f->w_root_f32;
-    p.R = f->R; p.scan = s; p.cap = f->Ncap; p.Tcap = f->Tcap; p.vnext = nb;
+    p.R = f->R; p.cap = f->Ncap; p.Tcap = f->Tcap; p.vnext = nb;
     p.new_index = f->new_index;
-    p.cnt = f->cnt; p.status = st_cur;
+    p.cnt = f->cnt; p.status = f->status2 + (s & 1);
     p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
-    p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off); p.M = M; p.W = W;
+    p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off);
     p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev); p.hint = f->hint_dev;
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
-    // deferred: workgroup 0 of the next scan's grow_kernel runs it, unless somebody needs the committed state before that
-    // (flush_commit).  One launch and one kernel boundary less per scan; with timing on, its time shows up in the next
-    // scan's "gate" stage and the "prune" stage reads zero.
-    f->pending = p;
+}
+
+// Host-side bookkeeping of a step.  begin: every check that can fail comes BEFORE the scan counter moves (a refused step must not
+// shift the ring / parity the later steps derive their buffers from); a launch failure after that kills the forest.
+struct StepPlan { int s; bool fused; int n_ub; int W; };
+static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl) {
+    MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "%s: M=%d exceeds max_meas=%d", who, M, f->cfg.max_meas);
+    MHT_REQUIRE(z || M == 0, "%s: z is null", who);
+    if (f->dead) {
+        set_error("%s: the forest is dead (a pool overflowed or a launch failed in an earlier scan); create a new one with larger max_nodes / max_targets", who);
+        return MHT_E_STATE;
+    }
+    if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
+    const int s = ++f->scan;
+    f->births_issue[s % 64] = f->births_cum;
+    f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
+    f->nT_ub_step = f->targets_ub(s);
+    f->births_since_step = 0;
+    f->last_M = M;
+    pl.s = s;
+    pl.fused = f->commit_pending;      // the previous scan's commit rides in this scan's grow launch
+    // one workgroup per slot of the table the scan runs on: the uncommitted one (targets before the last scan's terminations) when
+    // the commit rides along, else the committed one
+    pl.n_ub = pl.fused ? f->nT_ub_prev : f->nT_ub_step;
+    pl.W = (M + 63) / 64;
+    return MHT_OK;
+}
+static void forest_end_step(Forest* f, const StepPlan& pl, int M) {
+    // the target-side commit of this scan is deferred: workgroup 0 of the next scan's grow launch runs it, unless somebody needs
+    // the committed state before that (flush_commit).  One launch and one kernel boundary less per scan; with timing on, its time
+    // shows up in the next scan's "gate" stage and the "prune" stage reads zero.
+    fill_commit(f, pl.s, f->pending);
+    f->pending_dyn = CommitDyn{pl.s, M, pl.W};
     f->commit_pending = true;
-    if (f->timing) { MHT_HIP_CHECK(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     f->report_pending = true;
     f->L_ub = f->Ncap;        // unknown until the report is fetched
+}
+
+}  // namespace mht
+
+extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
+    Forest* f = ctx->forest;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    StepPlan pl;
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl); if (rc) return rc; }
+    hipStream_t st = ctx->stream;
+    hipEvent_t* ev = nullptr;
+    if (f->timing) {
+        ev = f->evp[f->ev_slot];
+        f->ev_slot = (f->ev_slot + 1) % EV_POOL;
+    }
+    // No memsets between scans: the used-measurement bytes are cleared by the commit, the other parity's status word, the edge
+    // and child counters and the cluster counters by the cluster kernel.
+#define MHT_STEP_CHECK(expr) do { const int rc_ = (expr); if (rc_) { f->dead = true; return rc_; } } while (0)
+#define MHT_STEP_HIP(expr) do { if ((expr) != hipSuccess) { f->dead = true; set_error("mht_forest_step: %s failed", #expr); return MHT_E_HIP; } } while (0)
+    if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[0], st));
+    // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
+    {
+        FGrowArgs g;
+        fill_fgrow(f, pl.s, pl.fused, g);
+        FDyn d = {};
+        d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.dbg = f->debug ? f->grow_dbg : nullptr;
+        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr));
+    }
+    f->commit_pending = false;
+    if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
+    // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
+    {
+        ClusterArgs c;
+        fill_cluster(f, pl.s, c);
+        MHT_STEP_CHECK(launch_cluster(ctx, c));
+    }
+    if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[2], st));
+    // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
+    {
+        BlpArgs b;
+        fill_blp(f, pl.s, b);
+        int grid = f->nT_ub_step / 2 + 8;
+        if (grid > 1024) grid = 1024;
+        MHT_STEP_CHECK(launch_blp(ctx, b, grid));
+    }
+    if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[3], st));
+    // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------
+    forest_end_step(f, pl, M);
+    if (f->timing) { MHT_STEP_HIP(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     return MHT_OK;
+}
+
+// ---- a group of sectors: BASELINE config 4 (independent sensor sectors = independent Tracker instances) on ONE device ----------
+// S forests step together with ONE launch per stage (blockIdx.y = sector): the single-sector path is a chain of dependent round
+// trips that leaves most of the chip idle, S sectors cost about one such chain.  The argument blocks of every member and every
+// phase of the ring are written to HBM once, here.
+struct mht_group {
+    int n = 0, period = 0;
+    mht_ctx* ctx[GROUP_MAX] = {};
+    FGrowArgs* ga = nullptr;      // [n][period][2]
+    CommitArgs* ca = nullptr;     // [n][period]
+    ClusterArgs* cl = nullptr;    // [n][2]
+    BlpArgs* bl = nullptr;        // [n][period]
+};
+
+extern "C" int mht_group_destroy(mht_group* g) {
+    if (!g) return MHT_OK;
+    if (g->n > 0) {
+        (void)hipSetDevice(g->ctx[0]->device);
+        (void)hipStreamSynchronize(g->ctx[0]->stream);
+    }
+    if (g->ga) (void)hipFree(g->ga);
+    if (g->ca) (void)hipFree(g->ca);
+    if (g->cl) (void)hipFree(g->cl);
+    if (g->bl) (void)hipFree(g->bl);
+    delete g;
+    return MHT_OK;
+}
+
+extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs) {
+    MHT_REQUIRE(out && ctxs && n >= 1 && n <= GROUP_MAX, "mht_group_create: need 1 <= n <= %d contexts", GROUP_MAX);
+    for (int i = 0; i < n; ++i) {
+        MHT_REQUIRE(ctxs[i] && ctxs[i]->forest, "mht_group_create: context %d has no forest", i);
+        const Forest *a = ctxs[0]->forest, *b = ctxs[i]->forest;
+        MHT_REQUIRE(ctxs[i]->device == ctxs[0]->device && ctxs[i]->stream == ctxs[0]->stream,
+                    "mht_group_create: the members must share one device and one stream (context %d does not)", i);
+        MHT_REQUIRE(a->Tcap == b->Tcap && a->Ncap == b->Ncap && a->Mpad == b->Mpad && a->R == b->R,
+                    "mht_group_create: the members must have the same forest configuration (context %d differs)", i);
+        for (int j = 0; j < i; ++j) MHT_REQUIRE(ctxs[j] != ctxs[i], "mht_group_create: context %d appears twice", i);
+    }
+    MHT_HIP_CHECK(hipSetDevice(ctxs[0]->device));
+    mht_group* g = new (std::nothrow) mht_group();
+    MHT_REQUIRE(g, "mht_group_create: out of host memory");
+    g->n = n;
+    g->period = 2 * ctxs[0]->forest->R;
+    const int P = g->period;
+    for (int i = 0; i < n; ++i) g->ctx[i] = ctxs[i];
+    FGrowArgs* hga = new FGrowArgs[(size_t)n * P * 2];
+    CommitArgs* hca = new CommitArgs[(size_t)n * P];
+    ClusterArgs* hcl = new ClusterArgs[(size_t)n * 2];
+    BlpArgs* hbl = new BlpArgs[(size_t)n * P];
+    for (int i = 0; i < n; ++i) {
+        const Forest* f = ctxs[i]->forest;
+        for (int v = 0; v < P; ++v) {
+            const int s = v == 0 ? P : v;      // any scan number with s % P == v (scans start at 1)
+            fill_fgrow(f, s, false, hga[((size_t)i * P + v) * 2]);
+            fill_fgrow(f, s, true, hga[((size_t)i * P + v) * 2 + 1]);
+            fill_commit(f, s, hca[(size_t)i * P + v]);
+            fill_blp(f, s, hbl[(size_t)i * P + v]);
+        }
+        fill_cluster(f, 2, hcl[(size_t)i * 2]);
+        fill_cluster(f, 1, hcl[(size_t)i * 2 + 1]);
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->ga), sizeof(FGrowArgs) * n * P * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->ca), sizeof(CommitArgs) * n * P);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->cl), sizeof(ClusterArgs) * n * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->bl), sizeof(BlpArgs) * n * P);
+    if (e == hipSuccess) e = hipMemcpy(g->ga, hga, sizeof(FGrowArgs) * n * P * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->ca, hca, sizeof(CommitArgs) * n * P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->cl, hcl, sizeof(ClusterArgs) * n * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->bl, hbl, sizeof(BlpArgs) * n * P, hipMemcpyHostToDevice);
+    delete[] hga; delete[] hca; delete[] hcl; delete[] hbl;
+    if (e != hipSuccess) {
+        set_error("mht_group_create: %s", hipGetErrorString(e));
+        (void)mht_group_destroy(g);
+        return MHT_E_HIP;
+    }
+    *out = g;
+    return MHT_OK;
+}
+
+extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t* M) {
+    MHT_REQUIRE(g && z && M, "mht_group_step: null argument");
+    const int n = g->n, P = g->period;
+    mht_ctx* c0 = g->ctx[0];
+    MHT_HIP_CHECK(hipSetDevice(c0->device));
+    for (int i = 0; i < n; ++i) {      // nothing may fail after the first member's scan counter has moved
+        const Forest* f = g->ctx[i]->forest;
+        MHT_REQUIRE(f, "mht_group_step: member %d lost its forest", i);
+        MHT_REQUIRE(M[i] >= 0 && M[i] <= f->cfg.max_meas, "mht_group_step: member %d: M=%d exceeds max_meas=%d", i, M[i], f->cfg.max_meas);
+        MHT_REQUIRE(z[i] || M[i] == 0, "mht_group_step: member %d: z is null", i);
+        MHT_REQUIRE(!f->timing, "mht_group_step: per-stage timing is per forest (mht_forest_set_timing(ctx, 0) first)");
+        if (f->dead) { set_error("mht_group_step: member %d is dead (a pool overflowed in an earlier scan)", i); return MHT_E_STATE; }
+    }
+    FBatch fb = {};
+    PBatch cb = {}, bb = {};
+    StepPlan pl[GROUP_MAX];
+    int grid_g = 1, grid_b = 1;
+    size_t lds = 256;
+    for (int i = 0; i < n; ++i) {
+        Forest* f = g->ctx[i]->forest;
+        { const int rc = forest_begin_step(g->ctx[i], f, z[i], M[i], "mht_group_step", pl[i]); if (rc) return rc; }
+        const int s = pl[i].s, v = s % P;
+        FDyn& d = fb.d[i];
+        d.z = z[i]; d.M = M[i]; d.W = pl[i].W;
+        d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.dbg = nullptr;
+        fgrow_plan(d, pl[i].n_ub, f->Tcap, pl[i].fused);
+        fb.ga[i] = g->ga + ((size_t)i * P + v) * 2 + (pl[i].fused ? 1 : 0);
+        fb.ca[i] = g->ca + (size_t)i * P + (s - 1 + P) % P;      // the commit of the scan before rides along (if fused)
+        cb.p[i] = g->cl + (size_t)i * 2 + (s & 1);
+        bb.p[i] = g->bl + (size_t)i * P + v;
+        const int gg = fgrow_grid_of(d);
+        if (gg > grid_g) grid_g = gg;
+        int gbl = f->nT_ub_step / 2 + 8;
+        if (gbl > 1024) gbl = 1024;
+        if (gbl > grid_b) grid_b = gbl;
+        const size_t l = fgrow_lds_bytes(d.W, f->pds, f->AW);
+        if (l > lds) lds = l;
+        f->commit_pending = false;
+    }
+    const Forest* f0 = c0->forest;
+    int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds);
+    if (!rc) rc = launch_cluster_batch(c0, cb, n, f0->Tcap, f0->n_mnodes);
+    if (!rc) rc = launch_blp_batch(c0, bb, n, grid_b);
+    for (int i = 0; i < n; ++i) {
+        Forest* f = g->ctx[i]->forest;
+        if (rc) f->dead = true;
+        else forest_end_step(f, pl[i], M[i]);
+    }
+    return rc;
 }
 
 extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) {

@@ -23,7 +23,6 @@
 // The bound is HBM traffic + launch/dependency latency; the kernel moves
 // 280 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
 #include "mht_kernels.h"
-#include "mht_commit.h"
 #include <stdlib.h>
 
 namespace mht {
@@ -209,7 +208,7 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
 
 constexpr int SPIN_LIMIT = 1 << 23;     // look-back watchdog: x ~0.1 us per poll
 
-__global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a, const CommitArgs cm) {
+__global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = a.M, W = a.W;
     const int Mpad = W * 64;
@@ -223,83 +222,15 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a,
     unsigned char* tshift = tdepth + a.Tcap;
     unsigned short* told = reinterpret_cast<unsigned short*>(tshift + a.Tcap);          // [Tcap] deferred commit: slot in the old table
     unsigned short* cand = told + a.Tcap;                                               // [Mpad] phase-2 candidates
-    __shared__ int s_base, s_total, s_stall, s_pref[GATE_TILE + 1], s_cs[GATE_THREADS / 64], s_cs2[GATE_THREADS / 64];
+    __shared__ int s_base, s_total, s_stall, s_pref[GATE_TILE + 1];
     __shared__ int s_box[4][4], s_ncand;      // up to 4 target segments per tile: {min x, max x, min y, max y} as sortable ints
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    if (a.fused) {           // deferred commit of the previous scan: workgroup 0 runs it, the tiles follow from workgroup 1
-        if (bid == 0) { __shared__ int s_commit[2 * (GATE_THREADS / 64) + 8]; commit_body<GATE_THREADS>(cm, s_commit); return; }
-        bid -= 1;
-    }
-    // First round trip, everything at once: the scalars that decide what this workgroup does, the first slice of the scan
-    // and -- deferred commit -- the first chunk of the previous scan's per-target results (index clamped by the table's
-    // capacity, entries beyond the real count are masked afterwards), so that nothing below waits for a second trip.
+    const int bid = blockIdx.x;
+    // First round trip: the first slice of the scan
     const float2* z2 = reinterpret_cast<const float2*>(a.z);
     const float2 z_first = (tid < M) ? z2[tid] : make_float2(3.0e38f, 3.0e38f);
-    int po = 0, so = 0, pch = 0, nT = 0, L = a.L;
-    int v_st = 1, v_cnt = 0, v_j = 0, v_first = 0, v_dep = 0;
-    if (a.prev_status) {     // forest mode
-        po = a.prev_status->overflow;
-        pch = a.prev_status->n_children;
-        so = *a.sticky_overflow;
-        nT = a.nT_dev[0];      // FCounts{nT, L, ...}
-        if (!a.fused) {
-            L = a.nT_dev[1];
-        } else {
-            const int tcl = tid < a.Tcap ? tid : 0;
-            v_st = a.p_status[tcl]; v_cnt = a.p_count[tcl]; v_j = a.p_jdrop[tcl]; v_first = a.p_firstsurv[tcl]; v_dep = a.p_depth[tcl];
-        }
-    }
-    if (po || so) {          // a scan that overflowed its pools voids every scan after it
-        if (bid == 0 && tid == 0) a.status->overflow = po ? po : 1;
-        return;
-    }
-    if (a.fused) {
-        // The committed table does not exist yet (workgroup 0 is writing it): every tile compacts the previous scan's
-        // per-target results itself -- alive flag, surviving leaf range, root advance -- with the same dual block scan as
-        // commit_body.  O(targets) per workgroup, all from L2; it replaces the staging of the committed table.
-        const int nTo = nT;
-        if (bid > 0 && bid * GATE_TILE >= pch) return;     // leaves <= children of the previous scan
-        int running = 0, lrun = 0;
-        for (int base = 0; base < nTo; base += GATE_THREADS) {
-            const int t = base + tid;
-            const bool in = t < nTo;
-            if (base > 0) {                 // further chunks (more than 512 targets): clamped, the look-ups go out together
-                const int tc = in ? t : 0;
-                v_st = a.p_status[tc]; v_cnt = a.p_count[tc]; v_j = a.p_jdrop[tc]; v_first = a.p_firstsurv[tc]; v_dep = a.p_depth[tc];
-            }
-            const int al = in && (v_st == 0);
-            const int cntl = v_cnt, j = v_j, first = v_first, dep = v_dep;
-            const int leaves = al ? cntl : 0;
-            int incl = al, incl2 = leaves;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(incl, o), u2 = __shfl_up(incl2, o);
-                if (lane >= o) { incl += u; incl2 += u2; }
-            }
-            if (lane == 63) { s_cs[wave] = incl; s_cs2[wave] = incl2; }
-            __syncthreads();
-            int wb = 0, wb2 = 0, tot = 0, tot2 = 0;
-#pragma unroll
-            for (int i = 0; i < GATE_THREADS / 64; ++i) {
-                const int v = s_cs[i], v2 = s_cs2[i];
-                if (i < wave) { wb += v; wb2 += v2; }
-                tot += v; tot2 += v2;
-            }
-            const int pos = running + wb + incl - al, lpos = lrun + wb2 + incl2 - leaves;
-            running += tot;
-            lrun += tot2;
-            if (al) {
-                off[pos] = lpos; tfirst[pos] = first;
-                tdepth[pos] = (unsigned char)(dep + 1 - j); tshift[pos] = (unsigned char)j; told[pos] = (unsigned short)t;
-            }
-            if (base + GATE_THREADS < nTo) __syncthreads();      // s_cs is re-used by the next chunk
-        }
-        nT = running;
-        L = lrun;
-        if (tid == 0) off[nT] = L;
-    }
+    const int nT = 0, L = a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
 
     // One tile per workgroup.  Static mapping (tile = blockIdx) whenever the whole grid is co-resident: a workgroup spinning
@@ -633,10 +564,10 @@ static inline size_t grow_lds_bytes(int W, int Tcap) {
            (size_t)W * 64 * 2 + 2;      // + candidate list
 }
 
-int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArgs* commit) {
+int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const int L = grid_leaves_hint > a.L ? grid_leaves_hint : a.L, W = a.W;
     if (!a.status) a.status = ctx->status;
-    a.fused = commit ? 1 : 0;
+    a.fused = 0;
     int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     if (ntiles < 1) ntiles = 1;
     // tile states: epoch-tagged; the forest owns its arrays and never resets them (ticket: reset to zero by whoever consumes
@@ -683,7 +614,7 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArg
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
-    hipLaunchKernelGGL(grow_kernel, dim3(blocks), dim3(GATE_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{});
+    hipLaunchKernelGGL(grow_kernel, dim3(blocks), dim3(GATE_THREADS), lds, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

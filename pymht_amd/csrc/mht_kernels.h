@@ -59,6 +59,8 @@ struct GateArgs {
 };
 
 struct CommitArgs;
+struct FDyn;
+struct FBatch;
 
 // fgrow_kernel (mht_fgrow.hip): the grow stage of the forest, one workgroup per target + covariance-chain workgroups
 struct FGrowArgs {
@@ -71,10 +73,8 @@ struct FGrowArgs {
     const int32_t* in_path;        // [cap][pds] measurement nodes below the root, one record per node of the input layer
     const int32_t* in_apath;       // [cap][pds] ancestor node per level
     int pds;                       // ints per record: 8 (PD <= 8) or 16
-    const float* z; int M; int W;
-    // the target table this scan runs on.  fused = 1: the commit of the previous scan has not run (it rides in workgroup 0):
+    // the target table this scan runs on.  fused (FDyn) = 1: the commit of the previous scan has not run (it rides in workgroup 0):
     // the per-target results of that scan (p_*), indexed by old slot, stand in for the compacted table
-    int fused;
     const int32_t* nT_dev;
     int Tcap;
     const int32_t* p_status; const int32_t* p_count; const int32_t* p_jdrop; const int32_t* p_firstsurv; const int32_t* p_depth;
@@ -93,9 +93,19 @@ struct FGrowArgs {
     unsigned char* used_bytes;
     DevStatus* status;             // this scan's status word: n_children is accumulated here
     const DevStatus* prev_status; const int32_t* sticky_overflow;
-    int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
-    unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][8] wall-clock ticks at phase boundaries
 };
+// What changes from scan to scan (everything in FGrowArgs repeats with period 2 x ring length, for fused = 0 and 1): passed by
+// value next to the argument block (one launch per sector) or to a pointer to it (one launch for a group of sectors).
+struct FDyn {
+    const float* z; int M; int W;  // the scan: dev (M,2) float32; W = ceil(M / 64)
+    int fused;                     // workgroup 0 runs the previous scan's commit (CommitDyn c)
+    int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
+    int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
+    unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
+};
+constexpr int GROUP_MAX = 32;      // sectors per batched launch
+struct FBatch { const FGrowArgs* ga[GROUP_MAX]; const CommitArgs* ca[GROUP_MAX]; FDyn d[GROUP_MAX]; };
+struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM) per sector
 
 struct ClusterArgs {
     const unsigned long long* assoc;   // [T][AW]
@@ -163,17 +173,24 @@ struct BlpArgs {
     int Nwin; double score_limit, cnllr_limit, radar_x, radar_y, radar_range;
     // N-scan prune per target (pyTarget.pruneDepth, pyTarget.py:343-356), done by whoever selected the target's leaf:
     // new root (ancestor table look-up), the target's report record, the surviving leaf range (first, count)
-    const int32_t* apath; int R; int scan;
+    const int32_t* apath; int R; int kc;      // kc = ring slot of this scan's layer (scan % R)
     RingLayer ring0; size_t ring_stride;      // layer k of the ring: every array of ring0 advanced by k * ring_stride BYTES
     const int32_t* t_id; const int32_t* t_root_scan; const int32_t* t_root_node; const int32_t* t_label;
     mht_target_report* rec; int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
 };
 
-int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint, const CommitArgs* commit = nullptr);
-int launch_fgrow(mht_ctx* ctx, FGrowArgs& a, int n_targets_ub, const CommitArgs* commit);
+int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit);
+size_t fgrow_lds_bytes(int W, int pds, int AW);
+void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);
+int fgrow_grid_of(const FDyn& d);
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds);
+int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes);
+int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x);
 void fill_model(GateArgs& a, const mht_model* m);
 void fill_model_only(Model& o, const mht_model* m);
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
+void cluster_prepare(ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);

@@ -123,6 +123,8 @@ class Tracker():
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
+        self._dead = False          # a device step failed: the forest cannot go on
+        self._staged = self._staged_np = None
         self.lastScanStats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -177,12 +179,61 @@ class Tracker():
     # ------------------------------------------------------------------------------------------------
     def addMeasurementList(self, scanList, aisList=AisMessageList(), **kwargs):
         """tracker.py:162-307 for the radar-only case."""
+        z = self._accept_scan(scanList, aisList, kwargs)
+        # steps 1-6 on the device.  The host mirror is only touched once the device has accepted the scan: a rejected step
+        # (too many measurements, dead forest) leaves the tracker exactly as it was.
+        try:
+            _lib.check(self._lib.mht_forest_step_host(self._ctx.handle, z.ctypes.data_as(C.c_void_p), z.shape[0]))
+        except _lib.MhtError as e:
+            if e.code != _lib.MHT_E_INVALID:
+                self._dead = True
+            raise
+        self._finish_scan(scanList, z, aisList)
+
+    def _accept_scan(self, scanList, aisList, kwargs):
+        """Argument checks of addMeasurementList; returns the scan as the (M,2) float32 array the device gates."""
+        if self._dead:
+            raise RuntimeError("this Tracker's device forest is dead (an earlier scan failed); create a new Tracker")
         if aisList is not None and len(aisList) > 0:
             raise NotImplementedError("AIS fusion (tracker.py:417-552) is outside the MI355X hot path")
-        if kwargs.get('dynamicWindow', False) or kwargs.get('pruneSimilar', False):
-            raise NotImplementedError("dynamicWindow / pruneSimilar are not supported by pymht_amd")
+        if kwargs.get('dynamicWindow', False):
+            raise NotImplementedError("dynamicWindow is not supported by pymht_amd")
         self.tic.clear()
         self.toc.clear()
+        self.tic['Total'] = time.time()
+        m = np.asarray(scanList.measurements)
+        z = np.ascontiguousarray(m, dtype=np.float32).reshape(-1, 2)
+        if m.dtype != np.float32 and m.size and not np.array_equal(z.astype(np.float64).reshape(m.shape), m.astype(np.float64)):
+            # the reference gates in the dtype it is given (its simulator produces float32); the device takes float32
+            log.warning("addMeasurementList: measurements are %s and not exactly representable as float32; they are rounded "
+                        "(the reference would gate them in %s)", m.dtype, m.dtype)
+        return z
+
+    def _stage_scan(self, scanList, aisList=None, **kwargs):
+        """SectorGroup: checks + the scan in device memory (a torch tensor kept alive until the next scan)."""
+        import torch
+        z = self._accept_scan(scanList, aisList, kwargs)
+        self._staged_np = z
+        self._staged = torch.from_numpy(z if z.size else np.zeros((1, 2), np.float32)).to(self._ctx.device)
+        if z.size == 0:
+            self._staged = self._staged[:0]
+        return self._staged
+
+    def _finish_scan(self, scanList, z=None, aisList=None):
+        """Everything after the device step: report, host mirror, step 7 (track initiation), timing log."""
+        if z is None:
+            z = self._staged_np
+        rep = _lib.MhtScanReport()
+        rc = self._lib.mht_forest_report(self._ctx.handle, C.byref(rep))
+        if rc == _lib.MHT_E_LIMIT:
+            # soft: an ILP ran into the branch-and-bound node limit.  The selection it returned is feasible (not proven optimal)
+            # and the device forest HAS advanced with it: fold the report like any other (the reference logs "Optim result NOT
+            # optimal", tracker.py:1201, and carries on as well)
+            log.warning("scan %d: %d ILP(s) hit the branch-and-bound node limit; their selection is feasible, not proven optimal",
+                        rep.scan, rep.n_limit)
+        elif rc:
+            self._dead = True
+            _lib.check(rc)
         self.__scanHistory__.append(scanList)
         if len(self.__scanHistory__) >= len(self._scan_times):
             self._scan_times = np.concatenate([self._scan_times, np.zeros(len(self._scan_times))])
@@ -190,13 +241,7 @@ class Tracker():
         self.__aisHistory__.append(aisList)
         scanTime = scanList.time
         scanNumber = len(self.__scanHistory__)
-        self.tic['Total'] = time.time()
-        z = np.ascontiguousarray(np.asarray(scanList.measurements, dtype=np.float32).reshape(-1, 2))
         nRadarMeas = z.shape[0]
-        # steps 1-6 on the device
-        _lib.check(self._lib.mht_forest_step_host(self._ctx.handle, z.ctypes.data_as(C.c_void_p), nRadarMeas))
-        rep = _lib.MhtScanReport()
-        _lib.check(self._lib.mht_forest_report(self._ctx.handle, C.byref(rep)))
         assert rep.scan == scanNumber
         nT = rep.n_targets
         recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * _REPORT_DTYPE.itemsize,)) \
@@ -232,7 +277,7 @@ class Tracker():
                 v.append(self.toc[k])
         self.lastScanStats = dict(L=rep.n_leaves_in, G=rep.n_children - rep.n_leaves_in, M=nRadarMeas,
                                   leaves_out=rep.n_leaves_out, clusters=rep.n_clusters, ilp=rep.n_ilp,
-                                  branched=rep.n_branched, blp_iters_max=rep.blp_iters_max,
+                                  branched=rep.n_branched, blp_iters_max=rep.blp_iters_max, limit=rep.n_limit,
                                   unused=unusedRadarMeasurementIndices)
 
     def _apply_report(self, recs, scanTime, scanNumber, z):

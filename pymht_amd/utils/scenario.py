@@ -24,7 +24,12 @@ CONFIGS = {
 
 
 def make_scenario(T, radius, lambda_phi, n_scans, P_d=0.9, period=2.5, sigma_r=2.5, sigma_v=8.0,
-                  sigma_q=0.05, seed=1234, centre=(0.0, 0.0), t0=1000.0, **_unused):
+                  sigma_q=0.05, seed=1234, centre=(0.0, 0.0), t0=1000.0, confine=False, **_unused):
+    """confine=True: a target outside the disc of radius 0.8 * radius (where the initial targets are drawn) is pulled back by a
+    gentle acceleration towards the centre (0.15 m/s^2 = 0.5 m per scan, far inside the process noise of the tracking model: it follows
+    without losing the track), so the target density -- and with it the number of clusters / ILPs per scan -- stays what it is at
+    the start however many scans are generated (bench.py: a short and a long timed window then see the same workload).
+    Without it the targets disperse (sigma_v = 8 m/s) and the scene thins out over a few hundred scans."""
     rng = np.random.default_rng(seed)
     centre = np.asarray(centre, dtype=np.float64)
     r = radius * 0.8 * np.sqrt(rng.uniform(size=T))
@@ -39,6 +44,12 @@ def make_scenario(T, radius, lambda_phi, n_scans, P_d=0.9, period=2.5, sigma_r=2
     for k in range(n_scans):
         # constant-velocity truth with a small white acceleration
         acc = rng.normal(0.0, sigma_q, size=(T, 2))
+        if confine:
+            rel = x[:, 0:2] - centre
+            rr = np.sqrt((rel * rel).sum(axis=1))
+            out = rr > 0.8 * radius
+            if out.any():
+                acc[out] -= 0.15 * rel[out] / rr[out, None]
         x[:, 0:2] += period * x[:, 2:4] + 0.5 * period * period * acc
         x[:, 2:4] += period * acc
         seen = rng.uniform(size=T) <= P_d

@@ -1,0 +1,108 @@
+"""GPU: several independent sectors stepped as ONE batched launch set (mht_group_step, BASELINE config 4 on one device) must give,
+sector by sector, exactly what the same trackers give when each is stepped on its own."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracker(sc, **kw):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=1024,
+                  maxNodes=1 << 18, maxMeasurements=1024, deviceTiming=False, **kw)
+    trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+    return trk
+
+
+def _sectors(n, n_scans, name="cfg3"):
+    from pymht_amd.utils.scenario import make_config
+    return [make_config(name, seed=5446 + 17 * q, n_scans=n_scans, centre=(0.0, 20000.0 * q)) for q in range(n)]
+
+
+def _same_state(a, b, what):
+    sa, sb = a._sel[0], b._sel[0]
+    for name in ("id", "status", "sel_meas", "sel_x", "sel_cnllr", "score", "root_scan", "root_meas", "root_x", "n_leaves", "cluster"):
+        assert np.array_equal(sa[name], sb[name]), (what, name)
+    assert a.nTargets == b.nTargets, what
+    for k in ("L", "G", "M", "leaves_out", "clusters", "ilp"):
+        assert a.lastScanStats[k] == b.lastScanStats[k], (what, k)
+
+
+def test_four_headline_sectors_batched_equal_four_single_trackers():
+    """cfg4's workload on one device: 4 x (500 targets, ~500 measurements/scan, N-scan 5) through the drop-in API, with the
+    initiator giving birth to tracks (so deferred and immediate commits both occur inside the batch)."""
+    from pymht_amd.sectors import SectorGroup
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    scs = _sectors(4, 9)
+    solo = [_tracker(sc) for sc in scs]
+    grp_t = [_tracker(sc) for sc in scs]
+    grp = SectorGroup(grp_t)
+    for k in range(9):
+        lists = [MeasurementList(float(sc["times"][k]), sc["scans"][k]) for sc in scs]
+        for t, sl in zip(solo, lists):
+            t.addMeasurementList(sl)
+        grp.addMeasurementLists(lists)
+        for q in range(4):
+            _same_state(grp_t[q], solo[q], "scan %d sector %d" % (k, q))
+    assert solo[0].lastScanStats["L"] > 10000 and solo[0].lastScanStats["ilp"] > 10      # the headline regime
+    for q in range(4):
+        la, lb = grp_t[q].leafBatch(), solo[q].leafBatch()
+        for key in la:
+            if key != "node":      # node indices are handles (block taken with an atomic)
+                assert np.array_equal(la[key], lb[key]), (q, key)
+    grp.close()
+    for t in solo + grp_t:
+        t.close()
+
+
+def test_group_raw_replay_uneven_sectors():
+    """Raw C-ABI replay (nothing fetched between the scans: every commit rides in the next batched grow launch): sectors of
+    different sizes, one of them with empty scans in between, compared with single-forest replays at the end."""
+    import torch
+    from pymht_amd import _lib
+    from pymht_amd.sectors import SectorGroup
+    from pymht_amd.tracker import _REPORT_DTYPE
+    from pymht_amd.utils.scenario import make_scenario
+    params = [dict(T=60, radius=500.0, lambda_phi=3e-5), dict(T=7, radius=300.0, lambda_phi=1e-5), dict(T=200, radius=2500.0, lambda_phi=2e-6)]
+    scs = []
+    for q, pr in enumerate(params):
+        sc = make_scenario(n_scans=10, P_d=0.85, seed=100 + q, centre=(0.0, 20000.0 * q), **pr)
+        sc["N"] = 3
+        scs.append(sc)
+    scs[1]["scans"][4] = np.zeros((0, 2), np.float32)      # a sector that sees nothing for a scan
+    solo = [_tracker(sc, useInitiator=False) for sc in scs]
+    grp_t = [_tracker(sc, useInitiator=False) for sc in scs]
+    grp = SectorGroup(grp_t)
+    dev = grp_t[0]._ctx.device
+    zd = [[torch.from_numpy(np.ascontiguousarray(z, np.float32).reshape(-1, 2) if len(z) else np.zeros((1, 2), np.float32)).to(dev)
+           for z in sc["scans"]] for sc in scs]
+    for k in range(10):
+        for q, t in enumerate(solo):
+            _lib.check(t._lib.mht_forest_step(t._ctx.handle, zd[q][k].data_ptr(), len(scs[q]["scans"][k])))
+        grp.step_dev([zd[q][k].data_ptr() for q in range(3)], [len(scs[q]["scans"][k]) for q in range(3)])
+
+    def report(trk):
+        rep = _lib.MhtScanReport()
+        _lib.check(trk._lib.mht_forest_report(trk._ctx.handle, C.byref(rep)))
+        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(rep.n_targets * _REPORT_DTYPE.itemsize,)) \
+            .view(_REPORT_DTYPE).copy()
+        return (rep.scan, rep.n_targets, rep.n_alive, rep.n_leaves_in, rep.n_children, rep.n_leaves_out, rep.n_clusters, rep.n_ilp), recs
+
+    for q in range(3):
+        ha, ra = report(grp_t[q])
+        hb, rb = report(solo[q])
+        assert ha == hb and ha[0] == 10, (q, ha, hb)
+        for name in _REPORT_DTYPE.names:
+            if name not in ("sel_node", "root_node"):
+                assert np.array_equal(ra[name], rb[name]), (q, name)
+        la, lb = grp_t[q].leafBatch(), solo[q].leafBatch()
+        for key in la:
+            if key != "node":
+                assert np.array_equal(la[key], lb[key]), (q, key)
+    grp.close()
+    for t in solo + grp_t:
+        t.close()
