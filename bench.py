@@ -296,12 +296,21 @@ def main():
             bq, _, _, _, _ = prepass(sq, local)
             scs.append(sq)
             brs.append(bq)
-        rps = [Replay(scs[q], brs[q], local) for q in range(S)]
-        grp = SectorGroup([r.trk for r in rps])
+        # the sectors form NG groups, each on its own HIP stream: one batched launch set per group and scan; two groups' chains of
+        # dependent kernels interleave on the device (while one group's ILP kernel holds a workgroup per CU, the other's grow runs)
+        NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "2")), S))
+        streams = [torch.cuda.Stream(device=local) for _ in range(NG)]
+        rps = []
+        for q in range(S):
+            with torch.cuda.stream(streams[q % NG]):
+                rps.append(Replay(scs[q], brs[q], local))
+        grps = [SectorGroup([r.trk for r in rps[gi::NG]]) for gi in range(NG)]
 
         def group_step():
             k = rps[0].k
-            grp.step_dev([r.z.data_ptr() + int(r.zoff[k]) * 8 for r in rps], [r.M[k] for r in rps])
+            for gi in range(NG):
+                mem = rps[gi::NG]
+                grps[gi].step_dev([r.z.data_ptr() + int(r.zoff[k]) * 8 for r in mem], [r.M[k] for r in mem])
             for r in rps:
                 r.births_after_step()
         for _ in range(W):
@@ -317,14 +326,17 @@ def main():
         for r in rps:
             repm, _ = r.report()
             okm = okm and repm.error == 0
-        grp.close()
+        for gq in grps:
+            gq.close()
         for r in rps:
             r.close()
         tmulti, okm = parallel.reduce_clock(tm1 - tm0, okm, dist, device="cuda")
         multi = {"sectors_per_gpu": S, "steps_per_sector": Km, "scans_per_sec": world * S * Km / tmulti,
                  "ms_per_scan_aggregate": 1e3 * tmulti / (S * Km), "ok": okm,
-                 "note": "independent sectors in one batched launch set per scan (mht_group_step, grid.y = sector); the single-sector "
-                         "path is a chain of dependent round trips that leaves most of the GPU idle"}
+                 "groups": NG,
+                 "note": "independent sectors in %d group(s), one batched launch set per group and scan (mht_group_step, grid.y = "
+                         "sector), groups on separate HIP streams; the single-sector path is a chain of dependent round trips that "
+                         "leaves most of the GPU idle" % NG}
 
     timed = stats[W:W + K]
     Lm, Gm, Mm = float(timed[:, 0].mean()), float(timed[:, 1].mean()), float(timed[:, 2].mean())

@@ -29,8 +29,8 @@ namespace mht {
 constexpr int BLP_THREADS = 256;
 constexpr int BLP_UW = 512;       // words of the cluster's measurement-node bitset kept in LDS (32768 nodes)
 constexpr double DINF = 1.0e300;
-constexpr int L_MAXH = 2048, L_MAXR = 1024, L_MAXK = 256;
-constexpr int L_KPAD = L_MAXK + 4;   // member tables: (L_MAXK+4) * 4 and * 8 are multiples of 16 bytes
+constexpr int BIG_MAXH = 2048, BIG_MAXR = 1024, BIG_MAXK = 256;      // default LDS tier: columns, rows, targets of a cluster solved out of LDS
+// (member tables hold cap_k + 4 entries: (cap_k + 4) * 4 and * 8 are multiples of 16 bytes when cap_k is a multiple of 4)
 
 struct Red {
     double d[BLP_THREADS / 64];
@@ -1086,7 +1086,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     // make the compiler lose the LDS address space and emit slow flat accesses.
     LStore s;
     unsigned char* q = lds;
-    int* s_wbase = reinterpret_cast<int*>(q); q += (size_t)BLP_UW * 4;
+    const int L_MAXH = a.cap_h, L_MAXR = a.cap_r, L_MAXK = a.cap_k, L_KPAD = a.cap_k + 4;      // this launch's LDS tier (BlpArgs)
+    int* s_wbase = reinterpret_cast<int*>(q); q += (size_t)a.cap_uw * 4;
     int* s_scal = reinterpret_cast<int*>(q); q += 16;
     int& s_nR = s_scal[0];
     int& s_nH = s_scal[1];
@@ -1138,6 +1139,13 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     }
     __syncthreads();
     const int nH = s_nH;
+    // two-tier launches (groups of sectors): tier 1 = small LDS footprint, several workgroups per CU, takes the clusters that fit
+    // it; tier 2 = the default footprint, takes the rest
+    if (a.tier == 1 && !(K <= a.t1_k && nH <= a.t1_h)) {      // left for tier 2
+        if (tid == 0) a.big_list[atomicAdd(a.big_count, 1)] = c;
+        __syncthreads();
+        return;
+    }
     const bool lds_cols = small_k && nH <= L_MAXH && a.PD <= 8 && !a.force_hbm;
     s.nH = nH; s.PD = a.PD; s.K = K;
     // ---- measurement nodes of the cluster (union of the rows of its columns); in the LDS case the columns are
@@ -1303,16 +1311,23 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
 
 constexpr size_t RED_SLOT = 512;      // LDS bytes reserved for the reduction scratch (multiple of 16)
 static_assert(sizeof(Red) <= RED_SLOT, "Red must fit its LDS slot");
-constexpr size_t BLP_LDS_BYTES = (size_t)BLP_UW * 8 + RED_SLOT + (size_t)BLP_UW * 4 + 16 + (size_t)L_MAXH * 16 + (size_t)L_MAXH * 8 * 2 +
-                                 (size_t)L_MAXR * 8 + 7 * (size_t)L_KPAD * 8 + 2 * (size_t)L_MAXR * 4 + 6 * (size_t)L_KPAD * 4 +
-                                 (size_t)L_MAXH * 2;
+static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
+    const size_t kpad = (size_t)cap_k + 4;
+    return (size_t)cap_uw * 8 + RED_SLOT + (size_t)cap_uw * 4 + 16 + (size_t)cap_h * 16 + (size_t)cap_h * 8 * 2 + (size_t)cap_r * 8 + 7 * kpad * 8 +
+           2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2;
+}
 
 __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
-    unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [BLP_UW]
-    Red* red = reinterpret_cast<Red*>(lds + (size_t)BLP_UW * 8);                     // sizeof(Red) padded to RED_SLOT
+    unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [cap_uw]
+    Red* red = reinterpret_cast<Red*>(lds + (size_t)a.cap_uw * 8);                   // sizeof(Red) padded to RED_SLOT
     if (a.status && a.status->overflow) return;
     const int nMulti = a.counts[1], nSingle = a.counts[2];
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)BLP_UW * 8 + RED_SLOT);
+    if (a.tier == 2) {            // what tier 1 left (the single-target clusters went with tier 1)
+        const int nBig = *a.big_count;
+        for (int i = blockIdx.x; i < nBig; i += gridDim.x) solve_cluster(a, a.big_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
+        return;
+    }
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
@@ -1355,28 +1370,41 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av)
     blp_body(a, lds);
 }
 
-int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x) {
-    static bool attr = false;
-    if (!attr) {
-        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLP_LDS_BYTES));
-        attr = true;
+int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds) {
+    static size_t attr = 0;
+    if (lds > 48 * 1024 && lds > attr) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
     }
-    hipLaunchKernelGGL(blp_batch_kernel, dim3(grid_x, n_sectors), dim3(BLP_THREADS), BLP_LDS_BYTES, ctx->stream, av);
+    hipLaunchKernelGGL(blp_batch_kernel, dim3(grid_x, n_sectors), dim3(BLP_THREADS), lds, ctx->stream, av);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
 
+// the LDS tier of an argument block: tier 0 = the only launch (default footprint), 1 = small footprint first, 2 = default footprint
+// for what tier 1 left; returns the dynamic LDS bytes of the launch
+size_t blp_set_tier(BlpArgs& a, int tier) {
+    const int uw = (((a.n_mnodes + 63) / 64) + 1) & ~1;
+    a.tier = tier;
+    a.t1_h = 512; a.t1_k = 16;
+    if (tier == 1) { a.cap_h = a.t1_h; a.cap_r = 256; a.cap_k = a.t1_k; }
+    else { a.cap_h = BIG_MAXH; a.cap_r = BIG_MAXR; a.cap_k = BIG_MAXK; }
+    a.cap_uw = uw;
+    return blp_lds_bytes(a.cap_h, a.cap_r, a.cap_k, a.cap_uw);
+}
+
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
-    if ((a.n_mnodes + 63) / 64 > BLP_UW) {
-        set_error("blp: %d measurement nodes exceed the LDS bitset (%d)", a.n_mnodes, BLP_UW * 64);
+    BlpArgs b = a;
+    const size_t lds = blp_set_tier(b, 0);
+    if (lds > 150 * 1024) {
+        set_error("blp: %d measurement nodes do not fit the solver's LDS tables", a.n_mnodes);
         return MHT_E_CAPACITY;
     }
-    if (ctx->lds_attr_blp < BLP_LDS_BYTES) {
-        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLP_LDS_BYTES));
-        ctx->lds_attr_blp = BLP_LDS_BYTES;
+    if (ctx->lds_attr_blp < lds) {
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->lds_attr_blp = lds;
     }
-    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), BLP_LDS_BYTES, ctx->stream, a);
+    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
@@ -1405,7 +1433,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     const size_t S = (size_t)2 * nT + 2;
     const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
     // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4] snapshots[BB_SLOTS][BB_RE_LEVELS][snap_rows]
-    const size_t snap_rows = nR > (size_t)L_MAXR ? nR : (size_t)L_MAXR;
+    const size_t snap_rows = nR > (size_t)BIG_MAXR ? nR : (size_t)BIG_MAXR;
     const size_t n_d = nR + 6 * S + 4 + (size_t)BB_SLOTS * BB_RE_LEVELS * snap_rows;
     // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd busy[BB_SLOTS]
     const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3 + BB_SLOTS;

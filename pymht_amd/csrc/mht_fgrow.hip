@@ -609,7 +609,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
 // repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
 typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
-__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_batch_kernel(const FBatch b) {
+__global__ __launch_bounds__(FG_THREADS, 4) void fgrow_batch_kernel(const FBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int y = blockIdx.y;
     const FDyn d = b.d[y];

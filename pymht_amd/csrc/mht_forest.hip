@@ -221,7 +221,7 @@ struct Forest {
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
     unsigned* edges; int32_t* edge_count;
-    int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts;
+    int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
@@ -288,7 +288,7 @@ struct Forest {
         edge_count = ar.take<int32_t>(EDGE_SEGS + 4);
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
-        cl_counts = ar.take<int32_t>(8);
+        cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
         u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
         bb_snap_rows = n_mnodes > 1024 ? n_mnodes : 1024;
         bb_snap = ar.take<double>((size_t)BB_SLOTS * BB_RE_LEVELS * bb_snap_rows); bb_busy = ar.take<int32_t>(BB_SLOTS);
@@ -569,7 +569,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     const int cb = s & 1;
     const mht_nodes& out = f->layer[s % f->R];
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
-    b.counts = f->cl_counts; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
+    b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD; b.pds = f->pds;
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
     b.bb_snap = f->bb_snap; b.bb_busy = f->bb_busy; b.bb_snap_rows = f->bb_snap_rows;
@@ -705,7 +705,10 @@ struct mht_group {
     FGrowArgs* ga = nullptr;      // [n][period][2]
     CommitArgs* ca = nullptr;     // [n][period]
     ClusterArgs* cl = nullptr;    // [n][2]
-    BlpArgs* bl = nullptr;        // [n][period]
+    BlpArgs* bl = nullptr;        // [n][period][2]: LDS tier 1 (small footprint), tier 2 (default footprint, what tier 1 left)
+    BlpArgs* bl0 = nullptr;       // [n][period]: one launch, default footprint
+    size_t blp_lds[3] = {0, 0, 0};
+    bool two_tier = false;        // development: MHT_BLP_TWO_TIER=1
 };
 
 extern "C" int mht_group_destroy(mht_group* g) {
@@ -718,6 +721,7 @@ extern "C" int mht_group_destroy(mht_group* g) {
     if (g->ca) (void)hipFree(g->ca);
     if (g->cl) (void)hipFree(g->cl);
     if (g->bl) (void)hipFree(g->bl);
+    if (g->bl0) (void)hipFree(g->bl0);
     delete g;
     return MHT_OK;
 }
@@ -743,7 +747,9 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     FGrowArgs* hga = new FGrowArgs[(size_t)n * P * 2];
     CommitArgs* hca = new CommitArgs[(size_t)n * P];
     ClusterArgs* hcl = new ClusterArgs[(size_t)n * 2];
-    BlpArgs* hbl = new BlpArgs[(size_t)n * P];
+    BlpArgs* hbl = new BlpArgs[(size_t)n * P * 2];
+    BlpArgs* hbl0 = new BlpArgs[(size_t)n * P];
+    { const char* e = getenv("MHT_BLP_TWO_TIER"); g->two_tier = e && e[0] == '1'; }
     for (int i = 0; i < n; ++i) {
         const Forest* f = ctxs[i]->forest;
         for (int v = 0; v < P; ++v) {
@@ -751,7 +757,13 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
             fill_fgrow(f, s, false, hga[((size_t)i * P + v) * 2]);
             fill_fgrow(f, s, true, hga[((size_t)i * P + v) * 2 + 1]);
             fill_commit(f, s, hca[(size_t)i * P + v]);
-            fill_blp(f, s, hbl[(size_t)i * P + v]);
+            for (int tier = 1; tier <= 2; ++tier) {
+                BlpArgs& b = hbl[((size_t)i * P + v) * 2 + tier - 1];
+                fill_blp(f, s, b);
+                g->blp_lds[tier - 1] = blp_set_tier(b, tier);
+            }
+            fill_blp(f, s, hbl0[(size_t)i * P + v]);
+            g->blp_lds[2] = blp_set_tier(hbl0[(size_t)i * P + v], 0);
         }
         fill_cluster(f, 2, hcl[(size_t)i * 2]);
         fill_cluster(f, 1, hcl[(size_t)i * 2 + 1]);
@@ -759,12 +771,14 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->ga), sizeof(FGrowArgs) * n * P * 2);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->ca), sizeof(CommitArgs) * n * P);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->cl), sizeof(ClusterArgs) * n * 2);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->bl), sizeof(BlpArgs) * n * P);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->bl), sizeof(BlpArgs) * n * P * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->bl0), sizeof(BlpArgs) * n * P);
     if (e == hipSuccess) e = hipMemcpy(g->ga, hga, sizeof(FGrowArgs) * n * P * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->ca, hca, sizeof(CommitArgs) * n * P, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->cl, hcl, sizeof(ClusterArgs) * n * 2, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g->bl, hbl, sizeof(BlpArgs) * n * P, hipMemcpyHostToDevice);
-    delete[] hga; delete[] hca; delete[] hcl; delete[] hbl;
+    if (e == hipSuccess) e = hipMemcpy(g->bl, hbl, sizeof(BlpArgs) * n * P * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->bl0, hbl0, sizeof(BlpArgs) * n * P, hipMemcpyHostToDevice);
+    delete[] hga; delete[] hca; delete[] hcl; delete[] hbl; delete[] hbl0;
     if (e != hipSuccess) {
         set_error("mht_group_create: %s", hipGetErrorString(e));
         (void)mht_group_destroy(g);
@@ -788,7 +802,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         if (f->dead) { set_error("mht_group_step: member %d is dead (a pool overflowed in an earlier scan)", i); return MHT_E_STATE; }
     }
     FBatch fb = {};
-    PBatch cb = {}, bb = {};
+    PBatch cb = {}, bb = {}, bb2 = {}, bb0 = {};
     StepPlan pl[GROUP_MAX];
     int grid_g = 1, grid_b = 1;
     size_t lds = 256;
@@ -804,7 +818,9 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         fb.ga[i] = g->ga + ((size_t)i * P + v) * 2 + (pl[i].fused ? 1 : 0);
         fb.ca[i] = g->ca + (size_t)i * P + (s - 1 + P) % P;      // the commit of the scan before rides along (if fused)
         cb.p[i] = g->cl + (size_t)i * 2 + (s & 1);
-        bb.p[i] = g->bl + (size_t)i * P + v;
+        bb.p[i] = g->bl + ((size_t)i * P + v) * 2;
+        bb2.p[i] = g->bl + ((size_t)i * P + v) * 2 + 1;
+        bb0.p[i] = g->bl0 + (size_t)i * P + v;
         const int gg = fgrow_grid_of(d);
         if (gg > grid_g) grid_g = gg;
         int gbl = f->nT_ub_step / 2 + 8;
@@ -817,7 +833,14 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     const Forest* f0 = c0->forest;
     int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds);
     if (!rc) rc = launch_cluster_batch(c0, cb, n, f0->Tcap, f0->n_mnodes);
-    if (!rc) rc = launch_blp_batch(c0, bb, n, grid_b);
+    // ILPs in two LDS tiers: the small footprint (several workgroups per CU) takes the clusters that fit it and the single-target
+    // clusters, a narrow launch with the default footprint takes the few that do not
+    if (g->two_tier) {
+        if (!rc) rc = launch_blp_batch(c0, bb, n, grid_b, g->blp_lds[0]);
+        if (!rc) rc = launch_blp_batch(c0, bb2, n, 24, g->blp_lds[1]);
+    } else {
+        if (!rc) rc = launch_blp_batch(c0, bb0, n, grid_b, g->blp_lds[2]);
+    }
     for (int i = 0; i < n; ++i) {
         Forest* f = g->ctx[i]->forest;
         if (rc) f->dead = true;
@@ -1006,6 +1029,9 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "multi_list")) { src = f->multi_list; avail = T * 4; }
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
+    else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
+    else if (!strcmp(name, "G0")) { src = f->G[0]; avail = (size_t)f->capc * 64; }
+    else if (!strcmp(name, "G1")) { src = f->G[1]; avail = (size_t)f->capc * 64; }
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);

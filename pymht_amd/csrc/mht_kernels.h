@@ -164,6 +164,11 @@ struct BlpArgs {
     int32_t* cl_time;               // [T][2] or null: wall-clock ticks (10 ns) spent in setup / in total, per cluster
     int max_iter; int node_limit;
     int force_hbm;                  // testing: run every cluster through the HBM storage policy (as oversized clusters do)
+    // LDS tier of the launch (blp_set_tier): capacities of the LDS-resident solve (columns, rows, targets, bitset words); clusters
+    // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
+    // targets; 2: default footprint, takes exactly those
+    int cap_h, cap_r, cap_k, cap_uw, tier, t1_h, t1_k;
+    int32_t* big_list; int32_t* big_count;      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])
     const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
     // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf
@@ -186,7 +191,8 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);
 int fgrow_grid_of(const FDyn& d);
 int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds);
 int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes);
-int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x);
+int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds);
+size_t blp_set_tier(BlpArgs& a, int tier);
 void fill_model(GateArgs& a, const mht_model* m);
 void fill_model_only(Model& o, const mht_model* m);
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
