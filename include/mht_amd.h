@@ -124,6 +124,18 @@ int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRows, int32_t
                   const int32_t* rows, const double* cost, int32_t max_iter, int32_t node_limit, int32_t* selected,
                   double* objective, int32_t* status, int32_t* iterations, int32_t* nodes);
 
+/* ---- seam (iv): Tracker._nScanPruning (tracker.py:1229-1231) -> _pruneTargetIndex (:1219-1227) -> Target.pruneDepth
+ * (pyTarget.py:343-356) -> _pruneAllHypothesisExceptThis(backtrack=True) (:330-337), for trees the caller owns ---------------
+ * The trees of all targets are one array of parent pointers.
+ *   parent    dev [n_nodes] int32 : parent node or -1 (top of a tree)
+ *   sel       dev [T] int32       : __trackNodes__[t], the selected leaf of target t
+ *   window    dev [T] int32       : __targetWindowSize__[t] (N)
+ *   new_root  dev [T] int32 out   : the ancestor `window` levels above sel[t] (the top of the tree if it is closer)
+ *   keep      dev [n_nodes] uint8 out : 1 iff the node survives (it is a new root, above one, or below one)
+ * Asynchronous on the ctx stream. */
+int mht_prune(mht_ctx* ctx, int32_t n_nodes, const int32_t* parent, int32_t T, const int32_t* sel, const int32_t* window,
+              int32_t* new_root, uint8_t* keep);
+
 /* ---- the device-resident hypothesis forest: Tracker.addMeasurementList end to end -----------------------------
  * Replaces steps 1-6 of tracker.py:162-307 (grow :207-209, cluster :220, optimise :228-236, terminate :252-253,
  * N-scan prune :258 = seam (iv) Tracker._nScanPruning, tracker.py:1219-1231 / pyTarget.py:343-356) without a host

@@ -93,6 +93,7 @@ def _declare(lib):
         "mht_cluster": [vp, i32, i32, vp, vp],
         "mht_solve_blp": [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(dbl), C.POINTER(i32),
                           C.POINTER(i32), C.POINTER(i32)],
+        "mht_prune": [vp, i32, vp, i32, vp, vp, vp, vp],
         "mht_forest_create": [vp, C.POINTER(MhtModel), C.POINTER(MhtForestConfig)],
         "mht_forest_add_targets": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
         "mht_forest_add_targets_dev": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],

@@ -137,3 +137,51 @@ def test_blp_clusters_without_certificate(gpu_ctx, gold_dir):
         sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=200)
         assert st == 2 and 0 < nd < 6000, (len(inst["cols"]), st, it, nd)
         assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
+
+
+def test_prune_seam_matches_oracle_trees():
+    """Seam (iv) mht_prune against the oracle's Node.prune_depth (pyTarget.py:343-356) on random trees: new roots and the exact
+    set of surviving nodes, for windows shorter, equal to and longer than the tree."""
+    import torch
+    from pymht_amd import _lib
+    from pymht_amd.device import Context
+    rng = np.random.default_rng(11)
+    ctx = Context(0)
+    for trial in range(6):
+        T = int(rng.integers(1, 40))
+        nodes, roots = [], []
+
+        def grow(node, depth, maxd):
+            nodes.append(node)
+            if depth >= maxd:
+                return
+            node.kids = [orc.Node(0.0, depth + 1, None, None, parent=node, meas=k) for k in range(int(rng.integers(1, 4)))]
+            for k in node.kids:
+                grow(k, depth + 1, maxd)
+        for t in range(T):
+            r = orc.Node(0.0, 0, None, None, ID=t)
+            r.is_root = True
+            roots.append(r)
+            grow(r, 0, int(rng.integers(0, 6)))
+        idx = {id(n): i for i, n in enumerate(nodes)}
+        parent = np.array([-1 if n.parent is None else idx[id(n.parent)] for n in nodes], np.int32)
+        sel_nodes = [r.leaves()[int(rng.integers(0, len(r.leaves())))] for r in roots]
+        window = rng.integers(0, 7, size=T).astype(np.int32)
+        sel = np.array([idx[id(s)] for s in sel_nodes], np.int32)
+        want_root = np.array([idx[id(s.prune_depth(int(w)))] for s, w in zip(sel_nodes, window)], np.int32)
+        alive = set()
+        for r in roots:      # what is still reachable from the tops after the reference's pruning
+            stack = [r]
+            while stack:
+                n = stack.pop()
+                alive.add(idx[id(n)])
+                if n.kids:
+                    stack.extend(n.kids)
+        dp, ds, dw = (torch.from_numpy(a).cuda() for a in (parent, sel, window))
+        nr = torch.zeros(T, dtype=torch.int32, device="cuda")
+        keep = torch.zeros(len(nodes), dtype=torch.uint8, device="cuda")
+        _lib.check(ctx.lib.mht_prune(ctx.handle, len(nodes), dp.data_ptr(), T, ds.data_ptr(), dw.data_ptr(), nr.data_ptr(), keep.data_ptr()))
+        ctx.synchronize()
+        assert np.array_equal(nr.cpu().numpy(), want_root), trial
+        assert set(np.nonzero(keep.cpu().numpy())[0].tolist()) == alive, trial
+    ctx.close()
