@@ -237,6 +237,34 @@ int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t by
 int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                      double* x, double* cnllr, float* P, int32_t* n_out);
 
+/* ---- step 7 of a scan: M-of-N track initiation on the device (tracker.py:264-278 -> initiators/m_of_n.py:215-478) -------------
+ * What Tracker.__init__ hands to m_of_n.Initiator (tracker.py:66-72) plus the model constants the initiator imports (pv.P0, pv.Q's
+ * sigmaQ, m_of_n.py:12-16 gamma = chi2(2).ppf(0.99)). */
+typedef struct mht_initiator_config {
+    int32_t m_required, n_checks;   /* Tracker.M_required / N_checks */
+    int32_t max_meas;               /* measurements per scan */
+    int32_t max_prelim;             /* preliminary tracks kept */
+    int32_t max_born;               /* new targets per scan */
+    double v_max;                   /* Tracker.maxSpeedMS */
+    double gamma;                   /* gate of the preliminary tracks */
+    double merge_threshold;         /* Tracker.mergeThreshold */
+    double default_pd;
+    float C[8], R[4], P0[16];       /* C_RADAR, R_RADAR(), pv.P0 */
+    float sigma_q;                  /* scale of pv.Q */
+} mht_initiator_config;
+typedef struct mht_initiator mht_initiator;
+int mht_initiator_create(mht_ctx* ctx, mht_initiator** out, const mht_initiator_config* cfg);
+int mht_initiator_destroy(mht_initiator* in);
+/* Initiator.processMeasurements (m_of_n.py:233-244) for one scan, asynchronous on the ctx stream: z dev (M,2) float32, the scan;
+ * used dev [ceil(M/64)] uint64 or NULL: bit j set = measurement j was gated by a track and is not offered to the initiator
+ * (tracker.py:266, MeasurementList.filterUnused); now = scan time stamp. */
+int mht_initiator_step(mht_initiator* in, const float* z, int32_t M, const uint64_t* used, double now);
+/* The targets the last step gave birth to (host arrays, any may be NULL): x0 [n][4] (float32 values), P0 [n][16],
+ * meas [n] measurementNumber (1-based index among the UNUSED measurements, 0 for a merged target) -- and the sizes of the
+ * initiator's lists.  Synchronises. */
+int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P0, int32_t* meas, int32_t* n_born,
+                       int32_t* n_prelim, int32_t* n_seeds);
+
 /* ---- a group of independent sectors on one device (BASELINE config 4: four sensor sectors = four independent Tracker
  * instances, pymht/tracker.py:39-137; nothing in tracker.py:162-307 couples two Tracker objects) -------------------------------
  * The members' forests step TOGETHER with one launch per stage (grow, cluster, ILP) for the whole group: a single sector is a

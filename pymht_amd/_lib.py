@@ -44,6 +44,13 @@ class MhtScanReport(C.Structure):
                 ("used_words", C.c_int32), ("pad", C.c_int32 * 3), ("used", C.c_void_p), ("targets", C.c_void_p)]
 
 
+class MhtInitiatorConfig(C.Structure):
+    _fields_ = [("m_required", C.c_int32), ("n_checks", C.c_int32), ("max_meas", C.c_int32), ("max_prelim", C.c_int32),
+                ("max_born", C.c_int32), ("v_max", C.c_double), ("gamma", C.c_double), ("merge_threshold", C.c_double),
+                ("default_pd", C.c_double), ("C", C.c_float * 8), ("R", C.c_float * 4), ("P0", C.c_float * 16),
+                ("sigma_q", C.c_float)]
+
+
 class MhtError(RuntimeError):
     def __init__(self, code, message):
         RuntimeError.__init__(self, "libmht_amd error %d: %s" % (code, message))
@@ -105,6 +112,10 @@ def _declare(lib):
         "mht_forest_debug_read": [vp, C.c_char_p, vp, i64],
         "mht_forest_set_timing": [vp, i32],
         "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5), C.POINTER(i32)],
+        "mht_initiator_create": [vp, C.POINTER(vp), C.POINTER(MhtInitiatorConfig)],
+        "mht_initiator_destroy": [vp],
+        "mht_initiator_step": [vp, vp, i32, vp, dbl],
+        "mht_initiator_born": [vp, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "mht_group_create": [C.POINTER(vp), i32, C.POINTER(vp)],
         "mht_group_step": [vp, C.POINTER(vp), C.POINTER(i32)],
         "mht_group_destroy": [vp],

@@ -27,7 +27,6 @@
 namespace mht {
 
 constexpr int BLP_THREADS = 256;
-constexpr int BLP_UW = 512;       // words of the cluster's measurement-node bitset kept in LDS (32768 nodes)
 constexpr double DINF = 1.0e300;
 constexpr int BIG_MAXH = 2048, BIG_MAXR = 1024, BIG_MAXK = 256;      // default LDS tier: columns, rows, targets of a cluster solved out of LDS
 // (member tables hold cap_k + 4 entries: (cap_k + 4) * 4 and * 8 are multiples of 16 bytes when cap_k is a multiple of 4)
