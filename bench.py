@@ -61,16 +61,18 @@ def prepass(sc, device):
     from pymht_amd.utils.classDefinitions import MeasurementList
     trk = make_tracker(sc, device, deviceTiming=False)
     births, stats = [], []
-    orig = trk._add_targets
+    orig = trk._apply_births
 
-    def recording(targets):
-        acc = orig(targets)
-        cur = births[-1] if births else None
-        if cur is not None:
-            cur.extend(acc)
-        return acc
+    class Born:          # what Replay needs of a new target
+        def __init__(self, x0, P0, meas):
+            self.x_0, self.P_0, self.measurementNumber = x0, P0, meas
 
-    trk._add_targets = recording
+    def recording(b, scanTime, scanNumber, z_unused):
+        orig(b, scanTime, scanNumber, z_unused)
+        for r in b[b["id"] >= 0]:
+            births[-1].append(Born(r["x0"].astype(np.float32), r["P0"].reshape(4, 4).copy(), int(r["meas"])))
+
+    trk._apply_births = recording
     t0 = time.time()
     for z, t in zip(sc["scans"], sc["times"]):
         births.append([])
@@ -158,7 +160,7 @@ def cpu_baseline(sc, n_warm, n_timed):
     host: stages Process+Cluster+Optim+Terminate+N-Prune of `n_timed` scans after `n_warm` warm-up scans."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mht_oracle as orc
-    from pymht_amd.initiators.m_of_n import Initiator
+    from m_of_n_oracle import Initiator
     from pymht_amd.utils.classDefinitions import MeasurementList
     from pymht_amd.models import pv
 

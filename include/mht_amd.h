@@ -173,6 +173,14 @@ typedef struct mht_target_report {
     int32_t cluster;    /* smallest target index of this target's cluster (tracker.py:961-974) */
 } mht_target_report;
 
+/* one target the device initiator gave birth to after the scan (mht_forest_initiate) */
+typedef struct mht_birth_report {
+    int32_t id;          /* Target.ID, or -1 if Tracker.initiateTarget discarded the candidate (too close to a current track) */
+    int32_t meas;        /* measurementNumber: 1-based index among the scan's UNUSED measurements, 0 for a merged target */
+    double x0[4];        /* float32 values */
+    float P0[16];
+} mht_birth_report;
+
 typedef struct mht_scan_report {
     int32_t scan;          /* scanNumber just processed */
     int32_t n_targets;     /* targets before termination (= number of records) */
@@ -186,9 +194,11 @@ typedef struct mht_scan_report {
     int32_t blp_iters_max;
     int32_t error;         /* 0 or MHT_E_CAPACITY if a pool overflowed during the scan */
     int32_t used_words;    /* number of valid words in `used` */
-    int32_t pad[3];
+    int32_t n_births;      /* candidates of the device initiator after this scan (0 without mht_forest_initiate) */
+    int32_t pad[2];
     const uint64_t* used;              /* host: bit j set iff measurement j was gated by some leaf */
     const mht_target_report* targets;  /* host: n_targets records */
+    const mht_birth_report* births;    /* host: n_births records */
 } mht_scan_report;
 
 int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg);
@@ -264,6 +274,12 @@ int mht_initiator_step(mht_initiator* in, const float* z, int32_t M, const uint6
  * initiator's lists.  Synchronises. */
 int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P0, int32_t* meas, int32_t* n_born,
                        int32_t* n_prelim, int32_t* n_seeds);
+
+/* Step 7 behind a forest step, on the stream, no host round trip: runs the scan's commit, offers the scan's unused measurements
+ * (tracker.py:266) to the initiator and hands its confirmed candidates to Tracker.initiateTarget's device twin
+ * (mht_forest_add_targets_dev, neighbour test included).  z / M: the scan just stepped; now: its time stamp.  The candidates and
+ * their fate appear in the report of that scan (mht_scan_report::births).  The initiator must have been created on the same ctx. */
+int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now);
 
 /* ---- a group of independent sectors on one device (BASELINE config 4: four sensor sectors = four independent Tracker
  * instances, pymht/tracker.py:39-137; nothing in tracker.py:162-307 couples two Tracker objects) -------------------------------

@@ -24,7 +24,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 import mht_oracle as orc  # noqa: E402
-from pymht_amd.initiators.m_of_n import Initiator  # noqa: E402
+from m_of_n_oracle import Initiator  # noqa: E402
 from pymht_amd.models import pv  # noqa: E402
 from pymht_amd.utils.classDefinitions import MeasurementList  # noqa: E402
 from pymht_amd.utils.scenario import make_scenario  # noqa: E402

@@ -88,7 +88,7 @@ def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=Tr
     """Run reference and oracle side by side on scenario `sc`; compare bitwise; dump a fixture."""
     T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
     ML = mods["classDefinitions"].MeasurementList
-    from pymht_amd.initiators.m_of_n import Initiator
+    from m_of_n_oracle import Initiator
     from pymht_amd.utils.classDefinitions import MeasurementList as MyML
     from pymht_amd.models import pv as mypv
 

@@ -48,7 +48,7 @@ def make_stream(seed, n_obj, n_scans, radius, clutter, p_d, period):
 if __name__ == "__main__":
     mods = refimport.load()
     ref_m, ref_cd, ref_pv = mods["m_of_n"], mods["classDefinitions"], mods["pv"]
-    from pymht_amd.initiators.m_of_n import Initiator
+    from m_of_n_oracle import Initiator
     from pymht_amd.models import pv
     from pymht_amd.utils.classDefinitions import MeasurementList
     fx, case = {}, 0

@@ -41,7 +41,12 @@ class MhtScanReport(C.Structure):
     _fields_ = [("scan", C.c_int32), ("n_targets", C.c_int32), ("n_alive", C.c_int32), ("n_leaves_in", C.c_int32),
                 ("n_children", C.c_int32), ("n_leaves_out", C.c_int32), ("n_clusters", C.c_int32), ("n_ilp", C.c_int32),
                 ("n_branched", C.c_int32), ("n_limit", C.c_int32), ("blp_iters_max", C.c_int32), ("error", C.c_int32),
-                ("used_words", C.c_int32), ("pad", C.c_int32 * 3), ("used", C.c_void_p), ("targets", C.c_void_p)]
+                ("used_words", C.c_int32), ("n_births", C.c_int32), ("pad", C.c_int32 * 2), ("used", C.c_void_p),
+                ("targets", C.c_void_p), ("births", C.c_void_p)]
+
+
+class MhtBirthReport(C.Structure):
+    _fields_ = [("id", C.c_int32), ("meas", C.c_int32), ("x0", C.c_double * 4), ("P0", C.c_float * 16)]
 
 
 class MhtInitiatorConfig(C.Structure):
@@ -116,6 +121,7 @@ def _declare(lib):
         "mht_initiator_destroy": [vp],
         "mht_initiator_step": [vp, vp, i32, vp, dbl],
         "mht_initiator_born": [vp, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+        "mht_forest_initiate": [vp, vp, vp, i32, dbl],
         "mht_group_create": [C.POINTER(vp), i32, C.POINTER(vp)],
         "mht_group_step": [vp, C.POINTER(vp), C.POINTER(i32)],
         "mht_group_destroy": [vp],

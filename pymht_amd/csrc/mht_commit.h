@@ -31,7 +31,7 @@ struct TTable {           // one buffer of the target table
 
 struct ReportHeader {     // device image of mht_scan_report up to the host pointers
     int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
-        blp_iters_max, error, used_words, pad[3];
+        blp_iters_max, error, used_words, n_births, pad[2];
 };
 
 struct CommitDyn { int scan, M, W; };      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
@@ -180,6 +180,7 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
         h.blp_iters_max = s_itmax;
         h.error = e_over ? MHT_E_CAPACITY : 0;
         h.used_words = dyn.W;
+        h.n_births = 0;
         a.cnt->L_in = L_in;
         a.cnt->n_children = nCh;
         a.cnt->nT = nAlive;

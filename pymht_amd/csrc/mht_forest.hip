@@ -28,6 +28,7 @@ namespace mht {
 
 constexpr int MAXR = 16;
 constexpr int EV_POOL = 64;
+constexpr int BIRTH_CAP = 256;      // candidates of the device initiator per scan that the report can hold
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
 
@@ -45,7 +46,9 @@ struct AddArgs {
     FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
     int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
-    Model model; float4* G; int root_base;   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
+    Model model; float4* G; int root_base;
+    const int32_t* n_dev;      // number of candidates in device memory (or null: n)
+    ReportHeader* hdr; mht_birth_report* births;      // report block of the device initiator's candidates (or null)   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
 };
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates.  The test against the existing leaves
@@ -54,7 +57,13 @@ struct AddArgs {
 __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
     const int tid = threadIdx.x;
     const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
-    for (int q = tid; q < a.n; q += 1024) a.near[q] = 0;
+    int an = a.n;
+    if (a.n_dev) { const int nd = *a.n_dev; an = nd < an ? nd : an; }
+    if (an <= 0) {          // nothing to admit (the usual case behind the device initiator)
+        if (a.hdr && tid == 0) a.hdr->n_births = 0;
+        return;
+    }
+    for (int q = tid; q < an; q += 1024) a.near[q] = 0;
     __syncthreads();
     if (a.check) {
         for (int i = tid; i < L0; i += 1024) {
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
             const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
             const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
-            for (int q = 0; q < a.n; ++q) {
+            for (int q = 0; q < an; ++q) {
                 const double dx = lx - a.x0[q * 4], dy = ly - a.x0[q * 4 + 1];
                 if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
             }
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
     __shared__ int s_adm[2048];                 // candidate indices admitted so far (chunked if more)
     if (tid == 0) s_nadm = 0;
     __syncthreads();
-    for (int q = 0; q < a.n; ++q) {
+    for (int q = 0; q < an; ++q) {
         if (tid == 0) s_near = a.near[q];
         __syncthreads();
         if (a.check && !s_near) {
@@ -134,9 +143,17 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
                 a.ids[q] = -1;
             }
             if (a.accepted) a.accepted[q] = (uint8_t)ok;
+            if (a.births) {      // the candidate and its fate, for the host mirror (mht_scan_report::births)
+                mht_birth_report& b = a.births[q];
+                b.id = ok ? a.cnt->id_counter - 1 : -1;
+                b.meas = a.meas[q];
+                for (int k = 0; k < 4; ++k) b.x0[k] = a.x0[q * 4 + k];
+                for (int e = 0; e < 16; ++e) b.P0[e] = a.P0[q * 16 + e];
+            }
         }
         __syncthreads();
     }
+    if (a.hdr && tid == 0) a.hdr->n_births = an;
     // gains of the admitted roots (what fgrow_kernel's chain workgroups compute for every other node one scan ahead)
     for (int k = tid; k < s_nadm; k += 1024) {
         const int q = s_adm[k & 2047];
@@ -228,7 +245,7 @@ struct Forest {
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
-    char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off;
+    char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;
     float* z_dev; float* z_host;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
@@ -390,7 +407,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->pds = f->PD <= 8 ? 8 : 16;
 
     f->used_off = sizeof(ReportHeader);
-    f->rec_off = f->used_off + (size_t)(f->Mpad / 64) * 8;
+    f->birth_off = (f->used_off + (size_t)(f->Mpad / 64) * 8 + 15) & ~(size_t)15;
+    f->rec_off = f->birth_off + (size_t)BIRTH_CAP * sizeof(mht_birth_report);
     f->report_bytes = f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report);
     Arena probe;
     f->layout(probe);                     // first pass: size
@@ -849,6 +867,49 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     return rc;
 }
 
+namespace mht {
+int initiator_launch(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now);
+struct InitArgs;
+void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
+                         const int32_t** n, int* cap, mht_ctx** ctx);
+}
+
+extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now) {
+    MHT_REQUIRE(ctx && ctx->forest && in, "mht_forest_initiate: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->scan > 0, "mht_forest_initiate: no scan processed yet");
+    MHT_REQUIRE(M == f->last_M, "mht_forest_initiate: M=%d is not the scan just stepped (M=%d)", M, f->last_M);
+    const double* bx; const float* bP; const uint8_t* bfl; const double* bpd; const int32_t* bme; const int32_t* bn; int cap; mht_ctx* ictx;
+    initiator_born_ptrs(in, &bx, &bP, &bfl, &bpd, &bme, &bn, &cap, &ictx);
+    MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
+    MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // the used-measurement mask of the scan is part of its commit
+    int rc = initiator_launch(in, z, M, reinterpret_cast<const unsigned long long*>(f->report_dev + f->used_off), now);
+    if (rc) return rc;
+    AddArgs a = {};
+    a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
+    a.check = 1; a.thr = f->cfg.merge_threshold;
+    const int nb = (f->scan + 1) & 1;
+    a.layer = f->layer[f->scan % f->R];
+    a.tab = f->tab[nb]; a.vidx = nb;
+    a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
+    a.near = f->near;
+    fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
+    a.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
+    a.births = reinterpret_cast<mht_birth_report*>(f->report_dev + f->birth_off);
+    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    // the host does not know how many of the candidates exist: every bound moves by the most there can be
+    f->nT_ub = (f->nT_ub + cap < f->Tcap) ? f->nT_ub + cap : f->Tcap;
+    f->L_ub = (f->L_ub + cap < f->Ncap) ? f->L_ub + cap : f->Ncap;
+    f->births_since_step += cap;
+    f->births_cum += cap;
+    f->report_pending = true;      // (the births block of the report changed)
+    return MHT_OK;
+}
+
 extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step_host: no forest");
     Forest* f = ctx->forest;
@@ -878,6 +939,7 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     memcpy(out, h, sizeof(ReportHeader));
     out->used = reinterpret_cast<const uint64_t*>(f->report_host + f->used_off);
     out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);
+    out->births = reinterpret_cast<const mht_birth_report*>(f->report_host + f->birth_off);
     // tighten the host-side bounds; targets added since that scan was launched are not in its report
     f->nT_ub = h->n_alive + f->births_since_step < f->Tcap ? h->n_alive + f->births_since_step : f->Tcap;
     f->L_ub = h->n_leaves_out + f->births_since_step < f->Ncap ? h->n_leaves_out + f->births_since_step : f->Ncap;

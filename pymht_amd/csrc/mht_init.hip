@@ -561,8 +561,11 @@ int initiator_launch(mht_initiator* in, const float* z, int M, const unsigned lo
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
-const InitArgs& initiator_args(const mht_initiator* in) { return in->args; }
-int initiator_born_cap(const mht_initiator* in) { return in->cfg.max_born; }
+void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
+                         const int32_t** n, int* cap, mht_ctx** ctx) {
+    const InitArgs& a = in->args;
+    *x = a.born_x; *P = a.born_P; *fl = a.born_flags; *pd = a.born_pd; *meas = a.born_meas; *n = a.born_n; *cap = in->cfg.max_born; *ctx = in->ctx;
+}
 }  // namespace mht
 
 using namespace mht;

@@ -29,6 +29,8 @@ _REPORT_DTYPE = np.dtype([("id", "<i4"), ("status", "<i4"), ("sel_node", "<i4"),
                           ("sel_x", "<f8", (4,)), ("sel_cnllr", "<f8"), ("score", "<f8"), ("root_cnllr", "<f8"),
                           ("root_x", "<f8", (4,)), ("root_meas", "<i4"), ("cluster", "<i4")])
 assert _REPORT_DTYPE.itemsize == C.sizeof(_lib.MhtTargetReport)
+_BIRTH_DTYPE = np.dtype([("id", "<i4"), ("meas", "<i4"), ("x0", "<f8", (4,)), ("P0", "<f4", (16,))])
+assert _BIRTH_DTYPE.itemsize == C.sizeof(_lib.MhtBirthReport)
 _STATUS_TAG = {0: activeTag, 1: outofrangeTag, 2: toolowscoreTag, 3: toolowscoreTag}
 
 
@@ -64,8 +66,6 @@ class Tracker():
         self.M_required = kwargs.get('M_required', 2)
         self.N_checks = kwargs.get('N_checks', 3)
         self.mergeThreshold = 4 * (model.sigmaR_RADAR_tracker ** 2)
-        self.initiator = m_of_n.Initiator(self.M_required, self.N_checks, self.maxSpeedMS, self.C, self.R_RADAR,
-                                          self.mergeThreshold)
         # Tracker storage (tracker.py:74-84): the forest lives on the device; the host keeps flat NumPy tables and
         # builds `Target` views only when somebody looks (properties __targetList__, __trackNodes__, ... below)
         self.__scanHistory__ = []
@@ -111,6 +111,10 @@ class Tracker():
         cfg.merge_threshold = float(self.mergeThreshold)
         self._cfg = cfg
         _lib.check(self._lib.mht_forest_create(self._ctx.handle, C.byref(self._model), C.byref(cfg)))
+        # Target initiator (tracker.py:61-72): on the device, behind every scan's commit (mht_forest_initiate)
+        self.initiator = m_of_n.Initiator(self.M_required, self.N_checks, self.maxSpeedMS, self.C, self.R_RADAR, self.mergeThreshold,
+                                          ctx=self._ctx, maxMeasurements=cfg.max_meas, default_pd=self.default_P_d) \
+            if self.useInitiator else None
         self._timing = bool(kwargs.get('deviceTiming', True))
         _lib.check(self._lib.mht_forest_set_timing(self._ctx.handle, int(self._timing)))
         # host mirror of the target list (one row per target, target-list order)
@@ -124,7 +128,7 @@ class Tracker():
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
         self._dead = False          # a device step failed: the forest cannot go on
-        self._staged = self._staged_np = None
+        self._staged = self._staged_prev = self._staged_np = None
         self.lastScanStats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -183,7 +187,8 @@ class Tracker():
         # steps 1-6 on the device.  The host mirror is only touched once the device has accepted the scan: a rejected step
         # (too many measurements, dead forest) leaves the tracker exactly as it was.
         try:
-            _lib.check(self._lib.mht_forest_step_host(self._ctx.handle, z.ctypes.data_as(C.c_void_p), z.shape[0]))
+            zd = self._upload_scan(z)
+            _lib.check(self._lib.mht_forest_step(self._ctx.handle, zd, z.shape[0]))
         except _lib.MhtError as e:
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
@@ -209,20 +214,30 @@ class Tracker():
                         "(the reference would gate them in %s)", m.dtype, m.dtype)
         return z
 
+    def _upload_scan(self, z):
+        """The scan in device memory (a torch tensor of the tracker, kept alive until the scan after the next): device pointer."""
+        import torch
+        self._staged_np = z
+        t = torch.from_numpy(z if z.size else np.zeros((1, 2), np.float32)).to(self._ctx.device, non_blocking=True)
+        self._staged_prev, self._staged = self._staged, t
+        return t.data_ptr()
+
     def _stage_scan(self, scanList, aisList=None, **kwargs):
         """SectorGroup: checks + the scan in device memory (a torch tensor kept alive until the next scan)."""
-        import torch
         z = self._accept_scan(scanList, aisList, kwargs)
-        self._staged_np = z
-        self._staged = torch.from_numpy(z if z.size else np.zeros((1, 2), np.float32)).to(self._ctx.device)
-        if z.size == 0:
-            self._staged = self._staged[:0]
-        return self._staged
+        self._upload_scan(z)
+        return self._staged[:z.shape[0]] if z.size else self._staged[:0]
 
     def _finish_scan(self, scanList, z=None, aisList=None):
         """Everything after the device step: report, host mirror, step 7 (track initiation), timing log."""
         if z is None:
             z = self._staged_np
+        self.tic['Init'] = time.time()
+        if self.useInitiator:
+            # 7 -- Initiate new tracks (tracker.py:264-278): on the device, right behind the scan's commit; what it gave birth to
+            # comes back with the scan's report
+            zp = self._staged.data_ptr()
+            _lib.check(self._lib.mht_forest_initiate(self._ctx.handle, self.initiator.handle, zp, z.shape[0], float(scanList.time)))
         rep = _lib.MhtScanReport()
         rc = self._lib.mht_forest_report(self._ctx.handle, C.byref(rep))
         if rc == _lib.MHT_E_LIMIT:
@@ -259,14 +274,13 @@ class Tracker():
         self.toc['ILP-Prune'] = 0.0
         self.toc['DynN'] = 0.0
         self.nOptimSolved = rep.n_ilp
+        births = None
+        if rep.n_births:
+            births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * _BIRTH_DTYPE.itemsize,)) \
+                .view(_BIRTH_DTYPE).copy()
         self._apply_report(recs, scanTime, scanNumber, z)
-        # 7 -- Initiate new tracks (tracker.py:264-278), host side
-        self.tic['Init'] = time.time()
-        if self.useInitiator:
-            unused = scanList.filterUnused(unusedRadarMeasurementIndices) if hasattr(scanList, "filterUnused") else \
-                MeasurementList(scanTime, z[unusedRadarMeasurementIndices])
-            new_initial_targets = self.initiator.processMeasurements(unused, [])
-            self._add_targets(new_initial_targets)
+        if births is not None:
+            self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
         self.toc['Init'] = time.time() - self.tic['Init']
         self.toc['Total'] = time.time() - self.tic['Total']
         if self.toc['Total'] > self.radarPeriod:
@@ -279,6 +293,30 @@ class Tracker():
                                   leaves_out=rep.n_leaves_out, clusters=rep.n_clusters, ilp=rep.n_ilp,
                                   branched=rep.n_branched, blp_iters_max=rep.blp_iters_max, limit=rep.n_limit,
                                   unused=unusedRadarMeasurementIndices)
+
+    def _apply_births(self, births, scanTime, scanNumber, z_unused):
+        """The device initiator's candidates that Tracker.initiateTarget's device twin admitted: append them to the host mirror."""
+        ok = births["id"] >= 0
+        if not ok.any():
+            return
+        b = births[ok]
+        n = len(b)
+        tb = self._tbl
+        x0 = b["x0"].astype(np.float32)
+        tb["id"] = np.concatenate([tb["id"], b["id"].astype(np.int64)])
+        tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(n, scanNumber, np.int64)])
+        tb["root_node"] = np.concatenate([tb["root_node"], np.full(n, -1, np.int64)])
+        tb["root_meas"] = np.concatenate([tb["root_meas"], b["meas"].astype(np.int64)])
+        tb["root_x"] = np.concatenate([tb["root_x"], b["x0"]], axis=0)
+        tb["root_cnllr"] = np.concatenate([tb["root_cnllr"], np.zeros(n)])
+        tb["root_time"] = np.concatenate([tb["root_time"], np.full(n, float(scanTime))])
+        tb["f32"] = np.concatenate([tb["f32"], np.ones(n, bool)])
+        for i in range(n):
+            m = int(b["meas"][i])
+            self._birth[int(b["id"][i])] = (scanTime, scanNumber, x0[i], b["P0"][i].reshape(4, 4).copy(), (m if m > 0 else None),
+                                            (z_unused[m - 1] if m > 0 else None), activeTag)
+        self.trackIdCounter = int(b["id"].max()) + 1
+        self._views.clear()
 
     def _apply_report(self, recs, scanTime, scanNumber, z):
         """Fold the scan report into the host tables (vectorised; no per-target Python objects are created here)."""
@@ -499,4 +537,7 @@ class Tracker():
         return self.__clusterList__
 
     def close(self):
+        if self.initiator is not None:
+            self.initiator.close()
+            self.initiator = None
         self._ctx.close()

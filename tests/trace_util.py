@@ -21,7 +21,7 @@ def sha(a):
 
 
 def make_oracle(g, with_initiator=True):
-    from pymht_amd.initiators.m_of_n import Initiator
+    from m_of_n_oracle import Initiator
     from pymht_amd.utils.classDefinitions import MeasurementList
     from pymht_amd.models import pv
     init = None
@@ -34,6 +34,20 @@ def make_oracle(g, with_initiator=True):
     return o
 
 
+def states_close(a, b, rel=1e-6):
+    """The north star's state tolerance (1e-6 relative): relative to the largest component of each state vector -- a velocity near
+    zero carries the rounding of the ~1e2..1e3 m positions it was differenced from.  Needed for float32 chains only: targets born
+    from the device initiator start from float32 states that agree with the reference's to an ulp, not bit for bit (its host BLAS
+    orders 4-term dot products its own way); float64 chains of pre-initialised targets are bit-exact."""
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1, 4), np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    if a.shape != b.shape:
+        return False
+    if a.size == 0:
+        return True
+    scale = np.maximum(np.abs(a).max(axis=1, keepdims=True), 1.0)
+    return bool(np.all(np.abs(a - b) <= rel * scale))
+
+
 def check_scan_against_fixture(g, k, ids, sel, clusters, n_leaves, leaf=None, score_atol=0.0):
     p = "s%02d_" % k
     assert np.array_equal(ids, g[p + "ids"]), "scan %d target ids" % k
@@ -41,7 +55,7 @@ def check_scan_against_fixture(g, k, ids, sel, clusters, n_leaves, leaf=None, sc
     if score_atol == 0.0:
         assert np.array_equal(sel["x"], g[p + "sel_x"]) and np.array_equal(sel["cnllr"], g[p + "sel_cnllr"])
     else:
-        assert np.allclose(sel["x"], g[p + "sel_x"], rtol=1e-6, atol=1e-9)
+        assert states_close(sel["x"], g[p + "sel_x"]), "scan %d selected states" % k
         assert np.allclose(sel["cnllr"], g[p + "sel_cnllr"], rtol=0, atol=score_atol)
     ptr, mem = g[p + "cl_ptr"], g[p + "cl_members"]
     assert len(clusters) == len(ptr) - 1
@@ -55,9 +69,9 @@ def check_scan_against_fixture(g, k, ids, sel, clusters, n_leaves, leaf=None, sc
                 assert np.array_equal(leaf["x"], g[p + "leaf_x"]) and np.array_equal(leaf["cnllr"], g[p + "leaf_cnllr"])
                 assert np.array_equal(leaf["P"], g[p + "leaf_P"])
             else:
-                assert np.allclose(leaf["x"], g[p + "leaf_x"], rtol=1e-6, atol=1e-9)
+                assert states_close(leaf["x"], g[p + "leaf_x"]), "scan %d leaf states" % k
                 assert np.allclose(leaf["cnllr"], g[p + "leaf_cnllr"], rtol=0, atol=score_atol)
-                assert np.array_equal(leaf["P"], g[p + "leaf_P"])
+                assert np.allclose(leaf["P"], g[p + "leaf_P"], rtol=2e-6, atol=1e-6)
     else:
         assert n_leaves == int(g[p + "leaf_n"][0])
 

@@ -6,7 +6,7 @@ from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
-sc = make_config('cfg3', seed=5446, n_scans=n)
+sc = make_config('cfg3', seed=5446, n_scans=n, confine=True)
 trk = bench.make_tracker(sc, 0)
 scans = [MeasurementList(float(t), z) for z, t in zip(sc['scans'], sc['times'])]
 for s in scans[:20]:
