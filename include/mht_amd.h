@@ -222,8 +222,15 @@ int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const 
 int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
 /* Same with z in host memory (copied through a pinned staging buffer of the ctx). */
 int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M);
-/* Wait for the last step and expose its report (pointers stay valid until the next call on this ctx). */
+/* Start the transfer of the last step's report into pinned host memory (runs the scan's commit first if it is still pending) and
+ * return at once.  A host that issues the next step before it calls mht_forest_report overlaps its own work with the device's;
+ * two transfers can be in flight. */
+int mht_forest_report_begin(mht_ctx* ctx);
+/* Wait for the last step (or for the transfer mht_forest_report_begin started) and expose its report (pointers stay valid until
+ * the next but one mht_forest_report_begin on this ctx). */
 int mht_forest_report(mht_ctx* ctx, mht_scan_report* out);
+/* The report whose transfer the last (which = 0) or the last but one (which = 1) mht_forest_report_begin started. */
+int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out);
 /* Snapshot of the current leaves in target-list / DFS order (pyTarget.getLeafNodes order): any pointer may be
  * NULL.  x host [n][4], P host [n][16], cnllr host [n], meas/target/id/node host [n] int32, flags host [n] uint8.
  * capacity = length of the host arrays; *n_out = number of leaves.  Synchronises. */

@@ -112,6 +112,8 @@ def _declare(lib):
         "mht_forest_step": [vp, vp, i32],
         "mht_forest_step_host": [vp, vp, i32],
         "mht_forest_report": [vp, C.POINTER(MhtScanReport)],
+        "mht_forest_report_begin": [vp],
+        "mht_forest_report_get": [vp, i32, C.POINTER(MhtScanReport)],
         "mht_forest_leaves": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_chain": [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_debug_read": [vp, C.c_char_p, vp, i64],

@@ -246,6 +246,7 @@ struct Forest {
     int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
     char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;
+    char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     float* z_dev; float* z_host;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
@@ -327,7 +328,10 @@ void forest_destroy(mht_ctx* ctx) {
     Forest* f = ctx->forest;
     if (!f) return;
     if (f->arena.base) (void)hipFree(f->arena.base);
-    if (f->report_host) (void)hipHostFree(f->report_host);
+    for (int b = 0; b < 2; ++b) {
+        if (f->report_host2[b]) (void)hipHostFree(f->report_host2[b]);
+        if (f->rep_ev[b]) (void)hipEventDestroy(f->rep_ev[b]);
+    }
     if (f->z_host) (void)hipHostFree(f->z_host);
     if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
@@ -441,9 +445,13 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
         }
     }
     MHT_HIP_CHECK(hipMemsetAsync(base, 0, total, ctx->stream));
-    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host), f->report_bytes, hipHostMallocDefault));
+    for (int b = 0; b < 2; ++b) {
+        MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host2[b]), f->report_bytes, hipHostMallocDefault));
+        memset(f->report_host2[b], 0, f->report_bytes);
+        MHT_HIP_CHECK(hipEventCreateWithFlags(&f->rep_ev[b], hipEventDisableTiming));
+    }
+    f->report_host = f->report_host2[0];
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
-    memset(f->report_host, 0, f->report_bytes);
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
@@ -923,26 +931,67 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
     return mht_forest_step(ctx, f->z_dev, M);
 }
 
+// Starts the transfer of the last scan's report (commit first, if it is still pending) into one of two pinned host buffers and
+// returns; mht_forest_report waits for it.  A host that steps scan k+1 before it reads the report of scan k overlaps its own work
+// with the device's.
+extern "C" int mht_forest_report_begin(mht_ctx* ctx) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_report_begin: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->scan > 0, "mht_forest_report_begin: no scan processed yet");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!f->report_pending) return MHT_OK;
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    f->rep_slot ^= 1;
+    if (f->rep_started[f->rep_slot]) MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[f->rep_slot]));      // (the buffer about to be reused)
+    const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
+    MHT_HIP_CHECK(hipMemcpyAsync(f->report_host2[f->rep_slot], f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->rep_slot], ctx->stream));
+    f->report_pending = false;
+    f->rep_inflight = true;
+    f->rep_started[f->rep_slot] = true;
+    return MHT_OK;
+}
+
+static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out);
+
 extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     MHT_REQUIRE(ctx && ctx->forest && out, "mht_forest_report: null argument");
     Forest* f = ctx->forest;
     MHT_REQUIRE(f->scan > 0, "mht_forest_report: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    if (f->report_pending) {
-        { const int rc = flush_commit(ctx, f); if (rc) return rc; }
-        const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
-        MHT_HIP_CHECK(hipMemcpyAsync(f->report_host, f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        f->report_pending = false;
+    if (f->report_pending) { const int rc = mht_forest_report_begin(ctx); if (rc) return rc; }
+    return report_expose(ctx, f, f->rep_slot, out);
+}
+
+// The report whose transfer the last (which = 0) or the last but one (which = 1) mht_forest_report_begin started: a host that
+// begins the report of scan k+1 before it reads the one of scan k keeps two scans in flight.
+extern "C" int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out) {
+    MHT_REQUIRE(ctx && ctx->forest && out && (which == 0 || which == 1), "mht_forest_report_get: bad argument");
+    Forest* f = ctx->forest;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    return report_expose(ctx, f, f->rep_slot ^ which, out);
+}
+
+static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out) {
+    if (f->rep_started[slot]) {
+        MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));
+        f->rep_started[slot] = false;
     }
+    if (slot == f->rep_slot) f->rep_inflight = false;
+    f->report_host = f->report_host2[slot];
     const ReportHeader* h = reinterpret_cast<const ReportHeader*>(f->report_host);
     memcpy(out, h, sizeof(ReportHeader));
     out->used = reinterpret_cast<const uint64_t*>(f->report_host + f->used_off);
     out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);
     out->births = reinterpret_cast<const mht_birth_report*>(f->report_host + f->birth_off);
-    // tighten the host-side bounds; targets added since that scan was launched are not in its report
-    f->nT_ub = h->n_alive + f->births_since_step < f->Tcap ? h->n_alive + f->births_since_step : f->Tcap;
-    f->L_ub = h->n_leaves_out + f->births_since_step < f->Ncap ? h->n_leaves_out + f->births_since_step : f->Ncap;
+    // tighten the host-side bounds; targets added since that scan was issued are not in its report (the report may be read after
+    // later scans have been issued: only births move the target count up)
+    if (f->scan - h->scan < 60) {
+        const long long since = f->births_cum - f->births_issue[h->scan % 64];
+        const long long ub = (long long)h->n_alive + since;
+        f->nT_ub = ub < f->Tcap ? (int)ub : f->Tcap;
+        f->L_ub = f->Ncap;
+    }
     if (h->error == MHT_E_HIP) {
         f->dead = true;
         set_error("forest: grow_kernel stalled in scan %d waiting for a tile that was never dispatched (GPU shared with another "

@@ -42,7 +42,7 @@ class SectorGroup:
         zs = [trk._stage_scan(sl) for trk, sl in zip(self.trackers, scanLists)]
         self.step_dev([z.data_ptr() for z in zs], [int(z.shape[0]) for z in zs])
         for trk, sl in zip(self.trackers, scanLists):
-            trk._finish_scan(sl)
+            trk._after_step(sl, trk._staged_np, None)
 
     def close(self):
         if self._h:

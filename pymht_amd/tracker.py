@@ -73,11 +73,11 @@ class Tracker():
         self.__aisHistory__ = []
         self.trackIdCounter = 0
         # Timing and logging (tracker.py:86-101)
-        self.runtimeLog = {k: [] for k in ('Total', 'Process', 'Cluster', 'Optim', 'ILP-Prune', 'DynN', 'N-Prune',
+        self._runtimeLog_ = {k: [] for k in ('Total', 'Process', 'Cluster', 'Optim', 'ILP-Prune', 'DynN', 'N-Prune',
                                            'Terminate', 'Init')}
         self.tic = {}
-        self.toc = {}
-        self.nOptimSolved = 0
+        self._toc_ = {}
+        self._nOptimSolved_ = 0
         # Tracker parameters (tracker.py:103-118)
         self.pruneSimilar = kwargs.get('pruneSimilar', False)
         self.lambda_phi = lambda_phi
@@ -115,21 +115,24 @@ class Tracker():
         self.initiator = m_of_n.Initiator(self.M_required, self.N_checks, self.maxSpeedMS, self.C, self.R_RADAR, self.mergeThreshold,
                                           ctx=self._ctx, maxMeasurements=cfg.max_meas, default_pd=self.default_P_d) \
             if self.useInitiator else None
-        self._timing = bool(kwargs.get('deviceTiming', True))
+        # per-stage device times (toc['Process'], ['Cluster'], ['Optim'], ['N-Prune']: five HIP events per scan and a stream
+        # synchronisation to read them): off by default, it keeps the host from running ahead of the device
+        self._timing = bool(kwargs.get('deviceTiming', False))
         _lib.check(self._lib.mht_forest_set_timing(self._ctx.handle, int(self._timing)))
         # host mirror of the target list (one row per target, target-list order)
-        self._tbl = dict(id=np.zeros(0, np.int64), root_scan=np.zeros(0, np.int64), root_node=np.zeros(0, np.int64),
+        self._tbl_ = dict(id=np.zeros(0, np.int64), root_scan=np.zeros(0, np.int64), root_node=np.zeros(0, np.int64),
                          root_meas=np.zeros(0, np.int64), root_x=np.zeros((0, 4)), root_cnllr=np.zeros(0),
                          root_time=np.zeros(0), f32=np.zeros(0, bool))
-        self._sel = None            # report records of the live targets after the last scan (selected leaves)
+        self._sel_ = None            # report records of the live targets after the last scan (selected leaves)
         self._labels = np.zeros(0, np.int64)
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
+        self._pending = None        # the scan whose report is still on its way (folded by the next scan or by the first look)
         self._dead = False          # a device step failed: the forest cannot go on
         self._staged = self._staged_prev = self._staged_np = None
-        self.lastScanStats = {}
+        self._stats_ = {}
 
     # ------------------------------------------------------------------------------------------------
     def preInitialize(self, simList):
@@ -145,6 +148,7 @@ class Tracker():
         self._add_targets([newTarget])
 
     def _add_targets(self, targets):
+        self._drain()
         n = len(targets)
         if n == 0:
             return []
@@ -164,7 +168,7 @@ class Tracker():
         out = [t for t, a in zip(targets, ok) if a]
         if not out:
             return out
-        tb = self._tbl
+        tb = self._tbl_
         tb["id"] = np.concatenate([tb["id"], ids[ok].astype(np.int64)])
         tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(len(out), scan, np.int64)])
         tb["root_node"] = np.concatenate([tb["root_node"], np.full(len(out), -1, np.int64)])
@@ -182,10 +186,16 @@ class Tracker():
 
     # ------------------------------------------------------------------------------------------------
     def addMeasurementList(self, scanList, aisList=AisMessageList(), **kwargs):
-        """tracker.py:162-307 for the radar-only case."""
+        """tracker.py:162-307 for the radar-only case.
+
+        Returns as soon as the scan is queued on the device: steps 1-7 run there without a host round trip, and the scan's report
+        travels to pinned host memory behind them.  It is folded into the host mirror by the next call or by the first look at
+        the tracker's state (every attribute / method that exposes results waits for it), so a host that streams scans in
+        overlaps its own bookkeeping with the device's work."""
+        tic = {'Total': time.time()}
         z = self._accept_scan(scanList, aisList, kwargs)
-        # steps 1-6 on the device.  The host mirror is only touched once the device has accepted the scan: a rejected step
-        # (too many measurements, dead forest) leaves the tracker exactly as it was.
+        # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
+        # forest) leaves the tracker exactly as it was.
         try:
             zd = self._upload_scan(z)
             _lib.check(self._lib.mht_forest_step(self._ctx.handle, zd, z.shape[0]))
@@ -193,7 +203,28 @@ class Tracker():
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
             raise
-        self._finish_scan(scanList, z, aisList)
+        self._after_step(scanList, z, aisList, tic)
+
+    def _after_step(self, scanList, z, aisList, tic=None):
+        """Behind the device step: step 7 on the device, then the report starts its way to the host."""
+        if self.useInitiator:
+            # 7 -- Initiate new tracks (tracker.py:264-278): on the device, right behind the scan's commit; what it gave birth to
+            # comes back with the scan's report
+            _lib.check(self._lib.mht_forest_initiate(self._ctx.handle, self.initiator.handle, self._staged.data_ptr(), z.shape[0],
+                                                     float(scanList.time)))
+        _lib.check(self._lib.mht_forest_report_begin(self._ctx.handle))
+        prev, self._pending = self._pending, (scanList, z, aisList, tic if tic is not None else {'Total': time.time()})
+        if prev is not None:      # the scan before: its report has arrived (or is about to) while the device works on this one
+            self._finish_scan(*prev, which=1)
+        if self._timing:          # (the stage times are read scan by scan)
+            self._drain()
+
+    def _drain(self):
+        """Fold the report of the scan that is still in flight (waits for it)."""
+        if self._pending is not None:
+            scanList, z, aisList, tic = self._pending
+            self._pending = None
+            self._finish_scan(scanList, z, aisList, tic)
 
     def _accept_scan(self, scanList, aisList, kwargs):
         """Argument checks of addMeasurementList; returns the scan as the (M,2) float32 array the device gates."""
@@ -203,9 +234,6 @@ class Tracker():
             raise NotImplementedError("AIS fusion (tracker.py:417-552) is outside the MI355X hot path")
         if kwargs.get('dynamicWindow', False):
             raise NotImplementedError("dynamicWindow is not supported by pymht_amd")
-        self.tic.clear()
-        self.toc.clear()
-        self.tic['Total'] = time.time()
         m = np.asarray(scanList.measurements)
         z = np.ascontiguousarray(m, dtype=np.float32).reshape(-1, 2)
         if m.dtype != np.float32 and m.size and not np.array_equal(z.astype(np.float64).reshape(m.shape), m.astype(np.float64)):
@@ -228,18 +256,13 @@ class Tracker():
         self._upload_scan(z)
         return self._staged[:z.shape[0]] if z.size else self._staged[:0]
 
-    def _finish_scan(self, scanList, z=None, aisList=None):
-        """Everything after the device step: report, host mirror, step 7 (track initiation), timing log."""
-        if z is None:
-            z = self._staged_np
+    def _finish_scan(self, scanList, z, aisList, tic, which=0):
+        """The host side of a scan: wait for its report, fold it (and the device initiator's births) into the host mirror."""
+        self.tic = tic
+        self._toc_ = {}
         self.tic['Init'] = time.time()
-        if self.useInitiator:
-            # 7 -- Initiate new tracks (tracker.py:264-278): on the device, right behind the scan's commit; what it gave birth to
-            # comes back with the scan's report
-            zp = self._staged.data_ptr()
-            _lib.check(self._lib.mht_forest_initiate(self._ctx.handle, self.initiator.handle, zp, z.shape[0], float(scanList.time)))
         rep = _lib.MhtScanReport()
-        rc = self._lib.mht_forest_report(self._ctx.handle, C.byref(rep))
+        rc = self._lib.mht_forest_report_get(self._ctx.handle, which, C.byref(rep))
         if rc == _lib.MHT_E_LIMIT:
             # soft: an ILP ran into the branch-and-bound node limit.  The selection it returned is feasible (not proven optimal)
             # and the device forest HAS advanced with it: fold the report like any other (the reference logs "Optim result NOT
@@ -267,13 +290,13 @@ class Tracker():
         if self._timing:
             ms = (C.c_float * 5)()
             _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms), None))
-            self.toc['Process'], self.toc['Cluster'], self.toc['Optim'] = ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3
-            self.toc['Terminate'] = 0.0
-            self.toc['N-Prune'] = ms[3] * 1e-3
-            self.toc['Device'] = ms[4] * 1e-3
-        self.toc['ILP-Prune'] = 0.0
-        self.toc['DynN'] = 0.0
-        self.nOptimSolved = rep.n_ilp
+            self._toc_['Process'], self._toc_['Cluster'], self._toc_['Optim'] = ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3
+            self._toc_['Terminate'] = 0.0
+            self._toc_['N-Prune'] = ms[3] * 1e-3
+            self._toc_['Device'] = ms[4] * 1e-3
+        self._toc_['ILP-Prune'] = 0.0
+        self._toc_['DynN'] = 0.0
+        self._nOptimSolved_ = rep.n_ilp
         births = None
         if rep.n_births:
             births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * _BIRTH_DTYPE.itemsize,)) \
@@ -281,15 +304,15 @@ class Tracker():
         self._apply_report(recs, scanTime, scanNumber, z)
         if births is not None:
             self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
-        self.toc['Init'] = time.time() - self.tic['Init']
-        self.toc['Total'] = time.time() - self.tic['Total']
-        if self.toc['Total'] > self.radarPeriod:
+        self._toc_['Init'] = time.time() - self.tic['Init']
+        self._toc_['Total'] = time.time() - self.tic['Total']
+        if self._toc_['Total'] > self.radarPeriod:
             log.critical("Did not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
-                self.toc['Total'] * 1000, self.radarPeriod * 1000))
-        for k, v in self.runtimeLog.items():
-            if k in self.toc:
-                v.append(self.toc[k])
-        self.lastScanStats = dict(L=rep.n_leaves_in, G=rep.n_children - rep.n_leaves_in, M=nRadarMeas,
+                self._toc_['Total'] * 1000, self.radarPeriod * 1000))
+        for k, v in self._runtimeLog_.items():
+            if k in self._toc_:
+                v.append(self._toc_[k])
+        self._stats_ = dict(L=rep.n_leaves_in, G=rep.n_children - rep.n_leaves_in, M=nRadarMeas,
                                   leaves_out=rep.n_leaves_out, clusters=rep.n_clusters, ilp=rep.n_ilp,
                                   branched=rep.n_branched, blp_iters_max=rep.blp_iters_max, limit=rep.n_limit,
                                   unused=unusedRadarMeasurementIndices)
@@ -301,7 +324,7 @@ class Tracker():
             return
         b = births[ok]
         n = len(b)
-        tb = self._tbl
+        tb = self._tbl_
         x0 = b["x0"].astype(np.float32)
         tb["id"] = np.concatenate([tb["id"], b["id"].astype(np.int64)])
         tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(n, scanNumber, np.int64)])
@@ -320,7 +343,7 @@ class Tracker():
 
     def _apply_report(self, recs, scanTime, scanNumber, z):
         """Fold the scan report into the host tables (vectorised; no per-target Python objects are created here)."""
-        tb = self._tbl
+        tb = self._tbl_
         self._views.clear()
         self._labels = recs["cluster"].astype(np.int64) if len(recs) else np.zeros(0, np.int64)
         alive = recs["status"] == 0
@@ -339,11 +362,42 @@ class Tracker():
             root_time[moved] = times
         else:
             root_time = tb["root_time"][alive]
-        self._tbl = dict(id=live["id"].astype(np.int64), root_scan=live["root_scan"].astype(np.int64),
+        self._tbl_ = dict(id=live["id"].astype(np.int64), root_scan=live["root_scan"].astype(np.int64),
                          root_node=live["root_node"].astype(np.int64), root_meas=live["root_meas"].astype(np.int64),
                          root_x=live["root_x"].copy(), root_cnllr=live["root_cnllr"].copy(), root_time=root_time,
                          f32=tb["f32"][alive])
-        self._sel = (live, scanTime, scanNumber, z)
+        self._sel_ = (live, scanTime, scanNumber, z)
+
+    # ---- results: every look at them first folds the report that is still in flight ---------------------------------------
+    @property
+    def lastScanStats(self):
+        self._drain()
+        return self._stats_
+
+    @property
+    def toc(self):
+        self._drain()
+        return self._toc_
+
+    @property
+    def runtimeLog(self):
+        self._drain()
+        return self._runtimeLog_
+
+    @property
+    def nOptimSolved(self):
+        self._drain()
+        return self._nOptimSolved_
+
+    @property
+    def _sel(self):
+        self._drain()
+        return self._sel_
+
+    @property
+    def _tbl(self):
+        self._drain()
+        return self._tbl_
 
     # ---- lazily built views (the reference's attributes, tracker.py:74-84) -----------------------------------------
     def _node_view(self, r, scanTime, scanNumber, z):
@@ -357,18 +411,19 @@ class Tracker():
 
     @property
     def __trackNodes__(self):
+        self._drain()
         v = self._views.get("track")
         if v is None:
-            v = np.empty(len(self._tbl["id"]), dtype=np.dtype(object))
-            if self._sel is not None and len(self._sel[0]) == len(v):
-                live, scanTime, scanNumber, z = self._sel
+            v = np.empty(len(self._tbl_["id"]), dtype=np.dtype(object))
+            if self._sel_ is not None and len(self._sel_[0]) == len(v):
+                live, scanTime, scanNumber, z = self._sel_
                 for i in range(len(live)):
                     v[i] = self._node_view(live[i], scanTime, scanNumber, z)
                 n0 = len(live)
             else:
-                n0 = 0 if self._sel is None else len(self._sel[0])
-                if self._sel is not None:
-                    live, scanTime, scanNumber, z = self._sel
+                n0 = 0 if self._sel_ is None else len(self._sel_[0])
+                if self._sel_ is not None:
+                    live, scanTime, scanNumber, z = self._sel_
                     for i in range(n0):
                         v[i] = self._node_view(live[i], scanTime, scanNumber, z)
             roots = self.__targetList__
@@ -379,9 +434,10 @@ class Tracker():
 
     @property
     def __targetList__(self):
+        self._drain()
         v = self._views.get("roots")
         if v is None:
-            tb = self._tbl
+            tb = self._tbl_
             v = []
             for i in range(len(tb["id"])):
                 tid = int(tb["id"][i])
@@ -401,10 +457,12 @@ class Tracker():
 
     @property
     def __clusterList__(self):
+        self._drain()
         return [np.where(self._labels == lab)[0] for lab in np.unique(self._labels)]
 
     @property
     def __terminatedTargets__(self):
+        self._drain()
         out = []
         for recs, scanTime, scanNumber, z in self._dead_chunks:
             for r in recs:
@@ -413,10 +471,12 @@ class Tracker():
 
     @property
     def __targetWindowSize__(self):
-        return [self.N] * len(self._tbl["id"])
+        self._drain()
+        return [self.N] * len(self._tbl_["id"])
 
     @property
     def __associatedMeasurements__(self):
+        self._drain()
         """The association sets live on the device as (target, measurement node) edges; the host view is rebuilt from
         the leaves' ancestor chains on demand (slow path, for inspection only)."""
         return [root.getMeasurementSet() if root.trackHypotheses is not None else set() for root in self.__targetList__]
@@ -466,8 +526,8 @@ class Tracker():
                 return None
             _lib.check(self._lib.mht_forest_chain(self._ctx.handle, view.scanNumber, view._node, n_max, p(nodes), p(meas),
                                                   p(x), p(cn), p(P), C.byref(n)))
-            i = int(np.where(self._tbl["id"] == target_id)[0][0]) if (self._tbl["id"] == target_id).any() else -1
-            root_scan = int(self._tbl["root_scan"][i]) if i >= 0 else -1
+            i = int(np.where(self._tbl_["id"] == target_id)[0][0]) if (self._tbl_["id"] == target_id).any() else -1
+            root_scan = int(self._tbl_["root_scan"][i]) if i >= 0 else -1
             view.P_0 = P[0].reshape(4, 4).copy()
             prev = view
             for k in range(1, n.value):
@@ -489,6 +549,7 @@ class Tracker():
         return load
 
     def _leaf_snapshot(self):
+        self._drain()
         cap = self._cfg.max_nodes
         n = C.c_int32(0)
         x = np.zeros((cap, 4)); P = np.zeros((cap, 16), dtype=np.float32); cn = np.zeros(cap)
@@ -525,18 +586,25 @@ class Tracker():
     @property
     def nTargets(self):
         """len(__targetList__) without building the views."""
-        return len(self._tbl["id"])
+        self._drain()
+        return len(self._tbl_["id"])
 
     def getTrackNodes(self):
         return self.__trackNodes__
 
+    def synchronize(self):
+        """Wait for everything queued on the device and fold it (reports are folded lazily otherwise)."""
+        self._drain()
+        self._ctx.synchronize()
+
     def getRuntimeAverage(self):
-        return {k: np.mean(np.array(v)) for k, v in self.runtimeLog.items() if len(v)}
+        return {k: np.mean(np.array(v)) for k, v in self._runtimeLog_.items() if len(v)}
 
     def _findClustersFromSets(self):
         return self.__clusterList__
 
     def close(self):
+        self._pending = None
         if self.initiator is not None:
             self.initiator.close()
             self.initiator = None

@@ -119,7 +119,7 @@ def test_capacity_overflow_is_reported_not_fatal():
 def test_api_rejections_and_views():
     from pymht_amd.utils.classDefinitions import MeasurementList
     sc = _scenario(n_scans=6)
-    trk = _mk(sc, useInitiator=False)
+    trk = _mk(sc, useInitiator=False, deviceTiming=True)      # (per-stage device times in runtimeLog)
     with pytest.raises(NotImplementedError):
         trk.addMeasurementList(MeasurementList(float(sc["times"][0]), sc["scans"][0]), aisList=[object()])
     o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)

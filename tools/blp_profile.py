@@ -6,7 +6,7 @@ import bench
 from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 sc = make_config('cfg3', seed=5446, n_scans=24, confine=True)
-trk = bench.make_tracker(sc, 0)
+trk = bench.make_tracker(sc, 0, deviceTiming=True)
 def rd(name, n, dt=np.int32):
     a = np.zeros(n, dtype=dt)
     bench._lib_check = None

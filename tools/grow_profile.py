@@ -9,7 +9,7 @@ from pymht_amd import _lib
 from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 sc = make_config('cfg3', seed=5446, n_scans=14)
-trk = bench.make_tracker(sc, 0, maxTargets=int(os.environ.get("MHT_PROF_MAXT", "640")))
+trk = bench.make_tracker(sc, 0, maxTargets=int(os.environ.get("MHT_PROF_MAXT", "640")), deviceTiming=True)
 names = ['rt1', 'phase1', 'cands', 'pairs', 'counts+alloc', 'edges(w1)', 'emit']
 COLS = [0, 1, 2, 3, 4, 5, 6, 7]
 raw = len(sys.argv) > 1 and sys.argv[1] == 'raw'      # raw: step through the C ABI without reports -> deferred commits (replay mode)
