@@ -220,7 +220,7 @@ int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const 
  * or runs as a launch of its own as soon as the report, new targets or an export are asked for.  Either order leaves the same
  * forest (tests/test_forest_edge_gpu.py).  */
 int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
-/* Same with z in host memory (copied through a pinned staging buffer of the ctx). */
+/* Same with z in host memory (copied through a ring of pinned staging buffers of the ctx: asynchronous). */
 int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M);
 /* Start the transfer of the last step's report into pinned host memory (runs the scan's commit first if it is still pending) and
  * return at once.  A host that issues the next step before it calls mht_forest_report overlaps its own work with the device's;
@@ -284,7 +284,8 @@ int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P
 
 /* Step 7 behind a forest step, on the stream, no host round trip: runs the scan's commit, offers the scan's unused measurements
  * (tracker.py:266) to the initiator and hands its confirmed candidates to Tracker.initiateTarget's device twin
- * (mht_forest_add_targets_dev, neighbour test included).  z / M: the scan just stepped; now: its time stamp.  The candidates and
+ * (mht_forest_add_targets_dev, neighbour test included).  z / M: the scan just stepped (z = NULL: the copy mht_forest_step_host
+ * staged); now: its time stamp.  The candidates and
  * their fate appear in the report of that scan (mht_scan_report::births).  The initiator must have been created on the same ctx. */
 int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now);
 

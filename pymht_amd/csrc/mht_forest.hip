@@ -19,6 +19,7 @@
 // committed state first (report, births, exports) -- see Forest::commit_pending.
 #include "mht_kernels.h"
 #include "mht_commit.h"
+#include "mht_init_dev.h"
 #include <string.h>
 #include <math.h>
 #include <new>
@@ -28,6 +29,7 @@ namespace mht {
 
 constexpr int MAXR = 16;
 constexpr int EV_POOL = 64;
+constexpr int Z_RING = 4;           // pinned staging buffers of mht_forest_step_host
 constexpr int BIRTH_CAP = 256;      // candidates of the device initiator per scan that the report can hold
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
@@ -54,7 +56,7 @@ struct AddArgs {
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates.  The test against the existing leaves
 // (pyTarget.haveNoNeightbours, pyTarget.py:181-189) runs for all candidates in one parallel sweep; the candidates are
 // then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
-__global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
+static __device__ void add_targets_body(const AddArgs& a) {
     const int tid = threadIdx.x;
     const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
     int an = a.n;
@@ -170,6 +172,24 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
         g[3] = make_float4(lnc, rx, ry, 0.f);
     }
 }
+__global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { add_targets_body(a); }
+
+// The end of a scan in the drop-in API path, ONE launch of one workgroup instead of three: the scan's commit (target table, report),
+// step 7 on the measurements the commit found unused (initiator_body), Tracker.initiateTarget for what it confirmed.
+static_assert(INIT_THREADS == 1024, "post_scan_kernel runs commit, initiator and admission with one block size");
+__global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit) {
+    __shared__ int s_commit[2 * (1024 / 64) + 8];
+    if (do_commit) {
+        commit_body<1024>(cm, dyn, s_commit);
+        __threadfence_block();
+        __syncthreads();
+        if (cm.hdr->error) return;      // void scan: nothing to initiate
+    }
+    initiator_body(in);
+    __threadfence_block();
+    __syncthreads();
+    add_targets_body(ad);
+}
 
 struct LeavesArgs {
     mht_nodes layer; TTable tab; const FCounts* cnt;
@@ -247,7 +267,7 @@ struct Forest {
     FCounts* cnt;
     char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
-    float* z_dev; float* z_host;
+    float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
@@ -262,14 +282,21 @@ struct Forest {
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
     // since that scan this bounds the current target count (targets only disappear otherwise)
     unsigned long long* hint_host = nullptr; unsigned long long* hint_dev = nullptr;
-    long long births_cum = 0; long long births_issue[64] = {};      // births issued so far / before step s was issued (ring by s % 64)
+    // births issued behind scan s, before scan s+1 (ring by s % 64): host-driven ones exactly, the device initiator's as an upper
+    // bound (its capacity) until the scan's report says how many candidates there were
+    int births_after[64] = {}; int births_init_ub[64] = {};
+    long long births_between(int k, int s) const {      // births issued behind scans k .. s-1
+        long long b = 0;
+        for (int j = k; j < s; ++j) b += births_after[j % 64] + births_init_ub[j % 64];
+        return b;
+    }
     int targets_ub(int s_table) const {      // upper bound of the targets in the table scan `s_table` runs on
         int ub = nT_ub;
         if (hint_host) {
             const unsigned long long h = *reinterpret_cast<volatile unsigned long long*>(hint_host);
             const int k = (int)(h >> 32), na = (int)(h & 0xffffffffu);
             if (k >= 1 && k < s_table && s_table - k < 60) {
-                const long long b = na + (births_issue[s_table % 64] - births_issue[k % 64]);
+                const long long b = na + births_between(k, s_table);
                 if (b < ub) ub = (int)b;
             }
         }
@@ -333,6 +360,7 @@ void forest_destroy(mht_ctx* ctx) {
         if (f->rep_ev[b]) (void)hipEventDestroy(f->rep_ev[b]);
     }
     if (f->z_host) (void)hipHostFree(f->z_host);
+    for (int b = 0; b < Z_RING; ++b) if (f->z_ev[b]) (void)hipEventDestroy(f->z_ev[b]);
     if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
@@ -451,7 +479,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
         MHT_HIP_CHECK(hipEventCreateWithFlags(&f->rep_ev[b], hipEventDisableTiming));
     }
     f->report_host = f->report_host2[0];
-    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)2 * f->Mpad * sizeof(float), hipHostMallocDefault));
+    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)Z_RING * 2 * f->Mpad * sizeof(float), hipHostMallocDefault));
+    for (int b = 0; b < Z_RING; ++b) MHT_HIP_CHECK(hipEventCreateWithFlags(&f->z_ev[b], hipEventDisableTiming));
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
@@ -500,7 +529,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     f->nT_ub = (f->nT_ub + n < f->Tcap) ? f->nT_ub + n : f->Tcap;
     f->L_ub = (f->L_ub + n < f->Ncap) ? f->L_ub + n : f->Ncap;
     f->births_since_step += n;
-    f->births_cum += n;
+    f->births_after[f->scan % 64] += n;
     return MHT_OK;
 }
 
@@ -645,7 +674,7 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     }
     if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
     const int s = ++f->scan;
-    f->births_issue[s % 64] = f->births_cum;
+    f->births_after[s % 64] = 0; f->births_init_ub[s % 64] = 0;
     f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
     f->nT_ub_step = f->targets_ub(s);
     f->births_since_step = 0;
@@ -876,8 +905,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
 }
 
 namespace mht {
-int initiator_launch(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now);
-struct InitArgs;
+void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now, InitArgs& a);
 void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
                          const int32_t** n, int* cap, mht_ctx** ctx);
 }
@@ -887,14 +915,14 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     Forest* f = ctx->forest;
     MHT_REQUIRE(f->scan > 0, "mht_forest_initiate: no scan processed yet");
     MHT_REQUIRE(M == f->last_M, "mht_forest_initiate: M=%d is not the scan just stepped (M=%d)", M, f->last_M);
+    if (!z) z = f->z_dev;      // (the scan mht_forest_step_host staged)
     const double* bx; const float* bP; const uint8_t* bfl; const double* bpd; const int32_t* bme; const int32_t* bn; int cap; mht_ctx* ictx;
     initiator_born_ptrs(in, &bx, &bP, &bfl, &bpd, &bme, &bn, &cap, &ictx);
     MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
     MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // the used-measurement mask of the scan is part of its commit
-    int rc = initiator_launch(in, z, M, reinterpret_cast<const unsigned long long*>(f->report_dev + f->used_off), now);
-    if (rc) return rc;
+    InitArgs ia;
+    initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(f->report_dev + f->used_off), now, ia);
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
     a.check = 1; a.thr = f->cfg.merge_threshold;
@@ -907,13 +935,15 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
     a.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
     a.births = reinterpret_cast<mht_birth_report*>(f->report_dev + f->birth_off);
-    hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    // commit (if it is still pending: the used-measurement mask of the scan is part of it) + initiator + admission: one launch
+    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0);
     MHT_HIP_CHECK(hipGetLastError());
+    f->commit_pending = false;
     // the host does not know how many of the candidates exist: every bound moves by the most there can be
     f->nT_ub = (f->nT_ub + cap < f->Tcap) ? f->nT_ub + cap : f->Tcap;
     f->L_ub = (f->L_ub + cap < f->Ncap) ? f->L_ub + cap : f->Ncap;
     f->births_since_step += cap;
-    f->births_cum += cap;
+    f->births_init_ub[f->scan % 64] = cap;
     f->report_pending = true;      // (the births block of the report changed)
     return MHT_OK;
 }
@@ -924,9 +954,16 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step_host: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
     if (M > 0) {
         MHT_REQUIRE(z_host, "mht_forest_step_host: z is null");
-        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the staging buffer may still be in flight
-        memcpy(f->z_host, z_host, (size_t)M * 2 * sizeof(float));
-        MHT_HIP_CHECK(hipMemcpyAsync(f->z_dev, f->z_host, (size_t)M * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        MHT_HIP_CHECK(hipSetDevice(ctx->device));
+        // a ring of pinned staging buffers: the host only waits if the copy that used this slot Z_RING scans ago is still in flight
+        const int slot = f->z_slot;
+        f->z_slot = (slot + 1) % Z_RING;
+        if (f->z_used[slot]) MHT_HIP_CHECK(hipEventSynchronize(f->z_ev[slot]));
+        float* zh = f->z_host + (size_t)slot * 2 * f->Mpad;
+        memcpy(zh, z_host, (size_t)M * 2 * sizeof(float));
+        MHT_HIP_CHECK(hipMemcpyAsync(f->z_dev, zh, (size_t)M * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], ctx->stream));
+        f->z_used[slot] = true;
     }
     return mht_forest_step(ctx, f->z_dev, M);
 }
@@ -987,8 +1024,8 @@ static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out
     // tighten the host-side bounds; targets added since that scan was issued are not in its report (the report may be read after
     // later scans have been issued: only births move the target count up)
     if (f->scan - h->scan < 60) {
-        const long long since = f->births_cum - f->births_issue[h->scan % 64];
-        const long long ub = (long long)h->n_alive + since;
+        if (f->births_init_ub[h->scan % 64] > h->n_births) f->births_init_ub[h->scan % 64] = h->n_births;      // (now known)
+        const long long ub = (long long)h->n_alive + f->births_between(h->scan, f->scan + 1);
         f->nT_ub = ub < f->Tcap ? (int)ub : f->Tcap;
         f->L_ub = f->Ncap;
     }

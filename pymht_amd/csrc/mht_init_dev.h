@@ -1,0 +1,497 @@
+// Device side of the M-of-N initiator (see mht_init.hip for the description and the reference lines): shared by initiator_kernel
+// (stand-alone entry, mht_initiator_step) and the forest's post_scan_kernel (commit -> initiation -> admission in one launch).
+#pragma once
+#include "mht_kernels.h"
+
+namespace mht {
+
+constexpr int INIT_THREADS = 1024;
+constexpr int INIT_ECAP = 1 << 15;      // edges of one GNN problem
+
+struct InitDev {                        // device-resident state of one initiator
+    int n_seeds, n_prelim, have_last, overflow;
+    double last_time;
+    int n_born, n_unused_out, pad0, pad1;
+};
+
+struct InitArgs {
+    InitDev* st;
+    float* seeds;                       // [Mcap][2] last scan's leftovers
+    float* pstate; float* pcov; int32_t* pn; int32_t* pm;      // preliminary tracks [Pcap]: state [4], covariance [16], n, m
+    float* pstate2; float* pcov2; int32_t* pn2; int32_t* pm2;  // compaction target (swapped by the host every scan)
+    int Mcap, Pcap;
+    const float* z; int M;              // the scan, dev (M,2) float32
+    const unsigned long long* used;     // [ceil(M/64)] bit j set = measurement j was gated by a track (null: all measurements are unused)
+    double now;
+    int Mreq, Nreq; double v_max, gamma, merge_threshold, default_pd;
+    float C[8], R[4], P0[16];
+    float sigma_q;                      // pv.Q scale (models/constants.py: sigmaQ_tracker)
+    // scratch (global)
+    int32_t* e_row; int32_t* e_col; double* e_cost; int32_t* e_next;   // edge lists [INIT_ECAP]
+    int32_t* node_parent; int32_t* row_head; int32_t* row_next; int32_t* comp_head; int32_t* match_row; int32_t* match_col;
+    double* bf_dist; int32_t* bf_pred; int32_t* comp_nodes;
+    int32_t* upos;                      // [Mcap] unused-list position -> measurement index in z
+    float* K;                           // [Pcap][8]
+    float* pred;                        // [Pcap][4]
+    int32_t* tmeas;                     // [Pcap] matched unused-list index of the track or -1
+    // output: born candidates, in the reference's order
+    double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
+};
+
+// LU with partial pivoting of an n x n float32 system (n <= 4), as LAPACK sgetrf/sgetri order it closely enough: inverse by solving
+// for the unit columns
+static __device__ inline bool inv_small(const float* a_in, int n, float* out) {
+    float a[16], b[16];
+    for (int i = 0; i < n * n; ++i) { a[i] = a_in[i]; b[i] = 0.f; }
+    for (int i = 0; i < n; ++i) b[i * n + i] = 1.f;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        float best = fabsf(a[c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabsf(a[r * n + c]) > best) { best = fabsf(a[r * n + c]); p = r; }
+        if (best == 0.f) return false;
+        if (p != c) for (int k = 0; k < n; ++k) { float t = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = t; t = b[c * n + k]; b[c * n + k] = b[p * n + k]; b[p * n + k] = t; }
+        for (int r = c + 1; r < n; ++r) {
+            const float l = a[r * n + c] / a[c * n + c];
+            for (int k = c; k < n; ++k) a[r * n + k] = fmaf(-l, a[c * n + k], a[r * n + k]);
+            for (int k = 0; k < n; ++k) b[r * n + k] = fmaf(-l, b[c * n + k], b[r * n + k]);
+        }
+    }
+    for (int col = 0; col < n; ++col)
+        for (int r = n - 1; r >= 0; --r) {
+            float v = b[r * n + col];
+            for (int k = r + 1; k < n; ++k) v = fmaf(-a[r * n + k], out[k * n + col], v);
+            out[r * n + col] = v / a[r * n + r];
+        }
+    return true;
+}
+
+// ---- GNN: minimum-cost maximum-cardinality matching of the allowed graph -------------------------------------------------------
+// rows 0..n1-1, columns 0..n2-1, edges (e_row, e_col, e_cost)[0..E).  One thread per connected component: successive shortest
+// augmenting paths (Bellman-Ford on the residual graph; components have a handful of nodes).  match_row[r] = column or -1.
+static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
+    const int tid = threadIdx.x;
+    const int V = n1 + n2;
+    for (int v = tid; v < V; v += INIT_THREADS) { a.node_parent[v] = v; a.row_head[v] = -1; a.comp_head[v] = -1; }
+    for (int r = tid; r < n1; r += INIT_THREADS) a.match_row[r] = -1;
+    for (int c = tid; c < n2; c += INIT_THREADS) a.match_col[c] = -1;
+    __threadfence_block();
+    __syncthreads();
+    auto find = [&](int v) { int p = a.node_parent[v]; while (p != v) { v = p; p = a.node_parent[v]; } return v; };
+    for (int e = tid; e < E; e += INIT_THREADS) {       // components: lock-free union (smaller root wins => the root is a row node)
+        int ra = find(a.e_row[e]), rb = find(n1 + a.e_col[e]);
+        while (ra != rb) {
+            if (ra > rb) { const int t = ra; ra = rb; rb = t; }
+            const int old = atomicCAS(&a.node_parent[rb], rb, ra);
+            if (old == rb) break;
+            rb = find(old);
+            ra = find(ra);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    int myroot[2] = {-1, -1};                            // (at most 2048 nodes: two per thread)
+    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += INIT_THREADS) myroot[q] = find(v);
+    __syncthreads();
+    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += INIT_THREADS) a.node_parent[v] = myroot[q];      // flattened: node -> root
+    for (int v = tid + 2 * INIT_THREADS; v < V; v += INIT_THREADS) a.node_parent[v] = find(v);            // (larger problems: racy but benign: roots are fixed points)
+    // adjacency: edges chained per row (row_head / e_next), rows with edges chained per component (comp_head / row_next)
+    for (int e = tid; e < E; e += INIT_THREADS) a.e_next[e] = atomicExch(&a.row_head[a.e_row[e]], e);
+    __threadfence_block();
+    __syncthreads();
+    for (int r = tid; r < n1; r += INIT_THREADS)
+        if (a.row_head[r] >= 0) a.row_next[r] = atomicExch(&a.comp_head[a.node_parent[r]], r);
+    __threadfence_block();
+    __syncthreads();
+    // one thread per component: successive shortest augmenting paths.  repeat { Bellman-Ford over the residual graph from all
+    // free rows; the free column with the smallest distance; augment } until no free column is reachable
+    for (int root = tid; root < n1; root += INIT_THREADS) {
+        if (a.comp_head[root] < 0) continue;
+        for (int guard_aug = 0; guard_aug <= n1; ++guard_aug) {
+            for (int r = a.comp_head[root]; r >= 0; r = a.row_next[r]) {
+                a.bf_dist[r] = (a.match_row[r] < 0) ? 0.0 : 1e300;
+                a.bf_pred[r] = -1;
+                for (int e = a.row_head[r]; e >= 0; e = a.e_next[e]) { a.bf_dist[n1 + a.e_col[e]] = 1e300; a.bf_pred[n1 + a.e_col[e]] = -1; }
+            }
+            bool changed = true;
+            for (int it = 0; it < V && changed; ++it) {
+                changed = false;
+                for (int r = a.comp_head[root]; r >= 0; r = a.row_next[r]) {
+                    const double dr = a.bf_dist[r];
+                    if (dr >= 1e299) continue;
+                    for (int e = a.row_head[r]; e >= 0; e = a.e_next[e]) {
+                        const int c = a.e_col[e];
+                        if (a.match_row[r] == c) continue;                  // matched edge: only backwards
+                        const double nd = dr + a.e_cost[e];
+                        if (nd < a.bf_dist[n1 + c]) {
+                            a.bf_dist[n1 + c] = nd; a.bf_pred[n1 + c] = e; changed = true;
+                            const int r2 = a.match_col[c];
+                            if (r2 >= 0) {                                  // follow the matched edge back to its row
+                                double w = 0.0;
+                                for (int e2 = a.row_head[r2]; e2 >= 0; e2 = a.e_next[e2]) if (a.e_col[e2] == c) { w = a.e_cost[e2]; break; }
+                                if (nd - w < a.bf_dist[r2]) { a.bf_dist[r2] = nd - w; a.bf_pred[r2] = c; }
+                            }
+                        }
+                    }
+                }
+            }
+            int bc = -1;
+            double bd = 1e299;
+            for (int r = a.comp_head[root]; r >= 0; r = a.row_next[r])
+                for (int e = a.row_head[r]; e >= 0; e = a.e_next[e]) {
+                    const int c = a.e_col[e];
+                    if (a.match_col[c] < 0 && (a.bf_dist[n1 + c] < bd || (a.bf_dist[n1 + c] == bd && c < bc))) { bd = a.bf_dist[n1 + c]; bc = c; }
+                }
+            if (bc < 0) break;
+            // augment along the predecessor chain: column bc <- edge <- row <- (the column that row gives up) <- ...
+            int c = bc;
+            for (int guard = 0; guard < V && c >= 0; ++guard) {
+                const int e = a.bf_pred[n1 + c];
+                const int r = a.e_row[e];
+                const int prev_c = a.match_row[r];
+                a.match_row[r] = c;
+                a.match_col[c] = r;
+                c = prev_c;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// One scan of the initiator, by ONE workgroup of INIT_THREADS threads (initiator_kernel; the forest runs it inside post_scan_kernel,
+// between the scan's commit and the admission of the new targets).
+static __device__ void initiator_body(const InitArgs& a) {
+    __shared__ int s_cnt[8], s_scan[INIT_THREADS / 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    InitDev& st = *a.st;
+    const int n_pre = st.n_prelim, n_seed = st.n_seeds, have_last = st.have_last;
+    const double last = st.last_time;
+    if (tid < 8) s_cnt[tid] = 0;
+    __syncthreads();
+    // ---- the unused measurements, in ascending index order (MeasurementList.filterUnused) ----------------------------------------
+    int nU = 0;
+    {
+        int running = 0;
+        for (int base = 0; base < a.M; base += INIT_THREADS) {
+            const int j = base + tid;
+            const bool un = j < a.M && !(a.used && ((a.used[j >> 6] >> (j & 63)) & 1ull));
+            const unsigned long long bal = __ballot(un);
+            if (lane == 0) s_scan[wave] = __popcll(bal);
+            __syncthreads();
+            int off = running;
+            for (int w = 0; w < wave; ++w) off += s_scan[w];
+            int tot = 0;
+            for (int w = 0; w < INIT_THREADS / 64; ++w) tot += s_scan[w];
+            if (un) a.upos[off + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+            running += tot;
+            __syncthreads();
+        }
+        nU = running;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- (1) preliminary tracks (m_of_n.py:246-378) --------------------------------------------------------------------------------
+    int E = 0;
+    if (n_pre > 0 && have_last) {
+        const double dt = a.now - last;
+        // pv.Phi(dt), pv.Q(dt): float64 arithmetic cast to float32, Q then scaled by sigmaQ in float32 (models/pv.py:17-34)
+        float F[16] = {1, 0, (float)dt, 0, 0, 1, 0, (float)dt, 0, 0, 1, 0, 0, 0, 0, 1};
+        float Q[16];
+        for (int i = 0; i < 16; ++i) Q[i] = 0.f;
+        const float q4 = (float)(dt * dt * dt * dt / 4.0) * a.sigma_q, q3 = (float)(dt * dt * dt / 3.0) * a.sigma_q, q2 = (float)(dt * dt) * a.sigma_q;
+        Q[0] = Q[5] = q4; Q[2] = Q[8] = Q[7] = Q[13] = q3; Q[10] = Q[15] = q2;
+        for (int i = tid; i < n_pre; i += INIT_THREADS) {
+            const float* x = a.pstate + (size_t)i * 4;
+            const float* P = a.pcov + (size_t)i * 16;
+            float xp[4], FP[16], Ft[16], Pb[16];
+            gemm_chain<float, float, float, 4, 4, 1>(F, x, xp);
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[r * 4 + c] = F[c * 4 + r];
+            gemm_chain<float, float, float, 4, 4, 4>(F, P, FP);
+            gemm_chain<float, float, float, 4, 4, 4>(FP, Ft, Pb);
+            for (int e = 0; e < 16; ++e) Pb[e] += Q[e];
+            float Ct[8], CP[8], S[4], Sinv[4], PCt[8], K[8];
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
+            gemm_chain<float, float, float, 2, 4, 4>(a.C, Pb, CP);
+            gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, S);
+            for (int e = 0; e < 4; ++e) S[e] += a.R[e];
+            inv2(S, Sinv);
+            gemm_chain<float, float, float, 4, 4, 2>(Pb, Ct, PCt);
+            gemm_chain<float, float, float, 4, 2, 2>(PCt, Sinv, K);
+            for (int e = 0; e < 4; ++e) a.pred[(size_t)i * 4 + e] = xp[e];
+            for (int e = 0; e < 16; ++e) a.pcov[(size_t)i * 16 + e] = Pb[e];      // (covariance = P_bar until the update below)
+            if (nU == 0) continue;      // (see below: an empty list leaves state and counters alone)
+            for (int e = 0; e < 8; ++e) a.K[(size_t)i * 8 + e] = K[e];
+            a.tmeas[i] = -1;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // The reference returns from __processPreliminaryTracks right after the prediction when the list of unused measurements is
+        // empty (m_of_n.py:276-278): the covariances have been propagated, states, counters and the track list stay as they are.
+        if (nU > 0) {
+        // gate: (track, unused measurement) pairs with NIS <= gamma -> edges with the Euclidean distance as cost
+        const long long npairs = (long long)n_pre * nU;
+        for (long long w = tid; w < npairs; w += INIT_THREADS) {
+            const int i = (int)(w / nU), k = (int)(w % nU);
+            const int j = a.upos[k];
+            const float* xp = a.pred + (size_t)i * 4;
+            const float* Pb = a.pcov + (size_t)i * 16;
+            float zh[2], Ct[8], CP[8], S[4], Sinv[4];
+            gemm_chain<float, float, float, 2, 4, 1>(a.C, xp, zh);
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
+            gemm_chain<float, float, float, 2, 4, 4>(a.C, Pb, CP);
+            gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, S);
+            for (int e = 0; e < 4; ++e) S[e] += a.R[e];
+            inv2(S, Sinv);
+            const float dx = a.z[2 * j] - zh[0], dy = a.z[2 * j + 1] - zh[1];
+            const float t0 = fmaf(dy, Sinv[2], dx * Sinv[0]), t1 = fmaf(dy, Sinv[3], dx * Sinv[1]);
+            const float nis = t0 * dx + t1 * dy;
+            if ((double)nis <= a.gamma) {
+                const int e = atomicAdd(&s_cnt[0], 1);
+                if (e < INIT_ECAP) { a.e_row[e] = i; a.e_col[e] = k; a.e_cost[e] = (double)sqrtf(dx * dx + dy * dy); }
+            }
+        }
+        __syncthreads();
+        E = s_cnt[0];
+        if (E > INIT_ECAP) { if (tid == 0) st.overflow = 1; E = INIT_ECAP; }
+        __threadfence_block();
+        __syncthreads();
+        gnn_solve(a, n_pre, nU, E);
+        // Kalman update of the matched tracks, counters
+        for (int i = tid; i < n_pre; i += INIT_THREADS) {
+            const int k = a.match_row[i];
+            float* x = a.pstate + (size_t)i * 4;
+            const float* xp = a.pred + (size_t)i * 4;
+            if (k >= 0) {
+                const int j = a.upos[k];
+                float* Pb = a.pcov + (size_t)i * 16;
+                const float* K = a.K + (size_t)i * 8;
+                float zh[2];
+                gemm_chain<float, float, float, 2, 4, 1>(a.C, xp, zh);
+                const float dz[2] = {a.z[2 * j] - zh[0], a.z[2 * j + 1] - zh[1]};
+                float Kd[4], KC[16], KCP[16];
+                gemm_chain<float, float, float, 4, 2, 1>(K, dz, Kd);
+                for (int e = 0; e < 4; ++e) x[e] = xp[e] + Kd[e];
+                gemm_chain<float, float, float, 4, 2, 4>(K, a.C, KC);
+                gemm_chain<float, float, float, 4, 4, 4>(KC, Pb, KCP);
+                for (int e = 0; e < 16; ++e) Pb[e] = Pb[e] - KCP[e];
+                a.pm[i] += 1;
+                a.tmeas[i] = k;
+            } else {
+                for (int e = 0; e < 4; ++e) x[e] = xp[e];
+            }
+            a.pn[i] += 1;
+        }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const bool frozen = (nU == 0);      // (no verdicts either: see above)
+    // verdicts, births (in track order), compaction of the surviving preliminary tracks into the second buffer
+    int n_keep = 0, n_born = 0;
+    {
+        int run_keep = 0, run_born = 0;
+        for (int base = 0; base < n_pre; base += INIT_THREADS) {
+            const int i = base + tid;
+            int keep = 0, born = 0;
+            if (i < n_pre && frozen) keep = 1;
+            else if (i < n_pre) {
+                const float* x = a.pstate + (size_t)i * 4;
+                const int verdict = (a.pm[i] >= a.Mreq) ? 1 : ((a.pn[i] >= a.Nreq) ? -1 : 0);
+                const float speed = sqrtf(x[2] * x[2] + x[3] * x[3]);
+                if ((double)speed > a.v_max * 1.5 || verdict == -1) { keep = 0; }
+                else if (verdict == 1) { born = 1; }
+                else keep = 1;
+            }
+            const unsigned long long bk = __ballot(keep), bb = __ballot(born);
+            if (lane == 0) { s_scan[wave] = __popcll(bk) | (__popcll(bb) << 16); }
+            __syncthreads();
+            int offk = run_keep, offb = run_born, totk = 0, totb = 0;
+            for (int w = 0; w < INIT_THREADS / 64; ++w) {
+                const int v = s_scan[w];
+                if (w < wave) { offk += v & 0xffff; offb += v >> 16; }
+                totk += v & 0xffff; totb += v >> 16;
+            }
+            if (keep) {
+                const int p = offk + __popcll(bk & ((1ull << lane) - 1ull));
+                for (int e = 0; e < 4; ++e) a.pstate2[(size_t)p * 4 + e] = a.pstate[(size_t)i * 4 + e];
+                for (int e = 0; e < 16; ++e) a.pcov2[(size_t)p * 16 + e] = a.pcov[(size_t)i * 16 + e];
+                a.pn2[p] = a.pn[i]; a.pm2[p] = a.pm[i];
+            }
+            if (born) {
+                const int p = offb + __popcll(bb & ((1ull << lane) - 1ull));
+                if (p < a.born_cap) {
+                    for (int e = 0; e < 4; ++e) a.born_x[(size_t)p * 4 + e] = (double)a.pstate[(size_t)i * 4 + e];
+                    for (int e = 0; e < 16; ++e) a.born_P[(size_t)p * 16 + e] = a.pcov[(size_t)i * 16 + e];
+                    a.born_meas[p] = a.tmeas[i] + 1;          // measurementNumber = index in the unused list + 1 (m_of_n.py:353-358)
+                } else st.overflow = 1;
+            }
+            run_keep += totk; run_born += totb;
+            __syncthreads();
+        }
+        n_keep = run_keep; n_born = run_born < a.born_cap ? run_born : a.born_cap;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- unused' = unused measurements no preliminary track took (ascending) -> comp_nodes[0..nU2) holds their unused-list indices
+    int nU2 = 0;
+    {
+        int running = 0;
+        const bool any_match = n_pre > 0 && have_last;
+        for (int base = 0; base < nU; base += INIT_THREADS) {
+            const int k = base + tid;
+            const bool free = k < nU && !(any_match && a.match_col[k] >= 0);
+            const unsigned long long bal = __ballot(free);
+            if (lane == 0) s_scan[wave] = __popcll(bal);
+            __syncthreads();
+            int off = running, tot = 0;
+            for (int w = 0; w < INIT_THREADS / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
+            if (free) a.comp_nodes[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+            running += tot;
+            __syncthreads();
+        }
+        nU2 = running;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- (2) pair the leftovers with last scan's initiators (m_of_n.py:380-478) ---------------------------------------------------
+    int n_pre_now = n_keep;
+    if (n_seed > 0 && nU2 > 0) {
+        if (tid == 0) s_cnt[1] = 0;
+        __syncthreads();
+        const double dts = a.now - last;                       // (all initiators carry last scan's time stamp)
+        const double gate = a.v_max * dts;
+        const long long npairs = (long long)n_seed * nU2;
+        for (long long w = tid; w < npairs; w += INIT_THREADS) {
+            const int i = (int)(w / nU2), q = (int)(w % nU2);
+            const int j = a.upos[a.comp_nodes[q]];
+            const float dx = a.z[2 * j] - a.seeds[2 * i], dy = a.z[2 * j + 1] - a.seeds[2 * i + 1];      // float32 differences ...
+            const double d = sqrt((double)dx * (double)dx + (double)dy * (double)dy);                    // ... float64 norm
+            if (!(d > gate)) {
+                const int e = atomicAdd(&s_cnt[1], 1);
+                if (e < INIT_ECAP) { a.e_row[e] = i; a.e_col[e] = q; a.e_cost[e] = d; }
+            }
+        }
+        __syncthreads();
+        int E2 = s_cnt[1];
+        if (E2 > INIT_ECAP) { if (tid == 0) st.overflow = 1; E2 = INIT_ECAP; }
+        __threadfence_block();
+        __syncthreads();
+        gnn_solve(a, n_seed, nU2, E2);
+        // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference)
+        __shared__ int s_similar, s_np;
+        if (tid == 0) s_np = n_keep;
+        __syncthreads();
+        for (int i = 0; i < n_seed; ++i) {
+            const int q = a.match_row[i];
+            if (q < 0) continue;                               // uniform (global memory, written before the barrier)
+            const int j = a.upos[a.comp_nodes[q]];
+            float cand[4];
+            cand[0] = a.z[2 * j]; cand[1] = a.z[2 * j + 1];
+            cand[2] = (cand[0] - a.seeds[2 * i]) / (float)dts; cand[3] = (cand[1] - a.seeds[2 * i + 1]) / (float)dts;
+            if (tid == 0) s_similar = 0;
+            __syncthreads();
+            const int np = s_np;
+            for (int p = tid; p < np; p += INIT_THREADS) {     // PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1
+                float d[4], S[16], Si[16];
+                for (int e = 0; e < 4; ++e) d[e] = a.pstate2[(size_t)p * 4 + e] - cand[e];
+                for (int e = 0; e < 16; ++e) S[e] = a.pcov2[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
+                if (inv_small(S, 4, Si)) {
+                    float t[4];
+                    for (int c = 0; c < 4; ++c) { float acc = d[0] * Si[c]; for (int k = 1; k < 4; ++k) acc = fmaf(d[k], Si[k * 4 + c], acc); t[c] = acc; }
+                    float sim = t[0] * d[0];
+                    for (int k = 1; k < 4; ++k) sim = fmaf(t[k], d[k], sim);
+                    if (sim <= 1.0f) s_similar = 1;
+                }
+            }
+            __syncthreads();
+            if (!s_similar) {
+                if (np < a.Pcap) {
+                    if (tid < 4) a.pstate2[(size_t)np * 4 + tid] = cand[tid];
+                    if (tid < 16) a.pcov2[(size_t)np * 16 + tid] = a.P0[tid];
+                    if (tid == 0) { a.pn2[np] = 0; a.pm2[np] = 0; s_np = np + 1; }
+                } else if (tid == 0) st.overflow = 1;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        n_pre_now = s_np;
+    }
+    // ---- (3) next scan's initiators = leftovers nobody paired (ascending) ----------------------------------------------------------
+    int n_left = 0;
+    {
+        int running = 0;
+        const bool paired = n_seed > 0 && nU2 > 0;
+        for (int base = 0; base < nU2; base += INIT_THREADS) {
+            const int q = base + tid;
+            const bool left = q < nU2 && !(paired && a.match_col[q] >= 0);
+            const unsigned long long bal = __ballot(left);
+            if (lane == 0) s_scan[wave] = __popcll(bal);
+            __syncthreads();
+            int off = running, tot = 0;
+            for (int w = 0; w < INIT_THREADS / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
+            if (left) {
+                const int p = off + __popcll(bal & ((1ull << lane) - 1ull));
+                const int j = a.upos[a.comp_nodes[q]];
+                // (the seeds of THIS scan are still being read above?  no: every read of a.seeds sits before the last barrier)
+                if (p < a.Mcap) { a.bf_dist[2 * p] = (double)a.z[2 * j]; a.bf_dist[2 * p + 1] = (double)a.z[2 * j + 1]; }
+            }
+            running += tot;
+            __syncthreads();
+        }
+        n_left = running < a.Mcap ? running : a.Mcap;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int p = tid; p < n_left; p += INIT_THREADS) { a.seeds[2 * p] = (float)a.bf_dist[2 * p]; a.seeds[2 * p + 1] = (float)a.bf_dist[2 * p + 1]; }
+    // ---- merge confirmed candidates closer than the threshold (m_of_n.py:133-154): greedy, in order; a handful at most -------------
+    if (tid == 0) {
+        int nb = n_born, out = 0;
+        // `used` flags in born_flags (scratch until the end)
+        for (int i = 0; i < nb; ++i) a.born_flags[i] = 0;
+        for (int i = 0; i < nb; ++i) {
+            if (a.born_flags[i]) continue;
+            double sx[4] = {0, 0, 0, 0};
+            float sP[16];
+            for (int e = 0; e < 16; ++e) sP[e] = 0.f;
+            int cnt = 0, first = -1;
+            float fsx[4] = {0, 0, 0, 0};
+            for (int o = 0; o < nb; ++o) {
+                const float dx = (float)a.born_x[(size_t)i * 4] - (float)a.born_x[(size_t)o * 4], dy = (float)a.born_x[(size_t)i * 4 + 1] - (float)a.born_x[(size_t)o * 4 + 1];
+                const float d = sqrtf(dx * dx + dy * dy);
+                if ((double)d < a.merge_threshold) {
+                    if (!a.born_flags[o]) {
+                        if (first < 0) first = o;
+                        for (int e = 0; e < 4; ++e) fsx[e] += (float)a.born_x[(size_t)o * 4 + e];
+                        for (int e = 0; e < 16; ++e) sP[e] += a.born_P[(size_t)o * 16 + e];
+                        ++cnt;
+                    }
+                    a.born_flags[o] = 1;
+                }
+            }
+            (void)sx;
+            // results are written in place at `out` <= i (entries before i are final or consumed)
+            if (cnt == 1) {
+                if (out != first) {
+                    for (int e = 0; e < 4; ++e) a.born_x[(size_t)out * 4 + e] = a.born_x[(size_t)first * 4 + e];
+                    for (int e = 0; e < 16; ++e) a.born_P[(size_t)out * 16 + e] = a.born_P[(size_t)first * 16 + e];
+                    a.born_meas[out] = a.born_meas[first];
+                }
+            } else {
+                for (int e = 0; e < 4; ++e) a.born_x[(size_t)out * 4 + e] = (double)(fsx[e] / (float)cnt);
+                for (int e = 0; e < 16; ++e) a.born_P[(size_t)out * 16 + e] = sP[e] / (float)cnt;
+                a.born_meas[out] = 0;                          // the merged Target has no measurementNumber (m_of_n.py:150)
+            }
+            ++out;
+        }
+        for (int i = 0; i < out; ++i) { a.born_flags[i] = F_STATE_F32 | F_SCORE_F32; a.born_pd[i] = a.default_pd; }
+        *a.born_n = out;
+        st.n_born = out;
+        st.n_prelim = n_pre_now;
+        st.n_seeds = n_left;
+        st.have_last = 1;
+        st.last_time = a.now;
+        st.n_unused_out = nU;
+    }
+}
+
+}  // namespace mht

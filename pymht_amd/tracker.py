@@ -120,9 +120,7 @@ class Tracker():
         self._timing = bool(kwargs.get('deviceTiming', False))
         _lib.check(self._lib.mht_forest_set_timing(self._ctx.handle, int(self._timing)))
         # host mirror of the target list (one row per target, target-list order)
-        self._tbl_ = dict(id=np.zeros(0, np.int64), root_scan=np.zeros(0, np.int64), root_node=np.zeros(0, np.int64),
-                         root_meas=np.zeros(0, np.int64), root_x=np.zeros((0, 4)), root_cnllr=np.zeros(0),
-                         root_time=np.zeros(0), f32=np.zeros(0, bool))
+        self._tbl_ = np.zeros(0, dtype=_REPORT_DTYPE)      # (only id, root_scan, root_node, root_meas, root_x, root_cnllr are read)
         self._sel_ = None            # report records of the live targets after the last scan (selected leaves)
         self._labels = np.zeros(0, np.int64)
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
@@ -168,15 +166,9 @@ class Tracker():
         out = [t for t, a in zip(targets, ok) if a]
         if not out:
             return out
-        tb = self._tbl_
-        tb["id"] = np.concatenate([tb["id"], ids[ok].astype(np.int64)])
-        tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(len(out), scan, np.int64)])
-        tb["root_node"] = np.concatenate([tb["root_node"], np.full(len(out), -1, np.int64)])
-        tb["root_meas"] = np.concatenate([tb["root_meas"], meas[ok].astype(np.int64)])
-        tb["root_x"] = np.concatenate([tb["root_x"], x0[ok]], axis=0)
-        tb["root_cnllr"] = np.concatenate([tb["root_cnllr"], np.zeros(len(out))])
-        tb["root_time"] = np.concatenate([tb["root_time"], np.array([float(t.time) for t in out])])
-        tb["f32"] = np.concatenate([tb["f32"], f32[ok]])
+        rows = np.zeros(len(out), dtype=_REPORT_DTYPE)
+        rows["id"], rows["root_scan"], rows["root_node"], rows["root_meas"], rows["root_x"] = ids[ok], scan, -1, meas[ok], x0[ok]
+        self._tbl_ = np.concatenate([self._tbl_, rows])
         for t, i in zip(out, ids[ok]):
             self._birth[int(i)] = (t.time, scan, t.x_0, t.P_0, t.measurementNumber, t.measurement, t.status)
             t.ID = int(i)
@@ -197,8 +189,8 @@ class Tracker():
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
         try:
-            zd = self._upload_scan(z)
-            _lib.check(self._lib.mht_forest_step(self._ctx.handle, zd, z.shape[0]))
+            self._staged, self._staged_np = None, z      # (the library stages the scan in pinned memory and copies it itself)
+            _lib.check(self._lib.mht_forest_step_host(self._ctx.handle, z.ctypes.data_as(C.c_void_p), z.shape[0]))
         except _lib.MhtError as e:
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
@@ -210,7 +202,8 @@ class Tracker():
         if self.useInitiator:
             # 7 -- Initiate new tracks (tracker.py:264-278): on the device, right behind the scan's commit; what it gave birth to
             # comes back with the scan's report
-            _lib.check(self._lib.mht_forest_initiate(self._ctx.handle, self.initiator.handle, self._staged.data_ptr(), z.shape[0],
+            _lib.check(self._lib.mht_forest_initiate(self._ctx.handle, self.initiator.handle,
+                                                     self._staged.data_ptr() if self._staged is not None else None, z.shape[0],
                                                      float(scanList.time)))
         _lib.check(self._lib.mht_forest_report_begin(self._ctx.handle))
         prev, self._pending = self._pending, (scanList, z, aisList, tic if tic is not None else {'Total': time.time()})
@@ -324,16 +317,10 @@ class Tracker():
             return
         b = births[ok]
         n = len(b)
-        tb = self._tbl_
         x0 = b["x0"].astype(np.float32)
-        tb["id"] = np.concatenate([tb["id"], b["id"].astype(np.int64)])
-        tb["root_scan"] = np.concatenate([tb["root_scan"], np.full(n, scanNumber, np.int64)])
-        tb["root_node"] = np.concatenate([tb["root_node"], np.full(n, -1, np.int64)])
-        tb["root_meas"] = np.concatenate([tb["root_meas"], b["meas"].astype(np.int64)])
-        tb["root_x"] = np.concatenate([tb["root_x"], b["x0"]], axis=0)
-        tb["root_cnllr"] = np.concatenate([tb["root_cnllr"], np.zeros(n)])
-        tb["root_time"] = np.concatenate([tb["root_time"], np.full(n, float(scanTime))])
-        tb["f32"] = np.concatenate([tb["f32"], np.ones(n, bool)])
+        rows = np.zeros(n, dtype=_REPORT_DTYPE)
+        rows["id"], rows["root_scan"], rows["root_node"], rows["root_meas"], rows["root_x"] = b["id"], scanNumber, -1, b["meas"], b["x0"]
+        self._tbl_ = np.concatenate([self._tbl_, rows])
         for i in range(n):
             m = int(b["meas"][i])
             self._birth[int(b["id"][i])] = (scanTime, scanNumber, x0[i], b["P0"][i].reshape(4, 4).copy(), (m if m > 0 else None),
@@ -342,30 +329,22 @@ class Tracker():
         self._views.clear()
 
     def _apply_report(self, recs, scanTime, scanNumber, z):
-        """Fold the scan report into the host tables (vectorised; no per-target Python objects are created here)."""
-        tb = self._tbl_
+        """Fold the scan report into the host tables (no per-target Python objects, no per-field copies: the table of the live
+        targets IS the report's rows)."""
+        prev = self._tbl_
         self._views.clear()
-        self._labels = recs["cluster"].astype(np.int64) if len(recs) else np.zeros(0, np.int64)
+        self._labels = recs["cluster"]
         alive = recs["status"] == 0
-        if (~alive).any():
-            self._dead_chunks.append((recs[~alive].copy(), scanTime, scanNumber, z))
-        live = recs[alive]
-        moved = live["root_scan"] != tb["root_scan"][alive]
-        if moved.any():      # the root of these targets advanced: commit the new root to the history
-            m = live[moved]
-            rs = m["root_scan"].astype(np.int64)
-            times = self._scan_times[np.maximum(rs, 0)]
-            self._history.append(dict(id=m["id"].astype(np.int64), scan=rs, node=m["root_node"].astype(np.int64),
-                                      meas=m["root_meas"].astype(np.int64), x=m["root_x"].copy(),
-                                      cnllr=m["root_cnllr"].copy(), time=times))
-            root_time = tb["root_time"][alive].copy()
-            root_time[moved] = times
+        if alive.all():
+            live = recs
+            moved = live["root_scan"] != prev["root_scan"]
         else:
-            root_time = tb["root_time"][alive]
-        self._tbl_ = dict(id=live["id"].astype(np.int64), root_scan=live["root_scan"].astype(np.int64),
-                         root_node=live["root_node"].astype(np.int64), root_meas=live["root_meas"].astype(np.int64),
-                         root_x=live["root_x"].copy(), root_cnllr=live["root_cnllr"].copy(), root_time=root_time,
-                         f32=tb["f32"][alive])
+            self._dead_chunks.append((recs[~alive], scanTime, scanNumber, z))
+            live = recs[alive]
+            moved = live["root_scan"] != prev["root_scan"][alive]
+        if moved.any():      # the root of these targets advanced: the new roots join the committed history
+            self._history.append(live if moved.all() else live[moved])
+        self._tbl_ = live
         self._sel_ = (live, scanTime, scanNumber, z)
 
     # ---- results: every look at them first folds the report that is still in flight ---------------------------------------
@@ -446,7 +425,7 @@ class Tracker():
                     root = DeviceTarget(b[0], b[1], b[2], b[3], ID=tid, P_d=self.default_P_d, measurementNumber=b[4],
                                         measurement=b[5], status=b[6])
                 else:
-                    root = DeviceTarget(float(tb["root_time"][i]), int(tb["root_scan"][i]), tb["root_x"][i].copy(), self.P_0,
+                    root = DeviceTarget(float(self._scan_times[max(int(tb["root_scan"][i]), 0)]), int(tb["root_scan"][i]), tb["root_x"][i].copy(), self.P_0,
                                         ID=tid, P_d=self.default_P_d, measurementNumber=int(tb["root_meas"][i]),
                                         cumulativeNLLR=float(tb["root_cnllr"][i]))
                     root._lazy_parent = self._history_parent_loader(tid)
@@ -493,13 +472,13 @@ class Tracker():
             chain.append(first)
         for ch in self._history:
             for k in np.where(ch["id"] == target_id)[0]:
-                sc = int(ch["scan"][k])
+                sc = int(ch["root_scan"][k])
                 zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
-                m = int(ch["meas"][k])
-                v = DeviceTarget(float(ch["time"][k]), sc, ch["x"][k].copy(), self.P_0, ID=target_id, P_d=self.default_P_d,
+                m = int(ch["root_meas"][k])
+                v = DeviceTarget(float(self._scan_times[max(sc, 0)]), sc, ch["root_x"][k].copy(), self.P_0, ID=target_id, P_d=self.default_P_d,
                                  measurementNumber=m, measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
-                                 cumulativeNLLR=float(ch["cnllr"][k]))
-                v._tracker, v._node = self, int(ch["node"][k])
+                                 cumulativeNLLR=float(ch["root_cnllr"][k]))
+                v._tracker, v._node = self, int(ch["root_node"][k])
                 v.parent = chain[-1] if chain else None
                 chain.append(v)
         return chain
