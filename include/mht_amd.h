@@ -289,6 +289,10 @@ int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P
  * their fate appear in the report of that scan (mht_scan_report::births).  The initiator must have been created on the same ctx. */
 int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now);
 
+/* One radar scan of Tracker.addMeasurementList (tracker.py:162-307) in one call, nothing waits for the device: steps 1-6
+ * (mht_forest_step_host), step 7 (mht_forest_initiate, skipped when `in` is NULL), mht_forest_report_begin. */
+int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now);
+
 /* ---- a group of independent sectors on one device (BASELINE config 4: four sensor sectors = four independent Tracker
  * instances, pymht/tracker.py:39-137; nothing in tracker.py:162-307 couples two Tracker objects) -------------------------------
  * The members' forests step TOGETHER with one launch per stage (grow, cluster, ILP) for the whole group: a single sector is a

@@ -968,6 +968,15 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
     return mht_forest_step(ctx, f->z_dev, M);
 }
 
+// One radar scan of the drop-in API path in one call: steps 1-6 (mht_forest_step_host), step 7 (mht_forest_initiate, if an
+// initiator is given) and the start of the report's way to the host (mht_forest_report_begin).  Nothing here waits for the device.
+extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
+    int rc = mht_forest_step_host(ctx, z_host, M);
+    if (rc) return rc;
+    if (in) { rc = mht_forest_initiate(ctx, in, nullptr, M, now); if (rc) return rc; }
+    return mht_forest_report_begin(ctx);
+}
+
 // Starts the transfer of the last scan's report (commit first, if it is still pending) into one of two pinned host buffers and
 // returns; mht_forest_report waits for it.  A host that steps scan k+1 before it reads the report of scan k overlaps its own work
 // with the device's.

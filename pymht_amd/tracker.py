@@ -127,6 +127,7 @@ class Tracker():
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
+        self.scanStatsLog = [] if kwargs.get('logScanStats', False) else None      # lastScanStats (+ nTargets) of every scan
         self._pending = None        # the scan whose report is still on its way (folded by the next scan or by the first look)
         self._dead = False          # a device step failed: the forest cannot go on
         self._staged = self._staged_prev = self._staged_np = None
@@ -190,12 +191,13 @@ class Tracker():
         # forest) leaves the tracker exactly as it was.
         try:
             self._staged, self._staged_np = None, z      # (the library stages the scan in pinned memory and copies it itself)
-            _lib.check(self._lib.mht_forest_step_host(self._ctx.handle, z.ctypes.data_as(C.c_void_p), z.shape[0]))
+            _lib.check(self._lib.mht_forest_scan(self._ctx.handle, self.initiator.handle if self.useInitiator else None,
+                                                 z.ctypes.data_as(C.c_void_p), z.shape[0], float(scanList.time)))
         except _lib.MhtError as e:
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
             raise
-        self._after_step(scanList, z, aisList, tic)
+        self._queue_report(scanList, z, aisList, tic)
 
     def _after_step(self, scanList, z, aisList, tic=None):
         """Behind the device step: step 7 on the device, then the report starts its way to the host."""
@@ -206,6 +208,9 @@ class Tracker():
                                                      self._staged.data_ptr() if self._staged is not None else None, z.shape[0],
                                                      float(scanList.time)))
         _lib.check(self._lib.mht_forest_report_begin(self._ctx.handle))
+        self._queue_report(scanList, z, aisList, tic)
+
+    def _queue_report(self, scanList, z, aisList, tic):
         prev, self._pending = self._pending, (scanList, z, aisList, tic if tic is not None else {'Total': time.time()})
         if prev is not None:      # the scan before: its report has arrived (or is about to) while the device works on this one
             self._finish_scan(*prev, which=1)
@@ -309,6 +314,8 @@ class Tracker():
                                   leaves_out=rep.n_leaves_out, clusters=rep.n_clusters, ilp=rep.n_ilp,
                                   branched=rep.n_branched, blp_iters_max=rep.blp_iters_max, limit=rep.n_limit,
                                   unused=unusedRadarMeasurementIndices)
+        if self.scanStatsLog is not None:
+            self.scanStatsLog.append(dict(self._stats_, nTargets=len(self._tbl_)))
 
     def _apply_births(self, births, scanTime, scanNumber, z_unused):
         """The device initiator's candidates that Tracker.initiateTarget's device twin admitted: append them to the host mirror."""
