@@ -289,6 +289,15 @@ int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P
  * their fate appear in the report of that scan (mht_scan_report::births).  The initiator must have been created on the same ctx. */
 int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now);
 
+/* ---- one tracker on several devices: the independent per-cluster ILPs (tracker.py:228-236) are spread --------------------------------
+ * Every device holds the same forest and is fed the same scans and births; device shard_i of shard_n solves the clusters c with
+ * c % shard_n == shard_i.  sel_rel: dev [max_targets] int32 owned by the caller; after _begin it holds, for the targets whose
+ * cluster this device solved, the selected child's ordinal inside the target's block, -1 elsewhere.  The caller combines the
+ * devices' arrays with an element-wise MAX (all-reduce over RCCL) and calls _end, which finishes the scan for all targets.
+ * Asynchronous on the ctx stream. */
+int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel);
+int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel);
+
 /* One radar scan of Tracker.addMeasurementList (tracker.py:162-307) in one call, nothing waits for the device: steps 1-6
  * (mht_forest_step_host), step 7 (mht_forest_initiate, skipped when `in` is NULL), mht_forest_report_begin. */
 int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now);

@@ -1249,6 +1249,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
+            if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
             if (a.t_alive) {
                 const TgtPre q = pre_ok ? pre : load_target(a, mem[k]);
                 s.ch[k] = finish_target(a, mem[k], h, q, true);
@@ -1289,6 +1290,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = gs.ub_sel[k];
             a.sel[mem[k]] = h;
+            if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
             if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
         }
         prune_members(a, mem, K, gs.ch);
@@ -1326,12 +1328,19 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
         for (int i = blockIdx.x; i < nBig; i += gridDim.x) solve_cluster(a, a.big_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
         return;
     }
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) solve_cluster(a, a.multi_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
+    // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- cluster c is solved
+    // where c % shard_n == shard_i, a single-target cluster where its target index says so; see blp_epilogue_kernel)
+    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) {
+        const int c = a.multi_list[i];
+        if (a.shard_n > 1 && c % a.shard_n != a.shard_i) continue;
+        solve_cluster(a, c, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
+    }
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
     for (int i = gw; i < nSingle; i += gridDim.x * (BLP_THREADS / 64)) {
         const int t = a.single_list[i];
+        if (a.shard_n > 1 && t % a.shard_n != a.shard_i) continue;
         TgtPre pre = {};
         int cb, ce;
         if (a.t_alive) { pre = load_target(a, t); cb = pre.cb; ce = pre.ce; }
@@ -1349,7 +1358,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
             const int oi = __shfl_xor(bi, o);
             if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
         }
-        if (lane == 0) a.sel[t] = bi;
+        if (lane == 0) { a.sel[t] = bi; if (a.sel_rel) a.sel_rel[t] = bi - cb; }
         if (a.t_alive) {      // wave-uniform: every lane evaluates the (broadcast) look-ups, lane 0 stores
             const int key = finish_target(a, t, bi, pre, lane == 0);
             sweep_survivors(a, t, pre.j, cb, ce, key, va0, lane);
@@ -1367,6 +1376,32 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av)
     BlpArgs a;
     load_args(a, static_cast<const BlpArgs*>(av.p[blockIdx.y]));
     blp_body(a, lds);
+}
+
+// Cluster-sharded trackers (several devices hold identical forests and solve disjoint sets of clusters): after the selections have
+// been exchanged (sel_rel[t] = selected child relative to the target's block, identical on every device although the blocks may
+// sit at different node indices), every device runs the per-target end of the scan for ALL targets: termination test, N-scan
+// prune decision, new root, report record, surviving leaf range -- what blp_kernel does behind its own solves (tracker.py:891-916,
+// pyTarget.py:343-356).  One wavefront per target.
+__global__ __launch_bounds__(BLP_THREADS) void blp_epilogue_kernel(const BlpArgs a, const int32_t* nT_dev) {
+    if (a.status && a.status->overflow) return;
+    const int nT = *nT_dev, lane = threadIdx.x & 63;
+    for (int t = blockIdx.x * (BLP_THREADS / 64) + (threadIdx.x >> 6); t < nT; t += gridDim.x * (BLP_THREADS / 64)) {
+        const TgtPre pre = load_target(a, t);
+        const int s = pre.cb + a.sel_rel[t];
+        if (lane == 0) a.sel[t] = s;
+        const int va0 = sweep_prefetch(a, pre.j, pre.cb, pre.ce, lane);
+        const int key = finish_target(a, t, s, pre, lane == 0);
+        sweep_survivors(a, t, pre.j, pre.cb, pre.ce, key, va0, lane);
+    }
+}
+
+int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub) {
+    int grid = (n_targets_ub + BLP_THREADS / 64 - 1) / (BLP_THREADS / 64);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(blp_epilogue_kernel, dim3(grid), dim3(BLP_THREADS), 0, ctx->stream, a, nT_dev);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
 }
 
 int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds) {

@@ -58,6 +58,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)
     for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
+    if (a.sel_rel_reset) for (int t = tid; t < T; t += CL_THREADS) a.sel_rel_reset[t] = -1;
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
     if (tid == 0) { s_edges = 0; s_changed = 0; s_pend = 0; a.counts[3] = 0; a.counts[4] = 0; }
     __syncthreads();

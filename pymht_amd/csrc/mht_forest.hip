@@ -278,6 +278,7 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
+    bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
     // since that scan this bounds the current target count (targets only disappear otherwise)
@@ -747,6 +748,70 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------
     forest_end_step(f, pl, M);
     if (f->timing) { MHT_STEP_HIP(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
+    return MHT_OK;
+}
+
+// ---- cluster-sharded step: ONE tracker on several devices (north star: "independent track clusters shard across the GPUs ... when
+// the gating graph actually partitions") ---------------------------------------------------------------------------------------
+// Every device holds the same forest and is fed the same scans.  Grow and clustering are replicated (17 + 9 us at the headline
+// size: less than moving a layer between devices would cost); the 0-1 ILPs -- independent per cluster, tracker.py:228-236 -- are
+// spread: device i of n solves the clusters c with c % n == i (and the single-target clusters of its targets).  The selections
+// travel as child ordinals inside each target's block (sel_rel, [max_targets] int32 in caller-owned device memory, -1 = "not mine"):
+// one all-reduce(MAX) over them between _begin and _end gives every device every selection; _end then runs the per-target end of
+// the scan (termination, N-scan pruning) for all targets, so the forests stay identical.  A gating graph that is ONE component is
+// solved by one device while the others wait: the one-GPU fallback the north star asks for.
+extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel) {
+    MHT_REQUIRE(ctx && ctx->forest && sel_rel, "mht_forest_step_sharded_begin: null argument");
+    MHT_REQUIRE(shard_n >= 1 && shard_i >= 0 && shard_i < shard_n, "mht_forest_step_sharded_begin: bad shard %d of %d", shard_i, shard_n);
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(!f->timing, "mht_forest_step_sharded_begin: per-stage timing is not available for sharded steps");
+    MHT_REQUIRE(!f->shard_open, "mht_forest_step_sharded_begin: the previous sharded step has not been ended");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    StepPlan pl;
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) return rc; }
+    int rc;
+    {
+        FGrowArgs g;
+        fill_fgrow(f, pl.s, pl.fused, g);
+        FDyn d = {};
+        d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        rc = launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr);
+    }
+    f->commit_pending = false;
+    if (!rc) {
+        ClusterArgs c;
+        fill_cluster(f, pl.s, c);
+        c.sel_rel_reset = sel_rel;
+        rc = launch_cluster(ctx, c);
+    }
+    if (!rc) {
+        BlpArgs b;
+        fill_blp(f, pl.s, b);
+        b.shard_n = shard_n; b.shard_i = shard_i; b.sel_rel = sel_rel;
+        b.t_alive = nullptr;      // solve only: the per-target end of the scan follows the exchange (mht_forest_step_sharded_end)
+        int grid = f->nT_ub_step / 2 + 8;
+        if (grid > 1024) grid = 1024;
+        rc = launch_blp(ctx, b, grid);
+    }
+    if (rc) { f->dead = true; return rc; }
+    f->shard_open = true; f->shard_plan_s = pl.s; f->shard_plan_W = pl.W; f->shard_M = M;
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel) {
+    MHT_REQUIRE(ctx && ctx->forest && sel_rel, "mht_forest_step_sharded_end: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->shard_open, "mht_forest_step_sharded_end: no sharded step is open");
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    BlpArgs b;
+    fill_blp(f, f->shard_plan_s, b);
+    b.sel_rel = const_cast<int32_t*>(sel_rel);
+    const int rc = launch_blp_epilogue(ctx, b, &f->cnt->nT, f->nT_ub_step);
+    f->shard_open = false;
+    if (rc) { f->dead = true; return rc; }
+    StepPlan pl = {};
+    pl.s = f->shard_plan_s; pl.W = f->shard_plan_W;
+    forest_end_step(f, pl, f->shard_M);
     return MHT_OK;
 }
 

@@ -125,6 +125,7 @@ struct ClusterArgs {
     int seg_cap;                       //   segment stride
     int32_t* ticket_reset;             //   grow_kernel's tile ticket, reset to zero here for the next scan
     unsigned* alloc_reset;             //   fgrow_kernel's child counters [FG_REGIONS][32], reset to zero here for the next scan
+    int32_t* sel_rel_reset;            //   cluster-sharded step: [Tcap] set to -1 here (every device then fills in what it solved)
     // outputs
     int32_t* t_label;      // [T] smallest member of the component
     int32_t* t_cluster;    // [T] cluster index
@@ -168,7 +169,9 @@ struct BlpArgs {
     // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
     // targets; 2: default footprint, takes exactly those
     int cap_h, cap_r, cap_k, cap_uw, tier, t1_h, t1_k;
-    int32_t* big_list; int32_t* big_count;      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])
+    int32_t* big_list; int32_t* big_count;
+    int shard_n, shard_i;           // cluster sharding over devices with identical forests (0 / 1: off)
+    int32_t* sel_rel;               // [T] or null: selected child relative to the target's block (tchild[t]); -1 = not solved here      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])
     const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
     // (tracker.py:891-916, pyTarget.py:343-356), evaluated by whoever selected the target's leaf
@@ -200,6 +203,7 @@ void cluster_prepare(ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
+int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);
 
 }  // namespace mht

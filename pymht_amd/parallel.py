@@ -1,9 +1,13 @@
-"""Multi-GPU layout of the scan path: one process per GPU, one independent sensor sector (or cluster group) per
-process.  The path shards without any data-path collective when the gating graph partitions (BASELINE config 4:
-disjoint sectors), so torch.distributed (RCCL over xGMI on the GPU box, gloo in the CPU tests) is used only for
- - the barrier / max-over-ranks clock of the benchmark, and
- - gathering the per-sector track lists into one picture after a scan (`gather_tracks`), KB-sized and latency bound.
-SURVEY.md 8(e)."""
+"""Multi-GPU layout of the scan path: one process per GPU.
+
+Two levels, as the north star allows them:
+ * independent sensor sectors (BASELINE config 4): one tracker per rank, no data-path collective; torch.distributed (RCCL over
+   xGMI on the GPU box, gloo in the CPU tests) only carries the barrier / max-over-ranks clock of the benchmark and the gathering
+   of the per-sector track lists into one picture (`gather_tracks`, KB-sized, latency bound);
+ * ONE tracker on several GPUs when its gating graph partitions (`ClusterShardedTracker`): every rank holds the same forest and is
+   fed the same scans; the independent per-cluster ILPs (tracker.py:228-236) are spread over the ranks (cluster c -> rank c % n) and
+   the selections travel in ONE all-reduce(MAX) of max_targets int32 per scan (child ordinals inside each target's block, -1 = not
+   mine).  A graph that is one component is solved by one rank while the others wait: the one-GPU fallback."""
 import numpy as np
 import torch
 
@@ -64,3 +68,51 @@ def gather_tracks(ids, states, dist=None, device="cpu", max_tracks=4096):
         a = b[:k].cpu().numpy()
         out.append((a[:, 0].astype(np.int64), a[:, 1:].copy()))
     return out
+
+
+def merge_selections(sel_rel, dist=None):
+    """The exchange step of a cluster-sharded scan: element-wise MAX over the ranks of the per-target selections (-1 = not solved
+    here).  `sel_rel`: int32 tensor [max_targets] on the rank's device (cpu tensors with gloo).  In place."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(sel_rel, op=dist.ReduceOp.MAX)
+    return sel_rel
+
+
+class ClusterShardedTracker:
+    """ONE tracker on `shard_n` devices: wraps a `pymht_amd.tracker.Tracker` (rank `shard_i`'s copy of the forest) and steps it with
+    `mht_forest_step_sharded_begin` -> exchange -> `mht_forest_step_sharded_end`.
+
+    exchange(sel_rel): combines the ranks' selection arrays in place (default: `merge_selections` over torch.distributed; tests that
+    run two shards inside one process pass a function that takes the element-wise maximum of the two tensors).
+    Every rank must be given the same targets and the same scans; track initiation (step 7) runs replicated on every rank."""
+
+    def __init__(self, tracker, shard_n, shard_i, exchange=None, dist=None):
+        import torch
+        self.trk, self.shard_n, self.shard_i = tracker, int(shard_n), int(shard_i)
+        self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist))
+        self.sel_rel = torch.full((tracker._cfg.max_targets,), -1, dtype=torch.int32, device=tracker._ctx.device)
+
+    def begin(self, scanList):
+        """Grow, cluster and this rank's share of the ILPs (asynchronous)."""
+        from . import _lib
+        trk = self.trk
+        trk._drain()
+        self._tic = {'Total': __import__('time').time()}
+        self._z = trk._accept_scan(scanList, None, {})
+        zd = trk._upload_scan(self._z)
+        self.sel_rel.fill_(-1)      # (the device resets the live targets' entries itself; this also clears slots of targets long gone)
+        _lib.check(trk._lib.mht_forest_step_sharded_begin(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,
+                                                          self.sel_rel.data_ptr()))
+        self._scan = scanList
+
+    def end(self):
+        """After the exchange: the per-target end of the scan for all targets, step 7, report."""
+        from . import _lib
+        trk = self.trk
+        _lib.check(trk._lib.mht_forest_step_sharded_end(trk._ctx.handle, self.sel_rel.data_ptr()))
+        trk._after_step(self._scan, self._z, None, self._tic)
+
+    def addMeasurementList(self, scanList):
+        self.begin(scanList)
+        self.exchange(self.sel_rel)
+        self.end()

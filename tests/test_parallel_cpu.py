@@ -58,3 +58,35 @@ def test_cluster_assignment_balances():
     ranks = assign_clusters(sizes, 4)
     load = np.bincount(ranks, weights=sizes, minlength=4)
     assert set(ranks.tolist()) == {0, 1, 2, 3} and load.max() == 900 and load.min() >= 400
+
+
+def _merge_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pymht_amd import parallel
+    # the exchange step of a cluster-sharded scan (ClusterShardedTracker): rank r solved the clusters c with c % world == r; every
+    # target carries its selection on exactly one rank, -1 elsewhere
+    T, labels = 40, np.arange(40) // 3
+    sel = np.where(labels % world == rank, 100 + np.arange(T), -1).astype(np.int32)
+    out = parallel.merge_selections(torch.from_numpy(sel), dist)
+    q.put((rank, out.numpy().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_selection_exchange_over_gloo():
+    world, port = 2, 29433 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == (100 + np.arange(40)).tolist()      # every rank ends up with every selection

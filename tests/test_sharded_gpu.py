@@ -1,0 +1,115 @@
+"""GPU: ONE tracker whose independent clusters are solved on several devices (pymht_amd.parallel.ClusterShardedTracker,
+mht_forest_step_sharded_*) against the same tracker on one device, scan by scan.
+ * two shards inside one process on one GPU (two contexts, the all-reduce replaced by an element-wise maximum);
+ * two processes over RCCL (needs two GPUs: skipped on a one-GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tracker(sc, device=0, **kw):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=1024, maxNodes=1 << 18,
+                  maxMeasurements=1024, device=device, **kw)
+    trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+    return trk
+
+
+def _same(a, b, what):
+    sa, sb = a._sel[0], b._sel[0]
+    for name in ("id", "status", "sel_meas", "sel_x", "sel_cnllr", "score", "root_scan", "root_meas", "root_x", "n_leaves", "cluster"):
+        assert np.array_equal(sa[name], sb[name]), (what, name)
+    assert a.nTargets == b.nTargets, what
+    for k in ("L", "G", "M", "leaves_out", "clusters"):
+        assert a.lastScanStats[k] == b.lastScanStats[k], (what, k)
+
+
+@pytest.mark.parametrize("name,n_scans,shards", [("cfg3", 8, 2), ("dense", 10, 3)])
+def test_cluster_sharded_equals_single_device(name, n_scans, shards):
+    import torch
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    sc = make_config(name, seed=5446, n_scans=n_scans)
+    solo = _tracker(sc)
+    parts = [ClusterShardedTracker(_tracker(sc), shards, i, exchange=lambda t: None) for i in range(shards)]
+    n_ilp = 0
+    for k in range(n_scans):
+        sl = MeasurementList(float(sc["times"][k]), sc["scans"][k])
+        solo.addMeasurementList(sl)
+        for p in parts:
+            p.begin(sl)
+        # what the all-reduce(MAX) over RCCL does between the ranks
+        merged = torch.stack([p.sel_rel for p in parts]).max(dim=0).values
+        solved = torch.stack([(p.sel_rel >= 0).int() for p in parts]).sum(dim=0)
+        assert int(solved.max()) <= 1, "a target was solved by two shards"
+        for p in parts:
+            p.sel_rel.copy_(merged)
+            p.end()
+        for i, p in enumerate(parts):
+            _same(p.trk, solo, "scan %d shard %d" % (k, i))
+        n_ilp += solo.lastScanStats["ilp"]
+    assert n_ilp > 0
+    la = solo.leafBatch()
+    for p in parts:
+        lb = p.trk.leafBatch()
+        for key in la:
+            if key != "node":
+                assert np.array_equal(la[key], lb[key]), key
+        p.trk.close()
+    solo.close()
+
+
+def _rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    sc = make_config("cfg3", seed=5446, n_scans=6)
+    part = ClusterShardedTracker(_tracker(sc, device=rank), world, rank, dist=dist)
+    solo = _tracker(sc, device=rank) if rank == 0 else None
+    ok = True
+    for k in range(6):
+        sl = MeasurementList(float(sc["times"][k]), sc["scans"][k])
+        part.addMeasurementList(sl)
+        if solo is not None:
+            solo.addMeasurementList(sl)
+            try:
+                _same(part.trk, solo, "scan %d" % k)
+            except AssertionError:
+                ok = False
+    q.put((rank, ok, part.trk.nTargets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cluster_sharded_two_processes_rccl():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-process two-shard test covers the same code path)")
+    import torch.multiprocessing as mp
+    world, port = 2, 29733 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and res[0][2] == res[1][2]
