@@ -352,6 +352,9 @@ def main():
         order = sorted(range(len(big)), key=lambda i: -len(big[i]["cols"]))
         keep = sorted(set(order[:40]) | set(order[40::7]))
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
+    if "g6b" in which:
+        # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
+        run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
 
 
 if __name__ == "__main__":

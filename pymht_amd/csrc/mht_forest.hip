@@ -2,7 +2,8 @@
 // round trips between the stages.
 //
 // Data layout in HBM (all structure-of-arrays, owned by the ctx):
-//   layers[R]      ring of mht_nodes, one per scan of the N-scan window (R = N+2): layer s % R holds every
+//   layers[R]      ring of mht_nodes, one per scan of the N-scan window and one to spare (R = N+3: a host that folds the report of
+//                  scan k while scan k+1 is already running still finds all N+2 levels above a leaf of scan k): layer s % R holds every
 //                  hypothesis created at scan s (children of that scan, then roots born after it).  A node refers
 //                  to its parent by index into the previous layer (pyTarget.Target.parent).
 //   leaves         implicit: target t owns the nodes first[t] .. first[t]+count-1 of the newest layer (contiguous, in
@@ -401,12 +402,12 @@ using namespace mht;
 extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg) {
     MHT_REQUIRE(ctx && model && cfg, "mht_forest_create: null argument");
     MHT_REQUIRE(!ctx->forest, "mht_forest_create: the ctx already owns a forest");
-    MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 2 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 2);
+    MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 3 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 3);
     MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
     MHT_REQUIRE(cfg->max_targets >= 1 && cfg->max_targets <= 8192, "mht_forest_create: max_targets must be in [1, 8192]");
     MHT_REQUIRE(cfg->max_nodes >= 2 * cfg->max_targets + 512, "mht_forest_create: max_nodes must be at least 2 * max_targets + 512");
-    MHT_REQUIRE((cfg->n_scan + 2) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,
-                "mht_forest_create: (n_scan + 2) x max_meas = %d measurement nodes exceed the 16 bits of an edge record", (cfg->n_scan + 2) * (((cfg->max_meas + 63) / 64) * 64));
+    MHT_REQUIRE((cfg->n_scan + 3) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,
+                "mht_forest_create: (n_scan + 3) x max_meas = %d measurement nodes exceed the 16 bits of an edge record", (cfg->n_scan + 3) * (((cfg->max_meas + 63) / 64) * 64));
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     Forest* f = new (std::nothrow) Forest();
     MHT_REQUIRE(f, "mht_forest_create: out of host memory");
@@ -417,7 +418,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->Tcap = cfg->max_targets;
     f->Ncap = cfg->max_nodes;
     f->Mpad = ((cfg->max_meas + 63) / 64) * 64;
-    f->R = cfg->n_scan + 2;
+    f->R = cfg->n_scan + 3;
     f->PD = cfg->n_scan + 1;
     f->n_mnodes = f->R * f->Mpad;
     f->AW = f->n_mnodes / 64;
@@ -487,7 +488,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
     // cluster-kernel LDS budget check up front
     if (cluster_elds(f->Tcap, f->n_mnodes) < f->Tcap || cluster_elds(f->Tcap, f->n_mnodes) < 1024) {
-        set_error("mht_forest_create: max_targets=%d and (n_scan+2) x max_meas = %d measurement nodes do not fit the clustering "
+        set_error("mht_forest_create: max_targets=%d and (n_scan+3) x max_meas = %d measurement nodes do not fit the clustering "
                   "kernel's LDS budget (150 KiB: 16 B per target + 4 B per node, and three quarters of the rest must hold max(1024, max_targets) edges): lower max_targets / max_meas",
                   f->Tcap, f->n_mnodes);
         forest_destroy(ctx);

@@ -346,7 +346,11 @@ class Tracker():
             live = recs
             moved = live["root_scan"] != prev["root_scan"]
         else:
-            self._dead_chunks.append((recs[~alive], scanTime, scanNumber, z))
+            # terminated tracks keep their whole history (the reference's _pruneEverythingExceptHistory): the window ancestors of the
+            # last selected node are fetched now, while they are still in the device ring
+            dead = recs[~alive]
+            chains = [self._window_chain(scanNumber, int(r["sel_node"])) for r in dead]
+            self._dead_chunks.append((dead, scanTime, scanNumber, z, chains))
             live = recs[alive]
             moved = live["root_scan"] != prev["root_scan"][alive]
         if moved.any():      # the root of these targets advanced: the new roots join the committed history
@@ -450,9 +454,13 @@ class Tracker():
     def __terminatedTargets__(self):
         self._drain()
         out = []
-        for recs, scanTime, scanNumber, z in self._dead_chunks:
-            for r in recs:
-                out.append(self._node_view(r, scanTime, scanNumber, z))
+        for recs, scanTime, scanNumber, z, chains in self._dead_chunks:
+            for r, chain in zip(recs, chains):
+                v = self._node_view(r, scanTime, scanNumber, z)
+                tid, rs = int(r["id"]), int(r["root_scan"])
+                hist = [c for c in self._history_chain(tid) if c.scanNumber <= rs]      # committed roots up to the root it died with
+                self._link_chain(v, tid, chain, rs, int(r["root_node"]), hist[-1] if hist else None)
+                out.append(v)
         return out
 
     @property
@@ -497,41 +505,59 @@ class Tracker():
             return older[-1] if older else None
         return load
 
+    def _window_chain(self, scan, node):
+        """The ancestors of (scan, node) that are still in the device ring: arrays nodes, meas, x, cnllr, P (index 0 = the node)."""
+        n_max = self._cfg.n_scan + 2
+        nodes = np.zeros(n_max, dtype=np.int32)
+        meas = np.zeros(n_max, dtype=np.int32)
+        x = np.zeros((n_max, 4))
+        cn = np.zeros(n_max)
+        P = np.zeros((n_max, 16), dtype=np.float32)
+        n = C.c_int32(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.mht_forest_chain(self._ctx.handle, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P), C.byref(n)))
+        k = n.value
+        return nodes[:k], meas[:k], x[:k], cn[:k], P[:k]
+
+    def _link_chain(self, view, target_id, chain, root_scan, root_node, root_view):
+        """Hang the window ancestors `chain` under `view`; where the chain reaches (root_scan, root_node) it continues with
+        `root_view` (the committed history).  An ancestor at the root's scan that is NOT the root means the view was taken
+        before a prune that cut its branch off: the chain ends there (parent None) instead of being joined to a foreign root."""
+        nodes, meas, x, cn, P = chain
+        if len(P):
+            view.P_0 = P[0].reshape(4, 4).copy()
+        prev = view
+        for k in range(1, len(nodes)):
+            sc = view.scanNumber - k
+            if sc == root_scan:
+                prev._parent, prev._lazy_parent = (root_view if int(nodes[k]) == root_node or root_node < 0 else None), None
+                return view._parent
+            if sc < root_scan:
+                break
+            zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
+            m = int(meas[k])
+            a = DeviceTarget(self.__scanHistory__[sc - 1].time if sc >= 1 else view.time, sc, x[k].copy(),
+                             P[k].reshape(4, 4).copy(), ID=target_id, P_d=self.default_P_d, measurementNumber=m,
+                             measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
+                             cumulativeNLLR=float(cn[k]))
+            a._tracker, a._node = self, int(nodes[k])
+            prev._parent, prev._lazy_parent = a, None
+            prev = a
+        prev._lazy_parent = None
+        return view._parent
+
     def _make_parent_loader(self, target_id):
         def load(view):
             # ancestors inside the device window, then the committed root history kept on the host
-            n_max = self._cfg.n_scan + 2
-            nodes = np.zeros(n_max, dtype=np.int32)
-            meas = np.zeros(n_max, dtype=np.int32)
-            x = np.zeros((n_max, 4))
-            cn = np.zeros(n_max)
-            P = np.zeros((n_max, 16), dtype=np.float32)
-            n = C.c_int32(0)
-            p = lambda a: a.ctypes.data_as(C.c_void_p)
-            if len(self.__scanHistory__) - view.scanNumber >= self._cfg.n_scan + 2:
+            if len(self.__scanHistory__) - view.scanNumber >= self._cfg.n_scan + 3:      # (the device ring holds N+3 scans)
                 return None
-            _lib.check(self._lib.mht_forest_chain(self._ctx.handle, view.scanNumber, view._node, n_max, p(nodes), p(meas),
-                                                  p(x), p(cn), p(P), C.byref(n)))
-            i = int(np.where(self._tbl_["id"] == target_id)[0][0]) if (self._tbl_["id"] == target_id).any() else -1
-            root_scan = int(self._tbl_["root_scan"][i]) if i >= 0 else -1
-            view.P_0 = P[0].reshape(4, 4).copy()
-            prev = view
-            for k in range(1, n.value):
-                sc = view.scanNumber - k
-                if sc == root_scan:          # reached the current root: continue with the committed history
-                    root = self.__targetList__[i]
-                    prev._parent, prev._lazy_parent = root, None
-                    return view._parent
-                zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
-                m = int(meas[k])
-                a = DeviceTarget(self.__scanHistory__[sc - 1].time if sc >= 1 else view.time, sc, x[k].copy(),
-                                 P[k].reshape(4, 4).copy(), ID=target_id, P_d=self.default_P_d, measurementNumber=m,
-                                 measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
-                                 cumulativeNLLR=float(cn[k]))
-                a._tracker, a._node = self, int(nodes[k])
-                prev._parent, prev._lazy_parent = a, None
-                prev = a
-            return view._parent
+            chain = self._window_chain(view.scanNumber, view._node)
+            hit = np.where(self._tbl_["id"] == target_id)[0]
+            if len(hit) == 0:
+                return self._link_chain(view, target_id, chain, -1, -1, None)
+            i = int(hit[0])
+            return self._link_chain(view, target_id, chain, int(self._tbl_["root_scan"][i]), int(self._tbl_["root_node"][i]),
+                                    self.__targetList__[i])
         return load
 
     def _leaf_snapshot(self):

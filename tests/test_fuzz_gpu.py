@@ -1,0 +1,20 @@
+"""GPU: a seeded slice of the randomised parity runs (tests/fuzz_util.py; tools/fuzz_parity.py runs as many as one likes): 200 random
+scenarios through the drop-in Tracker and the oracle, compared scan by scan -- gating (L, G, unused measurements), target lists,
+selections, states (1e-6), cumulative scores, clusters, leaf sets, number of ILPs.  MHT_FUZZ_CASES / MHT_FUZZ_SEED change the slice."""
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fuzz_slice_against_oracle():
+    from fuzz_util import run_case
+    n = int(os.environ.get("MHT_FUZZ_CASES", "200"))
+    seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000"))
+    bad = []
+    for case in range(n):
+        ok, desc, msg = run_case(seed0 + case, max_leaves=1200, budget_s=6.0)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+    assert not bad, "\n".join(bad)

@@ -88,9 +88,56 @@ def test_gate_vs_oracle_random_shapes(gpu_ctx, n, M, seed):
         return
     o = orc.process_leaves(A, Q, Cm, R, 5.99, 1.2e-4, x, P, [0.8] * n, z.reshape(-1, 2))
     assert gate_sets(r["row_ptr"], r["col_idx"]) == [tuple(i.tolist()) for i in o["idx"]]
-    assert np.array_equal(r["x_bar"], o["x_bar"]) and np.array_equal(r["P_hat"], o["P_hat"])
+    # A LIVE oracle runs on this box's CPU, whose OpenBLAS kernels may order `A.dot(x)` differently from the development container's
+    # (the golden fixtures pin the bit-exact values): states to the north star's 1e-6 (relative to the largest component), index
+    # sets exactly
+    from trace_util import states_close
+    assert states_close(r["x_bar"], o["x_bar"]) and np.allclose(r["P_hat"], o["P_hat"], rtol=1e-6, atol=0)
     if len(r["col_idx"]):
-        assert np.array_equal(r["x_hat"], np.concatenate(o["x_hat"], axis=0))
+        assert states_close(r["x_hat"], np.concatenate(o["x_hat"], axis=0))
         assert np.allclose(r["nllr"], np.concatenate(o["nllr"]), rtol=0, atol=NLLR_ATOL)
     miss = r["cnllr"][r["child_ptr"][:-1]]
     assert np.array_equal(miss, cn - np.log(1 - 0.8))
+
+
+def test_gain_table_matches_golden_S_Sinv_K(gold_dir):
+    """kalman.precalc's S^-1 and K (kalman.py:90-92) read back FROM THE GPU: the forest keeps them per covariance column in its gain
+    table (csrc/mht_fgrow.hip: written one scan ahead by the chain workgroups, for new roots by add_targets_kernel).  Roots with the
+    golden vectors' covariances are planted and their gain rows compared bit for bit with the reference's S_inv, K; the gate
+    half-axes and the score constant are re-derived from the reference's S."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.models import pv
+    from pymht_amd.tracker import Tracker
+    g = np.load(os.path.join(gold_dir, "g1_kalman.npz"))
+    assert np.array_equal(np.asarray(pv.Phi(2.5)), g["A"]) and np.array_equal(np.asarray(pv.Q(2.5)), g["Q"])
+    checked = 0
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        P = np.ascontiguousarray(k("P"), dtype=np.float32).reshape(-1, 16)
+        n = P.shape[0]
+        pd = float(k("P_d"))
+        trk = Tracker(pv, 2.5, float(g["lambda_ex"]) - 1e-4, 1e-4, P_d=pd, N=3, eta2=float(g["eta2"]), maxTargets=512, maxNodes=1 << 14,
+                      maxMeasurements=64, useInitiator=False)
+        x0 = np.zeros((n, 4)); x0[:, 0] = 1000.0 * np.arange(n)
+        fl, pdv, me = np.zeros(n, np.uint8), np.full(n, pd), np.zeros(n, np.int32)
+        acc, ids = np.zeros(n, np.uint8), np.zeros(n, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(trk._lib.mht_forest_add_targets(trk._ctx.handle, n, p(x0), p(P), p(fl), p(pdv), p(me), 0, p(acc), p(ids)))
+        assert acc.all()
+        capc = 2 * trk._cfg.max_nodes + trk._cfg.max_targets
+        G = np.zeros((capc, 16), np.float32)
+        _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"G0", p(G), G.nbytes))
+        rows = G[2 * trk._cfg.max_nodes: 2 * trk._cfg.max_nodes + n]
+        assert np.array_equal(rows[:, 0:4], k("S_inv").reshape(n, 4)), c
+        assert np.array_equal(rows[:, 4:12], k("K").reshape(n, 8)), c
+        S = k("S").reshape(n, 4).astype(np.float32)
+        eta2 = np.float32(g["eta2"])
+        assert np.array_equal(rows[:, 13], np.sqrt(eta2 * np.abs(S[:, 0]))) and np.array_equal(rows[:, 14], np.sqrt(eta2 * np.abs(S[:, 3]))), c
+        two_pi = np.float32(2.0 * np.pi)
+        det = (S[:, 0] * two_pi) * (S[:, 3] * two_pi) - (S[:, 1] * two_pi) * (S[:, 2] * two_pi)      # (S is diagonal for the CV model)
+        lnc = np.log((np.float32(g["lambda_ex"]) * np.sqrt(det) / np.float32(pd)).astype(np.float64))
+        assert np.allclose(rows[:, 12], lnc, rtol=0, atol=NLLR_ATOL), c
+        checked += n
+        trk.close()
+    assert checked > 500

@@ -44,10 +44,10 @@ def tracker_selected(trk):
     return dict(ID=np.array([n.ID for n in nodes], dtype=np.int64),
                 x=np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes]).reshape(-1, 4),
                 cnllr=np.array([float(n.cumulativeNLLR) for n in nodes]),
-                meas=np.array([n.measurementNumber for n in nodes], dtype=np.int64))
+                meas=np.array([0 if n.measurementNumber is None else n.measurementNumber for n in nodes], dtype=np.int64))      # (None: a merged new target, m_of_n.py:150)
 
 
-@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3"])
+@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long"])
 def test_tracker_replays_reference_trace(name, gold_dir):
     from pymht_amd.utils.classDefinitions import MeasurementList
     g = np.load(os.path.join(gold_dir, name + ".npz"))
@@ -116,4 +116,27 @@ def test_tracker_vs_oracle_fresh_scenario(N, P_d, period, eta2, lam, seed):
         h = n_o.history_meas()
         chain = [m.measurementNumber for m in n_t.backtrackNodes()]
         assert h[-len(chain):] == [0 if c is None else int(c) for c in chain][-len(h):] or h[-3:] == chain[-3:]
+    trk.close()
+
+
+def test_terminated_tracks_keep_their_history():
+    """A terminated track's view walks back through its whole life (the reference keeps it via _pruneEverythingExceptHistory,
+    tracker.py:353-381): window nodes captured at termination + the committed roots -- compared with the oracle's terminated nodes,
+    also when it is looked at long after the device ring has moved on."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_scenario
+    sc = make_scenario(T=30, radius=400.0, lambda_phi=3e-5, n_scans=16, P_d=0.55, seed=3)      # low P_d: tracks die
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], 3, 5.99, sc["x0"], sc["t0"], useInitiator=False)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)
+    for x, a in zip(sc["x0"], acc):
+        assert o.initiate_target(sc["t0"], x.copy(), orc.model_P0()) == a
+    for z, t in zip(sc["scans"], sc["times"]):
+        o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+    dead = trk.__terminatedTargets__
+    assert len(dead) == len(o.terminated) >= 3
+    want = {n.ID: n.history_meas() for n in o.terminated}
+    for v in dead:
+        chain = [0 if m.measurementNumber is None else int(m.measurementNumber) for m in v.backtrackNodes()]
+        assert chain == want[v.ID], v.ID
     trk.close()
