@@ -1,27 +1,27 @@
-// grow_kernel: gate / update / score -- the L x M fan-out of every leaf hypothesis against every measurement
-// of a scan and the creation of the child hypotheses, ONE launch per scan
+// grow_kernel: the STATELESS gate / update / score seam (mht_gate_scan) -- the L x M fan-out of an explicit list of leaf
+// hypotheses against every measurement of a scan and the creation of the child hypotheses, ONE launch per call
 // (reference: pymht/tracker.py:804-859 + pymht/utils/kalman.py; children: pyTarget.py:227-258, :319-328).
+// The forest does NOT come through here: its grow stage is fgrow_kernel (mht_fgrow.hip, one workgroup per target, gains one
+// scan ahead).  This kernel serves callers that hold their own node arrays, and is the piece the golden Kalman vectors pin.
 //
 // Workgroup = 8 wavefronts = ONE tile of 32 consecutive leaves (tile = blockIdx while the grid is co-resident, ticket-
 // numbered beyond that -- see the look-back below).
 //   phase 1  lanes 0..31: one leaf per lane, SoA loads (coalesced), predict + precalc in registers (4x4 / 2x2
 //            matrices: no MFMA), P_bar / P_hat written to the covariance table of the new layer, everything the
-//            children need (x_bar, K, S^-1, z_hat, score constant, path + ancestor entries) parked in LDS.
+//            children need (x_bar, K, S^-1, z_hat, score constant) parked in LDS.
 //   phase 2  the scan (staged in LDS once per workgroup) is cut down to the measurements inside one of <= 4 bounding boxes
-//            (one per run of leaves of the same target); thread = (leaf, candidate): the leaf's own conservative float32
+//            (one per run of neighbouring leaves); thread = (leaf, candidate): the leaf's own conservative float32
 //            box, the exact reference-order NIS only on pairs that pass; hits set bits in the leaf's hit mask (LDS
 //            atomicOr).  No (L,M) tensor is ever materialised (the reference builds a 40 MB z_tilde + a 20 MB NIS).
-//   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense, DFS-ordered child index needs the number of
+//   phase 3  children of a leaf = 1 (missed detection) + hits.  The dense child index needs the number of
 //            children of ALL earlier leaves: every tile publishes its count, every 64th tile a group sum, as
-//            {epoch, flag, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences); a tile's
+//            {epoch, value} words (one 64-bit agent-scope atomic each: the data is the flag, no fences); a tile's
 //            base = group sums of earlier groups + counts of the earlier tiles of its own group: two L2 round trips
 //            (<= 512 tiles: all earlier counts directly, one word per thread: one round trip).
 //   phase 4  one thread per child: k-th set bit of the hit mask -> measurement, x_hat = x_bar + K z_tilde,
-//            NLLR, cumulative score, ILP cost, root->leaf measurement path, ancestor table, target association bit +
-//            deduplicated (target, measurement-node) edge for the clustering kernel.  Consecutive threads write
-//            consecutive children: all SoA stores are coalesced.
+//            NLLR, cumulative score.  Consecutive threads write consecutive children: all SoA stores are coalesced.
 // The bound is HBM traffic + launch/dependency latency; the kernel moves
-// 280 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
+// 200 B/leaf + 48 B/gated pair + 8 B/measurement of algorithmic data.
 #include "mht_kernels.h"
 #include <stdlib.h>
 
@@ -34,32 +34,9 @@ struct LeafLds {          // per-leaf results of phase 1/2 parked in LDS for pha
     float K[8];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
-    double rootc;
-    int src, tgt, cnt, base, depth, last_real;
-    int ppath[MAXPD];
-    int apath[MAXPD];
-    unsigned char flags, f32state, valid, first_of_target, root_f32;
+    int src, cnt, base;
+    unsigned char flags, f32state, valid;
 };
-
-template <typename TS>
-__device__ __forceinline__ void load_leaf(const GateArgs& a, int src, TS* xs, float* P) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xs[k] = (TS)a.x[(size_t)k * a.cap_in + src];
-    const int c = a.cov[src];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc_in + c];
-}
-
-// forest mode: position i in the implicit leaf list -> (target slot, node of the previous layer)
-__device__ __forceinline__ void locate_leaf(const int* off, const int32_t* first, int nT, int i, int& tgt, int& src) {
-    int lo = 0, hi = nT;                 // largest t with off[t] <= i
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (off[mid] <= i) lo = mid; else hi = mid;
-    }
-    tgt = lo;
-    src = first[lo] + (i - off[lo]);
-}
 
 __device__ __forceinline__ void box_from_S(const float* S, double eta2, float zhx, float zhy, float& bx, float& by) {
     // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widen for float32 rounding of the
@@ -114,7 +91,7 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned epoch, unsigne
 
 template <typename TS>
 __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, int i, int c, int k,
-                                           const unsigned long long* hw, const float* zx, const float* zy, int& new_edge_node) {
+                                           const unsigned long long* hw, const float* zx, const float* zy) {
     const size_t cap = a.cap_out;
     const uint8_t fl = g.flags;
     int meas = 0, covcol = 2 * i, j = -1;
@@ -131,19 +108,6 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
         j = w * 64 + __ffsll((long long)bits) - 1;
         meas = j + 1;
         covcol = 2 * i + 1;
-    }
-    // association of the target (tracker.py:255-258 / pyTarget.getMeasurementSet), issued FIRST so that the round trip
-    // of the returning atomic overlaps the arithmetic and the stores below: a hit child contributes its measurement;
-    // the miss child contributes the LAST real measurement on the parent's path (every tree node with a real measurement
-    // is contributed exactly once: by the leaf reached from it through misses only).
-    int node = -1;
-    unsigned long long old = 0ull, bit = 0ull;
-    if (a.out_path) {
-        node = meas > 0 ? a.cur_slot_base + meas - 1 : g.last_real;
-        if (node >= 0) {
-            bit = 1ull << (node & 63);
-            old = atomicOr(&a.assoc[(size_t)g.tgt * a.assoc_words + (node >> 6)], bit);
-        }
     }
     double cnl, inc;
     uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
@@ -176,24 +140,6 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
     a.ocov[c] = covcol;
     a.oflags[c] = cfl;
     if (a.nllr) a.nllr[c] = inc;
-    if (a.out_path) {
-        const double rootc = g.rootc;
-        // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and
-        // float32 / int stay float32
-        if ((cfl & F_SCORE_F32) && g.root_f32) a.ocost[c] = (double)(((float)cnl - (float)rootc) / (float)a.Nwin);
-        else a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
-#pragma unroll
-        for (int d = 0; d < MAXPD; ++d)
-            if (d < a.PD) {
-                int v = g.ppath[d];
-                if (d == g.depth && meas > 0) v = a.cur_slot_base + meas - 1;
-                a.out_path[(size_t)d * cap + c] = v;
-                a.out_apath[(size_t)d * cap + c] = (d == g.depth) ? c : g.apath[d];
-            }
-        a.out_tgt[c] = g.tgt;
-        if (meas > 0) a.used_bytes[meas - 1] = 1;
-        if (node >= 0 && !(old & bit)) new_edge_node = node;
-    }
 }
 
 // per-phase wall-clock stamps of every tile (tools/grow_profile.py): compiled in only with -DMHT_GROW_STAMPS, they cost
@@ -216,12 +162,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     float* zy = zx + Mpad;
     LeafLds* lg = reinterpret_cast<LeafLds*>(zy + Mpad);
     unsigned long long* hw = reinterpret_cast<unsigned long long*>(lg + GATE_TILE);    // [GATE_TILE][W]
-    int* off = reinterpret_cast<int*>(hw + (size_t)GATE_TILE * W);                      // [Tcap+1] forest mode
-    int* tfirst = off + (a.Tcap + 1);                                                   // [Tcap] per-target tables staged once
-    unsigned char* tdepth = reinterpret_cast<unsigned char*>(tfirst + a.Tcap);          // [Tcap] (<= MAXPD)
-    unsigned char* tshift = tdepth + a.Tcap;
-    unsigned short* told = reinterpret_cast<unsigned short*>(tshift + a.Tcap);          // [Tcap] deferred commit: slot in the old table
-    unsigned short* cand = told + a.Tcap;                                               // [Mpad] phase-2 candidates
+    unsigned short* cand = reinterpret_cast<unsigned short*>(hw + (size_t)GATE_TILE * W);   // [Mpad] phase-2 candidates
     __shared__ int s_base, s_total, s_stall, s_pref[GATE_TILE + 1];
     __shared__ int s_box[4][4], s_ncand;      // up to 4 target segments per tile: {min x, max x, min y, max y} as sortable ints
 
@@ -230,7 +171,7 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     // First round trip: the first slice of the scan
     const float2* z2 = reinterpret_cast<const float2*>(a.z);
     const float2 z_first = (tid < M) ? z2[tid] : make_float2(3.0e38f, 3.0e38f);
-    const int nT = 0, L = a.L;
+    const int L = a.L;
     const int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
 
     // One tile per workgroup.  Static mapping (tile = blockIdx) whenever the whole grid is co-resident: a workgroup spinning
@@ -245,7 +186,6 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     if (ntiles == 0 && bid == 0 && tid == 0) {      // no leaves at all
         a.child_ptr[0] = 0;
         a.status->n_children = 0;
-        if (a.tchild) a.tchild[0] = 0;
     }
     int tile = bid;
     if (tile < ntiles && ntiles > a.max_resident) {      // (workgroups beyond the last tile leave without a ticket)
@@ -262,11 +202,6 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             zx[j] = v.x;
             zy[j] = v.y;
         }
-        if (a.t_leaf_off && !a.fused)
-            for (int j = tid; j <= nT; j += GATE_THREADS) {
-                off[j] = a.t_leaf_off[j];
-                if (j < nT) { tfirst[j] = a.t_first[j]; tdepth[j] = (unsigned char)a.tgt_depth[j]; tshift[j] = (unsigned char)a.tgt_shift[j]; }
-            }
         for (int w = tid; w < GATE_TILE * W; w += GATE_THREADS) hw[w] = 0ull;      // hit masks of phase 2
         if (tid < 16) s_box[tid >> 2][tid & 3] = (tid & 1) ? (int)0x80000000 : 0x7fffffff;
         if (tid == 16) s_ncand = 0;
@@ -279,41 +214,16 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             g.valid = i < L;
             g.cnt = 0;
             if (g.valid) {
-                int src = a.leaf_src ? a.leaf_src[i] : i, tgt = -1;
-                if (a.t_leaf_off) locate_leaf(off, tfirst, nT, i, tgt, src);
+                const int src = a.leaf_src ? a.leaf_src[i] : i;
                 g.src = src;
-                g.tgt = tgt;
-                g.first_of_target = (tgt >= 0 && i == off[tgt]);
-                // Two load batches only -- (A) everything addressed by the leaf or its target, (B) the covariance column that
-                // A's `cov` names.  All of A is issued before anything is consumed and nothing sits behind a branch: target
-                // look-ups use a clamped index and are masked afterwards (the stateless seam has no target table).
-                const bool forest = tgt >= 0;
-                const int tgc = forest ? tgt : 0;
-                const int depth = forest ? tdepth[tgc] : 0, shift = forest ? tshift[tgc] : 0;
+                // Two load batches only -- (A) everything addressed by the leaf, (B) the covariance column that A's `cov`
+                // names.  All of A is issued before anything is consumed.
                 const uint8_t fl = a.flags[src];
                 const double cn = a.cnllr[src], pd = a.pd[src];
                 const int covc = a.cov[src];
                 double xd[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap_in + src];
-                double rootc = 0.0;
-                uint8_t rootf = 0;
-                int pv[MAXPD], av[MAXPD];
-                if (a.t_leaf_off) {                       // uniform
-                    const int ri = a.fused ? (int)told[tgc] : tgc;      // deferred commit: the root arrays are still in old-slot order
-                    rootc = a.t_root_cnllr[ri];
-                    rootf = a.t_root_f32[ri];
-#pragma unroll
-                    for (int d = 0; d < MAXPD; ++d) {
-                        const int row = (d < depth) ? d + shift : 0;
-                        const bool on = d < a.PD;         // uniform: levels beyond the window are never read
-                        pv[d] = on ? a.in_path[(size_t)row * a.cap_in + src] : -1;
-                        av[d] = on ? a.in_apath[(size_t)row * a.cap_in + src] : -1;
-                    }
-                } else {
-#pragma unroll
-                    for (int d = 0; d < MAXPD; ++d) { pv[d] = -1; av[d] = -1; }
-                }
                 float P[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc_in + covc];
@@ -321,29 +231,17 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 g.f32state = (fl & F_STATE_F32) ? 1 : 0;
                 g.cn = cn;
                 g.pd = pd;
-                g.depth = depth;
-                g.rootc = forest ? rootc : 0.0;
-                g.root_f32 = forest ? rootf : 0;
-                int last = -1;
-#pragma unroll
-                for (int d = 0; d < MAXPD; ++d) {
-                    const int v = (forest && d < depth) ? pv[d] : -1;
-                    g.ppath[d] = v;
-                    g.apath[d] = (forest && d < depth) ? av[d] : -1;
-                    if (v >= 0) last = v;
-                }
-                g.last_real = last;
                 if (!(a.ablate & 8)) {
                     if (g.f32state) phase1_leaf<float>(a, i, xd, P, g);
                     else phase1_leaf<double>(a, i, xd, P, g);
                 }
             }
-            // bounding boxes of the gates, one per run of leaves of the same target (the leaves of a target sit within a few
-            // hundred metres of each other, targets do not): the scan is first cut down to the measurements inside one of
-            // the <= 4 boxes, only those are tested per leaf
-            const int tg = g.valid ? g.tgt : -2, tp = __shfl_up(tg, 1);
+            // bounding boxes of the gates, one per run of neighbouring leaves (callers list the leaves of a target together:
+            // they sit within a few hundred metres of each other, targets do not): the scan is first cut down to the
+            // measurements inside one of the <= 4 boxes, only those are tested per leaf
+            const int tg = g.valid ? -1 : -2, tp = __shfl_up(tg, 1);
             const float pzx = __shfl_up(g.zhx, 1), pzy = __shfl_up(g.zhy, 1), pbx = __shfl_up(g.bx, 1), pby = __shfl_up(g.by, 1);
-            // stateless seam (no target table): a run ends where the predicted measurement jumps by more than a few gate widths
+            // a run ends where the predicted measurement jumps by more than a few gate widths
             const bool jump = tg == -1 && (fabsf(g.zhx - pzx) > 8.0f * (g.bx + pbx) || fabsf(g.zhy - pzy) > 8.0f * (g.by + pby));
             const bool head = g.valid && (tid == 0 || tg != tp || jump);
             const unsigned long long hb = __ballot(head);
@@ -500,20 +398,17 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
             const int cb = base + s_pref[tid];
             lg[tid].base = cb;
             a.child_ptr[i] = cb;
-            if (a.tchild && lg[tid].first_of_target) a.tchild[lg[tid].tgt] = cb;
             if (i == L - 1) {
                 const int all = base + total;
                 a.child_ptr[L] = all;
                 a.status->n_children = all;
                 if (all > a.cap_out) a.status->overflow = 1;
-                if (a.tchild) a.tchild[lg[tid].tgt + 1] = all;
             }
         }
         __syncthreads();
         GROW_STAMP(5);
         // ---- phase 4: one thread per child -----------------------------------------------------------------------------
         for (int r = tid; r < ((a.ablate & 1) ? 0 : ((total + 63) & ~63)); r += GATE_THREADS) {
-            int new_node = -1, tgt = -1;
             if (r < total) {
                 int l = 0;
 #pragma unroll
@@ -522,27 +417,9 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
                 const int k = r - s_pref[l];
                 const int c = base + r;
                 const int i = tile * GATE_TILE + l;
-                tgt = g.tgt;
                 if (c < a.cap_out) {
-                    if (g.f32state) emit_child<float>(a, g, i, c, k, hw + (size_t)l * W, zx, zy, new_node);
-                    else emit_child<double>(a, g, i, c, k, hw + (size_t)l * W, zx, zy, new_node);
-                }
-            }
-            if (a.edges) {          // wave-aggregated append of the new (target, measurement node) edges
-                const unsigned long long m = __ballot(new_node >= 0);
-                if (m) {
-                    int pos = 0;
-                    const int leader = __ffsll((long long)m) - 1;
-                    // 64 edge segments with their own counters (segment = workgroup & 63): all workgroups reach this point
-                    // within a few microseconds of each other and one counter word saturates at ~88 atomics/us
-                    const int seg = blockIdx.x & (EDGE_SEGS - 1);
-                    if (lane == leader) pos = atomicAdd(&a.edge_count[seg], __popcll(m));
-                    pos = __shfl(pos, leader);
-                    if (new_node >= 0) {
-                        const int my = pos + __popcll(m & ((1ull << lane) - 1ull));
-                        if (my < a.edge_cap) a.edges[(size_t)seg * a.edge_cap + my] = ((unsigned)tgt << 16) | (unsigned)new_node;
-                        else a.status->overflow = 1;
-                    }
+                    if (g.f32state) emit_child<float>(a, g, i, c, k, hw + (size_t)l * W, zx, zy);
+                    else emit_child<double>(a, g, i, c, k, hw + (size_t)l * W, zx, zy);
                 }
             }
         }
@@ -559,20 +436,17 @@ __global__ __launch_bounds__(GATE_THREADS, 4) void grow_kernel(const GateArgs a)
     }
 }
 
-static inline size_t grow_lds_bytes(int W, int Tcap) {
-    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)(2 * Tcap + 1) * 4 + (size_t)4 * Tcap + 16 +
-           (size_t)W * 64 * 2 + 2;      // + candidate list
+static inline size_t grow_lds_bytes(int W) {
+    return (size_t)2 * W * 64 * sizeof(float) + GATE_TILE * sizeof(LeafLds) + (size_t)GATE_TILE * W * 8 + (size_t)W * 64 * 2 + 16;      // + candidate list
 }
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     const int L = grid_leaves_hint > a.L ? grid_leaves_hint : a.L, W = a.W;
     if (!a.status) a.status = ctx->status;
-    a.fused = 0;
     int ntiles = (L + GATE_TILE - 1) / GATE_TILE;
     if (ntiles < 1) ntiles = 1;
-    // tile states: epoch-tagged; the forest owns its arrays and never resets them (ticket: reset to zero by whoever consumes
-    // the scan, see callers).  The stateless seam borrows the ctx scratch, which mht_solve_blp also uses and which may just have
-    // been reallocated: whatever is in there could pass for a tile state of this epoch, so it is cleared on every call.
+    // tile states: epoch-tagged.  They live in the ctx scratch, which mht_solve_blp also uses and which may just have been
+    // reallocated: whatever is in there could pass for a tile state of this epoch, so it is cleared on every call.
     if (!a.tile_state) {
         const size_t bytes = ((size_t)ntiles + ntiles / 64 + 16) * 8;
         int rc = ctx->hitmask.ensure(bytes);
@@ -584,8 +458,7 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("MHT_GROW_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
-    const int Tl = a.t_leaf_off ? a.Tcap : 0;
-    const size_t lds = grow_lds_bytes(W, Tl);
+    const size_t lds = grow_lds_bytes(W);
     // the grid must be co-resident (see the tile prefix): <= 4 workgroups per CU by registers, fewer if LDS says so
     int per_cu = (int)((160 * 1024) / (lds + 256));
     const int by_regs = 16 / (GATE_THREADS / 64);     // 4 wavefronts per SIMD at 128 registers = 16 per CU
@@ -604,9 +477,9 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
             printed = true;
         }
     }
-    const int blocks = ntiles + a.fused;              // + the workgroup that runs the deferred commit
-    a.max_resident = max_blocks - a.fused;                    // more tiles than that: dynamic tile numbers (see grow_kernel)
-    if (ntiles > max_blocks && !a.ticket)             // stateless seam: ticket word behind the tile states (cleared above)
+    const int blocks = ntiles;
+    a.max_resident = max_blocks;                      // more tiles than that: dynamic tile numbers (see grow_kernel)
+    if (ntiles > max_blocks && !a.ticket)             // ticket word behind the tile states (cleared above)
         a.ticket = reinterpret_cast<int32_t*>(a.group_state + ntiles / 64 + 4);
     size_t& attr_bytes = ctx->lds_attr_gate;
     if (lds > 48 * 1024 && lds > attr_bytes) {

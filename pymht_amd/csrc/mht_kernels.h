@@ -10,8 +10,8 @@ struct GateArgs {
     // input layer
     const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
     int cap_in, capc_in;
-    const int32_t* leaf_src;      // stateless seam: explicit leaf list (or null = identity)
-    int L;                        // stateless seam: number of leaves
+    const int32_t* leaf_src;      // explicit leaf list (or null = identity)
+    int L;                        // number of leaves
     const float* z; int M; int W;
     // cross-workgroup machinery of grow_kernel
     int32_t* ticket;              // tile ticket counter (zero at launch)
@@ -26,36 +26,6 @@ struct GateArgs {
     int cap_out, capc_out;
     int32_t* child_ptr; double* nllr; unsigned long long* used;
     DevStatus* status;
-    // forest extras (null for the stateless seam).  In forest mode the leaves are implicit: target t owns the
-    // nodes t_first[t] .. of the previous layer and the leaf positions t_leaf_off[t] .. t_leaf_off[t+1]-1.
-    const int32_t* t_leaf_off;    // [T+1] exclusive prefix of the leaf counts; L = t_leaf_off[nT]
-    const int32_t* t_first;       // [T] node index of the target's first leaf
-    const int32_t* nT_dev;        // number of targets
-    int Tcap;
-    const int32_t* in_path;       // [PD][cap_in] path of measurement-node ids below the root (prev scan children)
-    const int32_t* tgt_shift;     // [T] entries dropped from the front of the path (root advance)
-    const int32_t* tgt_depth;     // [T] path length of the target's leaves before this scan
-    int32_t* out_path;            // [PD][cap_out]
-    const int32_t* in_apath;      // [PD][cap_in] node index of the ancestor at depth d+1 below the root (own layer each)
-    int32_t* out_apath;           // [PD][cap_out]
-    int32_t* out_tgt;             // [cap_out] target slot
-    unsigned char* used_bytes;    // [M] byte j set iff measurement j was gated (plain stores, no atomics)
-    unsigned long long* assoc;    // [T][assoc_words] bitsets over measurement nodes of the window (dedup filter)
-    int assoc_words; int PD; int cur_slot_base;   // measurement-node id of measurement j of this scan = cur_slot_base + j
-    unsigned* edges; int32_t* edge_count; int edge_cap;   // deduplicated (target<<16 | node) edges: [EDGE_SEGS][edge_cap], counts [EDGE_SEGS]
-    int32_t* tchild;              // [T+1] first child of every target (children of a target are contiguous)
-    double* ocost;                // [cap_out] ILP cost of every child: getScore()/N (tracker.py:1127)
-    const double* t_root_cnllr;   // [T] cumulativeNLLR of the target's root
-    const uint8_t* t_root_f32;    // [T] the root score is a float32 value
-    int Nwin;                     // Tracker.N
-    // Deferred commit (forest mode).  fused = 1: the target-side commit of the PREVIOUS scan has not run; workgroup 0 of this
-    // launch runs it (CommitArgs, second kernel argument) while every tile derives the compacted target table it needs
-    // -- leaf ranges, depth, shift, old slot -- in LDS from that scan's per-target results (p_*), indexed by old slot.
-    // nT_dev then points at the old table's target count and t_root_cnllr / t_root_f32 at the old-slot root arrays.
-    int fused;
-    const int32_t* p_status; const int32_t* p_count; const int32_t* p_jdrop; const int32_t* p_firstsurv; const int32_t* p_depth;
-    const DevStatus* prev_status;     // forest mode: status word of the previous scan (overflow there voids this scan too)
-    const int32_t* sticky_overflow;   // forest mode: FCounts::overflow
 };
 
 struct CommitArgs;

@@ -1,0 +1,38 @@
+"""Development aid: the slowest ILPs of a long headline stream (per-cluster times from the forest's debug arrays)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from pymht_amd import _lib
+from pymht_amd.utils.scenario import make_config
+from pymht_amd.utils.classDefinitions import MeasurementList
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+sc = make_config('cfg3', seed=5446, n_scans=n, confine=True)
+trk = bench.make_tracker(sc, 0, deviceTiming=True)
+def rd(name, k, dt=np.int32):
+    a = np.zeros(k, dtype=dt)
+    _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+    return a
+rows = []
+stage = []
+for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
+    trk.addMeasurementList(MeasurementList(float(t), z))
+    if k < 20: continue
+    stage.append(1e6 * trk.toc['Optim'])
+    cnt = rd('cl_counts', 8); nC, nM = cnt[0], cnt[1]
+    ptr = rd('cl_ptr', nC + 1); ml = rd('multi_list', nM); it = rd('cl_iters', nC); tm = rd('cl_time', 8 * nC).reshape(-1, 8); st = rd('cl_status', nC); nd = rd('cl_nodes', nC)
+    nT0 = int(ptr[nC]); tch = rd('tchild', nT0 + 1); tce = rd('tcend', nT0 + 1); mem = rd('cl_members', nT0)
+    for c in ml:
+        K = ptr[c + 1] - ptr[c]
+        nH = int(sum(tce[m] - tch[m] for m in mem[ptr[c]:ptr[c + 1]]))
+        rows.append((tm[c, 1] / 100.0, k, int(K), nH, int(it[c]), int(st[c]), int(nd[c]), tm[c, 0] / 100.0))
+rows.sort(reverse=True)
+t = np.array([r[0] for r in rows])
+print('%d ILPs over %d scans: mean %.1f us, p50 %.1f, p90 %.1f, p99 %.1f, max %.1f; Optim stage mean %.1f p90 %.1f max %.1f' % (
+    len(rows), n - 20, t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max(), np.mean(stage), np.percentile(stage, 90), np.max(stage)))
+print('slowest: (us, scan, K, nH, iters, status[1 cert 2 bb 3 limit], nodes, setup us)')
+for r in rows[:25]: print('  ', tuple(round(x, 1) if isinstance(x, float) else x for x in r))
+per_scan = {}
+for r in rows: per_scan[r[1]] = max(per_scan.get(r[1], 0), r[0])
+m = np.array(list(per_scan.values()))
+print('slowest ILP of a scan: mean %.1f p50 %.1f p90 %.1f max %.1f' % (m.mean(), np.percentile(m, 50), np.percentile(m, 90), m.max()))
