@@ -31,7 +31,7 @@ struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in L
     float K[8];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
-    int src;
+    int src, pidn;                    // pidn: hit/miss pattern of the leaf relative to the target's current root
     unsigned char flags, f32state, valid, pad;
 };
 static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesses");
@@ -75,11 +75,16 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
 #endif
 
 // ---- chain workgroups: the covariance chain one scan ahead ---------------------------------------------------------------
-// Wavefront = (target, hit/miss); lane = leaf.  For leaf `src` (node of the previous layer, covariance P = Pin[cov[src]]):
-//   full chain from P -> P_bar, P_hat; the child's covariance Pc = hit ? P_hat : P_bar goes to column 2*src+hit of the new
-//   layer's pool (exactly the sharing of the reference: one ndarray for all hit children, pyTarget.py:246), and the gains the
-//   child will need when IT is a leaf next scan -- S^-1, K, ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from
-//   predict(Pc) -- go to row 2*src+hit of the gain table.
+// The covariance of a hypothesis does not depend on WHICH measurements it was updated with, only on whether there was one:
+// P -> P_bar -> S, K -> P_hat never sees z (kalman.py:62, :90-93), and the reference itself shares one P_hat among all hit
+// children of a node (pyTarget.py:246).  So the covariances below a root are keyed by the hit/miss PATTERN since that root:
+// pattern id 1 = the root, child pattern = 2 * pattern + hit; a target has <= 2^depth of them whatever its number of leaves
+// (~3.5 distinct ones per target on the headline stream, 32 leaves).  Column of a node's covariance in its layer's pool =
+// slot * PS + pattern, PS = 2^(N+2), slot = the target's slot in the table the grow launch that made the node ran on.
+// Wavefront = (target, hit/miss); the lanes first agree on the distinct columns among the target's leaves (ballots), then lane k
+// runs, for the k-th distinct column: the full chain from P -> P_bar, P_hat; the child's covariance Pc = hit ? P_hat : P_bar goes
+// to the child pattern's column of the new layer's pool, and the gains the child will need when IT is a leaf next scan --
+// S^-1, K, ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from predict(Pc) -- to the same row of the gain table.
 __device__ __forceinline__ void gains_record(const Model& m, const CovChain& c, double pd, float4* g) {
     const float lnc = nllr_const(c.S, m.lambda_ex, pd);
     const float rx = sqrtf((float)m.eta2 * fabsf(c.S[0])), ry = sqrtf((float)m.eta2 * fabsf(c.S[3]));
@@ -99,13 +104,29 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
     const TInfo ti = target_info(a, d, t, nT);
     if (po || so) return;
     FG_STAMP(0);
-    for (int l = lane; l < ti.cnt; l += 64) {
-        const int src = ti.first + l;
+    const int PS = 1 << a.ps_log2;
+    for (int l0 = 0; l0 < ti.cnt; l0 += 64) {
+        const bool v = l0 + lane < ti.cnt;
+        const int src = ti.first + (v ? l0 + lane : 0);
         const int covc = a.cov[src];
-        const double pd = a.pd[src];
+        // distinct columns among these leaves: lane k takes the k-th (another chunk of the same target may repeat one: it is then
+        // computed twice, with identical results)
+        unsigned long long rem = __ballot(v);
+        int mycol = -1, mysrc = 0;
+        for (int k = 0; rem; ++k) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const int cv = __shfl(covc, leader), sv = __shfl(src, leader);
+            rem &= ~__ballot(covc == cv);
+            if (lane == k) { mycol = cv; mysrc = sv; }
+        }
+        if (mycol < 0) continue;
+        const double pd = a.pd[mysrc];
         float P[16];
+        {
+            const float4* pp = reinterpret_cast<const float4*>(a.P + (size_t)mycol * 16);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) P[e] = a.P[(size_t)e * a.capc + covc];
+            for (int q = 0; q < 4; ++q) { const float4 w = pp[q]; P[q * 4] = w.x; P[q * 4 + 1] = w.y; P[q * 4 + 2] = w.z; P[q * 4 + 3] = w.w; }
+        }
         Model mdl;          // (uniform registers)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
@@ -119,9 +140,14 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
         float Pc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) Pc[e] = h ? c.P_hat[e] : c.P_bar[e];
-        const int col = 2 * src + h;
+        // the leaf's pattern relative to the (possibly advanced) root, then the child's
+        const int pidn = ((mycol & (PS - 1)) & ((1 << ti.depth) - 1)) | (1 << ti.depth);
+        const int col = (t << a.ps_log2) + 2 * pidn + h;
+        {
+            float4* po = reinterpret_cast<float4*>(a.oP + (size_t)col * 16);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) a.oP[(size_t)e * a.capc + col] = Pc[e];
+            for (int q = 0; q < 4; ++q) po[q] = make_float4(Pc[q * 4], Pc[q * 4 + 1], Pc[q * 4 + 2], Pc[q * 4 + 3]);
+        }
         CovChain g;
         cov_chain(mdl, Pc, g, false);
         float4 rec[4];
@@ -140,7 +166,7 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 template <typename TS, typename ARGS>
 __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
-                                              double rootc, int root_f32) {
+                                              double rootc, int root_f32, int covbase) {
     const size_t cap = a.cap;
     const uint8_t fl = g.flags;
     int meas = 0, hit = 0, j = -1;
@@ -232,7 +258,7 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     }
     FG_STAMPX(5);
     a.omeas[c] = meas;
-    a.ocov[c] = 2 * g.src + hit;
+    a.ocov[c] = covbase + 2 * g.pidn + hit;
     a.oflags[c] = cfl;
     if (k > 0) a.used_bytes[j] = 1;
     // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and float32 / int stay
@@ -287,6 +313,10 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
         return;
     }
     if (!ti.alive) return;
+    if (ti.depth + 2 > a.ps_log2) {      // (cannot happen: the N-scan window bounds the depth) pattern ids would leave the slot's columns
+        if (tid == 0) a.status->overflow = 1;
+        return;
+    }
     FG_STAMP(1);
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
@@ -394,6 +424,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
                 g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by;
                 g.pad = 0;
+                g.pidn = ((covc & ((1 << a.ps_log2) - 1)) & ((1 << depth) - 1)) | (1 << depth);
                 if (keep) lg[tid] = g;
                 // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first
                 // cut down to the measurements inside it
@@ -578,8 +609,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (g.f32state) fg_emit_child<float>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    if (g.f32state) fg_emit_child<float>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, t << a.ps_log2);
+                    else fg_emit_child<double>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, t << a.ps_log2);
                 }
                 run += ctot;
             }

@@ -46,7 +46,7 @@ struct AddArgs {
     int check; double thr;
     mht_nodes layer;     // newest layer
     TTable tab; int32_t* path; int32_t* apath; int PD;
-    FCounts* cnt; int scan; int Nwin; int Tcap; int cov_base;
+    FCounts* cnt; int scan; int Nwin; int Tcap; int ps_log2;
     int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
     Model model; float4* G; int root_base;
@@ -59,7 +59,7 @@ struct AddArgs {
 // then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
 static __device__ void add_targets_body(const AddArgs& a) {
     const int tid = threadIdx.x;
-    const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
+    const int nT0 = a.cnt->nT, L0 = a.cnt->L;
     int an = a.n;
     if (a.n_dev) { const int nd = *a.n_dev; an = nd < an ? nd : an; }
     if (an <= 0) {          // nothing to admit (the usual case behind the device initiator)
@@ -119,9 +119,10 @@ static __device__ void add_targets_body(const AddArgs& a) {
                 a.layer.pd[idx] = a.pd[q];
                 a.layer.parent[idx] = -1;
                 a.layer.meas[idx] = a.meas[q];
-                a.layer.cov[idx] = a.cov_base + r;
+                const int col = (t << a.ps_log2) + 1;      // pattern 1 = the root (mht_fgrow.hip, chain workgroups)
+                a.layer.cov[idx] = col;
                 a.layer.flags[idx] = a.flags[q];
-                for (int e = 0; e < 16; ++e) a.layer.P[(size_t)e * a.layer.cap_cov + a.cov_base + r] = a.P0[q * 16 + e];
+                for (int e = 0; e < 16; ++e) a.layer.P[(size_t)col * 16 + e] = a.P0[q * 16 + e];
                 for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
                 a.tab.id[t] = a.cnt->id_counter;
                 a.tab.window[t] = a.Nwin;
@@ -166,7 +167,7 @@ static __device__ void add_targets_body(const AddArgs& a) {
         cov_chain(a.model, P, c, false);
         const float lnc = nllr_const(c.S, a.model.lambda_ex, a.pd[q]);
         const float rx = sqrtf((float)a.model.eta2 * fabsf(c.S[0])), ry = sqrtf((float)a.model.eta2 * fabsf(c.S[3]));
-        float4* g = a.G + (size_t)(a.cov_base + r0 + k) * 4;
+        float4* g = a.G + ((size_t)((nT0 + k) << a.ps_log2) + 1) * 4;      // (admissions are sequential: the k-th took slot nT0 + k)
         g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
         g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
         g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
@@ -205,7 +206,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
         const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
         for (int k = 0; k < 4; ++k) a.x[i * 4 + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
         const int c = a.layer.cov[nd];
-        for (int e = 0; e < 16; ++e) a.P[i * 16 + e] = a.layer.P[(size_t)e * a.layer.cap_cov + c];
+        for (int e = 0; e < 16; ++e) a.P[i * 16 + e] = a.layer.P[(size_t)c * 16 + e];
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
@@ -226,7 +227,7 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.cnllr[n] = l.cnllr[nd];
         for (int k = 0; k < 4; ++k) a.x[n * 4 + k] = l.x[(size_t)k * l.cap + nd];
         const int c = l.cov[nd];
-        for (int e = 0; e < 16; ++e) a.P[n * 16 + e] = l.P[(size_t)e * l.cap_cov + c];
+        for (int e = 0; e < 16; ++e) a.P[n * 16 + e] = l.P[(size_t)c * 16 + e];
         ++n;
         nd = l.parent[nd];
         --sc;
@@ -248,7 +249,7 @@ struct Arena {
 struct Forest {
     mht_forest_config cfg;
     mht_model model;
-    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, Ecap, SegCap;
+    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, ps_log2, Ecap, SegCap;
     Arena arena;
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
@@ -422,7 +423,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->PD = cfg->n_scan + 1;
     f->n_mnodes = f->R * f->Mpad;
     f->AW = f->n_mnodes / 64;
-    f->capc = 2 * f->Ncap + f->Tcap;
+    f->ps_log2 = cfg->n_scan + 2;      // hit/miss patterns below a root: ids < 2^(depth + 1), depth <= N + 1 after a grow
+    f->capc = f->Tcap << f->ps_log2;
     f->Ecap = 4 * f->Ncap;              // edges the clustering kernel can take beyond its LDS list (spill arrays)
     f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
     {   // node index space of a layer: [static block per target slot | overflow area in FG_REGIONS regions | roots born into the layer]
@@ -514,7 +516,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb]; a.vidx = nb;
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
-    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.ps_log2 = f->ps_log2;
     a.near = f->near;
     fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
@@ -583,7 +585,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     fill_model_only(g.model, &f->model);
     g.default_pd = f->model.default_pd; g.default_miss_nllr = f->model.default_miss_nllr;
     g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
-    g.cap = f->Ncap; g.capc = f->capc;
+    g.cap = f->Ncap; g.capc = f->capc; g.ps_log2 = f->ps_log2;
     g.G_in = f->G[(s - 1) & 1]; g.G_out = f->G[s & 1];
     g.in_path = f->path[(s - 1) & 1]; g.in_apath = f->apath[(s - 1) & 1]; g.pds = f->pds;
     g.Tcap = f->Tcap;
@@ -996,7 +998,7 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb]; a.vidx = nb;
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
-    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.cov_base = 2 * f->Ncap;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.ps_log2 = f->ps_log2;
     a.near = f->near;
     fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
     a.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);

@@ -38,7 +38,8 @@ struct FGrowArgs {
     double default_pd, default_miss_nllr;
     // input layer (the previous scan's nodes); cap / capc are the same for every layer of the ring
     const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
-    int cap, capc;
+    int cap, capc;                 // P: [capc][16] (a record per column); column = slot * 2^ps_log2 + hit/miss pattern (mht_fgrow.hip)
+    int ps_log2;
     const float4* G_in;            // [capc][4] gains by covariance column of the input layer (written one scan ahead)
     const int32_t* in_path;        // [cap][pds] measurement nodes below the root, one record per node of the input layer
     const int32_t* in_apath;       // [cap][pds] ancestor node per level
