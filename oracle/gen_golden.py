@@ -357,5 +357,24 @@ def main():
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
 
 
+def gen_g10(dump_dir):
+    """Small clusters without a dual certificate (3..9 near-duplicate tracks): the slowest ILPs of four 276-scan headline streams
+    (seeds 5446/5463/5480/5497, `confine=True`), dumped on the GPU box by `python tools/blp_tail.py 276 SEED gpurun_out/ilp`
+    (columns = path records of the forest, costs = its ILP cost array).  Exact optimum and uniqueness by HiGHS, as for g4."""
+    import glob
+    insts = []
+    for path in sorted(glob.glob(os.path.join(dump_dir, "*.npz"))):
+        d = np.load(path)
+        cols = [[int(m) for m in row if m >= 0] for row in d["cols"]]
+        sizes = [int(v) for v in d["sizes"]]
+        cost = np.asarray(d["cost"], dtype=np.float64)
+        sel, obj = orc.solve_blp_exact(cols, sizes, cost)
+        insts.append(dict(cols=cols, sizes=sizes, cost=cost, sel=sel, obj=obj))
+    gen_g4(insts, name="g10_ilp_small_hard")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "g10":      # python oracle/gen_golden.py g10 gpurun_out/ilp   (no reference import needed)
+        gen_g10(sys.argv[2])
+    else:
+        main()

@@ -158,9 +158,13 @@ struct GStore {      // HBM: column = global child index, row = global measureme
         }
     }
 };
+struct EnumEnt;
 struct LStore {      // LDS: column = dense local index, row = dense local id
     double* costL; unsigned short* entL; double* uL; int32_t* usageL; int32_t* markL; int32_t* colb; int32_t* gbase;
     double* rcL; unsigned short* membL; unsigned long long* minkey;   // per-column reduced cost / member, per-member minimum key
+    unsigned short* ordL;      // enumerate_small: column of every ranked entry
+    unsigned short* enumL;     // enumerate_small: search state of the wavefronts (ENUM_LDS bytes)
+    EnumEnt* xL;               // enumerate_small: [cap_h] reduced cost + signature of every column
     int nH, nR, PD, K;
     int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
     __device__ __forceinline__ int col_begin(int k) const { return colb[k]; }
@@ -576,6 +580,269 @@ template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, 
     return total;
 }
 
+// ---- exact search for small clusters the coordinate rounds did not certify ---------------------------------------------
+// The clusters that end up here are a handful of near-duplicate tracks (K = 3..9 targets, a few hundred columns each) whose LP
+// relaxation has a duality gap: prices zig-zag, the depth-first branch and bound pays ~10 us per node for re-priced bounds and
+// the subgradient steps ~5 us per iteration -- 80..550 us where the ordinary cluster takes 9.  What conflicts can exist is tiny,
+// though: only rows (measurement nodes) used by columns of >= 2 DIFFERENT members matter, and there are a dozen or two of those.
+//   1. contested rows get dense ids (<= 64 of them, else the routine declines), every column a 64-bit signature;
+//   2. columns are compared by REDUCED cost at the prices the coordinate rounds have reached (u >= 0): for any selection
+//      sum cost = sum rc - sum_{rows used} u >= sum rc - sum_{all rows} u,  so
+//      (rc of the columns chosen so far) + (cheapest rc of every member still open) - sum u  bounds every completion;
+//   3. a greedy dive gives a feasible point; a column whose reduced cost alone lifts the root bound above it cannot be part of
+//      anything better (reduced-cost fixing) and is dropped -- what survives is a few dozen columns per member, ranked by
+//      (reduced cost, index) with one pass over the member's list per survivor;
+//   4. depth-first search over the members (shortest list first) in that order, one search per wavefront: the state is
+//      wave-uniform, the 64 lanes look at 64 consecutive entries of a ranked list at once ("first entry that neither conflicts
+//      nor exceeds the bound" = one 16-byte LDS read per lane and two ballots; near-duplicate tracks conflict in most of their
+//      columns).  The entries of the shortest list are dealt out to the wavefronts; the incumbent is one LDS word.
+// Exact like the branch and bound: nothing is pruned unless its bound is strictly worse than a feasible point (ties survive: among
+// optimal selections the one with the lexicographically lowest column indices in member order wins, whatever the wave timing).
+constexpr int ENUM_MAXK = 10;
+constexpr int ENUM_AFTER = 8;             // coordinate rounds a small cluster gets before the exact search
+constexpr int ENUM_BUDGET = 1 << 13;      // search nodes per thread before the routine gives up (the branch and bound takes over)
+__device__ __forceinline__ unsigned long long enum_key(double v) {      // monotone map double -> u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double enum_val(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ bool enumerate_small(const GStore&, int, Red*, int&, unsigned long long*) { return false; }
+constexpr int ENUM_W = BLP_THREADS / 64;
+constexpr size_t ENUM_LDS = 768;             // search state of the wavefronts + scalars (see the carve in enumerate_small)
+struct alignas(16) EnumEnt { double rc; unsigned long long sig; };      // reduced cost and contested-row signature of a ranked column
+template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r);
+__device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, int& nodes_out, unsigned long long* stamp) {
+    if (K > ENUM_MAXK || K < 2) return false;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nH = s.nH, nR = s.nR;
+    EnumEnt* xL = s.xL;
+    // scratch (ENUM_LDS bytes): incumbent, bounds, member order, per-wavefront best cost / best selection / open positions
+    unsigned long long* s_ub = reinterpret_cast<unsigned long long*>(s.enumL);
+    unsigned long long* s_minrc = s_ub + 1;                             // [ENUM_MAXK] cheapest reduced cost of every member (as keys)
+    double* s_rest = reinterpret_cast<double*>(s_minrc + ENUM_MAXK);    // [ENUM_MAXK + 1] ... summed over the levels still open
+    double* s_bestc = s_rest + ENUM_MAXK + 1;                           // [ENUM_W]
+    int* s_order = reinterpret_cast<int*>(s_bestc + ENUM_W);            // [ENUM_MAXK]
+    int* s_len = s_order + ENUM_MAXK;                                   // [ENUM_MAXK] surviving columns of every member
+    int* s_cnt = s_len + ENUM_MAXK;
+    int* s_abort = s_cnt + 1;
+    int* s_nodes = s_abort + 1;                                         // [ENUM_W]
+    int* s_pos = s_nodes + ENUM_W;                                      // [ENUM_MAXK][ENUM_W] positions of the open levels
+    int* s_best = s_pos + ENUM_MAXK * ENUM_W;                           // [ENUM_MAXK][ENUM_W] best selection of the wavefront
+    static_assert(8 + ENUM_MAXK * 8 + (ENUM_MAXK + 1 + ENUM_W) * 8 + (2 * ENUM_MAXK + 2 + ENUM_W + 2 * ENUM_MAXK * ENUM_W) * 4 <= ENUM_LDS, "enumerate_small scratch");
+    // 0. a feasible point (the dive leaves the marks at zero)
+    const double ub0 = greedy_dive(s, K, s.ch, r);
+    stamp[1] = wall_clock64();
+    // 1. which members use a row (the usage / nomination counters are zero between iterations: borrowed, zeroed again below);
+    //    reduced costs at the current prices (the last sweep's values predate the last price step)
+    if (tid == 0) { *s_cnt = 0; *s_abort = 0; *s_ub = enum_key(ub0); }
+    if (tid < ENUM_W) { s_bestc[tid] = DINF; s_nodes[tid] = 0; }
+    if (tid < ENUM_MAXK) { s_minrc[tid] = enum_key(DINF); s_len[tid] = 0; }
+    __syncthreads();
+    for (int h = tid; h < nH; h += BLP_THREADS) {
+        const Rows8 e = rows_of(s, h);
+        const int k = s.membL[h];
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (e.e[d] != nR) atomicOr(&s.markL[e.e[d]], 1 << k);
+        const double rc = reduced_cost(s, h);
+        s.rcL[h] = rc;
+        atomicMin(&s_minrc[k], enum_key(rc));
+    }
+    double up = 0.0;
+    for (int m = tid; m < nR; m += BLP_THREADS) up += s.uL[m];
+    const double usum = block_sum(up, r);      // (its barriers also publish the row masks and the reduced costs)
+    for (int m = tid; m < nR; m += BLP_THREADS) s.usageL[m] = (__popc(s.markL[m]) >= 2) ? atomicAdd(s_cnt, 1) : -1;
+    __syncthreads();
+    bool ok = *s_cnt <= 64 && ub0 < DINF;
+    stamp[2] = wall_clock64();
+    auto slack = [](double ub) { return ub + 1e-9 * fmax(1.0, fabs(ub)); };
+    if (ok) {
+        // 2. reduced-cost fixing: the survivors of every member, in any order ...
+        double root = -usum;
+        for (int k = 0; k < K; ++k) root += enum_val(s_minrc[k]);
+        const double lim0 = slack(ub0);
+        for (int h = tid; h < nH; h += BLP_THREADS) {
+            const int k = s.membL[h];
+            const double c = s.rcL[h];
+            if (root + (c - enum_val(s_minrc[k])) > lim0) continue;      // cannot be part of anything as good as the dive's selection
+            EnumEnt en; en.rc = c; en.sig = (unsigned long long)h;
+            xL[s.colb[k] + atomicAdd(&s_len[k], 1)] = en;
+        }
+        __syncthreads();
+        // ... ranked by (reduced cost, index): a bitonic network per member, one wavefront each (comparators all ascending, so
+        // the entries beyond the list's end act as +infinity without being there)
+        for (int k = wave; k < K; k += ENUM_W) {
+            const int hb = s.colb[k], n = s_len[k];
+            int N = 1;
+            while (N < n) N <<= 1;
+            for (int size = 2; size <= N; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = lane; t < (N >> 1); t += 64) {
+                        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));      // t-th index with the stride bit clear
+                        const int hi = (stride == (size >> 1)) ? (lo ^ (size - 1)) : (lo | stride);
+                        const int a = lo < hi ? lo : hi, b = lo < hi ? hi : lo;
+                        if (b < n) {
+                            const EnumEnt ea = xL[hb + a], eb = xL[hb + b];
+                            if (eb.rc < ea.rc || (eb.rc == ea.rc && eb.sig < ea.sig)) { xL[hb + a] = eb; xL[hb + b] = ea; }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+        }
+        __syncthreads();
+        // the column of every ranked entry moves to ordL, its place is taken by the column's signature
+        for (int k = 0; k < K; ++k)
+            for (int i2 = s.colb[k] + tid; i2 < s.colb[k] + s_len[k]; i2 += BLP_THREADS) {
+                const int h = (int)xL[i2].sig;
+                const Rows8 e = rows_of(s, h);
+                unsigned long long sg = 0ull;
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (e.e[d] != nR) { const int cc = s.usageL[e.e[d]]; if (cc >= 0) sg |= 1ull << cc; }
+                s.ordL[i2] = (unsigned short)h;
+                xL[i2].sig = sg;
+            }
+        __syncthreads();
+        if (tid == 0) {      // members by surviving columns (fewest first); cheapest reduced costs of the levels still open
+            for (int k = 0; k < K; ++k) s_order[k] = k;
+            for (int i = 1; i < K; ++i) {
+                const int v = s_order[i], nv = s_len[v];
+                int j = i - 1;
+                while (j >= 0 && s_len[s_order[j]] > nv) { s_order[j + 1] = s_order[j]; --j; }
+                s_order[j + 1] = v;
+            }
+            s_rest[K] = 0.0;
+            for (int i = K - 1; i >= 0; --i) s_rest[i] = s_rest[i + 1] + enum_val(s_minrc[s_order[i]]);
+        }
+        __syncthreads();
+    }
+    stamp[3] = wall_clock64();
+    if (ok) {
+        // 3. the search.  A level's state is its position in the member's list; the mask and the sums above it are rebuilt from
+        //    the positions when the search comes back up (same order of additions: the same floating-point sums as on the way down).
+        const int k0 = s_order[0], b0 = s.colb[k0], n0 = s_len[k0];
+        double best = DINF;      // (wave-uniform)
+        int nodes = 0;
+        auto record = [&](double tot, int last_level) {      // a complete selection (positions in s_pos): better than this wavefront's best?
+            bool better = tot < best;
+            if (!better && tot == best) {      // lexicographically lower column indices in member order
+                int d = 0;
+                for (int q = 0; q <= last_level && d == 0; ++q) d = (int)s.ordL[s_pos[q * ENUM_W + wave]] - s_best[q * ENUM_W + wave];
+                better = d < 0;
+            }
+            if (better) {
+                best = tot;
+                if (lane == 0) {
+                    for (int q = 0; q <= last_level; ++q) s_best[q * ENUM_W + wave] = s.ordL[s_pos[q * ENUM_W + wave]];
+                    atomicMin(s_ub, enum_key(tot));
+                }
+            }
+        };
+        // the entries of the shortest list are dealt out to the wavefronts (the cheapest ones first: they carry the large subtrees)
+        for (int i0 = wave; i0 < n0 && !*s_abort; i0 += ENUM_W) {
+            const EnumEnt f0 = xL[b0 + i0];
+            if (f0.rc + s_rest[1] - usum > slack(enum_val(*s_ub))) break;      // ranked: no later entry of this list can do better
+            const double tot0 = s.costL[s.ordL[b0 + i0]];
+            ++nodes;
+            if (lane == 0) s_pos[0 * ENUM_W + wave] = b0 + i0;
+            if (K == 1) { record(tot0, 0); continue; }
+            int L = 1;
+            unsigned long long mask = f0.sig;
+            double acc = tot0, arc = f0.rc;
+            int i = s.colb[s_order[1]];
+            while (true) {
+                const int k = s_order[L], he = s.colb[k] + s_len[k];
+                const double lim = slack(enum_val(*s_ub)), tail = s_rest[L + 1] - usum;
+                // first entry at or after i that neither conflicts nor exceeds the bound; the bound is monotone along the list
+                int found = -1;
+                double frc = 0.0;
+                unsigned long long fsig = 0ull;
+                while (i < he) {
+                    const int idx = i + lane;
+                    const bool valid = idx < he;
+                    const EnumEnt en = xL[valid ? idx : he - 1];
+                    const bool over = !valid || (arc + en.rc + tail > lim);
+                    const bool feas = !over && !(en.sig & mask);
+                    const unsigned long long mo = __ballot(over);
+                    unsigned long long mf = __ballot(feas);
+                    if (mo) mf &= (1ull << (__ffsll((long long)mo) - 1)) - 1ull;
+                    if (mf) {
+                        const int fl = __ffsll((long long)mf) - 1;
+                        found = i + fl;
+                        frc = __shfl(en.rc, fl);
+                        fsig = __shfl(en.sig, fl);
+                        break;
+                    }
+                    if (mo) break;
+                    i += 64;
+                }
+                if (found >= 0) {
+                    if (++nodes > ENUM_BUDGET) { if (lane == 0) *s_abort = 1; break; }
+                    const double tot = acc + s.costL[s.ordL[found]];
+                    if (lane == 0) s_pos[L * ENUM_W + wave] = found;
+                    if (L == K - 1) {
+                        record(tot, L);
+                        i = found + 1;      // (the list is ranked by reduced cost, not by cost: a later entry can still be cheaper)
+                        continue;
+                    }
+                    mask |= fsig;          // one level down
+                    acc = tot;
+                    arc = arc + frc;
+                    ++L;
+                    i = s.colb[s_order[L]];
+                    continue;
+                }
+                // back up one level: its next entry; mask and sums rebuilt from the positions above it
+                --L;
+                if (L < 1) break;
+                i = s_pos[L * ENUM_W + wave] + 1;
+                mask = f0.sig;
+                acc = tot0;
+                arc = f0.rc;
+                for (int q = 1; q < L; ++q) {
+                    const int pq = s_pos[q * ENUM_W + wave];
+                    const EnumEnt en = xL[pq];
+                    mask |= en.sig;
+                    acc = acc + s.costL[s.ordL[pq]];
+                    arc = arc + en.rc;
+                }
+            }
+        }
+        if (lane == 0) { s_bestc[wave] = best; s_nodes[wave] = nodes; }
+    }
+    __syncthreads();
+    ok = ok && !*s_abort;
+    // 4. the winner: lowest cost, then lexicographically lowest columns in member order
+    if (ok) {
+        int w = -1;
+        for (int q = 0; q < ENUM_W; ++q) {
+            if (!(s_bestc[q] < DINF)) continue;
+            bool better = w < 0 || s_bestc[q] < s_bestc[w];
+            if (!better && s_bestc[q] == s_bestc[w]) {
+                int d = 0;
+                for (int l = 0; l < K && d == 0; ++l) d = s_best[l * ENUM_W + q] - s_best[l * ENUM_W + w];
+                better = d < 0;
+            }
+            if (better) w = q;
+        }
+        ok = w >= 0;
+        if (ok) {
+            for (int l = tid; l < K; l += BLP_THREADS) s.ub_sel[s_order[l]] = s_best[l * ENUM_W + w];
+            int tn = 0;
+            for (int q = 0; q < ENUM_W; ++q) tn += s_nodes[q];
+            nodes_out = tn;
+        }
+    }
+    for (int m = tid; m < nR; m += BLP_THREADS) { s.usageL[m] = 0; s.markL[m] = 0; }
+    __threadfence_block();
+    __syncthreads();
+    return ok;
+}
+
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
 template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -590,8 +857,15 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     const int ca_rounds = coordinate_rounds(s, K);
     const int ca_end = a.max_iter < ca_rounds ? a.max_iter : ca_rounds;        // rounds [0, ca_end) are coordinate rounds
     const int it_cap = bb_after_rounds(s, K) ? ca_end : a.max_iter;
+    const int enum_at = (ca_end > 0 && K >= 3 && K <= ENUM_MAXK) ? (ca_end < ENUM_AFTER ? ca_end : ENUM_AFTER) : -1;
     for (int it = 0; it <= it_cap; ++it) {
         iters = it;
+        if (it == enum_at && !a.no_enum) {      // small cluster the first rounds did not certify: exact search
+            const unsigned long long e0 = wall_clock64();
+            const bool solved = enumerate_small(s, K, r, nodes, stamp);
+            stamp[5] = wall_clock64() - e0;
+            if (solved) { status = MHT_BLP_BRANCHED; return; }
+        }
         if (it == ca_end && ca_end > 0 && !bb_after_rounds(s, K)) {
             // a larger cluster that the coordinate rounds did not certify: the subgradient steps start from zero prices, as
             // they always did (from the rounds' prices they converged worse: a 29-target / 18 k-column cluster then ran
@@ -1110,6 +1384,9 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     s.ch = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
     s.lix = reinterpret_cast<int32_t*>(q); q += (size_t)L_KPAD * 4;
     s.membL = reinterpret_cast<unsigned short*>(q); q += (size_t)L_MAXH * 2;
+    s.ordL = reinterpret_cast<unsigned short*>(q); q += (size_t)L_MAXH * 2;
+    s.enumL = reinterpret_cast<unsigned short*>(q); q += ENUM_LDS;
+    s.xL = reinterpret_cast<EnumEnt*>(q); q += (size_t)L_MAXH * 16;
     const bool small_k = K <= L_MAXK;
     for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
     // column ranges of the members: one global round trip, then a wave scan
@@ -1304,6 +1581,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             a.cl_time[8 * c + 1] = (int)(wall_clock64() - t_begin);
             for (int q = 1; q <= 4; ++q) a.cl_time[8 * c + 1 + q] = (int)(stamp[q] - t_begin);
             a.cl_time[8 * c + 6] = (int)(clock64() - c_begin);
+            a.cl_time[8 * c + 7] = (int)stamp[5];      // ticks spent in enumerate_small
         }
     }
     __threadfence_block();
@@ -1315,7 +1593,7 @@ static_assert(sizeof(Red) <= RED_SLOT, "Red must fit its LDS slot");
 static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
     const size_t kpad = (size_t)cap_k + 4;
     return (size_t)cap_uw * 8 + RED_SLOT + (size_t)cap_uw * 4 + 16 + (size_t)cap_h * 16 + (size_t)cap_h * 8 * 2 + (size_t)cap_r * 8 + 7 * kpad * 8 +
-           2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2;
+           2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16;
 }
 
 __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
@@ -1423,6 +1701,11 @@ size_t blp_set_tier(BlpArgs& a, int tier) {
     a.t1_h = 512; a.t1_k = 16;
     if (tier == 1) { a.cap_h = a.t1_h; a.cap_r = 256; a.cap_k = a.t1_k; }
     else { a.cap_h = BIG_MAXH; a.cap_r = BIG_MAXR; a.cap_k = BIG_MAXK; }
+    if (tier == 0) {
+        static int eh = -1, er = 0, ek = 0;
+        if (eh < 0) { const char* e = getenv("MHT_BLP_CAPS"); eh = 0; if (e) sscanf(e, "%d,%d,%d", &eh, &er, &ek); }
+        if (eh > 0) { a.cap_h = eh; a.cap_r = er; a.cap_k = ek; }
+    }
     a.cap_uw = uw;
     return blp_lds_bytes(a.cap_h, a.cap_r, a.cap_k, a.cap_uw);
 }
@@ -1494,6 +1777,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.tchild = group_ptr; a.tcend = group_ptr + 1; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;
+    { const char* e = getenv("MHT_BLP_NO_ENUM"); a.no_enum = (e && e[0] == '1') ? 1 : 0; }
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     // one cluster holding all targets

@@ -282,6 +282,7 @@ struct Forest {
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
+    bool no_enum = false;        // testing: MHT_BLP_NO_ENUM=1 at creation: no exact search for small clusters (branch and bound instead)
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
     // since that scan this bounds the current target count (targets only disappear otherwise)
     unsigned long long* hint_host = nullptr; unsigned long long* hint_dev = nullptr;
@@ -440,6 +441,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
+    { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     f->pds = f->PD <= 8 ? 8 : 16;
 
     f->used_off = sizeof(ReportHeader);
@@ -637,6 +639,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.sel = f->sel; b.cl_status = f->cl_status; b.cl_iters = f->cl_iters; b.cl_nodes = f->cl_nodes; b.cl_time = f->cl_time;
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = f->status2 + (s & 1);
     b.force_hbm = f->force_hbm ? 1 : 0;
+    b.no_enum = f->no_enum ? 1 : 0;
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
     b.apath = f->apath[s & 1]; b.R = f->R; b.kc = s % f->R;
@@ -1243,8 +1246,16 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     MHT_REQUIRE(ctx && ctx->forest && name && host && bytes > 0, "mht_forest_debug_read: bad argument");
     Forest* f = ctx->forest;
     const void* src = nullptr;
-    size_t avail = 0;
+    size_t avail = 0, offset = 0;
     const size_t T = f->Tcap;
+    char nbuf[32];
+    if (const char* at = strchr(name, '@')) {      // "array@byte_offset": a window of a large array
+        const size_t n = (size_t)(at - name) < sizeof(nbuf) - 1 ? (size_t)(at - name) : sizeof(nbuf) - 1;
+        memcpy(nbuf, name, n);
+        nbuf[n] = 0;
+        offset = (size_t)strtoull(at + 1, nullptr, 10);
+        name = nbuf;
+    }
     if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
     else if (!strcmp(name, "cl_iters")) { src = f->cl_iters; avail = T * 4; }
     else if (!strcmp(name, "cl_nodes")) { src = f->cl_nodes; avail = T * 4; }
@@ -1259,8 +1270,11 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "G1")) { src = f->G[1]; avail = (size_t)f->capc * 64; }
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
+    else if (!strcmp(name, "path")) { src = f->path[f->scan & 1]; avail = (size_t)f->pds * f->Ncap * 4; }      // records of the newest layer
+    else if (!strcmp(name, "cost")) { src = f->cost; avail = (size_t)f->Ncap * 8; }
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
-    MHT_REQUIRE((size_t)bytes <= avail, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
+    MHT_REQUIRE(offset <= avail && (size_t)bytes <= avail - offset, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
+    src = static_cast<const char*>(src) + offset;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     MHT_HIP_CHECK(hipMemcpyAsync(host, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -139,6 +139,23 @@ def test_blp_clusters_without_certificate(gpu_ctx, gold_dir):
         assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
 
 
+def test_blp_small_clusters_exact_search(gpu_ctx, gold_dir, monkeypatch):
+    """tests/golden/g10_ilp_small_hard.npz: 3..9 near-duplicate tracks with a duality gap, the slowest ILPs of four headline
+    streams (the coordinate rounds do not certify them).  The exact search over contested-row signatures (enumerate_small) must
+    return the HiGHS optimum (unique in every instance), and so must the branch and bound it replaces (MHT_BLP_NO_ENUM=1)."""
+    insts = load_instances(os.path.join(gold_dir, "g10_ilp_small_hard.npz"))
+    searched = 0
+    for inst in insts:
+        sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst)
+        assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist(), (len(inst["cols"]), st, it, nd)
+        searched += 1 if (st == 2 and it <= 16) else 0
+    assert searched >= len(insts) // 2
+    monkeypatch.setenv("MHT_BLP_NO_ENUM", "1")
+    for inst in insts[::4]:
+        sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst)
+        assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
+
+
 def test_prune_seam_matches_oracle_trees():
     """Seam (iv) mht_prune against the oracle's Node.prune_depth (pyTarget.py:343-356) on random trees: new roots and the exact
     set of surviving nodes, for windows shorter, equal to and longer than the tree."""

@@ -7,8 +7,11 @@ from pymht_amd import _lib
 from pymht_amd.utils.scenario import make_config
 from pymht_amd.utils.classDefinitions import MeasurementList
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-sc = make_config('cfg3', seed=5446, n_scans=n, confine=True)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5446
+sc = make_config('cfg3', seed=seed, n_scans=n, confine=True)
 trk = bench.make_tracker(sc, 0, deviceTiming=True)
+dump_dir = sys.argv[3] if len(sys.argv) > 3 else None
+if dump_dir: os.makedirs(dump_dir, exist_ok=True)
 def rd(name, k, dt=np.int32):
     a = np.zeros(k, dtype=dt)
     _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
@@ -25,13 +28,22 @@ for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     for c in ml:
         K = ptr[c + 1] - ptr[c]
         nH = int(sum(tce[m] - tch[m] for m in mem[ptr[c]:ptr[c + 1]]))
-        rows.append((tm[c, 1] / 100.0, k, int(K), nH, int(it[c]), int(st[c]), int(nd[c]), tm[c, 0] / 100.0))
+        rows.append((tm[c, 1] / 100.0, k, int(K), nH, int(it[c]), int(st[c]), int(nd[c]), tm[c, 0] / 100.0, tm[c, 7] / 100.0, tuple(int(v) // 100 for v in tm[c, 2:5])))
+        if dump_dir and tm[c, 1] / 100.0 > 60.0:      # the instance itself, for offline experiments (tools/blp_small.py)
+            sizes, costs, cols = [], [], []
+            for m in mem[ptr[c]:ptr[c + 1]]:
+                b, e = int(tch[m]), int(tce[m])
+                sizes.append(e - b)
+                costs.append(rd('cost@%d' % (8 * b), e - b, np.float64))
+                cols.append(rd('path@%d' % (32 * b), 8 * (e - b)).reshape(-1, 8))
+            np.savez(os.path.join(dump_dir, 'ilp_s%d_k%d_c%d.npz' % (seed, k, c)), sizes=np.array(sizes), cost=np.concatenate(costs), cols=np.concatenate(cols),
+                     us=tm[c, 1] / 100.0, iters=int(it[c]), status=int(st[c]), nodes=int(nd[c]))
 rows.sort(reverse=True)
 t = np.array([r[0] for r in rows])
 print('%d ILPs over %d scans: mean %.1f us, p50 %.1f, p90 %.1f, p99 %.1f, max %.1f; Optim stage mean %.1f p90 %.1f max %.1f' % (
     len(rows), n - 20, t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max(), np.mean(stage), np.percentile(stage, 90), np.max(stage)))
-print('slowest: (us, scan, K, nH, iters, status[1 cert 2 bb 3 limit], nodes, setup us)')
-for r in rows[:25]: print('  ', tuple(round(x, 1) if isinstance(x, float) else x for x in r))
+print('slowest: (us, scan, K, nH, iters, status[1 cert 2 bb 3 limit], nodes, setup us, search us)')
+for r in rows[:12]: print('  ', tuple(round(float(x), 1) if isinstance(x, (float, np.floating)) else x for x in r))
 per_scan = {}
 for r in rows: per_scan[r[1]] = max(per_scan.get(r[1], 0), r[0])
 m = np.array(list(per_scan.values()))

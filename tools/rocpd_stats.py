@@ -22,9 +22,10 @@ def main():
         agg[names[kid]].append((e - s) / 1e3)
         meta[names[kid]] = (g, w, lds) + regs[kid]
     tot = sum(sum(v) for v in agg.values())
-    print("%-58s %6s %11s %9s %9s %9s %6s  %s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%", "grid/wg/lds/vgpr/sgpr (last)"))
+    print("%-58s %6s %11s %9s %9s %9s %9s %9s %6s  %s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "p50_us", "p95_us", "max_us", "%", "grid/wg/lds/vgpr/sgpr (last)"))
+    pct = lambda v, q: sorted(v)[min(len(v) - 1, int(q * len(v)))]
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        print("%-58s %6d %11.1f %9.2f %9.2f %9.2f %6.1f  %s" % (k[:58], len(v), sum(v), sum(v) / len(v), min(v), max(v),
+        print("%-58s %6d %11.1f %9.2f %9.2f %9.2f %9.2f %9.2f %6.1f  %s" % (k[:58], len(v), sum(v), sum(v) / len(v), min(v), pct(v, 0.5), pct(v, 0.95), max(v),
                                                                  100 * sum(v) / tot, "/".join(str(x) for x in meta[k])))
 
 
