@@ -35,6 +35,38 @@ constexpr int BIRTH_CAP = 256;      // candidates of the device initiator per sc
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
 
+// The scan report goes to the host from inside the kernel that completes it: the workgroup copies header, used-measurement
+// mask, birth records and the target rows from the device block into pinned, device-mapped host memory with 16-byte stores
+// (posted PCIe writes: ~70 KB at the headline size).  A copy engine / blit kernel on the stream costs more than the copy: the
+// host issues two more calls per scan and the stream idles ~10 us in front of every engine switch.
+struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; };      // dst = null: no host block (report fetched by memcpy)
+template <int NT> __device__ __forceinline__ void publish_report(const PublishArgs& p) {
+    if (!p.dst) return;
+    __threadfence();
+    __syncthreads();
+    const ReportHeader* h = reinterpret_cast<const ReportHeader*>(p.src);
+    const int n_births = h->n_births, nT = h->n_targets;
+    const uint4* s4 = reinterpret_cast<const uint4*>(p.src);
+    uint4* d4 = reinterpret_cast<uint4*>(p.dst);
+    const int head = (p.birth_off + n_births * (int)sizeof(mht_birth_report) + 15) / 16;      // header + mask + births present
+    for (int i = threadIdx.x; i < head; i += NT) d4[i] = s4[i];
+    const int r0 = p.rec_off / 16, rn = (nT * (int)sizeof(mht_target_report) + 15) / 16;
+    for (int i = threadIdx.x; i < rn; i += NT) d4[r0 + i] = s4[r0 + i];
+    __threadfence_system();
+}
+static_assert(sizeof(mht_target_report) % 16 == 0 && sizeof(mht_birth_report) % 8 == 0, "report blocks are copied in 16-byte pieces");
+
+// the scan from the pinned staging ring (device-mapped) to its device buffer: one small workgroup on the stream, no copy engine
+__global__ void stage_scan_kernel(const float4* src, float4* dst, int n16) {
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(COMMIT_THREADS) void commit_publish_kernel(const CommitArgs a, const CommitDyn dyn, const PublishArgs pub) {
+    __shared__ int s_commit[2 * (COMMIT_THREADS / 64) + 8];
+    commit_body<COMMIT_THREADS>(a, dyn, s_commit);
+    publish_report<COMMIT_THREADS>(pub);
+}
+
 __global__ __launch_bounds__(COMMIT_THREADS) void commit_kernel(const CommitArgs a, const CommitDyn dyn) {
     __shared__ int s_commit[2 * (COMMIT_THREADS / 64) + 8];
     commit_body<COMMIT_THREADS>(a, dyn, s_commit);
@@ -179,18 +211,21 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { ad
 // The end of a scan in the drop-in API path, ONE launch of one workgroup instead of three: the scan's commit (target table, report),
 // step 7 on the measurements the commit found unused (initiator_body), Tracker.initiateTarget for what it confirmed.
 static_assert(INIT_THREADS == 1024, "post_scan_kernel runs commit, initiator and admission with one block size");
-__global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit) {
+__global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit,
+                                                         const PublishArgs pub) {
     __shared__ int s_commit[2 * (1024 / 64) + 8];
     if (do_commit) {
         commit_body<1024>(cm, dyn, s_commit);
         __threadfence_block();
         __syncthreads();
-        if (cm.hdr->error) return;      // void scan: nothing to initiate
     }
-    initiator_body(in);
-    __threadfence_block();
-    __syncthreads();
-    add_targets_body(ad);
+    if (!cm.hdr->error) {      // (void scan: nothing to initiate)
+        initiator_body(in);
+        __threadfence_block();
+        __syncthreads();
+        add_targets_body(ad);
+    }
+    publish_report<1024>(pub);
 }
 
 struct LeavesArgs {
@@ -267,7 +302,12 @@ struct Forest {
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
-    char* report_dev; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;
+    char* report_dev2[2]; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;      // device report blocks by scan parity
+    // no copy engine on the scan's path: a small kernel pulls the scan out of the pinned ring, the kernel that completes the report
+    // pushes it into pinned host memory (publish_report)
+    char* report_host_dev[2] = {nullptr, nullptr}; float* z_host_dev = nullptr;      // device addresses of the pinned host blocks
+    int published_scan = 0;      // scan whose report the device has been told to write into report_host2[scan & 1]
+    const float* z_cur = nullptr;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
     // small staging for add_targets / leaves / chain
@@ -350,8 +390,8 @@ struct Forest {
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         w_root_scan = ar.take<int32_t>(Tcap); w_root_node = ar.take<int32_t>(Tcap); w_root_cnllr = ar.take<double>(Tcap); w_root_f32 = ar.take<uint8_t>(Tcap);
         cnt = ar.take<FCounts>(1);
-        report_dev = ar.take<char>(report_bytes);
-        z_dev = ar.take<float>((size_t)2 * Mpad);
+        report_dev2[0] = ar.take<char>(report_bytes); report_dev2[1] = ar.take<char>(report_bytes);
+        z_dev = ar.take<float>((size_t)Z_RING * 2 * Mpad);
     }
 };
 
@@ -387,8 +427,17 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
 }
 
 // runs the pending commit now (see Forest::commit_pending)
-static int flush_commit(mht_ctx* ctx, Forest* f) {
+static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan goes to the pinned block of its parity
+    PublishArgs p;
+    p.src = f->report_dev2[f->scan & 1]; p.dst = f->report_host_dev[f->scan & 1]; p.rec_off = (int)f->rec_off; p.birth_off = (int)f->birth_off;
+    return p;
+}
+static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
     if (!f->commit_pending) return MHT_OK;
+    if (publish) {      // (the host block of this parity may still be in the host's hands: two scans ago)
+        hipLaunchKernelGGL(commit_publish_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending, f->pending_dyn, publish_args(f));
+        f->published_scan = f->scan;
+    } else
     hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending, f->pending_dyn);
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
@@ -487,6 +536,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->report_host = f->report_host2[0];
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->z_host), (size_t)Z_RING * 2 * f->Mpad * sizeof(float), hipHostMallocDefault));
     for (int b = 0; b < Z_RING; ++b) MHT_HIP_CHECK(hipEventCreateWithFlags(&f->z_ev[b], hipEventDisableTiming));
+    MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->z_host_dev), f->z_host, 0));
+    for (int b = 0; b < 2; ++b) MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->report_host_dev[b]), f->report_host2[b], 0));
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
@@ -646,7 +697,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.ring0 = RingLayer{f->layer[0].x, f->layer[0].cnllr, f->layer[0].meas, f->layer[0].flags};
     b.ring_stride = (size_t)(reinterpret_cast<const char*>(f->layer[1].x) - reinterpret_cast<const char*>(f->layer[0].x));   // layers are laid out identically, back to back
     b.t_id = f->tab[cb].id; b.t_root_scan = f->tab[cb].root_scan; b.t_root_node = f->tab[cb].root_node; b.t_label = f->t_label;
-    b.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
+    b.rec = reinterpret_cast<mht_target_report*>(f->report_dev2[s & 1] + f->rec_off);
     b.w_root_scan = f->w_root_scan; b.w_root_node = f->w_root_node; b.w_root_cnllr = f->w_root_cnllr; b.w_root_f32 = f->w_root_f32;
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
@@ -664,9 +715,9 @@ static void fill_commit(const Forest* f, int s, CommitArgs& p) {
     p.new_index = f->new_index;
     p.cnt = f->cnt; p.status = f->status2 + (s & 1);
     p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
-    p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev + f->used_off);
-    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev); p.hint = f->hint_dev;
-    p.rec = reinterpret_cast<mht_target_report*>(f->report_dev + f->rec_off);
+    p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev2[s & 1] + f->used_off);
+    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev2[s & 1]); p.hint = f->hint_dev;
+    p.rec = reinterpret_cast<mht_target_report*>(f->report_dev2[s & 1] + f->rec_off);
 }
 
 // Host-side bookkeeping of a step.  begin: every check that can fail comes BEFORE the scan counter moves (a refused step must not
@@ -986,14 +1037,15 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     Forest* f = ctx->forest;
     MHT_REQUIRE(f->scan > 0, "mht_forest_initiate: no scan processed yet");
     MHT_REQUIRE(M == f->last_M, "mht_forest_initiate: M=%d is not the scan just stepped (M=%d)", M, f->last_M);
-    if (!z) z = f->z_dev;      // (the scan mht_forest_step_host staged)
+    if (!z) z = f->z_cur;      // (the scan mht_forest_step_host staged)
     const double* bx; const float* bP; const uint8_t* bfl; const double* bpd; const int32_t* bme; const int32_t* bn; int cap; mht_ctx* ictx;
     initiator_born_ptrs(in, &bx, &bP, &bfl, &bpd, &bme, &bn, &cap, &ictx);
     MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
     MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     InitArgs ia;
-    initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(f->report_dev + f->used_off), now, ia);
+    char* report_dev = f->report_dev2[f->scan & 1];
+    initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia);
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
     a.check = 1; a.thr = f->cfg.merge_threshold;
@@ -1004,10 +1056,11 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.ps_log2 = f->ps_log2;
     a.near = f->near;
     fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
-    a.hdr = reinterpret_cast<ReportHeader*>(f->report_dev);
-    a.births = reinterpret_cast<mht_birth_report*>(f->report_dev + f->birth_off);
+    a.hdr = reinterpret_cast<ReportHeader*>(report_dev);
+    a.births = reinterpret_cast<mht_birth_report*>(report_dev + f->birth_off);
     // commit (if it is still pending: the used-measurement mask of the scan is part of it) + initiator + admission: one launch
-    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0);
+    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, publish_args(f));
+    f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
     // the host does not know how many of the candidates exist: every bound moves by the most there can be
@@ -1019,7 +1072,7 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     return MHT_OK;
 }
 
-extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) {
+static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mark_done) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step_host: no forest");
     Forest* f = ctx->forest;
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step_host: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
@@ -1031,18 +1084,27 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
         f->z_slot = (slot + 1) % Z_RING;
         if (f->z_used[slot]) MHT_HIP_CHECK(hipEventSynchronize(f->z_ev[slot]));
         float* zh = f->z_host + (size_t)slot * 2 * f->Mpad;
+        float* zd = f->z_dev + (size_t)slot * 2 * f->Mpad;
         memcpy(zh, z_host, (size_t)M * 2 * sizeof(float));
-        MHT_HIP_CHECK(hipMemcpyAsync(f->z_dev, zh, (size_t)M * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], ctx->stream));
+        const int n16 = (M * 2 + 3) / 4;
+        hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
+                           reinterpret_cast<float4*>(zd), n16);
+        MHT_HIP_CHECK(hipGetLastError());
+        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], ctx->stream));      // (the host may refill this slot once the kernel has run)
         f->z_used[slot] = true;
+        f->z_cur = zd;
+        (void)mark_done;
+        return mht_forest_step(ctx, zd, M);
     }
+    f->z_cur = f->z_dev;
     return mht_forest_step(ctx, f->z_dev, M);
 }
+extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) { return step_host_impl(ctx, z_host, M, true); }
 
 // One radar scan of the drop-in API path in one call: steps 1-6 (mht_forest_step_host), step 7 (mht_forest_initiate, if an
 // initiator is given) and the start of the report's way to the host (mht_forest_report_begin).  Nothing here waits for the device.
 extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
-    int rc = mht_forest_step_host(ctx, z_host, M);
+    int rc = step_host_impl(ctx, z_host, M, false);
     if (rc) return rc;
     if (in) { rc = mht_forest_initiate(ctx, in, nullptr, M, now); if (rc) return rc; }
     return mht_forest_report_begin(ctx);
@@ -1057,11 +1119,12 @@ extern "C" int mht_forest_report_begin(mht_ctx* ctx) {
     MHT_REQUIRE(f->scan > 0, "mht_forest_report_begin: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     if (!f->report_pending) return MHT_OK;
-    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
-    f->rep_slot ^= 1;
-    if (f->rep_started[f->rep_slot]) MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[f->rep_slot]));      // (the buffer about to be reused)
-    const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
-    MHT_HIP_CHECK(hipMemcpyAsync(f->report_host2[f->rep_slot], f->report_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    { const int rc = flush_commit(ctx, f, true); if (rc) return rc; }
+    f->rep_slot = f->scan & 1;      // host block = device block = scan parity
+    if (f->published_scan != f->scan) {      // the commit ran without a host block (inside a grow launch): fetch the device block
+        const size_t bytes = f->rec_off + (size_t)f->nT_ub_step * sizeof(mht_target_report);
+        MHT_HIP_CHECK(hipMemcpyAsync(f->report_host2[f->rep_slot], f->report_dev2[f->scan & 1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->rep_slot], ctx->stream));
     f->report_pending = false;
     f->rep_inflight = true;

@@ -280,8 +280,9 @@ class Tracker():
         nRadarMeas = z.shape[0]
         assert rep.scan == scanNumber
         nT = rep.n_targets
+        # (copied as bytes, viewed afterwards: NumPy copies a structured array field by field, 12x slower)
         recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * _REPORT_DTYPE.itemsize,)) \
-            .view(_REPORT_DTYPE).copy() if nT else np.zeros(0, dtype=_REPORT_DTYPE)
+            .copy().view(_REPORT_DTYPE) if nT else np.zeros(0, dtype=_REPORT_DTYPE)
         used_words = np.ctypeslib.as_array(C.cast(rep.used, C.POINTER(C.c_uint64)), shape=(max(rep.used_words, 1),)).copy()
         used = np.unpackbits(used_words.view(np.uint8), bitorder="little")[:nRadarMeas].astype(bool)
         unusedRadarMeasurementIndices = ~used
@@ -298,7 +299,7 @@ class Tracker():
         births = None
         if rep.n_births:
             births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * _BIRTH_DTYPE.itemsize,)) \
-                .view(_BIRTH_DTYPE).copy()
+                .copy().view(_BIRTH_DTYPE)
         self._apply_report(recs, scanTime, scanNumber, z)
         if births is not None:
             self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
