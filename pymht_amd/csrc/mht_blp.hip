@@ -1596,27 +1596,27 @@ static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
            2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16;
 }
 
-__device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
+__device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx) {      // workgroup bx of gx
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [cap_uw]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)a.cap_uw * 8);                   // sizeof(Red) padded to RED_SLOT
     if (a.status && a.status->overflow) return;
     const int nMulti = a.counts[1], nSingle = a.counts[2];
     if (a.tier == 2) {            // what tier 1 left (the single-target clusters went with tier 1)
         const int nBig = *a.big_count;
-        for (int i = blockIdx.x; i < nBig; i += gridDim.x) solve_cluster(a, a.big_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
+        for (int i = bx; i < nBig; i += gx) solve_cluster(a, a.big_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
         return;
     }
     // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- cluster c is solved
     // where c % shard_n == shard_i, a single-target cluster where its target index says so; see blp_epilogue_kernel)
-    for (int i = blockIdx.x; i < nMulti; i += gridDim.x) {
+    for (int i = bx; i < nMulti; i += gx) {
         const int c = a.multi_list[i];
         if (a.shard_n > 1 && c % a.shard_n != a.shard_i) continue;
         solve_cluster(a, c, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
     }
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
-    const int gw = (gridDim.x - 1 - blockIdx.x) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
-    for (int i = gw; i < nSingle; i += gridDim.x * (BLP_THREADS / 64)) {
+    const int gw = (gx - 1 - bx) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
+    for (int i = gw; i < nSingle; i += gx * (BLP_THREADS / 64)) {
         const int t = a.single_list[i];
         if (a.shard_n > 1 && t % a.shard_n != a.shard_i) continue;
         TgtPre pre = {};
@@ -1646,14 +1646,19 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds) {
 
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    blp_body(a, lds);
+    blp_body(a, lds, blockIdx.x, gridDim.x);
 }
-// a group of sectors per launch: blockIdx.y = sector, its argument block is read from HBM (written once, at group creation)
+// a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out
+// sector-interleaved in dispatch order (blockIdx.x fastest): the first n * nMulti workgroups to reach the machine are the ones that
+// carry ILPs, of ALL sectors -- with sector = blockIdx.y the last sector's ILPs queued behind every other sector's idle workgroups
+// (one workgroup per CU at this LDS footprint).
 __global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     BlpArgs a;
-    load_args(a, static_cast<const BlpArgs*>(av.p[blockIdx.y]));
-    blp_body(a, lds);
+    const int n = gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int sector = lin % n, bx = lin / n;
+    load_args(a, static_cast<const BlpArgs*>(av.p[sector]));
+    blp_body(a, lds, bx, gridDim.x);
 }
 
 // Cluster-sharded trackers (several devices hold identical forests and solve disjoint sets of clusters): after the selections have
