@@ -36,9 +36,10 @@ import torch  # noqa: E402
 
 LAMBDA_NU = 1e-4
 ETA2 = 5.99
-# HBM bytes per grow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
-# workload, steady-state scans): profiles/r01s_pmc_hbm_traffic.txt.  Keyed by config name; None = not profiled.
-PMC_TRAFFIC_BYTES = {"cfg3": (3331 + 6205) * 1024}
+# HBM bytes per fgrow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
+# workload, full-size scans): profiles/r02_pmc_hbm_traffic.txt.  NOT measured by this run (the counters need the profiler): the
+# bench line says so.  Keyed by config name; None = not profiled.
+PMC_TRAFFIC_BYTES = {"cfg3": (2359 + 6979) * 1024}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
 
 
@@ -390,8 +391,8 @@ def main():
                     "report D2H + host mirror per scan; same scans as `value` (pre-roll and warm-up untimed)",
         "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gate_gbs / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(args.config),
-                     "traffic_source": "profiles/r01s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
-                     "kernel": "grow_kernel (gate + update + score + child creation, 1 launch), HIP events on the ctx stream",
+                     "traffic_source": "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)",
+                     "kernel": "fgrow_kernel (gate + update + score + child creation + next scan's gains, 1 launch), HIP events on the ctx stream",
                      "algorithmic_bytes": b_gate},
     }
     if rank == 0 and world == 1 and args.cpu_scans > 0:
