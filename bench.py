@@ -52,7 +52,8 @@ def make_tracker(sc, device, **kw):
     from pymht_amd.pyTarget import Target
     from pymht_amd.models import pv
     trk = Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, device=device,
-                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2048"))), maxNodes=kw.pop("maxNodes", int(os.environ.get("MHT_BENCH_MAXN", str(1 << 19)))), maxMeasurements=1024, **kw)
+                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2048"))), maxNodes=kw.pop("maxNodes", int(os.environ.get("MHT_BENCH_MAXN", str(1 << 19)))),
+                  maxMeasurements=int(os.environ.get("MHT_BENCH_MAXM", "1024")), **kw)
     trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
     return trk
 
@@ -376,7 +377,8 @@ def main():
         "value": (1 if strong else world) * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64 state / f32 covariance (the reference's own mix)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: 500 targets, ~500 meas/scan, N-scan=5, P_d=0.9, eta2=5.99; "
+        "config": {"workload": ("BASELINE configs[2]: 500 targets, ~500 meas/scan, N-scan=5, P_d=0.9, eta2=5.99; " if args.config == "cfg3" else
+                                "config %s of pymht_amd/utils/scenario.py (NOT the headline workload): %d targets, N-scan=%d; " % (args.config, len(sc["x0"]), sc["N"])) +
                                "one independent sector per GPU" + (" -- STRONG: the same sector on every GPU, ILPs spread by cluster" if strong else ""), "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
                    "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),

@@ -20,6 +20,9 @@ CONFIGS = {
     "cfg2": dict(T=50, radius=700.0, lambda_phi=1e-4, N=3, n_scans=30, P_d=0.9),
     "cfg3": dict(T=500, radius=5000.0, lambda_phi=6.4e-7, N=5, n_scans=30, P_d=0.9),
     "dense": dict(T=20, radius=400.0, lambda_phi=2e-5, N=3, n_scans=12, P_d=0.9),
+    # BASELINE.json config 5 by SIZE (2 k targets, ~2 k measurements per scan, N-scan 6) with the reference's own 4-state CV model:
+    # the 6-state CT model it names does not exist in the reference.  Same target density as cfg3.
+    "cfg5": dict(T=2000, radius=10000.0, lambda_phi=4.8e-7, N=6, n_scans=12, P_d=0.9),
 }
 
 
