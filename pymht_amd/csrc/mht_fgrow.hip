@@ -14,9 +14,10 @@
 //     index space -- eight regions, neighbours in memory were written through the same L2.  tchild[t] / tcend[t] give the
 //     block; nothing downstream needs a dense numbering.
 //   * the measurement-independent covariance chain P -> P_bar, S, S^-1, K, P_hat (kalman.py:62, :90-93; ~700 dependent VALU
-//     operations per leaf) is off the critical path: "chain" workgroups of the same launch compute, per leaf and per
-//     hit/miss, the child's covariance and ITS gains (S^-1, K, score constant, gate half-axes) one scan ahead into the gain
-//     table G of the new layer, so a target workgroup only forms x_bar = A x, z_hat = C x_bar and looks its gains up.
+//     operations per leaf) is off the critical path AND shared: covariances live in a value table of the forest (mht_vtab.h),
+//     "chain" workgroups of the same launch resolve, per leaf and per hit/miss, the child's covariance and ITS gains (S^-1, K,
+//     score constant, gate half-axes) one scan ahead -- a look-up unless the transition is new -- so a target workgroup only
+//     forms x_bar = A x, z_hat = C x_bar and looks its gains up.
 //   * launch = [commit of the previous scan (deferred, workgroup 0)] + one workgroup per target slot + chain workgroups.
 // Algorithmic bytes of the stage: 280 B per leaf + 48 B per gated pair + 8 B per measurement.
 #include "mht_kernels.h"
@@ -31,7 +32,7 @@ struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in L
     float K[8];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
-    int src, pidn;                    // pidn: hit/miss pattern of the leaf relative to the target's current root
+    int src, cid;                     // cid: value id of the leaf's covariance (its children's keys are 2 * cid + hit/miss)
     unsigned char flags, f32state, valid, pad;
 };
 static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesses");
@@ -74,26 +75,15 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
 #define FG_STAMPX(k)
 #endif
 
-// ---- chain workgroups: the covariance chain one scan ahead ---------------------------------------------------------------
-// The covariance of a hypothesis does not depend on WHICH measurements it was updated with, only on whether there was one:
-// P -> P_bar -> S, K -> P_hat never sees z (kalman.py:62, :90-93), and the reference itself shares one P_hat among all hit
-// children of a node (pyTarget.py:246).  So the covariances below a root are keyed by the hit/miss PATTERN since that root:
-// pattern id 1 = the root, child pattern = 2 * pattern + hit; a target has <= 2^depth of them whatever its number of leaves
-// (~3.5 distinct ones per target on the headline stream, 32 leaves).  Column of a node's covariance in its layer's pool =
-// slot * PS + pattern, PS = 2^(N+2), slot = the target's slot in the table the grow launch that made the node ran on.
-// Wavefront = (target, hit/miss); the lanes first agree on the distinct columns among the target's leaves (ballots), then lane k
-// runs, for the k-th distinct column: the full chain from P -> P_bar, P_hat; the child's covariance Pc = hit ? P_hat : P_bar goes
-// to the child pattern's column of the new layer's pool, and the gains the child will need when IT is a leaf next scan --
-// S^-1, K, ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from predict(Pc) -- to the same row of the gain table.
-__device__ __forceinline__ void gains_record(const Model& m, const CovChain& c, double pd, float4* g) {
-    const float lnc = nllr_const(c.S, m.lambda_ex, pd);
-    const float rx = sqrtf((float)m.eta2 * fabsf(c.S[0])), ry = sqrtf((float)m.eta2 * fabsf(c.S[3]));
-    g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
-    g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
-    g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
-    g[3] = make_float4(lnc, rx, ry, 0.f);
-}
-
+// ---- chain workgroups: the gains one scan ahead --------------------------------------------------------------------------
+// A node names its covariance by a KEY into the forest's value table (mht_vtab.h): key = 2 * (value id of the parent) + hit/miss,
+// child[key] = the node's own value id, Gk[key] = the gains a leaf with that covariance needs.  For every leaf of the previous
+// layer and both hit/miss, the children's key 2 * child[leaf key] + h must be resolved before THEY are leaves (next scan):
+// wavefront = (target, hit/miss); the lanes first agree on the distinct keys among the target's leaves (ballots), then lane j
+// looks the j-th one's transition up.  Nearly always it is known (a 4-byte look-up: ~1 750 distinct covariances serve 13 k
+// leaves, and what the recursion has reached once it reaches again); otherwise the lane runs the chain P -> P_bar, S, K, P_hat
+// (kalman.py:62, :90-93), finds or inserts the child's covariance by value and writes its gains -- S^-1, K,
+// ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from predict(child covariance).
 template <typename ARGS>
 __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,29 +94,26 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
     const TInfo ti = target_info(a, d, t, nT);
     if (po || so) return;
     FG_STAMP(0);
-    const int PS = 1 << a.ps_log2;
     for (int l0 = 0; l0 < ti.cnt; l0 += 64) {
         const bool v = l0 + lane < ti.cnt;
         const int src = ti.first + (v ? l0 + lane : 0);
         const int covc = a.cov[src];
-        // distinct columns among these leaves: lane k takes the k-th (another chunk of the same target may repeat one: it is then
-        // computed twice, with identical results)
+        // distinct keys among these leaves: lane j takes the j-th (another chunk of the same target may repeat one: it is then
+        // resolved twice, with identical results)
         unsigned long long rem = __ballot(v);
-        int mycol = -1, mysrc = 0;
-        for (int k = 0; rem; ++k) {
+        int mykey = -1, mysrc = 0;
+        for (int j = 0; rem; ++j) {
             const int leader = __ffsll((long long)rem) - 1;
             const int cv = __shfl(covc, leader), sv = __shfl(src, leader);
             rem &= ~__ballot(covc == cv);
-            if (lane == k) { mycol = cv; mysrc = sv; }
+            if (lane == j) { mykey = cv; mysrc = sv; }
         }
-        if (mycol < 0) continue;
-        const double pd = a.pd[mysrc];
+        if (mykey < 0) continue;
+        const int id = a.vt.child[mykey];          // (set when the leaf was made: by this code one scan ago, or at its birth)
+        const int ckey = 2 * id + h;
+        if (a.vt.child[ckey] >= 0) continue;       // the transition is known
         float P[16];
-        {
-            const float4* pp = reinterpret_cast<const float4*>(a.P + (size_t)mycol * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const float4 w = pp[q]; P[q * 4] = w.x; P[q * 4 + 1] = w.y; P[q * 4 + 2] = w.z; P[q * 4 + 3] = w.w; }
-        }
+        vt_load(a.vt, id, P);
         Model mdl;          // (uniform registers)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
@@ -135,25 +122,26 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
         mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
-        CovChain c;
-        cov_chain(mdl, P, c, true);
         float Pc[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Pc[e] = h ? c.P_hat[e] : c.P_bar[e];
-        // the leaf's pattern relative to the (possibly advanced) root, then the child's
-        const int pidn = ((mycol & (PS - 1)) & ((1 << ti.depth) - 1)) | (1 << ti.depth);
-        const int col = (t << a.ps_log2) + 2 * pidn + h;
         {
-            float4* po = reinterpret_cast<float4*>(a.oP + (size_t)col * 16);
+            CovChain c;
+            cov_chain(mdl, P, c, h != 0);      // (the miss child's covariance is P_bar: no S, K, P_hat needed)
+            if (h) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) po[q] = make_float4(Pc[q * 4], Pc[q * 4 + 1], Pc[q * 4 + 2], Pc[q * 4 + 3]);
+                for (int e = 0; e < 16; ++e) Pc[e] = c.P_hat[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Pc[e] = c.P_bar[e];
+            }
         }
-        CovChain g;
-        cov_chain(mdl, Pc, g, false);
-        float4 rec[4];
-        gains_record(mdl, g, pd, rec);
+        const double pd = a.pd[mysrc];
+        {
+            float4 rec[4];
+            vt_gains(mdl, Pc, pd, rec);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a.G_out[(size_t)col * 4 + q] = rec[q];
+            for (int q = 0; q < 4; ++q) a.vt.Gk[(size_t)ckey * 4 + q] = rec[q];
+        }
+        a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
     }
     FG_STAMP(1);
 }
@@ -163,10 +151,10 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 // the work -- role 0: x[0..1], cumulativeNLLR; 1: x[2..3], P_d, parent; 2: measurement number, covariance column, flags, ILP
 // cost, used-measurement byte; 3: path and ancestor records.  (One wavefront doing everything was a ~1500-instruction serial
 // stream, 2.9 us; what every role needs -- which hit, z_tilde, NIS, the score -- is recomputed by each.)
-template <typename TS, typename ARGS>
+template <typename TS, int PQ, typename ARGS>
 __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
-                                              double rootc, int root_f32, int covbase) {
+                                              double rootc, int root_f32) {
     const size_t cap = a.cap;
     const uint8_t fl = g.flags;
     int meas = 0, hit = 0, j = -1;
@@ -187,13 +175,13 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     FG_STAMPX(2);
     if (role == 3 || role < 0) {
         // path / ancestor records of the child: the parent's entries from the new root on (d + shift), its own at level `depth`
-        const int* pl = s_pp + l * a.pds;
-        const int* al = s_ap + l * a.pds;
-        int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * a.pds);
-        int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * a.pds);
+        const int* pl = s_pp + l * (PQ * 4);
+        const int* al = s_ap + l * (PQ * 4);
+        int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * (PQ * 4));
+        int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * (PQ * 4));
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q * 4 < a.pds) {
+            if (q < PQ) {
                 int pe[4], ae[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -258,7 +246,7 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     }
     FG_STAMPX(5);
     a.omeas[c] = meas;
-    a.ocov[c] = covbase + 2 * g.pidn + hit;
+    a.ocov[c] = 2 * g.cid + hit;
     a.oflags[c] = cfl;
     if (k > 0) a.used_bytes[j] = 1;
     // getScore()/N (pyTarget.py:124, tracker.py:1127) with NumPy's scalar promotion: float32 - float32 and float32 / int stay
@@ -268,7 +256,12 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     FG_STAMPX(6);
 }
 
+// PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
+// a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
+// edge of its budget (128 for four workgroups per CU in the batched launch).
+template <int PQ>
 __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem) {
+    constexpr int PDS = PQ * 4;
     const auto& a = *ap0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = d.M, W = d.W, Mpad = W * 64, AW = a.AW;
@@ -277,8 +270,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     float* zy = zx + Mpad;
     FLeaf* lg = reinterpret_cast<FLeaf*>(zy + Mpad);                                        // [FG_CAP]
     int* s_pp = reinterpret_cast<int*>(lg + FG_CAP);                                        // [FG_CAP][pds] path records of the leaves
-    int* s_ap = s_pp + a.pds * FG_CAP;                                                      // [FG_CAP][pds] ancestor records
-    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + a.pds * FG_CAP);  // [FG_CAP][W] hit masks
+    int* s_ap = s_pp + PDS * FG_CAP;                                                        // [FG_CAP][pds] ancestor records
+    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + PDS * FG_CAP);    // [FG_CAP][W] hit masks
     unsigned long long* tb = hw + (size_t)FG_CAP * W;                                       // [AW] association bitset of the target
     int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [FG_CAP + 1]
     int* s_misc = s_pref + FG_CAP + 4;                                                      // [32]
@@ -313,10 +306,6 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
         return;
     }
     if (!ti.alive) return;
-    if (ti.depth + 2 > a.ps_log2) {      // (cannot happen: the N-scan window bounds the depth) pattern ids would leave the slot's columns
-        if (tid == 0) a.status->overflow = 1;
-        return;
-    }
     FG_STAMP(1);
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
@@ -359,19 +348,16 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
                 // the leaf's path / ancestor records (pds ints each: 2 or 4 x 16 bytes)
-                const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * a.pds);
-                const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * a.pds);
-                int4 pq[4], aq[4];
+                const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * PDS);
+                const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * PDS);
+                int4 pq[PQ], aq[PQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool on = q * 4 < a.pds;          // uniform
-                    pq[q] = on ? prec[q] : make_int4(-1, -1, -1, -1);
-                    aq[q] = on ? arec[q] : make_int4(-1, -1, -1, -1);
-                }
+                for (int q = 0; q < PQ; ++q) { pq[q] = prec[q]; aq[q] = arec[q]; }
                 // batch B: the gains of the leaf's covariance column
                 float4 gr[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gr[q] = a.G_in[(size_t)covc * 4 + q];
+                for (int q = 0; q < 4; ++q) gr[q] = a.vt.Gk[(size_t)covc * 4 + q];
+                const int cid = a.vt.child[covc];
                 g.valid = valid;
                 g.src = src;
                 g.flags = fl;
@@ -380,11 +366,10 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 g.pd = pd;
                 // records parked raw (the root advance `shift` is applied when they are read back); last real measurement on the path
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q * 4 < a.pds) {
+                for (int q = 0; q < PQ; ++q) {
                         if (keep) {
-                            reinterpret_cast<int4*>(s_pp + tid * a.pds)[q] = pq[q];
-                            reinterpret_cast<int4*>(s_ap + tid * a.pds)[q] = aq[q];
+                            reinterpret_cast<int4*>(s_pp + tid * PDS)[q] = pq[q];
+                            reinterpret_cast<int4*>(s_ap + tid * PDS)[q] = aq[q];
                         }
                         const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
 #pragma unroll
@@ -424,7 +409,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
                 g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by;
                 g.pad = 0;
-                g.pidn = ((covc & ((1 << a.ps_log2) - 1)) & ((1 << depth) - 1)) | (1 << depth);
+                g.cid = cid;
                 if (keep) lg[tid] = g;
                 // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first
                 // cut down to the measurements inside it
@@ -609,8 +594,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (g.f32state) fg_emit_child<float>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, t << a.ps_log2);
-                    else fg_emit_child<double>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, t << a.ps_log2);
+                    if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                 }
                 run += ctot;
             }
@@ -620,7 +605,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     FG_STAMP(7);
 }
 
-template <typename CARGS>
+template <int PQ, typename CARGS>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
@@ -628,24 +613,26 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         bid -= 1;
     }
     if (bid >= d.n_main) { chain_part(*ap, d, bid - d.n_main); return; }
-    target_part(ap, d, bid, smem);
+    target_part<PQ>(ap, d, bid, smem);
 }
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
+template <int PQ>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    fgrow_body((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+    fgrow_body<PQ>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
 // repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
 typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
+template <int PQ>
 __global__ __launch_bounds__(FG_THREADS, 4) void fgrow_batch_kernel(const FBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int y = blockIdx.y;
     const FDyn d = b.d[y];
     if ((int)blockIdx.x >= d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS) return;
-    fgrow_body((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
+    fgrow_body<PQ>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
 }
 
 size_t fgrow_lds_bytes(int W, int pds, int AW) {
@@ -662,8 +649,10 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
     }
     size_t& attr_bytes = ctx->lds_attr_fgrow;
     if (lds > 48 * 1024 && lds > attr_bytes) {
-        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
     return MHT_OK;
@@ -683,14 +672,16 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
     fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
     const size_t lds = fgrow_lds_bytes(d.W, a.pds, a.AW);
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(fgrow_kernel, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
+    if (a.pds == 8) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
+    else hipLaunchKernelGGL(fgrow_kernel<4>, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
 
-int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds) {
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds) {
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(fgrow_batch_kernel, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    if (pds == 8) hipLaunchKernelGGL(fgrow_batch_kernel<2>, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    else hipLaunchKernelGGL(fgrow_batch_kernel<4>, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

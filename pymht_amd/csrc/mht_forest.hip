@@ -78,10 +78,10 @@ struct AddArgs {
     int check; double thr;
     mht_nodes layer;     // newest layer
     TTable tab; int32_t* path; int32_t* apath; int PD;
-    FCounts* cnt; int scan; int Nwin; int Tcap; int ps_log2;
+    FCounts* cnt; int scan; int Nwin; int Tcap;
     int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
-    Model model; float4* G; int root_base;
+    Model model; VTab vt; int root_base;
     const int32_t* n_dev;      // number of candidates in device memory (or null: n)
     ReportHeader* hdr; mht_birth_report* births;      // report block of the device initiator's candidates (or null)   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
 };
@@ -91,7 +91,7 @@ struct AddArgs {
 // then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
 static __device__ void add_targets_body(const AddArgs& a) {
     const int tid = threadIdx.x;
-    const int nT0 = a.cnt->nT, L0 = a.cnt->L;
+    const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
     int an = a.n;
     if (a.n_dev) { const int nd = *a.n_dev; an = nd < an ? nd : an; }
     if (an <= 0) {          // nothing to admit (the usual case behind the device initiator)
@@ -151,10 +151,8 @@ static __device__ void add_targets_body(const AddArgs& a) {
                 a.layer.pd[idx] = a.pd[q];
                 a.layer.parent[idx] = -1;
                 a.layer.meas[idx] = a.meas[q];
-                const int col = (t << a.ps_log2) + 1;      // pattern 1 = the root (mht_fgrow.hip, chain workgroups)
-                a.layer.cov[idx] = col;
+                a.layer.cov[idx] = -1;                     // (its key is made below, once the admissions are known)
                 a.layer.flags[idx] = a.flags[q];
-                for (int e = 0; e < 16; ++e) a.layer.P[(size_t)col * 16 + e] = a.P0[q * 16 + e];
                 for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
                 a.tab.id[t] = a.cnt->id_counter;
                 a.tab.window[t] = a.Nwin;
@@ -190,20 +188,21 @@ static __device__ void add_targets_body(const AddArgs& a) {
         __syncthreads();
     }
     if (a.hdr && tid == 0) a.hdr->n_births = an;
-    // gains of the admitted roots (what fgrow_kernel's chain workgroups compute for every other node one scan ahead)
+    // covariance and gains of the admitted roots (what fgrow_kernel's chain workgroups resolve for every other node one scan
+    // ahead): the root's covariance by value, and a key of its own -- a pseudo parent id whose miss child is that value
     for (int k = tid; k < s_nadm; k += 1024) {
         const int q = s_adm[k & 2047];
         float P[16];
         for (int e = 0; e < 16; ++e) P[e] = a.P0[q * 16 + e];
-        CovChain c;
-        cov_chain(a.model, P, c, false);
-        const float lnc = nllr_const(c.S, a.model.lambda_ex, a.pd[q]);
-        const float rx = sqrtf((float)a.model.eta2 * fabsf(c.S[0])), ry = sqrtf((float)a.model.eta2 * fabsf(c.S[3]));
-        float4* g = a.G + ((size_t)((nT0 + k) << a.ps_log2) + 1) * 4;      // (admissions are sequential: the k-th took slot nT0 + k)
-        g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
-        g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
-        g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
-        g[3] = make_float4(lnc, rx, ry, 0.f);
+        const int id0 = vt_find_or_insert(a.vt, P, a.pd[q]);
+        const unsigned pid = atomicAdd(a.vt.count, 1u);
+        if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; continue; }
+        const int key = 2 * (int)pid;
+        float4 rec[4];
+        vt_gains(a.model, P, a.pd[q], rec);
+        for (int e = 0; e < 4; ++e) a.vt.Gk[(size_t)key * 4 + e] = rec[e];
+        a.vt.child[key] = id0;
+        a.layer.cov[a.root_base + r0 + k] = key;      // (admissions are sequential: the k-th took root r0 + k)
     }
 }
 __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { add_targets_body(a); }
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
 }
 
 struct LeavesArgs {
-    mht_nodes layer; TTable tab; const FCounts* cnt;
+    mht_nodes layer; TTable tab; const FCounts* cnt; VTab vt;
     int capacity; double* x; float* P; double* cnllr; int32_t* meas; int32_t* target; int32_t* id; int32_t* node; uint8_t* flags;
 };
 __global__ void leaves_kernel(const LeavesArgs a) {
@@ -240,8 +239,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
         const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
         for (int k = 0; k < 4; ++k) a.x[i * 4 + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
-        const int c = a.layer.cov[nd];
-        for (int e = 0; e < 16; ++e) a.P[i * 16 + e] = a.layer.P[(size_t)c * 16 + e];
+        vt_load(a.vt, a.vt.child[a.layer.cov[nd]], a.P + (size_t)i * 16);
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
@@ -251,7 +249,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
     }
 }
 
-struct ChainArgs { mht_nodes layers[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
+struct ChainArgs { mht_nodes layers[MAXR]; VTab vt; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
 __global__ void chain_kernel(const ChainArgs a) {
     if (threadIdx.x || blockIdx.x) return;
     int nd = a.node, sc = a.scan, n = 0;
@@ -261,8 +259,7 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.meas[n] = l.meas[nd];
         a.cnllr[n] = l.cnllr[nd];
         for (int k = 0; k < 4; ++k) a.x[n * 4 + k] = l.x[(size_t)k * l.cap + nd];
-        const int c = l.cov[nd];
-        for (int e = 0; e < 16; ++e) a.P[n * 16 + e] = l.P[(size_t)c * 16 + e];
+        vt_load(a.vt, a.vt.child[l.cov[nd]], a.P + (size_t)n * 16);
         ++n;
         nd = l.parent[nd];
         --sc;
@@ -284,12 +281,12 @@ struct Arena {
 struct Forest {
     mht_forest_config cfg;
     mht_model model;
-    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, capc, ps_log2, Ecap, SegCap;
+    int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, Ecap, SegCap;
+    VTab vt = {};                     // covariances by value, shared by all targets and scans (mht_vtab.h)
     Arena arena;
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
     int pds = 8;                      // ints per path / ancestor record (8 or 16)
-    float4* G[2];                     // gain tables by scan parity: row = covariance column (fgrow_kernel)
     unsigned* alloc; int block_cap = 0, over_base = 0, region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
     TTable tab[2];
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
@@ -352,10 +349,10 @@ struct Forest {
     void layout(Arena& ar) {
         for (int s = 0; s < R; ++s) {
             mht_nodes& l = layer[s];
-            l.cap = Ncap; l.cap_cov = capc;
+            l.cap = Ncap; l.cap_cov = 0;
             l.x = ar.take<double>((size_t)4 * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
             l.parent = ar.take<int32_t>(Ncap); l.meas = ar.take<int32_t>(Ncap); l.cov = ar.take<int32_t>(Ncap);
-            l.flags = ar.take<uint8_t>(Ncap); l.P = ar.take<float>((size_t)16 * capc);
+            l.flags = ar.take<uint8_t>(Ncap); l.P = nullptr;
         }
         for (int b = 0; b < 2; ++b) {
             path[b] = ar.take<int32_t>((size_t)pds * Ncap);
@@ -368,7 +365,9 @@ struct Forest {
         }
         cost = ar.take<double>(Ncap);
         tchild = ar.take<int32_t>((size_t)Tcap + 1); tcend = ar.take<int32_t>((size_t)Tcap + 1);
-        G[0] = ar.take<float4>((size_t)4 * capc); G[1] = ar.take<float4>((size_t)4 * capc);
+        vt.Pv = ar.take<unsigned long long>((size_t)8 * vt.vcap); vt.pdv = ar.take<double>(vt.vcap);
+        vt.Gk = ar.take<float4>((size_t)8 * vt.vcap); vt.child = ar.take<int32_t>((size_t)2 * vt.vcap);
+        vt.slots = ar.take<unsigned long long>((size_t)vt.hmask + 1); vt.count = ar.take<unsigned>(16);
         alloc = ar.take<unsigned>((size_t)FG_REGIONS * 32);
         used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
         status2 = ar.take<DevStatus>(2);
@@ -473,8 +472,17 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->PD = cfg->n_scan + 1;
     f->n_mnodes = f->R * f->Mpad;
     f->AW = f->n_mnodes / 64;
-    f->ps_log2 = cfg->n_scan + 2;      // hit/miss patterns below a root: ids < 2^(depth + 1), depth <= N + 1 after a grow
-    f->capc = f->Tcap << f->ps_log2;
+    {   // covariance-value table: ids are never recycled; the headline stream meets ~4 k distinct values in its first 120 scans and
+        // ~10 new ones per scan afterwards (a full table voids the scan with MHT_E_CAPACITY)
+        long long vc = 2ll * f->Ncap;
+        if (vc < (1 << 16)) vc = 1 << 16;
+        if (vc > (1 << 20)) vc = 1 << 20;
+        if (const char* e = getenv("MHT_VTAB_CAP")) vc = atoll(e);
+        f->vt.vcap = (int)vc;
+        unsigned hs = 1;
+        while (hs < 4u * (unsigned)vc) hs <<= 1;
+        f->vt.hmask = hs - 1;
+    }
     f->Ecap = 4 * f->Ncap;              // edges the clustering kernel can take beyond its LDS list (spill arrays)
     f->SegCap = f->Ncap / 8 + 1024;     // edges per segment (64 segments)
     {   // node index space of a layer: [static block per target slot | overflow area in FG_REGIONS regions | roots born into the layer]
@@ -528,6 +536,8 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
         }
     }
     MHT_HIP_CHECK(hipMemsetAsync(base, 0, total, ctx->stream));
+    MHT_HIP_CHECK(hipMemsetAsync(f->vt.child, 0xff, (size_t)2 * f->vt.vcap * sizeof(int32_t), ctx->stream));      // -1: no transition known
+    f->vt.overflow = &f->cnt->overflow;
     for (int b = 0; b < 2; ++b) {
         MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host2[b]), f->report_bytes, hipHostMallocDefault));
         memset(f->report_host2[b], 0, f->report_bytes);
@@ -569,9 +579,9 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb]; a.vidx = nb;
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
-    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.ps_log2 = f->ps_log2;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
-    fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
+    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
@@ -637,9 +647,8 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     const mht_nodes& out = f->layer[s % f->R];
     fill_model_only(g.model, &f->model);
     g.default_pd = f->model.default_pd; g.default_miss_nllr = f->model.default_miss_nllr;
-    g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags; g.P = in.P;
-    g.cap = f->Ncap; g.capc = f->capc; g.ps_log2 = f->ps_log2;
-    g.G_in = f->G[(s - 1) & 1]; g.G_out = f->G[s & 1];
+    g.x = in.x; g.cnllr = in.cnllr; g.pd = in.pd; g.cov = in.cov; g.flags = in.flags;
+    g.cap = f->Ncap; g.vt = f->vt;
     g.in_path = f->path[(s - 1) & 1]; g.in_apath = f->apath[(s - 1) & 1]; g.pds = f->pds;
     g.Tcap = f->Tcap;
     if (fused) {      // tables of the scan before, still uncommitted
@@ -653,7 +662,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     }
     g.t_first = f->tab[cb].first; g.t_leaf_off = f->tab[cb].leaf_off; g.t_depth = f->tab[cb].depth; g.t_shift = f->tab[cb].shift;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
-    g.oflags = out.flags; g.oP = out.P;
+    g.oflags = out.flags;
     g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
     g.tchild = f->tchild; g.tcend = f->tcend;
     g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
@@ -1008,7 +1017,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         f->commit_pending = false;
     }
     const Forest* f0 = c0->forest;
-    int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds);
+    int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds, g->ctx[0]->forest->pds);
     if (!rc) rc = launch_cluster_batch(c0, cb, n, f0->Tcap, f0->n_mnodes);
     // ILPs in two LDS tiers: the small footprint (several workgroups per CU) takes the clusters that fit it and the single-target
     // clusters, a narrow launch with the default footprint takes the few that do not
@@ -1053,9 +1062,9 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     a.layer = f->layer[f->scan % f->R];
     a.tab = f->tab[nb]; a.vidx = nb;
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
-    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap; a.ps_log2 = f->ps_log2;
+    a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
-    fill_model_only(a.model, &f->model); a.G = f->G[f->scan & 1]; a.root_base = f->root_base;
+    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
     a.hdr = reinterpret_cast<ReportHeader*>(report_dev);
     a.births = reinterpret_cast<mht_birth_report*>(report_dev + f->birth_off);
     // commit (if it is still pending: the used-measurement mask of the scan is part of it) + initiator + admission: one launch
@@ -1214,7 +1223,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     char* d = static_cast<char*>(f->stage_dev.ptr);
     char* h = static_cast<char*>(f->stage_host);
     const int nb = (f->scan + 1) & 1;
-    LeavesArgs a = {f->layer[f->scan % f->R], f->tab[nb], f->cnt, n,
+    LeavesArgs a = {f->layer[f->scan % f->R], f->tab[nb], f->cnt, f->vt, n,
                     (double*)(d + o_x), (float*)(d + o_P), (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
                     (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f)};
     hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
@@ -1253,6 +1262,7 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     char* h = static_cast<char*>(f->stage_host);
     ChainArgs a = {};
     for (int k = 0; k < f->R; ++k) a.layers[k] = f->layer[k];
+    a.vt = f->vt;
     a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
     a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
     a.P = (float*)(d + o_P); a.n_out = (int32_t*)(d + o_k);
@@ -1329,8 +1339,10 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
     else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
-    else if (!strcmp(name, "G0")) { src = f->G[0]; avail = (size_t)f->capc * 64; }
-    else if (!strcmp(name, "G1")) { src = f->G[1]; avail = (size_t)f->capc * 64; }
+    else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 128; }                  // gains by key
+    else if (!strcmp(name, "vchild")) { src = f->vt.child; avail = (size_t)f->vt.vcap * 8; }              // value id by key
+    else if (!strcmp(name, "vcount")) { src = f->vt.count; avail = 4; }                                 // value ids handed out
+    else if (!strcmp(name, "cov")) { src = f->layer[f->scan % f->R].cov; avail = (size_t)f->Ncap * 4; }     // keys of the newest layer's nodes
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     else if (!strcmp(name, "path")) { src = f->path[f->scan & 1]; avail = (size_t)f->pds * f->Ncap * 4; }      // records of the newest layer

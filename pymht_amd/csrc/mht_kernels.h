@@ -1,6 +1,7 @@
 // Kernel argument blocks and launchers shared by the translation units of libmht_amd.so.
 #pragma once
 #include "mht_common.h"
+#include "mht_vtab.h"
 
 namespace mht {
 
@@ -36,11 +37,10 @@ struct FBatch;
 struct FGrowArgs {
     Model model;
     double default_pd, default_miss_nllr;
-    // input layer (the previous scan's nodes); cap / capc are the same for every layer of the ring
-    const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags; const float* P;
-    int cap, capc;                 // P: [capc][16] (a record per column); column = slot * 2^ps_log2 + hit/miss pattern (mht_fgrow.hip)
-    int ps_log2;
-    const float4* G_in;            // [capc][4] gains by covariance column of the input layer (written one scan ahead)
+    // input layer (the previous scan's nodes); cap is the same for every layer of the ring
+    const double* x; const double* cnllr; const double* pd; const int32_t* cov; const uint8_t* flags;
+    int cap;                       // cov = key into the forest's covariance-value table (mht_vtab.h)
+    VTab vt;
     const int32_t* in_path;        // [cap][pds] measurement nodes below the root, one record per node of the input layer
     const int32_t* in_apath;       // [cap][pds] ancestor node per level
     int pds;                       // ints per record: 8 (PD <= 8) or 16
@@ -52,8 +52,7 @@ struct FGrowArgs {
     const int32_t* t_first; const int32_t* t_leaf_off; const int32_t* t_depth; const int32_t* t_shift;
     const double* t_root_cnllr; const uint8_t* t_root_f32;      // by slot of the table named above
     // output layer
-    double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags; float* oP;
-    float4* G_out;
+    double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags;
     int32_t* out_path; int32_t* out_apath; double* ocost;
     int32_t* tchild; int32_t* tcend;      // [T] children of (compacted) target t: tchild[t] .. tcend[t]-1
     int PD; int Nwin; int cur_slot_base; int AW;
@@ -164,7 +163,7 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);
 int fgrow_grid_of(const FDyn& d);
-int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds);
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds);
 int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes);
 int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds);
 size_t blp_set_tier(BlpArgs& a, int tier);

@@ -1,0 +1,126 @@
+// Covariances by VALUE: one table per forest, shared by all targets and all scans.
+//
+// The covariance of a hypothesis does not depend on which measurements it was updated with, only on whether there was one:
+// P -> P_bar -> S, K -> P_hat never sees z (kalman.py:62, :90-93), and the reference itself shares one P_hat among all hit
+// children of a node (pyTarget.py:246).  Targets that start from the same P_0 walk through the same matrices, and the recursion
+// converges: on the headline stream 13 k leaves carry ~1 750 distinct covariances.  So a node does not own a covariance, it names
+// one:
+//   value id   = index of a distinct (covariance, P_d) pair in Pv / pdv, found or inserted through a hash table over the bits;
+//   key        = 2 * (value id of the parent) + hit/miss: what a node stores (mht_nodes::cov).  child[key] = the node's own value
+//                id, Gk[key] = the gains a leaf with that covariance needs (S^-1, K, ln(lambda_ex sqrt(det 2 pi S)/P_d), the
+//                gate half-axes): 64 bytes, one dependent look-up behind the leaf's record, like the per-node column before.
+// A transition (parent value, hit/miss) is computed ONCE, by whichever chain lane of fgrow_kernel meets it first; afterwards a
+// leaf costs two 4-byte look-ups in the chain workgroups instead of ~1 400 dependent VALU operations and 256 bytes of stores.
+// Roots get a key of their own (a pseudo parent id whose miss child is the root's value).
+//
+// Concurrency (several workgroups, on different XCDs whose L2s are not coherent, may meet the same new value in one launch):
+// the hash slots are 64-bit words {tag, id + 1} driven by agent-scope atomics (they execute at the memory side); an inserter
+// claims an empty slot (id field all ones), takes an id, writes the value with agent-scope atomic stores, waits for their
+// acknowledgement and only then publishes the id in the slot.  A finder that meets a claimed slot re-reads it; one that meets
+// a published slot with its tag compares all 18 words through agent-scope loads.  child[] / Gk[] / duplicates of a transition
+// computed twice carry identical values: plain stores, consumed after the kernel boundary.  Value ids are handles: which id a
+// value gets depends on the timing, nothing else does.
+#pragma once
+#include "mht_common.h"
+#include "mht_math.h"
+
+namespace mht {
+
+struct VTab {
+    unsigned long long* Pv;        // [vcap][8] the 16 floats of a covariance as 8 words
+    double* pdv;                   // [vcap] P_d of the value (part of its identity: the score constant depends on it)
+    float4* Gk;                    // [2 * vcap][4] gains by key
+    int32_t* child;                // [2 * vcap] value id by key, -1 = transition not computed yet
+    unsigned long long* slots;     // [hmask + 1] hash table
+    unsigned* count;               // value ids handed out
+    int32_t* overflow;             // sticky error word of the forest (FCounts::overflow)
+    int vcap; unsigned hmask;
+};
+
+#if defined(__HIPCC__)
+constexpr unsigned VT_PENDING = 0xffffffffu;
+
+__device__ __forceinline__ unsigned long long vt_hash(const unsigned long long* w, double pd) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)__double_as_longlong(pd);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        h ^= w[q];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 32;
+    return h;
+}
+
+// value id of (P, pd): found or inserted.  Every lane may call this with its own value (no lane waits inside an iteration for
+// another lane of its wavefront: a claim is published within the iteration that made it).
+template <typename VT> __device__ __forceinline__ int vt_find_or_insert(const VT& t, const float* P, double pd) {
+    unsigned long long w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = ((unsigned long long)__float_as_uint(P[2 * q + 1]) << 32) | __float_as_uint(P[2 * q]);
+    const unsigned long long h = vt_hash(w, pd);
+    const unsigned tag = (unsigned)(h >> 32);
+    unsigned pos = (unsigned)h & t.hmask;
+    for (int guard = 0; guard < (1 << 24); ++guard) {
+        const unsigned long long s = __hip_atomic_load(&t.slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s == 0ull) {
+            const unsigned long long claim = ((unsigned long long)tag << 32) | VT_PENDING;
+            unsigned long long expected = 0ull;
+            if (__hip_atomic_compare_exchange_strong(&t.slots[pos], &expected, claim, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned id = atomicAdd(t.count, 1u);
+                if (id >= (unsigned)t.vcap) {      // table full: the scan is void (MHT_E_CAPACITY), the claim is given back
+                    *t.overflow = 1;
+                    __hip_atomic_store(&t.slots[pos], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return 0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) __hip_atomic_store(&t.Pv[(size_t)id * 8 + q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(&t.pdv[id]), (unsigned long long)__double_as_longlong(pd), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the value has arrived before its id becomes visible
+                __hip_atomic_store(&t.slots[pos], ((unsigned long long)tag << 32) | (unsigned long long)(id + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return (int)id;
+            }
+            continue;      // somebody else took the slot: look at it again
+        }
+        if ((unsigned)(s >> 32) == tag) {
+            const unsigned idp = (unsigned)s;
+            if (idp == VT_PENDING) { __builtin_amdgcn_s_sleep(1); continue; }      // being written: look again
+            const unsigned id = idp - 1u;
+            bool same = (unsigned long long)__double_as_longlong(pd) ==
+                        __hip_atomic_load(reinterpret_cast<unsigned long long*>(&t.pdv[id]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) same = same && (w[q] == __hip_atomic_load(&t.Pv[(size_t)id * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (same) return (int)id;
+        }
+        pos = (pos + 1u) & t.hmask;      // another value lives here
+    }
+    *t.overflow = 1;
+    return 0;
+}
+
+// the covariance of value `id` (written in an earlier launch, or by this thread)
+template <typename VT> __device__ __forceinline__ void vt_load(const VT& t, int id, float* P) {
+    const uint4* p = reinterpret_cast<const uint4*>(t.Pv + (size_t)id * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = p[q];
+        P[4 * q] = __uint_as_float(v.x); P[4 * q + 1] = __uint_as_float(v.y); P[4 * q + 2] = __uint_as_float(v.z); P[4 * q + 3] = __uint_as_float(v.w);
+    }
+}
+
+// what a leaf with covariance P needs: S^-1 (4), K (8), score constant, gate half-axes
+__device__ __forceinline__ void vt_gains(const Model& m, const float* P, double pd, float4* g) {
+    CovChain c;
+    cov_chain(m, P, c, false);
+    const float lnc = nllr_const(c.S, m.lambda_ex, pd);
+    const float rx = sqrtf((float)m.eta2 * fabsf(c.S[0])), ry = sqrtf((float)m.eta2 * fabsf(c.S[3]));
+    g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
+    g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
+    g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
+    g[3] = make_float4(lnc, rx, ry, 0.f);
+}
+#endif
+
+}  // namespace mht

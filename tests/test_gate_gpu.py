@@ -102,8 +102,8 @@ def test_gate_vs_oracle_random_shapes(gpu_ctx, n, M, seed):
 
 def test_gain_table_matches_golden_S_Sinv_K(gold_dir):
     """kalman.precalc's S^-1 and K (kalman.py:90-92) read back FROM THE GPU: the forest keeps them per covariance column in its gain
-    table (csrc/mht_fgrow.hip: written one scan ahead by the chain workgroups, for new roots by add_targets_kernel; column = slot * 2^(N+2) +
-    hit/miss pattern).  Roots with the
+    table (csrc/mht_vtab.h: filed under the key the node names its covariance by; written one scan ahead by the chain workgroups of
+    fgrow_kernel, for new roots by the admission code).  Roots with the
     golden vectors' covariances are planted and their gain rows compared bit for bit with the reference's S_inv, K; the gate
     half-axes and the score constant are re-derived from the reference's S."""
     import ctypes as C
@@ -126,10 +126,15 @@ def test_gain_table_matches_golden_S_Sinv_K(gold_dir):
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         _lib.check(trk._lib.mht_forest_add_targets(trk._ctx.handle, n, p(x0), p(P), p(fl), p(pdv), p(me), 0, p(acc), p(ids)))
         assert acc.all()
-        PS = 1 << (3 + 2)                      # covariance columns per target slot: 2^(N+2) hit/miss patterns; the root is pattern 1
-        G = np.zeros((trk._cfg.max_targets * PS, 16), np.float32)
-        _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"G0", p(G), G.nbytes))
-        rows = G[np.arange(n) * PS + 1]
+        # a root's node holds the KEY of its covariance in the forest's value table; the gains are filed under that key
+        keys = np.zeros(trk._cfg.max_nodes, np.int32)
+        _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"cov", p(keys), keys.nbytes))
+        lb = trk.leafBatch()
+        kk = keys[lb["node"]]
+        assert len(kk) == n and np.all(kk >= 0)
+        G = np.zeros((int(kk.max()) + 1, 16), np.float32)
+        _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"Gk", p(G), G.nbytes))
+        rows = G[kk]
         assert np.array_equal(rows[:, 0:4], k("S_inv").reshape(n, 4)), c
         assert np.array_equal(rows[:, 4:12], k("K").reshape(n, 8)), c
         S = k("S").reshape(n, 4).astype(np.float32)

@@ -18,7 +18,9 @@ BUDGET = {
     "mht_gate.hip": {"grow_kernel": (0, 128)},
     "mht_blp.hip": {"blp_kernel": (32, 256)},
     "mht_cluster.hip": {"cluster_kernel": (0, 128)},
-    "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 64)},
+    "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 128), "post_scan_kernel": (64, 128)},      # (1024 threads: 4 waves per SIMD; one workgroup:
+    # the initiator's small dense inverses index their scratch arrays dynamically)
+    "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128)},      # 3 / 4 workgroups per CU
 }
 
 
