@@ -145,6 +145,11 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
     }
     FG_STAMP(1);
 }
+// (Tried and dropped: resolving the transitions inside the target workgroups, behind their emission -- a new transition costs
+// ~5 us, some workgroup meets one on almost every scan, and there it lands at the end of the kernel: grow stage 22 -> 26 us; and
+// eight targets per chain workgroup -- a wavefront walks its targets one after the other, four dependent round trips each, and
+// the chain workgroups became the kernel's tail, 26 us again.  One (target, hit/miss) per wavefront starts with the launch and is
+// done at ~6 us, long before the target workgroups.)
 
 // ---- target workgroups ---------------------------------------------------------------------------------------------------
 // One child, one ROLE: the four wavefronts of the workgroup all walk the children (lane = child) and each does a quarter of
