@@ -105,6 +105,28 @@ int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nodes* in, con
                   const float* z, int32_t M, const mht_nodes* out, int32_t* child_ptr, double* nllr,
                   uint64_t* used, int32_t* n_children);
 
+/* ---- seam (i), dimension-generic: a linear-Gaussian model with nx states (4 or 6) and 2 measurements -----------------------
+ * BASELINE config 5 names a 6-state model; the reference ships none, but its kalman module is dimension-generic:
+ * predict / precalc (pymht/utils/kalman.py:55-101), z_tilde / NIS / gate (kalman.py:25-40, tracker.py:829), numpyFilter
+ * (kalman.py:43-52), nllr (kalman.py:14-22).  This is that module for L leaves x M measurements in one call, results in the
+ * reference's evaluation order.  All arrays are device memory, structure-of-arrays:
+ *   x [nx][L] f64, flags [L] (MHT_F_STATE_F32: the leaf's state chain is float32), P [nx*nx][L] f32, pd [L], z (M,2) f32
+ *   x_bar [nx][L] f64, P_bar / P_hat [nx*nx][L], S / S_inv [4][L], K [2*nx][L]  (K row-major nx x 2)
+ *   row_ptr [L+1], col_idx [cap] (gated measurement indices, ascending per leaf: np.nonzero, tracker.py:832),
+ *   x_hat [nx][cap] f64 and nllr [cap] per gated pair.  n_pairs (host, may be NULL) = row_ptr[L].  Synchronises.
+ * Returns MHT_E_CAPACITY if there are more gated pairs than cap. */
+typedef struct mht_model_x {
+    int32_t nx;             /* 4 or 6 */
+    const float* A;         /* host [nx*nx] row-major state transition */
+    const float* Q;         /* host [nx*nx] process noise */
+    const float* C;         /* host [2*nx] measurement matrix */
+    const float* R;         /* host [4] measurement noise */
+    double eta2, lambda_ex;
+} mht_model_x;
+int mht_gate_scan_x(mht_ctx* ctx, const mht_model_x* model, int32_t L, const double* x, const uint8_t* flags, const float* P,
+                    const double* pd, const float* z, int32_t M, double* x_bar, float* P_bar, float* P_hat, float* S, float* S_inv,
+                    float* K, int32_t* row_ptr, int32_t* col_idx, double* x_hat, double* nllr, int32_t cap, int32_t* n_pairs);
+
 
 /* ---- seam (ii): Tracker._findClustersFromSets (tracker.py:961-974) -------------------------------------------
  * assoc  dev [T][words] uint64: bit b of row t set iff target t is associated with measurement node b

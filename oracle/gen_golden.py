@@ -352,9 +352,69 @@ def main():
         order = sorted(range(len(big)), key=lambda i: -len(big[i]["cols"]))
         keep = sorted(set(order[:40]) | set(order[40::7]))
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
+    if "g11" in which:
+        gen_g11(mods)
     if "g6b" in which:
         # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
+
+
+def gen_g11(mods):
+    """Known-answer vectors of the reference's DIMENSION-GENERIC kalman module (kalman.py:14-101) for a 6-state model (BASELINE
+    config 5 names one; the reference ships none: the matrices are pymht_amd/models/ca.py, the arithmetic is the reference's)."""
+    kal = mods["kalman"]
+    sys.path.insert(0, ROOT)
+    from pymht_amd.models import ca
+    rng = np.random.default_rng(20260929)
+    A, Q, C, R = ca.Phi(2.5), ca.Q(2.5), ca.C_RADAR, ca.R_RADAR()
+    fx = dict(A=A, Q=Q, C=C, R=R, eta2=5.99, lambda_ex=1e-4 + 2e-5, nx=6)
+    case = 0
+    for n, M in ((1, 1), (10, 37), (257, 500), (64, 129), (2000, 64)):
+        for f32state in (False, True):
+            P = np.array([ca.P0] * n)
+            for i in range(n):      # covariances reached after 0..6 steps with random hit/miss patterns
+                Pi = ca.P0
+                for _ in range(int(rng.integers(0, 7))):
+                    xb, Pb = kal.predict(A, Q, np.zeros((1, 6)), Pi.reshape(1, 6, 6))
+                    Pi = kal.precalc(C, R, xb, Pb)[4][0] if rng.uniform() < 0.7 else Pb[0]
+                P[i] = Pi
+            x = np.concatenate([rng.uniform(-3000, 3000, size=(n, 2)), rng.normal(0, 8, size=(n, 2)), rng.normal(0, 0.3, size=(n, 2))], axis=1)
+            if f32state:
+                x = x.astype(np.float32)
+            xb = A.dot(x.T).T
+            z = rng.uniform(-3000, 3000, size=(M, 2))
+            for j in range(M):
+                if rng.uniform() < 0.6:
+                    i = int(rng.integers(0, n))
+                    z[j] = xb[i, 0:2] + rng.normal(0, 6.0, size=2)
+            z = z.astype(np.float32)
+            P_d = 0.9
+            x_bar, P_bar = kal.predict(A, Q, x, P)
+            z_hat, S, S_inv, K, P_hat = kal.precalc(C, R, x_bar, P_bar)
+            zt = kal.z_tilde(z, z_hat, n, 2)
+            nis = kal.normalizedInnovationSquared(zt, S_inv)
+            gate = nis <= 5.99
+            idx = [np.nonzero(gate[i])[0] for i in range(n)]
+            x_hat = [kal.numpyFilter(x_bar[i], K[i], zt[i, idx[i]]) for i in range(n)]
+            nl = [kal.nllr(fx["lambda_ex"], P_d, S[i], nis[i, gate[i]]) for i in range(n)]
+            r = orc.process_leaves(A, Q, C, R, 5.99, fx["lambda_ex"], x, P, [P_d] * n, z)      # the oracle is dimension-generic too
+            assert np.array_equal(r["x_bar"], x_bar) and np.array_equal(r["P_bar"], P_bar) and np.array_equal(r["P_hat"], P_hat)
+            assert all(np.array_equal(a, b) for a, b in zip(r["idx"], idx)) and all(np.array_equal(a, b) for a, b in zip(r["x_hat"], x_hat))
+            assert all(np.array_equal(a, b) for a, b in zip(r["nllr"], nl))
+            p = "c%d_" % case
+            fx[p + "x"], fx[p + "P"], fx[p + "z"], fx[p + "P_d"] = x, P, z, P_d
+            fx[p + "x_bar"], fx[p + "P_bar"], fx[p + "P_hat"] = x_bar, P_bar, P_hat
+            fx[p + "S"], fx[p + "S_inv"], fx[p + "K"] = S, S_inv, K
+            fx[p + "row_ptr"] = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).astype(np.int64)
+            fx[p + "col_idx"] = np.concatenate(idx).astype(np.int64) if n else np.zeros(0, np.int64)
+            fx[p + "x_hat"] = np.concatenate(x_hat, axis=0) if len(fx[p + "col_idx"]) else np.zeros((0, 6))
+            fx[p + "nllr"] = np.concatenate(nl) if len(fx[p + "col_idx"]) else np.zeros(0)
+            # margin of the closest non-decision to the gate threshold (what a different rounding order would have to cross)
+            fx[p + "gate_margin"] = float(np.min(np.abs(nis.astype(np.float64) - 5.99)))
+            case += 1
+    fx["n_cases"] = case
+    np.savez_compressed(os.path.join(GOLD, "g11_kalman6.npz"), **fx)
+    print("  g11_kalman6: %d cases" % case)
 
 
 def gen_g10(dump_dir):

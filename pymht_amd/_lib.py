@@ -17,6 +17,11 @@ class MhtModel(C.Structure):
                 ("default_miss_nllr", C.c_double)]
 
 
+class MhtModelX(C.Structure):      # mht_model_x: dimension-generic model (nx = 4 or 6 states, 2 measurements)
+    _fields_ = [("nx", C.c_int32), ("A", C.POINTER(C.c_float)), ("Q", C.POINTER(C.c_float)), ("C", C.POINTER(C.c_float)),
+                ("R", C.POINTER(C.c_float)), ("eta2", C.c_double), ("lambda_ex", C.c_double)]
+
+
 class MhtNodes(C.Structure):
     _fields_ = [("x", C.c_void_p), ("cnllr", C.c_void_p), ("pd", C.c_void_p), ("parent", C.c_void_p),
                 ("meas", C.c_void_p), ("cov", C.c_void_p), ("flags", C.c_void_p), ("P", C.c_void_p),
@@ -102,6 +107,7 @@ def _declare(lib):
         "mht_synchronize": [vp],
         "mht_gate_scan": [vp, C.POINTER(MhtModel), C.POINTER(MhtNodes), vp, i32, vp, i32, C.POINTER(MhtNodes), vp,
                           vp, vp, C.POINTER(i32)],
+        "mht_gate_scan_x": [vp, C.POINTER(MhtModelX), i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(i32)],
         "mht_cluster": [vp, i32, i32, vp, vp],
         "mht_solve_blp": [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(dbl), C.POINTER(i32),
                           C.POINTER(i32), C.POINTER(i32)],

@@ -56,8 +56,14 @@ constexpr int EMIT_THREADS = 64;  // one wavefront, one leaf per lane
 constexpr int MAX_MEAS = 4096;    // 64 hit-mask words per leaf, one per lane
 constexpr int EDGE_SEGS = 64;      // the (target, measurement) edge list is written in 64 independently counted segments
 constexpr int MAXPD = 15;         // longest root->leaf path kept per hypothesis (N-scan window + 1)
-constexpr int FG_THREADS = 256;   // fgrow_kernel: one workgroup per target
-constexpr int FG_CAP = 96;        //   leaves of a target handled per pass, one per lane of two wavefronts (more: chunks, two passes)
+#ifndef MHT_FG_THREADS
+#define MHT_FG_THREADS 256
+#endif
+#ifndef MHT_FG_CAP
+#define MHT_FG_CAP 96
+#endif
+constexpr int FG_THREADS = MHT_FG_THREADS;   // fgrow_kernel: one workgroup per target
+constexpr int FG_CAP = MHT_FG_CAP;        //   leaves of a target handled per pass, one per lane of two wavefronts (more: chunks, two passes)
 constexpr int FG_REGIONS = 8;     //   regions of the node index space, one child counter each (one per XCD)
 
 // device-side status word of a ctx (sticky until read)

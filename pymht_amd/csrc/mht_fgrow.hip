@@ -39,7 +39,7 @@ static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesse
 
 struct TInfo { int alive, first, cnt, depth, shift; };
 constexpr int FG_MAP = 1024;                          // entries of the child -> leaf table of a chunk (more children: binary search)
-constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128;     // targets per chain workgroup: wavefront = (target, hit/miss)
+constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128 > 0 ? FG_THREADS / 128 : 1;     // targets per chain workgroup: wavefront = (target, hit/miss)
 typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
 
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
@@ -316,6 +316,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) s_red[wave] = acc;      // (summed behind the first barrier below: nothing needs the index before the allocation)
+    if (tid < 4 && tid >= FG_THREADS / 64) s_red[tid] = 0;
     const int depth0 = ti.depth, shift0 = ti.shift, cnt = ti.cnt, first = ti.first;
     const int curw = a.cur_slot_base >> 6;      // first word of this scan's measurement nodes in the association bitset
 

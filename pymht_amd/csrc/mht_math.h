@@ -204,6 +204,47 @@ MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_ha
     for (int i = 0; i < 4; ++i) x_hat[i] = update_component<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt);
 }
 
+// ---- dimension-generic restatement (BASELINE config 5 names a 6-state model; the reference's kalman module is dimension-generic:
+//      kalman.py:55-101).  Same evaluation order as the 4-state code above, NX states, 2 measurements.
+template <int NX>
+struct ModelX {
+    float A[NX * NX], Q[NX * NX], C[2 * NX], R[4];
+    double eta2, lambda_ex;
+};
+template <typename TS, int NX>
+MHT_HD void predict_precalc_x(const ModelX<NX>& m, const TS* x, const float* P, TS* x_bar, TS* z_hat, float* P_bar, float* P_hat,
+                              float* K, float* S, float* S_inv) {
+    gemm_chain<TS, float, TS, NX, NX, 1>(m.A, x, x_bar);              // kalman.py:61
+    gemm_chain<TS, float, TS, 2, NX, 1>(m.C, x_bar, z_hat);           // kalman.py:89
+    float AP[NX * NX], At[NX * NX], APA[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) At[i * NX + j] = m.A[j * NX + i];
+    gemm_chain<float, float, float, NX, NX, NX>(m.A, P, AP);          // kalman.py:62
+    gemm_chain<float, float, float, NX, NX, NX>(AP, At, APA);
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) P_bar[i] = APA[i] + m.Q[i];
+    float Ct[2 * NX], CP[2 * NX], CPC[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Ct[j * 2 + i] = m.C[i * NX + j];
+    gemm_chain<float, float, float, 2, NX, NX>(m.C, P_bar, CP);       // kalman.py:90
+    gemm_chain<float, float, float, 2, NX, 2>(CP, Ct, CPC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[i] = CPC[i] + m.R[i];
+    inv2(S, S_inv);                                                   // kalman.py:91
+    float PCt[2 * NX];
+    gemm_chain<float, float, float, NX, NX, 2>(P_bar, Ct, PCt);       // kalman.py:92
+    gemm_chain<float, float, float, NX, 2, 2>(PCt, S_inv, K);
+    float KC[NX * NX], KCP[NX * NX];
+    gemm_chain<float, float, float, NX, 2, NX>(K, m.C, KC);           // kalman.py:93
+    gemm_chain<float, float, float, NX, NX, NX>(KC, P_bar, KCP);
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) P_hat[i] = P_bar[i] - KCP[i];
+}
+
 // Node flags (one byte per hypothesis)
 enum : uint8_t {
     F_STATE_F32 = 1,   // state chain (x, z_hat, z_tilde, NIS, NLLR) is float32: tracks born from the initiator

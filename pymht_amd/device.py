@@ -118,3 +118,43 @@ def process_leaf_nodes(ctx, model, x, P, cnllr, pd, flags, z):
                 x_bar=xs[cp[:-1]], P_bar=Pall[0::2], P_hat=Pall[1::2],
                 row_ptr=cp - np.arange(n + 1), col_idx=(meas[hit] - 1).astype(np.int64), x_hat=xs[hit],
                 nllr=incs[hit], used=used.cpu().numpy().view(np.uint64))
+
+
+def process_leaf_nodes_x(ctx, A, Q, Cm, R, eta2, lambda_ex, x, P, pd, flags, z):
+    """The dimension-generic form of seam (i) (`mht_gate_scan_x`: nx = 4 or 6 states): the reference's kalman module
+    (predict, precalc, z_tilde, NIS, gate, numpyFilter, nllr -- kalman.py:14-101) for n leaves x M measurements in one call.
+    Host arrays in (x (n,nx) f64|f32, P (n,nx,nx) f32), host arrays out, shaped like the oracle's process_leaves()."""
+    lib, dev = ctx.lib, ctx.device
+    n, nx, M = x.shape[0], x.shape[1], z.shape[0]
+    keep = [np.ascontiguousarray(np.asarray(m, dtype=np.float32).ravel()) for m in (A, Q, Cm, R)]
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    model = _lib.MhtModelX(nx, fp(keep[0]), fp(keep[1]), fp(keep[2]), fp(keep[3]), float(eta2), float(lambda_ex))
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    xd = t(np.asarray(x, dtype=np.float64).T, np.float64) if n else torch.zeros((nx, 0), dtype=torch.float64, device=dev)
+    Pd = t(np.asarray(P, dtype=np.float32).reshape(n, nx * nx).T, np.float32) if n else torch.zeros((nx * nx, 0), dtype=torch.float32, device=dev)
+    pdd, fd = t(np.asarray(pd, dtype=np.float64), np.float64), t(np.asarray(flags, dtype=np.uint8), np.uint8)
+    zd = t(np.asarray(z, dtype=np.float32).reshape(-1, 2), np.float32)
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+    f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    x_bar, P_bar, P_hat, S, S_inv, K = f64(nx, max(n, 1)), f32(nx * nx, max(n, 1)), f32(nx * nx, max(n, 1)), f32(4, max(n, 1)), f32(4, max(n, 1)), f32(2 * nx, max(n, 1))
+    if n:      # (the arrays are [rows][n] exactly: allocate them at that width)
+        x_bar, P_bar, P_hat, S, S_inv, K = f64(nx, n), f32(nx * nx, n), f32(nx * nx, n), f32(4, n), f32(4, n), f32(2 * nx, n)
+    row_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    cap = max(4 * n + 64, 64)
+    while True:
+        col_idx = torch.zeros(cap, dtype=torch.int32, device=dev)
+        x_hat, nllr = f64(nx, cap), f64(cap)
+        total = C.c_int32(0)
+        rc = lib.mht_gate_scan_x(ctx.handle, C.byref(model), n, xd.data_ptr(), fd.data_ptr(), Pd.data_ptr(), pdd.data_ptr(), zd.data_ptr(), M,
+                                 x_bar.data_ptr(), P_bar.data_ptr(), P_hat.data_ptr(), S.data_ptr(), S_inv.data_ptr(), K.data_ptr(),
+                                 row_ptr.data_ptr(), col_idx.data_ptr(), x_hat.data_ptr(), nllr.data_ptr(), cap, C.byref(total))
+        if rc == _lib.MHT_E_CAPACITY:
+            cap = total.value + 64
+            continue
+        _lib.check(rc)
+        break
+    g = total.value
+    T = lambda a, *shape: a.cpu().numpy().T.reshape((-1,) + shape).copy()
+    return dict(x_bar=T(x_bar, nx)[:n], P_bar=T(P_bar, nx, nx)[:n], P_hat=T(P_hat, nx, nx)[:n], S=T(S, 2, 2)[:n], S_inv=T(S_inv, 2, 2)[:n],
+                K=T(K, nx, 2)[:n], row_ptr=row_ptr.cpu().numpy().astype(np.int64), col_idx=col_idx[:g].cpu().numpy().astype(np.int64),
+                x_hat=x_hat[:, :g].cpu().numpy().T.copy(), nllr=nllr[:g].cpu().numpy())

@@ -47,3 +47,36 @@ extern "C" void mht_host_process(const float* A, const float* Q, const float* C,
     if (f32state) run<float>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, nis, gate, x_hat, nllr);
     else run<double>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, nis, gate, x_hat, nllr);
 }
+
+// dimension-generic arithmetic (predict_precalc_x), 6 states: tests/golden/g11_kalman6.npz
+template <typename TS>
+static void run6(const ModelX<6>& m, int n, int M, const double* x, const float* P, const float* z, double P_d,
+                 double* x_bar, float* P_bar, float* P_hat, float* S, float* S_inv, float* K,
+                 unsigned char* gate /*n*M*/, double* x_hat /*n*M*6*/, double* nllr /*n*M*/) {
+    for (int i = 0; i < n; ++i) {
+        TS xs[6], xb[6], zh[2];
+        for (int k = 0; k < 6; ++k) xs[k] = (TS)x[i * 6 + k];
+        float Pb[36], Ph[36], Kk[12], Ss[4], Si[4];
+        predict_precalc_x<TS, 6>(m, xs, P + i * 36, xb, zh, Pb, Ph, Kk, Ss, Si);
+        for (int k = 0; k < 6; ++k) x_bar[i * 6 + k] = (double)xb[k];
+        memcpy(P_bar + i * 36, Pb, 144); memcpy(P_hat + i * 36, Ph, 144);
+        memcpy(S + i * 4, Ss, 16); memcpy(S_inv + i * 4, Si, 16); memcpy(K + i * 12, Kk, 48);
+        const float lnc = nllr_const(Ss, m.lambda_ex, P_d);
+        for (int j = 0; j < M; ++j) {
+            TS zt[2], v;
+            gate[(size_t)i * M + j] = gate_pair<TS>(zh, Si, z[j * 2], z[j * 2 + 1], (TS)m.eta2, zt, v);
+            for (int k = 0; k < 6; ++k) x_hat[((size_t)i * M + j) * 6 + k] = (double)update_component<TS>(xb[k], Kk[2 * k], Kk[2 * k + 1], zt);
+            nllr[(size_t)i * M + j] = (double)((TS)0.5 * v + (TS)lnc);
+        }
+    }
+}
+extern "C" void mht_host_process_x6(const float* A, const float* Q, const float* C, const float* R, double eta2, double lambda_ex,
+                                    int f32state, int n, int M, const double* x, const float* P, const float* z, double P_d,
+                                    double* x_bar, float* P_bar, float* P_hat, float* S, float* S_inv, float* K,
+                                    unsigned char* gate, double* x_hat, double* nllr) {
+    ModelX<6> m;
+    memcpy(m.A, A, 144); memcpy(m.Q, Q, 144); memcpy(m.C, C, 48); memcpy(m.R, R, 16);
+    m.eta2 = eta2; m.lambda_ex = lambda_ex;
+    if (f32state) run6<float>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, gate, x_hat, nllr);
+    else run6<double>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, gate, x_hat, nllr);
+}

@@ -1,0 +1,61 @@
+"""GPU: the dimension-generic gate seam `mht_gate_scan_x` through the C ABI -- a 6-state model against known-answer vectors made
+with the reference's own dimension-generic kalman module (tests/golden/g11_kalman6.npz, BASELINE config 5's state dimension), the
+4-state model against the G1 vectors, edge shapes against the oracle."""
+import os
+import numpy as np
+import pytest
+
+import mht_oracle as orc
+from util import NLLR_ATOL, flags_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(r, k, c):
+    assert np.array_equal(r["row_ptr"], k("row_ptr")) and np.array_equal(r["col_idx"], k("col_idx")), c      # gating: bit-exact
+    assert np.array_equal(r["x_bar"], k("x_bar").astype(np.float64)), c
+    for name in ("P_bar", "P_hat", "S", "S_inv", "K"):
+        assert np.array_equal(r[name], k(name)), (c, name)
+    assert np.array_equal(r["x_hat"], k("x_hat").astype(np.float64)), c
+    assert np.allclose(r["nllr"], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c
+
+
+@pytest.mark.parametrize("fixture", ["g11_kalman6", "g1_kalman"])
+def test_gate_x_matches_reference_vectors(gpu_ctx, gold_dir, fixture):
+    from pymht_amd.device import process_leaf_nodes_x
+    g = np.load(os.path.join(gold_dir, fixture + ".npz"))
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        x = k("x")
+        r = process_leaf_nodes_x(gpu_ctx, g["A"], g["Q"], g["C"], g["R"], float(g["eta2"]), float(g["lambda_ex"]), x, k("P"),
+                                 np.full(len(x), float(k("P_d"))), flags_for(x), k("z"))
+        _check(r, k, (fixture, c))
+
+
+@pytest.mark.parametrize("n,M,seed", [(0, 5, 1), (3, 0, 2), (1, 1, 3), (700, 65, 4), (129, 2048, 5)])
+def test_gate_x_six_state_edge_shapes_vs_oracle(gpu_ctx, n, M, seed):
+    from pymht_amd.device import process_leaf_nodes_x
+    from pymht_amd.models import ca
+    from trace_util import states_close
+    rng = np.random.default_rng(seed)
+    A, Q, Cm, R = ca.Phi(2.5), ca.Q(2.5), ca.C_RADAR, ca.R_RADAR()
+    x = np.concatenate([rng.uniform(-500, 500, size=(n, 2)), rng.normal(0, 5, size=(n, 2)), rng.normal(0, 0.2, size=(n, 2))], axis=1)
+    P = np.array([ca.P0] * n).reshape(n, 6, 6)
+    z = rng.uniform(-500, 500, size=(M, 2))
+    if n and M:
+        xb = A.astype(np.float64).dot(x.T).T
+        pick = rng.integers(0, n, size=M)
+        near = rng.uniform(size=M) < 0.5
+        z[near] = xb[pick[near], 0:2] + rng.normal(0, 7.0, size=(int(near.sum()), 2))
+    z = z.astype(np.float32)
+    r = process_leaf_nodes_x(gpu_ctx, A, Q, Cm, R, 5.99, 1.2e-4, x, P, np.full(n, 0.8), flags_for(x), z)
+    if n == 0:
+        assert r["row_ptr"].tolist() == [0]
+        return
+    o = orc.process_leaves(A, Q, Cm, R, 5.99, 1.2e-4, x, P, [0.8] * n, z.reshape(-1, 2))
+    assert [tuple(r["col_idx"][r["row_ptr"][i]:r["row_ptr"][i + 1]].tolist()) for i in range(n)] == [tuple(i.tolist()) for i in o["idx"]]
+    # (a live oracle on this box's CPU: states to 1e-6 relative, index sets exactly -- the golden vectors pin the bits)
+    assert np.allclose(r["x_bar"], o["x_bar"], rtol=1e-6, atol=1e-9) and np.allclose(r["P_hat"], o["P_hat"], rtol=1e-6, atol=0)
+    if len(r["col_idx"]):
+        assert np.allclose(r["x_hat"], np.concatenate(o["x_hat"], axis=0), rtol=1e-6, atol=1e-6)
+        assert np.allclose(r["nllr"], np.concatenate(o["nllr"]), rtol=0, atol=NLLR_ATOL)

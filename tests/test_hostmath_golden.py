@@ -42,3 +42,30 @@ def test_hostmath_matches_reference_vectors(gold_dir, hostmath):
         assert np.array_equal(o["nis"][mask], k("nis_gated").astype(np.float64)), c  # NIS: bit-exact
         assert np.array_equal(o["x_hat"][mask], k("x_hat").astype(np.float64)), c    # states: bit-exact
         assert np.allclose(o["nllr"][mask], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c
+
+
+def test_hostmath_six_state_matches_reference_vectors(gold_dir, hostmath):
+    """The dimension-generic arithmetic (mht_math.h::predict_precalc_x, NX = 6) against known-answer vectors made with the reference's
+    own dimension-generic kalman module (tests/golden/g11_kalman6.npz): bit for bit, NLLR constant to 1 ulp(f32)."""
+    g = np.load(os.path.join(gold_dir, "g11_kalman6.npz"))
+    g = {k: g[k] for k in g.files}
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        x, P, z = k("x"), np.ascontiguousarray(k("P")), np.ascontiguousarray(k("z"))
+        n, M = x.shape[0], z.shape[0]
+        o = dict(x_bar=np.zeros((n, 6)), P_bar=np.zeros((n, 6, 6), np.float32), P_hat=np.zeros((n, 6, 6), np.float32),
+                 S=np.zeros((n, 2, 2), np.float32), S_inv=np.zeros((n, 2, 2), np.float32), K=np.zeros((n, 6, 2), np.float32),
+                 gate=np.zeros((n, M), np.uint8), x_hat=np.zeros((n, M, 6)), nllr=np.zeros((n, M)))
+        hostmath.mht_host_process_x6(_p(g["A"]), _p(g["Q"]), _p(g["C"]), _p(g["R"]), C.c_double(float(g["eta2"])), C.c_double(float(g["lambda_ex"])),
+                                     int(x.dtype == np.float32), n, M, _p(np.ascontiguousarray(x, dtype=np.float64)), _p(P), _p(z), C.c_double(float(k("P_d"))),
+                                     *[_p(o[q]) for q in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K", "gate", "x_hat", "nllr")])
+        assert np.array_equal(o["x_bar"], k("x_bar").astype(np.float64)), c
+        for name in ("P_bar", "P_hat", "S", "S_inv", "K"):
+            assert np.array_equal(o[name], k(name)), (c, name)
+        rp, ci = k("row_ptr"), k("col_idx")
+        mask = np.zeros((n, M), bool)
+        for i in range(n):
+            mask[i, ci[rp[i]:rp[i + 1]]] = True
+        assert np.array_equal(mask, o["gate"].astype(bool)), c
+        assert np.array_equal(o["x_hat"][mask], k("x_hat").astype(np.float64)), c
+        assert np.allclose(o["nllr"][mask], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c
