@@ -417,7 +417,7 @@ def gen_g11(mods):
     print("  g11_kalman6: %d cases" % case)
 
 
-def gen_g10(dump_dir):
+def gen_g10(dump_dir, name="g10_ilp_small_hard"):
     """Small clusters without a dual certificate (3..9 near-duplicate tracks): the slowest ILPs of four 276-scan headline streams
     (seeds 5446/5463/5480/5497, `confine=True`), dumped on the GPU box by `python tools/blp_tail.py 276 SEED gpurun_out/ilp`
     (columns = path records of the forest, costs = its ILP cost array).  Exact optimum and uniqueness by HiGHS, as for g4."""
@@ -430,11 +430,16 @@ def gen_g10(dump_dir):
         cost = np.asarray(d["cost"], dtype=np.float64)
         sel, obj = orc.solve_blp_exact(cols, sizes, cost)
         insts.append(dict(cols=cols, sizes=sizes, cost=cost, sel=sel, obj=obj))
-    gen_g4(insts, name="g10_ilp_small_hard")
+    gen_g4(insts, name=name)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "g10":      # python oracle/gen_golden.py g10 gpurun_out/ilp   (no reference import needed)
         gen_g10(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "g12":
+        # clusters of 26-29 targets / 2.8-4 k columns (too many for the LDS tables) of three dense fuzz scenarios (tools/fuzz_parity.py seeds
+        # 90096, 90507, 91032), dumped from the forest on the GPU: the reduced-cost fixing + LDS re-solve returned a selection worse than
+        # its own incumbent on them before the incumbent was carried through the coordinate rounds
+        gen_g10(sys.argv[2], name="g12_ilp_reduced")
     else:
         main()

@@ -161,6 +161,8 @@ struct GStore {      // HBM: column = global child index, row = global measureme
 struct EnumEnt;
 struct LStore {      // LDS: column = dense local index, row = dense local id
     double* costL; unsigned short* entL; double* uL; int32_t* usageL; int32_t* markL; int32_t* colb; int32_t* gbase;
+    int32_t* gcolL;            // [cap_h] global column of every LDS column (reduced clusters); `reduced` says whether it is in use
+    bool reduced;
     double* rcL; unsigned short* membL; unsigned long long* minkey;   // per-column reduced cost / member, per-member minimum key
     unsigned short* ordL;      // enumerate_small: column of every ranked entry
     unsigned short* enumL;     // enumerate_small: search state of the wavefronts (ENUM_LDS bytes)
@@ -175,6 +177,7 @@ struct LStore {      // LDS: column = dense local index, row = dense local id
     __device__ __forceinline__ int32_t& usage(int m) const { return usageL[m]; }
     __device__ __forceinline__ int32_t& mark(int m) const { return markL[m]; }
     __device__ __forceinline__ int to_global(int h) const {       // member k with colb[k] <= h
+        if (reduced) return gcolL[h];
         int lo = 0, hi = K;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (colb[mid] <= h) lo = mid; else hi = mid; }
         return gbase[lo] + (h - colb[lo]);
@@ -564,20 +567,29 @@ __device__ __forceinline__ void dive_order(const LStore& s, int K) {      // ran
     __syncthreads();
 }
 
+// (DINF if some member has no column left that is compatible with the earlier picks: cannot happen while every member still has
+// its conflict-free miss path, does happen in a cluster cut down to a few columns per member by reduced-cost fixing)
 template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r) {
     double total = 0.0;
+    bool ok = true;
     dive_order(s, K);
     for (int pos = 0; pos < K; ++pos) {
         const int k = dive_member(s, K, pos);
         double bv;
         int bi;
-        argmin_member(s, k, true, -DINF, -1, bv, bi, r);
+        argmin_member(s, k, true, -DINF, -1, bv, bi, r);      // (uniform result)
         if (threadIdx.x == 0) out_sel[k] = bi;
+        if (bi < 0) { ok = false; continue; }
         total += s.cost(bi);
         set_marks(s, bi, 1);
     }
-    for (int k = 0; k < K; ++k) set_marks(s, out_sel[k], 0);
-    return total;
+    __threadfence_block();
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const int h = out_sel[k];
+        if (h >= 0) set_marks(s, h, 0);
+    }
+    return ok ? total : DINF;
 }
 
 // ---- exact search for small clusters the coordinate rounds did not certify ---------------------------------------------
@@ -609,12 +621,12 @@ __device__ __forceinline__ double enum_val(unsigned long long k) {
     const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
-__device__ __forceinline__ bool enumerate_small(const GStore&, int, Red*, int&, unsigned long long*) { return false; }
+__device__ __forceinline__ bool enumerate_small(const GStore&, int, Red*, int&, unsigned long long*, double&) { return false; }
 constexpr int ENUM_W = BLP_THREADS / 64;
 constexpr size_t ENUM_LDS = 768;             // search state of the wavefronts + scalars (see the carve in enumerate_small)
 struct alignas(16) EnumEnt { double rc; unsigned long long sig; };      // reduced cost and contested-row signature of a ranked column
 template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r);
-__device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, int& nodes_out, unsigned long long* stamp) {
+__device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, int& nodes_out, unsigned long long* stamp, double& ub_known) {
     if (K > ENUM_MAXK || K < 2) return false;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nH = s.nH, nR = s.nR;
     EnumEnt* xL = s.xL;
@@ -632,7 +644,8 @@ __device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, 
     int* s_best = s_pos + ENUM_MAXK * ENUM_W;                           // [ENUM_MAXK][ENUM_W] best selection of the wavefront
     static_assert(8 + ENUM_MAXK * 8 + (ENUM_MAXK + 1 + ENUM_W) * 8 + (2 * ENUM_MAXK + 2 + ENUM_W + 2 * ENUM_MAXK * ENUM_W) * 4 <= ENUM_LDS, "enumerate_small scratch");
     // 0. a feasible point (the dive leaves the marks at zero)
-    const double ub0 = greedy_dive(s, K, s.ch, r);
+    double ub0 = greedy_dive(s, K, s.ch, r);
+    if (ub_known < ub0) ub0 = ub_known;      // (the caller's incumbent in s.ub_sel[]: it passes every test below and is found again)
     stamp[1] = wall_clock64();
     // 1. which members use a row (the usage / nomination counters are zero between iterations: borrowed, zeroed again below);
     //    reduced costs at the current prices (the last sweep's values predate the last price step)
@@ -655,7 +668,7 @@ __device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, 
     const double usum = block_sum(up, r);      // (its barriers also publish the row masks and the reduced costs)
     for (int m = tid; m < nR; m += BLP_THREADS) s.usageL[m] = (__popc(s.markL[m]) >= 2) ? atomicAdd(s_cnt, 1) : -1;
     __syncthreads();
-    bool ok = *s_cnt <= 64 && ub0 < DINF;
+    bool ok = *s_cnt <= 64;      // (a dive that ran into a dead end gives ub0 = DINF: nothing is fixed then, the search finds its own incumbent)
     stamp[2] = wall_clock64();
     auto slack = [](double ub) { return ub + 1e-9 * fmax(1.0, fabs(ub)); };
     if (ok) {
@@ -835,6 +848,7 @@ __device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, 
             int tn = 0;
             for (int q = 0; q < ENUM_W; ++q) tn += s_nodes[q];
             nodes_out = tn;
+            ub_known = s_bestc[w];
         }
     }
     for (int m = tid; m < nR; m += BLP_THREADS) { s.usageL[m] = 0; s.markL[m] = 0; }
@@ -843,10 +857,60 @@ __device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, 
     return ok;
 }
 
+// ---- giant clusters: reduced-cost fixing, then the LDS solver -----------------------------------------------------------------
+// A cluster too large for LDS (thousands of columns: dense clutter, long windows) runs its dual phase on HBM scratch, ~5 us per
+// sweep -- bearable -- but its branch and bound pays that per node, 0.2..5 s where the scan period is seconds.  Once the dual phase
+// has prices u and a feasible point UB, though, a column whose reduced cost alone lifts the root bound
+//     sum_k min_h rc_h - sum_m u_m
+// above UB cannot be part of anything better (for any selection sum cost >= sum rc - sum u), and what survives is a small
+// fraction of the columns.  If it fits the LDS tables (columns, rows, members), the cluster is rebuilt from the survivors and
+// solved there from scratch -- coordinate rounds, exact search or branch and bound at LDS speed -- which is exact: the survivors
+// contain every selection of cost <= UB, the incumbent itself included.
+constexpr int MHT_BLP_REDUCE = -2;      // solve_core(GStore): not solved, thresholds of the survivors in s.mn[], counts in s.lix[]
+__device__ __forceinline__ bool reducible(const BlpArgs&, const LStore&, int, double, Red*) { return false; }
+__device__ __forceinline__ bool reducible(const BlpArgs& a, const GStore& s, int K, double UB, Red* r) {
+    if (a.force_hbm || a.no_reduce || K > a.cap_k || a.PD > 8 || !(UB < DINF)) return false;
+    const int tid = threadIdx.x;
+    compute_minimisers(s, K, r);      // best_rc[] at the prices the dual phase ended with
+    double up = 0.0, rs = 0.0;
+    s.for_rows([&](int m) { up += s.u(m); });
+    for (int k = tid; k < K; k += BLP_THREADS) rs += s.best_rc[k];
+    const double root = block_sum(rs, r) - block_sum(up, r);
+    const double lim = UB + 1e-9 * fmax(1.0, fabs(UB));
+    int total = 0;
+    for (int k = 0; k < K; ++k) {
+        const double thr = lim - root + s.best_rc[k];
+        double c = 0.0;
+        for (int h = s.col_begin(k) + tid; h < s.col_end(k); h += BLP_THREADS) c += (reduced_cost(s, h) <= thr) ? 1.0 : 0.0;
+        const int ck = (int)block_sum(c, r);
+        if (tid == 0) { s.mn[k] = thr; s.lix[k] = ck; }
+        total += ck;
+        if (total > a.cap_h) return false;      // (uniform)
+    }
+    // distinct rows of the survivors (the marks are zero between uses)
+    for (int k = 0; k < K; ++k) {
+        const double thr = lim - root + s.best_rc[k];
+        for (int h = s.col_begin(k) + tid; h < s.col_end(k); h += BLP_THREADS)
+            if (reduced_cost(s, h) <= thr)
+                for (int d = 0; d < s.PD; ++d) { const int e = s.ent(d, h); if (e >= 0) s.mark(e) = 1; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double nr = 0.0;
+    s.for_rows([&](int m) { nr += s.mark(m) ? 1.0 : 0.0; s.mark(m) = 0; });
+    const int rows = (int)block_sum(nr, r);
+    __threadfence_block();
+    __syncthreads();
+    return rows < a.cap_r - 1;
+}
+
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
-template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp) {
+// `ub` in: cost of a feasible selection already sitting in s.ub_sel[] (DINF: none); out: cost of the selection returned there.
+template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp,
+                                                                 double& ub) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double UB = DINF, best_LB = -DINF, theta = 1.0, utot = 0.0;
+    double& UB = ub;
+    double best_LB = -DINF, theta = 1.0, utot = 0.0;
     int stall = 0;
     status = 0; iters = 0; nodes = 0;
     // dual iterations: the LDS policy does its coordinate-ascent rounds and then goes straight to the branch and bound (the
@@ -862,7 +926,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         iters = it;
         if (it == enum_at && !a.no_enum) {      // small cluster the first rounds did not certify: exact search
             const unsigned long long e0 = wall_clock64();
-            const bool solved = enumerate_small(s, K, r, nodes, stamp);
+            const bool solved = enumerate_small(s, K, r, nodes, stamp, UB);
             stamp[5] = wall_clock64() - e0;
             if (solved) { status = MHT_BLP_BRANCHED; return; }
         }
@@ -874,6 +938,9 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             __threadfence_block();
             __syncthreads();
         }
+        // a cluster on HBM scratch that has a feasible point: do few enough columns survive reduced-cost fixing at these prices to
+        // go on in LDS?  (asked a few times: every sweep over thousands of columns in HBM costs ~1 ms)
+        if ((it == 24 || it == 64 || it == 128) && UB < DINF && reducible(a, s, K, UB, r)) { status = MHT_BLP_REDUCE; return; }
         // A: per target the minimiser of the reduced cost (lowest column index wins ties)
         compute_minimisers(s, K, r);
         if (it == 0) stamp[1] = wall_clock64();
@@ -911,7 +978,16 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             slack = (ff >> 1) & 1;
             if (it == 0) stamp[3] = wall_clock64();
             if (!conflict) {        // the minimisers are a feasible selection (and optimal if no priced row is unused)
-                for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
+                bool take = true;
+                if (UB < DINF) {      // (only a cluster rebuilt from an HBM phase arrives with an incumbent: keep the better of the two)
+                    double sc = 0.0;
+                    for (int k = tid; k < K; k += BLP_THREADS) sc += s.cost(s.best_h[k]);
+                    sc = block_sum(sc, r);
+                    take = sc < UB;
+                    if (take) UB = sc;
+                }
+                if (take)
+                    for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = s.best_h[k];
                 __threadfence_block();
                 __syncthreads();
             }
@@ -1014,6 +1090,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         __threadfence_block();
         __syncthreads();
     }
+    if (reducible(a, s, K, UB, r)) { status = MHT_BLP_REDUCE; return; }      // (HBM policy only) solve_cluster rebuilds it in LDS
     int32_t* ord = reinterpret_cast<int32_t*>(s.best_rc);       // position -> member (best_rc is dead from here on)
     int32_t* bh = s.best_h;                                      // position -> minimiser column of the current node
     {   // hot-first order: minimisers and usage under the final prices
@@ -1387,6 +1464,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     s.ordL = reinterpret_cast<unsigned short*>(q); q += (size_t)L_MAXH * 2;
     s.enumL = reinterpret_cast<unsigned short*>(q); q += ENUM_LDS;
     s.xL = reinterpret_cast<EnumEnt*>(q); q += (size_t)L_MAXH * 16;
+    s.gcolL = reinterpret_cast<int32_t*>(q); q += (size_t)L_MAXH * 4;
+    s.reduced = false;
     const bool small_k = K <= L_MAXK;
     for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
     // column ranges of the members: one global round trip, then a wave scan
@@ -1483,33 +1562,109 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 }
         }
     }
-    __syncthreads();
-    if (tid < 64) {       // exclusive prefix of the popcounts: dense local row ids
-        int carry = 0;
-        for (int base = 0; base < UW; base += 64) {
-            const int w = base + tid;
-            const int pc = (w < UW) ? __popcll(uw[w]) : 0;
-            int incl = pc;
+    auto row_prefix = [&]() {      // exclusive prefix of the popcounts of the row bitset: dense local row ids
+        __syncthreads();
+        if (tid < 64) {
+            int carry = 0;
+            for (int base = 0; base < UW; base += 64) {
+                const int w = base + tid;
+                const int pc = (w < UW) ? __popcll(uw[w]) : 0;
+                int incl = pc;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (tid >= o) incl += v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (tid >= o) incl += v;
+                }
+                if (w < UW) s_wbase[w] = carry + incl - pc;
+                carry += __shfl(incl, 63);
             }
-            if (w < UW) s_wbase[w] = carry + incl - pc;
-            carry += __shfl(incl, 63);
+            if (tid == 0) s_nR = carry;
         }
-        if (tid == 0) s_nR = carry;
-    }
-    __syncthreads();
-    const int nR = s_nR;
+        __syncthreads();
+    };
+    row_prefix();
+    int nR = s_nR;
     int status, iters, nodes;
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long t_setup = wall_clock64();
-    if (lds_cols && nR < L_MAXR) {
+    bool use_lds = lds_cols && nR < L_MAXR;
+    int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
+    double ub_reduced = DINF;
+    if (!use_lds) {
+        // ---- HBM scratch: the same solver, generic column access ----------------------------------------------------
+        GStore gs;
+        gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
+        gs.best_h = a.best_h + slot; gs.best_rc = a.best_rc + slot; gs.ub_sel = a.bb_best + slot; gs.ch = a.bb_ch + slot;
+        gs.cst = a.bb_cost + slot; gs.uus = a.bb_uused + slot; gs.lrc = a.bb_last_rc + slot; gs.lix = a.bb_last_idx + slot;
+        gs.rest = a.bb_rest + slot; gs.mn = a.bb_min + slot;
+        gs.for_rows([&](int m) { a.u[m] = 0.0; });
+        __threadfence_block();
+        __syncthreads();
+        double ub = DINF;
+        solve_core(a, gs, K, r, status, iters, nodes, stamp, ub);
+        ub_reduced = ub;
+        if (status == MHT_BLP_REDUCE) {
+            // ---- reduced-cost fixing left few enough columns: rebuild the cluster from them in LDS (see reducible()) -------
+            if (tid == 0) {
+                int acc = 0;
+                for (int k = 0; k < K; ++k) { s.colb[k] = acc; acc += gs.lix[k]; }
+                s.colb[K] = acc;
+                s_nH = acc;
+            }
+            for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
+            __syncthreads();
+            nHl = s_nH;
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int k = 0; k < K; ++k) {      // survivors of member k, ascending column order
+                const double thr = gs.mn[k];
+                int run = 0;
+                for (int base = gs.col_begin(k); base < gs.col_end(k); base += BLP_THREADS) {
+                    const int h = base + tid;
+                    const bool keep = h < gs.col_end(k) && reduced_cost(gs, h) <= thr;
+                    const unsigned long long bal = __ballot(keep);
+                    if (lane == 0) r->i[wave] = __popcll(bal);
+                    __syncthreads();
+                    int off = run;
+                    for (int w = 0; w < wave; ++w) off += r->i[w];
+                    int tot = 0;
+                    for (int w = 0; w < BLP_THREADS / 64; ++w) tot += r->i[w];
+                    if (keep) {
+                        const int pos = s.colb[k] + off + __popcll(bal & ((1ull << lane) - 1ull));
+                        s.gcolL[pos] = h;
+                        if (h == gs.ub_sel[k]) s.ub_sel[k] = pos;      // the incumbent of the HBM phase survives by construction
+                        s.membL[pos] = (unsigned short)k;
+                        s.costL[pos] = a.cost[h];
+                        for (int d = 0; d < 8; ++d) {
+                            const int e = d < a.PD ? gs.ent(d, h) : -1;
+                            s.entL[pos * 8 + d] = (unsigned short)(e < 0 ? 0xffff : e);      // global node id for now
+                            if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+                        }
+                    }
+                    run += tot;
+                    __syncthreads();
+                }
+            }
+            row_prefix();
+            nR = s_nR;
+            s.reduced = true;
+            s.nH = nHl;
+            use_lds = true;
+        } else {
+            stamp[4] = wall_clock64();
+            for (int k = tid; k < K; k += BLP_THREADS) {
+                const int h = gs.ub_sel[k];
+                a.sel[mem[k]] = h;
+                if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
+                if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
+            }
+            prune_members(a, mem, K, gs.ch);
+        }
+    }
+    if (use_lds) {
         // ---- LDS-resident solve: global node ids -> dense local row ids (LDS only) --------------------------------
         s.nR = nR;
         for (int m = tid; m <= nR; m += BLP_THREADS) { s.uL[m] = 0.0; s.usageL[m] = 0; s.markL[m] = 0; }   // incl. dummy row nR
-        for (int h = tid; h < nH; h += BLP_THREADS) {       // one 16-byte record per thread: 8 independent rank look-ups
+        for (int h = tid; h < nHl; h += BLP_THREADS) {       // one 16-byte record per thread: 8 independent rank look-ups
             const Rows8 g8 = rows_of(s, h);
             unsigned o[8];
 #pragma unroll
@@ -1521,7 +1676,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             reinterpret_cast<uint4*>(s.entL)[h] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
         }
         __syncthreads();
-        solve_core(a, s, K, r, status, iters, nodes, stamp);
+        double ub = s.reduced ? ub_reduced : DINF;      // (a reduced cluster brings the HBM phase's incumbent along, see the rebuild)
+        solve_core(a, s, K, r, status, iters, nodes, stamp, ub);
         stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = s.to_global(s.ub_sel[k]);
@@ -1535,7 +1691,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 s.best_h[k] = 0x7fffffff;
             }
         }
-        if (a.t_alive) {
+        if (a.t_alive && s.reduced) {      // (the LDS store holds a subset of the children: generic sweep over the members' ranges)
+            __syncthreads();
+            prune_members(a, mem, K, s.ch);
+        } else if (a.t_alive) {
             // surviving leaf ranges: one thread per column (= child), one ancestor look-up each, LDS counters per member
             __syncthreads();
             for (int h = tid; h < nH; h += BLP_THREADS) {
@@ -1552,25 +1711,6 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 a.t_firstsurv[mem[k]] = s.best_h[k];
             }
         }
-    } else {
-        // ---- same code on HBM scratch ----------------------------------------------------------------------------
-        GStore gs;
-        gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
-        gs.best_h = a.best_h + slot; gs.best_rc = a.best_rc + slot; gs.ub_sel = a.bb_best + slot; gs.ch = a.bb_ch + slot;
-        gs.cst = a.bb_cost + slot; gs.uus = a.bb_uused + slot; gs.lrc = a.bb_last_rc + slot; gs.lix = a.bb_last_idx + slot;
-        gs.rest = a.bb_rest + slot; gs.mn = a.bb_min + slot;
-        gs.for_rows([&](int m) { a.u[m] = 0.0; });
-        __threadfence_block();
-        __syncthreads();
-        solve_core(a, gs, K, r, status, iters, nodes, stamp);
-        stamp[4] = wall_clock64();
-        for (int k = tid; k < K; k += BLP_THREADS) {
-            const int h = gs.ub_sel[k];
-            a.sel[mem[k]] = h;
-            if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
-            if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
-        }
-        prune_members(a, mem, K, gs.ch);
     }
     if (tid == 0) {
         a.cl_status[c] = status;
@@ -1593,7 +1733,7 @@ static_assert(sizeof(Red) <= RED_SLOT, "Red must fit its LDS slot");
 static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
     const size_t kpad = (size_t)cap_k + 4;
     return (size_t)cap_uw * 8 + RED_SLOT + (size_t)cap_uw * 4 + 16 + (size_t)cap_h * 16 + (size_t)cap_h * 8 * 2 + (size_t)cap_r * 8 + 7 * kpad * 8 +
-           2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16;
+           2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16 + (size_t)cap_h * 4;
 }
 
 __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx) {      // workgroup bx of gx
@@ -1718,7 +1858,7 @@ size_t blp_set_tier(BlpArgs& a, int tier) {
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
     BlpArgs b = a;
     const size_t lds = blp_set_tier(b, 0);
-    if (lds > 150 * 1024) {
+    if (lds > 158 * 1024) {
         set_error("blp: %d measurement nodes do not fit the solver's LDS tables", a.n_mnodes);
         return MHT_E_CAPACITY;
     }
@@ -1783,6 +1923,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;
     { const char* e = getenv("MHT_BLP_NO_ENUM"); a.no_enum = (e && e[0] == '1') ? 1 : 0; }
+    { const char* e = getenv("MHT_BLP_NO_REDUCE"); a.no_reduce = (e && e[0] == '1') ? 1 : 0; }
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     // one cluster holding all targets

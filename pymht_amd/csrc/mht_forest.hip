@@ -700,6 +700,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = f->status2 + (s & 1);
     b.force_hbm = f->force_hbm ? 1 : 0;
     b.no_enum = f->no_enum ? 1 : 0;
+    { static int nr = -1; if (nr < 0) { const char* e = getenv("MHT_BLP_NO_REDUCE"); nr = (e && e[0] == '1') ? 1 : 0; } b.no_reduce = nr; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
     b.apath = f->apath[s & 1]; b.R = f->R; b.kc = s % f->R;

@@ -136,6 +136,7 @@ struct BlpArgs {
     int max_iter; int node_limit;
     int force_hbm;                  // testing: run every cluster through the HBM storage policy (as oversized clusters do)
     int no_enum;                    // testing: small uncertified clusters go to the branch and bound instead of the exact search
+    int no_reduce;                  // testing: giant clusters stay on the HBM policy (no reduced-cost fixing + LDS re-solve)
     // LDS tier of the launch (blp_set_tier): capacities of the LDS-resident solve (columns, rows, targets, bitset words); clusters
     // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
     // targets; 2: default footprint, takes exactly those

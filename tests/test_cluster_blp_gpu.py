@@ -156,6 +156,21 @@ def test_blp_small_clusters_exact_search(gpu_ctx, gold_dir, monkeypatch):
         assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
 
 
+def test_blp_giant_clusters_reduced_cost_fixing(gpu_ctx, gold_dir, monkeypatch):
+    """Clusters too large for the LDS tables (G9: 29-43 targets, 3-18 k columns; G12: 26-29 targets, 2.8-4 k columns from dense fuzz
+    scenarios) run their dual phase on HBM scratch; reduced-cost fixing at its prices leaves a few dozen columns, the cluster is
+    rebuilt from them in LDS (with the HBM phase's incumbent) and solved there.  Same optimum as HiGHS, with the reduction and
+    without it (MHT_BLP_NO_REDUCE=1: branch and bound on HBM scratch)."""
+    insts = load_instances(os.path.join(gold_dir, "g12_ilp_reduced.npz")) + load_instances(os.path.join(gold_dir, "g9_ilp_giant.npz"))
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MHT_BLP_NO_REDUCE", flag)
+        for inst in insts:
+            sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst)
+            assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)), (flag, len(inst["cols"]), st, it, nd)
+            if inst["unique"]:
+                assert sel == inst["sel"].tolist(), (flag, len(inst["cols"]))
+
+
 def test_prune_seam_matches_oracle_trees():
     """Seam (iv) mht_prune against the oracle's Node.prune_depth (pyTarget.py:343-356) on random trees: new roots and the exact
     set of surviving nodes, for windows shorter, equal to and longer than the tree."""
