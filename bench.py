@@ -39,7 +39,7 @@ ETA2 = 5.99
 # HBM bytes per fgrow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
 # workload, full-size scans): profiles/r02_pmc_hbm_traffic.txt.  NOT measured by this run (the counters need the profiler): the
 # bench line says so.  Keyed by config name; None = not profiled.
-PMC_TRAFFIC_BYTES = {"cfg3": (2359 + 6979) * 1024}
+PMC_TRAFFIC_BYTES = {"cfg3": (1706 + 3625) * 1024}      # (median launch of 252; the transient scans of the first N+2 reach 2622 + 4647)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
 
 
