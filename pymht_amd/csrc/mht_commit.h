@@ -47,6 +47,7 @@ struct CommitArgs {
     int32_t* cl_counts; const int32_t* cl_status; const int32_t* cl_iters; const int32_t* multi_list;
     unsigned char* used_bytes; unsigned long long* used_words;
     ReportHeader* hdr; mht_target_report* rec;
+    const unsigned* vcount;        // value ids handed out by the covariance table of the forest (mht_vtab.h), published in hint[1]
     unsigned long long* hint;      // host-mapped word or null: {scan, targets alive after it}, so that the host can size the next grids
                                    // without fetching a report
 };
@@ -187,6 +188,7 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
         a.cnt->nTv[a.vnext] = nAlive;
         a.cnt->L = Lnext;
         if (a.hint) __hip_atomic_store(a.hint, ((unsigned long long)(unsigned)dyn.scan << 32) | (unsigned)nAlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.hint && a.vcount) __hip_atomic_store(a.hint + 1, (unsigned long long)*a.vcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // fill of the value table
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a

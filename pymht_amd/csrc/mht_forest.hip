@@ -249,7 +249,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
     }
 }
 
-struct ChainArgs { mht_nodes layers[MAXR]; VTab vt; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
+struct ChainArgs { mht_nodes layers[MAXR]; VTab vt[2]; int lgen[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
 __global__ void chain_kernel(const ChainArgs a) {
     if (threadIdx.x || blockIdx.x) return;
     int nd = a.node, sc = a.scan, n = 0;
@@ -259,7 +259,8 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.meas[n] = l.meas[nd];
         a.cnllr[n] = l.cnllr[nd];
         for (int k = 0; k < 4; ++k) a.x[n * 4 + k] = l.x[(size_t)k * l.cap + nd];
-        vt_load(a.vt, a.vt.child[l.cov[nd]], a.P + (size_t)n * 16);
+        const VTab& v = a.vt[a.lgen[sc % a.R]];      // (the generation of the value table this layer's keys belong to)
+        vt_load(v, v.child[l.cov[nd]], a.P + (size_t)n * 16);
         ++n;
         nd = l.parent[nd];
         --sc;
@@ -282,7 +283,12 @@ struct Forest {
     mht_forest_config cfg;
     mht_model model;
     int Tcap, Ncap, Mpad, R, PD, AW, n_mnodes, Ecap, SegCap;
-    VTab vt = {};                     // covariances by value, shared by all targets and scans (mht_vtab.h)
+    VTab vt = {};                     // covariances by value, shared by all targets and scans (mht_vtab.h): the CURRENT generation
+    // Value ids are never recycled within a generation.  When the table is three quarters full the live leaves are re-keyed into the
+    // other generation's (empty) table -- vt_rebuild_kernel, between two scans -- and the forest goes on there; the layers of the
+    // ring that were written before keep their keys into the old one (layer_gen), which is cleared when the ring has come round.
+    VTab vts[2] = {}; int vgen = 0; int layer_gen[MAXR] = {}; int last_rebuild_scan = -1000000; int32_t* vt_remap = nullptr;
+    int rebuilds = 0;
     Arena arena;
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
@@ -365,9 +371,14 @@ struct Forest {
         }
         cost = ar.take<double>(Ncap);
         tchild = ar.take<int32_t>((size_t)Tcap + 1); tcend = ar.take<int32_t>((size_t)Tcap + 1);
-        vt.Pv = ar.take<unsigned long long>((size_t)8 * vt.vcap); vt.pdv = ar.take<double>(vt.vcap);
-        vt.Gk = ar.take<float4>((size_t)8 * vt.vcap); vt.child = ar.take<int32_t>((size_t)2 * vt.vcap);
-        vt.slots = ar.take<unsigned long long>((size_t)vt.hmask + 1); vt.count = ar.take<unsigned>(16);
+        for (int g = 0; g < 2; ++g) {
+            VTab& v = vts[g];
+            v.vcap = vt.vcap; v.hmask = vt.hmask;
+            v.Pv = ar.take<unsigned long long>((size_t)8 * v.vcap); v.pdv = ar.take<double>(v.vcap);
+            v.Gk = ar.take<float4>((size_t)8 * v.vcap); v.child = ar.take<int32_t>((size_t)2 * v.vcap);
+            v.slots = ar.take<unsigned long long>((size_t)v.hmask + 1); v.count = ar.take<unsigned>(16);
+        }
+        vt_remap = ar.take<int32_t>((size_t)2 * vt.vcap);
         alloc = ar.take<unsigned>((size_t)FG_REGIONS * 32);
         used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
         status2 = ar.take<DevStatus>(2);
@@ -536,8 +547,11 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
         }
     }
     MHT_HIP_CHECK(hipMemsetAsync(base, 0, total, ctx->stream));
-    MHT_HIP_CHECK(hipMemsetAsync(f->vt.child, 0xff, (size_t)2 * f->vt.vcap * sizeof(int32_t), ctx->stream));      // -1: no transition known
-    f->vt.overflow = &f->cnt->overflow;
+    for (int g = 0; g < 2; ++g) {
+        MHT_HIP_CHECK(hipMemsetAsync(f->vts[g].child, 0xff, (size_t)2 * f->vt.vcap * sizeof(int32_t), ctx->stream));      // -1: no transition known
+        f->vts[g].overflow = &f->cnt->overflow;
+    }
+    f->vt = f->vts[0];
     for (int b = 0; b < 2; ++b) {
         MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->report_host2[b]), f->report_bytes, hipHostMallocDefault));
         memset(f->report_host2[b], 0, f->report_bytes);
@@ -726,13 +740,59 @@ static void fill_commit(const Forest* f, int s, CommitArgs& p) {
     p.cnt = f->cnt; p.status = f->status2 + (s & 1);
     p.cl_counts = f->cl_counts; p.cl_status = f->cl_status; p.cl_iters = f->cl_iters; p.multi_list = f->multi_list;
     p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev2[s & 1] + f->used_off);
-    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev2[s & 1]); p.hint = f->hint_dev;
+    p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev2[s & 1]); p.hint = f->hint_dev; p.vcount = f->vt.count;
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev2[s & 1] + f->rec_off);
 }
 
 // Host-side bookkeeping of a step.  begin: every check that can fail comes BEFORE the scan counter moves (a refused step must not
 // shift the ring / parity the later steps derive their buffers from); a launch failure after that kills the forest.
-struct StepPlan { int s; bool fused; int n_ub; int W; };
+// Re-keys the live leaves of the newest layer into the other generation of the value table (see Forest::vts): one thread per leaf;
+// leaves that share a key share the new one (remap[], first come first served).  The gains travel with the key (a 64-byte copy).
+struct RebuildArgs { mht_nodes layer; TTable tab; const FCounts* cnt; VTab from, to; int32_t* remap; };
+__global__ __launch_bounds__(256) void vt_rebuild_kernel(const RebuildArgs a) {
+    const int nT = a.cnt->nT, L = a.cnt->L;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+        int lo = 0, hi = nT;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
+        const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
+        const int k_old = a.layer.cov[nd];
+        int k_new = __hip_atomic_load(&a.remap[k_old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k_new < 0) {
+            float P[16];
+            vt_load(a.from, a.from.child[k_old], P);
+            const int id = vt_find_or_insert(a.to, P, a.layer.pd[nd]);
+            const unsigned pid = atomicAdd(a.to.count, 1u);      // a pseudo parent, as for a root: its miss child is the leaf's value
+            if (pid >= (unsigned)a.to.vcap) { *a.to.overflow = 1; continue; }
+            const int mine = 2 * (int)pid;
+            for (int q = 0; q < 4; ++q) a.to.Gk[(size_t)mine * 4 + q] = a.from.Gk[(size_t)k_old * 4 + q];
+            a.to.child[mine] = id;
+            int expected = -1;
+            k_new = __hip_atomic_compare_exchange_strong(&a.remap[k_old], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? mine : expected;
+        }
+        a.layer.cov[nd] = k_new;
+    }
+}
+
+struct StepPlan { int s; bool fused; int n_ub; int W; bool rebuilt; };
+// Switches the forest to the other generation of its value table in front of scan s (the newest layer is s - 1).
+static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
+    { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // (the leaf ranges of the committed table are what is re-keyed)
+    const int other = 1 - f->vgen;
+    VTab& to = f->vts[other];
+    MHT_HIP_CHECK(hipMemsetAsync(to.child, 0xff, (size_t)2 * to.vcap * sizeof(int32_t), ctx->stream));
+    MHT_HIP_CHECK(hipMemsetAsync(to.slots, 0, ((size_t)to.hmask + 1) * sizeof(unsigned long long), ctx->stream));
+    MHT_HIP_CHECK(hipMemsetAsync(to.count, 0, 16 * sizeof(unsigned), ctx->stream));
+    MHT_HIP_CHECK(hipMemsetAsync(f->vt_remap, 0xff, (size_t)2 * to.vcap * sizeof(int32_t), ctx->stream));
+    RebuildArgs a = {f->layer[(s - 1) % f->R], f->tab[s & 1], f->cnt, f->vts[f->vgen], to, f->vt_remap};
+    hipLaunchKernelGGL(vt_rebuild_kernel, dim3(256), dim3(256), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    f->vgen = other;
+    f->vt = f->vts[other];
+    f->layer_gen[(s - 1) % f->R] = other;
+    f->last_rebuild_scan = s;
+    f->rebuilds += 1;
+    return MHT_OK;
+}
 static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl) {
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "%s: M=%d exceeds max_meas=%d", who, M, f->cfg.max_meas);
     MHT_REQUIRE(z || M == 0, "%s: z is null", who);
@@ -742,6 +802,17 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     }
     if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
     const int s = ++f->scan;
+    pl.rebuilt = false;
+    if (f->hint_host) {      // value table three quarters full (as of the last commit the host has seen) and the other generation free again?
+        const unsigned long long used = reinterpret_cast<volatile unsigned long long*>(f->hint_host)[1];
+        if (used > (unsigned long long)f->vt.vcap / 4 * 3 && s - f->last_rebuild_scan > f->R + 1) {
+            const int rc = vt_switch_generation(ctx, f, s);
+            if (rc) { f->dead = true; return rc; }
+            reinterpret_cast<volatile unsigned long long*>(f->hint_host)[1] = 0;      // (until the next commit reports the new table's fill)
+            pl.rebuilt = true;
+        }
+    }
+    f->layer_gen[s % f->R] = f->vgen;
     f->births_after[s % 64] = 0; f->births_init_ub[s % 64] = 0;
     f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
     f->nT_ub_step = f->targets_ub(s);
@@ -975,6 +1046,26 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     return MHT_OK;
 }
 
+// a member switched the generation of its value table: its cached grow / commit blocks name the old one
+static int group_refresh_member(mht_group* g, int i) {
+    const int P = g->period;
+    const Forest* f = g->ctx[i]->forest;
+    FGrowArgs* hga = new FGrowArgs[(size_t)P * 2];
+    CommitArgs* hca = new CommitArgs[(size_t)P];
+    for (int v = 0; v < P; ++v) {
+        const int s = v == 0 ? P : v;
+        fill_fgrow(f, s, false, hga[(size_t)v * 2]);
+        fill_fgrow(f, s, true, hga[(size_t)v * 2 + 1]);
+        fill_commit(f, s, hca[v]);
+    }
+    hipError_t e = hipStreamSynchronize(g->ctx[0]->stream);      // (launches still reading the old blocks)
+    if (e == hipSuccess) e = hipMemcpy(g->ga + (size_t)i * P * 2, hga, sizeof(FGrowArgs) * P * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->ca + (size_t)i * P, hca, sizeof(CommitArgs) * P, hipMemcpyHostToDevice);
+    delete[] hga; delete[] hca;
+    if (e != hipSuccess) { set_error("mht_group_step: %s", hipGetErrorString(e)); return MHT_E_HIP; }
+    return MHT_OK;
+}
+
 extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t* M) {
     MHT_REQUIRE(g && z && M, "mht_group_step: null argument");
     const int n = g->n, P = g->period;
@@ -996,6 +1087,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     for (int i = 0; i < n; ++i) {
         Forest* f = g->ctx[i]->forest;
         { const int rc = forest_begin_step(g->ctx[i], f, z[i], M[i], "mht_group_step", pl[i]); if (rc) return rc; }
+        if (pl[i].rebuilt) { const int rc = group_refresh_member(g, i); if (rc) { f->dead = true; return rc; } }
         const int s = pl[i].s, v = s % P;
         FDyn& d = fb.d[i];
         d.z = z[i]; d.M = M[i]; d.W = pl[i].W;
@@ -1262,8 +1354,8 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     char* d = static_cast<char*>(f->stage_dev.ptr);
     char* h = static_cast<char*>(f->stage_host);
     ChainArgs a = {};
-    for (int k = 0; k < f->R; ++k) a.layers[k] = f->layer[k];
-    a.vt = f->vt;
+    for (int k = 0; k < f->R; ++k) { a.layers[k] = f->layer[k]; a.lgen[k] = f->layer_gen[k]; }
+    a.vt[0] = f->vts[0]; a.vt[1] = f->vts[1];
     a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
     a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
     a.P = (float*)(d + o_P); a.n_out = (int32_t*)(d + o_k);
@@ -1330,6 +1422,11 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
         offset = (size_t)strtoull(at + 1, nullptr, 10);
         name = nbuf;
     }
+    if (!strcmp(name, "vt_rebuilds")) {      // (host-side counter: generation switches of the covariance-value table so far)
+        MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'vt_rebuilds' is one int32");
+        *static_cast<int32_t*>(host) = f->rebuilds;
+        return MHT_OK;
+    }
     if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
     else if (!strcmp(name, "cl_iters")) { src = f->cl_iters; avail = T * 4; }
     else if (!strcmp(name, "cl_nodes")) { src = f->cl_nodes; avail = T * 4; }
@@ -1342,7 +1439,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
     else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 128; }                  // gains by key
     else if (!strcmp(name, "vchild")) { src = f->vt.child; avail = (size_t)f->vt.vcap * 8; }              // value id by key
-    else if (!strcmp(name, "vcount")) { src = f->vt.count; avail = 4; }                                 // value ids handed out
+    else if (!strcmp(name, "vcount")) { src = f->vt.count; avail = 4; }                                 // value ids handed out (current generation)
     else if (!strcmp(name, "cov")) { src = f->layer[f->scan % f->R].cov; avail = (size_t)f->Ncap * 4; }     // keys of the newest layer's nodes
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }

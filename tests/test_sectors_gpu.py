@@ -106,3 +106,40 @@ def test_group_raw_replay_uneven_sectors():
     grp.close()
     for t in solo + grp_t:
         t.close()
+
+
+def test_value_table_generations_single_and_batched(monkeypatch):
+    """The covariance-value table never recycles an id; three quarters full, the live leaves are re-keyed into the other generation
+    (mht_forest.hip: vt_switch_generation).  With a table of 2 048 ids a 50-target stream switches every few scans: selections, scores,
+    states and the leaves' covariances must be what a table that never fills gives -- stepped alone and as members of a group (whose
+    cached argument blocks are rewritten at every switch)."""
+    from pymht_amd import _lib
+    from pymht_amd.sectors import SectorGroup
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    n_scans = 60
+    scs = _sectors(2, n_scans, name="cfg2")
+    ref = [_tracker(sc) for sc in scs]                  # default capacity: no switch
+    monkeypatch.setenv("MHT_VTAB_CAP", "2048")
+    solo = [_tracker(sc) for sc in scs]
+    grp_t = [_tracker(sc) for sc in scs]
+    monkeypatch.delenv("MHT_VTAB_CAP")
+    grp = SectorGroup(grp_t)
+    for k in range(n_scans):
+        lists = [MeasurementList(float(sc["times"][k]), sc["scans"][k]) for sc in scs]
+        for t, sl in zip(ref + solo, lists + lists):
+            t.addMeasurementList(sl)
+        grp.addMeasurementLists(lists)
+        for q in range(2):
+            _same_state(solo[q], ref[q], "scan %d sector %d (alone)" % (k, q))
+            _same_state(grp_t[q], ref[q], "scan %d sector %d (group)" % (k, q))
+    for q in range(2):
+        la, lb, lc = ref[q].leafBatch(), solo[q].leafBatch(), grp_t[q].leafBatch()
+        for key in ("ID", "meas", "x", "cnllr", "P"):
+            assert np.array_equal(la[key], lb[key]) and np.array_equal(la[key], lc[key]), (q, key)
+    for t, least in zip(ref + solo + grp_t, [0, 0, 3, 3, 3, 3]):
+        r = np.zeros(1, np.int32)
+        _lib.check(t._lib.mht_forest_debug_read(t._ctx.handle, b"vt_rebuilds", r.ctypes.data_as(C.c_void_p), 4))
+        assert (r[0] == 0) if least == 0 else (r[0] >= least), (least, int(r[0]))
+    grp.close()
+    for t in ref + solo + grp_t:
+        t.close()
