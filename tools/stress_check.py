@@ -13,7 +13,7 @@ mode = sys.argv[1]
 if mode == 'big':
     sc = make_scenario(T=1800, radius=9500.0, lambda_phi=3.5e-7, n_scans=7, P_d=0.9, seed=77)
     N = 5
-    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=5.99, useInitiator=False, maxTargets=2048, maxNodes=1 << 17, maxMeasurements=2048)
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=5.99, useInitiator=False, maxTargets=2048, maxNodes=1 << 19, maxMeasurements=2048, deviceTiming=True)
     trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0) for x in sc["x0"]])
     o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=5.99)
     t0 = time.time()
