@@ -519,9 +519,6 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                     }
                     if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
                     s_base = b;
-                    atomicAdd(&a.status->n_children, tot);
-                    a.tchild[pos] = b < 0 ? 0 : b;
-                    a.tcend[pos] = b < 0 ? 0 : b + tot;
                 }
             } else if (wave == 1 && first_emit) {
                 // edges of the clustering graph = set bits of the association bitset (complete here: every leaf's last real
@@ -546,6 +543,15 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             }
             if (first_emit) {
                 base = s_base;
+                // the target's entries of the child tables go out behind the barrier: in front of it the barrier's release waited for
+                // the acknowledgement of these global stores (~1 us on the workgroup's critical path)
+                if (tid == 0) {
+                    const int tot = two_pass ? total : s_total;
+                    const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                    atomicAdd(&a.status->n_children, tot);
+                    a.tchild[pos] = base < 0 ? 0 : base;
+                    a.tcend[pos] = base < 0 ? 0 : base + tot;
+                }
                 if (base < 0) return;
                 if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
                     const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
