@@ -84,7 +84,7 @@ class OracleInitiatorAdapter:
                 for t in self.initiator.processMeasurements(self.make_list(time_, z))]
 
 
-def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=True):
+def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=True, prune_similar=False):
     """Run reference and oracle side by side on scenario `sc`; compare bitwise; dump a fixture."""
     T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
     ML = mods["classDefinitions"].MeasurementList
@@ -110,12 +110,13 @@ def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=Tr
               lambda_phi=sc["lambda_phi"], lambda_nu=LAMBDA_NU, N=sc["N"], eta2=5.99, times=sc["times"])
     K = len(sc["scans"]) if n_scans is None else n_scans
     fx["n_scans"] = K
+    fx["prune_similar"] = bool(prune_similar)      # addMeasurementList(..., pruneSimilar=True), threshold = the default (4 m)
     for k in range(K):
         z, t = sc["scans"][k], float(sc["times"][k])
         nT0 = len(trk.__targetList__)
         ids_before = [r.ID for r in trk.__targetList__]
-        trk.addMeasurementList(ML(t, z))
-        info = o.add_scan(t, z)
+        trk.addMeasurementList(ML(t, z), pruneSimilar=prune_similar)
+        info = o.add_scan(t, z, prune_similar=prune_similar, prune_threshold=trk.pruneThreshold)
         rb, ob = ref_leaf_batch(trk), orc_leaf_batch(o)
         for key in ("target", "ID", "x", "xf32", "P", "cnllr", "cf32", "meas"):
             assert np.array_equal(rb[key], ob[key]), "scan %d: leaf batch field %s differs" % (k, key)
@@ -354,6 +355,11 @@ def main():
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
     if "g11" in which:
         gen_g11(mods)
+    if "g13" in which:
+        # similar-state pruning (addMeasurementList(pruneSimilar=True); tracker.py:230-231, pyTarget.py:358-412) on the dense and
+        # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
+        run_trace(mods, make_config("dense", seed=1234), "g13_trace_similar", prune_similar=True)
+        run_trace(mods, make_config("cfg2", seed=5446), "g13b_trace_similar_cfg2", n_scans=10, store_leaves=False, prune_similar=True)
     if "g6b" in which:
         # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)

@@ -1,4 +1,4 @@
-"""Replay helpers for the golden scan traces (tests/golden/g2,g3,g3b)."""
+"""Replay helpers for the golden scan traces (tests/golden/g2,g3,g3b,g13)."""
 import hashlib
 import numpy as np
 
@@ -81,7 +81,7 @@ def replay_oracle(path):
     o = make_oracle(g)
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
-        info = o.add_scan(float(g["times"][k]), g[p + "z"])
+        info = o.add_scan(float(g["times"][k]), g[p + "z"], prune_similar=bool(g["prune_similar"]) if "prune_similar" in g else False)
         assert np.array_equal(info["unused"], g[p + "unused"])
         assert [info["L"], info["G"], info["M"]] == g[p + "LGM"].tolist()
         leaf = o.leaf_batch()
