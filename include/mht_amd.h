@@ -40,6 +40,7 @@ enum {
 /* node flag bits (mht_nodes.flags) -- dtype bookkeeping of the reference */
 #define MHT_F_STATE_F32 1u /* state chain is float32 (targets born from the initiator, m_of_n.py:353-358) */
 #define MHT_F_SCORE_F32 2u /* cumulativeNLLR currently holds a float32 value */
+#define MHT_F_DEAD 8u      /* forest only: taken out of the tree by similar-state pruning (never set in what mht_forest_leaves returns) */
 
 /* ILP status (mht_solve_blp / forest step) */
 #define MHT_BLP_CERTIFIED 1   /* Lagrangian certificate: conflict-free minimisers + complementary slackness */
@@ -258,6 +259,15 @@ int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out);
  * capacity = length of the host arrays; *n_out = number of leaves.  Synchronises. */
 int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
                       int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
+/* Similar-state pruning -- Tracker._pruneSimilarState (tracker.py:1233-1239) -> Target.pruneSimilarState (pyTarget.py:358-412),
+ * what addMeasurementList(..., pruneSimilar=True) asks for (tracker.py:230-231) -- for the scans stepped from now on: in every target
+ * that is alone in its cluster, the hit children of a node that lie within `threshold` metres (Tracker.pruneThreshold,
+ * tracker.py:117) of its missed-detection child are replaced, together with that child, by one measurement-less hypothesis carrying
+ * their mean state / covariance / cumulativeNLLR (NumPy's float32 / float64 arithmetic and summation order).  One extra launch
+ * per scan between clustering and the ILPs.  threshold <= 0 switches it off.  Not available for forests stepped by mht_group_step.
+ * With it on, n_leaves / n_leaves_out of the report count the slots of the surviving leaf ranges (emptied ones included);
+ * n_leaves_in and mht_forest_leaves count hypotheses. */
+int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold);
 /* Per-stage device time in milliseconds, SUMMED over the steps issued since the last call (at most 64 may be
  * pending): [0] grow kernel = the reference's toc['Process'], [1] cluster, [2] optimise (ILP + single-target selection,
  * incl. the per-target termination test / prune decision / surviving leaf ranges), [3] commit (target-table compaction,

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmht_amd.so")
-SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_gatex.hip", "mht_fgrow.hip", "mht_cluster.hip", "mht_blp.hip", "mht_prune.hip", "mht_init.hip", "mht_forest.hip"]
+SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_gatex.hip", "mht_fgrow.hip", "mht_cluster.hip", "mht_blp.hip", "mht_prune.hip", "mht_similar.hip", "mht_init.hip", "mht_forest.hip"]
 # -ffp-contract=off is REQUIRED: mht_math.h spells out every fused multiply-add of the reference's
 # BLAS evaluation order; letting the compiler contract anything else breaks bit-exact gating.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

@@ -1767,6 +1767,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
         int bi = -1;
         for (int h = cb + lane; h < ce; h += 64) {
             const double v = a.cnllr[h];
+            if (a.skip_dead && (a.flags[h] & F_DEAD)) continue;      // (fused away by similar-state pruning)
             if (bi < 0 || v <= bv) { bv = v; bi = h; }
         }
         const int va0 = a.t_alive ? sweep_prefetch(a, pre.j, cb, ce, lane) : -1;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
         }
         return;
     }
-    const int L_in = a.cur.leaf_off[nT];      // (only needed at the very end)
+    const int L_in = a.cur.leaf_off[nT] - a.status->n_dead;      // (only needed at the very end; slots minus what similar-state pruning emptied)
     if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
     int running = 0, lrun = 0;
     for (int base = 0; base < nT; base += PRUNE_THREADS) {

@@ -70,7 +70,8 @@ constexpr int FG_REGIONS = 8;     //   regions of the node index space, one chil
 struct DevStatus {
     int overflow;       // children did not fit `out`
     int n_children;     // children produced by the last gate
-    int pad[2];
+    int n_dead;         // forest: leaves the grow kernel skipped because similar-state pruning had taken them out of the tree
+    int pad[1];
 };
 
 struct Forest;

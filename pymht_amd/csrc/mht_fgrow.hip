@@ -344,10 +344,15 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             if (wave < 2) {          // (both wavefronts whole: the box reduction below runs over all their lanes)
                 const bool keep = tid < FG_CAP;
                 FLeaf g;
-                const bool valid = tid < n;
-                const int src = first + c0 + (valid ? tid : 0);
+                const bool in_chunk = tid < n;
+                const int src = first + c0 + (in_chunk ? tid : 0);
                 // batch A: everything addressed by the leaf; nothing sits behind a branch
                 const uint8_t fl = a.flags[src];
+                const bool valid = in_chunk && !(fl & F_DEAD);      // (a leaf similar-state pruning took out of the tree: no children)
+                if (pass == 1) {
+                    const unsigned long long deadm = __ballot(in_chunk && !valid);
+                    if (deadm && lane == 0) atomicAdd(&a.status->n_dead, __popcll(deadm));
+                }
                 const double cn = a.cnllr[src], pd = a.pd[src];
                 const int covc = a.cov[src];
                 double xd[4];
@@ -460,6 +465,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                     const int l = w & ((1 << sh) - 1), j = cand[w >> sh];
                     if (l >= n) continue;
                     const FLeaf& g = lg[l];
+                    if (!g.valid) continue;
                     const float mx = zx[j], my = zy[j];
                     if ((fabsf(mx - g.zhx) <= g.bx) && (fabsf(my - g.zhy) <= g.by)) {
                         bool hit;
@@ -485,7 +491,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 int h0 = 0, h1 = 0;
                 const int l1 = (lane + 64 < FG_CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
                 for (int w = 0; w < W; ++w) { h0 += __popcll(hw[(size_t)lane * W + w]); h1 += __popcll(hw[(size_t)l1 * W + w]); }
-                const int m0 = (lane < n) ? 1 + h0 : 0, m1 = (lane + 64 < n) ? 1 + h1 : 0;
+                const int m0 = (lane < n && lg[lane].valid) ? 1 + h0 : 0, m1 = (lane + 64 < n && lg[l1].valid) ? 1 + h1 : 0;
                 int i0 = m0, i1 = m1;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -502,7 +508,6 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 if (lane == 63) { s_pref[FG_CAP] = chunk_total; s_total = chunk_total; }
                 if (first_emit && lane == 0) {
                     const int tot = two_pass ? total : chunk_total;
-                    const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     // the target's block of the node index space: its slot's own static block (no atomic: nothing downstream needs a
                     // dense numbering, the index space is sized for 288 GB of HBM) or, for a target with more children than that, a
                     // piece of this XCD's region of the overflow area (one returning atomic; next region if full)

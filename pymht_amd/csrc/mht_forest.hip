@@ -106,6 +106,7 @@ static __device__ void add_targets_body(const AddArgs& a) {
             int lo = 0, hi = nT0;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
             const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
+            if (a.layer.flags[nd] & F_DEAD) continue;      // (taken out of the tree by similar-state pruning)
             const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
             for (int q = 0; q < an; ++q) {
                 const double dx = lx - a.x0[q * 4], dy = ly - a.x0[q * 4 + 1];
@@ -324,6 +325,7 @@ struct Forest {
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
+    float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     bool no_enum = false;        // testing: MHT_BLP_NO_ENUM=1 at creation: no exact search for small clusters (branch and bound instead)
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
@@ -714,6 +716,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.max_iter = f->cfg.blp_max_iter; b.node_limit = f->cfg.blp_node_limit; b.status = f->status2 + (s & 1);
     b.force_hbm = f->force_hbm ? 1 : 0;
     b.no_enum = f->no_enum ? 1 : 0;
+    b.skip_dead = f->prune_thr > 0.f ? 1 : 0;
     { static int nr = -1; if (nr < 0) { const char* e = getenv("MHT_BLP_NO_REDUCE"); nr = (e && e[0] == '1') ? 1 : 0; } b.no_reduce = nr; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
@@ -726,6 +729,20 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
+}
+
+// similar-state pruning of scan s's children (between the cluster and the ILP kernel; tracker.py:230-231)
+static void fill_similar(const Forest* f, int s, SimilarArgs& a) {
+    a = SimilarArgs{};
+    const int cb = s & 1;
+    const mht_nodes& out = f->layer[s % f->R];
+    a.single_list = f->single_list; a.counts = f->cl_counts; a.tchild = f->tchild; a.tcend = f->tcend;
+    a.x = out.x; a.cnllr = out.cnllr; a.pd = out.pd; a.meas = out.meas; a.cov = out.cov; a.flags = out.flags; a.cost = f->cost; a.cap = f->Ncap;
+    a.t_root_cnllr = f->tab[cb].root_cnllr; a.t_root_f32 = f->tab[cb].root_f32; a.Nwin = f->cfg.n_scan;
+    a.vt = f->vt;
+    fill_model_only(a.model, &f->model);
+    a.thr = f->prune_thr;
+    a.status = f->status2 + (s & 1);
 }
 
 // N-scan prune (tracker.py:256-259), target side: surviving leaf ranges -> target table / roots / report, for scan s
@@ -875,6 +892,11 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     }
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[2], st));
     // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
+    if (f->prune_thr > 0.f) {
+        SimilarArgs sa;
+        fill_similar(f, pl.s, sa);
+        MHT_STEP_CHECK(launch_prune_similar(ctx, sa, f->nT_ub_step));
+    }
     {
         BlpArgs b;
         fill_blp(f, pl.s, b);
@@ -921,6 +943,11 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
         fill_cluster(f, pl.s, c);
         c.sel_rel_reset = sel_rel;
         rc = launch_cluster(ctx, c);
+    }
+    if (!rc && f->prune_thr > 0.f) {      // (replicated, like grow and clustering: every device prunes every lone target)
+        SimilarArgs sa;
+        fill_similar(f, pl.s, sa);
+        rc = launch_prune_similar(ctx, sa, f->nT_ub_step);
     }
     if (!rc) {
         BlpArgs b;
@@ -994,6 +1021,7 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
         MHT_REQUIRE(a->Tcap == b->Tcap && a->Ncap == b->Ncap && a->Mpad == b->Mpad && a->R == b->R,
                     "mht_group_create: the members must have the same forest configuration (context %d differs)", i);
         for (int j = 0; j < i; ++j) MHT_REQUIRE(ctxs[j] != ctxs[i], "mht_group_create: context %d appears twice", i);
+        MHT_REQUIRE(!(b->prune_thr > 0.f), "mht_group_create: similar-state pruning is on for context %d (not available in grouped launches)", i);
     }
     MHT_HIP_CHECK(hipSetDevice(ctxs[0]->device));
     mht_group* g = new (std::nothrow) mht_group();
@@ -1077,6 +1105,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         MHT_REQUIRE(M[i] >= 0 && M[i] <= f->cfg.max_meas, "mht_group_step: member %d: M=%d exceeds max_meas=%d", i, M[i], f->cfg.max_meas);
         MHT_REQUIRE(z[i] || M[i] == 0, "mht_group_step: member %d: z is null", i);
         MHT_REQUIRE(!f->timing, "mht_group_step: per-stage timing is per forest (mht_forest_set_timing(ctx, 0) first)");
+        MHT_REQUIRE(!(f->prune_thr > 0.f), "mht_group_step: member %d has similar-state pruning on (not available in grouped launches)", i);
         if (f->dead) { set_error("mht_group_step: member %d is dead (a pool overflowed in an earlier scan)", i); return MHT_E_STATE; }
     }
     FBatch fb = {};
@@ -1293,6 +1322,15 @@ static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out
     return MHT_OK;
 }
 
+extern "C" int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_prune_similar: no forest");
+    MHT_REQUIRE(!(threshold != threshold), "mht_forest_set_prune_similar: threshold is NaN");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(!f->shard_open, "mht_forest_set_prune_similar: a sharded step is open");
+    f->prune_thr = threshold > 0.0 ? (float)threshold : 0.f;
+    return MHT_OK;
+}
+
 extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
                                  int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
     MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_leaves: null argument");
@@ -1323,14 +1361,32 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (x) memcpy(x, h + o_x, (size_t)n * 32);
-    if (cnllr) memcpy(cnllr, h + o_c, (size_t)n * 8);
-    if (P) memcpy(P, h + o_P, (size_t)n * 64);
-    if (meas) memcpy(meas, h + o_m, (size_t)n * 4);
-    if (target) memcpy(target, h + o_t, (size_t)n * 4);
-    if (id) memcpy(id, h + o_i, (size_t)n * 4);
-    if (node) memcpy(node, h + o_n, (size_t)n * 4);
-    if (flags) memcpy(flags, h + o_f, n);
+    // leaves that similar-state pruning took out of the tree keep their slot in the layer but are no hypotheses: squeezed out here
+    const uint8_t* hf = reinterpret_cast<const uint8_t*>(h + o_f);
+    int live = 0;
+    for (int i = 0; i < n; ++i) {
+        if (hf[i] & F_DEAD) continue;
+        if (live != i) {
+            memmove(h + o_x + (size_t)live * 32, h + o_x + (size_t)i * 32, 32);
+            memmove(h + o_c + (size_t)live * 8, h + o_c + (size_t)i * 8, 8);
+            memmove(h + o_P + (size_t)live * 64, h + o_P + (size_t)i * 64, 64);
+            memmove(h + o_m + (size_t)live * 4, h + o_m + (size_t)i * 4, 4);
+            memmove(h + o_t + (size_t)live * 4, h + o_t + (size_t)i * 4, 4);
+            memmove(h + o_i + (size_t)live * 4, h + o_i + (size_t)i * 4, 4);
+            memmove(h + o_n + (size_t)live * 4, h + o_n + (size_t)i * 4, 4);
+            h[o_f + live] = h[o_f + i];
+        }
+        ++live;
+    }
+    *n_out = c.L - (n - live);
+    if (x) memcpy(x, h + o_x, (size_t)live * 32);
+    if (cnllr) memcpy(cnllr, h + o_c, (size_t)live * 8);
+    if (P) memcpy(P, h + o_P, (size_t)live * 64);
+    if (meas) memcpy(meas, h + o_m, (size_t)live * 4);
+    if (target) memcpy(target, h + o_t, (size_t)live * 4);
+    if (id) memcpy(id, h + o_i, (size_t)live * 4);
+    if (node) memcpy(node, h + o_n, (size_t)live * 4);
+    if (flags) memcpy(flags, h + o_f, live);
     return MHT_OK;
 }
 

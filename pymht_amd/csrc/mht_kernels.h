@@ -137,6 +137,7 @@ struct BlpArgs {
     int force_hbm;                  // testing: run every cluster through the HBM storage policy (as oversized clusters do)
     int no_enum;                    // testing: small uncertified clusters go to the branch and bound instead of the exact search
     int no_reduce;                  // testing: giant clusters stay on the HBM policy (no reduced-cost fixing + LDS re-solve)
+    int skip_dead;                  // similar-state pruning ran on this scan's children: F_DEAD ones are no hypotheses any more
     // LDS tier of the launch (blp_set_tier): capacities of the LDS-resident solve (columns, rows, targets, bitset words); clusters
     // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
     // targets; 2: default footprint, takes exactly those
@@ -159,7 +160,20 @@ struct BlpArgs {
     mht_target_report* rec; int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
 };
 
+// prune_similar_kernel (mht_similar.hip): similar-state pruning of the targets that are alone in their cluster, between the
+// cluster kernel and the ILP kernel of a scan
+struct SimilarArgs {
+    const int32_t* single_list; const int32_t* counts;      // cluster kernel: targets alone in their cluster, counts[2] of them
+    const int32_t* tchild; const int32_t* tcend;            // children of target t
+    double* x; double* cnllr; const double* pd; const int32_t* meas; int32_t* cov; uint8_t* flags; double* cost; int cap;   // this scan's layer
+    const double* t_root_cnllr; const uint8_t* t_root_f32; int Nwin;
+    VTab vt; Model model;
+    float thr;                                              // Tracker.pruneThreshold (tracker.py:117), compared in float32
+    const DevStatus* status;
+};
+
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
+int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit);
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);

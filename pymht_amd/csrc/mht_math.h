@@ -249,7 +249,8 @@ MHT_HD void predict_precalc_x(const ModelX<NX>& m, const TS* x, const float* P, 
 enum : uint8_t {
     F_STATE_F32 = 1,   // state chain (x, z_hat, z_tilde, NIS, NLLR) is float32: tracks born from the initiator
     F_SCORE_F32 = 2,   // cumulativeNLLR currently holds a float32 value (all-hit path from an int-0 root)
-    F_SCORE_INT0 = 4   // cumulativeNLLR is the Python int 0 of a fresh root (weak scalar)
+    F_SCORE_INT0 = 4,  // cumulativeNLLR is the Python int 0 of a fresh root (weak scalar)
+    F_DEAD = 8         // taken out of the tree by similar-state pruning (mht_similar.hip): the slot stays, the hypothesis is gone
 };
 
 }  // namespace mht

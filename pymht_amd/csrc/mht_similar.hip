@@ -1,0 +1,151 @@
+// Similar-state pruning of the forest: Tracker._pruneSimilarState (pymht/tracker.py:1233-1239) -> Target.pruneSimilarState
+// (pymht/pyTarget.py:358-412), asked for per scan with addMeasurementList(pruneSimilar=True) (tracker.py:230-231).
+//
+// For every target that is ALONE in its cluster, and for every node that got children in this scan: the hit children whose
+// position lies within `threshold` of the missed-detection child's (= the predicted) position are taken out of the tree, and the
+// missed-detection child is REPLACED by one measurement-less node carrying their mean state, mean covariance and mean score.
+// The arithmetic is NumPy's, in NumPy's order:
+//   distance   float32: positions rounded to float32, dx*dx + dy*dy and its correctly rounded root (np.linalg.norm, axis=1)
+//   mean x, P  np.mean(axis=0): rows added one after the other in the array's dtype (float64 or float32 chain; P is float32),
+//              then ONE division by the count in that dtype
+//   mean score np.mean of a 1-D array: sequential below 8 elements, NumPy's 8-accumulator block sum from 8 on
+// In the forest the children of a leaf are contiguous (missed detection first), so a node's children are found from the
+// missed-detection child: one lane per such child walks its siblings.  Fused siblings stay where they are and get F_DEAD: the
+// next scan's grow kernel, the leaf exports and the neighbour test of initiateTarget skip them; the merged node takes the slot
+// (and the path / ancestor records) of the missed-detection child.  Its covariance is a VALUE like any other (mht_vtab.h): when
+// the mean of n identical matrices gives the matrix back (n = 1, 2, 4 always) it keeps the hit children's key, otherwise the
+// mean is found / inserted and gets a key of its own, as a root does.
+#include "mht_kernels.h"
+
+namespace mht {
+
+namespace {
+
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ double div_rn(double a, double b) { return a / b; }
+
+__device__ __forceinline__ bool is_near(const SimilarArgs& a, int g, float p0x, float p0y) {
+    const float dx = __fsub_rn((float)a.x[g], p0x), dy = __fsub_rn((float)a.x[(size_t)a.cap + g], p0y);
+    const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    return d < a.thr;
+}
+
+// np.add.reduce of a contiguous 1-D array, streamed: element i of n (pairwise_sum of NumPy's loops: n < 8 sequential; else eight
+// running sums over the blocks of eight, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 leftovers one by one.
+// Exact for n <= 128, NumPy's block size; beyond that NumPy recurses -- no radar scan puts 128 plots within 4 m of one prediction)
+template <typename T> struct Sum1D {
+    T r[8]; T res; int n, blocked;
+    __device__ __forceinline__ void begin(int n_) { n = n_; blocked = n_ - (n_ % 8); res = (T)0; }
+    __device__ __forceinline__ void add(int i, T v) {
+        if (n < 8) { res = (i == 0) ? v : res + v; return; }
+        if (i < 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == i) r[j] = v;
+        } else if (i < blocked) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == (i & 7)) r[j] = r[j] + v;
+        }
+        if (i == blocked - 1) res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (i >= blocked) res = res + v;
+    }
+};
+
+template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarArgs& a, int t, int h, int ce, int n, float p0x, float p0y) {
+    const size_t cap = a.cap;
+    TS xs[4] = {(TS)0, (TS)0, (TS)0, (TS)0};
+    float Ps[16], P1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ps[e] = 0.f;
+    int first = -1, i = 0;
+    uint8_t fl = 0;
+    bool score_f32 = false;
+    Sum1D<double> sd; Sum1D<float> sf;
+    for (int g = h + 1; g < ce && a.meas[g] > 0; ++g) {
+        if (!is_near(a, g, p0x, p0y)) continue;
+        const uint8_t fg = a.flags[g];
+        float P[16];
+        vt_load(a.vt, a.vt.child[a.cov[g]], P);
+        if (first < 0) {
+            first = g; fl = fg;
+            score_f32 = (fg & F_SCORE_F32) != 0;      // (the hit children of one node share their dtypes)
+            if (score_f32) sf.begin(n); else sd.begin(n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xs[k] = (TS)a.x[(size_t)k * cap + g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { Ps[e] = P[e]; P1[e] = P[e]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xs[k] = xs[k] + (TS)a.x[(size_t)k * cap + g];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Ps[e] = Ps[e] + P[e];
+        }
+        if (score_f32) sf.add(i, (float)a.cnllr[g]); else sd.add(i, a.cnllr[g]);
+        a.flags[g] = (uint8_t)(fg | F_DEAD);
+        ++i;
+    }
+    // the merged node, in the slot of the missed-detection child (pyTarget.py:392-412)
+    const TS cnt = (TS)n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.x[(size_t)k * cap + h] = (double)div_rn(xs[k], cnt);
+    bool same = true;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        Ps[e] = __fdiv_rn(Ps[e], (float)n);
+        same = same && (__float_as_uint(Ps[e]) == __float_as_uint(P1[e]));
+    }
+    const double cn = score_f32 ? (double)__fdiv_rn(sf.res, (float)n) : sd.res / (double)n;
+    a.cnllr[h] = cn;
+    const uint8_t mfl = (uint8_t)(fl & (F_STATE_F32 | F_SCORE_F32));
+    a.flags[h] = mfl;
+    if (same) {
+        a.cov[h] = a.cov[first];
+    } else {
+        const double pd = a.pd[h];
+        const int id0 = vt_find_or_insert(a.vt, Ps, pd);
+        const unsigned pid = atomicAdd(a.vt.count, 1u);      // a key of its own: a pseudo parent whose miss child is the mean
+        if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; return; }
+        const int key = 2 * (int)pid;
+        float4 rec[4];
+        vt_gains(a.model, Ps, pd, rec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.vt.Gk[(size_t)key * 4 + e] = rec[e];
+        a.vt.child[key] = id0;
+        a.cov[h] = key;
+    }
+    // its ILP cost, like any child's (fgrow_kernel; nothing reads it before the next scan overwrites the array, kept consistent)
+    const double rootc = a.t_root_cnllr[t];
+    if ((mfl & F_SCORE_F32) && a.t_root_f32[t]) a.cost[h] = (double)(((float)cn - (float)rootc) / (float)a.Nwin);
+    else a.cost[h] = (cn - rootc) / (double)a.Nwin;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void prune_similar_kernel(const SimilarArgs a) {
+    if (a.status && a.status->overflow) return;
+    const int nSingle = a.counts[2];
+    const int lane = threadIdx.x & 63, nw = gridDim.x * (blockDim.x >> 6);
+    for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < nSingle; i += nw) {
+        const int t = a.single_list[i];
+        const int cb = a.tchild[t], ce = a.tcend[t];
+        for (int h = cb + lane; h < ce; h += 64) {
+            if (a.meas[h] != 0) continue;              // (a node's children start with its missed-detection child)
+            const float p0x = (float)a.x[h], p0y = (float)a.x[(size_t)a.cap + h];
+            int n = 0;
+            for (int g = h + 1; g < ce && a.meas[g] > 0; ++g) n += is_near(a, g, p0x, p0y) ? 1 : 0;
+            if (n == 0) continue;
+            if (a.flags[h] & F_STATE_F32) fuse_group<float>(a, t, h, ce, n, p0x, p0y);
+            else fuse_group<double>(a, t, h, ce, n, p0x, p0y);
+        }
+    }
+}
+
+int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub) {
+    int grid = (n_targets_ub + 3) / 4;
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(prune_similar_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
+}  // namespace mht

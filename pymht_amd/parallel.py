@@ -92,13 +92,15 @@ class ClusterShardedTracker:
         self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist))
         self.sel_rel = torch.full((tracker._cfg.max_targets,), -1, dtype=torch.int32, device=tracker._ctx.device)
 
-    def begin(self, scanList):
-        """Grow, cluster and this rank's share of the ILPs (asynchronous)."""
+    def begin(self, scanList, **kwargs):
+        """Grow, cluster and this rank's share of the ILPs (asynchronous).  `pruneSimilar=True` (tracker.py:230): similar-state
+        pruning of the lone targets, replicated on every rank like grow and clustering."""
         from . import _lib
         trk = self.trk
         trk._drain()
         self._tic = {'Total': __import__('time').time()}
-        self._z = trk._accept_scan(scanList, None, {})
+        self._z = trk._accept_scan(scanList, None, kwargs)
+        trk._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))
         zd = trk._upload_scan(self._z)
         self.sel_rel.fill_(-1)      # (the device resets the live targets' entries itself; this also clears slots of targets long gone)
         _lib.check(trk._lib.mht_forest_step_sharded_begin(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,
@@ -112,7 +114,7 @@ class ClusterShardedTracker:
         _lib.check(trk._lib.mht_forest_step_sharded_end(trk._ctx.handle, self.sel_rel.data_ptr()))
         trk._after_step(self._scan, self._z, None, self._tic)
 
-    def addMeasurementList(self, scanList):
-        self.begin(scanList)
+    def addMeasurementList(self, scanList, **kwargs):
+        self.begin(scanList, **kwargs)
         self.exchange(self.sel_rel)
         self.end()

@@ -4,9 +4,9 @@ Same constructor, `preInitialize`, `initiateTarget`, `addMeasurementList(scanLis
 `getTrackNodes`, `getRuntimeAverage`, `runtimeLog`/`toc` keys and double-underscore attributes as the reference
 (pymht/tracker.py:39-307).  Steps 1-6 of a scan (grow, cluster, optimise, terminate, N-scan
 prune) run as three HIP launches (+ one for the report) on the device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h);
-the host sees one report per scan.  Step 7 (M-of-N initiation, off the hot path) stays on the host.
+the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
 
-Not supported (raise): AIS fusion (`aisList` non-empty; tracker.py:417-552), `dynamicWindow`, `pruneSimilar`.
+Not supported (raise): AIS fusion (`aisList` non-empty; tracker.py:417-552), `dynamicWindow`.
 There is no CPU fallback: without the HIP library or without a GPU the constructor raises.
 """
 import ctypes as C
@@ -91,7 +91,7 @@ class Tracker():
         self.scoreUpperLimit = -np.log(1 - self.default_P_d) * 0.8
         self.clnnrUpperLimit = 3.0
         self.pruneThreshold = kwargs.get("pruneThreshold", 4)
-        assert not self.pruneSimilar, "pruneSimilar is not supported by pymht_amd"
+        self._prune_similar_on = False      # (what the device forest is currently set to; decided per scan like the reference does)
         # MI355X side
         self.useInitiator = kwargs.get('useInitiator', True)
         self._ctx = Context(kwargs.get('device', 0))
@@ -187,6 +187,7 @@ class Tracker():
         overlaps its own bookkeeping with the device's work."""
         tic = {'Total': time.time()}
         z = self._accept_scan(scanList, aisList, kwargs)
+        self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
         try:
@@ -198,6 +199,11 @@ class Tracker():
                 self._dead = True
             raise
         self._queue_report(scanList, z, aisList, tic)
+
+    def _set_prune_similar(self, want):
+        if want != self._prune_similar_on:
+            _lib.check(self._lib.mht_forest_set_prune_similar(self._ctx.handle, float(self.pruneThreshold) if want else 0.0))
+            self._prune_similar_on = want
 
     def _after_step(self, scanList, z, aisList, tic=None):
         """Behind the device step: step 7 on the device, then the report starts its way to the host."""
@@ -250,6 +256,8 @@ class Tracker():
 
     def _stage_scan(self, scanList, aisList=None, **kwargs):
         """SectorGroup: checks + the scan in device memory (a torch tensor kept alive until the next scan)."""
+        if kwargs.get('pruneSimilar', False):
+            raise NotImplementedError("pruneSimilar is not available for the batched launches of a SectorGroup")
         z = self._accept_scan(scanList, aisList, kwargs)
         self._upload_scan(z)
         return self._staged[:z.shape[0]] if z.size else self._staged[:0]

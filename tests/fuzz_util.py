@@ -17,15 +17,20 @@ def scenario_of(seed):
     return sc, N, eta2, desc
 
 
-def run_case(seed, max_leaves=2000, budget_s=15.0):
-    """Returns (ok, description, message)."""
+def run_case(seed, max_leaves=2000, budget_s=15.0, similar=False):
+    """Returns (ok, description, message).  similar=True: similar-state pruning (addMeasurementList(pruneSimilar=True)) switched on
+    and off at random from scan to scan, with a random pruneThreshold."""
     from test_tracker_gpu import make_tracker, tracker_selected, states_close, SCORE_ATOL
     from trace_util import make_oracle
     from pymht_amd.utils.classDefinitions import MeasurementList
     sc, N, eta2, desc = scenario_of(seed)
     g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, x0=sc["x0"], t0=sc["t0"], accepted=None)
     t0 = time.time()
-    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], N, eta2, sc["x0"], sc["t0"])
+    prng = np.random.default_rng(seed + 77)
+    thr = float(prng.choice([4.0, 6.0, 12.0])) if similar else 4
+    if similar:
+        desc += ' similar thr=%.0f' % thr
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], N, eta2, sc["x0"], sc["t0"], pruneThreshold=thr)
     try:
         g["accepted"] = acc
         o = make_oracle(g)
@@ -34,8 +39,9 @@ def run_case(seed, max_leaves=2000, budget_s=15.0):
             if time.time() - t0 > budget_s or (k > 0 and st["L"] > max_leaves):
                 msg = 'stopped after scan %d (the oracle gets slow beyond this size)' % k
                 break
-            info = o.add_scan(float(t), z)
-            trk.addMeasurementList(MeasurementList(float(t), z))
+            on = bool(similar and prng.uniform() < 0.75)
+            info = o.add_scan(float(t), z, prune_similar=on, prune_threshold=thr)
+            trk.addMeasurementList(MeasurementList(float(t), z), pruneSimilar=on)
             st = trk.lastScanStats
             os_, ts = o.selected(), tracker_selected(trk)
             lb, tb = o.leaf_batch(), trk.leafBatch()
@@ -43,7 +49,8 @@ def run_case(seed, max_leaves=2000, budget_s=15.0):
                       [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__],
                       np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
                       states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
-                      len(o.clusters) == len(trk.__clusterList__), np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]),
+                      len(o.clusters) == len(trk.__clusterList__),
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"]),
                       o.n_ilp == trk.nOptimSolved]
             if not all(checks):
                 return False, desc, 'MISMATCH at scan %d: gating %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))

@@ -18,3 +18,16 @@ def test_fuzz_slice_against_oracle():
         if not ok:
             bad.append(desc + ' ' + msg)
     assert not bad, "\n".join(bad)
+
+
+def test_fuzz_slice_with_similar_state_pruning():
+    """The same with similar-state pruning (tracker.py:230-231) switched on and off at random from scan to scan."""
+    from fuzz_util import run_case
+    n = int(os.environ.get("MHT_FUZZ_CASES", "200")) // 2
+    seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000")) + 500000
+    bad = []
+    for case in range(n):
+        ok, desc, msg = run_case(seed0 + case, max_leaves=1200, budget_s=6.0, similar=True)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+    assert not bad, "\n".join(bad)

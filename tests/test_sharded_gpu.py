@@ -31,8 +31,8 @@ def _same(a, b, what):
         assert a.lastScanStats[k] == b.lastScanStats[k], (what, k)
 
 
-@pytest.mark.parametrize("name,n_scans,shards", [("cfg3", 8, 2), ("dense", 10, 3)])
-def test_cluster_sharded_equals_single_device(name, n_scans, shards):
+@pytest.mark.parametrize("name,n_scans,shards,similar", [("cfg3", 8, 2, False), ("dense", 10, 3, False), ("cfg2", 9, 2, True)])
+def test_cluster_sharded_equals_single_device(name, n_scans, shards, similar):
     import torch
     from pymht_amd.parallel import ClusterShardedTracker
     from pymht_amd.utils.classDefinitions import MeasurementList
@@ -43,9 +43,9 @@ def test_cluster_sharded_equals_single_device(name, n_scans, shards):
     n_ilp = 0
     for k in range(n_scans):
         sl = MeasurementList(float(sc["times"][k]), sc["scans"][k])
-        solo.addMeasurementList(sl)
+        solo.addMeasurementList(sl, pruneSimilar=similar)      # (similar-state pruning is replicated on every shard)
         for p in parts:
-            p.begin(sl)
+            p.begin(sl, pruneSimilar=similar)
         # what the all-reduce(MAX) over RCCL does between the ranks
         merged = torch.stack([p.sel_rel for p in parts]).max(dim=0).values
         solved = torch.stack([(p.sel_rel >= 0).int() for p in parts]).sum(dim=0)

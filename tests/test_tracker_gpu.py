@@ -47,7 +47,8 @@ def tracker_selected(trk):
                 meas=np.array([0 if n.measurementNumber is None else n.measurementNumber for n in nodes], dtype=np.int64))      # (None: a merged new target, m_of_n.py:150)
 
 
-@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long"])
+@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long",
+                                  "g13_trace_similar", "g13b_trace_similar_cfg2"])
 def test_tracker_replays_reference_trace(name, gold_dir):
     from pymht_amd.utils.classDefinitions import MeasurementList
     g = np.load(os.path.join(gold_dir, name + ".npz"))
@@ -57,7 +58,8 @@ def test_tracker_replays_reference_trace(name, gold_dir):
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
         ids_before = [r.ID for r in trk.__targetList__]
-        trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]))
+        # (g13*: recorded with addMeasurementList(pruneSimilar=True), tracker.py:230-231)
+        trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), pruneSimilar=bool(g["prune_similar"]) if "prune_similar" in g else False)
         st = trk.lastScanStats
         assert [st["L"], st["G"], st["M"]] == g[p + "LGM"].tolist(), "scan %d L/G/M" % k      # gating: exact counts
         assert np.array_equal(st["unused"], g[p + "unused"]), "scan %d unused measurements" % k
@@ -116,6 +118,52 @@ def test_tracker_vs_oracle_fresh_scenario(N, P_d, period, eta2, lam, seed):
         h = n_o.history_meas()
         chain = [m.measurementNumber for m in n_t.backtrackNodes()]
         assert h[-len(chain):] == [0 if c is None else int(c) for c in chain][-len(h):] or h[-3:] == chain[-3:]
+    trk.close()
+
+
+@pytest.mark.parametrize("N,P_d,thr,lam,seed,T,radius", [
+    (5, 0.9, 4, 3e-5, 21, 40, 500.0),
+    (3, 0.8, 7.5, 6e-5, 22, 40, 400.0),       # wider merge radius, more clutter: several hits fused into one node
+    (2, 0.95, 15.0, 1e-3, 23, 25, 250.0),     # dense clutter and a radius as wide as the gate: means over up to 6 hits (new covariance values)
+])
+def test_tracker_vs_oracle_similar_state_pruning(N, P_d, thr, lam, seed, T, radius):
+    """Similar-state pruning (tracker.py:230-231, pyTarget.py:358-412) switched on and off from scan to scan, oracle and device
+    forest side by side: leaves (fused ones gone, merged ones in the missed-detection slot), selections, clusters, births."""
+    from pymht_amd.utils.scenario import make_scenario
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = make_scenario(T=T, radius=radius, lambda_phi=lam, n_scans=16, P_d=P_d, seed=seed)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=5.99,
+             x0=sc["x0"], t0=sc["t0"], accepted=None)
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], N, 5.99, sc["x0"], sc["t0"], pruneThreshold=thr)
+    g["accepted"] = acc
+    o = make_oracle(g)
+    n_merged = n_multi = 0
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        on = (k % 5) != 3
+        before = sum(len(r.leaves()) for r in o.targets)
+        info = o.add_scan(float(t), z, prune_similar=on, prune_threshold=thr)
+        trk.addMeasurementList(MeasurementList(float(t), z), pruneSimilar=on)
+        st = trk.lastScanStats
+        assert (st["L"], st["G"]) == (info["L"], info["G"]), k
+        assert before == info["L"]
+        assert np.array_equal(st["unused"], info["unused"]), k
+        assert [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__], k
+        os_, ts = o.selected(), tracker_selected(trk)
+        assert np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]), k
+        assert states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL), k
+        assert len(o.clusters) == len(trk.__clusterList__)
+        lb, tb = o.leaf_batch(), trk.leafBatch()
+        assert np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]), k
+        assert states_close(lb["x"], tb["x"]), k
+        assert np.allclose(lb["cnllr"], tb["cnllr"], rtol=0, atol=SCORE_ATOL), k
+        assert np.allclose(lb["P"], tb["P"], rtol=2e-6, atol=1e-6), k
+        assert not np.any(tb["flags"] & 8)
+        # merged nodes: measurement-less leaves that do not sit at their parent's prediction
+        n_merged += sum(1 for r in o.targets for l in r.leaves()
+                        if l.meas == 0 and l.parent is not None and l.parent.kids[0] is l
+                        and not np.allclose(np.asarray(l.x, dtype=np.float64), o.A @ np.asarray(l.parent.x, dtype=np.float64), rtol=0, atol=1e-4))
+        n_multi += sum(1 for c in o.clusters if len(c) > 1)
+    assert n_merged > 0 and n_multi > 0
     trk.close()
 
 
