@@ -190,8 +190,34 @@ struct LStore {      // LDS: column = dense local index, row = dense local id
 // ---- column operations, generic (HBM policy) and specialised (LDS policy: one 16-byte record per column holds its
 //      <= 8 rows as dense ids, "no row" = the dummy row nR whose price / mark / usage are never non-zero, so all
 //      eight look-ups are unconditional and independent: two LDS round trips instead of 2*PD dependent ones) ----------
+// The rows of a column with at most 8 path levels, fetched as ONE batch of independent loads (a forest record is two 16-byte
+// pieces; the stateless layout is a strided gather), so that the prices / marks behind them are a second batch: two dependent
+// round trips per column instead of 2 * PD -- a sweep over the 18 k columns of a giant cluster is nothing but these look-ups.
+#ifndef MHT_ROWS8
+#define MHT_ROWS8 1
+#endif
+__device__ __forceinline__ void rows8(const GStore& s, int h, int (&e)[8]) {
+    if (s.a->pds == 8) {
+        const int4* p = reinterpret_cast<const int4*>(s.a->path + (size_t)h * 8);
+        const int4 q0 = p[0], q1 = p[1];
+        e[0] = q0.x; e[1] = q0.y; e[2] = q0.z; e[3] = q0.w; e[4] = q1.x; e[5] = q1.y; e[6] = q1.z; e[7] = q1.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) e[d] = (d < s.PD) ? s.ent(d, h) : -1;
+    }
+}
 __device__ __forceinline__ double reduced_cost(const GStore& s, int h) {
     double rc = s.cost(h);
+    if (s.PD <= 8 && MHT_ROWS8) {
+        int e[8];
+        rows8(s, h, e);
+        double uv[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) uv[d] = s.u(e[d] >= 0 ? e[d] : 0);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) rc = (e[d] >= 0) ? rc + uv[d] : rc;      // (same order of additions as the loop below)
+        return rc;
+    }
     for (int d = 0; d < s.PD; ++d) {
         const int e = s.ent(d, h);
         if (e >= 0) rc += s.u(e);
@@ -199,6 +225,14 @@ __device__ __forceinline__ double reduced_cost(const GStore& s, int h) {
     return rc;
 }
 __device__ __forceinline__ bool compatible(const GStore& s, int h) {
+    if (s.PD <= 8 && MHT_ROWS8) {
+        int e[8];
+        rows8(s, h, e);
+        int bad = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) bad |= (e[d] >= 0) ? s.mark(e[d] >= 0 ? e[d] : 0) : 0;
+        return bad == 0;
+    }
     for (int d = 0; d < s.PD; ++d) {
         const int e = s.ent(d, h);
         if (e >= 0 && s.mark(e)) return false;
@@ -1603,6 +1637,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         double ub = DINF;
         solve_core(a, gs, K, r, status, iters, nodes, stamp, ub);
         ub_reduced = ub;
+#ifdef MHT_BLP_TRACE
+        if (tid == 0) printf("[blp] cluster %d K=%d nH=%d: HBM phase status %d iters %d nodes %d, %.2f ms (setup %.2f)\n", c, K, nH, status, iters, nodes,
+                             1e-5 * (double)(wall_clock64() - t_begin), 1e-5 * (double)(t_setup - t_begin));
+#endif
         if (status == MHT_BLP_REDUCE) {
             // ---- reduced-cost fixing left few enough columns: rebuild the cluster from them in LDS (see reducible()) -------
             if (tid == 0) {
@@ -1677,7 +1715,13 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         }
         __syncthreads();
         double ub = s.reduced ? ub_reduced : DINF;      // (a reduced cluster brings the HBM phase's incumbent along, see the rebuild)
+#ifdef MHT_BLP_TRACE
+        if (tid == 0 && s.reduced) printf("[blp] cluster %d: rebuilt with %d columns %d rows at %.2f ms\n", c, nHl, nR, 1e-5 * (double)(wall_clock64() - t_begin));
+#endif
         solve_core(a, s, K, r, status, iters, nodes, stamp, ub);
+#ifdef MHT_BLP_TRACE
+        if (tid == 0 && s.reduced) printf("[blp] cluster %d: LDS phase status %d iters %d nodes %d at %.2f ms\n", c, status, iters, nodes, 1e-5 * (double)(wall_clock64() - t_begin));
+#endif
         stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = s.to_global(s.ub_sel[k]);

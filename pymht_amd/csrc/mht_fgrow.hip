@@ -622,6 +622,23 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     FG_STAMP(7);
 }
 
+// The PREVIOUS scan's report rides to the host in this launch (drop-in API path): FG_PUB_WGS extra workgroups copy it from its device
+// block into pinned, device-mapped host memory (16-byte posted PCIe writes, ~70 KB at the headline size) while the others grow the
+// tree -- in the kernel that completed the report the copy sat on the critical path of every scan (~10 us).  The host waits for an
+// event recorded behind this launch.
+constexpr int FG_PUB_WGS = 8;
+__device__ __forceinline__ void publish_part(const PublishArgs& p, int w) {
+    const ReportHeader* h = reinterpret_cast<const ReportHeader*>(p.src);
+    const int n_births = h->n_births, nT = h->n_targets;
+    const uint4* s4 = reinterpret_cast<const uint4*>(p.src);
+    uint4* d4 = reinterpret_cast<uint4*>(p.dst);
+    const int head = (p.birth_off + n_births * (int)sizeof(mht_birth_report) + 15) / 16;      // header + mask + births present
+    const int r0 = p.rec_off / 16, rn = (nT * (int)sizeof(mht_target_report) + 15) / 16;
+    const int i0 = w * FG_THREADS + threadIdx.x, st = FG_PUB_WGS * FG_THREADS;
+    for (int i = i0; i < head; i += st) d4[i] = s4[i];
+    for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
+}
+
 template <int PQ, typename CARGS>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
@@ -635,8 +652,10 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
 template <int PQ>
-__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d) {
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_grow = d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
+    if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
     fgrow_body<PQ>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
@@ -685,12 +704,15 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused) {
     d.n_main = n_main;
 }
 
-int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit) {
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
     fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
     const size_t lds = fgrow_lds_bytes(d.W, a.pds, a.AW);
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
-    if (a.pds == 8) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
-    else hipLaunchKernelGGL(fgrow_kernel<4>, dim3(fgrow_grid(d)), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d);
+    const bool pub = publish && publish->dst;
+    const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
+    const PublishArgs pa = pub ? *publish : PublishArgs{};
+    if (a.pds == 8) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d, pa);
+    else hipLaunchKernelGGL(fgrow_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d, pa);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

@@ -39,7 +39,6 @@ struct LayerView { const double* x; const double* cnllr; const int32_t* parent; 
 // mask, birth records and the target rows from the device block into pinned, device-mapped host memory with 16-byte stores
 // (posted PCIe writes: ~70 KB at the headline size).  A copy engine / blit kernel on the stream costs more than the copy: the
 // host issues two more calls per scan and the stream idles ~10 us in front of every engine switch.
-struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; };      // dst = null: no host block (report fetched by memcpy)
 template <int NT> __device__ __forceinline__ void publish_report(const PublishArgs& p) {
     if (!p.dst) return;
     __threadfence();
@@ -311,6 +310,9 @@ struct Forest {
     // pushes it into pinned host memory (publish_report)
     char* report_host_dev[2] = {nullptr, nullptr}; float* z_host_dev = nullptr;      // device addresses of the pinned host blocks
     int published_scan = 0;      // scan whose report the device has been told to write into report_host2[scan & 1]
+    // streaming API path (mht_forest_scan with an initiator): the report of a scan is pushed to the host by extra workgroups of the
+    // NEXT scan's grow launch (fgrow_kernel: publish_part), or by publish_kernel if the host asks for it before there is one
+    bool pub_deferred = false; PublishArgs pub_args = {}; int pub_slot = 0;
     const float* z_cur = nullptr;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
@@ -453,6 +455,18 @@ static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
     hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending, f->pending_dyn);
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
+    return MHT_OK;
+}
+
+__global__ __launch_bounds__(1024) void publish_kernel(const PublishArgs pub) { publish_report<1024>(pub); }
+// the deferred report push (Forest::pub_deferred) now, as a launch of its own
+static int flush_publish(mht_ctx* ctx, Forest* f) {
+    if (!f->pub_deferred) return MHT_OK;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pub_args);
+    MHT_HIP_CHECK(hipGetLastError());
+    MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->pub_slot], ctx->stream));
+    f->rep_started[f->pub_slot] = true;
+    f->pub_deferred = false;
     return MHT_OK;
 }
 
@@ -880,7 +894,12 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
         d.dbg = f->debug ? f->grow_dbg : nullptr;
-        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr));
+        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr));
+        if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
+            MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st));
+            f->rep_started[f->pub_slot] = true;
+            f->pub_deferred = false;
+        }
     }
     f->commit_pending = false;
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
@@ -927,6 +946,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     MHT_REQUIRE(!f->timing, "mht_forest_step_sharded_begin: per-stage timing is not available for sharded steps");
     MHT_REQUIRE(!f->shard_open, "mht_forest_step_sharded_begin: the previous sharded step has not been ended");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     StepPlan pl;
     { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) return rc; }
     int rc;
@@ -1108,6 +1128,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         MHT_REQUIRE(!(f->prune_thr > 0.f), "mht_group_step: member %d has similar-state pruning on (not available in grouped launches)", i);
         if (f->dead) { set_error("mht_group_step: member %d is dead (a pool overflowed in an earlier scan)", i); return MHT_E_STATE; }
     }
+    for (int i = 0; i < n; ++i) { const int rc = flush_publish(g->ctx[i], g->ctx[i]->forest); if (rc) return rc; }
     FBatch fb = {};
     PBatch cb = {}, bb = {}, bb2 = {}, bb0 = {};
     StepPlan pl[GROUP_MAX];
@@ -1163,7 +1184,7 @@ void initiator_born_ptrs(const mht_initiator* in, const double** x, const float*
                          const int32_t** n, int* cap, mht_ctx** ctx);
 }
 
-extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now) {
+static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now, bool defer_publish) {
     MHT_REQUIRE(ctx && ctx->forest && in, "mht_forest_initiate: null argument");
     Forest* f = ctx->forest;
     MHT_REQUIRE(f->scan > 0, "mht_forest_initiate: no scan processed yet");
@@ -1190,7 +1211,11 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     a.hdr = reinterpret_cast<ReportHeader*>(report_dev);
     a.births = reinterpret_cast<mht_birth_report*>(report_dev + f->birth_off);
     // commit (if it is still pending: the used-measurement mask of the scan is part of it) + initiator + admission: one launch
-    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, publish_args(f));
+    { const int rc = flush_publish(ctx, f); if (rc) return rc; }      // (an older report still waiting for a ride: its device block is about to be reused)
+    // the report goes to the host from this launch, or -- streaming: mht_forest_scan -- with the next scan's grow launch
+    PublishArgs pub = publish_args(f);
+    if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
+    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub);
     f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
@@ -1201,6 +1226,10 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     f->births_init_ub[f->scan % 64] = cap;
     f->report_pending = true;      // (the births block of the report changed)
     return MHT_OK;
+}
+
+extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now) {
+    return forest_initiate_impl(ctx, in, z, M, now, false);
 }
 
 static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mark_done) {
@@ -1237,8 +1266,19 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
 extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
     int rc = step_host_impl(ctx, z_host, M, false);
     if (rc) return rc;
-    if (in) { rc = mht_forest_initiate(ctx, in, nullptr, M, now); if (rc) return rc; }
-    return mht_forest_report_begin(ctx);
+    if (!in) return mht_forest_report_begin(ctx);
+    rc = forest_initiate_impl(ctx, in, nullptr, M, now, true);
+    if (rc) return rc;
+    // the report is complete in its device block; its push to the host rides in the next scan's grow launch (or in a launch of its
+    // own as soon as somebody asks for it: report_expose)
+    Forest* f = ctx->forest;
+    f->rep_slot = f->scan & 1;
+    f->pub_slot = f->rep_slot;
+    f->pub_deferred = true;
+    f->rep_started[f->rep_slot] = false;
+    f->report_pending = false;
+    f->rep_inflight = true;
+    return MHT_OK;
 }
 
 // Starts the transfer of the last scan's report (commit first, if it is still pending) into one of two pinned host buffers and
@@ -1250,6 +1290,7 @@ extern "C" int mht_forest_report_begin(mht_ctx* ctx) {
     MHT_REQUIRE(f->scan > 0, "mht_forest_report_begin: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     if (!f->report_pending) return MHT_OK;
+    { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     { const int rc = flush_commit(ctx, f, true); if (rc) return rc; }
     f->rep_slot = f->scan & 1;      // host block = device block = scan parity
     if (f->published_scan != f->scan) {      // the commit ran without a host block (inside a grow launch): fetch the device block
@@ -1284,6 +1325,7 @@ extern "C" int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_repor
 }
 
 static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out) {
+    if (f->pub_deferred && slot == f->pub_slot) { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     if (f->rep_started[slot]) {
         MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));
         f->rep_started[slot] = false;

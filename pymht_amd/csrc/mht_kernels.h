@@ -73,6 +73,8 @@ struct FDyn {
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
 };
+// The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.
+struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; };      // dst = null: no host block (report fetched by memcpy)
 constexpr int GROUP_MAX = 32;      // sectors per batched launch
 struct FBatch { const FGrowArgs* ga[GROUP_MAX]; const CommitArgs* ca[GROUP_MAX]; FDyn d[GROUP_MAX]; };
 struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM) per sector
@@ -174,7 +176,7 @@ struct SimilarArgs {
 
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
-int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit);
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr);
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);
 int fgrow_grid_of(const FDyn& d);
