@@ -47,6 +47,54 @@ def p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def pmc_traffic_live(config, timeout_s=180.0):
+    """HBM bytes per steady-state fgrow_kernel launch from the PMC counters, measured NOW: two rocprofv3 passes (FETCH_SIZE, then
+    WRITE_SIZE -- they do not fit one pass, and --pmc is not combined with any tracing) over a short replay of this same command
+    on this GPU, as MI355X_MICROARCH.md prescribes.  Counter values are KiB per dispatch (calibrated on this kernel's access
+    pattern in round 1: profiles/r01_pmc_hbm_traffic.txt); the figure is the mean over the last quarter of the launches (the
+    replay's steady-state scans).  Returns (bytes or None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tot, t0 = 0.0, time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mht_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config", config,
+                   "--cpu-scans", "0", "--sectors", "0", "--steps", "40", "--warmup", "8", "--pmc", "off"]
+            left = timeout_s - (time.time() - t0)
+            if left < 20:
+                return None, "time budget of the counter passes used up"
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=left)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            c = sqlite3.connect(dbs[0])
+            tabs = [q[0] for q in c.execute("select name from sqlite_master where type='table'")]
+            t = lambda pre: next(x for x in tabs if x.startswith(pre))
+            pmc, disp, sym = t("rocpd_pmc_event"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
+            vals = [v for (v,) in c.execute(
+                'select p.value from "%s" d join "%s" p on p.event_id = d.event_id join "%s" s on s.id = d.kernel_id '
+                "where s.kernel_name like '%%fgrow_kernel%%' order by d.start" % (disp, pmc, sym))]
+            c.close()
+            if len(vals) < 16:
+                return None, "only %d fgrow_kernel launches in the %s pass" % (len(vals), counter)
+            tail = vals[-(len(vals) // 4):]
+            tot += 1024.0 * sum(tail) / len(tail)
+        except Exception as e:      # (a bench line without the counters is still a bench line)
+            return None, "counter pass failed: %s" % repr(e)[:120]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return tot, "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a 64-scan replay of the same stream on this GPU, " \
+                "KiB per fgrow_kernel dispatch, mean of the last quarter of the launches (steady state)"
+
+
 def make_tracker(sc, device, **kw):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
@@ -212,6 +260,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank tracks its own sector (BASELINE config 4); strong: ALL ranks track the same sector, "
                          "its independent clusters' ILPs spread over the ranks (one all-reduce of the selections per scan)")
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
+                    help="auto: roofline.traffic is measured by two rocprofv3 counter passes over a short replay (rank 0, one GPU; ~40 s); "
+                         "off: the figure of profiles/ is quoted and labelled as not measured by this run")
     args = ap.parse_args()
 
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
@@ -372,6 +423,14 @@ def main():
     # algorithmic bytes of the grow stage per scan: 280 B per leaf + 48 B per gated pair + 8 B per measurement
     b_gate = 280.0 * Lm + 48.0 * Gm + 8.0 * Mm
     gate_gbs = b_gate / (ms[0] * 1e-3) / 1e9
+    traffic, traffic_src = PMC_TRAFFIC_BYTES.get(args.config), \
+        "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)"
+    if args.pmc == "auto" and rank == 0 and world == 1:
+        live, note = pmc_traffic_live(args.config)
+        if live is not None:
+            traffic, traffic_src = live, note
+        else:
+            traffic_src += "; live counter passes unavailable (%s)" % note
     out = {
         "metric": "scans/sec at ~5k+ leaf hypotheses x 500 measurements (per-scan gate + cluster + ILP + N-scan prune)",
         "value": (1 if strong else world) * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -392,8 +451,7 @@ def main():
                     "read after the last scan): PCIe copy of every scan, steps 1-7 on the device (M-of-N initiator included), "
                     "report D2H + host mirror per scan; same scans as `value` (pre-roll and warm-up untimed)",
         "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gate_gbs / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(args.config),
-                     "traffic_source": "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)",
+                     "frac": gate_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fgrow_kernel (gate + update + score + child creation + next scan's gains, 1 launch), HIP events on the ctx stream",
                      "algorithmic_bytes": b_gate},
     }

@@ -1,6 +1,7 @@
 """GPU: seams (ii) clustering and (iii) the 0-1 ILP through the C ABI, against the oracle and the recorded instances."""
 import ctypes as C
 import os
+import time
 import numpy as np
 import pytest
 import torch
@@ -67,8 +68,11 @@ def gpu_blp(ctx, inst, max_iter=200, node_limit=1 << 20):
     cs = torch.from_numpy(np.asarray(cost, dtype=np.float64)).to(dev)
     sel = torch.zeros(nT, dtype=torch.int32, device=dev)
     obj, st, it, nd = C.c_double(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     _lib.check(ctx.lib.mht_solve_blp(ctx.handle, nH, nT, nrows, depth, gp.data_ptr(), rw.data_ptr(), cs.data_ptr(),
                                      max_iter, node_limit, sel.data_ptr(), C.byref(obj), C.byref(st), C.byref(it), C.byref(nd)))
+    gpu_blp.last_call_s = time.perf_counter() - t0      # (the call synchronises: device time + launch, without the Python packing above)
     return sorted(sel.cpu().numpy().tolist()), obj.value, st.value, it.value, nd.value
 
 
