@@ -63,6 +63,8 @@ constexpr int MAXPD = 15;         // longest root->leaf path kept per hypothesis
 #define MHT_FG_CAP 96
 #endif
 constexpr int FG_THREADS = MHT_FG_THREADS;   // fgrow_kernel: one workgroup per target
+constexpr int FG_CAP_SOLO = 128;          //   ... in the one-sector launch: every scan in nine of the headline stream has a target with 97..128 leaves, and a
+                                          //   second pass over it sets the duration of the whole launch (32 instead of 20 us); 45 KB of LDS, three workgroups per CU
 constexpr int FG_CAP = MHT_FG_CAP;        //   leaves of a target handled per pass, one per lane of two wavefronts (more: chunks, two passes)
 constexpr int FG_REGIONS = 8;     //   regions of the node index space, one child counter each (one per XCD)
 

@@ -264,7 +264,7 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
 // PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
 // a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
 // edge of its budget (128 for four workgroups per CU in the batched launch).
-template <int PQ>
+template <int PQ, int CAP>
 __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem) {
     constexpr int PDS = PQ * 4;
     const auto& a = *ap0;
@@ -273,13 +273,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     // LDS carve (every block a multiple of 16 bytes)
     float* zx = reinterpret_cast<float*>(smem);
     float* zy = zx + Mpad;
-    FLeaf* lg = reinterpret_cast<FLeaf*>(zy + Mpad);                                        // [FG_CAP]
-    int* s_pp = reinterpret_cast<int*>(lg + FG_CAP);                                        // [FG_CAP][pds] path records of the leaves
-    int* s_ap = s_pp + PDS * FG_CAP;                                                        // [FG_CAP][pds] ancestor records
-    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + PDS * FG_CAP);    // [FG_CAP][W] hit masks
-    unsigned long long* tb = hw + (size_t)FG_CAP * W;                                       // [AW] association bitset of the target
-    int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [FG_CAP + 1]
-    int* s_misc = s_pref + FG_CAP + 4;                                                      // [32]
+    FLeaf* lg = reinterpret_cast<FLeaf*>(zy + Mpad);                                        // [CAP]
+    int* s_pp = reinterpret_cast<int*>(lg + CAP);                                        // [CAP][pds] path records of the leaves
+    int* s_ap = s_pp + PDS * CAP;                                                        // [CAP][pds] ancestor records
+    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + PDS * CAP);    // [CAP][W] hit masks
+    unsigned long long* tb = hw + (size_t)CAP * W;                                       // [AW] association bitset of the target
+    int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [CAP + 1]
+    int* s_misc = s_pref + CAP + 4;                                                      // [32]
     unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
     unsigned char* s_map = reinterpret_cast<unsigned char*>(cand + Mpad);                   // [FG_MAP] leaf of the chunk's r-th child
     int& s_ncand = s_misc[0];
@@ -321,13 +321,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     const int curw = a.cur_slot_base >> 6;      // first word of this scan's measurement nodes in the association bitset
 
     // ---- the target's children: count, take a block of the node index space, emit -------------------------------------------
-    // A chunk = FG_CAP leaves, one per lane of wavefronts 0 and 1.  A target with more leaves runs the chunk loop twice: pass 0
+    // A chunk = CAP leaves, one per lane of wavefronts 0 and 1.  A target with more leaves runs the chunk loop twice: pass 0
     // only counts, pass 1 emits.
-    const bool two_pass = cnt > FG_CAP;
+    const bool two_pass = cnt > CAP;
     int total = 0, run = 0, base = 0;
     for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
-        for (int c0 = 0; c0 < cnt; c0 += FG_CAP) {
-            // (the loops exist for targets with more than FG_CAP leaves only.  The argument block is re-read through an opaque
+        for (int c0 = 0; c0 < cnt; c0 += CAP) {
+            // (the loops exist for targets with more than CAP leaves only.  The argument block is re-read through an opaque
             // pointer in every iteration: otherwise every address and every uniform predicate of the unrolled body is
             // hoisted in front of the loops and held in registers across them -- +100 VGPRs, ~400 spilled SGPRs)
             int depth = __builtin_amdgcn_readfirstlane(depth0), shift = __builtin_amdgcn_readfirstlane(shift0);
@@ -335,14 +335,14 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             KArgs ap = ap0;
             asm volatile("" : "+s"(ap));
             const auto& a = *ap;
-            const int n = (cnt - c0 < FG_CAP) ? cnt - c0 : FG_CAP;
+            const int n = (cnt - c0 < CAP) ? cnt - c0 : CAP;
             const bool first_emit = (pass == 1 && c0 == 0);
             // ---- phase 1: predict, one leaf per lane of wavefronts 0 and 1; the gains come from the table -----------------------
-            for (int w = tid; w < FG_CAP * W; w += FG_THREADS) hw[w] = 0ull;
+            for (int w = tid; w < CAP * W; w += FG_THREADS) hw[w] = 0ull;
             if (tid == 0) s_ncand = 0;
             int last = -1;
             if (wave < 2) {          // (both wavefronts whole: the box reduction below runs over all their lanes)
-                const bool keep = tid < FG_CAP;
+                const bool keep = tid < CAP;
                 FLeaf g;
                 const bool in_chunk = tid < n;
                 const int src = first + c0 + (in_chunk ? tid : 0);
@@ -489,7 +489,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             //      target's block of the node index space and its slice of the edge list: wavefront 0 / wavefront 1
             if (wave == 0) {
                 int h0 = 0, h1 = 0;
-                const int l1 = (lane + 64 < FG_CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
+                const int l1 = (lane + 64 < CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
                 for (int w = 0; w < W; ++w) { h0 += __popcll(hw[(size_t)lane * W + w]); h1 += __popcll(hw[(size_t)l1 * W + w]); }
                 const int m0 = (lane < n && lg[lane].valid) ? 1 + h0 : 0, m1 = (lane + 64 < n && lg[l1].valid) ? 1 + h1 : 0;
                 int i0 = m0, i1 = m1;
@@ -501,11 +501,11 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 const int t0 = __shfl(i0, 63);
                 i1 += t0;
                 s_pref[lane] = i0 - m0;
-                if (lane + 64 < FG_CAP) s_pref[64 + lane] = i1 - m1;
+                if (lane + 64 < CAP) s_pref[64 + lane] = i1 - m1;
                 for (int q = 0, p = i0 - m0; q < m0 && p < FG_MAP; ++q, ++p) s_map[p] = (unsigned char)lane;          // child -> leaf
                 for (int q = 0, p = i1 - m1; q < m1 && p < FG_MAP; ++q, ++p) s_map[p] = (unsigned char)(lane + 64);
                 const int chunk_total = __shfl(i1, 63);
-                if (lane == 63) { s_pref[FG_CAP] = chunk_total; s_total = chunk_total; }
+                if (lane == 63) { s_pref[CAP] = chunk_total; s_total = chunk_total; }
                 if (first_emit && lane == 0) {
                     const int tot = two_pass ? total : chunk_total;
                     // the target's block of the node index space: its slot's own static block (no atomic: nothing downstream needs a
@@ -587,13 +587,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             FG_STAMP(6);
             // ---- phase 4: one thread per child; children of the chunk at base + run .. ------------------------------------------------
             {
-                const int ctot = s_pref[FG_CAP];
+                const int ctot = s_pref[CAP];
                 for (int r = tid; r < ctot; r += FG_THREADS) {
                     int l;
                     if (r < FG_MAP) {
                         l = s_map[r];                        // child -> leaf table written with the counts
                     } else {                                 // (more children than the table holds: search the prefix)
-                        int lo = 0, hi = FG_CAP;
+                        int lo = 0, hi = CAP;
                         while (hi - lo > 1) {
                             const int mid = (lo + hi) >> 1;
                             if (s_pref[mid] <= r) lo = mid; else hi = mid;
@@ -616,7 +616,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 }
                 run += ctot;
             }
-            if (c0 + FG_CAP < cnt) __syncthreads();      // the chunk tables are re-used
+            if (c0 + CAP < cnt) __syncthreads();      // the chunk tables are re-used
         }
     }
     FG_STAMP(7);
@@ -639,7 +639,7 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w) {
     for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
 }
 
-template <int PQ, typename CARGS>
+template <int PQ, int CAP, typename CARGS>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
@@ -647,7 +647,7 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         bid -= 1;
     }
     if (bid >= d.n_main) { chain_part(*ap, d, bid - d.n_main); return; }
-    target_part<PQ>(ap, d, bid, smem);
+    target_part<PQ, CAP>(ap, d, bid, smem);
 }
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_grow = d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
-    fgrow_body<PQ>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+    fgrow_body<PQ, FG_CAP_SOLO>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
@@ -668,15 +668,17 @@ __global__ __launch_bounds__(FG_THREADS, 4) void fgrow_batch_kernel(const FBatch
     const int y = blockIdx.y;
     const FDyn d = b.d[y];
     if ((int)blockIdx.x >= d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS) return;
-    fgrow_body<PQ>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
+    fgrow_body<PQ, FG_CAP>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
 }
 
-size_t fgrow_lds_bytes(int W, int pds, int AW) {
-    size_t b = (size_t)2 * W * 64 * 4 + (size_t)FG_CAP * sizeof(FLeaf) + (size_t)2 * pds * FG_CAP * 4 + (size_t)FG_CAP * W * 8 + (size_t)AW * 8 +
-               (size_t)(FG_CAP + 4) * 4 + 128 + (size_t)W * 64 * 2 + FG_MAP;
+static size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap) {
+    size_t b = (size_t)2 * W * 64 * 4 + (size_t)cap * sizeof(FLeaf) + (size_t)2 * pds * cap * 4 + (size_t)cap * W * 8 + (size_t)AW * 8 +
+               (size_t)(cap + 4) * 4 + 128 + (size_t)W * 64 * 2 + FG_MAP;
     if (b < 256) b = 256;      // the commit workgroup keeps its scan partials here
     return (b + 15) & ~(size_t)15;
 }
+
+size_t fgrow_lds_bytes(int W, int pds, int AW) { return fgrow_lds_bytes_cap(W, pds, AW, FG_CAP); }      // (the batched launch)
 
 static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
     if (lds > 150 * 1024) {
@@ -706,7 +708,7 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused) {
 
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
     fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
-    const size_t lds = fgrow_lds_bytes(d.W, a.pds, a.AW);
+    const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP_SOLO);
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
     const bool pub = publish && publish->dst;
     const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
