@@ -268,6 +268,12 @@ int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, doubl
  * With it on, n_leaves / n_leaves_out of the report count the slots of the surviving leaf ranges (emptied ones included);
  * n_leaves_in and mht_forest_leaves count hypotheses. */
 int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold);
+/* Real-time guard for the global-hypothesis ILPs (_solveBLP_OR_TOOLS, tracker.py:1124-1217, has none: a giant cluster without
+ * a dual certificate keeps CBC -- and this library's branch and bound -- busy for as long as it takes): a cluster whose
+ * branch and bound has run for `milliseconds` of wall-clock time stops like one that reached blp_node_limit -- the best feasible
+ * selection found so far is used, the scan's report counts it in n_limit and the report call returns MHT_E_LIMIT.  0 = no limit
+ * (default).  For forests stepped by mht_group_step: set it before mht_group_create. */
+int mht_forest_set_blp_time_limit(mht_ctx* ctx, double milliseconds);
 /* Per-stage device time in milliseconds, SUMMED over the steps issued since the last call (at most 64 may be
  * pending): [0] grow kernel = the reference's toc['Process'], [1] cluster, [2] optimise (ILP + single-target selection,
  * incl. the per-target termination test / prune decision / surviving leaf ranges), [3] commit (target-table compaction,

@@ -1180,6 +1180,12 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         const double eps = 1e-12 * fmax(1.0, fabs(UB));
         if (enter) {
             if (++nodes > a.node_limit) { status = MHT_BLP_NODE_LIMIT; break; }
+            // wall-clock budget of the cluster (mht_forest_set_blp_time_limit): looked at every 64 nodes, decided by the whole
+            // workgroup (the threads read the clock at slightly different times)
+            if (a.time_limit > 0 && (nodes & 63) == 0 && block_or(wall_clock64() - stamp[0] > (unsigned long long)a.time_limit ? 1 : 0, r)) {
+                status = MHT_BLP_NODE_LIMIT;
+                break;
+            }
             if (level == K) {
                 if (s.cst[K] < UB - eps) {
                     UB = s.cst[K];
@@ -1619,7 +1625,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     row_prefix();
     int nR = s_nR;
     int status, iters, nodes;
-    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp[6] = {t_begin, 0, 0, 0, 0, 0};      // [0]: start of the cluster (the time limit counts from here)
     const unsigned long long t_setup = wall_clock64();
     bool use_lds = lds_cols && nR < L_MAXR;
     int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
@@ -1970,6 +1976,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     { const char* e = getenv("MHT_BLP_NO_ENUM"); a.no_enum = (e && e[0] == '1') ? 1 : 0; }
     { const char* e = getenv("MHT_BLP_NO_REDUCE"); a.no_reduce = (e && e[0] == '1') ? 1 : 0; }
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
+    { const char* e = getenv("MHT_BLP_TIME_LIMIT_US"); a.time_limit = e ? atoll(e) * 100 : 0; }      // testing: wall-clock budget per cluster (10 ns ticks)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     // one cluster holding all targets
     int32_t* hbuf = new int32_t[nT + 8];

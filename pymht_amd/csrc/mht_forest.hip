@@ -327,6 +327,7 @@ struct Forest {
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
+    long long blp_time_limit = 0;   // wall-clock budget per ILP in 10 ns ticks, 0 = none (mht_forest_set_blp_time_limit)
     float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     bool no_enum = false;        // testing: MHT_BLP_NO_ENUM=1 at creation: no exact search for small clusters (branch and bound instead)
@@ -731,6 +732,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.force_hbm = f->force_hbm ? 1 : 0;
     b.no_enum = f->no_enum ? 1 : 0;
     b.skip_dead = f->prune_thr > 0.f ? 1 : 0;
+    b.time_limit = f->blp_time_limit;
     { static int nr = -1; if (nr < 0) { const char* e = getenv("MHT_BLP_NO_REDUCE"); nr = (e && e[0] == '1') ? 1 : 0; } b.no_reduce = nr; }
     b.x = out.x; b.flags = out.flags; b.t_root_cnllr = f->tab[cb].root_cnllr; b.t_root_f32 = f->tab[cb].root_f32;
     b.t_depth = f->tab[cb].depth; b.t_window = f->tab[cb].window;
@@ -1361,6 +1363,13 @@ static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out
         set_error("forest: %d ILP(s) hit the branch-and-bound node limit in scan %d", h->n_limit, h->scan);
         return MHT_E_LIMIT;
     }
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_set_blp_time_limit(mht_ctx* ctx, double milliseconds) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_blp_time_limit: no forest");
+    MHT_REQUIRE(!(milliseconds != milliseconds), "mht_forest_set_blp_time_limit: NaN");
+    ctx->forest->blp_time_limit = milliseconds > 0.0 ? (long long)(milliseconds * 1e5) : 0;
     return MHT_OK;
 }
 

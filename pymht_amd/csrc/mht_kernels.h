@@ -136,6 +136,8 @@ struct BlpArgs {
     int32_t* cl_status; int32_t* cl_iters; int32_t* cl_nodes;   // [T] per cluster (indexed by cluster id)
     int32_t* cl_time;               // [T][2] or null: wall-clock ticks (10 ns) spent in setup / in total, per cluster
     int max_iter; int node_limit;
+    long long time_limit;           // wall-clock budget of a cluster's branch and bound in 10 ns ticks (0 = none): like the node limit, the best
+                                    // feasible selection found so far is returned with MHT_BLP_NODE_LIMIT
     int force_hbm;                  // testing: run every cluster through the HBM storage policy (as oversized clusters do)
     int no_enum;                    // testing: small uncertified clusters go to the branch and bound instead of the exact search
     int no_reduce;                  // testing: giant clusters stay on the HBM policy (no reduced-cost fixing + LDS re-solve)

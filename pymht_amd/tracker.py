@@ -104,6 +104,7 @@ class Tracker():
         cfg.n_scan = int(N)
         cfg.blp_max_iter = int(kwargs.get('blpMaxIter', 200))
         cfg.blp_node_limit = int(kwargs.get('blpNodeLimit', 1 << 20))
+        self._blp_time_limit = kwargs.get('blpTimeLimit', None)      # seconds of branch and bound per cluster (None: exact, however long)
         cfg.score_limit = float(self.scoreUpperLimit)
         cfg.cnllr_limit = float(self.clnnrUpperLimit)
         cfg.radar_x, cfg.radar_y = float(self.position[0]), float(self.position[1])
@@ -111,6 +112,8 @@ class Tracker():
         cfg.merge_threshold = float(self.mergeThreshold)
         self._cfg = cfg
         _lib.check(self._lib.mht_forest_create(self._ctx.handle, C.byref(self._model), C.byref(cfg)))
+        if self._blp_time_limit is not None:
+            _lib.check(self._lib.mht_forest_set_blp_time_limit(self._ctx.handle, 1e3 * float(self._blp_time_limit)))
         # Target initiator (tracker.py:61-72): on the device, behind every scan's commit (mht_forest_initiate)
         self.initiator = m_of_n.Initiator(self.M_required, self.N_checks, self.maxSpeedMS, self.C, self.R_RADAR, self.mergeThreshold,
                                           ctx=self._ctx, maxMeasurements=cfg.max_meas, default_pd=self.default_P_d) \

@@ -143,6 +143,42 @@ def test_blp_clusters_without_certificate(gpu_ctx, gold_dir):
         assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
 
 
+def test_blp_time_limit_returns_a_feasible_selection(gpu_ctx, gold_dir, monkeypatch):
+    """The wall-clock budget of a cluster's branch and bound (mht_forest_set_blp_time_limit; MHT_BLP_TIME_LIMIT_US for the stateless
+    seam): the 43-target G9 cluster needs ~2 700 nodes / 150 ms for the proof; with 20 ms it comes back in time with MHT_E_LIMIT and
+    a conflict-free selection within 3 % of the optimum (the incumbent of the dual phase and the first dives)."""
+    inst = load_instances(os.path.join(gold_dir, "g9_ilp_giant.npz"))[2]
+    monkeypatch.setenv("MHT_BLP_TIME_LIMIT_US", "20000")
+    cols, sizes, cost = inst["cols"], inst["sizes"], inst["cost"]
+    nH, nT = len(cols), len(sizes)
+    depth = max(len(c) for c in cols)
+    nrows = 1 + max(int(c.max()) for c in cols if len(c))
+    rows = -np.ones((depth, nH), dtype=np.int32)
+    for h, c in enumerate(cols):
+        rows[:len(c), h] = c
+    dev = gpu_ctx.device
+    gp = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(dev)
+    rw, cs = torch.from_numpy(rows).to(dev), torch.from_numpy(np.asarray(cost, dtype=np.float64)).to(dev)
+    sel = torch.zeros(nT, dtype=torch.int32, device=dev)
+    obj, st, it, nd = C.c_double(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = gpu_ctx.lib.mht_solve_blp(gpu_ctx.handle, nH, nT, nrows, depth, gp.data_ptr(), rw.data_ptr(), cs.data_ptr(), 200, 1 << 20, sel.data_ptr(),
+                                   C.byref(obj), C.byref(st), C.byref(it), C.byref(nd))
+    dt = time.perf_counter() - t0
+    assert rc == _lib.MHT_E_LIMIT and st.value == 3, (rc, st.value)
+    assert dt < 0.06, dt
+    chosen = sel.cpu().numpy().tolist()
+    used = set()
+    for t, h in enumerate(chosen):
+        assert gp[t].item() <= h < gp[t + 1].item()
+        for m in cols[h]:
+            assert int(m) not in used
+            used.add(int(m))
+    true_obj = float(sum(cost[h] for h in chosen))
+    assert abs(true_obj - obj.value) < 1e-9 and inst["obj"] - 1e-9 <= true_obj <= inst["obj"] + 0.03 * abs(inst["obj"])
+
+
 def test_blp_small_clusters_exact_search(gpu_ctx, gold_dir, monkeypatch):
     """tests/golden/g10_ilp_small_hard.npz: 3..9 near-duplicate tracks with a duality gap, the slowest ILPs of four headline
     streams (the coordinate rounds do not certify them).  The exact search over contested-row signatures (enumerate_small) must
