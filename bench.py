@@ -386,7 +386,13 @@ def main():
                 rps.append(Replay(scs[q], brs[q], local))
         grps = [SectorGroup([r.trk for r in rps[gi::NG]]) for gi in range(NG)]
 
+        solo = os.environ.get("MHT_BENCH_SOLO") == "1"      # development: every sector stepped on its own (needs MHT_BENCH_GROUPS = sectors)
+
         def group_step():
+            if solo:
+                for r in rps:
+                    r.step()
+                return
             k = rps[0].k
             for gi in range(NG):
                 mem = rps[gi::NG]
