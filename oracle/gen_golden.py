@@ -355,6 +355,8 @@ def main():
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
     if "g11" in which:
         gen_g11(mods)
+    if "g14" in which:
+        gen_g14(mods)
     if "g13" in which:
         # similar-state pruning (addMeasurementList(pruneSimilar=True); tracker.py:230-231, pyTarget.py:358-412) on the dense and
         # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
@@ -363,6 +365,32 @@ def main():
     if "g6b" in which:
         # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
+
+
+def gen_g14(mods):
+    """XML result export (tracker.py:1469-1545, pyTarget.py:804-829): the reference's own <Tracker-settings> block and the <Track>
+    elements of `_storeRun(preInitialized=False)` after the dense stream (terminated tracks included).  The fixture holds the
+    serialised elements (expected OUTPUT; run times are not compared: they are wall-clock)."""
+    import xml.etree.ElementTree as ET
+    T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
+    ML = mods["classDefinitions"].MeasurementList
+    sc = make_config("dense", seed=1234)
+    trk = T.Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=5.99)
+    for x in sc["x0"]:
+        trk.initiateTarget(Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized"))
+    for z, t in zip(sc["scans"], sc["times"]):
+        trk.addMeasurementList(ML(float(t), z))
+    scen = trk.getScenarioElement()
+    trk._storeTrackerArgs(scen, name="dense", seed_of_stream=1234)
+    trk._storeRun(scen, preInitialized=False, seed=7)
+    run = scen.find("Run")
+    fx = dict(scenario_attrib=np.array(sorted("%s=%s" % kv for kv in scen.attrib.items())),
+              settings=np.array(ET.tostring(scen.find("Tracker-settings"), encoding="unicode")),
+              run_attrib=np.array(sorted("%s=%s" % kv for kv in run.attrib.items())),
+              runtime_stages=np.array([e.tag for e in run.find("Runtime")]),
+              tracks=np.array([ET.tostring(e, encoding="unicode") for e in run.findall("Track")]))
+    np.savez_compressed(os.path.join(GOLD, "g14_xml_export.npz"), **fx)
+    print("  g14_xml_export: %d tracks (%d terminated)" % (len(fx["tracks"]), sum("terminated" in t for t in fx["tracks"])))
 
 
 def gen_g11(mods):

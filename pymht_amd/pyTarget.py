@@ -6,13 +6,16 @@ the hypothesis forest itself lives in HBM (structure-of-arrays layers, see DESIG
 objects are what the host hands in (`Tracker.initiateTarget`) and what it gets back as *views* of
 device nodes (`Tracker.getTrackNodes()`, `Tracker.__targetList__`): plain Python objects whose
 `parent` / `trackHypotheses` links are materialised lazily from a snapshot of the device layers.
-Plotting, XML export and pykalman smoothing of the reference class are out of scope.
+The XML result export (`_storeNode`, `_storeNodeSparse`) is here; plotting and pykalman smoothing of the reference class are out of scope.
 """
 import copy
 import datetime
 import numpy as np
 
-from .utils.xmlDefinitions import activeTag
+import xml.etree.ElementTree as ET
+
+from .utils.xmlDefinitions import (activeTag, eastTag, idTag, inverseResidualCovarianceTag, lengthTag, mmsiTag, northTag, positionTag,
+                                   smoothedstatesTag, statesTag, stateTag, timeTag, trackTag, velocityTag)
 
 
 class Position:
@@ -183,6 +186,65 @@ class Target:
             chain.append(node)
             node = node.parent
         return chain[::-1]
+
+    # ---- XML result export (pyTarget.py:127-132, :297-302, :745-829): one <Track> per selected hypothesis -------------------------
+    def getXmlStateStrings(self, precision=2):
+        return tuple(str(round(self.x_0[i], precision)) for i in range(4))
+
+    def _getHistoricalMmsi(self):
+        node = self
+        while node is not None:
+            if getattr(node, "mmsi", None) is not None:
+                return node.mmsi
+            node = node.parent
+        return None
+
+    def _track_element(self, parent_element, attributes):
+        """<Track id=.. [mmsi=..] ..> with an empty <States> child; returns (track, states)."""
+        track = ET.SubElement(parent_element, trackTag)
+        states = ET.SubElement(track, statesTag)
+        mmsi = self._getHistoricalMmsi()
+        if mmsi is not None:
+            track.attrib[mmsiTag] = str(mmsi)
+        track.attrib[idTag] = str(self.ID)
+        for key, value in attributes.items():
+            track.attrib[str(key)] = str(value)
+        return track, states
+
+    @staticmethod
+    def _state_element(states, node):
+        """<S t=..><P><N/><E/></P><V><N/><E/></V></S> for one node of the chain (north before east, as the reference writes it)."""
+        east_p, north_p, east_v, north_v = node.getXmlStateStrings()
+        el = ET.SubElement(states, stateTag, attrib={timeTag: str(node.time)})
+        for tag, north, east in ((positionTag, north_p, east_p), (velocityTag, north_v, east_v)):
+            pair = ET.SubElement(el, tag)
+            ET.SubElement(pair, northTag).text = north
+            ET.SubElement(pair, eastTag).text = east
+        if node.status != activeTag:
+            el.attrib[stateTag] = node.status
+        return el
+
+    def _storeNode(self, simulationElement, radarPeriod, **kwargs):
+        """Every node of the chain root-of-time .. self (pyTarget.py:745-802).  The reference also writes a pykalman-smoothed copy
+        (`getSmoothTrack`); smoothing is outside this package: the <SmoothedStates> element is there and empty, which is what the
+        reference writes when its smoother reports failure."""
+        track, states = self._track_element(simulationElement, kwargs)
+        chain = self.backtrackNodes()
+        track.attrib[lengthTag] = str(len(chain))
+        ET.SubElement(track, smoothedstatesTag)
+        for node in chain:
+            el = self._state_element(states, node)
+            if getattr(node, "S_inv", None) is not None:
+                ET.SubElement(el, inverseResidualCovarianceTag).text = np.array_str(node.S_inv, max_line_width=9999)
+        return track
+
+    def _storeNodeSparse(self, simulationElement, **kwargs):
+        """First and last node of the chain only (pyTarget.py:804-829)."""
+        track, states = self._track_element(simulationElement, kwargs)
+        chain = self.backtrackNodes()
+        for node in ([chain[0], chain[-1]] if len(chain) > 1 else [chain[0]]):
+            self._state_element(states, node)
+        return track
 
     def backtrackPosition(self, stepsBack=float("inf")):
         return [n.x_0[0:2] for n in self.backtrackNodes()]

@@ -6,6 +6,7 @@ Same constructor, `preInitialize`, `initiateTarget`, `addMeasurementList(scanLis
 prune) run as three HIP launches (+ one for the report) on the device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h);
 the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
 
+XML result export: `getScenarioElement` / `_storeTrackerArgs` / `_storeRun` (tracker.py:1469-1545).
 Not supported (raise): AIS fusion (`aisList` non-empty; tracker.py:417-552), `dynamicWindow`.
 There is no CPU fallback: without the HIP library or without a GPU the constructor raises.
 """
@@ -20,6 +21,7 @@ from .device import Context, make_model
 from .initiators import m_of_n
 from .pyTarget import Target
 from .utils.classDefinitions import AisMessageList, MeasurementList  # noqa: F401
+from .utils import xmlDefinitions as xmltags
 from .utils.xmlDefinitions import activeTag, outofrangeTag, preinitializedTag, toolowscoreTag
 
 log = logging.getLogger(__name__)
@@ -91,6 +93,7 @@ class Tracker():
         self.scoreUpperLimit = -np.log(1 - self.default_P_d) * 0.8
         self.clnnrUpperLimit = 3.0
         self.pruneThreshold = kwargs.get("pruneThreshold", 4)
+        self.targetSizeLimit = 3000      # (tracker.py:118: only used by the reference's dynamic window; kept for the XML settings block)
         self._prune_similar_on = False      # (what the device forest is currently set to; decided per scan like the reference does)
         # MI355X side
         self.useInitiator = kwargs.get('useInitiator', True)
@@ -620,6 +623,49 @@ class Tracker():
         """Wait for everything queued on the device and fold it (reports are folded lazily otherwise)."""
         self._drain()
         self._ctx.synchronize()
+
+    # ---- XML result export (tracker.py:1469-1545): what the reference's evaluation scripts read ----------------------------------
+    def getScenarioElement(self, **kwargs):
+        import xml.etree.ElementTree as ET
+        return ET.Element(xmltags.scenarioTag)
+
+    def _storeTrackerArgs(self, scenarioElement, **kwargs):
+        import xml.etree.ElementTree as ET
+        for key, value in kwargs.items():
+            scenarioElement.attrib[str(key)] = str(value)
+        settings = ET.SubElement(scenarioElement, xmltags.trackerSettingsTag)
+        for name, value in (("M_required", self.M_required), ("N_checks", self.N_checks), ("mergeThreshold", self.mergeThreshold),
+                            ("ownPosition", self.position), ("radarRange", self.radarRange), ("radarPeriod", self.radarPeriod),
+                            ("lambdaPhi", self.lambda_phi), ("lambdaNu", self.lambda_nu), ("lambdaEx", self.lambda_ex), ("eta2", self.eta2),
+                            ("N_max", self.N_max), ("NLLR_upperLimit", self.scoreUpperLimit), ("pruneThreshold", self.pruneThreshold),
+                            ("targetSizeLimit", self.targetSizeLimit), ("maxSpeedMS", self.maxSpeedMS)):
+            ET.SubElement(settings, name).text = str(value)
+
+    def _storeRun(self, scenarioElement, preInitialized=True, **kwargs):
+        """One <Run>: the per-stage run times of every scan and one <Track> per live and per terminated target -- all states of
+        the selected hypothesis' chain (preInitialized=True; without the reference's pykalman-smoothed copy) or its first and last."""
+        import xml.etree.ElementTree as ET
+        run = ET.SubElement(scenarioElement, xmltags.runTag)
+        run.attrib[xmltags.iterationTag] = str(kwargs[xmltags.iterationTag] if xmltags.iterationTag in kwargs
+                                               else len(scenarioElement.findall(xmltags.runTag)))
+        if xmltags.seedTag in kwargs:
+            run.attrib[xmltags.seedTag] = str(kwargs[xmltags.seedTag])
+        prec = xmltags.timeLogPrecision
+        runtime = ET.SubElement(run, xmltags.runtimeTag, attrib={xmltags.descriptionTag: "Per iteration", xmltags.precisionTag: str(prec)})
+        for stage, values in self.runtimeLog.items():
+            if not values:
+                continue
+            v = np.array(values)
+            ET.SubElement(runtime, str(stage), attrib={xmltags.meanTag: str(round(np.mean(v), prec)), xmltags.minTag: str(round(np.min(v), prec)),
+                                                       xmltags.maxTag: str(round(np.max(v), prec))}
+                          ).text = np.array_str(v, precision=prec, max_line_width=999999)
+        for nodes, extra in ((self.__trackNodes__, {}), (self.__terminatedTargets__, {xmltags.terminatedTag: True})):
+            for node in nodes:
+                if preInitialized:
+                    node._storeNode(run, self.radarPeriod, **extra)
+                else:
+                    node._storeNodeSparse(run, **extra)
+        return run
 
     def getRuntimeAverage(self):
         return {k: np.mean(np.array(v)) for k, v in self._runtimeLog_.items() if len(v)}
