@@ -12,6 +12,7 @@
 // offset; slot + rank for the ascending member lists.  Clusters come out ordered by smallest
 // member with ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
 #include "mht_kernels.h"
+#include "mht_init_dev.h"
 
 namespace mht {
 
@@ -361,6 +362,19 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cluster_body(a, smem);
 }
+// Streaming API path: step 7 of the scan (the M-of-N initiator, tracker.py:264-278) needs nothing of steps 2-6 -- only which
+// measurements the grow kernel gated -- so it runs as a SECOND workgroup of this launch, next to the clustering, instead of behind
+// the ILPs in post_scan_kernel (10 us of the critical path of every streamed scan).  No hand-off inside the kernel: what it gives
+// birth to is admitted by post_scan_kernel, two launches later.
+__global__ __launch_bounds__(CL_THREADS) void cluster_init_kernel(const ClusterArgs a, const InitArgs in, const int32_t* sticky_overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x == 1) {
+        if ((a.status && a.status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
+        initiator_body(in);
+        return;
+    }
+    cluster_body(a, smem);
+}
 // a group of sectors per launch: blockIdx.y = sector, its argument block is read from HBM (two variants by scan parity)
 __global__ __launch_bounds__(CL_THREADS) void cluster_batch_kernel(const PBatch av) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -393,7 +407,7 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
     return ((size_t)4 * Tcap + mslots + (size_t)elds + (size_t)pcap) * 4;
 }
 
-int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in) {
+int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in, const InitArgs* init, const int32_t* sticky_overflow) {
     ClusterArgs a = a_in;
     size_t& attr_bytes = ctx->lds_attr_cluster;
     cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap);
@@ -406,9 +420,12 @@ int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in) {
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_init_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
-    hipLaunchKernelGGL(cluster_kernel, dim3(1), dim3(CL_THREADS), lds, ctx->stream, a);
+    if (init) hipLaunchKernelGGL(cluster_init_kernel, dim3(2), dim3(CL_THREADS), lds, ctx->stream, a, *init, sticky_overflow);
+    else hipLaunchKernelGGL(cluster_kernel, dim3(1), dim3(CL_THREADS), lds, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { ad
 // step 7 on the measurements the commit found unused (initiator_body), Tracker.initiateTarget for what it confirmed.
 static_assert(INIT_THREADS == 1024, "post_scan_kernel runs commit, initiator and admission with one block size");
 __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit,
-                                                         const PublishArgs pub) {
+                                                         const PublishArgs pub, const int run_init) {
     __shared__ int s_commit[2 * (1024 / 64) + 8];
     if (do_commit) {
         commit_body<1024>(cm, dyn, s_commit);
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
         __syncthreads();
     }
     if (!cm.hdr->error) {      // (void scan: nothing to initiate)
-        initiator_body(in);
-        __threadfence_block();
-        __syncthreads();
+        if (run_init) {        // (streaming: the initiator already ran next to the scan's clustering, cluster_init_kernel)
+            initiator_body(in);
+            __threadfence_block();
+            __syncthreads();
+        }
         add_targets_body(ad);
     }
     publish_report<1024>(pub);
@@ -313,6 +315,7 @@ struct Forest {
     // streaming API path (mht_forest_scan with an initiator): the report of a scan is pushed to the host by extra workgroups of the
     // NEXT scan's grow launch (fgrow_kernel: publish_part), or by publish_kernel if the host asks for it before there is one
     bool pub_deferred = false; PublishArgs pub_args = {}; int pub_slot = 0;
+    int init_ran_scan = 0;       // last scan whose initiator ran inside its cluster launch (mht_forest_scan)
     const float* z_cur = nullptr;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
@@ -872,7 +875,14 @@ static void forest_end_step(Forest* f, const StepPlan& pl, int M) {
 
 }  // namespace mht
 
-extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
+namespace mht {
+void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now, InitArgs& a);
+void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
+                         const int32_t** n, int* cap, mht_ctx** ctx);
+}
+
+// init != null (mht_forest_scan): the scan's step 7 rides in the cluster launch (cluster_init_kernel)
+static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiator* init, double now) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
     Forest* f = ctx->forest;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -909,7 +919,15 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     {
         ClusterArgs c;
         fill_cluster(f, pl.s, c);
-        MHT_STEP_CHECK(launch_cluster(ctx, c));
+        if (init) {
+            InitArgs ia;
+            initiator_scan_args(init, z, M, nullptr, now, ia);
+            ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
+            MHT_STEP_CHECK(launch_cluster(ctx, c, &ia, &f->cnt->overflow));
+            f->init_ran_scan = pl.s;
+        } else {
+            MHT_STEP_CHECK(launch_cluster(ctx, c));
+        }
     }
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[2], st));
     // ---- 3: global hypothesis per cluster (tracker.py:225-237) + per-target termination / prune decision ---------------
@@ -931,6 +949,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) {
     if (f->timing) { MHT_STEP_HIP(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     return MHT_OK;
 }
+extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) { return forest_step_impl(ctx, z, M, nullptr, 0.0); }
 
 // ---- cluster-sharded step: ONE tracker on several devices (north star: "independent track clusters shard across the GPUs ... when
 // the gating graph actually partitions") ---------------------------------------------------------------------------------------
@@ -1180,12 +1199,6 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     return rc;
 }
 
-namespace mht {
-void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now, InitArgs& a);
-void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
-                         const int32_t** n, int* cap, mht_ctx** ctx);
-}
-
 static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now, bool defer_publish) {
     MHT_REQUIRE(ctx && ctx->forest && in, "mht_forest_initiate: null argument");
     Forest* f = ctx->forest;
@@ -1197,9 +1210,10 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
     MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    InitArgs ia;
+    InitArgs ia = {};
     char* report_dev = f->report_dev2[f->scan & 1];
-    initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia);
+    const bool init_done = f->init_ran_scan == f->scan;      // (mht_forest_scan: it ran inside this scan's cluster launch)
+    if (!init_done) initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia);
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
     a.check = 1; a.thr = f->cfg.merge_threshold;
@@ -1217,7 +1231,8 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     // the report goes to the host from this launch, or -- streaming: mht_forest_scan -- with the next scan's grow launch
     PublishArgs pub = publish_args(f);
     if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
-    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub);
+    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
+                       init_done ? 0 : 1);
     f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
@@ -1234,7 +1249,7 @@ extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float*
     return forest_initiate_impl(ctx, in, z, M, now, false);
 }
 
-static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mark_done) {
+static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mark_done, mht_initiator* init = nullptr, double now = 0.0) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step_host: no forest");
     Forest* f = ctx->forest;
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "mht_forest_step_host: M=%d exceeds max_meas=%d", M, f->cfg.max_meas);
@@ -1256,17 +1271,24 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         f->z_used[slot] = true;
         f->z_cur = zd;
         (void)mark_done;
-        return mht_forest_step(ctx, zd, M);
+        return forest_step_impl(ctx, zd, M, init, now);
     }
     f->z_cur = f->z_dev;
-    return mht_forest_step(ctx, f->z_dev, M);
+    return forest_step_impl(ctx, f->z_dev, M, init, now);
 }
 extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) { return step_host_impl(ctx, z_host, M, true); }
 
 // One radar scan of the drop-in API path in one call: steps 1-6 (mht_forest_step_host), step 7 (mht_forest_initiate, if an
 // initiator is given) and the start of the report's way to the host (mht_forest_report_begin).  Nothing here waits for the device.
 extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
-    int rc = step_host_impl(ctx, z_host, M, false);
+    if (in) {      // (checked before the scan is stepped: nothing may fail between the initiator's run and the admission of its births)
+        MHT_REQUIRE(ctx && ctx->forest, "mht_forest_scan: no forest");
+        const double* bx; const float* bP; const uint8_t* bfl; const double* bpd; const int32_t* bme; const int32_t* bn; int cap; mht_ctx* ictx;
+        initiator_born_ptrs(in, &bx, &bP, &bfl, &bpd, &bme, &bn, &cap, &ictx);
+        MHT_REQUIRE(ictx == ctx, "mht_forest_scan: the initiator belongs to another context");
+        MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_scan: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
+    }
+    int rc = step_host_impl(ctx, z_host, M, false, in, now);
     if (rc) return rc;
     if (!in) return mht_forest_report_begin(ctx);
     rc = forest_initiate_impl(ctx, in, nullptr, M, now, true);

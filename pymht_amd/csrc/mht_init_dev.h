@@ -22,6 +22,7 @@ struct InitArgs {
     int Mcap, Pcap;
     const float* z; int M;              // the scan, dev (M,2) float32
     const unsigned long long* used;     // [ceil(M/64)] bit j set = measurement j was gated by a track (null: all measurements are unused)
+    const unsigned char* used_b;        // the same as one byte per measurement (what the forest's grow kernel writes); takes precedence
     double now;
     int Mreq, Nreq; double v_max, gamma, merge_threshold, default_pd;
     float C[8], R[4], P0[16];
@@ -174,7 +175,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         int running = 0;
         for (int base = 0; base < a.M; base += INIT_THREADS) {
             const int j = base + tid;
-            const bool un = j < a.M && !(a.used && ((a.used[j >> 6] >> (j & 63)) & 1ull));
+            const bool un = j < a.M && !(a.used_b ? a.used_b[j] != 0 : (a.used && ((a.used[j >> 6] >> (j & 63)) & 1ull)));
             const unsigned long long bal = __ballot(un);
             if (lane == 0) s_scan[wave] = __popcll(bal);
             __syncthreads();

@@ -188,7 +188,9 @@ int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, 
 size_t blp_set_tier(BlpArgs& a, int tier);
 void fill_model(GateArgs& a, const mht_model* m);
 void fill_model_only(Model& o, const mht_model* m);
-int launch_cluster(mht_ctx* ctx, const ClusterArgs& a);
+struct InitArgs;
+// init != null: a second workgroup of the launch runs the M-of-N initiator on this scan's used-measurement bytes (streaming API path)
+int launch_cluster(mht_ctx* ctx, const ClusterArgs& a, const InitArgs* init = nullptr, const int32_t* sticky_overflow = nullptr);
 void cluster_prepare(ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
