@@ -545,17 +545,22 @@ __device__ __forceinline__ bool coordinate_step(const LStore& s, int K, bool con
     return false;
 }
 
-// Two-target clusters (the most common kind) whose minimisers collide: the optimum straight away, by enumeration.  Every column
-// gets the bit mask of its (dense) rows; thread i holds column i of the first target and walks the columns of the second
-// (broadcast LDS reads): min cost[i] + cost[j] over pairs with disjoint masks, ties to the lowest (i, j).  n0 x n1 is a few
-// thousand pairs -- about one dual round's time, where the rounds needed 1-6 of them (near-duplicate tracks zig-zag).
-// Needs <= 64 rows; returns false (nothing touched but rcL) if that does not hold.
+// Two-target clusters (the most common kind) whose minimisers collide: the optimum straight away, by enumeration -- of the few
+// pairs that can be optimal.  Every column gets the bit mask of its (dense) rows.  A pair through the cheapest column of one
+// target (with the cheapest compatible column of the other) gives an upper bound UB; a column c of target t can only be in a pair
+// of cost <= UB if cost[c] + (cheapest column of the other target) <= UB.  What passes that test (typically a dozen columns per
+// target out of a few hundred) is listed, and only list x list is enumerated: min cost[i] + cost[j] over pairs with disjoint masks,
+// ties to the lowest (i, j).  Exact: the optimal pair passes the test by construction.  (The plain n0 x n1 enumeration took 28-32 us
+// on pairs with 250 + 250 columns and was the slowest ILP of one headline scan in five.)
+// Needs <= 64 rows; returns false (nothing touched but rcL / the exact search's scratch) if that does not hold.
 __device__ __forceinline__ bool enumerate_pair(const GStore&, Red*) { return false; }
 __device__ __forceinline__ bool enumerate_pair(const LStore& s, Red* r) {
     if (s.nR > 64) return false;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = s.colb[0], b1 = s.colb[1], n0 = b1 - b0, n1 = s.colb[2] - b1;
     unsigned long long* mk = reinterpret_cast<unsigned long long*>(s.rcL);      // the reduced costs are dead until the next sweep
+    unsigned short* list = s.ordL;                                              // [nH] candidates of target 0, then of target 1 (from n0 on)
+    int* cnt = reinterpret_cast<int*>(s.enumL);                                 // [2] list lengths
     for (int h = tid; h < s.nH; h += BLP_THREADS) {
         const Rows8 e = rows_of(s, h);
         unsigned long long m = 0ull;
@@ -564,20 +569,55 @@ __device__ __forceinline__ bool enumerate_pair(const LStore& s, Red* r) {
             if ((int)e.e[d] != s.nR) m |= 1ull << e.e[d];
         mk[h] = m;
     }
+    if (tid < 2) cnt[tid] = 0;
+    // cheapest column of either target: wavefronts 0 and 1
+    if (wave < 2) {
+        const int bb = wave ? b1 : b0, nn = wave ? n1 : n0;
+        double cv = DINF;
+        int ci = -1;
+        for (int h = lane; h < nn; h += 64) {
+            const double c = s.costL[bb + h];
+            if (ci < 0 || c < cv) { cv = c; ci = h; }
+        }
+        wave_min_pair(cv, ci);
+        if (lane == 0) { r->q[0][wave] = cv; r->q[1][wave] = (double)ci; }
+    }
     __syncthreads();
+    const double min0 = r->q[0][0], min1 = r->q[0][1];
+    const int a0 = (int)r->q[1][0], a1 = (int)r->q[1][1];
+    // upper bound: (a0, cheapest compatible j) and (cheapest compatible i, a1)
+    double ub = DINF;
+    {
+        const unsigned long long ma0 = mk[b0 + a0], ma1 = mk[b1 + a1];
+        for (int j = tid; j < n1; j += BLP_THREADS)
+            if ((ma0 & mk[b1 + j]) == 0ull) ub = fmin(ub, min0 + s.costL[b1 + j]);
+        for (int i = tid; i < n0; i += BLP_THREADS)
+            if ((ma1 & mk[b0 + i]) == 0ull) ub = fmin(ub, s.costL[b0 + i] + min1);
+        ub = wave_min_value(ub);
+        __syncthreads();
+        if (lane == 0) r->d[wave] = ub;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < BLP_THREADS / 64; ++w) ub = fmin(ub, r->d[w]);
+    }
+    if (ub >= DINF) return false;      // (cannot happen: the missed-detection columns have no rows)
+    // candidates (sums are compared exactly as the enumeration forms them: cost[i] + cost[j])
+    for (int i = tid; i < n0; i += BLP_THREADS)
+        if (s.costL[b0 + i] + min1 <= ub) list[atomicAdd(&cnt[0], 1)] = (unsigned short)i;
+    for (int j = tid; j < n1; j += BLP_THREADS)
+        if (min0 + s.costL[b1 + j] <= ub) list[n0 + atomicAdd(&cnt[1], 1)] = (unsigned short)j;
+    __syncthreads();
+    const int m0 = cnt[0], m1 = cnt[1];
     double bv = DINF;
     int bi = -1;
-    for (int i = tid; i < n0; i += BLP_THREADS) {
-        const double c0 = s.costL[b0 + i];
-        const unsigned long long m0 = mk[b0 + i];
-#pragma unroll 4
-        for (int j = 0; j < n1; ++j) {
-            const double v = c0 + s.costL[b1 + j];
-            if ((m0 & mk[b1 + j]) == 0ull && v < bv) { bv = v; bi = i * n1 + j; }
-        }
+    for (int p = tid; p < m0 * m1; p += BLP_THREADS) {
+        const int i = list[p / m1], j = list[n0 + p % m1];
+        const double v = s.costL[b0 + i] + s.costL[b1 + j];
+        const int idx = i * n1 + j;
+        if ((mk[b0 + i] & mk[b1 + j]) == 0ull && (v < bv || (v == bv && idx < bi) || bi < 0)) { bv = v; bi = idx; }
     }
     block_min_pair(bv, bi, r);
-    if (bi < 0) return false;          // (cannot happen: the missed-detection columns have no rows)
+    if (bi < 0) return false;
     if (tid == 0) { s.ub_sel[0] = b0 + bi / n1; s.ub_sel[1] = b1 + bi % n1; }
     __threadfence_block();
     __syncthreads();

@@ -48,3 +48,18 @@ per_scan = {}
 for r in rows: per_scan[r[1]] = max(per_scan.get(r[1], 0), r[0])
 m = np.array(list(per_scan.values()))
 print('slowest ILP of a scan: mean %.1f p50 %.1f p90 %.1f max %.1f' % (m.mean(), np.percentile(m, 50), np.percentile(m, 90), m.max()))
+# who is the slowest ILP of a scan?
+worst = {}
+for r in rows:
+    if r[1] not in worst or r[0] > worst[r[1]][0]: worst[r[1]] = r
+import collections
+by_it = collections.Counter(min(w[4], 9) for w in worst.values())
+by_k = collections.Counter(min(w[2], 12) for w in worst.values())
+print('slowest ILP of a scan by dual rounds:', sorted(by_it.items()), ' by K:', sorted(by_k.items()))
+for it in sorted(by_it):
+    sel = [w for w in worst.values() if min(w[4], 9) == it]
+    print('  rounds %d: %3d scans, mean %.1f us, setup %.1f us, columns %.0f, K %.1f' % (it, len(sel), np.mean([w[0] for w in sel]), np.mean([w[7] for w in sel]), np.mean([w[3] for w in sel]), np.mean([w[2] for w in sel])))
+allr = np.array([(r[0], r[2], r[3], r[4], r[7]) for r in rows])
+for it in range(0, 6):
+    m = allr[:, 3] == it
+    if m.any(): print('  all ILPs with %d rounds: %5d, mean %.1f us (setup %.1f), columns %.0f' % (it, m.sum(), allr[m, 0].mean(), allr[m, 4].mean(), allr[m, 2].mean()))
