@@ -686,6 +686,7 @@ template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, 
 // optimal selections the one with the lexicographically lowest column indices in member order wins, whatever the wave timing).
 constexpr int ENUM_MAXK = 10;
 constexpr int ENUM_AFTER = 8;             // coordinate rounds a small cluster gets before the exact search
+constexpr int ENUM_WIDE = 512, ENUM_AFTER_WIDE = 4;      // ... a cluster with more than ENUM_WIDE columns
 constexpr int ENUM_BUDGET = 1 << 13;      // search nodes per thread before the routine gives up (the branch and bound takes over)
 __device__ __forceinline__ unsigned long long enum_key(double v) {      // monotone map double -> u64
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -995,7 +996,9 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     const int ca_rounds = coordinate_rounds(s, K);
     const int ca_end = a.max_iter < ca_rounds ? a.max_iter : ca_rounds;        // rounds [0, ca_end) are coordinate rounds
     const int it_cap = bb_after_rounds(s, K) ? ca_end : a.max_iter;
-    const int enum_at = (ca_end > 0 && K >= 3 && K <= ENUM_MAXK) ? (ca_end < ENUM_AFTER ? ca_end : ENUM_AFTER) : -1;
+    // (a round of a cluster with many columns costs ~10 us instead of ~4.4: the exact search is worth its set-up earlier there)
+    const int enum_after = (s.col_end(K - 1) - s.col_begin(0) > ENUM_WIDE) ? ENUM_AFTER_WIDE : ENUM_AFTER;
+    const int enum_at = (ca_end > 0 && K >= 3 && K <= ENUM_MAXK) ? (ca_end < enum_after ? ca_end : enum_after) : -1;
     for (int it = 0; it <= it_cap; ++it) {
         iters = it;
         if (it == enum_at && !a.no_enum) {      // small cluster the first rounds did not certify: exact search
