@@ -27,6 +27,7 @@
 namespace mht {
 
 constexpr int BLP_THREADS = 256;
+constexpr int FUSED_K = 8;           // clusters of up to this many targets: a wavefront per target for minimisers / usage / regrets
 constexpr double DINF = 1.0e300;
 constexpr int BIG_MAXH = 2048, BIG_MAXR = 1024, BIG_MAXK = 256;      // default LDS tier: columns, rows, targets of a cluster solved out of LDS
 // (member tables hold cap_k + 4 entries: (cap_k + 4) * 4 and * 8 are multiples of 16 bytes when cap_k is a multiple of 4)
@@ -315,11 +316,11 @@ __device__ __forceinline__ void compute_minimisers(const GStore& s, int K, Red* 
     __syncthreads();
 }
 __device__ __forceinline__ void compute_minimisers(const LStore& s, int K, Red* r) {
-    if (K <= BLP_THREADS / 64) {
-        // small cluster: one wavefront per target, reduced costs computed in the same sweep (kept in rcL for the
-        // coordinate step), DPP reduction: a single phase
-        const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (k < K) {
+    if (K <= FUSED_K) {
+        // small cluster: one wavefront per target (two in turn from five targets on), reduced costs computed in the same sweep (kept
+        // in rcL for the coordinate step), DPP reduction: a single phase
+        const int lane = threadIdx.x & 63;
+        for (int k = threadIdx.x >> 6; k < K; k += BLP_THREADS / 64) {
             const int hb = s.colb[k], he = s.colb[k + 1];
             double bv = DINF;
             int bi = -1;
@@ -415,7 +416,7 @@ constexpr int BB_NODE_STEPS = 4;   // subgradient steps per such node
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
 __device__ __forceinline__ bool usage_counted_by_minimisers(const GStore&, int) { return false; }
-__device__ __forceinline__ bool usage_counted_by_minimisers(const LStore&, int K) { return K <= BLP_THREADS / 64; }
+__device__ __forceinline__ bool usage_counted_by_minimisers(const LStore&, int K) { return K <= FUSED_K; }
 // Branch and bound right after the coordinate rounds only where it is cheap and cannot explode: clusters of <= 4 targets.
 // Larger clusters go on with subgradient steps (up to max_iter) first: their branch and bound needs good prices (a 68-target
 // scenario ran into the node limit with the prices of 16 coordinate rounds).
@@ -467,12 +468,14 @@ __device__ __forceinline__ bool coordinate_step(const LStore& s, int K, bool con
     const int tid = threadIdx.x;
     if (conflict) {
         // regrets of the users of active rows (mn[k] = regret, -1 = target not taking part)
-        if (K <= BLP_THREADS / 64) {
-            const int k = tid >> 6, lane = tid & 63;
-            const int m = (k < K) ? s.lix[k] : -1;
-            const bool active = m >= 0 && s.markL[m] == s.usageL[m];
-            const double alt = regret_of<64>(s, k, m, active, lane);
-            if (lane == 0 && k < K) s.mn[k] = active ? alt - s.best_rc[k] : -1.0;
+        if (K <= FUSED_K) {
+            const int lane = tid & 63;
+            for (int k = tid >> 6; k < K; k += BLP_THREADS / 64) {
+                const int m = s.lix[k];
+                const bool active = m >= 0 && s.markL[m] == s.usageL[m];
+                const double alt = regret_of<64>(s, k, m, active, lane);
+                if (lane == 0) s.mn[k] = active ? alt - s.best_rc[k] : -1.0;
+            }
         } else {
             const int row = tid >> 4, l16 = tid & 15;
             for (int k0 = 0; k0 < K; k0 += BLP_THREADS / 16) {
