@@ -415,6 +415,8 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 constexpr int BB_NODE_STEPS = 4;   // subgradient steps per such node
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
+__device__ __forceinline__ bool scratch_is_private(const GStore&) { return false; }
+__device__ __forceinline__ bool scratch_is_private(const LStore&) { return true; }
 __device__ __forceinline__ bool usage_counted_by_minimisers(const GStore&, int) { return false; }
 __device__ __forceinline__ bool usage_counted_by_minimisers(const LStore&, int K) { return K <= FUSED_K; }
 // Branch and bound right after the coordinate rounds only where it is cheap and cannot explode: clusters of <= 4 targets.
@@ -1135,6 +1137,8 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             if (theta < 1.0 / 16.0) done = true;      // the dual bound has stalled through four step halvings: no certificate is
                                                       // coming (duality gap), hand over to the branch and bound now
         }
+        // a certified cluster in LDS is finished here: its tables die with it (HBM scratch is shared and must be left clean)
+        if (done && status != 0 && scratch_is_private(s)) break;
         // projected subgradient step on the prices (skipped when done); usage counters go back to zero either way
         const double step = (done || coord) ? 0.0 : theta * fmax(UB - LB, 1e-6) / nrm;
         if (!counters_reset)
