@@ -406,3 +406,43 @@ def test_deferred_commit_edge_cases_raw_abi():
     with pytest.raises(_lib.MhtError):       # the forest refuses further scans
         step(trk, sc["scans"][-1])
     trk.close()
+
+
+def test_streaming_equals_reading_after_every_scan():
+    """The drop-in API is pipelined: `addMeasurementList` only queues the scan, its report rides to the host with the NEXT scan's grow
+    launch (or in a launch of its own as soon as somebody looks), the initiator runs next to the scan's clustering.  Three hosts on
+    the same stream with births and terminations (config 2): A looks at the results after every scan, B streams everything and looks
+    once at the end, C mixes (leaf snapshots, reports, injected targets in between).  Same forest, same births, same reports."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    sc = make_config("cfg2", seed=5446, n_scans=24)
+    A, B, Cc = _mk(sc, N=sc["N"], logScanStats=True), _mk(sc, N=sc["N"], logScanStats=True), _mk(sc, N=sc["N"], logScanStats=True)
+    extra = Target(sc["t0"], None, np.array([5000.0, 5000.0, 1.0, 1.0]), pv.P0)
+    ids_a = []
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        for trk in (A, B, Cc):
+            trk.addMeasurementList(MeasurementList(float(t), z))
+        ids_a.append([r.ID for r in A.__targetList__])                  # (waits for scan k's report: a launch of its own)
+        if k % 3 == 1:
+            assert Cc.lastScanStats["M"] == len(z)
+        if k % 5 == 2:
+            Cc.leafBatch()
+        if k == 9:
+            for trk in (A, B, Cc):
+                trk.initiateTarget(Target(sc["t0"], None, extra.x_0.copy(), pv.P0))      # (host-side injection between two scans)
+    assert [r.ID for r in B.__targetList__] == ids_a[-1] == [r.ID for r in Cc.__targetList__]
+    assert len(set(map(tuple, ids_a))) > 3          # births / terminations happened
+    for name in ("L", "G", "M", "ilp", "clusters", "leaves_out"):
+        a, b, c = ([s[name] for s in t.scanStatsLog] for t in (A, B, Cc))
+        assert a == b == c, name
+    la, lb, lc = A.leafBatch(), B.leafBatch(), Cc.leafBatch()
+    for key in la:
+        if key != "node":
+            assert np.array_equal(la[key], lb[key]) and np.array_equal(la[key], lc[key]), key
+    sa, sb = A._sel[0], B._sel[0]
+    for name in ("id", "status", "sel_meas", "sel_x", "sel_cnllr", "score", "root_scan", "root_meas", "root_x"):
+        assert np.array_equal(sa[name], sb[name]), name
+    for trk in (A, B, Cc):
+        trk.close()
