@@ -362,6 +362,9 @@ def main():
         # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
         run_trace(mods, make_config("dense", seed=1234), "g13_trace_similar", prune_similar=True)
         run_trace(mods, make_config("cfg2", seed=5446), "g13b_trace_similar_cfg2", n_scans=10, store_leaves=False, prune_similar=True)
+    if "g13c" in which:
+        # the same on the headline config (500 targets, ~500 measurements per scan): hashed trace, 8 scans, ~2 000 fusions
+        run_trace(mods, make_config("cfg3", seed=5446), "g13c_trace_similar_cfg3", n_scans=8, store_leaves=False, prune_similar=True)
     if "g6b" in which:
         # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)

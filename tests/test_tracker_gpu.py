@@ -48,7 +48,7 @@ def tracker_selected(trk):
 
 
 @pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long",
-                                  "g13_trace_similar", "g13b_trace_similar_cfg2"])
+                                  "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3"])
 def test_tracker_replays_reference_trace(name, gold_dir):
     from pymht_amd.utils.classDefinitions import MeasurementList
     g = np.load(os.path.join(gold_dir, name + ".npz"))
