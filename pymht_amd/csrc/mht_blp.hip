@@ -1303,8 +1303,22 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                         slack |= (um > 0.0 && ug == 0);
                     }
                 });
-                rs_all = block_sum(rs, r);
-                usumU = block_sum(us, r);
+                // one fused block reduction for the four sums and the two flags (each value summed exactly as block_sum does it)
+                double csum = 0.0;
+                {
+                    const double v0 = wave_sum(rs), v1 = wave_sum(us), v2 = wave_sum(cs), v3 = wave_sum(nrm);
+                    int f = (__any(conflict) ? 1 : 0) | (__any(slack) ? 2 : 0);
+                    __syncthreads();
+                    if (lane == 0) { r->q[wave][0] = v0; r->q[wave][1] = v1; r->q[wave][2] = v2; r->q[wave][3] = v3; r->i[wave] = f; }
+                    __syncthreads();
+                    rs_all = 0.0; usumU = 0.0; nrm = 0.0; f = 0;
+#pragma unroll
+                    for (int w = 0; w < BLP_THREADS / 64; ++w) {
+                        rs_all += r->q[w][0]; usumU += r->q[w][1]; csum += r->q[w][2]; nrm += r->q[w][3]; f |= r->i[w];
+                    }
+                    conflict = f & 1;
+                    slack = (f >> 1) & 1;
+                }
                 const double lb = s.cst[level] + rs_all - usumU;
                 bool stop = false;
                 if (rounds > 0 && !final_eval && lb > best_lb) {       // keep the best prices of the node (a Polyak step with a loose
@@ -1313,10 +1327,6 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     s.for_rows([&](int m) { sl[m] = s.u(m); });
                 }
                 if (rounds > 0) {
-                    const double csum = block_sum(cs, r);
-                    nrm = block_sum(nrm, r);
-                    conflict = block_or(conflict, r);
-                    slack = block_or(slack, r);
                     if (!conflict) {                            // the minimisers complete the fixed columns feasibly
                         const double cand = s.cst[level] + csum;
                         if (cand < UB - eps) {
