@@ -651,12 +651,12 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
 }
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
-template <int PQ>
+template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_grow = d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
-    fgrow_body<PQ, FG_CAP_SOLO>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+    fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
@@ -689,6 +689,8 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<2, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
@@ -708,13 +710,21 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused) {
 
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
     fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
-    const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP_SOLO);
+    // 128 leaves per pass unless the larger tables cost a workgroup per CU (long scans: the hit masks grow with the scan): 3 per CU is
+    // all the launch bounds allow, fewer than with 96 leaves per pass is a loss (config-5 size, 2 048 measurements: 1 instead of 2)
+    const size_t lds_hi = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP_SOLO), lds_lo = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP);
+    auto per_cu = [](size_t b) { const size_t n = (size_t)160 * 1024 / b; return n > 3 ? (size_t)3 : n; };
+    const bool wide = per_cu(lds_hi) >= per_cu(lds_lo);
+    const size_t lds = wide ? lds_hi : lds_lo;
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
     const bool pub = publish && publish->dst;
     const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
     const PublishArgs pa = pub ? *publish : PublishArgs{};
-    if (a.pds == 8) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d, pa);
-    else hipLaunchKernelGGL(fgrow_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, commit ? *commit : CommitArgs{}, d, pa);
+    const CommitArgs cm = commit ? *commit : CommitArgs{};
+    if (a.pds == 8 && wide) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+    else if (a.pds == 8) hipLaunchKernelGGL((fgrow_kernel<2, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+    else if (wide) hipLaunchKernelGGL(fgrow_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+    else hipLaunchKernelGGL((fgrow_kernel<4, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }
