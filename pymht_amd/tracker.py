@@ -193,6 +193,7 @@ class Tracker():
         overlaps its own bookkeeping with the device's work."""
         tic = {'Total': time.time()}
         z = self._accept_scan(scanList, aisList, kwargs)
+        tic['_print'] = {k: v for k, v in kwargs.items() if k in ("printTime", "printCluster", "printInfo", "on_color") and v}
         self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
@@ -331,6 +332,15 @@ class Tracker():
                                   unused=unusedRadarMeasurementIndices)
         if self.scanStatsLog is not None:
             self.scanStatsLog.append(dict(self._stats_, nTargets=len(self._tbl_)))
+        # the reference's per-scan console output (tracker.py:222-223, :296-301), when the scan is folded
+        kw = tic.get('_print')
+        if kw:
+            if kw.get("printCluster", False):
+                self.printClusterList(self.__clusterList__)
+            if kw.get("printInfo", False):
+                print("Added scan number:", len(self.__scanHistory__), " \tnRadarMeas ", nRadarMeas, sep="")
+            if kw.get("printTime", False):
+                self.printTimeLog(**kw)
 
     def _apply_births(self, births, scanTime, scanNumber, z_unused):
         """The device initiator's candidates that Tracker.initiateTarget's device twin admitted: append them to the host mirror."""
@@ -623,6 +633,53 @@ class Tracker():
         """Wait for everything queued on the device and fold it (reports are folded lazily otherwise)."""
         self._drain()
         self._ctx.synchronize()
+
+    # ---- the reference's console log (tracker.py:129-137, :1402-1467): same columns, fed from the device's scan report ---------------
+    def setHighPriority(self):
+        import platform
+        import psutil
+        proc = psutil.Process()
+        proc.nice(psutil.HIGH_PRIORITY_CLASS if platform.system() == "Windows" else 5)
+
+    def getTimeLogHeader(self):
+        cols = (('{:3} ', "Nr"), ('{:9} ', "Num Targets"), ('{:12} ', "Iteration (ms)"),
+                ('({0:23} ', "(nMeasurements + nAisUpdates / nNodes) Process time ms"))
+        return ("".join(f.format(v) for f, v in cols) + '({0:2}) {1:5}'.format("nClusters", 'Cluster') +
+                '({0:3}) {1:6}'.format("nOptimSolved", 'Optim') + '{:4}'.format('DynN') + '{:5}'.format('N-Prune') +
+                '{:3}'.format('Terminate') + '{:5}'.format('Init'))
+
+    def getTimeLogString(self):
+        """One line per scan like the reference's.  Stage times are the device's (with `deviceTiming=True`; otherwise only Total and
+        Init are known); the node count of the reference's line is the number of hypotheses the scan produced (children of the grow
+        kernel): the forest keeps no per-target node totals."""
+        st = self.lastScanStats
+        ms = {k: 1e3 * self.toc.get(k, 0.0) for k in ('Total', 'Process', 'Cluster', 'Optim', 'DynN', 'N-Prune', 'Terminate', 'Init')}
+        return ('{:<3.0f} '.format(len(self.__scanHistory__)) + 'nTrack {:2.0f} '.format(len(self.__targetList__)) +
+                'Total {0:6.0f} '.format(ms['Total']) +
+                'Process({0:4.0f}+{1:<3.0f}/{2:6.0f}) {3:6.1f} '.format(st["M"], 0, st["L"] + st["G"], ms['Process']) +
+                'Cluster({0:2.0f}) {1:5.1f} '.format(st["clusters"], ms['Cluster']) +
+                'Optim({0:g}) {1:6.1f} '.format(self.nOptimSolved, ms['Optim']) + 'DynN {:4.1f} '.format(ms['DynN']) +
+                'N-Prune {:5.1f} '.format(ms['N-Prune']) + 'Kill {:3.1f} '.format(ms['Terminate']) + 'Init {:5.1f}'.format(ms['Init']))
+
+    def printTimeLog(self, **kwargs):
+        late = self.toc['Total'] > self.radarPeriod
+        print(("!! " if late else "   ") + self.getTimeLogString())      # (the reference colours the line with termcolor)
+
+    def printTimeLogHeader(self):
+        print(self.getTimeLogHeader())
+
+    @staticmethod
+    def printClusterList(clusterList):
+        print("Clusters:")
+        for i, cluster in enumerate(clusterList):
+            print("Cluster ", i, " contains target(s):\t", cluster, sep="")
+
+    def printTargetList(self, **kwargs):
+        np.set_printoptions(precision=2, suppress=True)
+        print("TargetList:")
+        for i, target in enumerate(self.__targetList__):
+            print("%3d: %s" % (i, target))
+        print()
 
     # ---- XML result export (tracker.py:1469-1545): what the reference's evaluation scripts read ----------------------------------
     def getScenarioElement(self, **kwargs):

@@ -446,3 +446,24 @@ def test_streaming_equals_reading_after_every_scan():
         assert np.array_equal(sa[name], sb[name]), name
     for trk in (A, B, Cc):
         trk.close()
+
+
+def test_console_log_of_the_reference(capsys):
+    """printTime / printCluster / printInfo of addMeasurementList, getTimeLogHeader / getTimeLogString (tracker.py:1402-1467): the
+    reference's columns, fed from the device's scan report when the scan is folded."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(n_scans=3)
+    trk = _mk(sc, N=3, deviceTiming=True)
+    for z, t in zip(sc["scans"], sc["times"]):
+        trk.addMeasurementList(MeasurementList(float(t), z), printTime=True, printCluster=True, printInfo=True)
+    trk.synchronize()
+    out = capsys.readouterr().out
+    assert out.count("Clusters:") == 3 and out.count("Added scan number:") == 3 and out.count("nTrack") == 3
+    line = trk.getTimeLogString()
+    for word in ("nTrack", "Total", "Process(", "Cluster(", "Optim(", "DynN", "N-Prune", "Kill", "Init"):
+        assert word in line
+    assert line.startswith("3 ") and "Process(%4.0f+0  /" % len(sc["scans"][-1]) in line
+    assert "Num Targets" in trk.getTimeLogHeader()
+    trk.printTimeLogHeader(); trk.printTargetList()
+    assert "TargetList:" in capsys.readouterr().out
+    trk.close()
