@@ -61,6 +61,8 @@ def pmc_traffic_live(config, timeout_s=180.0):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself being profiled (no nested counter passes)"
     tot, t0 = 0.0, time.time()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mht_pmc_", dir="/tmp")
