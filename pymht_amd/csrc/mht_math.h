@@ -245,6 +245,26 @@ MHT_HD void predict_precalc_x(const ModelX<NX>& m, const TS* x, const float* P, 
     for (int i = 0; i < NX * NX; ++i) P_hat[i] = P_bar[i] - KCP[i];
 }
 
+// np.add.reduce of a contiguous 1-D array, streamed: element i of n (pairwise_sum of NumPy's loops: n < 8 sequential; else eight
+// running sums over the blocks of eight, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 leftovers one by one.
+// Exact for n <= 128, NumPy's block size; beyond that NumPy recurses -- no radar scan puts 128 plots within 4 m of one prediction)
+template <typename T> struct Sum1D {
+    T r[8]; T res; int n, blocked;
+    MHT_HD void begin(int n_) { n = n_; blocked = n_ - (n_ % 8); res = (T)0; }
+    MHT_HD void add(int i, T v) {
+        if (n < 8) { res = (i == 0) ? v : res + v; return; }
+        if (i < 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == i) r[j] = v;
+        } else if (i < blocked) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j == (i & 7)) r[j] = r[j] + v;
+        }
+        if (i == blocked - 1) res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (i >= blocked) res = res + v;
+    }
+};
+
 // Node flags (one byte per hypothesis)
 enum : uint8_t {
     F_STATE_F32 = 1,   // state chain (x, z_hat, z_tilde, NIS, NLLR) is float32: tracks born from the initiator

@@ -30,26 +30,6 @@ __device__ __forceinline__ bool is_near(const SimilarArgs& a, int g, float p0x, 
     return d < a.thr;
 }
 
-// np.add.reduce of a contiguous 1-D array, streamed: element i of n (pairwise_sum of NumPy's loops: n < 8 sequential; else eight
-// running sums over the blocks of eight, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 leftovers one by one.
-// Exact for n <= 128, NumPy's block size; beyond that NumPy recurses -- no radar scan puts 128 plots within 4 m of one prediction)
-template <typename T> struct Sum1D {
-    T r[8]; T res; int n, blocked;
-    __device__ __forceinline__ void begin(int n_) { n = n_; blocked = n_ - (n_ % 8); res = (T)0; }
-    __device__ __forceinline__ void add(int i, T v) {
-        if (n < 8) { res = (i == 0) ? v : res + v; return; }
-        if (i < 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (j == i) r[j] = v;
-        } else if (i < blocked) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (j == (i & 7)) r[j] = r[j] + v;
-        }
-        if (i == blocked - 1) res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        if (i >= blocked) res = res + v;
-    }
-};
-
 template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarArgs& a, int t, int h, int ce, int n, float p0x, float p0y) {
     const size_t cap = a.cap;
     TS xs[4] = {(TS)0, (TS)0, (TS)0, (TS)0};

@@ -80,3 +80,17 @@ extern "C" void mht_host_process_x6(const float* A, const float* Q, const float*
     if (f32state) run6<float>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, gate, x_hat, nllr);
     else run6<double>(m, n, M, x, P, z, P_d, x_bar, P_bar, P_hat, S, S_inv, K, gate, x_hat, nllr);
 }
+
+// np.add.reduce of a 1-D array as similar-state pruning forms the mean score (Sum1D): against NumPy itself in the CPU suite
+extern "C" double mht_host_sum1d_f64(const double* v, int n) {
+    Sum1D<double> s;
+    s.begin(n);
+    for (int i = 0; i < n; ++i) s.add(i, v[i]);
+    return s.res;
+}
+extern "C" float mht_host_sum1d_f32(const float* v, int n) {
+    Sum1D<float> s;
+    s.begin(n);
+    for (int i = 0; i < n; ++i) s.add(i, v[i]);
+    return s.res;
+}

@@ -69,3 +69,18 @@ def test_hostmath_six_state_matches_reference_vectors(gold_dir, hostmath):
         assert np.array_equal(mask, o["gate"].astype(bool)), c
         assert np.array_equal(o["x_hat"][mask], k("x_hat").astype(np.float64)), c
         assert np.allclose(o["nllr"][mask], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL), c
+
+
+def test_sum1d_is_numpys_reduction(hostmath):
+    """The mean cumulativeNLLR of fused hypotheses (pyTarget.py:386-387) is np.mean of a 1-D array: NumPy adds < 8 elements one after
+    the other and uses eight running sums from 8 on.  Sum1D (mht_math.h; prune_similar_kernel) must give the same bits for every
+    length up to NumPy's block size, in both dtypes."""
+    hostmath.mht_host_sum1d_f64.restype = C.c_double
+    hostmath.mht_host_sum1d_f32.restype = C.c_float
+    rng = np.random.default_rng(3)
+    for n in list(range(1, 41)) + [63, 64, 65, 100, 127, 128]:
+        for _ in range(40):
+            a = rng.normal(size=n) * 10.0 ** rng.integers(-3, 4)
+            assert hostmath.mht_host_sum1d_f64(_p(a), n) == float(np.add.reduce(a)), n
+            b = a.astype(np.float32)
+            assert np.float32(hostmath.mht_host_sum1d_f32(_p(b), n)) == np.add.reduce(b), n
