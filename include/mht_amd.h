@@ -264,7 +264,7 @@ int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, doubl
  * that is alone in its cluster, the hit children of a node that lie within `threshold` metres (Tracker.pruneThreshold,
  * tracker.py:117) of its missed-detection child are replaced, together with that child, by one measurement-less hypothesis carrying
  * their mean state / covariance / cumulativeNLLR (NumPy's float32 / float64 arithmetic and summation order).  One extra launch
- * per scan between clustering and the ILPs.  threshold <= 0 switches it off.  Not available for forests stepped by mht_group_step.
+ * per scan between clustering and the ILPs (also for a member of a group stepped by mht_group_step).  threshold <= 0 switches it off.
  * With it on, n_leaves / n_leaves_out of the report count the slots of the surviving leaf ranges (emptied ones included);
  * n_leaves_in and mht_forest_leaves count hypotheses. */
 int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold);

@@ -1062,7 +1062,6 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
         MHT_REQUIRE(a->Tcap == b->Tcap && a->Ncap == b->Ncap && a->Mpad == b->Mpad && a->R == b->R,
                     "mht_group_create: the members must have the same forest configuration (context %d differs)", i);
         for (int j = 0; j < i; ++j) MHT_REQUIRE(ctxs[j] != ctxs[i], "mht_group_create: context %d appears twice", i);
-        MHT_REQUIRE(!(b->prune_thr > 0.f), "mht_group_create: similar-state pruning is on for context %d (not available in grouped launches)", i);
     }
     MHT_HIP_CHECK(hipSetDevice(ctxs[0]->device));
     mht_group* g = new (std::nothrow) mht_group();
@@ -1087,9 +1086,11 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
             for (int tier = 1; tier <= 2; ++tier) {
                 BlpArgs& b = hbl[((size_t)i * P + v) * 2 + tier - 1];
                 fill_blp(f, s, b);
+                b.skip_dead = 1;      // (the blocks are written once: similar-state pruning may be switched on for any later scan)
                 g->blp_lds[tier - 1] = blp_set_tier(b, tier);
             }
             fill_blp(f, s, hbl0[(size_t)i * P + v]);
+            hbl0[(size_t)i * P + v].skip_dead = 1;
             g->blp_lds[2] = blp_set_tier(hbl0[(size_t)i * P + v], 0);
         }
         fill_cluster(f, 2, hcl[(size_t)i * 2]);
@@ -1146,7 +1147,6 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         MHT_REQUIRE(M[i] >= 0 && M[i] <= f->cfg.max_meas, "mht_group_step: member %d: M=%d exceeds max_meas=%d", i, M[i], f->cfg.max_meas);
         MHT_REQUIRE(z[i] || M[i] == 0, "mht_group_step: member %d: z is null", i);
         MHT_REQUIRE(!f->timing, "mht_group_step: per-stage timing is per forest (mht_forest_set_timing(ctx, 0) first)");
-        MHT_REQUIRE(!(f->prune_thr > 0.f), "mht_group_step: member %d has similar-state pruning on (not available in grouped launches)", i);
         if (f->dead) { set_error("mht_group_step: member %d is dead (a pool overflowed in an earlier scan)", i); return MHT_E_STATE; }
     }
     for (int i = 0; i < n; ++i) { const int rc = flush_publish(g->ctx[i], g->ctx[i]->forest); if (rc) return rc; }
@@ -1183,6 +1183,15 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     const Forest* f0 = c0->forest;
     int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds, g->ctx[0]->forest->pds);
     if (!rc) rc = launch_cluster_batch(c0, cb, n, f0->Tcap, f0->n_mnodes);
+    // similar-state pruning of the members that ask for it: a launch of their own each, between clustering and the ILPs
+    for (int i = 0; i < n && !rc; ++i) {
+        const Forest* f = g->ctx[i]->forest;
+        if (f->prune_thr > 0.f) {
+            SimilarArgs sa;
+            fill_similar(f, pl[i].s, sa);
+            rc = launch_prune_similar(c0, sa, f->nT_ub_step);
+        }
+    }
     // ILPs in two LDS tiers: the small footprint (several workgroups per CU) takes the clusters that fit it and the single-target
     // clusters, a narrow launch with the default footprint takes the few that do not
     if (g->two_tier) {

@@ -35,11 +35,13 @@ class SectorGroup:
         if rc:
             _lib.check(rc)
 
-    def addMeasurementLists(self, scanLists):
+    def addMeasurementLists(self, scanLists, pruneSimilar=False):
         """One `MeasurementList` per sector: all sectors' steps 1-6 in one batched launch set, then every tracker folds its own
-        report and runs its own step 7 -- the result for every sector is what `Tracker.addMeasurementList` gives."""
+        report and runs its own step 7 -- the result for every sector is what `Tracker.addMeasurementList` gives.
+        pruneSimilar: bool or one bool per sector (tracker.py:230)."""
         assert len(scanLists) == len(self.trackers)
-        zs = [trk._stage_scan(sl) for trk, sl in zip(self.trackers, scanLists)]
+        ps = list(pruneSimilar) if hasattr(pruneSimilar, "__len__") else [bool(pruneSimilar)] * len(self.trackers)
+        zs = [trk._stage_scan(sl, pruneSimilar=p) for trk, sl, p in zip(self.trackers, scanLists, ps)]
         self.step_dev([z.data_ptr() for z in zs], [int(z.shape[0]) for z in zs])
         for trk, sl in zip(self.trackers, scanLists):
             trk._after_step(sl, trk._staged_np, None)

@@ -263,9 +263,8 @@ class Tracker():
 
     def _stage_scan(self, scanList, aisList=None, **kwargs):
         """SectorGroup: checks + the scan in device memory (a torch tensor kept alive until the next scan)."""
-        if kwargs.get('pruneSimilar', False):
-            raise NotImplementedError("pruneSimilar is not available for the batched launches of a SectorGroup")
         z = self._accept_scan(scanList, aisList, kwargs)
+        self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))
         self._upload_scan(z)
         return self._staged[:z.shape[0]] if z.size else self._staged[:0]
 

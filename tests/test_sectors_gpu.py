@@ -170,3 +170,30 @@ def test_value_table_generations_with_similar_state_pruning(monkeypatch):
     assert r[0] >= 2, int(r[0])
     ref.close()
     small.close()
+
+
+def test_grouped_sectors_with_similar_state_pruning():
+    """Similar-state pruning (tracker.py:230-231) inside a group: members 0 and 2 prune on most scans, members 1 and 3 never; every
+    member must end up exactly where a single tracker with the same switch sequence does."""
+    from pymht_amd.sectors import SectorGroup
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    n_scans, S = 14, 4
+    scs = _sectors(S, n_scans, name="cfg2")
+    solo = [_tracker(sc) for sc in scs]
+    grouped = [_tracker(sc) for sc in scs]
+    grp = SectorGroup(grouped)
+    for k in range(n_scans):
+        flags = [(q % 2 == 0) and (k % 4 != 1) for q in range(S)]
+        lists = [MeasurementList(float(sc["times"][k]), sc["scans"][k]) for sc in scs]
+        for q in range(S):
+            solo[q].addMeasurementList(lists[q], pruneSimilar=flags[q])
+        grp.addMeasurementLists(lists, pruneSimilar=flags)
+        for q in range(S):
+            _same_state(grouped[q], solo[q], "scan %d sector %d" % (k, q))
+    for q in range(S):
+        la, lb = solo[q].leafBatch(), grouped[q].leafBatch()
+        for key in ("ID", "meas", "x", "cnllr", "P"):
+            assert np.array_equal(la[key], lb[key]), (q, key)
+    grp.close()
+    for t in solo + grouped:
+        t.close()
