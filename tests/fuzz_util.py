@@ -50,7 +50,9 @@ def run_case(seed, max_leaves=2000, budget_s=15.0, similar=False):
                       np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
                       states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
                       len(o.clusters) == len(trk.__clusterList__),
-                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"]),
+                      # (all leaves, not only the selected ones: 1e-5 -- a float32 chain born by the initiator starts an ulp off the
+                      # reference's and a few missed detections in a row carry a 3-ulp velocity difference into the position)
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=1e-5),
                       o.n_ilp == trk.nOptimSolved]
             if not all(checks):
                 return False, desc, 'MISMATCH at scan %d: gating %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))
