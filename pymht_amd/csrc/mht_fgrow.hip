@@ -157,7 +157,7 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 // cost, used-measurement byte; 3: path and ancestor records.  (One wavefront doing everything was a ~1500-instruction serial
 // stream, 2.9 us; what every role needs -- which hit, z_tilde, NIS, the score -- is recomputed by each.)
 template <typename TS, int PQ, typename ARGS>
-__device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, const unsigned long long* hwl,
+__device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, int nh, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
                                               double rootc, int root_f32) {
     const size_t cap = a.cap;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         double xo[4] = {g.xbar[0], g.xbar[1], g.xbar[2], g.xbar[3]};
         if (k > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xo[i] = (double)update_component<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt);
+            for (int i = 0; i < 4; ++i) xo[i] = (double)update_component_n<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt, nh == 1);      // (one hit: gemv, mht_math.h)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) a.ox[(size_t)i * cap + c] = xo[i];
@@ -236,8 +236,8 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         const int i0 = 2 * role, i1 = 2 * role + 1;
         double x0 = g.xbar[i0], x1 = g.xbar[i1];
         if (k > 0) {
-            x0 = (double)update_component<TS>((TS)g.xbar[i0], g.K[i0 * 2], g.K[i0 * 2 + 1], zt);
-            x1 = (double)update_component<TS>((TS)g.xbar[i1], g.K[i1 * 2], g.K[i1 * 2 + 1], zt);
+            x0 = (double)update_component_n<TS>((TS)g.xbar[i0], g.K[i0 * 2], g.K[i0 * 2 + 1], zt, nh == 1);
+            x1 = (double)update_component_n<TS>((TS)g.xbar[i1], g.K[i1 * 2], g.K[i1 * 2 + 1], zt, nh == 1);
         }
         a.ox[(size_t)i0 * cap + c] = x0;
         a.ox[(size_t)i1 * cap + c] = x1;
@@ -288,6 +288,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     int& s_total = s_misc[3];
     int* s_red = s_misc + 4;          // [4] per-wave partials of the alive prefix
     int* s_boxp = s_misc + 8;         // [2][4] per-wave gate boxes as sortable ints: min x, max x, min y, max y
+    int& s_live = s_misc[16];         // live leaves of a target with more than 64 leaf slots (only counted behind similar-state pruning)
 
     FG_STAMP(0);
     // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
@@ -318,6 +319,16 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     if (lane == 0) s_red[wave] = acc;      // (summed behind the first barrier below: nothing needs the index before the allocation)
     if (tid < 4 && tid >= FG_THREADS / 64) s_red[tid] = 0;
     const int depth0 = ti.depth, shift0 = ti.shift, cnt = ti.cnt, first = ti.first;
+    if (d.maybe_dead && cnt > 64) {      // (rare: the live count of a wide target is not in one wavefront's ballot)
+        if (tid == 0) s_live = 0;
+        __syncthreads();
+        int nl = 0;
+        for (int i = tid; i < cnt; i += FG_THREADS) nl += (a.flags[first + i] & F_DEAD) ? 0 : 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nl += __shfl_xor(nl, o);
+        if (lane == 0 && nl) atomicAdd(&s_live, nl);
+        __syncthreads();
+    }
     const int curw = a.cur_slot_base >> 6;      // first word of this scan's measurement nodes in the association bitset
 
     // ---- the target's children: count, take a block of the node index space, emit -------------------------------------------
@@ -395,15 +406,21 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+                // ONE live leaf in the target: the reference's per-target call hands a (4,4) x (4,1) product to BLAS gemv, whose rows are
+                // not FMA chains (mht_math.h::gemv_row).  Dead leaves (similar-state pruning, previous scan) do not count.
+                bool single = (cnt == 1);
+                if (d.maybe_dead && cnt > 1) single = (cnt <= 64) ? (__popcll(__ballot(valid)) == 1) : (s_live == 1);
                 if (g.f32state) {
                     float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
-                    state_predict<float>(mdl, xs, xb, zh);
+                    if (single) state_predict_single<float>(mdl, xs, xb, zh);
+                    else state_predict<float>(mdl, xs, xb, zh);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
                     g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
                 } else {
                     double xb[4], zh[2];
-                    state_predict<double>(mdl, xd, xb, zh);
+                    if (single) state_predict_single<double>(mdl, xd, xb, zh);
+                    else state_predict<double>(mdl, xd, xb, zh);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
                     g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
@@ -601,6 +618,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                         l = lo;
                     }
                     const int k = r - s_pref[l], c = base + run + r;
+                    const int nh = s_pref[l + 1] - s_pref[l] - 1;      // gated measurements of the leaf (lanes beyond the chunk carry the total)
                     // the leaf's record and the child's path / ancestor sources in ONE batch of wide LDS reads (field-by-field reads
                     // behind the branches below were ~40 dependent LDS round trips per child: 2 us)
                     FG_STAMPX(1);
@@ -611,8 +629,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                 }
                 run += ctot;
             }

@@ -332,6 +332,7 @@ struct Forest {
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
     long long blp_time_limit = 0;   // wall-clock budget per ILP in 10 ns ticks, 0 = none (mht_forest_set_blp_time_limit)
     float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
+    int similar_ran_scan = -100; // last scan prune_similar_kernel ran on: its children may carry F_DEAD when they are leaves (FDyn::maybe_dead)
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     bool no_enum = false;        // testing: MHT_BLP_NO_ENUM=1 at creation: no exact search for small clusters (branch and bound instead)
     // grid sizing without reports: the commit publishes {scan, targets alive} in a host-mapped word; with the births the host issued
@@ -905,6 +906,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         fill_fgrow(f, pl.s, pl.fused, g);
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr));
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
@@ -935,6 +937,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         SimilarArgs sa;
         fill_similar(f, pl.s, sa);
         MHT_STEP_CHECK(launch_prune_similar(ctx, sa, f->nT_ub_step));
+        f->similar_ran_scan = pl.s;
     }
     {
         BlpArgs b;
@@ -976,6 +979,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
         fill_fgrow(f, pl.s, pl.fused, g);
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         rc = launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr);
     }
     f->commit_pending = false;
@@ -989,6 +993,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
         SimilarArgs sa;
         fill_similar(f, pl.s, sa);
         rc = launch_prune_similar(ctx, sa, f->nT_ub_step);
+        f->similar_ran_scan = pl.s;
     }
     if (!rc) {
         BlpArgs b;
@@ -1163,6 +1168,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         FDyn& d = fb.d[i];
         d.z = z[i]; d.M = M[i]; d.W = pl[i].W;
         d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.maybe_dead = (f->similar_ran_scan == pl[i].s - 1);
         d.dbg = nullptr;
         fgrow_plan(d, pl[i].n_ub, f->Tcap, pl[i].fused);
         fb.ga[i] = g->ga + ((size_t)i * P + v) * 2 + (pl[i].fused ? 1 : 0);
@@ -1190,6 +1196,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
             SimilarArgs sa;
             fill_similar(f, pl[i].s, sa);
             rc = launch_prune_similar(c0, sa, f->nT_ub_step);
+            g->ctx[i]->forest->similar_ran_scan = pl[i].s;
         }
     }
     // ILPs in two LDS tiers: the small footprint (several workgroups per CU) takes the clusters that fit it and the single-target

@@ -52,7 +52,7 @@ __device__ __forceinline__ void phase1_leaf(const GateArgs& a, int i, const doub
 #pragma unroll
     for (int k = 0; k < 4; ++k) xs[k] = (TS)xd[k];
     Predicted<TS> p;
-    predict_precalc<TS>(a.model, xs, P, p);
+    predict_precalc<TS>(a.model, xs, P, p, a.L == 1);      // (one leaf in the call: NumPy's gemv order, mht_math.h::gemv_row)
 #pragma unroll
     for (int k = 0; k < 4; ++k) g.xbar[k] = (double)p.x_bar[k];
     g.zhat[0] = (double)p.z_hat[0];
@@ -121,7 +121,7 @@ __device__ __forceinline__ void emit_child(const GateArgs& a, const LeafLds& g, 
         TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, xb[4] = {(TS)g.xbar[0], (TS)g.xbar[1], (TS)g.xbar[2], (TS)g.xbar[3]};
         TS zt[2], nis, xh[4];
         gate_pair<TS>(zh, g.sinv, m.x, m.y, (TS)a.model.eta2, zt, nis);
-        update_state<TS>(xb, g.K, zt, xh);
+        update_state<TS>(xb, g.K, zt, xh, g.cnt == 1);      // (one gated measurement: matrix x column = gemv)
 #pragma unroll
         for (int q = 0; q < 4; ++q) a.ox[(size_t)q * cap + c] = (double)xh[q];
         const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19

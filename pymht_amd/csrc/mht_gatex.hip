@@ -36,7 +36,7 @@ __device__ __forceinline__ void gatex_leaf(const GateXArgs<NX>& a, int l) {
     for (int k = 0; k < NX; ++k) xs[k] = (TS)a.x[(size_t)k * L + l];
 #pragma unroll
     for (int e = 0; e < NX * NX; ++e) P[e] = a.P[(size_t)e * L + l];
-    predict_precalc_x<TS, NX>(a.model, xs, P, xb, zh, Pb, Ph, K, S, Si);
+    predict_precalc_x<TS, NX>(a.model, xs, P, xb, zh, Pb, Ph, K, S, Si, a.L == 1);      // (one leaf in the call: gemv order)
 #pragma unroll
     for (int k = 0; k < NX; ++k) a.x_bar[(size_t)k * L + l] = (double)xb[k];
 #pragma unroll
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void gatex_emit_kernel(const GateXArgs<NX> a) 
     const size_t L = a.L;
     const bool f32 = (a.flags[l] & F_STATE_F32) != 0;
     int base = a.row_ptr[l];
+    const bool one = a.row_ptr[l + 1] - base == 1;      // one gated measurement: np.matmul(K, z_tilde.T) is matrix x column = gemv
     double xb[NX];
     float K[2 * NX];
 #pragma unroll
@@ -151,11 +152,11 @@ __global__ __launch_bounds__(256) void gatex_emit_kernel(const GateXArgs<NX> a) 
                 if (f32) {
                     const float ztf[2] = {(float)zt[0], (float)zt[1]};
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) a.x_hat[(size_t)k * a.cap + c] = (double)update_component<float>((float)xb[k], K[2 * k], K[2 * k + 1], ztf);
+                    for (int k = 0; k < NX; ++k) a.x_hat[(size_t)k * a.cap + c] = (double)update_component_n<float>((float)xb[k], K[2 * k], K[2 * k + 1], ztf, one);
                     a.nllr[c] = (double)(0.5f * (float)nis + lnc);                 // kalman.py:19 (float32 chain)
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) a.x_hat[(size_t)k * a.cap + c] = update_component<double>(xb[k], K[2 * k], K[2 * k + 1], zt);
+                    for (int k = 0; k < NX; ++k) a.x_hat[(size_t)k * a.cap + c] = update_component_n<double>(xb[k], K[2 * k], K[2 * k + 1], zt, one);
                     a.nllr[c] = 0.5 * nis + (double)lnc;
                 }
             }

@@ -39,30 +39,32 @@ struct InitArgs {
     double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
 };
 
-// LU with partial pivoting of an n x n float32 system (n <= 4), as LAPACK sgetrf/sgetri order it closely enough: inverse by solving
-// for the unit columns
+// np.linalg.inv of an n x n float32 matrix (n <= 4): numpy.linalg computes in float64 and casts the result to float32 (mht_math.h:
+// inv2), so this is an LU with partial pivoting in double, inverse by solving for the unit columns, rounded once
 static __device__ inline bool inv_small(const float* a_in, int n, float* out) {
-    float a[16], b[16];
-    for (int i = 0; i < n * n; ++i) { a[i] = a_in[i]; b[i] = 0.f; }
-    for (int i = 0; i < n; ++i) b[i * n + i] = 1.f;
+    double a[16], b[16], x[16];
+    for (int i = 0; i < n * n; ++i) { a[i] = (double)a_in[i]; b[i] = 0.0; }
+    for (int i = 0; i < n; ++i) b[i * n + i] = 1.0;
     for (int c = 0; c < n; ++c) {
         int p = c;
-        float best = fabsf(a[c * n + c]);
-        for (int r = c + 1; r < n; ++r) if (fabsf(a[r * n + c]) > best) { best = fabsf(a[r * n + c]); p = r; }
-        if (best == 0.f) return false;
-        if (p != c) for (int k = 0; k < n; ++k) { float t = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = t; t = b[c * n + k]; b[c * n + k] = b[p * n + k]; b[p * n + k] = t; }
+        double best = fabs(a[c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabs(a[r * n + c]) > best) { best = fabs(a[r * n + c]); p = r; }
+        if (best == 0.0) return false;
+        if (p != c) for (int k = 0; k < n; ++k) { double t = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = t; t = b[c * n + k]; b[c * n + k] = b[p * n + k]; b[p * n + k] = t; }
+        const double rp = 1.0 / a[c * n + c];
         for (int r = c + 1; r < n; ++r) {
-            const float l = a[r * n + c] / a[c * n + c];
-            for (int k = c; k < n; ++k) a[r * n + k] = fmaf(-l, a[c * n + k], a[r * n + k]);
-            for (int k = 0; k < n; ++k) b[r * n + k] = fmaf(-l, b[c * n + k], b[r * n + k]);
+            const double l = a[r * n + c] * rp;
+            for (int k = c; k < n; ++k) a[r * n + k] = fma(-l, a[c * n + k], a[r * n + k]);
+            for (int k = 0; k < n; ++k) b[r * n + k] = fma(-l, b[c * n + k], b[r * n + k]);
         }
     }
     for (int col = 0; col < n; ++col)
         for (int r = n - 1; r >= 0; --r) {
-            float v = b[r * n + col];
-            for (int k = r + 1; k < n; ++k) v = fmaf(-a[r * n + k], out[k * n + col], v);
-            out[r * n + col] = v / a[r * n + r];
+            double v = b[r * n + col];
+            for (int k = r + 1; k < n; ++k) v = fma(-a[r * n + k], x[k * n + col], v);
+            x[r * n + col] = v / a[r * n + r];
         }
+    for (int i = 0; i < n * n; ++i) out[i] = (float)x[i];
     return true;
 }
 
@@ -205,7 +207,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             const float* x = a.pstate + (size_t)i * 4;
             const float* P = a.pcov + (size_t)i * 16;
             float xp[4], FP[16], Ft[16], Pb[16];
-            gemm_chain<float, float, float, 4, 4, 1>(F, x, xp);
+            for (int r = 0; r < 4; ++r) xp[r] = gemv_row<float, 4>(F + r * 4, x);      // F.dot(state): matrix x vector = BLAS gemv (m_of_n.py:187; mht_math.h::gemv_row)
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[r * 4 + c] = F[c * 4 + r];
             gemm_chain<float, float, float, 4, 4, 4>(F, P, FP);
             gemm_chain<float, float, float, 4, 4, 4>(FP, Ft, Pb);
@@ -237,7 +239,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             const float* xp = a.pred + (size_t)i * 4;
             const float* Pb = a.pcov + (size_t)i * 16;
             float zh[2], Ct[8], CP[8], S[4], Sinv[4];
-            gemm_chain<float, float, float, 2, 4, 1>(a.C, xp, zh);
+            for (int r = 0; r < 2; ++r) zh[r] = gemv_row<float, 4>(a.C + r * 4, xp);      // C.dot(predicted_state): gemv (m_of_n.py:283)
             for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
             gemm_chain<float, float, float, 2, 4, 4>(a.C, Pb, CP);
             gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, S);
@@ -267,10 +269,10 @@ static __device__ void initiator_body(const InitArgs& a) {
                 float* Pb = a.pcov + (size_t)i * 16;
                 const float* K = a.K + (size_t)i * 8;
                 float zh[2];
-                gemm_chain<float, float, float, 2, 4, 1>(a.C, xp, zh);
+                for (int r = 0; r < 2; ++r) zh[r] = gemv_row<float, 4>(a.C + r * 4, xp);      // m_of_n.py:302
                 const float dz[2] = {a.z[2 * j] - zh[0], a.z[2 * j + 1] - zh[1]};
                 float Kd[4], KC[16], KCP[16];
-                gemm_chain<float, float, float, 4, 2, 1>(K, dz, Kd);
+                for (int r = 0; r < 4; ++r) Kd[r] = gemv_row<float, 2>(K + r * 2, dz);      // K.dot(delta_vector): gemv, two separately rounded products (m_of_n.py:303)
                 for (int e = 0; e < 4; ++e) x[e] = xp[e] + Kd[e];
                 gemm_chain<float, float, float, 4, 2, 4>(K, a.C, KC);
                 gemm_chain<float, float, float, 4, 4, 4>(KC, Pb, KCP);
@@ -397,10 +399,13 @@ static __device__ void initiator_body(const InitArgs& a) {
                 for (int e = 0; e < 4; ++e) d[e] = a.pstate2[(size_t)p * 4 + e] - cand[e];
                 for (int e = 0; e < 16; ++e) S[e] = a.pcov2[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
                 if (inv_small(S, 4, Si)) {
+                    // deltaState.T.dot(S_inv).dot(deltaState) (m_of_n.py:207): vector x matrix = gemv (two interleaved FMA chains per
+                    // column, added), then vector . vector = sdot (float32 products summed in float64, one rounding at the end)
                     float t[4];
-                    for (int c = 0; c < 4; ++c) { float acc = d[0] * Si[c]; for (int k = 1; k < 4; ++k) acc = fmaf(d[k], Si[k * 4 + c], acc); t[c] = acc; }
-                    float sim = t[0] * d[0];
-                    for (int k = 1; k < 4; ++k) sim = fmaf(t[k], d[k], sim);
+                    for (int c = 0; c < 4; ++c) t[c] = fmaf(d[2], Si[8 + c], d[0] * Si[c]) + fmaf(d[3], Si[12 + c], d[1] * Si[4 + c]);
+                    double sacc = (double)(t[0] * d[0]);
+                    for (int k = 1; k < 4; ++k) sacc += (double)(t[k] * d[k]);
+                    const float sim = (float)sacc;
                     if (sim <= 1.0f) s_similar = 1;
                 }
             }

@@ -71,6 +71,7 @@ struct FDyn {
     int fused;                     // workgroup 0 runs the previous scan's commit (CommitDyn c)
     int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
+    int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
 };
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.

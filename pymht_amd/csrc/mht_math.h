@@ -64,36 +64,41 @@ struct Predicted {
     float S_inv[4];
 };
 
-// LU with partial pivoting of a 2x2 f32 matrix as LAPACK sgetrf does it (first maximum wins).
+// np.linalg.inv / np.linalg.det of a float32 matrix: numpy.linalg computes BOTH in float64 (its gufunc signature is 'd->d' for
+// every real dtype) and casts the result back to float32 (`ainv.astype(result_t)`), so S^-1 is the float64 LAPACK inverse of the
+// float32 S, rounded once -- for the CV model's diagonal S simply the correctly rounded 1 / S00.  (Rounds 1-2 ran the LU in
+// float32: identical for a diagonal S, off by ulps for a dense one -- found with the dense-R cases of tests/golden/g15_single.npz.)
+// The float64 operation order below is dgetf2's / dgetrs's (pivot = first maximum, reciprocal pivot scaling); at float64 precision
+// it cannot change the float32 result except on a ~1e-8 tie.
 struct LU2 {
-    float u00, u01, u11, l10;
+    double u00, u01, u11, l10;
     bool swapped;
 };
 MHT_HD LU2 lu2(const float* s) {
     LU2 f;
-    float a = s[0], b = s[1], c = s[2], d = s[3];
-    f.swapped = fabsf(c) > fabsf(a);
-    if (f.swapped) { float t = a; a = c; c = t; t = b; b = d; d = t; }
-    f.l10 = c / a;
+    double a = s[0], b = s[1], c = s[2], d = s[3];
+    f.swapped = fabs(c) > fabs(a);
+    if (f.swapped) { double t = a; a = c; c = t; t = b; b = d; d = t; }
+    f.l10 = c * (1.0 / a);
     f.u00 = a;
     f.u01 = b;
-    f.u11 = fmaf(-f.l10, b, d);
+    f.u11 = fma(-f.l10, b, d);
     return f;
 }
 
-// np.linalg.inv on one 2x2 (gesv with the identity as right-hand side)
+// np.linalg.inv on one 2x2 (dgesv with the identity as right-hand side, result cast to float32)
 MHT_HD void inv2(const float* s, float* out) {
-    LU2 f = lu2(s);
-    // solve for the two unit columns e0, e1 (row-swapped if pivoted)
+    const LU2 f = lu2(s);
+    const double r00 = 1.0 / f.u00, r11 = 1.0 / f.u11;
 #pragma unroll
     for (int col = 0; col < 2; ++col) {
-        float y0 = (col == 0) ? 1.0f : 0.0f, y1 = (col == 1) ? 1.0f : 0.0f;
-        if (f.swapped) { float t = y0; y0 = y1; y1 = t; }
-        y1 = fmaf(-f.l10, y0, y1);
-        float x1 = y1 / f.u11;
-        float x0 = fmaf(-f.u01, x1, y0) / f.u00;
-        out[0 + col] = x0;
-        out[2 + col] = x1;
+        double y0 = (col == 0) ? 1.0 : 0.0, y1 = (col == 1) ? 1.0 : 0.0;
+        if (f.swapped) { const double t = y0; y0 = y1; y1 = t; }
+        y1 = fma(-f.l10, y0, y1);
+        const double x1 = y1 * r11;
+        const double x0 = fma(-f.u01, x1, y0) * r00;
+        out[0 + col] = (float)x0;
+        out[2 + col] = (float)x1;
     }
 }
 
@@ -150,9 +155,42 @@ MHT_HD void state_predict(const Model& m, const TS* x, TS* x_bar, TS* z_hat) {
     gemm_chain<TS, float, TS, 2, 4, 1>(m.C, x_bar, z_hat);
 }
 
+// ---- ONE leaf / ONE hit: NumPy hands a matrix times a single column to BLAS gemv, not gemm --------------------------------------
+// `A.dot(x_0_list.T)` (kalman.py:60, :88) with ONE leaf in the call -- a target whose tree is a single hypothesis: every target in
+// its first scan, a target N-scan pruning or similar-state pruning cut down to one leaf -- is (4,4) x (4,1): numpy's
+// cblas_matrixproduct calls ?gemv for a matrix times a column, and OpenBLAS's gemv kernels (Haswell / SkylakeX / Zen, the same
+// code) do not accumulate a row in one FMA chain: every product is rounded on its own and the four are added pairwise, float64
+// (p0 + p2) + (p1 + p3), float32 (p0 + p1) + (p2 + p3); six terms (float64): the first four as before, + fma(a4, x4, a5 * x5).
+// Probed on the development host and on the GPU box's host (tools/probe/blas_order_probe.py); pinned by tests/golden/g15_single.npz,
+// recorded from the reference's kalman module.  For the CV model (rows like [1, 0, T, 0]) this is x + round(T v) instead of
+// fma(T, v, x): a last-bit difference in 3.5 % of the single-leaf predictions.
+template <typename TS, int K_>
+MHT_HD TS gemv_row(const float* a, const TS* x) {
+    static_assert(K_ == 2 || K_ == 4 || K_ == 6, "gemv_row: 2, 4 or 6 terms");
+    if (K_ == 2) {            // np.matmul(K_row, z_tilde.T) with one gated measurement (kalman.py:50): float64 fma(a0, x0, a1 * x1), float32 p0 + p1
+        if (sizeof(TS) == 8) return fmaT((TS)a[0], x[0], (TS)a[1] * x[1]);
+        return (TS)a[0] * x[0] + (TS)a[1] * x[1];
+    }
+    const TS p0 = (TS)a[0] * x[0], p1 = (TS)a[1] * x[1], p2 = (TS)a[2] * x[2], p3 = (TS)a[3] * x[3];
+    if (K_ == 4) return (sizeof(TS) == 8) ? (p0 + p2) + (p1 + p3) : (p0 + p1) + (p2 + p3);
+    // six terms.  float64: probed (all rows).  float32: the rows OpenBLAS's sgemv_t hands to its scalar tail loop add the six products
+    // one after the other; the vector kernel's rows are NOT reproduced (no float32 six-state chain exists: the initiator is 4-state)
+    if (sizeof(TS) == 8) return ((p0 + p2) + (p1 + p3)) + fmaT((TS)a[4], x[4], (TS)a[5] * x[5]);
+    return ((((p0 + p1) + p2) + p3) + (TS)a[4] * x[4]) + (TS)a[5] * x[5];
+}
+// x_bar, z_hat of the ONLY leaf of a call (see above)
 template <typename TS>
-MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predicted<TS>& o) {
-    state_predict<TS>(m, x, o.x_bar, o.z_hat);
+MHT_HD void state_predict_single(const Model& m, const TS* x, TS* x_bar, TS* z_hat) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x_bar[i] = gemv_row<TS, 4>(m.A + i * 4, x);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, 4>(m.C + i * 4, x_bar);
+}
+
+template <typename TS>
+MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predicted<TS>& o, bool single = false) {
+    if (single) state_predict_single<TS>(m, x, o.x_bar, o.z_hat);
+    else state_predict<TS>(m, x, o.x_bar, o.z_hat);
     CovChain c;
     cov_chain(m, P, c);
 #pragma unroll
@@ -164,16 +202,17 @@ MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predict
 }
 
 // kalman.py:19  ln( lambda_ex * sqrt(det(2 pi S)) / P_d ), evaluated in f32 exactly as NumPy evaluates it for an
-// f32 S: python floats are weak scalars (f32 arithmetic), det = sign * u00 * u11 of the pivoted LU factors,
-// sqrt and the divide are correctly rounded.  The final f32 log is NumPy's own SIMD polynomial, which is not
+// f32 S: python floats are weak scalars (f32 arithmetic), det = sign * u00 * u11 of the pivoted LU factors (in float64, cast to
+// float32: numpy.linalg works in double), sqrt and the divide are correctly rounded.  The final f32 log is NumPy's own SIMD polynomial, which is not
 // correctly rounded; here it is a double-precision log rounded to f32 (= correctly rounded), which differs
 // from NumPy's by at most 1 ulp(f32) (measured: 5 % of inputs, |delta| <= 4.8e-7).  DESIGN.md "NLLR tolerance".
 MHT_HD float nllr_const(const float* S, double lambda_ex, double P_d) {
     const float two_pi = (float)(2.0 * 3.141592653589793);
     float s2[4] = {S[0] * two_pi, S[1] * two_pi, S[2] * two_pi, S[3] * two_pi};
-    LU2 f = lu2(s2);
-    float det = f.u00 * f.u11;
-    if (f.swapped) det = -det;
+    const LU2 f = lu2(s2);                       // np.linalg.det: float64 LU of the float32 matrix, cast back to float32
+    double det64 = f.u00 * f.u11;
+    if (f.swapped) det64 = -det64;
+    const float det = (float)det64;
     float r = sqrtf(det);
     r = (float)lambda_ex * r;
     r = r / (float)P_d;
@@ -198,10 +237,20 @@ MHT_HD TS update_component(TS x_bar_i, float k0, float k1, const TS* zt) {
     acc = fmaT((TS)k1, zt[1], acc);
     return x_bar_i + acc;
 }
+// the same for a leaf with exactly ONE gated measurement: np.matmul(K, z_tilde.T) is then matrix x column = gemv (gemv_row<TS, 2>)
 template <typename TS>
-MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat) {
+MHT_HD TS update_component_single(TS x_bar_i, float k0, float k1, const TS* zt) {
+    const float kk[2] = {k0, k1};
+    return x_bar_i + gemv_row<TS, 2>(kk, zt);
+}
+template <typename TS>
+MHT_HD TS update_component_n(TS x_bar_i, float k0, float k1, const TS* zt, bool single_hit) {
+    return single_hit ? update_component_single<TS>(x_bar_i, k0, k1, zt) : update_component<TS>(x_bar_i, k0, k1, zt);
+}
+template <typename TS>
+MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat, bool single_hit = false) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_hat[i] = update_component<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt);
+    for (int i = 0; i < 4; ++i) x_hat[i] = update_component_n<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt, single_hit);
 }
 
 // ---- dimension-generic restatement (BASELINE config 5 names a 6-state model; the reference's kalman module is dimension-generic:
@@ -213,9 +262,16 @@ struct ModelX {
 };
 template <typename TS, int NX>
 MHT_HD void predict_precalc_x(const ModelX<NX>& m, const TS* x, const float* P, TS* x_bar, TS* z_hat, float* P_bar, float* P_hat,
-                              float* K, float* S, float* S_inv) {
-    gemm_chain<TS, float, TS, NX, NX, 1>(m.A, x, x_bar);              // kalman.py:61
-    gemm_chain<TS, float, TS, 2, NX, 1>(m.C, x_bar, z_hat);           // kalman.py:89
+                              float* K, float* S, float* S_inv, bool single = false) {
+    if (single) {             // one leaf in the call: gemv (gemv_row above)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x_bar[i] = gemv_row<TS, NX>(m.A + i * NX, x);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, NX>(m.C + i * NX, x_bar);
+    } else {
+        gemm_chain<TS, float, TS, NX, NX, 1>(m.A, x, x_bar);              // kalman.py:61
+        gemm_chain<TS, float, TS, 2, NX, 1>(m.C, x_bar, z_hat);           // kalman.py:89
+    }
     float AP[NX * NX], At[NX * NX], APA[NX * NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i)

@@ -1,9 +1,14 @@
 """Randomised parity scenarios (shared by tests/test_fuzz_gpu.py and tools/fuzz_parity.py): the drop-in Tracker (device forest, device
 initiator) against the oracle (NumPy restatement of the reference, its own initiator restatement) on a random small scenario --
 targets, area, clutter, N-scan window, detection probability, gate, radar period -- scan by scan."""
+import os
 import time
 
 import numpy as np
+
+# all-leaves state tolerance against the LIVE oracle (this host's BLAS): the north star's 1e-6; MHT_FUZZ_REL=0 demands bit equality
+# (holds where the host's OpenBLAS picks the kernels the device arithmetic follows: Haswell / SkylakeX / Zen)
+FUZZ_REL = float(os.environ.get("MHT_FUZZ_REL", "1e-6"))
 
 
 def scenario_of(seed):
@@ -50,9 +55,8 @@ def run_case(seed, max_leaves=2000, budget_s=15.0, similar=False):
                       np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
                       states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
                       len(o.clusters) == len(trk.__clusterList__),
-                      # (all leaves, not only the selected ones: 1e-5 -- a float32 chain born by the initiator starts an ulp off the
-                      # reference's and a few missed detections in a row carry a 3-ulp velocity difference into the position)
-                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=1e-5),
+                      # (ALL leaves, not only the selected ones, at the north star's 1e-6 -- against a live oracle on this host's BLAS)
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=FUZZ_REL),
                       o.n_ilp == trk.nOptimSolved]
             if not all(checks):
                 return False, desc, 'MISMATCH at scan %d: gating %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))

@@ -13,7 +13,7 @@ static void run(const Model& m, int n, int M, const double* x, const float* P, c
         TS xs[4];
         for (int k = 0; k < 4; ++k) xs[k] = (TS)x[i * 4 + k];
         Predicted<TS> p;
-        predict_precalc<TS>(m, xs, P + i * 16, p);
+        predict_precalc<TS>(m, xs, P + i * 16, p, n == 1);      // (ONE leaf in the call: NumPy's gemv order, like the kernels)
         for (int k = 0; k < 4; ++k) x_bar[i * 4 + k] = (double)p.x_bar[k];
         memcpy(P_bar + i * 16, p.P_bar, 64);
         memcpy(P_hat + i * 16, p.P_hat, 64);
@@ -22,13 +22,15 @@ static void run(const Model& m, int n, int M, const double* x, const float* P, c
         memcpy(K + i * 8, p.K, 32);
         float lnc = nllr_const(p.S, m.lambda_ex, P_d);
         TS eta2 = (TS)m.eta2;
+        int hits = 0;
+        for (int j = 0; j < M; ++j) { TS zt[2], v; hits += gate_pair<TS>(p.z_hat, p.S_inv, z[j * 2], z[j * 2 + 1], eta2, zt, v) ? 1 : 0; }
         for (int j = 0; j < M; ++j) {
             TS zt[2], v;
             bool g = gate_pair<TS>(p.z_hat, p.S_inv, z[j * 2], z[j * 2 + 1], eta2, zt, v);
             nis[(size_t)i * M + j] = (double)v;
             gate[(size_t)i * M + j] = g;
             TS xh[4];
-            update_state<TS>(p.x_bar, p.K, zt, xh);
+            update_state<TS>(p.x_bar, p.K, zt, xh, hits == 1);      // (ONE gated measurement: gemv)
             for (int k = 0; k < 4; ++k) x_hat[((size_t)i * M + j) * 4 + k] = (double)xh[k];
             TS half = (TS)0.5;
             nllr[(size_t)i * M + j] = (double)(half * v + (TS)lnc);
@@ -57,15 +59,17 @@ static void run6(const ModelX<6>& m, int n, int M, const double* x, const float*
         TS xs[6], xb[6], zh[2];
         for (int k = 0; k < 6; ++k) xs[k] = (TS)x[i * 6 + k];
         float Pb[36], Ph[36], Kk[12], Ss[4], Si[4];
-        predict_precalc_x<TS, 6>(m, xs, P + i * 36, xb, zh, Pb, Ph, Kk, Ss, Si);
+        predict_precalc_x<TS, 6>(m, xs, P + i * 36, xb, zh, Pb, Ph, Kk, Ss, Si, n == 1);
         for (int k = 0; k < 6; ++k) x_bar[i * 6 + k] = (double)xb[k];
         memcpy(P_bar + i * 36, Pb, 144); memcpy(P_hat + i * 36, Ph, 144);
         memcpy(S + i * 4, Ss, 16); memcpy(S_inv + i * 4, Si, 16); memcpy(K + i * 12, Kk, 48);
         const float lnc = nllr_const(Ss, m.lambda_ex, P_d);
+        int hits = 0;
+        for (int j = 0; j < M; ++j) { TS zt[2], v; hits += gate_pair<TS>(zh, Si, z[j * 2], z[j * 2 + 1], (TS)m.eta2, zt, v) ? 1 : 0; }
         for (int j = 0; j < M; ++j) {
             TS zt[2], v;
             gate[(size_t)i * M + j] = gate_pair<TS>(zh, Si, z[j * 2], z[j * 2 + 1], (TS)m.eta2, zt, v);
-            for (int k = 0; k < 6; ++k) x_hat[((size_t)i * M + j) * 6 + k] = (double)update_component<TS>(xb[k], Kk[2 * k], Kk[2 * k + 1], zt);
+            for (int k = 0; k < 6; ++k) x_hat[((size_t)i * M + j) * 6 + k] = (double)update_component_n<TS>(xb[k], Kk[2 * k], Kk[2 * k + 1], zt, hits == 1);
             nllr[(size_t)i * M + j] = (double)((TS)0.5 * v + (TS)lnc);
         }
     }

@@ -59,3 +59,36 @@ def test_gate_x_six_state_edge_shapes_vs_oracle(gpu_ctx, n, M, seed):
     if len(r["col_idx"]):
         assert np.allclose(r["x_hat"], np.concatenate(o["x_hat"], axis=0), rtol=1e-6, atol=1e-6)
         assert np.allclose(r["nllr"], np.concatenate(o["nllr"]), rtol=0, atol=NLLR_ATOL)
+
+
+def test_single_leaf_single_hit_orders_both_seams(gpu_ctx, gold_dir):
+    """g15 (oracle/gen_golden.py::gen_g15): ONE leaf per call / ONE gated measurement per leaf -- the shapes NumPy hands to BLAS gemv
+    instead of gemm (kalman.py:60, :88, :50), every target's first scan.  Known answers from the reference's kalman module, through
+    `mht_gate_scan_x` (4 and 6 states) and, for the 4-state groups, `mht_gate_scan`: bit for bit, dense-R variants included (S^-1 of a
+    non-diagonal S is numpy.linalg's float64 inverse rounded to float32)."""
+    from pymht_amd.device import make_model, process_leaf_nodes, process_leaf_nodes_x
+    g = np.load(os.path.join(gold_dir, "g15_single.npz"))
+    eta2, lam, pd = float(g["eta2"]), float(g["lambda_ex"]), float(g["P_d"])
+    n_one = 0
+    for grp in range(int(g["n_groups"])):
+        k = lambda s: g["g%d_%s" % (grp, s)]
+        nx, X, Pin, Z, Mi = int(k("nx")), k("x"), k("P"), k("z"), k("M")
+        model4 = make_model(k("A"), k("Q"), k("C"), k("R"), eta2, lam, pd) if nx == 4 else None
+        for c in range(X.shape[0]):
+            M = int(Mi[c])
+            x, P, z = X[c:c + 1], Pin[c:c + 1], Z[c, :M]
+            gate = k("gate")[c, :M]
+            want_idx = np.nonzero(gate)[0]
+            want_xhat = k("x_hat")[c, :M][gate].astype(np.float64)
+            rs = [process_leaf_nodes_x(gpu_ctx, k("A"), k("Q"), k("C"), k("R"), eta2, lam, x, P, np.full(1, pd), flags_for(x), z)]
+            if model4 is not None:
+                rs.append(process_leaf_nodes(gpu_ctx, model4, x, P, np.zeros(1), np.full(1, pd), flags_for(x), z))
+            for r in rs:
+                assert np.array_equal(r["col_idx"], want_idx), (grp, c)
+                assert np.array_equal(r["x_bar"][0], k("x_bar")[c].astype(np.float64)), (grp, c)
+                assert np.array_equal(r["P_hat"][0], k("P_hat")[c]), (grp, c)
+                assert np.array_equal(r["x_hat"], want_xhat), (grp, c, len(want_idx))
+                assert np.allclose(r["nllr"], k("nllr")[c, :M][gate], rtol=0, atol=NLLR_ATOL), (grp, c)
+            assert np.array_equal(rs[0]["S_inv"][0], k("S_inv")[c]) and np.array_equal(rs[0]["K"][0], k("K")[c]), (grp, c)
+            n_one += int(len(want_idx) == 1)
+    assert n_one > 300

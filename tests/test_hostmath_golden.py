@@ -84,3 +84,38 @@ def test_sum1d_is_numpys_reduction(hostmath):
             assert hostmath.mht_host_sum1d_f64(_p(a), n) == float(np.add.reduce(a)), n
             b = a.astype(np.float32)
             assert np.float32(hostmath.mht_host_sum1d_f32(_p(b), n)) == np.add.reduce(b), n
+
+
+def test_single_leaf_single_hit_orders(gold_dir, hostmath):
+    """g15: calls with ONE leaf / leaves with ONE gated measurement, where NumPy hands the product to BLAS gemv (not gemm) and the rows
+    are not FMA chains (mht_math.h::gemv_row).  Known answers from the reference's own kalman module, 4-state (both state dtypes, CV
+    model and a dense-R variant) and 6-state (float64): x_bar, S^-1, K, P_hat, gating and x_hat bit for bit."""
+    g = np.load(os.path.join(gold_dir, "g15_single.npz"))
+    n_single_hit = 0
+    for grp in range(int(g["n_groups"])):
+        k = lambda s: g["g%d_%s" % (grp, s)]
+        nx = int(k("nx"))
+        X, Pin, Z, Mi = k("x"), k("P"), k("z"), k("M")
+        f32 = X.dtype == np.float32
+        for c in range(X.shape[0]):
+            M = int(Mi[c])
+            z = np.ascontiguousarray(Z[c, :M])
+            xd = np.ascontiguousarray(X[c:c + 1], dtype=np.float64)
+            P = np.ascontiguousarray(Pin[c:c + 1])
+            o = dict(x_bar=np.zeros((1, nx)), P_bar=np.zeros((1, nx, nx), np.float32), P_hat=np.zeros((1, nx, nx), np.float32),
+                     S=np.zeros((1, 2, 2), np.float32), S_inv=np.zeros((1, 2, 2), np.float32), K=np.zeros((1, nx, 2), np.float32),
+                     nis=np.zeros((1, M)), gate=np.zeros((1, M), np.uint8), x_hat=np.zeros((1, M, nx)), nllr=np.zeros((1, M)))
+            args = [_p(np.ascontiguousarray(k("A"))), _p(np.ascontiguousarray(k("Q"))), _p(np.ascontiguousarray(k("C"))), _p(np.ascontiguousarray(k("R"))),
+                    C.c_double(float(g["eta2"])), C.c_double(float(g["lambda_ex"])), int(f32), 1, M, _p(xd), _p(P), _p(z), C.c_double(float(g["P_d"]))]
+            if nx == 4:
+                hostmath.mht_host_process(*args, *[_p(o[q]) for q in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K", "nis", "gate", "x_hat", "nllr")])
+            else:
+                hostmath.mht_host_process_x6(*args, *[_p(o[q]) for q in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K", "gate", "x_hat", "nllr")])
+            assert np.array_equal(o["x_bar"][0], k("x_bar")[c].astype(np.float64)), (grp, c)
+            assert np.array_equal(o["S_inv"][0], k("S_inv")[c]) and np.array_equal(o["K"][0], k("K")[c]) and np.array_equal(o["P_hat"][0], k("P_hat")[c]), (grp, c)
+            gate = k("gate")[c, :M]
+            assert np.array_equal(o["gate"][0].astype(bool), gate), (grp, c)
+            assert np.array_equal(o["x_hat"][0][gate], k("x_hat")[c, :M][gate].astype(np.float64)), (grp, c, int(gate.sum()))
+            assert np.allclose(o["nllr"][0][gate], k("nllr")[c, :M][gate], rtol=0, atol=NLLR_ATOL), (grp, c)
+            n_single_hit += int(gate.sum() == 1)
+    assert n_single_hit > 300

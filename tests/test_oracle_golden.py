@@ -64,7 +64,8 @@ def test_blp_exact_survives_the_instance_that_crashes_highs_presolve():
     assert sel == sorted(bs) == [2, 8] and ties == 1 and abs(obj - bo) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3"])
+@pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3",
+                                  "g16_fgrow_kat"])
 def test_scan_trace_replay(gold_dir, name):
     """Replays the recorded scans through OracleTracker and compares every scan with what the reference did."""
     from trace_util import replay_oracle

@@ -26,15 +26,16 @@ def states_close(a, b, rel=1e-6):
     return bool(np.all(np.abs(a - b) <= rel * scale))
 
 
-def make_tracker(period, lambda_phi, lambda_nu, P_d, N, eta2, x0, t0, **kw):
+def make_tracker(period, lambda_phi, lambda_nu, P_d, N, eta2, x0, t0, P0s=None, x0_f32=None, **kw):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
     from pymht_amd.models import pv
     trk = Tracker(pv, period, lambda_phi, lambda_nu, P_d=P_d, N=N, eta2=eta2, **kw)
     acc = []
-    for x in x0:
+    for i, x in enumerate(x0):
         n0 = len(trk.__targetList__)
-        trk.initiateTarget(Target(t0, None, x.copy(), pv.P0, status="preinitialized"))
+        xr = x.astype(np.float32) if (x0_f32 is not None and x0_f32[i]) else x.copy()      # (g16: float32 roots, own covariances)
+        trk.initiateTarget(Target(t0, None, xr, pv.P0 if P0s is None else np.array(P0s[i], dtype=np.float32), status="preinitialized"))
         acc.append(len(trk.__targetList__) > n0)
     return trk, acc
 
@@ -48,12 +49,17 @@ def tracker_selected(trk):
 
 
 @pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long",
-                                  "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3"])
+                                  "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3", "g16_fgrow_kat"])
 def test_tracker_replays_reference_trace(name, gold_dir):
+    """Every scan of a trace recorded from the real reference: gating counts, unused measurements, selections, clusters, target lists,
+    terminations -- and the states and covariances of ALL leaves bit for bit (np.array_equal, or sha-256 over all leaves for the hashed
+    traces), both dtype chains, births of the device initiator included.  g16 is the known-answer trace of fgrow_kernel itself: roots
+    with their own covariances and float32 states (oracle/gen_golden.py::gen_g16)."""
     from pymht_amd.utils.classDefinitions import MeasurementList
     g = np.load(os.path.join(gold_dir, name + ".npz"))
     trk, acc = make_tracker(float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), float(g["P_d"]),
-                            int(g["N"]), float(g["eta2"]), g["x0"], float(g["t0"]))
+                            int(g["N"]), float(g["eta2"]), g["x0"], float(g["t0"]),
+                            P0s=g["P0s"] if "P0s" in g.files else None, x0_f32=g["x0_f32"] if "x0_f32" in g.files else None)
     assert acc == [bool(a) for a in g["accepted"]]
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
