@@ -219,6 +219,10 @@ typedef struct mht_scan_report {
     int32_t used_words;    /* number of valid words in `used` */
     int32_t n_births;      /* candidates of the device initiator after this scan (0 without mht_forest_initiate) */
     int32_t pad[2];
+    /* device time of the scan's stages in 10 ns ticks of the GPU's wall clock, stamped by the kernels themselves (no HIP events, no
+     * host cost): t_process = grow launch (tracker.py toc['Process']), t_cluster (toc['Cluster']), t_optim = similar-state pruning +
+     * ILPs + termination / N-scan prune decisions (toc['Optim']), t_scan = start of the grow launch .. end of the last ILP workgroup */
+    int32_t t_process, t_cluster, t_optim, t_scan;
     const uint64_t* used;              /* host: bit j set iff measurement j was gated by some leaf */
     const mht_target_report* targets;  /* host: n_targets records */
     const mht_birth_report* births;    /* host: n_births records */

@@ -46,7 +46,8 @@ class MhtScanReport(C.Structure):
     _fields_ = [("scan", C.c_int32), ("n_targets", C.c_int32), ("n_alive", C.c_int32), ("n_leaves_in", C.c_int32),
                 ("n_children", C.c_int32), ("n_leaves_out", C.c_int32), ("n_clusters", C.c_int32), ("n_ilp", C.c_int32),
                 ("n_branched", C.c_int32), ("n_limit", C.c_int32), ("blp_iters_max", C.c_int32), ("error", C.c_int32),
-                ("used_words", C.c_int32), ("n_births", C.c_int32), ("pad", C.c_int32 * 2), ("used", C.c_void_p),
+                ("used_words", C.c_int32), ("n_births", C.c_int32), ("pad", C.c_int32 * 2),
+                ("t_process", C.c_int32), ("t_cluster", C.c_int32), ("t_optim", C.c_int32), ("t_scan", C.c_int32), ("used", C.c_void_p),
                 ("targets", C.c_void_p), ("births", C.c_void_p)]
 
 

@@ -1895,9 +1895,22 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
     }
 }
 
+// stage stamps of the scan (DevStatus::t, forest only): [2] = start of the first ILP launch, [4] = end of the last ILP workgroup
+__device__ __forceinline__ void blp_stamp_begin(const BlpArgs& a, int bx) {
+    if (a.status && bx == 0 && threadIdx.x == 0) {
+        DevStatus* st = const_cast<DevStatus*>(a.status);
+        if (st->t[2] == 0) st->t[2] = wall_clock64();
+    }
+}
+__device__ __forceinline__ void blp_stamp_end(const BlpArgs& a) {
+    if (a.status && threadIdx.x == 0) atomicMax(&const_cast<DevStatus*>(a.status)->t[4], (unsigned long long)wall_clock64());
+}
+
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    blp_stamp_begin(a, blockIdx.x);
     blp_body(a, lds, blockIdx.x, gridDim.x);
+    blp_stamp_end(a);
 }
 // a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out
 // sector-interleaved in dispatch order (blockIdx.x fastest): the first n * nMulti workgroups to reach the machine are the ones that
@@ -1909,7 +1922,9 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av)
     const int n = gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
     const int sector = lin % n, bx = lin / n;
     load_args(a, static_cast<const BlpArgs*>(av.p[sector]));
+    blp_stamp_begin(a, bx);
     blp_body(a, lds, bx, gridDim.x);
+    blp_stamp_end(a);
 }
 
 // Cluster-sharded trackers (several devices hold identical forests and solve disjoint sets of clusters): after the selections have
@@ -1928,6 +1943,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_epilogue_kernel(const BlpArgs
         const int key = finish_target(a, t, s, pre, lane == 0);
         sweep_survivors(a, t, pre.j, pre.cb, pre.ce, key, va0, lane);
     }
+    blp_stamp_end(a);
 }
 
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
         for (int q = 0; q < CL_SPEC / 16; ++q) spec[q] = a.edges_in[(size_t)sg * a.seg_cap + l16 + 16 * q];
     }
     if (s_over) return;       // a pool overflowed in grow_kernel: the scan is void (commit reports it)
+    if (a.status && tid == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     if (a.status_other && tid == 0) { a.status_other->overflow = 0; a.status_other->n_children = 0; a.status_other->n_dead = 0; }      // the scan after this one starts from a clean word
     const unsigned long long t0 = wall_clock64();
 #define CL_STAMP(q) do { if (a.dbg && tid == 0) a.dbg[q] = (int)(wall_clock64() - t0); } while (0)

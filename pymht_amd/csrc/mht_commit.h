@@ -32,6 +32,7 @@ struct TTable {           // one buffer of the target table
 struct ReportHeader {     // device image of mht_scan_report up to the host pointers
     int32_t scan, n_targets, n_alive, n_leaves_in, n_children, n_leaves_out, n_clusters, n_ilp, n_branched, n_limit,
         blp_iters_max, error, used_words, n_births, pad[2];
+    int32_t t_process, t_cluster, t_optim, t_scan;      // device time of the stages in 10 ns ticks (mht_scan_report)
 };
 
 struct CommitDyn { int scan, M, W; };      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
@@ -83,6 +84,7 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
             h.scan = dyn.scan; h.n_targets = 0; h.n_alive = 0; h.n_leaves_in = a.cur.leaf_off[nT];
             h.n_children = nCh; h.n_leaves_out = 0; h.n_clusters = 0; h.n_ilp = 0; h.n_branched = 0; h.n_limit = 0;
             h.blp_iters_max = 0; h.error = (s_over == 2) ? MHT_E_HIP : MHT_E_CAPACITY; h.used_words = 0;
+            h.t_process = h.t_cluster = h.t_optim = h.t_scan = 0;
             a.cnt->overflow = 1;
         }
         return;
@@ -182,6 +184,12 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
         h.error = e_over ? MHT_E_CAPACITY : 0;
         h.used_words = dyn.W;
         h.n_births = 0;
+        {   // per-stage device times (tracker.py:192-294 keeps toc['Process'], ['Cluster'], ['Optim'] per scan): from the stamps of the launches
+            const unsigned long long t0 = a.status->t[0], t1 = a.status->t[1], t2 = a.status->t[2], t3 = a.status->t[3], t4 = a.status->t[4];
+            const unsigned long long to = (t3 && t3 < t2) ? t3 : t2;      // the optimisation stage starts with similar-state pruning when it ran
+            auto ticks = [](unsigned long long b, unsigned long long e) { return (e > b && e - b < 0x7fffffffull) ? (int32_t)(e - b) : 0; };
+            h.t_process = ticks(t0, t1); h.t_cluster = ticks(t1, to); h.t_optim = ticks(to, t4); h.t_scan = ticks(t0, t4);
+        }
         a.cnt->L_in = L_in;
         a.cnt->n_children = nCh;
         a.cnt->nT = nAlive;

@@ -74,6 +74,10 @@ struct DevStatus {
     int n_children;     // children produced by the last gate
     int n_dead;         // forest: leaves the grow kernel skipped because similar-state pruning had taken them out of the tree
     int pad[1];
+    // forest: device wall-clock stamps of the scan's stages (s_memrealtime, 10 ns ticks), written by thread 0 of the first workgroup of
+    // each launch: [0] grow start, [1] cluster start, [2] first ILP launch start, [3] similar-state pruning start (0: did not run),
+    // [4] end of the last ILP workgroup (atomic max).  The commit turns them into the report's per-stage times (mht_scan_report).
+    unsigned long long t[6];
 };
 
 struct Forest;

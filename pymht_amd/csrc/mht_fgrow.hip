@@ -261,6 +261,33 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     FG_STAMPX(6);
 }
 
+// the prediction of a target's ONLY leaf, in BLAS gemv order (see target_part)
+template <typename ARGS>
+__device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32state, FLeaf& out) {
+    Model mdl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+    double xd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+    double xb[4], zh[2];
+    if (f32state) {
+        float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xbf[4], zhf[2];
+        state_predict_single<float>(mdl, xs, xbf, zhf);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xb[k] = (double)xbf[k];
+        zh[0] = (double)zhf[0]; zh[1] = (double)zhf[1];
+    } else {
+        state_predict_single<double>(mdl, xd, xb, zh);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out.xbar[k] = xb[k];
+    out.zhat[0] = zh[0]; out.zhat[1] = zh[1];
+    out.zhx = (float)zh[0]; out.zhy = (float)zh[1];
+}
+
 // PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
 // a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
 // edge of its budget (128 for four workgroups per CU in the batched launch).
@@ -406,21 +433,15 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
-                // ONE live leaf in the target: the reference's per-target call hands a (4,4) x (4,1) product to BLAS gemv, whose rows are
-                // not FMA chains (mht_math.h::gemv_row).  Dead leaves (similar-state pruning, previous scan) do not count.
-                bool single = (cnt == 1);
-                if (d.maybe_dead && cnt > 1) single = (cnt <= 64) ? (__popcll(__ballot(valid)) == 1) : (s_live == 1);
                 if (g.f32state) {
                     float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
-                    if (single) state_predict_single<float>(mdl, xs, xb, zh);
-                    else state_predict<float>(mdl, xs, xb, zh);
+                    state_predict<float>(mdl, xs, xb, zh);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
                     g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
                 } else {
                     double xb[4], zh[2];
-                    if (single) state_predict_single<double>(mdl, xd, xb, zh);
-                    else state_predict<double>(mdl, xd, xb, zh);
+                    state_predict<double>(mdl, xd, xb, zh);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
                     g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
@@ -439,6 +460,10 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 g.pad = 0;
                 g.cid = cid;
                 if (keep) lg[tid] = g;
+                if (d.maybe_dead && cnt > 1 && cnt <= 64 && wave == 0) {      // live leaves of the target (cnt > 64: counted up front)
+                    const int nl = __popcll(__ballot(valid));
+                    if (lane == 0) s_live = nl;
+                }
                 // bounding box of the target's gates (its leaves sit within a few hundred metres of each other): the scan is first
                 // cut down to the measurements inside it
                 float lox = zhx - bx, hix = zhx + bx, loy = zhy - by, hiy = zhy + by;
@@ -455,6 +480,16 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             }
             __syncthreads();
             FG_STAMP(2);
+            // ONE live leaf in the target: the reference's per-target call hands a (4,4) x (4,1) product to BLAS gemv, whose rows are
+            // not FMA chains (mht_math.h::gemv_row; dead leaves -- similar-state pruning, previous scan -- do not count).  Rare (a
+            // target's first scan): the leaf's prediction is redone here, outside phase 1's register peak, from a second load of its
+            // state; phase 2 (b) reads it behind the next barrier.  (The gate boxes come from the FMA-chain prediction: an ulp away,
+            // well inside their widening.)
+            if (__builtin_amdgcn_readfirstlane((cnt == 1 || (d.maybe_dead && cnt > 1 && s_live == 1)) ? 1 : 0) && tid < n) {
+                const int src1 = first + c0 + tid;
+                const uint8_t fl1 = a.flags[src1];
+                if (!(fl1 & F_DEAD)) fg_single_leaf(a, src1, (fl1 & F_STATE_F32) != 0, lg[tid]);
+            }
             // ---- phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront) -----
             if (last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));      // (the bitset was cleared in front of the barrier)
             const int x0 = min(s_boxp[0], s_boxp[4]), x1 = max(s_boxp[1], s_boxp[5]);
@@ -660,11 +695,17 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w) {
 template <int PQ, int CAP, typename CARGS>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
+    // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
+    // register budget -- the commit workgroup (first of the launch) or, without one, the first chain workgroup (the whole launch is
+    // co-resident: it starts within a microsecond of the first target workgroup)
+    auto stamp = [&]() {
+        if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
+    };
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
-        if (bid == 0) { commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, reinterpret_cast<int*>(smem)); return; }
+        if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, reinterpret_cast<int*>(smem)); return; }
         bid -= 1;
     }
-    if (bid >= d.n_main) { chain_part(*ap, d, bid - d.n_main); return; }
+    if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part(*ap, d, bid - d.n_main); return; }
     target_part<PQ, CAP>(ap, d, bid, smem);
 }
 

@@ -332,6 +332,7 @@ struct Forest {
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
     long long blp_time_limit = 0;   // wall-clock budget per ILP in 10 ns ticks, 0 = none (mht_forest_set_blp_time_limit)
     float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
+    int in_groups = 0;           // mht_group_create snapshots the ILP argument blocks of its members: settings behind them are frozen while > 0
     int similar_ran_scan = -100; // last scan prune_similar_kernel ran on: its children may carry F_DEAD when they are leaves (FDyn::maybe_dead)
     bool force_hbm = false;      // testing: MHT_BLP_FORCE_HBM=1 at creation runs every ILP through the HBM storage policy
     bool no_enum = false;        // testing: MHT_BLP_NO_ENUM=1 at creation: no exact search for small clusters (branch and bound instead)
@@ -1040,6 +1041,7 @@ struct mht_group {
     BlpArgs* bl0 = nullptr;       // [n][period]: one launch, default footprint
     size_t blp_lds[3] = {0, 0, 0};
     bool two_tier = false;        // development: MHT_BLP_TWO_TIER=1
+    bool counted = false;         // the members' in_groups counters include this group
 };
 
 extern "C" int mht_group_destroy(mht_group* g) {
@@ -1048,6 +1050,7 @@ extern "C" int mht_group_destroy(mht_group* g) {
         (void)hipSetDevice(g->ctx[0]->device);
         (void)hipStreamSynchronize(g->ctx[0]->stream);
     }
+    for (int i = 0; i < g->n; ++i) if (g->counted && g->ctx[i] && g->ctx[i]->forest) g->ctx[i]->forest->in_groups -= 1;
     if (g->ga) (void)hipFree(g->ga);
     if (g->ca) (void)hipFree(g->ca);
     if (g->cl) (void)hipFree(g->cl);
@@ -1117,6 +1120,8 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
         (void)mht_group_destroy(g);
         return MHT_E_HIP;
     }
+    for (int i = 0; i < n; ++i) ctxs[i]->forest->in_groups += 1;
+    g->counted = true;
     *out = g;
     return MHT_OK;
 }
@@ -1407,6 +1412,10 @@ static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out
 extern "C" int mht_forest_set_blp_time_limit(mht_ctx* ctx, double milliseconds) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_blp_time_limit: no forest");
     MHT_REQUIRE(!(milliseconds != milliseconds), "mht_forest_set_blp_time_limit: NaN");
+    if (ctx->forest->in_groups > 0) {      // (mht_group_step reads the limit from argument blocks written at mht_group_create: it would be ignored silently)
+        set_error("mht_forest_set_blp_time_limit: the forest is a member of a group; set the limit before mht_group_create");
+        return MHT_E_STATE;
+    }
     ctx->forest->blp_time_limit = milliseconds > 0.0 ? (long long)(milliseconds * 1e5) : 0;
     return MHT_OK;
 }

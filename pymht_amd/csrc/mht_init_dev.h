@@ -39,32 +39,53 @@ struct InitArgs {
     double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
 };
 
-// np.linalg.inv of an n x n float32 matrix (n <= 4): numpy.linalg computes in float64 and casts the result to float32 (mht_math.h:
-// inv2), so this is an LU with partial pivoting in double, inverse by solving for the unit columns, rounded once
-static __device__ inline bool inv_small(const float* a_in, int n, float* out) {
-    double a[16], b[16], x[16];
-    for (int i = 0; i < n * n; ++i) { a[i] = (double)a_in[i]; b[i] = 0.0; }
-    for (int i = 0; i < n; ++i) b[i * n + i] = 1.0;
+// np.linalg.inv of the 4 x 4 float32 matrix of PreliminaryTrack.compareSimilarity (m_of_n.py:205-206): numpy.linalg computes in
+// float64 and casts the result to float32 (mht_math.h: inv2).  The covariances of this initiator come from pv.P0 through pv.Phi / pv.Q
+// and the radar update only (m_of_n.py:268-269, :304, :449): x and y never couple, the eight cross entries are EXACT zeros, and LAPACK's
+// LU of such a matrix is its LU of the two 2 x 2 blocks {0, 2} and {1, 3} (the other operations multiply by or add an exact zero).  So:
+// two float64 2 x 2 inverses, rounded once.  A matrix with a non-zero cross entry (not reachable with the reference's model) takes
+// the float32 elimination of rounds 1-2 (a decision test only: d' S^-1 d <= 1).
+// LU with partial pivoting of an n x n float32 system (n <= 4), as LAPACK sgetrf/sgetri order it closely enough: inverse by solving
+// for the unit columns
+static __device__ inline bool inv_small_f32(const float* a_in, int n, float* out) {
+    float a[16], b[16];
+    for (int i = 0; i < n * n; ++i) { a[i] = a_in[i]; b[i] = 0.f; }
+    for (int i = 0; i < n; ++i) b[i * n + i] = 1.f;
     for (int c = 0; c < n; ++c) {
         int p = c;
-        double best = fabs(a[c * n + c]);
-        for (int r = c + 1; r < n; ++r) if (fabs(a[r * n + c]) > best) { best = fabs(a[r * n + c]); p = r; }
-        if (best == 0.0) return false;
-        if (p != c) for (int k = 0; k < n; ++k) { double t = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = t; t = b[c * n + k]; b[c * n + k] = b[p * n + k]; b[p * n + k] = t; }
-        const double rp = 1.0 / a[c * n + c];
+        float best = fabsf(a[c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabsf(a[r * n + c]) > best) { best = fabsf(a[r * n + c]); p = r; }
+        if (best == 0.f) return false;
+        if (p != c) for (int k = 0; k < n; ++k) { float t = a[c * n + k]; a[c * n + k] = a[p * n + k]; a[p * n + k] = t; t = b[c * n + k]; b[c * n + k] = b[p * n + k]; b[p * n + k] = t; }
         for (int r = c + 1; r < n; ++r) {
-            const double l = a[r * n + c] * rp;
-            for (int k = c; k < n; ++k) a[r * n + k] = fma(-l, a[c * n + k], a[r * n + k]);
-            for (int k = 0; k < n; ++k) b[r * n + k] = fma(-l, b[c * n + k], b[r * n + k]);
+            const float l = a[r * n + c] / a[c * n + c];
+            for (int k = c; k < n; ++k) a[r * n + k] = fmaf(-l, a[c * n + k], a[r * n + k]);
+            for (int k = 0; k < n; ++k) b[r * n + k] = fmaf(-l, b[c * n + k], b[r * n + k]);
         }
     }
     for (int col = 0; col < n; ++col)
         for (int r = n - 1; r >= 0; --r) {
-            double v = b[r * n + col];
-            for (int k = r + 1; k < n; ++k) v = fma(-a[r * n + k], x[k * n + col], v);
-            x[r * n + col] = v / a[r * n + r];
+            float v = b[r * n + col];
+            for (int k = r + 1; k < n; ++k) v = fmaf(-a[r * n + k], out[k * n + col], v);
+            out[r * n + col] = v / a[r * n + r];
         }
-    for (int i = 0; i < n * n; ++i) out[i] = (float)x[i];
+    return true;
+}
+
+
+static __device__ inline bool inv_small(const float* s, int n, float* out) {
+    if (n != 4 || s[1] != 0.f || s[3] != 0.f || s[4] != 0.f || s[6] != 0.f || s[9] != 0.f || s[11] != 0.f || s[12] != 0.f || s[14] != 0.f)
+        return inv_small_f32(s, n, out);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float m[4] = {s[blk * 5], s[blk * 5 + 2], s[blk * 5 + 8], s[blk * 5 + 10]};      // rows / columns {blk, blk + 2}
+        if (m[0] == 0.f && m[2] == 0.f) return false;
+        float r[4];
+        inv2(m, r);
+        out[blk * 5] = r[0]; out[blk * 5 + 2] = r[1]; out[blk * 5 + 8] = r[2]; out[blk * 5 + 10] = r[3];
+    }
     return true;
 }
 

@@ -243,9 +243,15 @@ MHT_HD TS update_component_single(TS x_bar_i, float k0, float k1, const TS* zt) 
     const float kk[2] = {k0, k1};
     return x_bar_i + gemv_row<TS, 2>(kk, zt);
 }
+// either order from one multiply and one FMA (the kernels' emission is at the edge of its register budget: no second code path).
+// gemm: fma(k1, z1, k0 * z0).  gemv, float64: fma(k0, z0, k1 * z1); float32: k0 * z0 + k1 * z1 = fma(1, k0 * z0, k1 * z1) -- exact product
+// of 1 and an already rounded number, so the FMA rounds once, like the addition.
 template <typename TS>
 MHT_HD TS update_component_n(TS x_bar_i, float k0, float k1, const TS* zt, bool single_hit) {
-    return single_hit ? update_component_single<TS>(x_bar_i, k0, k1, zt) : update_component<TS>(x_bar_i, k0, k1, zt);
+    const TS p = single_hit ? (TS)k1 * zt[1] : (TS)k0 * zt[0];
+    TS a = single_hit ? (TS)k0 : (TS)k1, b = single_hit ? zt[0] : zt[1];
+    if (sizeof(TS) == 4 && single_hit) { a = (TS)1; b = (TS)k0 * zt[0]; }
+    return x_bar_i + fmaT(a, b, p);
 }
 template <typename TS>
 MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat, bool single_hit = false) {

@@ -102,6 +102,7 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
 
 __global__ __launch_bounds__(256) void prune_similar_kernel(const SimilarArgs a) {
     if (a.status && a.status->overflow) return;
+    if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[3] = wall_clock64();      // stage stamp
     const int nSingle = a.counts[2];
     const int lane = threadIdx.x & 63, nw = gridDim.x * (blockDim.x >> 6);
     for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < nSingle; i += nw) {

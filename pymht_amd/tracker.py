@@ -191,7 +191,7 @@ class Tracker():
         travels to pinned host memory behind them.  It is folded into the host mirror by the next call or by the first look at
         the tracker's state (every attribute / method that exposes results waits for it), so a host that streams scans in
         overlaps its own bookkeeping with the device's work."""
-        tic = {'Total': time.time()}
+        tic = {'Total': time.time(), '_call': time.perf_counter()}
         z = self._accept_scan(scanList, aisList, kwargs)
         tic['_print'] = {k: v for k, v in kwargs.items() if k in ("printTime", "printCluster", "printInfo", "on_color") and v}
         self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
@@ -205,6 +205,7 @@ class Tracker():
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
             raise
+        tic['_call'] = time.perf_counter() - tic['_call']      # host time of this call up to here (the scan is queued; nothing waited)
         self._queue_report(scanList, z, aisList, tic)
 
     def _set_prune_similar(self, want):
@@ -273,6 +274,7 @@ class Tracker():
         self.tic = tic
         self._toc_ = {}
         self.tic['Init'] = time.time()
+        t_fold = time.perf_counter()
         rep = _lib.MhtScanReport()
         rc = self._lib.mht_forest_report_get(self._ctx.handle, which, C.byref(rep))
         if rc == _lib.MHT_E_LIMIT:
@@ -300,11 +302,18 @@ class Tracker():
         used_words = np.ctypeslib.as_array(C.cast(rep.used, C.POINTER(C.c_uint64)), shape=(max(rep.used_words, 1),)).copy()
         used = np.unpackbits(used_words.view(np.uint8), bitorder="little")[:nRadarMeas].astype(bool)
         unusedRadarMeasurementIndices = ~used
+        # Per-stage times (tracker.py:192-294: the reference's own per-scan metric).  The kernels stamp the GPU's wall clock (10 ns ticks)
+        # at the start of every stage and the commit files the differences in the report: no HIP events, no host cost, present on every
+        # scan.  Track termination and the N-scan prune decision are part of the ILP launch (toc['Optim']); the target-side commit
+        # rides in the next scan's grow launch (toc['N-Prune'] = 0 unless deviceTiming measures it with HIP events).
+        self._toc_['Process'], self._toc_['Cluster'], self._toc_['Optim'] = rep.t_process * 1e-8, rep.t_cluster * 1e-8, rep.t_optim * 1e-8
+        self._toc_['Terminate'] = 0.0
+        self._toc_['N-Prune'] = 0.0
+        self._toc_['Device'] = rep.t_scan * 1e-8
         if self._timing:
             ms = (C.c_float * 5)()
             _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms), None))
             self._toc_['Process'], self._toc_['Cluster'], self._toc_['Optim'] = ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3
-            self._toc_['Terminate'] = 0.0
             self._toc_['N-Prune'] = ms[3] * 1e-3
             self._toc_['Device'] = ms[4] * 1e-3
         self._toc_['ILP-Prune'] = 0.0
@@ -318,9 +327,16 @@ class Tracker():
         if births is not None:
             self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
         self._toc_['Init'] = time.time() - self.tic['Init']
-        self._toc_['Total'] = time.time() - self.tic['Total']
+        # toc['Total'] = what THIS scan cost: the host time of its addMeasurementList call + the device time of its stages + the host
+        # time of folding its report.  NOT the wall time between the call and the fold: the report of scan k is folded by the call for
+        # scan k+1 (or by the first look at the results), so that interval is the host's idle time between scans -- a real-time host
+        # feeding one scan per radarPeriod would see Total ~ radarPeriod and a spurious "Did not pass real time demand".
+        self._toc_['Total'] = float(tic.get('_call', 0.0)) + self._toc_['Device'] + (time.perf_counter() - t_fold)
         if self._toc_['Total'] > self.radarPeriod:
             log.critical("Did not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
+                self._toc_['Total'] * 1000, self.radarPeriod * 1000))
+        elif self._toc_['Total'] > self.radarPeriod * 0.6:      # tracker.py:285-287
+            log.warning("Did almost not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
                 self._toc_['Total'] * 1000, self.radarPeriod * 1000))
         for k, v in self._runtimeLog_.items():
             if k in self._toc_:
@@ -585,22 +601,37 @@ class Tracker():
         return load
 
     def _leaf_snapshot(self):
+        """All leaves of the forest, exported once per scan: cached with the other lazily built views (dropped by the next scan or
+        birth), sized by the report's leaf count rather than by max_nodes (`Target.getLeafNodes` of every root goes through here)."""
         self._drain()
-        cap = self._cfg.max_nodes
+        snap = self._views.get("_leaves")
+        if snap is not None:
+            return snap
+        cap = int(min(self._cfg.max_nodes, max(4096, 2 * int(self._stats_.get("leaves_out", 0)) + 4 * len(self._tbl_) + 1024)))
+        while True:
+            snap = self._leaf_export(cap)
+            if snap is not None:
+                break
+            cap = self._cfg.max_nodes
+        self._views["_leaves"] = snap
+        return snap
+
+    def _leaf_export(self, cap):
         n = C.c_int32(0)
         x = np.zeros((cap, 4)); P = np.zeros((cap, 16), dtype=np.float32); cn = np.zeros(cap)
         meas = np.zeros(cap, dtype=np.int32); tgt = np.zeros(cap, dtype=np.int32); ids = np.zeros(cap, dtype=np.int32)
         node = np.zeros(cap, dtype=np.int32); fl = np.zeros(cap, dtype=np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.mht_forest_leaves(self._ctx.handle, cap, p(x), p(P), p(cn), p(meas), p(tgt), p(ids), p(node),
-                                               p(fl), C.byref(n)))
-        k = n.value
+        _lib.check(self._lib.mht_forest_leaves(self._ctx.handle, cap, p(x), p(P), p(cn), p(meas), p(tgt), p(ids), p(node), p(fl), C.byref(n)))
+        if n.value > cap and cap < self._cfg.max_nodes:
+            return None      # (more leaves than the estimate -- the export is truncated to the capacity: the caller retries with the full one)
+        k = min(n.value, cap)
         return dict(x=x[:k], P=P[:k].reshape(k, 4, 4), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
                     node=node[:k], flags=fl[:k])
 
     def leafBatch(self):
         """All current leaves in target-list / DFS order (what the next scan will gate): dict of arrays."""
-        return self._leaf_snapshot()
+        return dict(self._leaf_snapshot())
 
     def _leaf_views(self, root):
         snap = self._leaf_snapshot()

@@ -194,3 +194,30 @@ def test_terminated_tracks_keep_their_history():
         chain = [0 if m.measurementNumber is None else int(m.measurementNumber) for m in v.backtrackNodes()]
         assert chain == want[v.ID], v.ID
     trk.close()
+
+
+def test_toc_is_the_scans_own_cost_not_the_hosts_idle_time(caplog):
+    """addMeasurementList is pipelined (the report of scan k is folded by the call for scan k+1), so the wall time between a call and
+    its fold is the host's idle time.  toc['Total'] must be what the scan cost -- host call + device stages + fold -- and the per-stage
+    keys the reference always logs (tracker.py:87-98, :291-294) must be there on every scan without deviceTiming: they come from
+    wall-clock stamps the kernels take themselves."""
+    import logging
+    import time as _time
+    from pymht_amd.utils.scenario import make_scenario
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = make_scenario(T=60, radius=600.0, lambda_phi=3e-5, n_scans=6, P_d=0.9, period=0.05, seed=5)
+    trk, _ = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], 4, 5.99, sc["x0"], sc["t0"])
+    with caplog.at_level(logging.WARNING, logger="pymht_amd.tracker"):
+        for z, t in zip(sc["scans"], sc["times"]):
+            trk.addMeasurementList(MeasurementList(float(t), z))
+            _time.sleep(0.08)                      # a host that feeds one scan per (longer than the) radar period and reads nothing in between
+        log = trk.runtimeLog
+    assert not [r for r in caplog.records if "real time demand" in r.getMessage()], "idle time between scans was billed to the scans"
+    n = len(sc["scans"])
+    for key in ("Total", "Process", "Cluster", "Optim", "ILP-Prune", "DynN", "N-Prune", "Terminate", "Init"):
+        assert len(log[key]) == n, key
+    tot, proc, clu, opt = (np.array(log[k]) for k in ("Total", "Process", "Cluster", "Optim"))
+    assert np.all(tot < 0.02) and np.all(tot > 0)
+    assert np.all(proc > 1e-6) and np.all(proc < 1e-3) and np.all(clu > 1e-6) and np.all(clu < 1e-3) and np.all(opt > 1e-6) and np.all(opt < 5e-3)
+    assert np.all(tot >= proc + clu + opt - 1e-9)
+    trk.close()
