@@ -25,7 +25,15 @@
 extern "C" {
 #endif
 
-#define MHT_ABI_VERSION 1
+#define MHT_ABI_VERSION 2
+
+/* State dimension of the library build the header is used with: 4 (libmht_amd.so: the reference's CV model, models/pv.py) or 6
+ * (libmht_amd6.so: the same sources compiled with -DMHT_NX=6 for BASELINE config 5's six-state model).  It sizes the model matrices
+ * and the state vectors / covariances of the forest's reports; the stateless seams mht_gate_scan (4 states) and mht_gate_scan_x
+ * (4 or 6 at run time) do not depend on it. */
+#ifndef MHT_NX
+#define MHT_NX 4
+#endif
 
 enum {
     MHT_OK = 0,
@@ -52,10 +60,10 @@ typedef struct mht_ctx mht_ctx;
 /* The linear-Gaussian model: what Tracker.__init__ reads off the model module (tracker.py:54-59, pv.py:7-34)
  * plus the two scalars the gate and the score need (tracker.py:107, :110).  Row-major float32. */
 typedef struct mht_model {
-    float A[16]; /* Phi(radarPeriod) */
-    float Q[16]; /* Q(radarPeriod)   */
-    float C[8];  /* C_RADAR (2x4)    */
-    float R[4];  /* R_RADAR() (2x2)  */
+    float A[MHT_NX * MHT_NX]; /* Phi(radarPeriod) */
+    float Q[MHT_NX * MHT_NX]; /* Q(radarPeriod)   */
+    float C[2 * MHT_NX];      /* C_RADAR (2 x nx) */
+    float R[4];               /* R_RADAR() (2x2)  */
     double eta2;
     double lambda_ex;
     double default_pd;        /* Tracker.default_P_d; nodes whose pd equals it use default_miss_nllr */
@@ -187,11 +195,11 @@ typedef struct mht_target_report {
     int32_t root_scan;  /* scanNumber of the root after N-scan pruning */
     int32_t root_node;  /* node index of that root in its layer */
     int32_t n_leaves;   /* leaves kept for the next scan */
-    double sel_x[4];    /* state of the selected leaf */
+    double sel_x[MHT_NX];    /* state of the selected leaf */
     double sel_cnllr;   /* its cumulativeNLLR */
     double score;       /* getScore() = cNLLR - root.cNLLR before pruning (pyTarget.py:124) */
     double root_cnllr;  /* cumulativeNLLR of the root after pruning */
-    double root_x[4];   /* state of the root after pruning */
+    double root_x[MHT_NX];   /* state of the root after pruning */
     int32_t root_meas;  /* measurementNumber of the root after pruning */
     int32_t cluster;    /* smallest target index of this target's cluster (tracker.py:961-974) */
 } mht_target_report;
@@ -200,8 +208,8 @@ typedef struct mht_target_report {
 typedef struct mht_birth_report {
     int32_t id;          /* Target.ID, or -1 if Tracker.initiateTarget discarded the candidate (too close to a current track) */
     int32_t meas;        /* measurementNumber: 1-based index among the scan's UNUSED measurements, 0 for a merged target */
-    double x0[4];        /* float32 values */
-    float P0[16];
+    double x0[MHT_NX];   /* float32 values */
+    float P0[MHT_NX * MHT_NX];
 } mht_birth_report;
 
 typedef struct mht_scan_report {

@@ -364,6 +364,8 @@ def main():
         gen_g15(mods)
     if "g16" in which:
         gen_g16(mods)
+    if "g17" in which:
+        gen_g17(mods)
     if "g14" in which:
         gen_g14(mods)
     if "g13" in which:
@@ -499,6 +501,51 @@ def gen_g16(mods):
         times.append(1000.0 + 2.5 * (k + 1))
     sc = dict(x0=x0, P0s=P0s, x0_f32=f32, t0=1000.0, period=2.5, P_d=0.9, lambda_phi=6.4e-7, N=5, scans=scans, times=np.array(times))
     run_trace(mods, sc, "g16_fgrow_kat")
+
+
+def gen_g17(mods):
+    """Six-state trace (BASELINE config 5's state dimension).  The reference's TRACKER is hard-wired to its 4-state model
+    (tracker.py:14, :389; shape asserts pyTarget.py:231-234) -- only its kalman module is dimension-generic (kalman.py:55-101).  So:
+    the oracle tracker (oracle/mht_oracle.py: the restatement pinned bit for bit on every 4-state fixture) runs the constant-
+    acceleration model pymht_amd/models/ca.py with its Kalman steps REPLACED by the reference's own kalman.predict / precalc /
+    z_tilde / normalizedInnovationSquared / numpyFilter / nllr, and records what came out: per scan the gating counts, unused
+    measurements, clusters, selections, terminations and ALL leaves (states, covariances, scores).  60 targets in 600 m, 10 scans,
+    N-scan 4: single-leaf first scans (gemv order), ILPs, terminations."""
+    kal = mods["kalman"]
+    from pymht_amd.models import ca
+    from pymht_amd.utils.scenario import make_scenario
+    orc.kf_predict = lambda A, Q, x, P: kal.predict(A, Q, x, P)
+    orc.kf_precalc = lambda C, R, xb, Pb: kal.precalc(C, R, xb, Pb)
+    orc.kf_innovations = lambda z, zh: kal.z_tilde(z, zh, zh.shape[0], zh.shape[1])
+    orc.kf_nis = lambda zt, Si: kal.normalizedInnovationSquared(zt, Si)
+    orc.kf_update = lambda xb, K, zt: kal.numpyFilter(xb, K, zt)
+    orc.kf_nllr = lambda lam, pd, S, nis: kal.nllr(lam, pd, S, nis)
+    sc = make_scenario(T=60, radius=600.0, lambda_phi=3e-5, n_scans=10, P_d=0.88, seed=4242)
+    N, eta2 = 4, 5.99
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=N, eta2=eta2, model=ca)
+    x0 = np.concatenate([sc["x0"], np.zeros((len(sc["x0"]), 2))], axis=1)      # [x, y, vx, vy, ax = 0, ay = 0]
+    acc = [o.initiate_target(sc["t0"], x.copy(), ca.P0.copy(), status="preinitialized") for x in x0]
+    fx = dict(x0=x0, accepted=np.array(acc), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"], lambda_phi=sc["lambda_phi"], lambda_nu=LAMBDA_NU,
+              N=N, eta2=eta2, times=sc["times"], n_scans=len(sc["scans"]), nx=6)
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        ids_before = [r.ID for r in o.targets]
+        info = o.add_scan(float(t), z)
+        p = "s%02d_" % k
+        lb, sel = o.leaf_batch(), o.selected()
+        fx[p + "z"], fx[p + "unused"] = z, info["unused"]
+        fx[p + "LGM"] = np.array([info["L"], info["G"], info["M"]], dtype=np.int64)
+        fx[p + "ids"] = np.array([r.ID for r in o.targets], dtype=np.int64)
+        fx[p + "dead"] = np.array(sorted(info["dead"]), dtype=np.int64)
+        fx[p + "new_ids"] = np.zeros(0, np.int64)
+        fx[p + "cl_members"] = np.concatenate(o.clusters) if o.clusters else np.zeros(0, np.int64)
+        fx[p + "cl_ptr"] = np.concatenate([[0], np.cumsum([len(c) for c in o.clusters])]).astype(np.int64)
+        fx[p + "n_ilp"] = o.n_ilp
+        for key in ("ID", "x", "cnllr", "meas"):
+            fx[p + "sel_" + key] = sel[key]
+            fx[p + "leaf_" + key] = lb[key]
+        fx[p + "leaf_P"] = lb["P"]
+        print("  g17 scan %2d  M=%3d  T=%3d->%3d  L=%5d G=%5d leaves_after=%5d ilp=%d dead=%s" % (k, len(z), len(ids_before), len(o.targets), info["L"], info["G"], len(lb["ID"]), o.n_ilp, sorted(info["dead"])))
+    np.savez_compressed(os.path.join(GOLD, "g17_trace_6state.npz"), **fx)
 
 
 def gen_g15(mods):

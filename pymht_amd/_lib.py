@@ -11,10 +11,21 @@ MHT_OK, MHT_E_INVALID, MHT_E_HIP, MHT_E_CAPACITY, MHT_E_INFEASIBLE, MHT_E_LIMIT,
 F_STATE_F32, F_SCORE_F32 = 1, 2
 
 
-class MhtModel(C.Structure):
-    _fields_ = [("A", C.c_float * 16), ("Q", C.c_float * 16), ("C", C.c_float * 8), ("R", C.c_float * 4),
-                ("eta2", C.c_double), ("lambda_ex", C.c_double), ("default_pd", C.c_double),
-                ("default_miss_nllr", C.c_double)]
+def _model_type(nx):
+    class _M(C.Structure):
+        _fields_ = [("A", C.c_float * (nx * nx)), ("Q", C.c_float * (nx * nx)), ("C", C.c_float * (2 * nx)), ("R", C.c_float * 4),
+                    ("eta2", C.c_double), ("lambda_ex", C.c_double), ("default_pd", C.c_double),
+                    ("default_miss_nllr", C.c_double)]
+    _M.__name__ = "MhtModel%d" % nx
+    return _M
+
+
+MhtModel = _model_type(4)       # mht_model of libmht_amd.so (MHT_NX = 4)
+MhtModel6 = _model_type(6)      # ... of libmht_amd6.so (MHT_NX = 6)
+
+
+def model_type(nx):
+    return MhtModel if nx == 4 else MhtModel6
 
 
 class MhtModelX(C.Structure):      # mht_model_x: dimension-generic model (nx = 4 or 6 states, 2 measurements)
@@ -35,11 +46,17 @@ class MhtForestConfig(C.Structure):
                 ("radar_range", C.c_double), ("merge_threshold", C.c_double)]
 
 
-class MhtTargetReport(C.Structure):
-    _fields_ = [("id", C.c_int32), ("status", C.c_int32), ("sel_node", C.c_int32), ("sel_meas", C.c_int32),
-                ("new_index", C.c_int32), ("root_scan", C.c_int32), ("root_node", C.c_int32), ("n_leaves", C.c_int32),
-                ("sel_x", C.c_double * 4), ("sel_cnllr", C.c_double), ("score", C.c_double), ("root_cnllr", C.c_double),
-                ("root_x", C.c_double * 4), ("root_meas", C.c_int32), ("cluster", C.c_int32)]
+def _report_type(nx):
+    class _R(C.Structure):
+        _fields_ = [("id", C.c_int32), ("status", C.c_int32), ("sel_node", C.c_int32), ("sel_meas", C.c_int32),
+                    ("new_index", C.c_int32), ("root_scan", C.c_int32), ("root_node", C.c_int32), ("n_leaves", C.c_int32),
+                    ("sel_x", C.c_double * nx), ("sel_cnllr", C.c_double), ("score", C.c_double), ("root_cnllr", C.c_double),
+                    ("root_x", C.c_double * nx), ("root_meas", C.c_int32), ("cluster", C.c_int32)]
+    return _R
+
+
+MhtTargetReport = _report_type(4)
+MhtTargetReport6 = _report_type(6)
 
 
 class MhtScanReport(C.Structure):
@@ -55,6 +72,10 @@ class MhtBirthReport(C.Structure):
     _fields_ = [("id", C.c_int32), ("meas", C.c_int32), ("x0", C.c_double * 4), ("P0", C.c_float * 16)]
 
 
+class MhtBirthReport6(C.Structure):
+    _fields_ = [("id", C.c_int32), ("meas", C.c_int32), ("x0", C.c_double * 6), ("P0", C.c_float * 36)]
+
+
 class MhtInitiatorConfig(C.Structure):
     _fields_ = [("m_required", C.c_int32), ("n_checks", C.c_int32), ("max_meas", C.c_int32), ("max_prelim", C.c_int32),
                 ("max_born", C.c_int32), ("v_max", C.c_double), ("gamma", C.c_double), ("merge_threshold", C.c_double),
@@ -68,23 +89,24 @@ class MhtError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 
-def load(build_if_missing=True):
-    """dlopen libmht_amd.so (building it in-tree with hipcc first if the sources are newer)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(build_if_missing=True, nx=4):
+    """dlopen libmht_amd.so (nx = 4) or libmht_amd6.so (nx = 6: the same sources compiled with -DMHT_NX=6), building it in-tree with
+    hipcc first if the sources are newer."""
+    if nx in _libs:
+        return _libs[nx]
+    from . import build
+    LIB_PATH = build.lib_path(nx)
     if build_if_missing and os.environ.get("MHT_AMD_NO_BUILD", "0") != "1":
-        from . import build
         try:
-            build.build_library(verbose=False)
+            build.build_library(verbose=False, nx=nx)
         except Exception:
             if not os.path.exists(LIB_PATH):
                 raise
     if not os.path.exists(LIB_PATH):
-        raise ImportError("libmht_amd.so is missing (%s); run `python -m pymht_amd.build`" % LIB_PATH)
+        raise ImportError("%s is missing (%s); run `python -m pymht_amd.build`" % (os.path.basename(LIB_PATH), LIB_PATH))
     # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  If libmht_amd.so is loaded first it pulls in
     # /opt/rocm's copy, a later `import torch` then brings a second runtime into the process and one of the two reports
     # "no ROCm-capable device".  Importing torch first makes both resolve to the same runtime.
@@ -95,13 +117,15 @@ def load(build_if_missing=True):
     lib = C.CDLL(LIB_PATH)
     lib.mht_last_error.restype = C.c_char_p
     lib.mht_abi_version.restype = C.c_int
-    _lib = lib
-    _declare(lib)
+    lib.nx = nx
+    _libs[nx] = lib
+    _declare(lib, nx)
     return lib
 
 
-def _declare(lib):
+def _declare(lib, nx=4):
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    MhtModel = model_type(nx)
     sig = {
         "mht_create": [C.POINTER(vp), C.c_int, vp],
         "mht_destroy": [vp],
@@ -146,9 +170,11 @@ def _declare(lib):
         fn.restype = C.c_int
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != MHT_OK:
-        raise MhtError(rc, load().mht_last_error().decode("utf-8", "replace"))
+        libs = [lib] if lib is not None else (list(_libs.values()) or [load()])
+        msgs = [l.mht_last_error().decode("utf-8", "replace") for l in libs]
+        raise MhtError(rc, msgs[0] if len(msgs) == 1 else " | ".join("[%d-state build] %s" % (l.nx, m) for l, m in zip(libs, msgs) if m))
 
 
 def exported_symbols():

@@ -6,6 +6,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmht_amd.so")
+LIB6 = os.path.join(HERE, "libmht_amd6.so")      # the same sources with -DMHT_NX=6: the six-state build (BASELINE config 5's state dimension)
+
+
+def lib_path(nx=4):
+    assert nx in (4, 6), "libmht_amd is built for 4 or 6 states"
+    return LIB if nx == 4 else LIB6
 SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_gatex.hip", "mht_fgrow.hip", "mht_cluster.hip", "mht_blp.hip", "mht_prune.hip", "mht_similar.hip", "mht_init.hip", "mht_forest.hip"]
 # -ffp-contract=off is REQUIRED: mht_math.h spells out every fused multiply-add of the reference's
 # BLAS evaluation order; letting the compiler contract anything else breaks bit-exact gating.
@@ -13,31 +19,33 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-function"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mht_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force=False, verbose=True):
-    """Compile the library if it is missing or older than its sources.  Safe under concurrent callers (one process per
-    GPU all importing the package at once): an exclusive file lock serialises them, the second one finds a fresh library;
-    the output is written to a temporary file and renamed, so a reader never sees a half-written .so."""
-    if not force and not _stale():
+def build_library(force=False, verbose=True, nx=4):
+    """Compile the library (nx = 4: libmht_amd.so, nx = 6: libmht_amd6.so) if it is missing or older than its sources.  Safe under
+    concurrent callers (one process per GPU all importing the package at once): an exclusive file lock serialises them, the second one
+    finds a fresh library; the output is written to a temporary file and renamed, so a reader never sees a half-written .so."""
+    LIB = lib_path(nx)
+    if not force and not _stale(LIB):
         return LIB
     import fcntl
     with open(LIB + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not _stale():
+            if not force and not _stale(LIB):
                 return LIB
             hipcc = os.environ.get("HIPCC", "hipcc")
             srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
             extra = os.environ.get("MHT_EXTRA_HIPCC_FLAGS", "").split()      # development: e.g. -DMHT_GROW_STAMPS (tools/grow_profile.py)
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = [hipcc] + FLAGS + extra + srcs + ["-o", tmp]
+            cmd = [hipcc] + FLAGS + (["-DMHT_NX=%d" % nx] if nx != 4 else []) + extra + srcs + ["-o", tmp]
             if verbose:
                 print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
             try:
@@ -51,5 +59,12 @@ def build_library(force=False, verbose=True):
     return LIB
 
 
+def build_all(force=False, verbose=True):
+    """Both builds, side by side (two hipcc processes)."""
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(2) as ex:
+        return [f.result() for f in [ex.submit(build_library, force, verbose, nx) for nx in (4, 6)]]
+
+
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_all(force="--force" in sys.argv)

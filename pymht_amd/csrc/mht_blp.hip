@@ -1432,7 +1432,10 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
     const double cn = a.cnllr[s];
     const uint8_t fl = a.flags[s];
     const int smeas = ring_ptr(a.ring0.meas, a.ring_stride, kc)[s];
-    const double sx0 = a.x[s], sx1 = a.x[(size_t)a.cap + s], sx2 = a.x[(size_t)2 * a.cap + s], sx3 = a.x[(size_t)3 * a.cap + s];
+    double sx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) sx[k] = a.x[(size_t)k * a.cap + s];
+    const double sx0 = sx[0], sx1 = sx[1];
     const int j = p.j;
     const int anc_l = a.apath[(size_t)s * a.pds + (j > 0 ? j - 1 : 0)];      // unconditional (clamped level): one batch with the loads above
     const int anc = (j > 0) ? anc_l : -1;
@@ -1457,7 +1460,9 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
     const double* rx = ring_ptr(a.ring0.x, a.ring_stride, kr);
     const double rc_l = ring_ptr(a.ring0.cnllr, a.ring_stride, kr)[rnode];
     const uint8_t rf_l = ring_ptr(a.ring0.flags, a.ring_stride, kr)[rnode];
-    const double rx0 = rx[rnode], rx1 = rx[(size_t)a.cap + rnode], rx2 = rx[(size_t)2 * a.cap + rnode], rx3 = rx[(size_t)3 * a.cap + rnode];
+    double rxv[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) rxv[k] = rx[(size_t)k * a.cap + rnode];
     const int rmeas = ring_ptr(a.ring0.meas, a.ring_stride, kr)[rnode];
     const double rc = moved ? rc_l : p.rootc;
     const uint8_t rf = moved ? (uint8_t)((rf_l & F_SCORE_F32) ? 1 : 0) : p.rootf;
@@ -1473,11 +1478,13 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
         r.sel_meas = smeas;
         r.root_scan = rscan;
         r.root_node = rnode;
-        r.sel_x[0] = sx0; r.sel_x[1] = sx1; r.sel_x[2] = sx2; r.sel_x[3] = sx3;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) r.sel_x[k] = sx[k];
         r.sel_cnllr = cn;
         r.score = score;
         r.root_cnllr = rc;
-        r.root_x[0] = rx0; r.root_x[1] = rx1; r.root_x[2] = rx2; r.root_x[3] = rx3;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) r.root_x[k] = rxv[k];
         r.root_meas = rmeas;
         r.cluster = p.lab;
     }

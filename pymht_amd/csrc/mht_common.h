@@ -67,6 +67,10 @@ constexpr int FG_CAP_SOLO = 128;          //   ... in the one-sector launch: eve
                                           //   second pass over it sets the duration of the whole launch (32 instead of 20 us); 45 KB of LDS, three workgroups per CU
 constexpr int FG_CAP = MHT_FG_CAP;        //   leaves of a target handled per pass, one per lane of two wavefronts (more: chunks, two passes)
 constexpr int FG_REGIONS = 8;     //   regions of the node index space, one child counter each (one per XCD)
+// covariance-value table (mht_vtab.h), sized by the state dimension of the build (mht_math.h: NX, NP, NK)
+constexpr int VT_PW = NP / 2;                   // 64-bit words of one covariance value (8 at 4 states, 18 at 6)
+constexpr int GKQ = (4 + NK + 3 + 3) / 4;       // float4 per gains row: S^-1 (4), K (NX x 2), score constant, two gate half-axes (4 / 5)
+constexpr int GKF = GKQ * 4;                    // floats per gains row
 
 // device-side status word of a ctx (sticky until read)
 struct DevStatus {

@@ -26,10 +26,10 @@
 namespace mht {
 
 struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in LDS for the later phases (one chunk = FG_CAP leaves)
-    double xbar[4];
+    double xbar[NX];
     double zhat[2];
     double cn, pd;
-    float K[8];
+    float K[NK];
     float sinv[4];
     float lnc, bx, by, zhx, zhy;
     int src, cid;                     // cid: value id of the leaf's covariance (its children's keys are 2 * cid + hit/miss)
@@ -112,34 +112,34 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
         const int id = a.vt.child[mykey];          // (set when the leaf was made: by this code one scan ago, or at its birth)
         const int ckey = 2 * id + h;
         if (a.vt.child[ckey] >= 0) continue;       // the transition is known
-        float P[16];
+        float P[NP];
         vt_load(a.vt, id, P);
         Model mdl;          // (uniform registers)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
+        for (int e = 0; e < NP; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+        for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
         mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
-        float Pc[16];
+        float Pc[NP];
         {
             CovChain c;
             cov_chain(mdl, P, c, h != 0);      // (the miss child's covariance is P_bar: no S, K, P_hat needed)
             if (h) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) Pc[e] = c.P_hat[e];
+                for (int e = 0; e < NP; ++e) Pc[e] = c.P_hat[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) Pc[e] = c.P_bar[e];
+                for (int e = 0; e < NP; ++e) Pc[e] = c.P_bar[e];
             }
         }
         const double pd = a.pd[mysrc];
         {
-            float4 rec[4];
+            float4 rec[GKQ];
             vt_gains(mdl, Pc, pd, rec);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a.vt.Gk[(size_t)ckey * 4 + q] = rec[q];
+            for (int q = 0; q < GKQ; ++q) a.vt.Gk[(size_t)ckey * GKQ + q] = rec[q];
         }
         a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
     }
@@ -221,14 +221,16 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         }
     }
     FG_STAMPX(4);
-    if (role < 0) {          // (all four state components)
-        double xo[4] = {g.xbar[0], g.xbar[1], g.xbar[2], g.xbar[3]};
+    if (role < 0) {          // (all state components)
+        double xo[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xo[i] = g.xbar[i];
         if (k > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xo[i] = (double)update_component_n<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt, nh == 1);      // (one hit: gemv, mht_math.h)
+            for (int i = 0; i < NX; ++i) xo[i] = (double)update_component_n<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt, nh == 1);      // (one hit: gemv, mht_math.h)
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a.ox[(size_t)i * cap + c] = xo[i];
+        for (int i = 0; i < NX; ++i) a.ox[(size_t)i * cap + c] = xo[i];
         a.ocnllr[c] = cnl;
         a.opd[c] = g.pd;
         a.oparent[c] = g.src;
@@ -266,24 +268,26 @@ template <typename ARGS>
 __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32state, FLeaf& out) {
     Model mdl;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+    for (int e = 0; e < NP; ++e) mdl.A[e] = a.model.A[e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
-    double xd[4];
+    for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
+    double xd[NX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
-    double xb[4], zh[2];
+    for (int k = 0; k < NX; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+    double xb[NX], zh[2];
     if (f32state) {
-        float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xbf[4], zhf[2];
+        float xs[NX], xbf[NX], zhf[2];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) xs[k] = (float)xd[k];
         state_predict_single<float>(mdl, xs, xbf, zhf);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xb[k] = (double)xbf[k];
+        for (int k = 0; k < NX; ++k) xb[k] = (double)xbf[k];
         zh[0] = (double)zhf[0]; zh[1] = (double)zhf[1];
     } else {
         state_predict_single<double>(mdl, xd, xb, zh);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out.xbar[k] = xb[k];
+    for (int k = 0; k < NX; ++k) out.xbar[k] = xb[k];
     out.zhat[0] = zh[0]; out.zhat[1] = zh[1];
     out.zhx = (float)zh[0]; out.zhy = (float)zh[1];
 }
@@ -393,9 +397,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 }
                 const double cn = a.cnllr[src], pd = a.pd[src];
                 const int covc = a.cov[src];
-                double xd[4];
+                double xd[NX];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+                for (int k = 0; k < NX; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
                 // the leaf's path / ancestor records (pds ints each: 2 or 4 x 16 bytes)
                 const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * PDS);
                 const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * PDS);
@@ -403,9 +407,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                 for (int q = 0; q < PQ; ++q) { pq[q] = prec[q]; aq[q] = arec[q]; }
                 // batch B: the gains of the leaf's covariance column
-                float4 gr[4];
+                float4 gr[GKQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gr[q] = a.vt.Gk[(size_t)covc * 4 + q];
+                for (int q = 0; q < GKQ; ++q) gr[q] = a.vt.Gk[(size_t)covc * GKQ + q];
                 const int cid = a.vt.child[covc];
                 g.valid = valid;
                 g.src = src;
@@ -430,28 +434,34 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 if (!valid) last = -1;
                 Model mdl;          // (only A and C are used: uniform registers)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mdl.A[e] = a.model.A[e];
+                for (int e = 0; e < NP; ++e) mdl.A[e] = a.model.A[e];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) mdl.C[e] = a.model.C[e];
+                for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
                 if (g.f32state) {
-                    float xs[4] = {(float)xd[0], (float)xd[1], (float)xd[2], (float)xd[3]}, xb[4], zh[2];
+                    float xs[NX], xb[NX], zh[2];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) xs[k] = (float)xd[k];
                     state_predict<float>(mdl, xs, xb, zh);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) g.xbar[k] = (double)xb[k];
+                    for (int k = 0; k < NX; ++k) g.xbar[k] = (double)xb[k];
                     g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
                 } else {
-                    double xb[4], zh[2];
+                    double xb[NX], zh[2];
                     state_predict<double>(mdl, xd, xb, zh);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) g.xbar[k] = xb[k];
+                    for (int k = 0; k < NX; ++k) g.xbar[k] = xb[k];
                     g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
                 }
-                g.sinv[0] = gr[0].x; g.sinv[1] = gr[0].y; g.sinv[2] = gr[0].z; g.sinv[3] = gr[0].w;
-                g.K[0] = gr[1].x; g.K[1] = gr[1].y; g.K[2] = gr[1].z; g.K[3] = gr[1].w;
-                g.K[4] = gr[2].x; g.K[5] = gr[2].y; g.K[6] = gr[2].z; g.K[7] = gr[2].w;
-                g.lnc = gr[3].x;
+                {   // the gains row: S^-1 (4), K (NX x 2), score constant, gate half-axes (mht_vtab.h::vt_gains)
+                    const float* grf = reinterpret_cast<const float*>(gr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g.sinv[e] = grf[e];
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) g.K[e] = grf[4 + e];
+                    g.lnc = grf[GK_LNC];
+                }
                 const float zhx = (float)g.zhat[0], zhy = (float)g.zhat[1];
-                const float rx = gr[3].y, ry = gr[3].z;
+                const float rx = reinterpret_cast<const float*>(gr)[GK_RX], ry = reinterpret_cast<const float*>(gr)[GK_RY];
                 // NIS <= eta2  =>  |dz_x| <= sqrt(eta2*S00), |dz_y| <= sqrt(eta2*S11); widened for the float32 rounding of the
                 // pre-filter subtraction (coordinates up to ~1e6 m) -- the exact test decides, this only prunes
                 const float bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
 // repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
 typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
 template <int PQ>
-__global__ __launch_bounds__(FG_THREADS, 4) void fgrow_batch_kernel(const FBatch b) {
+__global__ __launch_bounds__(FG_THREADS, NX == 4 ? 4 : 3) void fgrow_batch_kernel(const FBatch b) {      // (six states: 165 registers, three workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int y = blockIdx.y;
     const FDyn d = b.d[y];

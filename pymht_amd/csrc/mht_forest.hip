@@ -108,7 +108,7 @@ static __device__ void add_targets_body(const AddArgs& a) {
             if (a.layer.flags[nd] & F_DEAD) continue;      // (taken out of the tree by similar-state pruning)
             const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
             for (int q = 0; q < an; ++q) {
-                const double dx = lx - a.x0[q * 4], dy = ly - a.x0[q * 4 + 1];
+                const double dx = lx - a.x0[q * NX], dy = ly - a.x0[q * NX + 1];
                 if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
             }
         }
@@ -126,12 +126,12 @@ static __device__ void add_targets_body(const AddArgs& a) {
         if (tid == 0) s_near = a.near[q];
         __syncthreads();
         if (a.check && !s_near) {
-            const double qx = a.x0[q * 4], qy = a.x0[q * 4 + 1];
+            const double qx = a.x0[q * NX], qy = a.x0[q * NX + 1];
             const int na = s_nadm;
             int hit = 0;
             for (int i = tid; i < na; i += 1024) {
                 const int pc = s_adm[i & 2047];
-                const double dx = a.x0[pc * 4] - qx, dy = a.x0[pc * 4 + 1] - qy;
+                const double dx = a.x0[pc * NX] - qx, dy = a.x0[pc * NX + 1] - qy;
                 if (sqrt(dx * dx + dy * dy) < a.thr) hit = 1;
             }
             if (hit) s_near = 1;
@@ -146,7 +146,7 @@ static __device__ void add_targets_body(const AddArgs& a) {
                 // of the node index space below it (fgrow_kernel)
                 const int r = a.cnt->n_roots, idx = a.root_base + r, t = a.cnt->nT, L = a.cnt->L;
                 const size_t cap = a.layer.cap;
-                for (int k = 0; k < 4; ++k) a.layer.x[k * cap + idx] = a.x0[q * 4 + k];
+                for (int k = 0; k < NX; ++k) a.layer.x[k * cap + idx] = a.x0[q * NX + k];
                 a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
                 a.layer.pd[idx] = a.pd[q];
                 a.layer.parent[idx] = -1;
@@ -181,8 +181,8 @@ static __device__ void add_targets_body(const AddArgs& a) {
                 mht_birth_report& b = a.births[q];
                 b.id = ok ? a.cnt->id_counter - 1 : -1;
                 b.meas = a.meas[q];
-                for (int k = 0; k < 4; ++k) b.x0[k] = a.x0[q * 4 + k];
-                for (int e = 0; e < 16; ++e) b.P0[e] = a.P0[q * 16 + e];
+                for (int k = 0; k < NX; ++k) b.x0[k] = a.x0[q * NX + k];
+                for (int e = 0; e < NP; ++e) b.P0[e] = a.P0[q * NP + e];
             }
         }
         __syncthreads();
@@ -192,15 +192,15 @@ static __device__ void add_targets_body(const AddArgs& a) {
     // ahead): the root's covariance by value, and a key of its own -- a pseudo parent id whose miss child is that value
     for (int k = tid; k < s_nadm; k += 1024) {
         const int q = s_adm[k & 2047];
-        float P[16];
-        for (int e = 0; e < 16; ++e) P[e] = a.P0[q * 16 + e];
+        float P[NP];
+        for (int e = 0; e < NP; ++e) P[e] = a.P0[q * NP + e];
         const int id0 = vt_find_or_insert(a.vt, P, a.pd[q]);
         const unsigned pid = atomicAdd(a.vt.count, 1u);
         if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; continue; }
         const int key = 2 * (int)pid;
-        float4 rec[4];
+        float4 rec[GKQ];
         vt_gains(a.model, P, a.pd[q], rec);
-        for (int e = 0; e < 4; ++e) a.vt.Gk[(size_t)key * 4 + e] = rec[e];
+        for (int e = 0; e < GKQ; ++e) a.vt.Gk[(size_t)key * GKQ + e] = rec[e];
         a.vt.child[key] = id0;
         a.layer.cov[a.root_base + r0 + k] = key;      // (admissions are sequential: the k-th took root r0 + k)
     }
@@ -240,8 +240,8 @@ __global__ void leaves_kernel(const LeavesArgs a) {
         int lo = 0, hi = nT;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
         const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
-        for (int k = 0; k < 4; ++k) a.x[i * 4 + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
-        vt_load(a.vt, a.vt.child[a.layer.cov[nd]], a.P + (size_t)i * 16);
+        for (int k = 0; k < NX; ++k) a.x[i * NX + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
+        vt_load(a.vt, a.vt.child[a.layer.cov[nd]], a.P + (size_t)i * NP);
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
@@ -260,9 +260,9 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.nodes[n] = nd;
         a.meas[n] = l.meas[nd];
         a.cnllr[n] = l.cnllr[nd];
-        for (int k = 0; k < 4; ++k) a.x[n * 4 + k] = l.x[(size_t)k * l.cap + nd];
+        for (int k = 0; k < NX; ++k) a.x[n * NX + k] = l.x[(size_t)k * l.cap + nd];
         const VTab& v = a.vt[a.lgen[sc % a.R]];      // (the generation of the value table this layer's keys belong to)
-        vt_load(v, v.child[l.cov[nd]], a.P + (size_t)n * 16);
+        vt_load(v, v.child[l.cov[nd]], a.P + (size_t)n * NP);
         ++n;
         nd = l.parent[nd];
         --sc;
@@ -366,7 +366,7 @@ struct Forest {
         for (int s = 0; s < R; ++s) {
             mht_nodes& l = layer[s];
             l.cap = Ncap; l.cap_cov = 0;
-            l.x = ar.take<double>((size_t)4 * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
+            l.x = ar.take<double>((size_t)NX * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
             l.parent = ar.take<int32_t>(Ncap); l.meas = ar.take<int32_t>(Ncap); l.cov = ar.take<int32_t>(Ncap);
             l.flags = ar.take<uint8_t>(Ncap); l.P = nullptr;
         }
@@ -384,8 +384,8 @@ struct Forest {
         for (int g = 0; g < 2; ++g) {
             VTab& v = vts[g];
             v.vcap = vt.vcap; v.hmask = vt.hmask;
-            v.Pv = ar.take<unsigned long long>((size_t)8 * v.vcap); v.pdv = ar.take<double>(v.vcap);
-            v.Gk = ar.take<float4>((size_t)8 * v.vcap); v.child = ar.take<int32_t>((size_t)2 * v.vcap);
+            v.Pv = ar.take<unsigned long long>((size_t)VT_PW * v.vcap); v.pdv = ar.take<double>(v.vcap);
+            v.Gk = ar.take<float4>((size_t)2 * GKQ * v.vcap); v.child = ar.take<int32_t>((size_t)2 * v.vcap);
             v.slots = ar.take<unsigned long long>((size_t)v.hmask + 1); v.count = ar.take<unsigned>(16);
         }
         vt_remap = ar.take<int32_t>((size_t)2 * vt.vcap);
@@ -624,7 +624,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     for (int c0 = 0; c0 < n; c0 += 2048) {
         AddArgs ac = a;
         ac.n = n - c0 < 2048 ? n - c0 : 2048;
-        ac.x0 = x0 + (size_t)c0 * 4; ac.pd = pd + c0; ac.P0 = P0 + (size_t)c0 * 16; ac.meas = meas + c0; ac.flags = flags + c0;
+        ac.x0 = x0 + (size_t)c0 * NX; ac.pd = pd + c0; ac.P0 = P0 + (size_t)c0 * NP; ac.meas = meas + c0; ac.flags = flags + c0;
         ac.ids = ids ? ids + c0 : nullptr; ac.accepted = accepted ? accepted + c0 : nullptr;
         hipLaunchKernelGGL(add_targets_kernel, dim3(1), dim3(1024), 0, ctx->stream, ac);
         MHT_HIP_CHECK(hipGetLastError());
@@ -645,7 +645,7 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     if (n == 0) return MHT_OK;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     // pack inputs: x0 | pd | P0 | meas | flags    outputs: ids | accepted
-    const size_t o_x = 0, o_pd = o_x + (size_t)n * 32, o_P = o_pd + (size_t)n * 8, o_m = o_P + (size_t)n * 64,
+    const size_t o_x = 0, o_pd = o_x + (size_t)n * (NX * 8), o_P = o_pd + (size_t)n * 8, o_m = o_P + (size_t)n * (NP * 4),
                  o_f = o_m + (size_t)n * 4, o_id = (o_f + n + 7) & ~(size_t)7, o_acc = o_id + (size_t)n * 4,
                  total = o_acc + n + 16;
     // the staging buffers are reused: anything still in flight from a previous call must have drained
@@ -655,7 +655,7 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     rc = f->stage_dev.ensure(total);
     if (rc) return rc;
     char* h = static_cast<char*>(f->stage_host);
-    memcpy(h + o_x, x0, (size_t)n * 32); memcpy(h + o_pd, pd, (size_t)n * 8); memcpy(h + o_P, P0, (size_t)n * 64);
+    memcpy(h + o_x, x0, (size_t)n * (NX * 8)); memcpy(h + o_pd, pd, (size_t)n * 8); memcpy(h + o_P, P0, (size_t)n * (NP * 4));
     memcpy(h + o_m, meas, (size_t)n * 4); memcpy(h + o_f, flags, n);
     char* d = static_cast<char*>(f->stage_dev.ptr);
     MHT_HIP_CHECK(hipMemcpyAsync(d, h, o_id, hipMemcpyHostToDevice, ctx->stream));
@@ -796,13 +796,13 @@ __global__ __launch_bounds__(256) void vt_rebuild_kernel(const RebuildArgs a) {
         const int k_old = a.layer.cov[nd];
         int k_new = __hip_atomic_load(&a.remap[k_old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k_new < 0) {
-            float P[16];
+            float P[NP];
             vt_load(a.from, a.from.child[k_old], P);
             const int id = vt_find_or_insert(a.to, P, a.layer.pd[nd]);
             const unsigned pid = atomicAdd(a.to.count, 1u);      // a pseudo parent, as for a root: its miss child is the leaf's value
             if (pid >= (unsigned)a.to.vcap) { *a.to.overflow = 1; continue; }
             const int mine = 2 * (int)pid;
-            for (int q = 0; q < 4; ++q) a.to.Gk[(size_t)mine * 4 + q] = a.from.Gk[(size_t)k_old * 4 + q];
+            for (int q = 0; q < GKQ; ++q) a.to.Gk[(size_t)mine * GKQ + q] = a.from.Gk[(size_t)k_old * GKQ + q];
             a.to.child[mine] = id;
             int expected = -1;
             k_new = __hip_atomic_compare_exchange_strong(&a.remap[k_old], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? mine : expected;
@@ -1267,6 +1267,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
 }
 
 extern "C" int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now) {
+    MHT_REQUIRE(NX == 4, "mht_forest_initiate: the M-of-N initiator is the reference's 4-state one (m_of_n.py imports models/pv); this is the %d-state build", NX);
     return forest_initiate_impl(ctx, in, z, M, now, false);
 }
 
@@ -1303,6 +1304,7 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
 // initiator is given) and the start of the report's way to the host (mht_forest_report_begin).  Nothing here waits for the device.
 extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
     if (in) {      // (checked before the scan is stepped: nothing may fail between the initiator's run and the admission of its births)
+        MHT_REQUIRE(NX == 4, "mht_forest_scan: the M-of-N initiator is the reference's 4-state one (m_of_n.py imports models/pv); this is the %d-state build", NX);
         MHT_REQUIRE(ctx && ctx->forest, "mht_forest_scan: no forest");
         const double* bx; const float* bP; const uint8_t* bfl; const double* bpd; const int32_t* bme; const int32_t* bn; int cap; mht_ctx* ictx;
         initiator_born_ptrs(in, &bx, &bP, &bfl, &bpd, &bme, &bn, &cap, &ictx);
@@ -1442,7 +1444,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     *n_out = c.L;
     const int n = c.L < capacity ? c.L : capacity;
     if (n == 0) return MHT_OK;
-    const size_t o_x = 0, o_c = o_x + (size_t)n * 32, o_P = o_c + (size_t)n * 8, o_m = o_P + (size_t)n * 64,
+    const size_t o_x = 0, o_c = o_x + (size_t)n * (NX * 8), o_P = o_c + (size_t)n * 8, o_m = o_P + (size_t)n * (NP * 4),
                  o_t = o_m + (size_t)n * 4, o_i = o_t + (size_t)n * 4, o_n = o_i + (size_t)n * 4, o_f = o_n + (size_t)n * 4,
                  total = o_f + n + 16;
     int rc = stage_host_ensure(f, total);
@@ -1465,9 +1467,9 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     for (int i = 0; i < n; ++i) {
         if (hf[i] & F_DEAD) continue;
         if (live != i) {
-            memmove(h + o_x + (size_t)live * 32, h + o_x + (size_t)i * 32, 32);
+            memmove(h + o_x + (size_t)live * (NX * 8), h + o_x + (size_t)i * (NX * 8), NX * 8);
             memmove(h + o_c + (size_t)live * 8, h + o_c + (size_t)i * 8, 8);
-            memmove(h + o_P + (size_t)live * 64, h + o_P + (size_t)i * 64, 64);
+            memmove(h + o_P + (size_t)live * (NP * 4), h + o_P + (size_t)i * (NP * 4), NP * 4);
             memmove(h + o_m + (size_t)live * 4, h + o_m + (size_t)i * 4, 4);
             memmove(h + o_t + (size_t)live * 4, h + o_t + (size_t)i * 4, 4);
             memmove(h + o_i + (size_t)live * 4, h + o_i + (size_t)i * 4, 4);
@@ -1477,9 +1479,9 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
         ++live;
     }
     *n_out = c.L - (n - live);
-    if (x) memcpy(x, h + o_x, (size_t)live * 32);
+    if (x) memcpy(x, h + o_x, (size_t)live * (NX * 8));
     if (cnllr) memcpy(cnllr, h + o_c, (size_t)live * 8);
-    if (P) memcpy(P, h + o_P, (size_t)live * 64);
+    if (P) memcpy(P, h + o_P, (size_t)live * (NP * 4));
     if (meas) memcpy(meas, h + o_m, (size_t)live * 4);
     if (target) memcpy(target, h + o_t, (size_t)live * 4);
     if (id) memcpy(id, h + o_i, (size_t)live * 4);
@@ -1499,8 +1501,8 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     int len = max_len;
     const int avail = f->R - (f->scan - scan);   // layers still in the ring going backwards
     if (len > avail) len = avail;
-    const size_t o_n = 0, o_m = o_n + (size_t)len * 4, o_x = (o_m + (size_t)len * 4 + 7) & ~(size_t)7, o_c = o_x + (size_t)len * 32,
-                 o_P = o_c + (size_t)len * 8, o_k = o_P + (size_t)len * 64, total = o_k + 16;
+    const size_t o_n = 0, o_m = o_n + (size_t)len * 4, o_x = (o_m + (size_t)len * 4 + 7) & ~(size_t)7, o_c = o_x + (size_t)len * (NX * 8),
+                 o_P = o_c + (size_t)len * 8, o_k = o_P + (size_t)len * (NP * 4), total = o_k + 16;
     int rc = stage_host_ensure(f, total);
     if (rc) return rc;
     rc = f->stage_dev.ensure(total);
@@ -1521,9 +1523,9 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     *n_out = n;
     if (nodes) memcpy(nodes, h + o_n, (size_t)n * 4);
     if (meas) memcpy(meas, h + o_m, (size_t)n * 4);
-    if (x) memcpy(x, h + o_x, (size_t)n * 32);
+    if (x) memcpy(x, h + o_x, (size_t)n * (NX * 8));
     if (cnllr) memcpy(cnllr, h + o_c, (size_t)n * 8);
-    if (P) memcpy(P, h + o_P, (size_t)n * 64);
+    if (P) memcpy(P, h + o_P, (size_t)n * (NP * 4));
     return MHT_OK;
 }
 
@@ -1591,7 +1593,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
     else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
-    else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 128; }                  // gains by key
+    else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 2 * GKF * 4; }                  // gains by key
     else if (!strcmp(name, "vchild")) { src = f->vt.child; avail = (size_t)f->vt.vcap * 8; }              // value id by key
     else if (!strcmp(name, "vcount")) { src = f->vt.count; avail = 4; }                                 // value ids handed out (current generation)
     else if (!strcmp(name, "cov")) { src = f->layer[f->scan % f->R].cov; avail = (size_t)f->Ncap * 4; }     // keys of the newest layer's nodes

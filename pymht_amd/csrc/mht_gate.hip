@@ -493,8 +493,8 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint) {
 }
 
 void fill_model_only(Model& o, const mht_model* m) {
-    for (int i = 0; i < 16; ++i) { o.A[i] = m->A[i]; o.Q[i] = m->Q[i]; }
-    for (int i = 0; i < 8; ++i) o.C[i] = m->C[i];
+    for (int i = 0; i < NP; ++i) { o.A[i] = m->A[i]; o.Q[i] = m->Q[i]; }
+    for (int i = 0; i < NK; ++i) o.C[i] = m->C[i];
     for (int i = 0; i < 4; ++i) o.R[i] = m->R[i];
     o.eta2 = m->eta2;
     o.lambda_ex = m->lambda_ex;
@@ -513,6 +513,7 @@ using namespace mht;
 extern "C" int mht_gate_scan(mht_ctx* ctx, const mht_model* model, const mht_nodes* in, const int32_t* leaf_src,
                              int32_t L, const float* z, int32_t M, const mht_nodes* out, int32_t* child_ptr,
                              double* nllr, uint64_t* used, int32_t* n_children) {
+    MHT_REQUIRE(NX == 4, "mht_gate_scan: the tile kernel of this seam is 4-state; this is the %d-state build of the library (use mht_gate_scan_x)", NX);
     MHT_REQUIRE(ctx && model && in && out && child_ptr, "mht_gate_scan: null argument");
     MHT_REQUIRE(L >= 0 && M >= 0 && M <= MAX_MEAS, "mht_gate_scan: need 0 <= M <= %d, L >= 0 (M=%d L=%d)", MAX_MEAS, M, L);
     MHT_REQUIRE(z || M == 0, "mht_gate_scan: z is null");

@@ -23,13 +23,25 @@
 #define MHT_HD inline
 #endif
 
+// State dimension of this BUILD of the library: 4 (the reference's CV model, models/pv.py; the default, libmht_amd.so) or 6
+// (BASELINE config 5 names a 6-state model; libmht_amd6.so is the same sources compiled with -DMHT_NX=6).  The reference's kalman
+// module is dimension-generic (kalman.py:55-101); everything below is written for NX states and 2 measurements.
+#ifndef MHT_NX
+#define MHT_NX 4
+#endif
+
 namespace mht {
+
+constexpr int NX = MHT_NX;      // states
+constexpr int NP = NX * NX;     // covariance entries
+constexpr int NK = 2 * NX;      // gain entries (NX x 2)
+static_assert(NX == 4 || NX == 6, "MHT_NX: 4 or 6 states");
 
 // The linear-Gaussian model, f32 like the reference's pv module (models/pv.py:7-34).
 struct Model {
-    float A[16];   // state transition Phi(T), row-major 4x4
-    float Q[16];   // process noise
-    float C[8];    // measurement matrix 2x4
+    float A[NP];   // state transition Phi(T), row-major NX x NX
+    float Q[NP];   // process noise
+    float C[NK];   // measurement matrix 2 x NX
     float R[4];    // measurement noise 2x2
     double eta2;   // gate threshold (chi-square, 2 dof)      tracker.py:110
     double lambda_ex;  // lambda_phi + lambda_nu                tracker.py:107
@@ -55,11 +67,11 @@ MHT_HD void gemm_chain(const TA* a, const TB* b, TO* c) {
 // Per-leaf quantities that do not depend on the measurements.
 template <typename TS>
 struct Predicted {
-    TS x_bar[4];
+    TS x_bar[NX];
     TS z_hat[2];
-    float P_bar[16];
-    float P_hat[16];
-    float K[8];      // 4x2
+    float P_bar[NP];
+    float P_hat[NP];
+    float K[NK];     // NX x 2
     float S[4];
     float S_inv[4];
 };
@@ -106,53 +118,53 @@ MHT_HD void inv2(const float* s, float* out) {
 // All float32, like the reference's model matrices; `with_phat` = false stops after K (the gains of a node whose children's
 // covariance is not needed yet).
 struct CovChain {
-    float P_bar[16];
-    float P_hat[16];
-    float K[8];      // 4x2
+    float P_bar[NP];
+    float P_hat[NP];
+    float K[NK];     // NX x 2
     float S[4];
     float S_inv[4];
 };
 MHT_HD void cov_chain(const Model& m, const float* P, CovChain& o, bool with_phat = true) {
     // kalman.py:62  P_bar = matmul(matmul(A, P), A.T) + Q
-    float AP[16], At[16], APA[16];
+    float AP[NP], At[NP], APA[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NX; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) At[i * 4 + j] = m.A[j * 4 + i];
-    gemm_chain<float, float, float, 4, 4, 4>(m.A, P, AP);
-    gemm_chain<float, float, float, 4, 4, 4>(AP, At, APA);
+        for (int j = 0; j < NX; ++j) At[i * NX + j] = m.A[j * NX + i];
+    gemm_chain<float, float, float, NX, NX, NX>(m.A, P, AP);
+    gemm_chain<float, float, float, NX, NX, NX>(AP, At, APA);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o.P_bar[i] = APA[i] + m.Q[i];
+    for (int i = 0; i < NP; ++i) o.P_bar[i] = APA[i] + m.Q[i];
     // kalman.py:90  S = matmul(matmul(C, P_bar), C.T) + R
-    float Ct[8], CP[8], CPC[4];
+    float Ct[NK], CP[NK], CPC[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Ct[j * 2 + i] = m.C[i * 4 + j];
-    gemm_chain<float, float, float, 2, 4, 4>(m.C, o.P_bar, CP);
-    gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, CPC);
+        for (int j = 0; j < NX; ++j) Ct[j * 2 + i] = m.C[i * NX + j];
+    gemm_chain<float, float, float, 2, NX, NX>(m.C, o.P_bar, CP);
+    gemm_chain<float, float, float, 2, NX, 2>(CP, Ct, CPC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o.S[i] = CPC[i] + m.R[i];
     // kalman.py:91  S_inv = np.linalg.inv(S)
     inv2(o.S, o.S_inv);
     // kalman.py:92  K = matmul(matmul(P_bar, C.T), S_inv)
-    float PCt[8];
-    gemm_chain<float, float, float, 4, 4, 2>(o.P_bar, Ct, PCt);
-    gemm_chain<float, float, float, 4, 2, 2>(PCt, o.S_inv, o.K);
+    float PCt[NK];
+    gemm_chain<float, float, float, NX, NX, 2>(o.P_bar, Ct, PCt);
+    gemm_chain<float, float, float, NX, 2, 2>(PCt, o.S_inv, o.K);
     if (!with_phat) return;
     // kalman.py:93  P_hat = P_bar - matmul(K.dot(C), P_bar)
-    float KC[16], KCP[16];
-    gemm_chain<float, float, float, 4, 2, 4>(o.K, m.C, KC);
-    gemm_chain<float, float, float, 4, 4, 4>(KC, o.P_bar, KCP);
+    float KC[NP], KCP[NP];
+    gemm_chain<float, float, float, NX, 2, NX>(o.K, m.C, KC);
+    gemm_chain<float, float, float, NX, NX, NX>(KC, o.P_bar, KCP);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o.P_hat[i] = o.P_bar[i] - KCP[i];
+    for (int i = 0; i < NP; ++i) o.P_hat[i] = o.P_bar[i] - KCP[i];
 }
 
 // kalman.py:61 / :89  x_bar = A.dot(x.T).T (A promoted to the state dtype), z_hat = C.dot(x_bar.T).T
 template <typename TS>
 MHT_HD void state_predict(const Model& m, const TS* x, TS* x_bar, TS* z_hat) {
-    gemm_chain<TS, float, TS, 4, 4, 1>(m.A, x, x_bar);
-    gemm_chain<TS, float, TS, 2, 4, 1>(m.C, x_bar, z_hat);
+    gemm_chain<TS, float, TS, NX, NX, 1>(m.A, x, x_bar);
+    gemm_chain<TS, float, TS, 2, NX, 1>(m.C, x_bar, z_hat);
 }
 
 // ---- ONE leaf / ONE hit: NumPy hands a matrix times a single column to BLAS gemv, not gemm --------------------------------------
@@ -182,9 +194,9 @@ MHT_HD TS gemv_row(const float* a, const TS* x) {
 template <typename TS>
 MHT_HD void state_predict_single(const Model& m, const TS* x, TS* x_bar, TS* z_hat) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_bar[i] = gemv_row<TS, 4>(m.A + i * 4, x);
+    for (int i = 0; i < NX; ++i) x_bar[i] = gemv_row<TS, NX>(m.A + i * NX, x);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, 4>(m.C + i * 4, x_bar);
+    for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, NX>(m.C + i * NX, x_bar);
 }
 
 template <typename TS>
@@ -194,9 +206,9 @@ MHT_HD void predict_precalc(const Model& m, const TS* x, const float* P, Predict
     CovChain c;
     cov_chain(m, P, c);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o.P_bar[i] = c.P_bar[i]; o.P_hat[i] = c.P_hat[i]; }
+    for (int i = 0; i < NP; ++i) { o.P_bar[i] = c.P_bar[i]; o.P_hat[i] = c.P_hat[i]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o.K[i] = c.K[i];
+    for (int i = 0; i < NK; ++i) o.K[i] = c.K[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o.S[i] = c.S[i]; o.S_inv[i] = c.S_inv[i]; }
 }
@@ -256,55 +268,55 @@ MHT_HD TS update_component_n(TS x_bar_i, float k0, float k1, const TS* zt, bool 
 template <typename TS>
 MHT_HD void update_state(const TS* x_bar, const float* K, const TS* zt, TS* x_hat, bool single_hit = false) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_hat[i] = update_component_n<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt, single_hit);
+    for (int i = 0; i < NX; ++i) x_hat[i] = update_component_n<TS>(x_bar[i], K[i * 2], K[i * 2 + 1], zt, single_hit);
 }
 
 // ---- dimension-generic restatement (BASELINE config 5 names a 6-state model; the reference's kalman module is dimension-generic:
 //      kalman.py:55-101).  Same evaluation order as the 4-state code above, NX states, 2 measurements.
-template <int NX>
+template <int NXX>
 struct ModelX {
-    float A[NX * NX], Q[NX * NX], C[2 * NX], R[4];
+    float A[NXX * NXX], Q[NXX * NXX], C[2 * NXX], R[4];
     double eta2, lambda_ex;
 };
-template <typename TS, int NX>
-MHT_HD void predict_precalc_x(const ModelX<NX>& m, const TS* x, const float* P, TS* x_bar, TS* z_hat, float* P_bar, float* P_hat,
+template <typename TS, int NXX>
+MHT_HD void predict_precalc_x(const ModelX<NXX>& m, const TS* x, const float* P, TS* x_bar, TS* z_hat, float* P_bar, float* P_hat,
                               float* K, float* S, float* S_inv, bool single = false) {
     if (single) {             // one leaf in the call: gemv (gemv_row above)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x_bar[i] = gemv_row<TS, NX>(m.A + i * NX, x);
+        for (int i = 0; i < NXX; ++i) x_bar[i] = gemv_row<TS, NXX>(m.A + i * NXX, x);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, NX>(m.C + i * NX, x_bar);
+        for (int i = 0; i < 2; ++i) z_hat[i] = gemv_row<TS, NXX>(m.C + i * NXX, x_bar);
     } else {
-        gemm_chain<TS, float, TS, NX, NX, 1>(m.A, x, x_bar);              // kalman.py:61
-        gemm_chain<TS, float, TS, 2, NX, 1>(m.C, x_bar, z_hat);           // kalman.py:89
+        gemm_chain<TS, float, TS, NXX, NXX, 1>(m.A, x, x_bar);              // kalman.py:61
+        gemm_chain<TS, float, TS, 2, NXX, 1>(m.C, x_bar, z_hat);           // kalman.py:89
     }
-    float AP[NX * NX], At[NX * NX], APA[NX * NX];
+    float AP[NXX * NXX], At[NXX * NXX], APA[NXX * NXX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
+    for (int i = 0; i < NXX; ++i)
 #pragma unroll
-        for (int j = 0; j < NX; ++j) At[i * NX + j] = m.A[j * NX + i];
-    gemm_chain<float, float, float, NX, NX, NX>(m.A, P, AP);          // kalman.py:62
-    gemm_chain<float, float, float, NX, NX, NX>(AP, At, APA);
+        for (int j = 0; j < NXX; ++j) At[i * NXX + j] = m.A[j * NXX + i];
+    gemm_chain<float, float, float, NXX, NXX, NXX>(m.A, P, AP);          // kalman.py:62
+    gemm_chain<float, float, float, NXX, NXX, NXX>(AP, At, APA);
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) P_bar[i] = APA[i] + m.Q[i];
-    float Ct[2 * NX], CP[2 * NX], CPC[4];
+    for (int i = 0; i < NXX * NXX; ++i) P_bar[i] = APA[i] + m.Q[i];
+    float Ct[2 * NXX], CP[2 * NXX], CPC[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NX; ++j) Ct[j * 2 + i] = m.C[i * NX + j];
-    gemm_chain<float, float, float, 2, NX, NX>(m.C, P_bar, CP);       // kalman.py:90
-    gemm_chain<float, float, float, 2, NX, 2>(CP, Ct, CPC);
+        for (int j = 0; j < NXX; ++j) Ct[j * 2 + i] = m.C[i * NXX + j];
+    gemm_chain<float, float, float, 2, NXX, NXX>(m.C, P_bar, CP);       // kalman.py:90
+    gemm_chain<float, float, float, 2, NXX, 2>(CP, Ct, CPC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) S[i] = CPC[i] + m.R[i];
     inv2(S, S_inv);                                                   // kalman.py:91
-    float PCt[2 * NX];
-    gemm_chain<float, float, float, NX, NX, 2>(P_bar, Ct, PCt);       // kalman.py:92
-    gemm_chain<float, float, float, NX, 2, 2>(PCt, S_inv, K);
-    float KC[NX * NX], KCP[NX * NX];
-    gemm_chain<float, float, float, NX, 2, NX>(K, m.C, KC);           // kalman.py:93
-    gemm_chain<float, float, float, NX, NX, NX>(KC, P_bar, KCP);
+    float PCt[2 * NXX];
+    gemm_chain<float, float, float, NXX, NXX, 2>(P_bar, Ct, PCt);       // kalman.py:92
+    gemm_chain<float, float, float, NXX, 2, 2>(PCt, S_inv, K);
+    float KC[NXX * NXX], KCP[NXX * NXX];
+    gemm_chain<float, float, float, NXX, 2, NXX>(K, m.C, KC);           // kalman.py:93
+    gemm_chain<float, float, float, NXX, NXX, NXX>(KC, P_bar, KCP);
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) P_hat[i] = P_bar[i] - KCP[i];
+    for (int i = 0; i < NXX * NXX; ++i) P_hat[i] = P_bar[i] - KCP[i];
 }
 
 // np.add.reduce of a contiguous 1-D array, streamed: element i of n (pairwise_sum of NumPy's loops: n < 8 sequential; else eight

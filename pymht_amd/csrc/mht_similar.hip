@@ -32,10 +32,12 @@ __device__ __forceinline__ bool is_near(const SimilarArgs& a, int g, float p0x, 
 
 template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarArgs& a, int t, int h, int ce, int n, float p0x, float p0y) {
     const size_t cap = a.cap;
-    TS xs[4] = {(TS)0, (TS)0, (TS)0, (TS)0};
-    float Ps[16], P1[16];
+    TS xs[NX];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Ps[e] = 0.f;
+    for (int k = 0; k < NX; ++k) xs[k] = (TS)0;
+    float Ps[NP], P1[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) Ps[e] = 0.f;
     int first = -1, i = 0;
     uint8_t fl = 0;
     bool score_f32 = false;
@@ -43,21 +45,21 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
     for (int g = h + 1; g < ce && a.meas[g] > 0; ++g) {
         if (!is_near(a, g, p0x, p0y)) continue;
         const uint8_t fg = a.flags[g];
-        float P[16];
+        float P[NP];
         vt_load(a.vt, a.vt.child[a.cov[g]], P);
         if (first < 0) {
             first = g; fl = fg;
             score_f32 = (fg & F_SCORE_F32) != 0;      // (the hit children of one node share their dtypes)
             if (score_f32) sf.begin(n); else sd.begin(n);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xs[k] = (TS)a.x[(size_t)k * cap + g];
+            for (int k = 0; k < NX; ++k) xs[k] = (TS)a.x[(size_t)k * cap + g];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { Ps[e] = P[e]; P1[e] = P[e]; }
+            for (int e = 0; e < NP; ++e) { Ps[e] = P[e]; P1[e] = P[e]; }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xs[k] = xs[k] + (TS)a.x[(size_t)k * cap + g];
+            for (int k = 0; k < NX; ++k) xs[k] = xs[k] + (TS)a.x[(size_t)k * cap + g];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Ps[e] = Ps[e] + P[e];
+            for (int e = 0; e < NP; ++e) Ps[e] = Ps[e] + P[e];
         }
         if (score_f32) sf.add(i, (float)a.cnllr[g]); else sd.add(i, a.cnllr[g]);
         a.flags[g] = (uint8_t)(fg | F_DEAD);
@@ -66,10 +68,10 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
     // the merged node, in the slot of the missed-detection child (pyTarget.py:392-412)
     const TS cnt = (TS)n;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a.x[(size_t)k * cap + h] = (double)div_rn(xs[k], cnt);
+    for (int k = 0; k < NX; ++k) a.x[(size_t)k * cap + h] = (double)div_rn(xs[k], cnt);
     bool same = true;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < NP; ++e) {
         Ps[e] = __fdiv_rn(Ps[e], (float)n);
         same = same && (__float_as_uint(Ps[e]) == __float_as_uint(P1[e]));
     }
@@ -85,10 +87,10 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
         const unsigned pid = atomicAdd(a.vt.count, 1u);      // a key of its own: a pseudo parent whose miss child is the mean
         if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; return; }
         const int key = 2 * (int)pid;
-        float4 rec[4];
+        float4 rec[GKQ];
         vt_gains(a.model, Ps, pd, rec);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a.vt.Gk[(size_t)key * 4 + e] = rec[e];
+        for (int e = 0; e < GKQ; ++e) a.vt.Gk[(size_t)key * GKQ + e] = rec[e];
         a.vt.child[key] = id0;
         a.cov[h] = key;
     }

@@ -17,7 +17,7 @@
 // the hash slots are 64-bit words {tag, id + 1} driven by agent-scope atomics (they execute at the memory side); an inserter
 // claims an empty slot (id field all ones), takes an id, writes the value with agent-scope atomic stores, waits for their
 // acknowledgement and only then publishes the id in the slot.  A finder that meets a claimed slot re-reads it; one that meets
-// a published slot with its tag compares all 18 words through agent-scope loads.  child[] / Gk[] / duplicates of a transition
+// a published slot with its tag compares all words of the value through agent-scope loads.  child[] / Gk[] / duplicates of a transition
 // computed twice carry identical values: plain stores, consumed after the kernel boundary.  Value ids are handles: which id a
 // value gets depends on the timing, nothing else does.
 #pragma once
@@ -27,9 +27,9 @@
 namespace mht {
 
 struct VTab {
-    unsigned long long* Pv;        // [vcap][8] the 16 floats of a covariance as 8 words
+    unsigned long long* Pv;        // [vcap][VT_PW] the NX * NX floats of a covariance as 64-bit words
     double* pdv;                   // [vcap] P_d of the value (part of its identity: the score constant depends on it)
-    float4* Gk;                    // [2 * vcap][4] gains by key
+    float4* Gk;                    // [2 * vcap][GKQ] gains by key
     int32_t* child;                // [2 * vcap] value id by key, -1 = transition not computed yet
     unsigned long long* slots;     // [hmask + 1] hash table
     unsigned* count;               // value ids handed out
@@ -43,7 +43,7 @@ constexpr unsigned VT_PENDING = 0xffffffffu;
 __device__ __forceinline__ unsigned long long vt_hash(const unsigned long long* w, double pd) {
     unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)__double_as_longlong(pd);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < VT_PW; ++q) {
         h ^= w[q];
         h *= 0xff51afd7ed558ccdull;
         h ^= h >> 29;
@@ -56,9 +56,9 @@ __device__ __forceinline__ unsigned long long vt_hash(const unsigned long long* 
 // value id of (P, pd): found or inserted.  Every lane may call this with its own value (no lane waits inside an iteration for
 // another lane of its wavefront: a claim is published within the iteration that made it).
 template <typename VT> __device__ __forceinline__ int vt_find_or_insert(const VT& t, const float* P, double pd) {
-    unsigned long long w[8];
+    unsigned long long w[VT_PW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = ((unsigned long long)__float_as_uint(P[2 * q + 1]) << 32) | __float_as_uint(P[2 * q]);
+    for (int q = 0; q < VT_PW; ++q) w[q] = ((unsigned long long)__float_as_uint(P[2 * q + 1]) << 32) | __float_as_uint(P[2 * q]);
     const unsigned long long h = vt_hash(w, pd);
     const unsigned tag = (unsigned)(h >> 32);
     unsigned pos = (unsigned)h & t.hmask;
@@ -75,7 +75,7 @@ template <typename VT> __device__ __forceinline__ int vt_find_or_insert(const VT
                     return 0;
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) __hip_atomic_store(&t.Pv[(size_t)id * 8 + q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 0; q < VT_PW; ++q) __hip_atomic_store(&t.Pv[(size_t)id * VT_PW + q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(&t.pdv[id]), (unsigned long long)__double_as_longlong(pd), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the value has arrived before its id becomes visible
@@ -91,7 +91,7 @@ template <typename VT> __device__ __forceinline__ int vt_find_or_insert(const VT
             bool same = (unsigned long long)__double_as_longlong(pd) ==
                         __hip_atomic_load(reinterpret_cast<unsigned long long*>(&t.pdv[id]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) same = same && (w[q] == __hip_atomic_load(&t.Pv[(size_t)id * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int q = 0; q < VT_PW; ++q) same = same && (w[q] == __hip_atomic_load(&t.Pv[(size_t)id * VT_PW + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (same) return (int)id;
         }
         pos = (pos + 1u) & t.hmask;      // another value lives here
@@ -102,25 +102,33 @@ template <typename VT> __device__ __forceinline__ int vt_find_or_insert(const VT
 
 // the covariance of value `id` (written in an earlier launch, or by this thread)
 template <typename VT> __device__ __forceinline__ void vt_load(const VT& t, int id, float* P) {
-    const uint4* p = reinterpret_cast<const uint4*>(t.Pv + (size_t)id * 8);
+    const uint4* p = reinterpret_cast<const uint4*>(t.Pv + (size_t)id * VT_PW);      // (VT_PW is even: 16-byte records)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NP / 4; ++q) {
         const uint4 v = p[q];
         P[4 * q] = __uint_as_float(v.x); P[4 * q + 1] = __uint_as_float(v.y); P[4 * q + 2] = __uint_as_float(v.z); P[4 * q + 3] = __uint_as_float(v.w);
     }
 }
 
-// what a leaf with covariance P needs: S^-1 (4), K (8), score constant, gate half-axes
+// what a leaf with covariance P needs, one row of GKF floats: S^-1 (4), K (NX x 2), score constant, the two gate half-axes, padding
 __device__ __forceinline__ void vt_gains(const Model& m, const float* P, double pd, float4* g) {
     CovChain c;
     cov_chain(m, P, c, false);
-    const float lnc = nllr_const(c.S, m.lambda_ex, pd);
-    const float rx = sqrtf((float)m.eta2 * fabsf(c.S[0])), ry = sqrtf((float)m.eta2 * fabsf(c.S[3]));
-    g[0] = make_float4(c.S_inv[0], c.S_inv[1], c.S_inv[2], c.S_inv[3]);
-    g[1] = make_float4(c.K[0], c.K[1], c.K[2], c.K[3]);
-    g[2] = make_float4(c.K[4], c.K[5], c.K[6], c.K[7]);
-    g[3] = make_float4(lnc, rx, ry, 0.f);
+    float row[GKF];
+#pragma unroll
+    for (int e = 0; e < GKF; ++e) row[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) row[e] = c.S_inv[e];
+#pragma unroll
+    for (int e = 0; e < NK; ++e) row[4 + e] = c.K[e];
+    row[4 + NK] = nllr_const(c.S, m.lambda_ex, pd);
+    row[5 + NK] = sqrtf((float)m.eta2 * fabsf(c.S[0]));
+    row[6 + NK] = sqrtf((float)m.eta2 * fabsf(c.S[3]));
+#pragma unroll
+    for (int q = 0; q < GKQ; ++q) g[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
 }
+// the fields of a gains row
+constexpr int GK_LNC = 4 + NK, GK_RX = 5 + NK, GK_RY = 6 + NK;
 #endif
 
 }  // namespace mht

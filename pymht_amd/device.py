@@ -17,9 +17,10 @@ def require_gpu():
 class Context:
     """One mht_ctx bound to torch's current stream on `device`."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, nx=4):
         require_gpu()
-        self.lib = _lib.load()
+        self.nx = int(nx)
+        self.lib = _lib.load(nx=self.nx)      # libmht_amd.so, or the six-state build libmht_amd6.so
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.current_stream(self.device)
@@ -43,8 +44,9 @@ class Context:
 
 
 def make_model(A, Q, Cm, R, eta2, lambda_ex, default_pd):
-    m = _lib.MhtModel()
-    for name, arr, n in (("A", A, 16), ("Q", Q, 16), ("C", Cm, 8), ("R", R, 4)):
+    nx = int(np.asarray(A).shape[0])
+    m = _lib.model_type(nx)()
+    for name, arr, n in (("A", A, nx * nx), ("Q", Q, nx * nx), ("C", Cm, 2 * nx), ("R", R, 4)):
         a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
         assert a.size == n, name
         getattr(m, name)[:] = a.tolist()

@@ -26,13 +26,19 @@ from .utils.xmlDefinitions import activeTag, outofrangeTag, preinitializedTag, t
 
 log = logging.getLogger(__name__)
 
-_REPORT_DTYPE = np.dtype([("id", "<i4"), ("status", "<i4"), ("sel_node", "<i4"), ("sel_meas", "<i4"),
-                          ("new_index", "<i4"), ("root_scan", "<i4"), ("root_node", "<i4"), ("n_leaves", "<i4"),
-                          ("sel_x", "<f8", (4,)), ("sel_cnllr", "<f8"), ("score", "<f8"), ("root_cnllr", "<f8"),
-                          ("root_x", "<f8", (4,)), ("root_meas", "<i4"), ("cluster", "<i4")])
-assert _REPORT_DTYPE.itemsize == C.sizeof(_lib.MhtTargetReport)
-_BIRTH_DTYPE = np.dtype([("id", "<i4"), ("meas", "<i4"), ("x0", "<f8", (4,)), ("P0", "<f4", (16,))])
-assert _BIRTH_DTYPE.itemsize == C.sizeof(_lib.MhtBirthReport)
+def _report_dtypes(nx):
+    """NumPy views of mht_target_report / mht_birth_report for the nx-state build of the library (include/mht_amd.h: MHT_NX)."""
+    rep = np.dtype([("id", "<i4"), ("status", "<i4"), ("sel_node", "<i4"), ("sel_meas", "<i4"),
+                    ("new_index", "<i4"), ("root_scan", "<i4"), ("root_node", "<i4"), ("n_leaves", "<i4"),
+                    ("sel_x", "<f8", (nx,)), ("sel_cnllr", "<f8"), ("score", "<f8"), ("root_cnllr", "<f8"),
+                    ("root_x", "<f8", (nx,)), ("root_meas", "<i4"), ("cluster", "<i4")])
+    birth = np.dtype([("id", "<i4"), ("meas", "<i4"), ("x0", "<f8", (nx,)), ("P0", "<f4", (nx * nx,))])
+    return rep, birth
+
+
+_REPORT_DTYPE, _BIRTH_DTYPE = _report_dtypes(4)
+assert _REPORT_DTYPE.itemsize == C.sizeof(_lib.MhtTargetReport) and _BIRTH_DTYPE.itemsize == C.sizeof(_lib.MhtBirthReport)
+assert _report_dtypes(6)[0].itemsize == C.sizeof(_lib.MhtTargetReport6) and _report_dtypes(6)[1].itemsize == C.sizeof(_lib.MhtBirthReport6)
 _STATUS_TAG = {0: activeTag, 1: outofrangeTag, 2: toolowscoreTag, 3: toolowscoreTag}
 
 
@@ -96,8 +102,15 @@ class Tracker():
         self.targetSizeLimit = 3000      # (tracker.py:118: only used by the reference's dynamic window; kept for the XML settings block)
         self._prune_similar_on = False      # (what the device forest is currently set to; decided per scan like the reference does)
         # MI355X side
-        self.useInitiator = kwargs.get('useInitiator', True)
-        self._ctx = Context(kwargs.get('device', 0))
+        # state dimension: 4 (the reference's models/pv) or 6 (e.g. pymht_amd.models.ca -- BASELINE config 5 names a six-state model; the
+        # reference's kalman module is dimension-generic, its tracker and initiator are not): the six-state build of the library
+        self.nx = int(np.asarray(self.C).shape[1])
+        assert self.nx in (4, 6), "pymht_amd is built for 4- and 6-state models"
+        self._REPORT_DTYPE, self._BIRTH_DTYPE = _report_dtypes(self.nx)
+        self.useInitiator = kwargs.get('useInitiator', self.nx == 4)
+        if self.useInitiator and self.nx != 4:
+            raise NotImplementedError("the M-of-N initiator is the reference's 4-state one (m_of_n.py imports models/pv): useInitiator=False for a six-state model")
+        self._ctx = Context(kwargs.get('device', 0), nx=self.nx)
         self._lib = self._ctx.lib
         self._model = make_model(self.A, self.Q, self.C, self.R_RADAR, self.eta2, self.lambda_ex, self.default_P_d)
         cfg = _lib.MhtForestConfig()
@@ -126,7 +139,7 @@ class Tracker():
         self._timing = bool(kwargs.get('deviceTiming', False))
         _lib.check(self._lib.mht_forest_set_timing(self._ctx.handle, int(self._timing)))
         # host mirror of the target list (one row per target, target-list order)
-        self._tbl_ = np.zeros(0, dtype=_REPORT_DTYPE)      # (only id, root_scan, root_node, root_meas, root_x, root_cnllr are read)
+        self._tbl_ = np.zeros(0, dtype=self._REPORT_DTYPE)      # (only id, root_scan, root_node, root_meas, root_x, root_cnllr are read)
         self._sel_ = None            # report records of the live targets after the last scan (selected leaves)
         self._labels = np.zeros(0, np.int64)
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
@@ -157,8 +170,8 @@ class Tracker():
         n = len(targets)
         if n == 0:
             return []
-        x0 = np.ascontiguousarray(np.array([np.asarray(t.x_0, dtype=np.float64) for t in targets]).reshape(n, 4))
-        P0 = np.ascontiguousarray(np.array([np.asarray(t.P_0, dtype=np.float32) for t in targets]).reshape(n, 16))
+        x0 = np.ascontiguousarray(np.array([np.asarray(t.x_0, dtype=np.float64) for t in targets]).reshape(n, self.nx))
+        P0 = np.ascontiguousarray(np.array([np.asarray(t.P_0, dtype=np.float32) for t in targets]).reshape(n, self.nx * self.nx))
         f32 = np.array([np.asarray(t.x_0).dtype == np.float32 for t in targets])
         flags = np.where(f32, _lib.F_STATE_F32 | _lib.F_SCORE_F32, 0).astype(np.uint8)
         pd = np.full(n, self.default_P_d, dtype=np.float64)
@@ -173,7 +186,7 @@ class Tracker():
         out = [t for t, a in zip(targets, ok) if a]
         if not out:
             return out
-        rows = np.zeros(len(out), dtype=_REPORT_DTYPE)
+        rows = np.zeros(len(out), dtype=self._REPORT_DTYPE)
         rows["id"], rows["root_scan"], rows["root_node"], rows["root_meas"], rows["root_x"] = ids[ok], scan, -1, meas[ok], x0[ok]
         self._tbl_ = np.concatenate([self._tbl_, rows])
         for t, i in zip(out, ids[ok]):
@@ -297,8 +310,8 @@ class Tracker():
         assert rep.scan == scanNumber
         nT = rep.n_targets
         # (copied as bytes, viewed afterwards: NumPy copies a structured array field by field, 12x slower)
-        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * _REPORT_DTYPE.itemsize,)) \
-            .copy().view(_REPORT_DTYPE) if nT else np.zeros(0, dtype=_REPORT_DTYPE)
+        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * self._REPORT_DTYPE.itemsize,)) \
+            .copy().view(self._REPORT_DTYPE) if nT else np.zeros(0, dtype=self._REPORT_DTYPE)
         used_words = np.ctypeslib.as_array(C.cast(rep.used, C.POINTER(C.c_uint64)), shape=(max(rep.used_words, 1),)).copy()
         used = np.unpackbits(used_words.view(np.uint8), bitorder="little")[:nRadarMeas].astype(bool)
         unusedRadarMeasurementIndices = ~used
@@ -321,8 +334,8 @@ class Tracker():
         self._nOptimSolved_ = rep.n_ilp
         births = None
         if rep.n_births:
-            births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * _BIRTH_DTYPE.itemsize,)) \
-                .copy().view(_BIRTH_DTYPE)
+            births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * self._BIRTH_DTYPE.itemsize,)) \
+                .copy().view(self._BIRTH_DTYPE)
         self._apply_report(recs, scanTime, scanNumber, z)
         if births is not None:
             self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
@@ -365,12 +378,12 @@ class Tracker():
         b = births[ok]
         n = len(b)
         x0 = b["x0"].astype(np.float32)
-        rows = np.zeros(n, dtype=_REPORT_DTYPE)
+        rows = np.zeros(n, dtype=self._REPORT_DTYPE)
         rows["id"], rows["root_scan"], rows["root_node"], rows["root_meas"], rows["root_x"] = b["id"], scanNumber, -1, b["meas"], b["x0"]
         self._tbl_ = np.concatenate([self._tbl_, rows])
         for i in range(n):
             m = int(b["meas"][i])
-            self._birth[int(b["id"][i])] = (scanTime, scanNumber, x0[i], b["P0"][i].reshape(4, 4).copy(), (m if m > 0 else None),
+            self._birth[int(b["id"][i])] = (scanTime, scanNumber, x0[i], b["P0"][i].reshape(self.nx, self.nx).copy(), (m if m > 0 else None),
                                             (z_unused[m - 1] if m > 0 else None), activeTag)
         self.trackIdCounter = int(b["id"].max()) + 1
         self._views.clear()
@@ -550,9 +563,9 @@ class Tracker():
         n_max = self._cfg.n_scan + 2
         nodes = np.zeros(n_max, dtype=np.int32)
         meas = np.zeros(n_max, dtype=np.int32)
-        x = np.zeros((n_max, 4))
+        x = np.zeros((n_max, self.nx))
         cn = np.zeros(n_max)
-        P = np.zeros((n_max, 16), dtype=np.float32)
+        P = np.zeros((n_max, self.nx * self.nx), dtype=np.float32)
         n = C.c_int32(0)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         _lib.check(self._lib.mht_forest_chain(self._ctx.handle, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P), C.byref(n)))
@@ -565,7 +578,7 @@ class Tracker():
         before a prune that cut its branch off: the chain ends there (parent None) instead of being joined to a foreign root."""
         nodes, meas, x, cn, P = chain
         if len(P):
-            view.P_0 = P[0].reshape(4, 4).copy()
+            view.P_0 = P[0].reshape(self.nx, self.nx).copy()
         prev = view
         for k in range(1, len(nodes)):
             sc = view.scanNumber - k
@@ -577,7 +590,7 @@ class Tracker():
             zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
             m = int(meas[k])
             a = DeviceTarget(self.__scanHistory__[sc - 1].time if sc >= 1 else view.time, sc, x[k].copy(),
-                             P[k].reshape(4, 4).copy(), ID=target_id, P_d=self.default_P_d, measurementNumber=m,
+                             P[k].reshape(self.nx, self.nx).copy(), ID=target_id, P_d=self.default_P_d, measurementNumber=m,
                              measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
                              cumulativeNLLR=float(cn[k]))
             a._tracker, a._node = self, int(nodes[k])
@@ -618,7 +631,7 @@ class Tracker():
 
     def _leaf_export(self, cap):
         n = C.c_int32(0)
-        x = np.zeros((cap, 4)); P = np.zeros((cap, 16), dtype=np.float32); cn = np.zeros(cap)
+        x = np.zeros((cap, self.nx)); P = np.zeros((cap, self.nx * self.nx), dtype=np.float32); cn = np.zeros(cap)
         meas = np.zeros(cap, dtype=np.int32); tgt = np.zeros(cap, dtype=np.int32); ids = np.zeros(cap, dtype=np.int32)
         node = np.zeros(cap, dtype=np.int32); fl = np.zeros(cap, dtype=np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -626,7 +639,7 @@ class Tracker():
         if n.value > cap and cap < self._cfg.max_nodes:
             return None      # (more leaves than the estimate -- the export is truncated to the capacity: the caller retries with the full one)
         k = min(n.value, cap)
-        return dict(x=x[:k], P=P[:k].reshape(k, 4, 4), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
+        return dict(x=x[:k], P=P[:k].reshape(k, self.nx, self.nx), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
                     node=node[:k], flags=fl[:k])
 
     def leafBatch(self):

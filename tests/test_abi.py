@@ -6,13 +6,17 @@ from pymht_amd import _lib
 
 
 def test_library_loads_and_exports_header_symbols():
-    lib = _lib.load()
-    assert os.path.exists(_lib.LIB_PATH)
-    assert lib.mht_abi_version() == 1
+    """Both builds of the library -- libmht_amd.so (4 states) and libmht_amd6.so (the same sources with -DMHT_NX=6) -- load and export
+    every entry point the header declares; no compute call without a GPU."""
+    from pymht_amd import build
     names = _lib.exported_symbols()
-    assert "mht_gate_scan" in names and "mht_create" in names
-    for name in names:
-        assert hasattr(lib, name), "libmht_amd.so does not export %s" % name
+    assert "mht_gate_scan" in names and "mht_create" in names and "mht_forest_scan" in names
+    for nx in (4, 6):
+        lib = _lib.load(nx=nx)
+        assert os.path.exists(build.lib_path(nx))
+        assert lib.mht_abi_version() == 2
+        for name in names:
+            assert hasattr(lib, name), "%s does not export %s" % (os.path.basename(build.lib_path(nx)), name)
 
 
 def test_product_fails_loudly_without_gpu():

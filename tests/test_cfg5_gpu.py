@@ -1,38 +1,47 @@
-"""GPU, BASELINE config 5 by size: 2 000 targets, ~1 950 measurements per scan, N-scan 6 (the 6-state CT model the config names
-does not exist in the reference -- SURVEY.md fact 3 -- so this is the reference's 4-state CV model at that size).  The first scans
-are compared with the oracle (gating counts, unused measurements, clusters, selections, states, leaf sets); at the full size
-(~100 k leaves x 2 k measurements, ~250 k children per scan) the size-independent properties: no measurement used twice, leaves in
-target order, two runs identical."""
+"""GPU, BASELINE config 5 as named: a SIX-state model, 2 000 targets, ~1 950 measurements per scan, N-scan 6.  The reference ships
+no six-state model (its tracker is hard-wired to models/pv, only its kalman module is dimension-generic), so the
+model is the linear constant-acceleration one of pymht_amd/models/ca.py (the matrices of the g11 / g15 / g17 known-answer vectors,
+made with the reference's kalman module) in the six-state forest (libmht_amd6.so).  The first scans are compared with the oracle
+(gating counts, unused measurements, clusters, selections, states, leaf sets); at the full size the size-independent properties:
+no measurement used twice, leaves in target order, two runs identical.  `test_cfg5_four_state_size` keeps the round-2 run of the
+same SIZE with the reference's own 4-state CV model."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def _tracker(sc):
+def _model(nx):
+    from pymht_amd.models import pv, ca
+    return pv if nx == 4 else ca
+
+
+def _tracker(sc, nx):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
-    from pymht_amd.models import pv
-    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=2304, maxNodes=1 << 20,
+    model = _model(nx)
+    trk = Tracker(model, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=2304, maxNodes=1 << 20,
                   maxMeasurements=2048, useInitiator=False)
-    cands = [Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]]
+    x0 = sc["x0"] if nx == 4 else np.concatenate([sc["x0"], np.zeros((len(sc["x0"]), 2))], axis=1)      # [x, y, vx, vy, ax = 0, ay = 0]
+    cands = [Target(sc["t0"], None, x.copy(), model.P0, status="preinitialized") for x in x0]
     admitted = set(id(t) for t in trk._add_targets(cands))
-    return trk, np.array([id(t) in admitted for t in cands])
+    return trk, np.array([id(t) in admitted for t in cands]), x0
 
 
-def _run(n_scans, oracle_scans=0):
+def _run(n_scans, oracle_scans=0, nx=6):
     from pymht_amd.utils.scenario import make_config
     from pymht_amd.utils.classDefinitions import MeasurementList
     sc = make_config("cfg5", seed=907, n_scans=n_scans)
-    trk, acc = _tracker(sc)
+    trk, acc, x0 = _tracker(sc, nx)
+    assert trk.nx == nx
     o = None
     if oracle_scans:
         from test_tracker_gpu import tracker_selected, states_close, SCORE_ATOL
         from trace_util import make_oracle
-        g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, x0=sc["x0"], t0=sc["t0"],
+        g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, x0=x0, t0=sc["t0"],
                  accepted=acc)      # (a few of the 2 000 are drawn within the merge threshold of an earlier one: the oracle must agree)
         assert trk.nTargets == int(acc.sum()) >= 1900
-        o = make_oracle(g, with_initiator=False)
+        o = make_oracle(g, with_initiator=False, model=None if nx == 4 else _model(nx))
     digest = []
     try:
         for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
@@ -44,7 +53,7 @@ def _run(n_scans, oracle_scans=0):
             assert len(np.unique(hits)) == len(hits), "scan %d: a measurement is used by two selected leaves" % k
             if o is not None and k < oracle_scans:
                 info = o.add_scan(float(t), z)
-                os_, ts = o.selected(), tracker_selected(trk)
+                os_, ts = o.selected(), tracker_selected(trk, nx)
                 assert (st["L"], st["G"]) == (info["L"], info["G"]) and np.array_equal(st["unused"], info["unused"]), k
                 assert np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]), k
                 assert states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL), k
@@ -60,12 +69,19 @@ def _run(n_scans, oracle_scans=0):
 
 
 def test_cfg5_first_scans_match_oracle():
-    d = _run(4, oracle_scans=4)
-    assert d[-1][0] >= 12000             # ~2 000 targets x ~1.9^3 leaves going into the fourth scan
+    d = _run(3, oracle_scans=3)
+    assert d[-1][0] >= 6000              # 2 000 targets, two scans of growth going into the third scan
 
 
 def test_cfg5_full_size_properties_and_reproducibility():
-    a = _run(10)
-    b = _run(10)
+    a = _run(9)
+    b = _run(9)
     assert a == b
-    assert a[-1][0] > 80000 and a[-1][2] > 100          # ~100 k leaves x ~1 950 measurements, a few hundred ILPs per scan
+    assert a[-1][0] > 80000 and a[-1][2] > 0            # ~100 k leaves x ~1 950 measurements (the constant-acceleration model's wider gates tie the
+    # targets into fewer, larger clusters than the CV model's few hundred)
+
+
+def test_cfg5_four_state_size():
+    """The same size with the reference's own 4-state CV model (what round 2 ran): first scans against the oracle."""
+    d = _run(4, oracle_scans=4, nx=4)
+    assert d[-1][0] >= 12000

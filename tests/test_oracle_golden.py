@@ -65,7 +65,7 @@ def test_blp_exact_survives_the_instance_that_crashes_highs_presolve():
 
 
 @pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3",
-                                  "g16_fgrow_kat"])
+                                  "g16_fgrow_kat", "g17_trace_6state"])
 def test_scan_trace_replay(gold_dir, name):
     """Replays the recorded scans through OracleTracker and compares every scan with what the reference did."""
     from trace_util import replay_oracle

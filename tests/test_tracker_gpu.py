@@ -40,10 +40,10 @@ def make_tracker(period, lambda_phi, lambda_nu, P_d, N, eta2, x0, t0, P0s=None, 
     return trk, acc
 
 
-def tracker_selected(trk):
+def tracker_selected(trk, nx=4):
     nodes = list(trk.getTrackNodes())
     return dict(ID=np.array([n.ID for n in nodes], dtype=np.int64),
-                x=np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes]).reshape(-1, 4),
+                x=np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes]).reshape(-1, nx),
                 cnllr=np.array([float(n.cumulativeNLLR) for n in nodes]),
                 meas=np.array([0 if n.measurementNumber is None else n.measurementNumber for n in nodes], dtype=np.int64))      # (None: a merged new target, m_of_n.py:150)
 

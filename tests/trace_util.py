@@ -20,15 +20,19 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def make_oracle(g, with_initiator=True):
+def make_oracle(g, with_initiator=True, model=None):
     from m_of_n_oracle import Initiator
     from pymht_amd.utils.classDefinitions import MeasurementList
     from pymht_amd.models import pv
     init = None
-    if with_initiator:
+    if with_initiator and model is None:
         init = OracleInitiatorAdapter(Initiator(2, 3, 20, pv.C_RADAR, pv.R_RADAR(), 4 * 2.5 ** 2), MeasurementList)
     o = orc.OracleTracker(float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]),
-                          N=int(g["N"]), eta2=float(g["eta2"]), initiator=init)
+                          N=int(g["N"]), eta2=float(g["eta2"]), initiator=init, model=model)
+    if model is not None:      # (a six-state model: pymht_amd.models.ca; roots carry the model's P0)
+        for x, ok in zip(g["x0"], g["accepted"]):
+            assert o.initiate_target(float(g["t0"]), x.copy(), model.P0.copy(), status="preinitialized") == bool(ok)
+        return o
     custom = "P0s" in (g.files if hasattr(g, "files") else g)      # g16: roots with their own covariance, some with float32 states
     for i, (x, ok) in enumerate(zip(g["x0"], g["accepted"])):
         xr = x.astype(np.float32) if (custom and g["x0_f32"][i]) else x.copy()
@@ -42,7 +46,9 @@ def states_close(a, b, rel=1e-6):
     zero carries the rounding of the ~1e2..1e3 m positions it was differenced from.  Needed for float32 chains only: targets born
     from the device initiator start from float32 states that agree with the reference's to an ulp, not bit for bit (its host BLAS
     orders 4-term dot products its own way); float64 chains of pre-initialised targets are bit-exact."""
-    a, b = np.asarray(a, dtype=np.float64).reshape(-1, 4), np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    nx = a.shape[-1] if a.ndim > 1 and a.shape[-1] in (4, 6) else 4
+    a, b = a.reshape(-1, nx), b.reshape(-1, nx)
     if a.shape != b.shape:
         return False
     if a.size == 0:
@@ -88,7 +94,10 @@ def check_scan_against_fixture(g, k, ids, sel, clusters, n_leaves, leaf=None, sc
 
 def replay_oracle(path):
     g = np.load(path)
-    o = make_oracle(g)
+    model = None
+    if "nx" in g.files and int(g["nx"]) == 6:
+        from pymht_amd.models import ca as model
+    o = make_oracle(g, model=model)
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
         info = o.add_scan(float(g["times"][k]), g[p + "z"], prune_similar=bool(g["prune_similar"]) if "prune_similar" in g else False)
@@ -98,5 +107,5 @@ def replay_oracle(path):
         check_scan_against_fixture(g, k, np.array([r.ID for r in o.targets]), o.selected(), o.clusters,
                                    len(leaf["ID"]), leaf, score_atol=2e-5)
         assert sorted(info["dead"]) == g[p + "dead"].tolist()
-        assert info["new_ids"] == g[p + "new_ids"].tolist()
+        assert list(info["new_ids"]) == g[p + "new_ids"].tolist()
     return o
