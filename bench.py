@@ -97,14 +97,30 @@ def pmc_traffic_live(config, timeout_s=180.0):
                 "KiB per fgrow_kernel dispatch, mean of the last quarter of the launches (steady state)"
 
 
+def model_of(sc):
+    """The tracking model of a config: the reference's 4-state CV model (models/pv.py), or -- BASELINE config 5 names a six-state model,
+    the reference ships none -- the constant-acceleration model pymht_amd/models/ca.py in the six-state build of the library."""
+    from pymht_amd.models import pv, ca
+    return ca if sc.get("name") == "cfg5" and os.environ.get("MHT_BENCH_CFG5_MODEL", "ca") == "ca" else pv
+
+
+def roots_of(sc, model):
+    nx = model.C_RADAR.shape[1]
+    return sc["x0"] if nx == 4 else np.concatenate([sc["x0"], np.zeros((len(sc["x0"]), nx - 4))], axis=1)
+
+
 def make_tracker(sc, device, **kw):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
-    from pymht_amd.models import pv
-    trk = Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, device=device,
-                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2048"))), maxNodes=kw.pop("maxNodes", int(os.environ.get("MHT_BENCH_MAXN", str(1 << 19)))),
-                  maxMeasurements=int(os.environ.get("MHT_BENCH_MAXM", "1024")), **kw)
-    trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+    model = model_of(sc)
+    big = sc.get("name") == "cfg5"
+    if model.C_RADAR.shape[1] != 4:
+        kw["useInitiator"] = False      # (the M-of-N initiator is the reference's 4-state one)
+    trk = Tracker(model, sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, device=device,
+                  maxTargets=kw.pop("maxTargets", int(os.environ.get("MHT_BENCH_MAXT", "2304" if big else "2048"))),
+                  maxNodes=kw.pop("maxNodes", int(os.environ.get("MHT_BENCH_MAXN", str(1 << (20 if big else 19))))),
+                  maxMeasurements=int(os.environ.get("MHT_BENCH_MAXM", "2048" if big else "1024")), **kw)
+    trk._add_targets([Target(sc["t0"], None, x.copy(), model.P0, status="preinitialized") for x in roots_of(sc, model)])
     return trk
 
 
@@ -125,7 +141,7 @@ def prepass(sc, device, n_untimed=0):
     def recording(b, scanTime, scanNumber, z_unused):
         orig(b, scanTime, scanNumber, z_unused)
         for r in b[b["id"] >= 0]:
-            births[scanNumber - 1].append(Born(r["x0"].astype(np.float32), r["P0"].reshape(4, 4).copy(), int(r["meas"])))
+            births[scanNumber - 1].append(Born(r["x0"].astype(np.float32), r["P0"].reshape(trk.nx, trk.nx).copy(), int(r["meas"])))
 
     trk._apply_births = recording
     # streaming use of the drop-in API: scans go in one after the other, results are looked at after the last one (every look at
@@ -165,10 +181,11 @@ class Replay:
         self.nb = [len(per) for per in births]
         self.boff = np.concatenate([[0], np.cumsum(self.nb)]).astype(np.int64)
         n = max(len(flat), 1)
-        x0 = np.zeros((n, 4)); P0 = np.zeros((n, 16), np.float32); fl = np.zeros(n, np.uint8); me = np.zeros(n, np.int32)
+        nx = self.nx = self.trk.nx
+        x0 = np.zeros((n, nx)); P0 = np.zeros((n, nx * nx), np.float32); fl = np.zeros(n, np.uint8); me = np.zeros(n, np.int32)
         for i, b in enumerate(flat):
             x0[i] = np.asarray(b.x_0, dtype=np.float64)
-            P0[i] = np.asarray(b.P_0, dtype=np.float32).reshape(16)
+            P0[i] = np.asarray(b.P_0, dtype=np.float32).reshape(nx * nx)
             fl[i] = 3 if np.asarray(b.x_0).dtype == np.float32 else 0
             me[i] = 0 if b.measurementNumber is None else int(b.measurementNumber)
         self.bx, self.bP = torch.from_numpy(x0).to(dev), torch.from_numpy(P0).to(dev)
@@ -196,7 +213,7 @@ class Replay:
         nb = self.nb[k]
         if nb:
             o = int(self.boff[k])
-            rc = lib.mht_forest_add_targets_dev(h, nb, self.bx.data_ptr() + o * 32, self.bP.data_ptr() + o * 64,
+            rc = lib.mht_forest_add_targets_dev(h, nb, self.bx.data_ptr() + o * 8 * self.nx, self.bP.data_ptr() + o * 4 * self.nx * self.nx,
                                                 self.bf.data_ptr() + o, self.bpd.data_ptr() + o * 8,
                                                 self.bm.data_ptr() + o * 4, 1, None, None)
             if rc:
@@ -205,7 +222,7 @@ class Replay:
     def report(self):
         rep = self._lib_mod.MhtScanReport()
         self._lib_mod.check(self.lib.mht_forest_report(self.h, C.byref(rep)))
-        from pymht_amd.tracker import _REPORT_DTYPE
+        _REPORT_DTYPE = self.trk._REPORT_DTYPE
         nT = rep.n_targets
         recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * _REPORT_DTYPE.itemsize,)) \
             .view(_REPORT_DTYPE).copy()
@@ -223,6 +240,8 @@ def cpu_baseline(sc, n_warm, n_timed):
     from m_of_n_oracle import Initiator
     from pymht_amd.utils.classDefinitions import MeasurementList
     from pymht_amd.models import pv
+    model = model_of(sc)
+    four = model.C_RADAR.shape[1] == 4
 
     class Adapter:
         def __init__(self):
@@ -232,9 +251,10 @@ def cpu_baseline(sc, n_warm, n_timed):
             return [(t.x_0, t.P_0, t.measurementNumber, t.measurement)
                     for t in self.i.processMeasurements(MeasurementList(time_, z))]
 
-    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, initiator=Adapter())
-    for x in sc["x0"]:
-        o.initiate_target(sc["t0"], x.copy(), orc.model_P0(), status="preinitialized")
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=sc["N"], eta2=ETA2, initiator=Adapter() if four else None,
+                          model=None if four else model)
+    for x in roots_of(sc, model):
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0() if four else model.P0.copy(), status="preinitialized")
     hot, stats = 0.0, []
     for k in range(n_warm + n_timed):
         info = o.add_scan(float(sc["times"][k]), sc["scans"][k])
@@ -341,7 +361,8 @@ def main():
     elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
     # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
     alive = [r for r in recs if int(r["status"]) == 0]
-    picture = parallel.gather_tracks([int(r["id"]) for r in alive], np.array([r["sel_x"] for r in alive]).reshape(-1, 4),
+    nx = model_of(sc).C_RADAR.shape[1]
+    picture = parallel.gather_tracks([int(r["id"]) for r in alive], np.array([r["sel_x"] for r in alive]).reshape(-1, nx)[:, :4],
                                      dist, device="cuda")
 
     # ---- stage times with HIP events on the launch stream (identical replay) ----------------------------------------
@@ -428,8 +449,11 @@ def main():
 
     timed = stats[W:W + K]
     Lm, Gm, Mm = float(timed[:, 0].mean()), float(timed[:, 1].mean()), float(timed[:, 2].mean())
-    # algorithmic bytes of the grow stage per scan: 280 B per leaf + 48 B per gated pair + 8 B per measurement
-    b_gate = 280.0 * Lm + 48.0 * Gm + 8.0 * Mm
+    # algorithmic bytes of the grow stage per scan: per leaf read x, P, cNLLR, P_d and write x_bar, P_bar, cNLLR, P_hat;
+    # per gated pair x_hat, cNLLR, measurement index, parent index; 8 B per measurement -- 280 / 48 / 8 at four states, 552 / 64 / 8 at six
+    per_leaf = (8 * nx + 4 * nx * nx + 16) + (8 * nx + 4 * nx * nx + 8 + 4 * nx * nx)
+    per_pair = 8 * nx + 16
+    b_gate = float(per_leaf) * Lm + float(per_pair) * Gm + 8.0 * Mm
     gate_gbs = b_gate / (ms[0] * 1e-3) / 1e9
     traffic, traffic_src = PMC_TRAFFIC_BYTES.get(args.config), \
         "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)"
@@ -445,7 +469,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64 state / f32 covariance (the reference's own mix)", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[2]: 500 targets, ~500 meas/scan, N-scan=5, P_d=0.9, eta2=5.99; " if args.config == "cfg3" else
-                                "config %s of pymht_amd/utils/scenario.py (NOT the headline workload): %d targets, N-scan=%d; " % (args.config, len(sc["x0"]), sc["N"])) +
+                                "config %s of pymht_amd/utils/scenario.py (NOT the headline workload): %d targets, N-scan=%d, %d-state model %s; " % (args.config, len(sc["x0"]), sc["N"], nx, model_of(sc).__name__.split(".")[-1])) +
                                "one independent sector per GPU" + (" -- STRONG: the same sector on every GPU, ILPs spread by cluster" if strong else ""), "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
                    "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),

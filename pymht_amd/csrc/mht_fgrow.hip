@@ -84,6 +84,47 @@ __device__ __forceinline__ int fg_sortable(float f) {      // monotone map float
 // leaves, and what the recursion has reached once it reaches again); otherwise the lane runs the chain P -> P_bar, S, K, P_hat
 // (kalman.py:62, :90-93), finds or inserts the child's covariance by value and writes its gains -- S^-1, K,
 // ln(lambda_ex sqrt(det 2 pi S)/P_d), gate half-axes, all from predict(child covariance).
+// One transition of the value table: the child (hit: h = 1, miss: h = 0) of covariance value `id` -- its covariance by value and ITS
+// gains, filed under key 2 * id + h (see chain_part)
+// Covariances are shared by VALUE across all targets (and sectors' targets of one forest): a transition that is new this scan is
+// usually met by many wavefronts at once.  The first one claims it (child[key]: -1 -> -2 with one agent-scope compare-and-swap) and
+// computes it; the others have nothing to wait for -- nobody reads the entry before the next scan -- and move on.
+constexpr int VT_CLAIMED = -2;
+template <typename ARGS>
+__device__ __forceinline__ void chain_resolve(const ARGS& a, int id, int h, double pd) {
+    const int ckey = 2 * id + h;
+    if (atomicCAS(&a.vt.child[ckey], -1, VT_CLAIMED) != -1) return;      // known, or somebody else is at it
+    float P[NP];
+    vt_load(a.vt, id, P);
+    Model mdl;          // (uniform registers)
+#pragma unroll
+    for (int e = 0; e < NP; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
+#pragma unroll
+    for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
+    mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
+    float Pc[NP];
+    {
+        CovChain c;
+        cov_chain(mdl, P, c, h != 0);      // (the miss child's covariance is P_bar: no S, K, P_hat needed)
+        if (h) {
+#pragma unroll
+            for (int e = 0; e < NP; ++e) Pc[e] = c.P_hat[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < NP; ++e) Pc[e] = c.P_bar[e];
+        }
+    }
+    {
+        float4 rec[GKQ];
+        vt_gains(mdl, Pc, pd, rec);
+#pragma unroll
+        for (int q = 0; q < GKQ; ++q) a.vt.Gk[(size_t)ckey * GKQ + q] = rec[q];
+    }
+    a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
+}
+
 template <typename ARGS>
 __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,36 +153,8 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
         const int id = a.vt.child[mykey];          // (set when the leaf was made: by this code one scan ago, or at its birth)
         const int ckey = 2 * id + h;
         if (a.vt.child[ckey] >= 0) continue;       // the transition is known
-        float P[NP];
-        vt_load(a.vt, id, P);
-        Model mdl;          // (uniform registers)
-#pragma unroll
-        for (int e = 0; e < NP; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
-#pragma unroll
-        for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
-        mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
-        float Pc[NP];
-        {
-            CovChain c;
-            cov_chain(mdl, P, c, h != 0);      // (the miss child's covariance is P_bar: no S, K, P_hat needed)
-            if (h) {
-#pragma unroll
-                for (int e = 0; e < NP; ++e) Pc[e] = c.P_hat[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < NP; ++e) Pc[e] = c.P_bar[e];
-            }
-        }
         const double pd = a.pd[mysrc];
-        {
-            float4 rec[GKQ];
-            vt_gains(mdl, Pc, pd, rec);
-#pragma unroll
-            for (int q = 0; q < GKQ; ++q) a.vt.Gk[(size_t)ckey * GKQ + q] = rec[q];
-        }
-        a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
+        chain_resolve(a, id, h, pd);
     }
     FG_STAMP(1);
 }
@@ -159,7 +172,9 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 template <typename TS, int PQ, typename ARGS>
 __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, int nh, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
-                                              double rootc, int root_f32) {
+                                              double rootc, int root_f32, const unsigned short* cand = nullptr, const float2* zg = nullptr) {
+    // (cand != null -- the wavefront-per-target kernel: the hit words index the target's candidate list, and the scan is read from
+    // global memory, zg, not from an LDS copy)
     const size_t cap = a.cap;
     const uint8_t fl = g.flags;
     int meas = 0, hit = 0, j = -1;
@@ -174,6 +189,7 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         }
         for (int q = 0; q < need; ++q) bits &= bits - 1;
         j = w * 64 + __ffsll((long long)bits) - 1;
+        if (cand) j = cand[j];
         meas = j + 1;
         hit = 1;
     }
@@ -209,7 +225,8 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         const double inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
         cnl = g.cn + inc;
     } else {
-        const float mx = zx[j], my = zy[j];
+        float mx, my;
+        if (zg) { const float2 v = zg[j]; mx = v.x; my = v.y; } else { mx = zx[j]; my = zy[j]; }
         TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, nis;
         gate_pair<TS>(zh, g.sinv, mx, my, (TS)a.model.eta2, zt, nis);
         const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19
@@ -685,6 +702,417 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     FG_STAMP(7);
 }
 
+// ---- wavefront-per-target variant (batched launches: several sectors' targets resident at once) -----------------------------
+// A target has ~27 leaves and ~25 gated pairs: a 256-thread workgroup per target (target_part) spends most of its 10 us waiting --
+// four dependent round trips and five barriers -- with 44 KB of LDS and 16 wavefront slots held per CU by four targets.  Here ONE
+// WAVEFRONT runs a target (four independent targets per 256-thread workgroup, no barrier between them), with ~9 KB of LDS:
+//   * lane = leaf (FW_LP per pass): records, gains, prediction, box -- as target_part's phase 1;
+//   * the scan is not staged in LDS: the lanes sweep it from global memory (4 KB, L2 resident) against the target's box; the
+//     candidates (a handful) go to an LDS list in ascending measurement order;
+//   * lane = (leaf, candidate): the exact gate; a leaf's hits are bits over the CANDIDATE list (one 64-bit word per 64 candidates and
+//     leaf, not ceil(M / 64) words per leaf);
+//   * lane = leaf: child counts, wave prefix; lane = child: emission (fg_emit_child).
+// Wave-synchronous: the phases of a wavefront are ordered by the in-order LDS pipeline and a wave-level fence, not by barriers.
+// Everything a target produces is what target_part produces for it (same blocks, same child order, same edge records).
+#ifndef MHT_FW_LP
+#define MHT_FW_LP 64
+#endif
+constexpr int FW_LP = MHT_FW_LP;      // leaves per pass, one per lane (32: 40 KB per workgroup, three per CU, but a third of the targets needs two passes: slower)
+constexpr int FW_MASKW = 64;          // 64-bit hit words of a wavefront: FW_LP leaves x up to 128 candidates in one pass; more candidates: fewer leaves per pass
+constexpr int FW_CZ = 64;             // candidates whose coordinates are kept in LDS (the rest are re-read from the scan)
+constexpr int FW_MAP = 256;           // child -> leaf table entries (more children: binary search)
+struct FWLayout { int lf, pp, ap, mask, tb, cand, candz, pref, map, total; };      // byte offsets inside a wavefront's LDS slice
+__host__ __device__ __forceinline__ FWLayout fw_layout(int pds, int AW, int Mpad) {
+    FWLayout o;
+    int b = 0;
+    o.lf = b; b += FW_LP * (int)sizeof(FLeaf);
+    o.pp = b; b += FW_LP * pds * 4;
+    o.ap = b; b += FW_LP * pds * 4;
+    o.mask = b; b += FW_MASKW * 8;
+    o.tb = b; b += AW * 8;
+    o.cand = b; b += (Mpad * 2 + 15) & ~15;
+    o.candz = b; b += FW_CZ * 8;
+    o.pref = b; b += ((FW_LP + 4) * 4 + 15) & ~15;
+    o.map = b; b += FW_MAP;
+    o.total = (b + 15) & ~15;
+    return o;
+}
+#ifdef MHT_GROW_STAMPS
+#define FW_STAMP(k) do { if (d.dbg && lane == 0 && t < 3900) d.dbg[32 + (size_t)t * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define FW_STAMP(k)
+#endif
+#define FW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int PQ>
+__device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, unsigned char* sm) {
+    constexpr int PDS = PQ * 4;
+    constexpr int LP = FW_LP;
+    const auto& a = *ap0;
+    const int lane = threadIdx.x & 63;
+    const int M = d.M, W = d.W, Mpad = W * 64, AW = a.AW;
+    const FWLayout lo = fw_layout(PDS, AW, Mpad);
+    FLeaf* lg = reinterpret_cast<FLeaf*>(sm + lo.lf);
+    int* s_pp = reinterpret_cast<int*>(sm + lo.pp);
+    int* s_ap = reinterpret_cast<int*>(sm + lo.ap);
+    unsigned long long* mk = reinterpret_cast<unsigned long long*>(sm + lo.mask);
+    unsigned long long* tb = reinterpret_cast<unsigned long long*>(sm + lo.tb);
+    unsigned short* cand = reinterpret_cast<unsigned short*>(sm + lo.cand);
+    float2* candz = reinterpret_cast<float2*>(sm + lo.candz);
+    int* s_pref = reinterpret_cast<int*>(sm + lo.pref);
+    unsigned char* s_map = reinterpret_cast<unsigned char*>(sm + lo.map);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- first round trip: everything addressed by the target slot alone ------------------------------------------------------------
+    FW_STAMP(0);
+    const int nT = a.nT_dev[0];
+    const int po = a.prev_status->overflow, so = *a.sticky_overflow;
+    const TInfo ti = target_info(a, d, t, nT);
+    const int tc = (t < a.Tcap) ? t : 0;
+    const double rootc = a.t_root_cnllr[tc];
+    const int root_f32 = a.t_root_f32[tc];
+    int acc = 0;
+    if (d.fused)          // compacted index of this target = alive slots before it (eight look-ups per batch: one round trip each)
+        for (int i0 = 0; i0 < t; i0 += 512) {
+            int v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = i0 + q * 64 + lane; v[q] = a.p_status[i < t ? i : 0]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (i0 + q * 64 + lane < t && v[q] == 0) ? 1 : 0;
+        }
+    if (po || so) {          // a scan that overflowed its pools voids every scan after it
+        if (t == 0 && lane == 0) a.status->overflow = po ? po : 1;
+        return;
+    }
+    if (!ti.alive) return;
+    FW_STAMP(1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const int pos = d.fused ? __builtin_amdgcn_readfirstlane(acc) : t;
+    for (int w = lane; w < AW; w += 64) tb[w] = 0ull;
+    const int depth0 = ti.depth, shift0 = ti.shift;
+    const int cnt = __builtin_amdgcn_readfirstlane(ti.cnt), first = __builtin_amdgcn_readfirstlane(ti.first);
+    const int curw = a.cur_slot_base >> 6;
+    const float2* z2 = reinterpret_cast<const float2*>(d.z);
+    // ONE live leaf in the target: gemv order of its prediction (see target_part / mht_math.h::gemv_row)
+    bool single = (cnt == 1);
+    if (d.maybe_dead && cnt > 1) {
+        int nl = 0;
+        for (int i = lane; i < cnt; i += 64) nl += (a.flags[first + i] & F_DEAD) ? 0 : 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nl += __shfl_xor(nl, o);
+        single = __builtin_amdgcn_readfirstlane(nl) == 1;
+    }
+
+    // The children go to the slot's static block of the node index space, chunk after chunk, as long as they fit (optimistic: no
+    // counting pass -- a target of 33..64 leaves takes two chunk iterations, not four).  A target whose children outgrow the block
+    // (rare) is counted first (pass 0) and then emitted into a piece of the overflow area.
+    int total = 0, run = 0, base = 0, ndead = 0;
+    int pass = 1;
+    bool counted = false;      // the counting pass has run
+    for (; pass < 2; ++pass) {
+        int c0 = 0;
+        bool redo = false;
+        while (c0 < cnt) {
+            int depth = __builtin_amdgcn_readfirstlane(depth0), shift = __builtin_amdgcn_readfirstlane(shift0);
+            asm volatile("" : "+s"(depth), "+s"(shift));
+            KArgs ap = ap0;
+            asm volatile("" : "+s"(ap));
+            const auto& a = *ap;
+            const int n = (cnt - c0 < LP) ? cnt - c0 : LP;
+            // ---- phase 1: lane = leaf ----------------------------------------------------------------------------------------------
+            int last = -1;
+            bool valid;
+            {
+                const bool in_chunk = lane < n;
+                const int src = first + c0 + (in_chunk ? lane : 0);
+                const uint8_t fl = a.flags[src];
+                valid = in_chunk && !(fl & F_DEAD);
+                const double cn = a.cnllr[src], pd = a.pd[src];
+                const int covc = a.cov[src];
+                double xd[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+                const int4* prec = reinterpret_cast<const int4*>(a.in_path + (size_t)src * PDS);
+                const int4* arec = reinterpret_cast<const int4*>(a.in_apath + (size_t)src * PDS);
+                int4 pq[PQ], aq[PQ];
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) { pq[q] = prec[q]; aq[q] = arec[q]; }
+                float4 gr[GKQ];
+#pragma unroll
+                for (int q = 0; q < GKQ; ++q) gr[q] = a.vt.Gk[(size_t)covc * GKQ + q];
+                const int cid = a.vt.child[covc];
+                FLeaf g;
+                g.valid = valid; g.src = src; g.flags = fl; g.f32state = (fl & F_STATE_F32) ? 1 : 0; g.cn = cn; g.pd = pd;
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    if (lane < LP) {
+                        reinterpret_cast<int4*>(s_pp + lane * PDS)[q] = pq[q];
+                        reinterpret_cast<int4*>(s_ap + lane * PDS)[q] = aq[q];
+                    }
+                    const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = q * 4 + e;
+                        if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
+                    }
+                }
+                if (!valid) last = -1;
+                Model mdl;
+#pragma unroll
+                for (int e = 0; e < NP; ++e) mdl.A[e] = a.model.A[e];
+#pragma unroll
+                for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
+                if (g.f32state) {
+                    float xs[NX], xb[NX], zh[2];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) xs[k] = (float)xd[k];
+                    state_predict<float>(mdl, xs, xb, zh);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) g.xbar[k] = (double)xb[k];
+                    g.zhat[0] = (double)zh[0]; g.zhat[1] = (double)zh[1];
+                } else {
+                    double xb[NX], zh[2];
+                    state_predict<double>(mdl, xd, xb, zh);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) g.xbar[k] = xb[k];
+                    g.zhat[0] = zh[0]; g.zhat[1] = zh[1];
+                }
+                const float* grf = reinterpret_cast<const float*>(gr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g.sinv[e] = grf[e];
+#pragma unroll
+                for (int e = 0; e < NK; ++e) g.K[e] = grf[4 + e];
+                g.lnc = grf[GK_LNC];
+                const float zhx = (float)g.zhat[0], zhy = (float)g.zhat[1];
+                const float rx = grf[GK_RX], ry = grf[GK_RY];
+                const float bx = rx * 1.001f + 1e-6f * (fabsf(zhx) + rx) + 1e-3f;      // (the leaf's conservative float32 box: target_part)
+                const float by = ry * 1.001f + 1e-6f * (fabsf(zhy) + ry) + 1e-3f;
+                g.zhx = zhx; g.zhy = zhy; g.bx = bx; g.by = by; g.pad = 0; g.cid = cid;
+                if (lane < LP) lg[lane] = g;
+                // bounding box of the chunk's gates
+                float lox = zhx - bx, hix = zhx + bx, loy = zhy - by, hiy = zhy + by;
+                lox -= fabsf(lox) * 2.4e-7f + 1e-30f; hix += fabsf(hix) * 2.4e-7f + 1e-30f;
+                loy -= fabsf(loy) * 2.4e-7f + 1e-30f; hiy += fabsf(hiy) * 2.4e-7f + 1e-30f;
+                int b0 = valid ? fg_sortable(lox) : 0x7fffffff, b1 = valid ? fg_sortable(hix) : (int)0x80000000;
+                int b2 = valid ? fg_sortable(loy) : 0x7fffffff, b3 = valid ? fg_sortable(hiy) : (int)0x80000000;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    b0 = min(b0, __shfl_xor(b0, o)); b1 = max(b1, __shfl_xor(b1, o));
+                    b2 = min(b2, __shfl_xor(b2, o)); b3 = max(b3, __shfl_xor(b3, o));
+                }
+                if (pass == 1) ndead += __popcll(__ballot(in_chunk && !valid));
+                FW_SYNC();
+                FW_STAMP(2);
+                if (single && valid) fg_single_leaf(a, src, (fl & F_STATE_F32) != 0, lg[lane]);
+                if (last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));
+                // ---- phase 2 (a): the measurements inside the box, ascending -> candidate list -----------------------------------------
+                const int x0 = __builtin_amdgcn_readfirstlane(b0), x1 = __builtin_amdgcn_readfirstlane(b1);
+                const int y0 = __builtin_amdgcn_readfirstlane(b2), y1 = __builtin_amdgcn_readfirstlane(b3);
+                int ncand = 0;
+                for (int jb = 0; jb < M; jb += 512) {      // eight words of the scan per batch of loads (one round trip)
+                    float2 zv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int j = jb + q * 64 + lane; zv[q] = z2[j < M ? j : 0]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = jb + q * 64 + lane;
+                        const int kx = fg_sortable(zv[q].x), ky = fg_sortable(zv[q].y);
+                        const bool in = (j < M) && (kx >= x0) && (kx <= x1) && (ky >= y0) && (ky <= y1);
+                        const unsigned long long bal = __ballot(in);
+                        if (in) {
+                            const int ci = ncand + __popcll(bal & lt_mask);
+                            cand[ci] = (unsigned short)j;
+                            if (ci < FW_CZ) candz[ci] = zv[q];
+                        }
+                        ncand += __popcll(bal);
+                    }
+                }
+                FW_STAMP(3);
+                // leaves of this pass: all n unless their hit words do not fit (a box with more than 256 candidates)
+                const int nblk = (ncand + 63) >> 6;
+                int n_eff = n;
+                if (n * nblk > FW_MASKW) n_eff = FW_MASKW / nblk > 0 ? FW_MASKW / nblk : 1;
+                for (int w = lane; w < n_eff * nblk; w += 64) mk[w] = 0ull;
+                FW_SYNC();
+                // ---- phase 2 (b): lane = (leaf, candidate): the leaf's float32 box, then the exact reference-order NIS -----------------
+                {
+                    const int sh = (n_eff > 1) ? 32 - __clz(n_eff - 1) : 0;
+                    for (int w = lane; w < (ncand << sh); w += 64) {
+                        const int l = w & ((1 << sh) - 1), ci = w >> sh;
+                        if (l >= n_eff) continue;
+                        const FLeaf& gl = lg[l];
+                        if (!gl.valid) continue;
+                        const int j = cand[ci];
+                        const float2 mv = (ci < FW_CZ) ? candz[ci] : z2[j];
+                        if ((fabsf(mv.x - gl.zhx) <= gl.bx) && (fabsf(mv.y - gl.zhy) <= gl.by)) {
+                            bool hit;
+                            if (gl.f32state) {
+                                float zh[2] = {(float)gl.zhat[0], (float)gl.zhat[1]}, zt[2], nis;
+                                hit = gate_pair<float>(zh, gl.sinv, mv.x, mv.y, (float)a.model.eta2, zt, nis);
+                            } else {
+                                double zh[2] = {gl.zhat[0], gl.zhat[1]}, zt[2], nis;
+                                hit = gate_pair<double>(zh, gl.sinv, mv.x, mv.y, a.model.eta2, zt, nis);
+                            }
+                            if (hit) {
+                                atomicOr(&mk[l * nblk + (ci >> 6)], 1ull << (ci & 63));
+                                atomicOr(&tb[curw + (j >> 6)], 1ull << (j & 63));
+                            }
+                        }
+                    }
+                }
+                FW_SYNC();
+                FW_STAMP(4);
+                // ---- child counts, wave prefix, block of the node index space, edge slice -------------------------------------------------
+                int mine = 0;
+                if (lane < n_eff && lg[lane].valid) {
+                    mine = 1;
+                    for (int b = 0; b < nblk; ++b) mine += __popcll(mk[lane * nblk + b]);
+                }
+                int incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int ctot = __shfl(incl, 63);
+                if (lane <= LP && lane < 64) s_pref[lane] = incl - mine;
+                if (LP == 64 && lane == 63) s_pref[64] = incl;
+                for (int q = 0, p = incl - mine; q < mine && p < FW_MAP; ++q, ++p) s_map[p] = (unsigned char)lane;
+                if (pass == 0) {
+                    total += ctot;
+                    c0 += n_eff;
+                    FW_SYNC();
+                    continue;
+                }
+                if (c0 == 0) {      // where the children go
+                    if (!counted) {
+                        base = t * a.block_cap;
+                    } else {
+                        int b = -1;
+                        if (lane == 0) {
+                            if (total <= a.block_cap) {
+                                b = t * a.block_cap;
+                            } else {
+                                int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
+                                for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
+                                    const unsigned old = atomicAdd(&a.alloc[r * 32], (unsigned)total);
+                                    if (old + (unsigned)total <= (unsigned)a.region_cap) b = a.over_base + r * a.region_cap + (int)old;
+                                    else r = (r + 1) & (FG_REGIONS - 1);
+                                }
+                            }
+                            if (b < 0) { a.status->overflow = 1; a.tchild[pos] = 0; a.tcend[pos] = 0; }      // every region is full: the scan is void (MHT_E_CAPACITY)
+                        }
+                        base = __shfl(b, 0);
+                        if (base < 0) return;
+                    }
+                }
+                if (!counted && run + ctot > a.block_cap) {      // the static block is too small for this target: count, then take a piece of the overflow area
+                    redo = true;
+                    c0 = cnt;
+                    continue;
+                }
+                FW_SYNC();
+                FW_STAMP(5);
+                // ---- emission: lane = child ---------------------------------------------------------------------------------------------
+                const float* zdummy = reinterpret_cast<const float*>(s_pref);      // (the LDS scan copy of target_part: not used, the scan is read through z2)
+                for (int r = lane; r < ctot; r += 64) {
+                    int l;
+                    if (r < FW_MAP) {
+                        l = s_map[r];
+                    } else {
+                        int lo2 = 0, hi2 = n_eff;
+                        while (hi2 - lo2 > 1) {
+                            const int mid = (lo2 + hi2) >> 1;
+                            if (s_pref[mid] <= r) lo2 = mid; else hi2 = mid;
+                        }
+                        l = lo2;
+                    }
+                    const int k = r - s_pref[l], c = base + run + r;
+                    const int nh = s_pref[l + 1] - s_pref[l] - 1;
+                    FLeaf gc;
+                    {
+                        const uint4* srcq = reinterpret_cast<const uint4*>(lg + l);
+                        uint4* dstq = reinterpret_cast<uint4*>(&gc);
+#pragma unroll
+                        for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
+                    }
+                    if (gc.f32state) fg_emit_child<float, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, s_pp, s_ap, depth, shift, rootc, root_f32, cand, z2);
+                    else fg_emit_child<double, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, s_pp, s_ap, depth, shift, rootc, root_f32, cand, z2);
+                }
+                FW_STAMP(6);
+                // The gains one scan ahead (chain_part's job, folded into the target's wavefront here: a launch of many sectors has no idle
+                // workgroup slots for separate chain workgroups): are the hit / miss transitions of these leaves' covariances known?  Two
+                // 4-byte look-ups per leaf behind the emission (the leaf's value id is in its LDS record), nearly always yes; what
+                // nobody has computed yet (~10 per scan in steady state) is resolved here, the distinct ones spread over the lanes.
+#ifndef MHT_FW_NOFOLD
+                {
+                    const bool mine_l = lane < n_eff;
+                    const int cidl = mine_l ? lg[lane].cid : 0;
+                    const int k0 = a.vt.child[2 * cidl], k1 = a.vt.child[2 * cidl + 1];
+                    unsigned long long rem = __ballot(mine_l && (k0 < 0 || k1 < 0));
+                    while (rem) {      // (rounds of 32 distinct values: one is the rule)
+                        // lane 2 q + h takes transition h of the q-th distinct value that needs one
+                        int my_id = -1, my_src = 0, q = 0;
+                        while (rem && q < 32) {
+                            const int leader = __ffsll((long long)rem) - 1;
+                            const int idl = __shfl(cidl, leader);
+                            const int kk0 = __shfl(k0, leader), kk1 = __shfl(k1, leader);
+                            rem &= ~__ballot(cidl == idl);      // (leaves that share the covariance)
+                            if (lane == 2 * q && kk0 < 0) { my_id = idl; my_src = leader; }
+                            if (lane == 2 * q + 1 && kk1 < 0) { my_id = idl; my_src = leader; }
+                            ++q;
+                        }
+                        if (my_id >= 0) chain_resolve(a, my_id, lane & 1, lg[my_src].pd);
+                    }
+                }
+#endif
+                FW_STAMP(7);
+                run += ctot;
+                c0 += n_eff;
+                FW_SYNC();      // the chunk tables are re-used
+            }
+        }
+        if (redo) { counted = true; pass = -1; run = 0; total = 0; ndead = 0; continue; }
+        if (pass == 1) {      // all children are out: the target's entries of the child tables, its edges of the clustering graph
+            const auto& a = *ap0;
+            int e0 = 0, ne = 0;
+            for (int w = lane; w < AW; w += 64) ne += __popcll(tb[w]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+            const int seg = t & (EDGE_SEGS - 1);
+            if (lane == 0) {
+                e0 = atomicAdd(&a.edge_count[seg], ne);
+                if (e0 + ne > a.edge_cap) a.status->overflow = 1;
+                atomicAdd(&a.status->n_children, run);
+                if (ndead) atomicAdd(&a.status->n_dead, ndead);
+                a.tchild[pos] = base;
+                a.tcend[pos] = base + run;
+            }
+            int eb = __shfl(e0, 0);
+            for (int w0 = 0; w0 < AW; w0 += 64) {      // edge list: (target << 16 | node) for every set bit
+                const int w = w0 + lane;
+                unsigned long long bits = (w < AW) ? tb[w] : 0ull;
+                const int pc = __popcll(bits);
+                int in2 = pc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(in2, o);
+                    if (lane >= o) in2 += v;
+                }
+                int my = eb + in2 - pc;
+                while (bits) {
+                    const int bpos = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    if (my < a.edge_cap) a.edges[(size_t)seg * a.edge_cap + my] = ((unsigned)pos << 16) | (unsigned)(w * 64 + bpos);
+                    ++my;
+                }
+                eb += __shfl(in2, 63);
+            }
+        }
+    }
+}
+
 // The PREVIOUS scan's report rides to the host in this launch (drop-in API path): FG_PUB_WGS extra workgroups copy it from its device
 // block into pinned, device-mapped host memory (16-byte posted PCIe writes, ~70 KB at the headline size) while the others grow the
 // tree -- in the kernel that completed the report the copy sat on the critical path of every scan (~10 us).  The host waits for an
@@ -716,14 +1144,22 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         bid -= 1;
     }
     if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part(*ap, d, bid - d.n_main); return; }
-    target_part<PQ, CAP>(ap, d, bid, smem);
+    if (CAP == 0) {          // wavefront-per-target variant: four targets per workgroup, each wavefront on its own LDS slice
+        const int wave = threadIdx.x >> 6;
+        const int t = bid * (FG_THREADS / 64) + wave;
+        if (!d.fused && bid == 0) stamp();      // (no commit and no chain workgroup in this launch)
+        if (t >= d.n_tgt) return;
+        target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
+    } else {
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP)>(ap, d, bid, smem);
+    }
 }
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
 template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_grow = d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;
+    const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
     fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
@@ -731,13 +1167,13 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
 // repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
 typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
-template <int PQ>
+template <int PQ, int CAP = FG_CAP>      // CAP = 0: the wavefront-per-target variant
 __global__ __launch_bounds__(FG_THREADS, NX == 4 ? 4 : 3) void fgrow_batch_kernel(const FBatch b) {      // (six states: 165 registers, three workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int y = blockIdx.y;
     const FDyn d = b.d[y];
-    if ((int)blockIdx.x >= d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS) return;
-    fgrow_body<PQ, FG_CAP>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
+    if ((int)blockIdx.x >= d.fused + d.n_main + d.n_chain) return;
+    fgrow_body<PQ, CAP>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
 }
 
 static size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap) {
@@ -747,7 +1183,11 @@ static size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap) {
     return (b + 15) & ~(size_t)15;
 }
 
-size_t fgrow_lds_bytes(int W, int pds, int AW) { return fgrow_lds_bytes_cap(W, pds, AW, FG_CAP); }      // (the batched launch)
+size_t fgrow_lds_bytes(int W, int pds, int AW) { return fgrow_lds_bytes_cap(W, pds, AW, FG_CAP); }      // (the batched launch, workgroup per target)
+size_t fgrow_wave_lds_bytes(int W, int pds, int AW) {      // (the batched launch, wavefront per target: four slices)
+    size_t b = (size_t)(FG_THREADS / 64) * fw_layout(pds, AW, W * 64).total;
+    return b < 256 ? 256 : b;
+}
 
 static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
     if (lds > 150 * 1024) {
@@ -762,23 +1202,47 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
     return MHT_OK;
 }
 
 // grid of one sector: [commit] + one workgroup per target slot + chain workgroups
-static inline int fgrow_grid(const FDyn& d) { return d.fused + d.n_main + (d.n_main + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS; }
+static inline int fgrow_grid(const FDyn& d) { return d.fused + d.n_main + d.n_chain; }
 
-void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused) {
+// wave: the wavefront-per-target variant (four target slots per workgroup)
+void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave) {
     d.fused = fused ? 1 : 0;
-    int n_main = n_targets_ub < 1 ? 1 : n_targets_ub;
-    if (n_main > Tcap) n_main = Tcap;
-    d.n_main = n_main;
+    int n_tgt = n_targets_ub < 1 ? 1 : n_targets_ub;
+    if (n_tgt > Tcap) n_tgt = Tcap;
+    d.n_tgt = n_tgt;
+    d.n_main = wave ? (n_tgt + FG_THREADS / 64 - 1) / (FG_THREADS / 64) : n_tgt;
+#ifdef MHT_FW_NOFOLD
+    wave = false;
+#endif
+    d.n_chain = wave ? 0 : (n_tgt + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;      // (the wavefronts of the wave variant resolve their own transitions)
 }
 
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
-    fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr);
+    static int wave_solo = -1;      // development: MHT_FG_WAVE_SOLO=1 runs the wavefront-per-target variant in the one-sector launch too
+    if (wave_solo < 0) { const char* e = getenv("MHT_FG_WAVE_SOLO"); wave_solo = (e && e[0] == '1') ? 1 : 0; }
+    fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, wave_solo != 0);
+    if (wave_solo) {
+        const size_t lds = fgrow_wave_lds_bytes(d.W, a.pds, a.AW);
+        { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+        const bool pub = publish && publish->dst;
+        const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
+        const PublishArgs pa = pub ? *publish : PublishArgs{};
+        const CommitArgs cm = commit ? *commit : CommitArgs{};
+        if (a.pds == 8) hipLaunchKernelGGL((fgrow_kernel<2, 0>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        else hipLaunchKernelGGL((fgrow_kernel<4, 0>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
     // 128 leaves per pass unless the larger tables cost a workgroup per CU (long scans: the hit masks grow with the scan): 3 per CU is
     // all the launch bounds allow, fewer than with 96 leaves per pass is a loss (config-5 size, 2 048 measurements: 1 instead of 2)
     const size_t lds_hi = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP_SOLO), lds_lo = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP);
@@ -798,9 +1262,11 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
     return MHT_OK;
 }
 
-int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds) {
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds, bool wave) {
     { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
-    if (pds == 8) hipLaunchKernelGGL(fgrow_batch_kernel<2>, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    if (wave && pds == 8) hipLaunchKernelGGL((fgrow_batch_kernel<2, 0>), dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    else if (wave) hipLaunchKernelGGL((fgrow_batch_kernel<4, 0>), dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
+    else if (pds == 8) hipLaunchKernelGGL(fgrow_batch_kernel<2>, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
     else hipLaunchKernelGGL(fgrow_batch_kernel<4>, dim3(grid_x, n_sectors), dim3(FG_THREADS), lds, ctx->stream, b);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;

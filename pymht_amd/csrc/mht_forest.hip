@@ -1042,6 +1042,7 @@ struct mht_group {
     size_t blp_lds[3] = {0, 0, 0};
     bool two_tier = false;        // development: MHT_BLP_TWO_TIER=1
     bool counted = false;         // the members' in_groups counters include this group
+    bool wave = true;             // grow launch: wavefront per target (MHT_FG_WAVE=0: the workgroup-per-target kernel of the one-sector launch)
 };
 
 extern "C" int mht_group_destroy(mht_group* g) {
@@ -1084,6 +1085,9 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     BlpArgs* hbl = new BlpArgs[(size_t)n * P * 2];
     BlpArgs* hbl0 = new BlpArgs[(size_t)n * P];
     { const char* e = getenv("MHT_BLP_TWO_TIER"); g->two_tier = e && e[0] == '1'; }
+    // grow launch of the group: wavefront per target from eight sectors on (measured, headline config: 4 sectors 49 us workgroup-
+    // per-target vs 54 us; 16 sectors 136 vs 121 us -- the wavefront variant costs 5.6 us per further sector, the other 7.2)
+    { const char* e = getenv("MHT_FG_WAVE"); g->wave = e ? (e[0] != '0') : (n >= 8); }
     for (int i = 0; i < n; ++i) {
         const Forest* f = ctxs[i]->forest;
         for (int v = 0; v < P; ++v) {
@@ -1175,7 +1179,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
         d.maybe_dead = (f->similar_ran_scan == pl[i].s - 1);
         d.dbg = nullptr;
-        fgrow_plan(d, pl[i].n_ub, f->Tcap, pl[i].fused);
+        fgrow_plan(d, pl[i].n_ub, f->Tcap, pl[i].fused, g->wave);
         fb.ga[i] = g->ga + ((size_t)i * P + v) * 2 + (pl[i].fused ? 1 : 0);
         fb.ca[i] = g->ca + (size_t)i * P + (s - 1 + P) % P;      // the commit of the scan before rides along (if fused)
         cb.p[i] = g->cl + (size_t)i * 2 + (s & 1);
@@ -1187,12 +1191,12 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         int gbl = f->nT_ub_step / 2 + 8;
         if (gbl > 1024) gbl = 1024;
         if (gbl > grid_b) grid_b = gbl;
-        const size_t l = fgrow_lds_bytes(d.W, f->pds, f->AW);
+        const size_t l = g->wave ? fgrow_wave_lds_bytes(d.W, f->pds, f->AW) : fgrow_lds_bytes(d.W, f->pds, f->AW);
         if (l > lds) lds = l;
         f->commit_pending = false;
     }
     const Forest* f0 = c0->forest;
-    int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds, g->ctx[0]->forest->pds);
+    int rc = launch_fgrow_batch(c0, fb, n, grid_g, lds, g->ctx[0]->forest->pds, g->wave);
     if (!rc) rc = launch_cluster_batch(c0, cb, n, f0->Tcap, f0->n_mnodes);
     // similar-state pruning of the members that ask for it: a launch of their own each, between clustering and the ILPs
     for (int i = 0; i < n && !rc; ++i) {

@@ -69,7 +69,8 @@ struct FGrowArgs {
 struct FDyn {
     const float* z; int M; int W;  // the scan: dev (M,2) float32; W = ceil(M / 64)
     int fused;                     // workgroup 0 runs the previous scan's commit (CommitDyn c)
-    int n_main;                    // workgroups [fused, fused + n_main): one target slot each; the rest: covariance chain
+    int n_main;                    // workgroups [fused, fused + n_main): the targets (one slot each, or four -- one per wavefront); then n_chain
+    int n_tgt, n_chain;            // target slots covered; covariance-chain workgroups (two targets each)
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
@@ -181,9 +182,10 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr);
 size_t fgrow_lds_bytes(int W, int pds, int AW);
-void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused);
+void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave);
+size_t fgrow_wave_lds_bytes(int W, int pds, int AW);
 int fgrow_grid_of(const FDyn& d);
-int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds);
+int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x, size_t lds, int pds, bool wave);
 int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes);
 int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds);
 size_t blp_set_tier(BlpArgs& a, int tier);
