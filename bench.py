@@ -232,6 +232,59 @@ class Replay:
         self.trk.close()
 
 
+def ilp_accounting(sc, births, device, n_warm, n_scans):
+    """SURVEY.md 8(d) "ILP stage accounting": instances, sum of nHyp (columns) and of nnz(A1) (measurement rows on the columns' paths)
+    over the multi-target clusters, how they were solved, the slowest cluster -- read from the forest's tables after every scan of a
+    short separate replay (untimed: every read synchronises)."""
+    rp = Replay(sc, births, device)
+    trk = rp.trk
+
+    def rd(name, k, dt=np.int32):
+        a = np.zeros(max(int(k), 1), dtype=dt)
+        rp._lib_mod.check(rp.lib.mht_forest_debug_read(rp.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+    for _ in range(n_warm):
+        rp.step()
+    inst = n_hyp = nnz = cols_sampled = certified = branched = limit = 0
+    iters_max, us_max, us_sum = 0, 0.0, 0.0
+    pds = 8 if int(sc["N"]) + 1 <= 8 else 16      # (ints per path record: mht_forest_create)
+    for _ in range(n_scans):
+        rp.step()
+        rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
+        cnt = rd("cl_counts", 8)
+        nC, nM = int(cnt[0]), int(cnt[1])
+        if nM == 0:
+            continue
+        ptr, ml, it, st = rd("cl_ptr", nC + 1), rd("multi_list", nM), rd("cl_iters", nC), rd("cl_status", nC)
+        tm = rd("cl_time", 8 * nC).reshape(-1, 8)
+        nT0 = int(ptr[nC])
+        tch, tce, mem = rd("tchild", nT0 + 1), rd("tcend", nT0 + 1), rd("cl_members", nT0)
+        for c in ml:
+            members = mem[ptr[c]:ptr[c + 1]]
+            cols = int(sum(int(tce[m]) - int(tch[m]) for m in members))
+            inst += 1
+            n_hyp += cols
+            certified += int(st[c] == 1); branched += int(st[c] == 2); limit += int(st[c] == 3)
+            iters_max = max(iters_max, int(it[c]))
+            us = tm[c, 1] / 100.0
+            us_max = max(us_max, us); us_sum += us
+        # nnz(A1) of this scan's ILPs: entries >= 0 of the path records of their columns (one record of pds ints per column)
+        sample = [m for c in ml for m in mem[ptr[c]:ptr[c + 1]]]
+        for m in sample[:64]:      # (a sample of the member targets: every read is a device round trip)
+            b, e = int(tch[m]), int(tce[m])
+            if e > b:
+                rec = rd("path@%d" % (4 * pds * b), pds * (e - b)).reshape(-1, pds)
+                nnz += int((rec >= 0).sum())
+        cols_sampled += sum(int(tce[m]) - int(tch[m]) for m in sample[:64])
+    rp.close()
+    cs = max(1, cols_sampled)
+    return {"scans": n_scans, "instances": inst, "sum_nHyp": n_hyp, "sum_nnz_A1_estimate": int(round(n_hyp * nnz / cs)),
+            "nnz_per_column_sampled": nnz / cs, "certified_by_dual": certified, "branch_and_bound_or_exact_search": branched, "node_limit": limit,
+            "dual_iters_max": iters_max, "cluster_us_mean": us_sum / max(1, inst), "cluster_us_max": us_max,
+            "note": "multi-target clusters of %d scans behind the warm-up (separate untimed replay); status 2 = solved exactly by the pair / signature search "
+                    "or the GPU branch and bound after the dual rounds did not certify; nnz(A1) from the path records of a sample of the columns" % n_scans}
+
+
 def cpu_baseline(sc, n_warm, n_timed):
     """The oracle (NumPy restatement of the reference algorithm, validated bitwise against the reference) on the
     host: stages Process+Cluster+Optim+Terminate+N-Prune of `n_timed` scans after `n_warm` warm-up scans."""
@@ -276,7 +329,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="cfg3")
-    ap.add_argument("--sectors", type=int, default=4, help="concurrent independent sectors per GPU for the multi_sector figure (0 disables)")
+    ap.add_argument("--sectors", default="4,16", help="concurrent independent sectors per GPU for the multi_sector figures, comma separated (0 disables)")
     ap.add_argument("--cpu-scans", type=int, default=16, help="timed oracle scans for cpu_baseline (0 disables)")
     ap.add_argument("--cpu-warm", type=int, default=8)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -328,6 +381,7 @@ def main():
     strong = args.scaling == "strong"
     srank = 0 if strong else rank      # (strong scaling: every rank is fed the same sector)
     sc = make_config(args.config, seed=parallel.sector_seed(5446, srank), n_scans=W + K, centre=parallel.sector_centre(srank), confine=True)
+    nx = model_of(sc).C_RADAR.shape[1]
     births, stats, final, api_s, init_s = prepass(sc, local, W)
 
     # ---- timed replay ---------------------------------------------------------------------------------------------
@@ -361,7 +415,6 @@ def main():
     elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
     # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
     alive = [r for r in recs if int(r["status"]) == 0]
-    nx = model_of(sc).C_RADAR.shape[1]
     picture = parallel.gather_tracks([int(r["id"]) for r in alive], np.array([r["sel_x"] for r in alive]).reshape(-1, nx)[:, :4],
                                      dist, device="cuda")
 
@@ -387,18 +440,20 @@ def main():
 
     # ---- several independent sectors per GPU (BASELINE config 4 on one device): ONE batched launch set per scan for all of them
     #      (mht_group_step: blockIdx.y = sector), every sector its own forest, scan stream and births ------------------------------
-    multi = None
-    if args.sectors > 1:
+    per_leaf = (8 * nx + 4 * nx * nx + 16) + (8 * nx + 4 * nx * nx + 8 + 4 * nx * nx)
+    per_pair = 8 * nx + 16
+
+    def run_multi(S):
         from pymht_amd.sectors import SectorGroup
-        S = args.sectors
-        Km = min(K, 200)
-        scs, brs = [sc], [births]
+        Km = min(K, 200 if S <= 4 else 100)
+        scs, brs, sts = [sc], [births], [stats]
         for q in range(1, S):
             sq = make_config(args.config, seed=parallel.sector_seed(5446, rank) + 17 * q, n_scans=W + Km,
                              centre=(parallel.sector_centre(rank)[0], 20000.0 * q), confine=True)
-            bq, _, _, _, _ = prepass(sq, local)
+            bq, stq, _, _, _ = prepass(sq, local)
             scs.append(sq)
             brs.append(bq)
+            sts.append(stq)
         # the sectors form NG groups, each on its own HIP stream: one batched launch set per group and scan; two groups' chains of
         # dependent kernels interleave on the device (while one group's ILP kernel holds a workgroup per CU, the other's grow runs)
         NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "2")), S))
@@ -408,7 +463,6 @@ def main():
             with torch.cuda.stream(streams[q % NG]):
                 rps.append(Replay(scs[q], brs[q], local))
         grps = [SectorGroup([r.trk for r in rps[gi::NG]]) for gi in range(NG)]
-
         solo = os.environ.get("MHT_BENCH_SOLO") == "1"      # development: every sector stepped on its own (needs MHT_BENCH_GROUPS = sectors)
 
         def group_step():
@@ -432,27 +486,40 @@ def main():
         tm1 = time.perf_counter()
         barrier()
         okm = True
+        t_grow = []
         for r in rps:
             repm, _ = r.report()
             okm = okm and repm.error == 0
+            t_grow.append(repm.t_process * 1e-8)      # device stamps of the LAST scan's launches: grow start -> cluster start of this sector's group
         for gq in grps:
             gq.close()
         for r in rps:
             r.close()
         tmulti, okm = parallel.reduce_clock(tm1 - tm0, okm, dist, device="cuda")
-        multi = {"sectors_per_gpu": S, "steps_per_sector": Km, "scans_per_sec": world * S * Km / tmulti,
-                 "ms_per_scan_aggregate": 1e3 * tmulti / (S * Km), "ok": okm,
-                 "groups": NG,
-                 "note": "independent sectors in %d group(s), one batched launch set per group and scan (mht_group_step, grid.y = "
-                         "sector), groups on separate HIP streams; the single-sector path is a chain of dependent round trips that "
-                         "leaves most of the GPU idle" % NG}
+        # algorithmic bytes of ALL sectors' grow stages of one scan over the duration of their batched grow launch(es)
+        bytes_scan = sum(float(per_leaf) * st[W:W + Km, 0].mean() + float(per_pair) * st[W:W + Km, 1].mean() + 8.0 * st[W:W + Km, 2].mean() for st in sts)
+        tg = float(np.mean(t_grow)) * NG if not solo else float(np.sum(t_grow))      # NG groups' grow launches per scan, one after the other at worst
+        gbs = bytes_scan / tg / 1e9 if tg > 0 else 0.0
+        return {"sectors_per_gpu": S, "steps_per_sector": Km, "scans_per_sec": world * S * Km / tmulti,
+                "ms_per_scan_aggregate": 1e3 * tmulti / (S * Km), "ok": okm, "groups": NG,
+                "x_single_sector": None,
+                "roofline": {"bound": "hbm", "kernel": "fgrow_batch_kernel: the grow stage of all sectors of a group in one launch (device wall-clock stamps of the last timed scan)",
+                             "algorithmic_bytes_all_sectors": bytes_scan, "grow_us_per_scan_all_groups": 1e6 * tg, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                "note": "independent sectors in %d group(s), one batched launch set per group and scan (mht_group_step, grid.y = "
+                        "sector), groups on separate HIP streams; the single-sector path is a chain of dependent round trips that "
+                        "leaves most of the GPU idle" % NG}
+
+    multi_all = []
+    for S in [int(v) for v in str(args.sectors).split(",") if v.strip()]:
+        if S > 1:
+            multi_all.append(run_multi(S))
+    multi = multi_all[0] if multi_all else None
 
     timed = stats[W:W + K]
     Lm, Gm, Mm = float(timed[:, 0].mean()), float(timed[:, 1].mean()), float(timed[:, 2].mean())
     # algorithmic bytes of the grow stage per scan: per leaf read x, P, cNLLR, P_d and write x_bar, P_bar, cNLLR, P_hat;
     # per gated pair x_hat, cNLLR, measurement index, parent index; 8 B per measurement -- 280 / 48 / 8 at four states, 552 / 64 / 8 at six
-    per_leaf = (8 * nx + 4 * nx * nx + 16) + (8 * nx + 4 * nx * nx + 8 + 4 * nx * nx)
-    per_pair = 8 * nx + 16
     b_gate = float(per_leaf) * Lm + float(per_pair) * Gm + 8.0 * Mm
     gate_gbs = b_gate / (ms[0] * 1e-3) / 1e9
     traffic, traffic_src = PMC_TRAFFIC_BYTES.get(args.config), \
@@ -463,6 +530,9 @@ def main():
             traffic, traffic_src = live, note
         else:
             traffic_src += "; live counter passes unavailable (%s)" % note
+    for m_ in multi_all:
+        m_["x_single_sector"] = m_["scans_per_sec"] / ((1 if strong else world) * K / elapsed)
+    ilp_acc = ilp_accounting(sc, births, local, W, min(K, 32)) if rank == 0 else None
     out = {
         "metric": "scans/sec at ~5k+ leaf hypotheses x 500 measurements (per-scan gate + cluster + ILP + N-scan prune)",
         "value": (1 if strong else world) * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -478,6 +548,8 @@ def main():
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},
         "multi_sector": multi,
+        "multi_sector_all": multi_all,
+        "ilp": ilp_acc,
         "api_scans_per_sec": 1.0 / api_s,
         "api_note": "drop-in Tracker.addMeasurementList, streaming (scan k+1 is queued while the report of scan k is folded; results "
                     "read after the last scan): PCIe copy of every scan, steps 1-7 on the device (M-of-N initiator included), "
