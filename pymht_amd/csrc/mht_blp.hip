@@ -986,8 +986,21 @@ __device__ __forceinline__ bool reducible(const BlpArgs& a, const GStore& s, int
 
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
 // `ub` in: cost of a feasible selection already sitting in s.ub_sel[] (DINF: none); out: cost of the selection returned there.
+// A member of a team (see mht_kernels.h: TEAM_*): q of W, the team's shared incumbent word.  W = 1: a cluster searched by its own workgroup only.
+struct Team { int q, W; unsigned long long* gub; };
+#ifndef MHT_TEAM_LEVEL
+#define MHT_TEAM_LEVEL 5
+#endif
+constexpr int TEAM_LEVEL = MHT_TEAM_LEVEL;      // the search is dealt out at this level (0-based): the members all walk the levels above it (a few dozen nodes),
+                                                // below it each descends only into its own subtrees.  G9's 147 ms instance, 32 members: level 1 80 ms (two members hold half of the nodes),
+                                                // 3: 53, 4: 46, 5: 35, 6: 64 ms (the shared levels grow).
+__device__ __forceinline__ unsigned team_hash(int c0, int c1) {      // (level-0 column, level-1 column) -> member: price-independent
+    unsigned h = (unsigned)c0 * 0x9E3779B1u ^ ((unsigned)c1 * 0x85EBCA6Bu + 0x7F4A7C15u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
 template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp,
-                                                                 double& ub) {
+                                                                 double& ub, const Team tm = Team{0, 1, nullptr}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double& UB = ub;
     double best_LB = -DINF, theta = 1.0, utot = 0.0;
@@ -1226,7 +1239,21 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     int level = 0;
     bool enter = true;
     status = MHT_BLP_BRANCHED;
+    // team search: `own` = cost of the selection in THIS member's ub_sel[]; UB = the pruning bound = min(own, best value any member has
+    // published).  The root node is processed with the member's own (deterministic) incumbent, so that every member sees the same
+    // prices and the same level-0 candidates; from level 1 on the shared value prunes.
+    double own = UB;
+    const bool team = tm.W > 1 && tm.gub != nullptr;
+    if (team && tid == 0 && UB < DINF) atomicMin(tm.gub, enum_key(UB));
     while (true) {
+        if (team && enter && level >= 1) {
+            __syncthreads();
+            if (tid == 0) r->q[0][0] = enum_val(__hip_atomic_load(tm.gub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __syncthreads();
+            const double g = r->q[0][0];
+            __syncthreads();
+            if (g < UB) UB = g;
+        }
         const double eps = 1e-12 * fmax(1.0, fabs(UB));
         if (enter) {
             if (++nodes > a.node_limit) { status = MHT_BLP_NODE_LIMIT; break; }
@@ -1238,7 +1265,8 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             }
             if (level == K) {
                 if (s.cst[K] < UB - eps) {
-                    UB = s.cst[K];
+                    UB = own = s.cst[K];
+                    if (team && tid == 0) atomicMin(tm.gub, enum_key(UB));
                     for (int p = tid; p < K; p += BLP_THREADS) s.ub_sel[ord[p]] = s.ch[p];
                     __threadfence_block();
                     __syncthreads();
@@ -1330,7 +1358,8 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     if (!conflict) {                            // the minimisers complete the fixed columns feasibly
                         const double cand = s.cst[level] + csum;
                         if (cand < UB - eps) {
-                            UB = cand;
+                            UB = own = cand;
+                            if (team && tid == 0) atomicMin(tm.gub, enum_key(UB));
                             for (int p = tid; p < K; p += BLP_THREADS) s.ub_sel[ord[p]] = (p < level) ? s.ch[p] : bh[p];
                             __threadfence_block();
                             __syncthreads();
@@ -1390,6 +1419,21 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             set_marks(s, s.ch[level], 0);
             continue;
         }
+        bool foreign = false;
+        if (team && level == TEAM_LEVEL) {      // the columns fixed at levels 0 .. TEAM_LEVEL name the subtree: whose is it?
+            unsigned hsh = 0x9E3779B9u;
+            for (int l = 0; l < TEAM_LEVEL; ++l) hsh = team_hash((int)hsh, s.to_global(s.ch[l]));
+            hsh = team_hash((int)hsh, s.to_global(bi));
+            foreign = hsh % (unsigned)tm.W != (unsigned)tm.q;
+        }
+        if (foreign) {
+            // another member's subtree: step over the candidate (the enumeration state moves on, nothing is fixed)
+            __syncthreads();      // (every thread has read ch[0] / lrc / lix of this level)
+            if (tid == 0) { s.lrc[level] = bv; s.lix[level] = bi; }
+            __threadfence_block();
+            __syncthreads();
+            continue;
+        }
         if (tid == 0) {
             s.lrc[level] = bv;
             s.lix[level] = bi;
@@ -1400,6 +1444,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         ++level;
         enter = true;
     }
+    ub = own;      // (the cost of what ub_sel[] holds: a team member may have pruned with a better value found elsewhere)
     for (int l = 0; l < level; ++l) set_marks(s, s.ch[l], 0);     // leave no marks behind
     if (slot >= 0 && tid == 0) atomicExch(&a.bb_busy[slot], 0);
 }
@@ -1527,7 +1572,8 @@ __device__ __forceinline__ void prune_members(const BlpArgs& a, const int32_t* m
     }
 }
 
-__device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds) {
+__device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds,
+                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1) {
     const int tid = threadIdx.x;
     const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
     const int32_t* mem = a.cl_members + a.cl_ptr[c];
@@ -1695,9 +1741,71 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     unsigned long long stamp[6] = {t_begin, 0, 0, 0, 0, 0};      // [0]: start of the cluster (the time limit counts from here)
     const unsigned long long t_setup = wall_clock64();
     bool use_lds = lds_cols && nR < L_MAXR;
+    // a team searches a cluster that is solved out of LDS from the start (every member holds its own copy); a cluster on HBM scratch
+    // (shared) is its owner's alone
+    bool team = tm.W > 1 && use_lds;
+    // ... or that reduced-cost fixing cuts down to what LDS holds: the owner runs the HBM phase alone, files the reduced problem,
+    // and the members (waiting for it) join the search from there
+    const bool team_hbm = tm.W > 1 && !use_lds && a.team_prob != nullptr && K <= TEAM_SEL && K <= L_MAXK;
+    if (tm.q > 0 && !team && !team_hbm) return;
+    const int32_t* final_sel = nullptr;      // team search: the best member's selection (global columns), read by the last finisher
+    int32_t team_nodes = 0;
     int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
     double ub_reduced = DINF;
-    if (!use_lds) {
+    if (!use_lds && tm.q > 0) {
+        // ---- member of a giant cluster's team: wait for the owner's reduced problem, build it in LDS ---------------------------
+        // (the owner -- a workgroup with a lower block index -- was dispatched before this one and finishes whatever this one does:
+        // the wait ends; it is bounded anyway, and a member that gives up files an empty result so that the count stays complete)
+        TeamState* ts = a.team_state + team_idx;
+        TeamProblem* pb = a.team_prob + team_idx;
+        int ready = 0;
+        if (tid == 0) {
+            const unsigned long long w0 = wall_clock64();
+            while ((ready = __hip_atomic_load(&ts->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - w0 < 1000000000ull) __builtin_amdgcn_s_sleep(127);
+            r->i[0] = ready;
+        }
+        __syncthreads();
+        ready = r->i[0];
+        __syncthreads();
+        if (ready == 2) return;      // the owner finished without a reduction: nothing to share, no report expected
+        if (ready == 0) {            // gave up waiting (the owner's HBM phase takes longer than the bound): an empty result keeps the count complete
+            if (tid == 0) {
+                TeamResult& me = a.team_res[(size_t)team_idx * TEAM_W + tm.q];
+                me.ub = DINF; me.status = MHT_BLP_BRANCHED; me.nodes = 0; me.iters = 0;
+                __threadfence();
+                atomicAdd(&ts->done, 1);
+            }
+            return;
+        }
+        __threadfence();
+        auto ld = [](int32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        nHl = ld(&pb->nH);
+        ub_reduced = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&pb->ub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (int k = tid; k <= K; k += BLP_THREADS) s.colb[k] = ld(&pb->colb[k]);
+        for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = ld(&pb->ubpos[k]);
+        for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
+        if (tid == 0) s_nH = nHl;
+        __syncthreads();
+        for (int pos = tid; pos < nHl; pos += BLP_THREADS) {
+            const int h = ld(&pb->gcol[pos]);
+            int lo = 0, hi = K;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= pos) lo = mid; else hi = mid; }
+            s.gcolL[pos] = h;
+            s.membL[pos] = (unsigned short)lo;
+            s.costL[pos] = a.cost[h];
+            for (int d = 0; d < 8; ++d) {
+                const int e = d < a.PD ? (a.pds ? a.path[(size_t)h * a.pds + d] : a.path[(size_t)d * a.cap + h]) : -1;
+                s.entL[pos * 8 + d] = (unsigned short)(e < 0 ? 0xffff : e);      // global node id for now
+                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+            }
+        }
+        row_prefix();
+        nR = s_nR;
+        s.reduced = true;
+        s.nH = nHl;
+        use_lds = true;
+        team = true;
+    } else if (!use_lds) {
         // ---- HBM scratch: the same solver, generic column access ----------------------------------------------------
         GStore gs;
         gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
@@ -1760,7 +1868,21 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             s.reduced = true;
             s.nH = nHl;
             use_lds = true;
+            if (team_hbm && nHl <= TEAM_COLS) {      // file the reduced problem for the team, then search it together
+                TeamProblem* pb = a.team_prob + team_idx;
+                for (int pos = tid; pos < nHl; pos += BLP_THREADS) pb->gcol[pos] = s.gcolL[pos];
+                for (int k = tid; k <= K; k += BLP_THREADS) pb->colb[k] = s.colb[k];
+                for (int k = tid; k < K; k += BLP_THREADS) pb->ubpos[k] = s.ub_sel[k];
+                if (tid == 0) { pb->nH = nHl; pb->ub = ub_reduced; }
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(&a.team_state[team_idx].ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                team = true;
+            } else if (team_hbm && tid == 0) {
+                __hip_atomic_store(&a.team_state[team_idx].ready, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
+            if (team_hbm && tid == 0) __hip_atomic_store(&a.team_state[team_idx].ready, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // solved without a reduction
             stamp[4] = wall_clock64();
             for (int k = tid; k < K; k += BLP_THREADS) {
                 const int h = gs.ub_sel[k];
@@ -1791,13 +1913,51 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
 #ifdef MHT_BLP_TRACE
         if (tid == 0 && s.reduced) printf("[blp] cluster %d: rebuilt with %d columns %d rows at %.2f ms\n", c, nHl, nR, 1e-5 * (double)(wall_clock64() - t_begin));
 #endif
-        solve_core(a, s, K, r, status, iters, nodes, stamp, ub);
+        solve_core(a, s, K, r, status, iters, nodes, stamp, ub, team ? tm : Team{0, 1, nullptr});
 #ifdef MHT_BLP_TRACE
         if (tid == 0 && s.reduced) printf("[blp] cluster %d: LDS phase status %d iters %d nodes %d at %.2f ms\n", c, status, iters, nodes, 1e-5 * (double)(wall_clock64() - t_begin));
 #endif
+        if (team && status == MHT_BLP_CERTIFIED) {
+            if (tm.q > 0) return;      // the dual phase is deterministic: every member holds the same certificate, the owner finishes
+        } else if (team) {
+            // every member files what it found; the LAST one to finish takes the best and runs the cluster's epilogue.  Nobody waits.
+            TeamResult* res = a.team_res + (size_t)team_idx * TEAM_W;
+            TeamResult& me = res[tm.q];
+            for (int k = tid; k < K; k += BLP_THREADS) me.sel[k] = s.to_global(s.ub_sel[k]);
+            if (tid == 0) { me.ub = ub; me.status = status; me.nodes = nodes; me.iters = iters; }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) r->i[0] = atomicAdd(&a.team_state[team_idx].done, 1);
+            __syncthreads();
+            const int before = r->i[0];
+            __syncthreads();
+            if (before != tm.W - 1) return;
+            __threadfence();
+            if (tid == 0) {
+                int bq = 0, any_limit = 0, nsum = 0, itmax = 0;
+                double bub = DINF;
+                for (int q = 0; q < tm.W; ++q) {
+                    const double u = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&res[q].ub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const int st = __hip_atomic_load(&res[q].status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nsum += __hip_atomic_load(&res[q].nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int itq = __hip_atomic_load(&res[q].iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    itmax = itq > itmax ? itq : itmax;
+                    any_limit |= (st == MHT_BLP_NODE_LIMIT);
+                    if (u < bub) { bub = u; bq = q; }      // (ties: the lowest member)
+                }
+                r->i[0] = bq; r->i[1] = any_limit; r->i[2] = nsum; r->i[3] = itmax;
+            }
+            __syncthreads();
+            final_sel = res[r->i[0]].sel;
+            status = r->i[1] ? MHT_BLP_NODE_LIMIT : MHT_BLP_BRANCHED;
+            team_nodes = r->i[2];
+            nodes = team_nodes;
+            iters = r->i[3];
+            __syncthreads();
+        }
         stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
-            const int h = s.to_global(s.ub_sel[k]);
+            const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
             if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
             if (a.t_alive) {
@@ -1853,6 +2013,7 @@ static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
            2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16 + (size_t)cap_h * 4;
 }
 
+__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle);
 __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx) {      // workgroup bx of gx
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [cap_uw]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)a.cap_uw * 8);                   // sizeof(Red) padded to RED_SLOT
@@ -1865,11 +2026,47 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
     }
     // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- cluster c is solved
     // where c % shard_n == shard_i, a single-target cluster where its target index says so; see blp_epilogue_kernel)
-    for (int i = bx; i < nMulti; i += gx) {
-        const int c = a.multi_list[i];
-        if (a.shard_n > 1 && c % a.shard_n != a.shard_i) continue;
-        solve_cluster(a, c, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
+    // teams (mht_kernels.h: TEAM_*): the launch's workgroups without a cluster of their own (block index >= nMulti) are dealt out to
+    // the clusters of the team list; member 0 of a team is the workgroup that owns the cluster anyway
+    const bool teams_on = a.team_list && a.tier == 0 && a.shard_n <= 1 && gx > nMulti;
+    const int nTeam = teams_on ? a.counts[5] : 0;
+    const int nIdle = gx - nMulti;
+    auto team_W = [&](int ti) { const int w = 1 + (nIdle - ti + nTeam - 1) / nTeam; return w < TEAM_W ? w : TEAM_W; };
+    // (ONE call site of the solver: the workgroup's own clusters first, then the single-target clusters, then -- if it has no cluster
+    // of its own -- its share of a team's search)
+    int own_i = bx;
+    for (int stage = 0; stage < 3; ) {
+        int c = -1, ti = -1;
+        Team tm = Team{0, 1, nullptr};
+        if (stage == 0) {
+            if (own_i >= nMulti) { stage = 1; continue; }
+            c = a.multi_list[own_i];
+            own_i += gx;
+            if (a.shard_n > 1 && c % a.shard_n != a.shard_i) continue;
+            if (nTeam > 0 && a.cl_ptr[c + 1] - a.cl_ptr[c] >= TEAM_MIN_K)
+                for (int q = 0; q < nTeam; ++q) if (a.team_list[q] == c) ti = q;
+            if (ti >= 0 && team_W(ti) > 1) tm = Team{0, team_W(ti), &a.team_state[ti].gub};
+            else ti = -1;
+        } else if (stage == 1) {
+            stage = 2;
+            blp_singles(a, bx, gx, nSingle);
+            continue;
+        } else {
+            stage = 3;
+            if (!(nTeam > 0 && bx >= nMulti)) break;      // a workgroup without a cluster: member of a team
+            const int j = bx - nMulti, q = 1 + j / nTeam;
+            ti = j % nTeam;
+            if (q >= team_W(ti)) break;
+            __syncthreads();      // (the wavefronts of this workgroup are done with the single-target clusters)
+            c = a.team_list[ti];
+            tm = Team{q, team_W(ti), &a.team_state[ti].gub};
+        }
+        solve_cluster(a, c, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti);
     }
+}
+
+// targets alone in their cluster: one wavefront each, dealt out from the END of the grid (the workgroups without an ILP)
+__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle) {
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gx - 1 - bx) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
@@ -2032,7 +2229,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     const size_t snap_rows = nR > (size_t)BIG_MAXR ? nR : (size_t)BIG_MAXR;
     const size_t n_d = nR + 6 * S + 4 + (size_t)BB_SLOTS * BB_RE_LEVELS * snap_rows;
     // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd busy[BB_SLOTS]
-    const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 4 + 3 + BB_SLOTS;
+    const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 8 + 3 + BB_SLOTS;
     int rc = ctx->hitmask.ensure(n_d * 8 + n_i * 4 + 64);
     if (rc) return rc;
     double* d = static_cast<double*>(ctx->hitmask.ptr);
@@ -2049,7 +2246,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     int32_t* multi = members + nT;
     int32_t* single = multi + 1;
     int32_t* counts = single + 1;
-    int32_t* st = counts + 4;
+    int32_t* st = counts + 8;
     a.cl_ptr = cl_ptr; a.cl_members = members; a.multi_list = multi; a.single_list = single; a.counts = counts;
     a.cl_status = st; a.cl_iters = st + 1; a.cl_nodes = st + 2;
     a.bb_busy = st + 3;
@@ -2062,16 +2259,34 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     { const char* e = getenv("MHT_BLP_TIME_LIMIT_US"); a.time_limit = e ? atoll(e) * 100 : 0; }      // testing: wall-clock budget per cluster (10 ns ticks)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     // one cluster holding all targets
-    int32_t* hbuf = new int32_t[nT + 8];
+    // a large cluster is searched by a team of workgroups (mht_kernels.h: TEAM_*), as in the forest: the launch gets TEAM_W - 1
+    // workgroups without a cluster of their own
+    bool seam_team = nT >= TEAM_MIN_K && nT <= TEAM_SEL;
+    { const char* e = getenv("MHT_BLP_NO_TEAMS"); if (e && e[0] == '1') seam_team = false; }
+    if (seam_team) {
+        const size_t tb = 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W + sizeof(TeamProblem);
+        rc = ctx->counts.ensure(tb);
+        if (rc) return rc;
+        char* tp = static_cast<char*>(ctx->counts.ptr);
+        MHT_HIP_CHECK(hipMemsetAsync(tp, 0, tb, ctx->stream));
+        a.team_list = reinterpret_cast<int32_t*>(tp);                                  // [0] = cluster 0 (memset)
+        a.team_state = reinterpret_cast<TeamState*>(tp + 64);
+        a.team_res = reinterpret_cast<TeamResult*>(tp + 64 + sizeof(TeamState) * TEAM_MAX);
+        a.team_prob = reinterpret_cast<TeamProblem*>(tp + 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W);
+        const unsigned long long inf_key = ~0ull;
+        MHT_HIP_CHECK(hipMemcpyAsync(&a.team_state[0].gub, &inf_key, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int32_t* hbuf = new int32_t[nT + 12];
     hbuf[0] = 0; hbuf[1] = nT;
     for (int t = 0; t < nT; ++t) hbuf[2 + t] = t;
     hbuf[2 + nT] = 0; hbuf[3 + nT] = 0;
     hbuf[4 + nT] = 1; hbuf[5 + nT] = 1; hbuf[6 + nT] = 0; hbuf[7 + nT] = 0;
-    hipError_t e = hipMemcpyAsync(cl_ptr, hbuf, (size_t)(nT + 8) * 4, hipMemcpyHostToDevice, ctx->stream);
+    hbuf[8 + nT] = 0; hbuf[9 + nT] = seam_team ? 1 : 0; hbuf[10 + nT] = 0; hbuf[11 + nT] = 0;      // counts[4..7]: [5] = clusters in the team list
+    hipError_t e = hipMemcpyAsync(cl_ptr, hbuf, (size_t)(nT + 12) * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     delete[] hbuf;
     MHT_HIP_CHECK(e);
-    rc = launch_blp(ctx, a, 1);
+    rc = launch_blp(ctx, a, seam_team ? TEAM_W : 1);
     if (rc) return rc;
     hipLaunchKernelGGL(blp_objective_kernel, dim3(1), dim3(64), 0, ctx->stream, selected, cost, nT, st, st + 1, st + 2, out);
     MHT_HIP_CHECK(hipGetLastError());

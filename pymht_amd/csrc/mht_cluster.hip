@@ -62,7 +62,9 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
     for (int t = tid; t < T; t += CL_THREADS) { tlabel[t] = t; cnt[t] = 0; fill[t] = 0; }
     if (a.sel_rel_reset) for (int t = tid; t < T; t += CL_THREADS) a.sel_rel_reset[t] = -1;
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
-    if (tid == 0) { s_edges = 0; s_changed = 0; s_pend = 0; a.counts[3] = 0; a.counts[4] = 0; }
+    __shared__ int s_team;
+    if (tid == 0) { s_edges = 0; s_changed = 0; s_pend = 0; s_team = 0; a.counts[3] = 0; a.counts[4] = 0; }
+    if (a.team_state && tid < TEAM_MAX) { a.team_state[tid].gub = ~0ull; a.team_state[tid].done = 0; a.team_state[tid].ready = 0; }
     __syncthreads();
     int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);
@@ -337,7 +339,13 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
             a.single_list[atomicAdd(&s_changed, 1)] = t;
         } else {
             tmp[base + atomicAdd(&fill[h], 1)] = t;
-            if (h == t) a.multi_list[atomicAdd(&s_edges, 1)] = c;
+            if (h == t) {
+                a.multi_list[atomicAdd(&s_edges, 1)] = c;
+                if (a.team_list && K >= TEAM_MIN_K) {      // large cluster: its branch and bound (if it needs one) is shared by a team
+                    const int q = atomicAdd(&s_team, 1);
+                    if (q < TEAM_MAX) a.team_list[q] = c;
+                }
+            }
         }
     }
     __syncthreads();
@@ -356,6 +364,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
         a.counts[0] = nC;
         a.counts[1] = s_edges;
         a.counts[2] = s_changed;
+        if (a.team_list) a.counts[5] = s_team < TEAM_MAX ? s_team : TEAM_MAX;
     }
 }
 

@@ -301,6 +301,7 @@ struct Forest {
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
     unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
+    int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
@@ -398,6 +399,8 @@ struct Forest {
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
+        team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
+        team_prob = ar.take<TeamProblem>(TEAM_MAX);
         u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
         bb_snap_rows = n_mnodes > 1024 ? n_mnodes : 1024;
         bb_snap = ar.take<double>((size_t)BB_SLOTS * BB_RE_LEVELS * bb_snap_rows); bb_busy = ar.take<int32_t>(BB_SLOTS);
@@ -532,6 +535,7 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
+    { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
     f->pds = f->PD <= 8 ? 8 : 16;
 
     f->used_off = sizeof(ReportHeader);
@@ -718,6 +722,7 @@ static void fill_cluster(const Forest* f, int s, ClusterArgs& c) {
     c.dbg = f->debug ? reinterpret_cast<int32_t*>(f->grow_dbg) + 16 : nullptr;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
+    c.team_list = f->teams ? f->team_list : nullptr; c.team_state = f->teams ? f->team_state : nullptr;
     cluster_prepare(c);
 }
 
@@ -726,6 +731,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     const int cb = s & 1;
     const mht_nodes& out = f->layer[s % f->R];
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
+    b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state; b.team_res = f->team_res; b.team_prob = f->team_prob;
     b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD; b.pds = f->pds;
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;

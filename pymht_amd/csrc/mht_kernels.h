@@ -81,6 +81,21 @@ constexpr int GROUP_MAX = 32;      // sectors per batched launch
 struct FBatch { const FGrowArgs* ga[GROUP_MAX]; const CommitArgs* ca[GROUP_MAX]; FDyn d[GROUP_MAX]; };
 struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM) per sector
 
+// Teams: a cluster of >= TEAM_MIN_K targets that needs a branch and bound is searched by SEVERAL workgroups of the launch -- the one
+// it belongs to (member 0) and up to TEAM_W - 1 of the launch's workgroups that have no cluster of their own.  Every member
+// replicates the (deterministic) dual phase on its own LDS copy of the cluster; below the root of the search member q descends
+// only into the (level-0 column, level-1 column) pairs whose hash is q mod W; the value of the best selection found anywhere is
+// shared through one 64-bit atomic-min word; the member that finishes LAST takes the best selection and runs the cluster's
+// epilogue (nobody waits for anybody).  At most TEAM_MAX clusters per scan form teams.
+constexpr int TEAM_MIN_K = 24, TEAM_MAX = 8, TEAM_W = 32, TEAM_SEL = 256;
+struct TeamResult { double ub; int32_t status, nodes, iters, pad; int32_t sel[TEAM_SEL]; };      // what a member found (global column per target)
+struct TeamState { unsigned long long gub; int32_t done, ready, pad[12]; };                    // per team: shared incumbent key, finished members, TeamProblem filed
+// A giant cluster (more columns than the LDS tables hold) runs its dual phase on HBM scratch, which is its owner's alone; when
+// reduced-cost fixing has cut it down to what LDS holds (mht_blp.hip: reducible), the owner files the surviving columns here and the
+// team's other members -- who have been waiting for exactly this -- build the same LDS problem and share the search.
+constexpr int TEAM_COLS = 2048;      // (= BIG_MAXH: columns of an LDS-resident cluster)
+struct TeamProblem { double ub; int32_t nH, pad; int32_t colb[TEAM_SEL + 4]; int32_t ubpos[TEAM_SEL]; int32_t gcol[TEAM_COLS]; };
+
 struct ClusterArgs {
     const unsigned long long* assoc;   // [T][AW]
     int AW;                            // words per target
@@ -107,13 +122,15 @@ struct ClusterArgs {
     int32_t* cl_members;   // [T]
     int32_t* multi_list;   // [T] cluster indices with >= 2 members
     int32_t* single_list;  // [T] target indices that are alone in their cluster
-    int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow
+    int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow; [5]: clusters in team_list (forest)
+    int32_t* team_list;    // [TEAM_MAX] or null: clusters of >= TEAM_MIN_K targets (searched by teams of workgroups, see BlpArgs)
+    TeamState* team_state; // [TEAM_MAX] reset here for this scan
 };
 
 // branch and bound of blp_kernel: the first BB_RE_LEVELS levels re-optimise the prices of their residual problem and keep a
 // snapshot of them in HBM; BB_SLOTS snapshot sets are shared by the workgroups of a launch (clusters that branch are rare)
 constexpr int BB_RE_LEVELS = 32;
-constexpr int BB_SLOTS = 8;
+constexpr int BB_SLOTS = 8 + TEAM_W;
 
 struct RingLayer { const double* x; const double* cnllr; const int32_t* meas; const uint8_t* flags; };   // one layer of the node ring
 
@@ -148,6 +165,7 @@ struct BlpArgs {
     // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
     // targets; 2: default footprint, takes exactly those
     int cap_h, cap_r, cap_k, cap_uw, tier, t1_h, t1_k;
+    const int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob;      // teams (null: off): [TEAM_MAX], [TEAM_MAX], [TEAM_MAX][TEAM_W], [TEAM_MAX]
     int32_t* big_list; int32_t* big_count;
     int shard_n, shard_i;           // cluster sharding over devices with identical forests (0 / 1: off)
     int32_t* sel_rel;               // [T] or null: selected child relative to the target's block (tchild[t]); -1 = not solved here      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])

@@ -139,8 +139,48 @@ def test_blp_clusters_without_certificate(gpu_ctx, gold_dir):
     2 677 nodes."""
     for inst in load_instances(os.path.join(gold_dir, "g9_ilp_giant.npz")):
         sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=200)
-        assert st == 2 and 0 < nd < 6000, (len(inst["cols"]), st, it, nd)
+        # (a cluster of >= 24 targets is searched by a TEAM of workgroups -- see the next test: nd sums the members' nodes, the levels above
+        # the deal-out level are walked by all of them)
+        assert st == 2 and 0 < nd < 15000, (len(inst["cols"]), st, it, nd)
         assert abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
+        assert gpu_blp.last_call_s < 0.060, "a giant cluster took %.1f ms (round-3 bar: < 50 ms device time; the call adds launches and a read-back)" % (1e3 * gpu_blp.last_call_s)
+
+
+def test_blp_team_search_equals_single_workgroup_search(gpu_ctx, gold_dir, monkeypatch):
+    """Branch and bound by a team of workgroups (csrc/mht_kernels.h: TEAM_*; tracker.py:1155-1217 is one CBC call): every member
+    replicates the deterministic dual phase, the subtrees below the deal-out level are dealt out by a hash of their columns, the
+    incumbent value is one shared atomic-min word, the last member to finish takes the best selection.  Same optimum and -- the
+    recorded optima being unique -- the same selection as the single-workgroup search (MHT_BLP_NO_TEAMS=1), which needs 4x as long
+    on the third G9 instance; and inside the forest: a dense scenario scan by scan with teams on and off."""
+    insts = load_instances(os.path.join(gold_dir, "g9_ilp_giant.npz")) + load_instances(os.path.join(gold_dir, "g12_ilp_reduced.npz"))
+    got = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("MHT_BLP_NO_TEAMS", off)
+        got[off] = [gpu_blp(gpu_ctx, inst, max_iter=200) + (gpu_blp.last_call_s,) for inst in insts]
+    for inst, a, b in zip(insts, got["0"], got["1"]):
+        assert a[0] == b[0] == inst["sel"].tolist() and abs(a[1] - b[1]) <= 1e-12 * max(1.0, abs(b[1])) and a[2] == b[2] and a[2] in (1, 2)
+    assert got["0"][2][5] < 0.6 * got["1"][2][5], "the team did not speed the 43-target instance up: %.1f vs %.1f ms" % (1e3 * got["0"][2][5], 1e3 * got["1"][2][5])
+    # inside the forest (teams are formed by the launch's workgroups without a cluster of their own)
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.utils.scenario import make_scenario
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = make_scenario(T=66, radius=201.0, lambda_phi=1.5e-4, n_scans=7, P_d=0.73, period=2.5, seed=5494)
+    runs = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("MHT_BLP_NO_TEAMS", off)
+        trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=9.21, useInitiator=False, maxTargets=512, maxNodes=1 << 18)
+        trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+        out = []
+        for z, t in zip(sc["scans"], sc["times"]):
+            trk.addMeasurementList(MeasurementList(float(t), z))
+            sel = trk._sel[0]
+            out.append((sel["id"].tolist(), sel["sel_meas"].tolist(), sel["sel_x"].tobytes(), trk.lastScanStats["branched"], trk.lastScanStats["leaves_out"]))
+        trk.close()
+        runs[off] = out
+    assert runs["0"] == runs["1"]
+    assert sum(r[3] for r in runs["0"]) > 0      # (some cluster did branch)
 
 
 def test_blp_time_limit_returns_a_feasible_selection(gpu_ctx, gold_dir, monkeypatch):
