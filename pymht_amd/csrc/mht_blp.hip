@@ -2042,7 +2042,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             if (own_i >= nMulti) { stage = 1; continue; }
             c = a.multi_list[own_i];
             own_i += gx;
-            if (a.shard_n > 1 && c % a.shard_n != a.shard_i) continue;
+            if (a.shard_n > 1 && (a.cl_owner ? a.cl_owner[c] : c % a.shard_n) != a.shard_i) continue;
             if (nTeam > 0 && a.cl_ptr[c + 1] - a.cl_ptr[c] >= TEAM_MIN_K)
                 for (int q = 0; q < nTeam; ++q) if (a.team_list[q] == c) ti = q;
             if (ti >= 0 && team_W(ti) > 1) tm = Team{0, team_W(ti), &a.team_state[ti].gub};

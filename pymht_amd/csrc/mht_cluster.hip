@@ -360,6 +360,43 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
     CL_STAMP(5);
     if (a.dbg && tid == 0) a.dbg[7] = E;
     __syncthreads();
+    if (a.cl_owner && a.shard_n > 1) {
+        // ---- which device solves which ILP (cluster-sharded step): LPT on the column counts --------------------------------------
+        // weight of a multi-target cluster = its columns (children of its members); rank by (weight descending, cluster index
+        // ascending) by counting, then ONE thread deals them out in that order, each to the least loaded device.  The table is
+        // indexed by cluster index, so it does not depend on the (atomic) order of multi_list.
+        const int nM = s_edges;
+        int* wgt = tmp;                 // [nM] (the member scratch is dead; nM <= Tcap / 2: a multi-target cluster has two members at least)
+        int* cix = tmp + a.Tcap / 2;    // [nM]
+        int* ord = tlabel;              // [nM] cluster list position by rank (the union-find parents are dead as well)
+        for (int i = tid; i < nM; i += CL_THREADS) {
+            const int c = a.multi_list[i];
+            int w = 0;
+            for (int k = a.cl_ptr[c]; k < a.cl_ptr[c + 1]; ++k) { const int t = a.cl_members[k]; w += a.tcend[t] - a.tchild[t]; }
+            wgt[i] = w; cix[i] = c;
+        }
+        __syncthreads();
+        for (int i = tid; i < nM; i += CL_THREADS) {
+            const int w = wgt[i], c = cix[i];
+            int rank = 0;
+            for (int j = 0; j < nM; ++j) { const int wj = wgt[j], cj = cix[j]; rank += (wj > w || (wj == w && cj < c)) ? 1 : 0; }
+            ord[rank] = i;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long load[16];
+            const int ns = a.shard_n < 16 ? a.shard_n : 16;
+            for (int r = 0; r < ns; ++r) load[r] = 0;
+            for (int q = 0; q < nM; ++q) {
+                const int i = ord[q];
+                int best = 0;
+                for (int r = 1; r < ns; ++r) if (load[r] < load[best]) best = r;
+                a.cl_owner[cix[i]] = best;
+                load[best] += wgt[i];
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
         a.counts[0] = nC;
         a.counts[1] = s_edges;

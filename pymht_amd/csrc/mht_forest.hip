@@ -301,6 +301,7 @@ struct Forest {
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
     unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
+    int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
     int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
@@ -399,6 +400,7 @@ struct Forest {
         t_label = ar.take<int32_t>(Tcap); t_cluster = ar.take<int32_t>(Tcap); cl_ptr = ar.take<int32_t>((size_t)Tcap + 1);
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
+        cl_owner = ar.take<int32_t>(Tcap);
         team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         team_prob = ar.take<TeamProblem>(TEAM_MAX);
         u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
@@ -994,6 +996,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
         ClusterArgs c;
         fill_cluster(f, pl.s, c);
         c.sel_rel_reset = sel_rel;
+        c.shard_n = shard_n; c.tchild = f->tchild; c.tcend = f->tcend; c.cl_owner = f->cl_owner;
         rc = launch_cluster(ctx, c);
     }
     if (!rc && f->prune_thr > 0.f) {      // (replicated, like grow and clustering: every device prunes every lone target)
@@ -1005,7 +1008,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     if (!rc) {
         BlpArgs b;
         fill_blp(f, pl.s, b);
-        b.shard_n = shard_n; b.shard_i = shard_i; b.sel_rel = sel_rel;
+        b.shard_n = shard_n; b.shard_i = shard_i; b.sel_rel = sel_rel; b.cl_owner = f->cl_owner;
         b.t_alive = nullptr;      // solve only: the per-target end of the scan follows the exchange (mht_forest_step_sharded_end)
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
@@ -1601,6 +1604,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "cl_members")) { src = f->cl_members; avail = T * 4; }
     else if (!strcmp(name, "multi_list")) { src = f->multi_list; avail = T * 4; }
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
+    else if (!strcmp(name, "cl_owner")) { src = f->cl_owner; avail = T * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
     else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
     else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 2 * GKF * 4; }                  // gains by key

@@ -123,6 +123,10 @@ struct ClusterArgs {
     int32_t* multi_list;   // [T] cluster indices with >= 2 members
     int32_t* single_list;  // [T] target indices that are alone in their cluster
     int32_t* counts;       // [4]: nClusters, nMulti, nSingle, edge overflow; [5]: clusters in team_list (forest)
+    // cluster-sharded step (one tracker on shard_n devices with identical forests): which device solves which multi-target cluster.
+    // Longest-processing-time rule on the clusters' column counts (largest first, each to the least loaded device; ties: lower cluster
+    // index / lower device) -- every device computes the same table from the same data.
+    int shard_n; const int32_t* tchild; const int32_t* tcend; int32_t* cl_owner;      // [T] by cluster index, or null / shard_n <= 1: off
     int32_t* team_list;    // [TEAM_MAX] or null: clusters of >= TEAM_MIN_K targets (searched by teams of workgroups, see BlpArgs)
     TeamState* team_state; // [TEAM_MAX] reset here for this scan
 };
@@ -168,6 +172,7 @@ struct BlpArgs {
     const int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob;      // teams (null: off): [TEAM_MAX], [TEAM_MAX], [TEAM_MAX][TEAM_W], [TEAM_MAX]
     int32_t* big_list; int32_t* big_count;
     int shard_n, shard_i;           // cluster sharding over devices with identical forests (0 / 1: off)
+    const int32_t* cl_owner;        // [T] device of every multi-target cluster (cluster kernel: LPT by column count); null: cluster c on device c % shard_n
     int32_t* sel_rel;               // [T] or null: selected child relative to the target's block (tchild[t]); -1 = not solved here      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])
     const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target

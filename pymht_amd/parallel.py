@@ -22,8 +22,10 @@ def sector_seed(base_seed, rank):
 
 
 def assign_clusters(cluster_sizes, world_size):
-    """Longest-processing-time assignment of independent clusters (or sectors) to ranks: returns rank per cluster.
-    Used when one scan's gating graph partitions into many clusters that are to be solved on different GPUs."""
+    """Longest-processing-time assignment of independent clusters to ranks: returns rank per cluster (largest first, each to the least
+    loaded rank; ties: lower cluster index, lower rank).  The cluster-sharded step computes exactly this table ON THE DEVICE, on every
+    rank identically, from the clusters' column counts (csrc/mht_cluster.hip: `cl_owner`); this host statement of the rule is what the
+    tests compare the device's table with (tests/test_sharded_gpu.py, tests/test_parallel_cpu.py)."""
     order = np.argsort(-np.asarray(cluster_sizes, dtype=np.int64), kind="stable")
     load = np.zeros(world_size, dtype=np.int64)
     out = np.zeros(len(cluster_sizes), dtype=np.int64)

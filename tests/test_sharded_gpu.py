@@ -31,6 +31,39 @@ def _same(a, b, what):
         assert a.lastScanStats[k] == b.lastScanStats[k], (what, k)
 
 
+def _rd(trk, name, n):
+    import ctypes as C
+    from pymht_amd import _lib
+    a = np.zeros(max(int(n), 1), dtype=np.int32)
+    _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+    return a
+
+
+def _owner_table(trk):
+    trk._ctx.synchronize()
+    cnt = _rd(trk, "cl_counts", 8)
+    nC, nM = int(cnt[0]), int(cnt[1])
+    ml, own = _rd(trk, "multi_list", nM)[:nM], _rd(trk, "cl_owner", nC)
+    return sorted((int(c), int(own[c])) for c in ml)
+
+
+def _check_lpt(trk, owners, shards):
+    from pymht_amd.parallel import assign_clusters
+    if not owners:
+        return
+    cnt = _rd(trk, "cl_counts", 8)
+    nC = int(cnt[0])
+    ptr = _rd(trk, "cl_ptr", nC + 1)
+    nT = int(ptr[nC])
+    mem, tch, tce = _rd(trk, "cl_members", nT), _rd(trk, "tchild", nT + 1), _rd(trk, "tcend", nT + 1)
+    cs = [c for c, _ in owners]      # ascending cluster index = the tie order of the device's ranking
+    sizes = [int(sum(int(tce[m]) - int(tch[m]) for m in mem[ptr[c]:ptr[c + 1]])) for c in cs]
+    want = assign_clusters(sizes, shards)
+    assert [o for _, o in owners] == want.tolist(), "the device's cluster -> device table is not the LPT assignment"
+    load = np.bincount(want, weights=sizes, minlength=shards)
+    assert load.max() <= load.mean() + max(sizes), "LPT bound"
+
+
 @pytest.mark.parametrize("name,n_scans,shards,similar", [("cfg3", 8, 2, False), ("dense", 10, 3, False), ("cfg2", 9, 2, True)])
 def test_cluster_sharded_equals_single_device(name, n_scans, shards, similar):
     import torch
@@ -50,6 +83,12 @@ def test_cluster_sharded_equals_single_device(name, n_scans, shards, similar):
         merged = torch.stack([p.sel_rel for p in parts]).max(dim=0).values
         solved = torch.stack([(p.sel_rel >= 0).int() for p in parts]).sum(dim=0)
         assert int(solved.max()) <= 1, "a target was solved by two shards"
+        # which device solved which cluster: the device's own table (cluster kernel: LPT on the clusters' column counts) must be the
+        # longest-processing-time assignment of pymht_amd.parallel.assign_clusters, and the same on every shard
+        owners = [_owner_table(p.trk) for p in parts]
+        for o in owners[1:]:
+            assert o == owners[0], "the shards disagree on who solves which cluster"
+        _check_lpt(parts[0].trk, owners[0], shards)
         for p in parts:
             p.sel_rel.copy_(merged)
             p.end()
