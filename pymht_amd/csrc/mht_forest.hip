@@ -291,6 +291,7 @@ struct Forest {
     // ring that were written before keep their keys into the old one (layer_gen), which is cleared when the ring has come round.
     VTab vts[2] = {}; int vgen = 0; int layer_gen[MAXR] = {}; int last_rebuild_scan = -1000000; int32_t* vt_remap = nullptr;
     int rebuilds = 0;
+    unsigned long long vt_used_seen = 0, vt_rate = 0;      // ids in use at the last commit the host saw; largest per-commit consumption seen (a burst predicts the next)
     Arena arena;
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
@@ -320,6 +321,7 @@ struct Forest {
     int init_ran_scan = 0;       // last scan whose initiator ran inside its cluster launch (mht_forest_scan)
     const float* z_cur = nullptr;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
+    hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
@@ -433,6 +435,7 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
+    if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
     if (f->evp) {
         for (int k = 0; k < EV_POOL; ++k) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(f->evp[k][i]);
         delete[] f->evp;
@@ -851,10 +854,20 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     pl.rebuilt = false;
     if (f->hint_host) {      // value table three quarters full (as of the last commit the host has seen) and the other generation free again?
         const unsigned long long used = reinterpret_cast<volatile unsigned long long*>(f->hint_host)[1];
-        if (used > (unsigned long long)f->vt.vcap / 4 * 3 && s - f->last_rebuild_scan > f->R + 1) {
+        // ids are consumed by new covariance values AND by pseudo parents (roots, births, re-keyed leaves, merged hypotheses of
+        // similar-state pruning): the switch comes when the table is three quarters full, or earlier when, at the largest per-scan
+        // consumption seen so far, what is left would not last through the R + 2 scans until the NEXT switch is allowed (twice over:
+        // the hint lags a scan or two behind the device)
+        if (used > f->vt_used_seen) { const unsigned long long dlt = used - f->vt_used_seen; if (dlt > f->vt_rate) f->vt_rate = dlt; }
+        if (used) f->vt_used_seen = used;
+        const unsigned long long need = 2ull * (unsigned long long)(f->R + 3) * f->vt_rate;
+        const bool tight = used > (unsigned long long)f->vt.vcap / 4 * 3 || (used > (unsigned long long)f->vt.vcap / 8 && used + need > (unsigned long long)f->vt.vcap);
+        if (tight && s - f->last_rebuild_scan > f->R + 1) {
             const int rc = vt_switch_generation(ctx, f, s);
             if (rc) { f->dead = true; return rc; }
             reinterpret_cast<volatile unsigned long long*>(f->hint_host)[1] = 0;      // (until the next commit reports the new table's fill)
+            f->vt_used_seen = 0;
+            f->vt_rate /= 2;      // (the re-keying itself is a burst: let the estimate decay)
             pl.rebuilt = true;
         }
     }
@@ -1299,10 +1312,20 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         float* zd = f->z_dev + (size_t)slot * 2 * f->Mpad;
         memcpy(zh, z_host, (size_t)M * 2 * sizeof(float));
         const int n16 = (M * 2 + 3) / 4;
-        hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
+        // The scan is pulled out of pinned memory by a one-workgroup kernel on a stream of its own: a host that streams scans in queues
+        // scan k + 1 while scan k is still on the device, so the pull overlaps scan k's ILPs instead of standing in front of scan k + 1's
+        // grow launch (4 us + a launch gap per scan); the ctx stream waits for the event (already signalled by then).
+        if (!f->stage_stream_tried) {
+            f->stage_stream_tried = true;
+            const char* e = getenv("MHT_STAGE_STREAM");
+            if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&f->stage_stream, hipStreamNonBlocking) != hipSuccess) f->stage_stream = nullptr;
+        }
+        hipStream_t sst = f->stage_stream ? f->stage_stream : ctx->stream;
+        hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
                            reinterpret_cast<float4*>(zd), n16);
         MHT_HIP_CHECK(hipGetLastError());
-        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], ctx->stream));      // (the host may refill this slot once the kernel has run)
+        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run)
+        if (f->stage_stream) MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0));
         f->z_used[slot] = true;
         f->z_cur = zd;
         (void)mark_done;
