@@ -559,6 +559,12 @@ def main():
                      "kernel": "fgrow_kernel (gate + update + score + child creation + next scan's gains, 1 launch), HIP events on the ctx stream",
                      "algorithmic_bytes": b_gate},
     }
+    if strong:
+        # the Amdahl split of the sharded scan, from the device wall-clock stamps of the LAST timed scan on this rank (10 ns ticks in the
+        # report header): grow and clustering are replicated on every rank, only the ILP stage shrinks with the rank count
+        out["strong_stage_us"] = {"grow_replicated": rep.t_process * 1e-2, "cluster_replicated": rep.t_cluster * 1e-2,
+                                  "ilp_this_rank": rep.t_optim * 1e-2, "scan_on_device": rep.t_scan * 1e-2,
+                                  "note": "per scan: grow + cluster are replicated, the ILPs of this rank's clusters (placed by size), then one all-reduce(MAX) of T int32 and the per-target epilogue"}
     if rank == 0 and world == 1 and args.cpu_scans > 0:
         n_warm = min(args.cpu_warm, len(sc["scans"]) - args.cpu_scans)
         out["cpu_baseline"] = cpu_baseline(sc, n_warm, args.cpu_scans)
