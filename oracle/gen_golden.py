@@ -368,6 +368,8 @@ def main():
         gen_g17(mods)
     if "g14" in which:
         gen_g14(mods)
+    if "g18" in which:
+        gen_g18(mods)
     if "g13" in which:
         # similar-state pruning (addMeasurementList(pruneSimilar=True); tracker.py:230-231, pyTarget.py:358-412) on the dense and
         # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
@@ -379,6 +381,113 @@ def main():
     if "g6b" in which:
         # the headline config for 22 scans (13 of them at the steady-state size, more births and terminations than g6): hashed trace only
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
+
+
+def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=True):
+    """G18: reference and oracle side by side on a scenario WITH AIS traffic (Tracker.addMeasurementList(scan, aisList,
+    aisInitialization=False): tracker.py:162-307 with the fusion of :417-552); every scan compared bitwise; fixture = the scans,
+    the messages and what came out.  The tracker needs a finite radarRange here (tracker.py:438 divides by its square; with the
+    default inf the reference dies in kalman.nllr)."""
+    T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
+    cd = mods["classDefinitions"]
+    from m_of_n_oracle import Initiator
+    from pymht_amd.utils.classDefinitions import MeasurementList as MyML
+    from pymht_amd.models import pv as mypv
+    kw = dict(P_d=sc["P_d"], N=sc["N"], eta2=5.99, radarRange=float(sc["radius"]), position=np.asarray(sc["centre"], dtype=np.float64))
+    trk = T.Tracker(pv, sc["period"], sc["lambda_phi"], LAMBDA_NU, **kw)
+    adapter = None
+    if with_initiator:
+        my_init = Initiator(trk.M_required, trk.N_checks, trk.maxSpeedMS, mypv.C_RADAR, mypv.R_RADAR(), trk.mergeThreshold)
+        adapter = OracleInitiatorAdapter(my_init, MyML)
+    else:
+        trk.initiator.processMeasurements = lambda radar, ais_=(): []      # (no births on either side)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, initiator=adapter, **kw)
+    accepted = []
+    for x in sc["x0"]:
+        n0 = len(trk.__targetList__)
+        trk.initiateTarget(Target(sc["t0"], None, x.copy(), pv.P0.copy(), status="preinitialized"))
+        ok = o.initiate_target(sc["t0"], x.copy(), orc.model_P0(), status="preinitialized")
+        assert ok == (len(trk.__targetList__) > n0)
+        accepted.append(ok)
+    K = len(sc["scans"]) if n_scans is None else n_scans
+    fx = dict(x0=sc["x0"], accepted=np.array(accepted), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"], lambda_phi=sc["lambda_phi"],
+              lambda_nu=LAMBDA_NU, N=sc["N"], eta2=5.99, eta2_ais=trk.eta2_ais, times=sc["times"][:K], n_scans=K,
+              radar_range=float(sc["radius"]), position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=bool(with_initiator))
+
+    def leaf_rows(roots, leaves_of, get):
+        rows = [l for r in roots for l in leaves_of(r)]
+        return dict(ID=np.array([get(l, "ID") for l in rows], dtype=np.int64),
+                    x=np.array([np.asarray(get(l, "x"), dtype=np.float64) for l in rows]).reshape(-1, 4),
+                    xf32=np.array([get(l, "x").dtype == np.float32 for l in rows], dtype=bool),
+                    P=np.array([np.asarray(get(l, "P"), dtype=np.float64) for l in rows]).reshape(-1, 4, 4),
+                    Pf64=np.array([get(l, "P").dtype == np.float64 for l in rows], dtype=bool),
+                    cnllr=np.array([float(get(l, "cnllr")) for l in rows], dtype=np.float64),
+                    meas=np.array([-1 if get(l, "meas") is None else get(l, "meas") for l in rows], dtype=np.int64),
+                    mmsi=np.array([0 if get(l, "mmsi") is None else get(l, "mmsi") for l in rows], dtype=np.int64))
+    ref_names = dict(ID="ID", x="x_0", P="P_0", cnllr="cumulativeNLLR", meas="measurementNumber", mmsi="mmsi")
+    n_fused_total = n_fused_sel = 0
+    for k in range(K):
+        z, t = sc["scans"][k], float(sc["times"][k])
+        msgs = ais_scans[k]
+        ids_before = [r.ID for r in trk.__targetList__]
+        trk.addMeasurementList(ML_of(mods)(t, z), cd.AisMessageList([cd.AIS_message(time=m[0], state=m[1].copy(), mmsi=m[2], highAccuracy=m[3]) for m in msgs]),
+                               aisInitialization=False, checkIntegrity=True)
+        info = o.add_scan(t, z, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs])
+        rb = leaf_rows(trk.__targetList__, lambda r: r.getLeafNodes(), lambda l, f: getattr(l, ref_names[f]))
+        ob = leaf_rows(o.targets, lambda r: r.leaves(), lambda l, f: getattr(l, f))
+        for key in rb:
+            assert np.array_equal(rb[key], ob[key]), "scan %d: leaf batch field %s differs" % (k, key)
+        rs = leaf_rows(trk.__trackNodes__, lambda n: [n], lambda l, f: getattr(l, ref_names[f]))
+        os_ = leaf_rows(o.track_nodes, lambda n: [n], lambda l, f: getattr(l, f))
+        for key in rs:
+            assert np.array_equal(rs[key], os_[key]), "scan %d: selected %s differs" % (k, key)
+        rc = [np.asarray(c) for c in trk.__clusterList__]
+        assert len(rc) == len(o.clusters) and all(np.array_equal(a, b) for a, b in zip(rc, o.clusters)), "clusters"
+        ids_after = [r.ID for r in trk.__targetList__]
+        dead = [i for i in ids_before if i not in ids_after]
+        assert sorted(dead) == sorted(info["dead"]), (dead, info["dead"])
+        p = "s%02d_" % k
+        fx[p + "z"] = z
+        fx[p + "ais_time"] = np.array([m[0] for m in msgs], dtype=np.float64)
+        fx[p + "ais_state"] = np.array([m[1] for m in msgs], dtype=np.float64).reshape(-1, 4)
+        fx[p + "ais_mmsi"] = np.array([m[2] for m in msgs], dtype=np.int64)
+        fx[p + "ais_high"] = np.array([m[3] for m in msgs], dtype=bool)
+        fx[p + "ids"] = np.array(ids_after, dtype=np.int64)
+        fx[p + "dead"] = np.array(sorted(dead), dtype=np.int64)
+        fx[p + "new_ids"] = np.array(info["new_ids"], dtype=np.int64)
+        fx[p + "unused"] = info["unused"]
+        fx[p + "used_mmsi"] = np.array(info["used_mmsi"], dtype=np.int64)
+        fx[p + "LGM"] = np.array([info["L"], info["G"], info["M"], info["n_fused"]], dtype=np.int64)
+        fx[p + "cl_members"] = np.concatenate(rc) if rc else np.zeros(0, dtype=np.int64)
+        fx[p + "cl_ptr"] = np.concatenate([[0], np.cumsum([len(c) for c in rc])]).astype(np.int64)
+        for key, v in rs.items():
+            fx[p + "sel_" + key] = v
+        for key, v in rb.items():
+            fx[p + "leaf_" + key] = v
+        born = [r for r in trk.__targetList__ if r.ID in info["new_ids"]]
+        fx[p + "born_x"] = np.array([np.asarray(b.x_0, dtype=np.float64) for b in born]).reshape(-1, 4)
+        fx[p + "born_P"] = np.array([np.asarray(b.P_0, dtype=np.float32) for b in born]).reshape(-1, 4, 4)
+        n_fused_total += info["n_fused"]
+        n_fused_sel += int((rs["mmsi"] > 0).sum())
+        print("  %s scan %2d  M=%3d ais=%2d  T=%3d  L=%5d G=%5d fused=%4d  leaves_after=%5d (f64 P: %d)  ilp=%d  sel with mmsi=%d new=%s dead=%s" % (
+            out_name, k, len(z), len(msgs), len(ids_after), info["L"], info["G"], info["n_fused"], len(rb["ID"]), int(rb["Pf64"].sum()),
+            trk.nOptimSolved, int((rs["mmsi"] > 0).sum()), info["new_ids"], dead))
+    fx["n_fused_total"], fx["n_fused_selected"] = n_fused_total, n_fused_sel
+    np.savez_compressed(os.path.join(GOLD, out_name + ".npz"), **fx)
+    return trk, o
+
+
+def ML_of(mods):
+    return mods["classDefinitions"].MeasurementList
+
+
+def gen_g18(mods):
+    """AIS-aided traces: config 1 with every target equipped, the dense stream (20 targets in 400 m, ILPs, births, terminations)."""
+    from pymht_amd.utils.scenario import make_ais
+    sc = make_config("cfg1", seed=172362)
+    run_trace_ais(mods, sc, make_ais(sc, seed=3, equipped=1.0, p_report=0.8), "g18_trace_ais_cfg1")
+    sc = make_config("dense", seed=1234)
+    run_trace_ais(mods, sc, make_ais(sc, seed=77), "g18b_trace_ais_dense")
 
 
 def gen_g14(mods):

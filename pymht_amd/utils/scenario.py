@@ -43,7 +43,7 @@ def make_scenario(T, radius, lambda_phi, n_scans, P_d=0.9, period=2.5, sigma_r=2
     x[:, 2:] = rng.normal(0.0, sigma_v, size=(T, 2))
     x0 = x.copy()
     area = np.pi * radius * radius
-    scans, times = [], []
+    scans, times, truth = [], [], []
     for k in range(n_scans):
         # constant-velocity truth with a small white acceleration
         acc = rng.normal(0.0, sigma_q, size=(T, 2))
@@ -55,6 +55,7 @@ def make_scenario(T, radius, lambda_phi, n_scans, P_d=0.9, period=2.5, sigma_r=2
                 acc[out] -= 0.15 * rel[out] / rr[out, None]
         x[:, 0:2] += period * x[:, 2:4] + 0.5 * period * period * acc
         x[:, 2:4] += period * acc
+        truth.append(x.copy())
         seen = rng.uniform(size=T) <= P_d
         det = x[seen, 0:2] + rng.normal(0.0, sigma_r, size=(int(seen.sum()), 2))
         n_cl = rng.poisson(lambda_phi * area)
@@ -67,7 +68,36 @@ def make_scenario(T, radius, lambda_phi, n_scans, P_d=0.9, period=2.5, sigma_r=2
         times.append(t0 + (k + 1) * period)
     return dict(x0=x0, scans=scans, times=np.asarray(times, dtype=np.float64), t0=float(t0),
                 period=float(period), P_d=float(P_d), lambda_phi=float(lambda_phi), radius=float(radius),
-                centre=centre, seed=int(seed), truth_final=x.copy())
+                centre=centre, seed=int(seed), truth_final=x.copy(), truth=truth)
+
+
+def make_ais(sc, seed=77, equipped=0.5, p_report=0.7, offsets=(0.25, 0.5, 0.75), first_mmsi=257000000):
+    """AIS traffic for a scenario (the reference's simulator makes such lists with `simulateAIS`, simulator.py:112-172): a fixed
+    share of the targets carries a transponder (mmsi = first_mmsi + target index); in every radar period each of them reports with
+    probability `p_report`, at one of a few instants inside the period (so that several messages share a time and several times
+    occur, tracker.py:429, :447-465), its state [x, y, vx, vy] at that instant plus noise of the accuracy class it claims
+    (models/ais.py:6-13: sigma 1.0 high / 3.0 low, all four components).  Returns per scan a list of
+    (time, state float64[4], mmsi, highAccuracy) in target order."""
+    rng = np.random.default_rng(seed)
+    T = len(sc["x0"])
+    has = rng.uniform(size=T) < equipped
+    period = sc["period"]
+    out = []
+    for k, t in enumerate(sc["times"]):
+        xk = sc["truth"][k]                                     # truth AT the scan
+        msgs = []
+        for i in np.flatnonzero(has):
+            if rng.uniform() >= p_report:
+                continue
+            off = float(offsets[int(rng.integers(0, len(offsets)))])
+            tm = float(t) - (1.0 - off) * period                 # strictly inside (t - period, t)
+            st = xk[i].copy()
+            st[0:2] -= (float(t) - tm) * st[2:4]                 # back along the velocity to the message's instant
+            high = bool(rng.uniform() > 0.5)
+            st = st + rng.normal(0.0, 1.0 if high else 3.0, size=4)
+            msgs.append((tm, st, int(first_mmsi + i), high))
+        out.append(msgs)
+    return out
 
 
 def make_config(name, seed=1234, **overrides):

@@ -70,3 +70,13 @@ def test_scan_trace_replay(gold_dir, name):
     """Replays the recorded scans through OracleTracker and compares every scan with what the reference did."""
     from trace_util import replay_oracle
     replay_oracle(os.path.join(gold_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense"])
+def test_ais_trace_replay(gold_dir, name):
+    """The AIS-aided path (tracker.py:417-552; messages start no tracks: aisInitialization=False): the oracle replays the traces
+    recorded from the reference bit for bit -- fused and pure-AIS children, their float64 covariances and the float64 contagion of
+    their siblings' chains, the identity filter (pyTarget.py:269-272), (scan, mmsi) rows in clustering and ILP."""
+    from trace_util import replay_oracle_ais
+    o = replay_oracle_ais(os.path.join(gold_dir, name + ".npz"))
+    assert o.n_scans > 0
