@@ -370,6 +370,8 @@ def main():
         gen_g14(mods)
     if "g18" in which:
         gen_g18(mods)
+    if "g19" in which:
+        gen_g19(mods)
     if "g13" in which:
         # similar-state pruning (addMeasurementList(pruneSimilar=True); tracker.py:230-231, pyTarget.py:358-412) on the dense and
         # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
@@ -488,6 +490,107 @@ def gen_g18(mods):
     run_trace_ais(mods, sc, make_ais(sc, seed=3, equipped=1.0, p_report=0.8), "g18_trace_ais_cfg1")
     sc = make_config("dense", seed=1234)
     run_trace_ais(mods, sc, make_ais(sc, seed=77), "g18b_trace_ais_dense")
+
+
+def gen_g19(mods):
+    """Known-answer vectors of the AIS fusion itself: Tracker.__fuseRadarAndAis (tracker.py:417-552) called on hand-made leaves.
+    Cases: float64 and float32 leaf states, covariances from a few steps of the filter, 1-3 message times per scan, both accuracy
+    classes, messages that gate with no / one / several radar measurements, messages of other ships."""
+    T, pv, Target = mods["tracker"], mods["pv"], mods["pyTarget"].Target
+    cd = mods["classDefinitions"]
+    rng = np.random.default_rng(1905)
+    period = 2.5
+    fx = dict(period=period, lambda_phi=2e-5, lambda_nu=LAMBDA_NU, eta2=5.99)
+    cases = []
+    for ci in range(8):
+        radar_range = 1500.0 + 200.0 * ci
+        trk = T.Tracker(pv, period, 2e-5, LAMBDA_NU, P_d=0.9, N=3, eta2=5.99, radarRange=radar_range, position=np.zeros(2))
+        nT = 3 + ci                      # (only its length matters: lambda_ais, tracker.py:438)
+        trk.__targetList__ = [None] * nT
+        t_leaf = 1000.0 + period * ci
+        t_scan = t_leaf + period
+        n_leaf = int(rng.integers(2, 9))
+        f32 = (ci % 3 == 2)
+        centre = rng.uniform(-600, 600, size=2)
+        vel = rng.normal(0, 6, size=2)
+        # covariances: P0 through 0-3 steps of predict/update (float32 like the tree's)
+        nodes, Ps = [], []
+        for l in range(n_leaf):
+            P = orc.model_P0()
+            for _ in range(int(rng.integers(0, 4))):
+                _, Pb = orc.kf_predict(orc.model_Phi(period), orc.model_Q(period), np.zeros((1, 4)), P[None])
+                if rng.uniform() < 0.7:
+                    P = orc.kf_precalc(orc.model_C(), orc.model_R(), np.zeros((1, 4)), Pb)[4][0]
+                else:
+                    P = Pb[0]
+            P = np.asarray(P, dtype=np.float32)
+            x = np.concatenate([centre + rng.normal(0, 3.0, 2), vel + rng.normal(0, 0.5, 2)])
+            x = x.astype(np.float32) if f32 else x
+            pd = 0.9 if l % 2 == 0 else 0.8
+            nodes.append(Target(t_leaf, 5, x, P, ID=l, P_d=pd))
+            Ps.append(P)
+        # where the leaves will be at the scan, roughly: radar measurements and AIS messages around it
+        pos_scan = centre + vel * period
+        n_rad = int(rng.integers(3, 12))
+        z = np.concatenate([pos_scan + rng.normal(0, 2.5, size=(n_rad, 2)), pos_scan + rng.uniform(-400, 400, size=(4, 2))]).astype(np.float32)
+        if ci == 3:
+            z = (pos_scan + rng.uniform(200, 400, size=(5, 2))).astype(np.float32)       # nothing gates: pure-AIS children
+        msgs = []
+        n_msg = int(rng.integers(1, 5))
+        for q in range(n_msg):
+            tm = t_leaf + period * float(rng.choice([0.25, 0.5, 0.75]))
+            high = bool(rng.uniform() > 0.5)
+            st = np.concatenate([centre + vel * (tm - t_leaf), vel]) + rng.normal(0, 1.0 if high else 3.0, size=4)
+            if q == 3:
+                st[:2] += 80.0                                                            # a ship elsewhere: does not gate
+            msgs.append(cd.AIS_message(time=tm, state=st, mmsi=257000100 + 10 * ci + q, highAccuracy=high))
+        ais = cd.AisMessageList(msgs)
+        out = trk._Tracker__fuseRadarAndAis(nodes, ais, cd.MeasurementList(t_scan, z))
+        xs, Pf, ridx, nl, mm = out
+        p = "c%d_" % ci
+        fx[p + "radar_range"], fx[p + "n_targets"], fx[p + "t_leaf"], fx[p + "t_scan"] = radar_range, nT, t_leaf, t_scan
+        fx[p + "lambda_ais"] = (nT * trk.P_ais) / (np.pi * radar_range ** 2)
+        fx[p + "eta2_ais"] = trk.eta2_ais
+        fx[p + "x"] = np.array([np.asarray(n.x_0, dtype=np.float64) for n in nodes])
+        fx[p + "xf32"] = np.array([n.x_0.dtype == np.float32 for n in nodes])
+        fx[p + "P"] = np.array(Ps, dtype=np.float32)
+        fx[p + "pd"] = np.array([n.P_d for n in nodes], dtype=np.float64)
+        fx[p + "z"] = z
+        fx[p + "ais_time"] = np.array([m.time for m in ais], dtype=np.float64)
+        fx[p + "ais_state"] = np.array([m.state for m in ais], dtype=np.float64).reshape(-1, 4)
+        fx[p + "ais_mmsi"] = np.array([m.mmsi for m in ais], dtype=np.int64)
+        fx[p + "ais_high"] = np.array([m.highAccuracy for m in ais], dtype=bool)
+        ptr = [0]
+        ax, aP, ar, an, am = [], [], [], [], []
+        for l in range(n_leaf):
+            k = 0 if xs[l].size == 0 else xs[l].shape[0]
+            for j in range(k):
+                ax.append(np.asarray(xs[l][j], dtype=np.float64)); aP.append(np.asarray(Pf[l][j], dtype=np.float64))
+                ar.append(-1 if ridx[l][j] is None else int(ridx[l][j])); an.append(float(nl[l][j])); am.append(int(mm[l][j]))
+            ptr.append(len(ax))
+        fx[p + "ptr"] = np.array(ptr, dtype=np.int64)
+        fx[p + "out_x"] = np.array(ax, dtype=np.float64).reshape(-1, 4)
+        fx[p + "out_P"] = np.array(aP, dtype=np.float64).reshape(-1, 4, 4)
+        fx[p + "out_radar"] = np.array(ar, dtype=np.int64)
+        fx[p + "out_nllr"] = np.array(an, dtype=np.float64)
+        fx[p + "out_mmsi"] = np.array(am, dtype=np.int64)
+        # the oracle's restatement gives the same, bit for bit
+        class _L:
+            pass
+        leaves = []
+        for n in nodes:
+            o_ = _L(); o_.time, o_.x, o_.P, o_.P_d = n.time, n.x_0, n.P_0, n.P_d
+            leaves.append(o_)
+        oo = orc.fuse_radar_ais(leaves, [orc.AisMessage(m.time, m.state, m.mmsi, m.highAccuracy) for m in ais], z, t_scan, orc.model_C(), orc.model_R(),
+                                5.99, trk.eta2_ais, trk.lambda_ex, fx[p + "lambda_ais"])
+        flat = [k_ for l_ in oo for k_ in l_]
+        assert len(flat) == len(ax)
+        for (x_, P_, r_, n_, m_), xr, Pr, rr, nr, mr in zip(flat, ax, aP, ar, an, am):
+            assert np.array_equal(x_, xr) and np.array_equal(P_, Pr) and (-1 if r_ is None else r_) == rr and n_ == nr and m_ == mr
+        cases.append((ci, n_leaf, len(ais), len(z), len(ax), int((np.array(ar) < 0).sum())))
+        print("  g19 case %d: leaves %d (f32 %s)  msgs %d  radar %d  children %d (pure AIS %d)" % (ci, n_leaf, f32, len(ais), len(z), len(ax), int((np.array(ar) < 0).sum())))
+    fx["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(GOLD, "g19_ais_fusion.npz"), **fx)
 
 
 def gen_g14(mods):

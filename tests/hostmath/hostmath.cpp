@@ -98,3 +98,32 @@ extern "C" float mht_host_sum1d_f32(const float* v, int n) {
     for (int i = 0; i < n; ++i) s.add(i, v[i]);
     return s.res;
 }
+
+// ---- AIS fusion (csrc/mht_ais_math.h): tests/golden/g19_ais_fusion.npz -------------------------------------------------------
+#include "../../pymht_amd/csrc/mht_ais_math.h"
+struct HostEmit {
+    double* ox; double* oP; int* oradar; double* onllr; int* omsg; int cap; int n;
+    void operator()(const double* x, const double* P, int radar, double nllr, int msg) {
+        if (n < cap) {
+            memcpy(ox + n * 4, x, 32); memcpy(oP + n * 16, P, 128);
+            oradar[n] = radar; onllr[n] = nllr; omsg[n] = msg;
+        }
+        ++n;
+    }
+};
+extern "C" int mht_host_fuse_ais(const float* Cm, const float* R, double eta2, double lambda_ex, const void* groups, int nG, const void* msgs,
+                                 int f32state, const double* x, const float* P, double pd, int own, double eta2_ais, double lambda_ais,
+                                 const float* z, int M, int cap, double* ox, double* oP, int* oradar, double* onllr, int* omsg) {
+    Model m;
+    memset(&m, 0, sizeof(m));
+    memcpy(m.C, Cm, 32); memcpy(m.R, R, 16);
+    m.eta2 = eta2; m.lambda_ex = lambda_ex;
+    HostEmit e{ox, oP, oradar, onllr, omsg, cap, 0};
+    const AisGroup* g = reinterpret_cast<const AisGroup*>(groups);
+    const AisMsg* ms = reinterpret_cast<const AisMsg*>(msgs);
+    if (f32state) {
+        float xs[4] = {(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+        return ais_fuse_leaf<float>(m, g, nG, ms, xs, P, pd, own, eta2_ais, lambda_ais, z, M, e);
+    }
+    return ais_fuse_leaf<double>(m, g, nG, ms, x, P, pd, own, eta2_ais, lambda_ais, z, M, e);
+}
