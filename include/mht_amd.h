@@ -167,6 +167,38 @@ int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRows, int32_t
 int mht_prune(mht_ctx* ctx, int32_t n_nodes, const int32_t* parent, int32_t T, const int32_t* sel, const int32_t* window,
               int32_t* new_root, uint8_t* keep);
 
+/* ---- AIS-aided children: Tracker.__fuseRadarAndAis (tracker.py:417-552), stateless ------------------------------------------
+ * Per leaf and per AIS message (a 4-state report [x, y, vx, vy] of a ship with identity mmsi, made inside the radar period in
+ * front of the scan; models/ais.py) that gates with it (eta2_ais, tracker.py:111): the leaf is predicted to the message's time,
+ * updated with it, predicted on to the scan's time and gated against the radar measurements; one child per gated radar
+ * measurement, score (nllr_ais + nllr_radar) / 2, or ONE child without a radar measurement, score nllr_ais (tracker.py:497-526).
+ * The messages come grouped as the reference walks them (tracker.py:447-453: message times in the iteration order of their SET,
+ * high accuracy before low, list order inside a group; pymht_amd/ais.py::group_messages builds the arrays):
+ *   groups  host [nG]: Phi, Q (models/pv.py:12-24, float32) over dT1 = t_message - t_leaves and dT2 = t_scan - t_message,
+ *           sigma^2 of the accuracy class (models/ais.py:9-13), first message and count
+ *   msgs    host [nA]: state float64[4], mmsi
+ * Leaves as in mht_gate_scan_x (x dev [4][L] float64, flags, P dev [L][16] float32, pd), own dev [L] int32 or null: the identity
+ * a leaf's track is bound to, 0 = none -- messages of other ships are skipped (pyTarget.py:269-272).  model: C, R, eta2,
+ * lambda_ex are read.  lambda_ais = nTargets P_ais / (pi radarRange^2) (tracker.py:438; needs a finite radarRange).
+ * Out, CSR by leaf in the reference's order: child_ptr dev [L+1]; out_x dev [4][cap] float64; out_P dev [cap][16] float64 (the
+ * reference's fused covariances are float64: ais.C is); out_radar dev [cap] (0-based radar measurement or -1); out_nllr;
+ * out_msg dev [cap] index into msgs.  Synchronous; MHT_E_CAPACITY if cap is too small (*n_children = what is needed).
+ * 4-state build only. */
+typedef struct mht_ais_group {
+    float A1[16], Q1[16], A2[16], Q2[16];
+    float r_diag;
+    int32_t first, count, pad;
+} mht_ais_group;
+typedef struct mht_ais_msg {
+    double state[4];
+    int32_t mmsi;
+    int32_t pad;
+} mht_ais_msg;
+int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const float* P, const double* pd,
+                 const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                 double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                 double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children);
+
 /* ---- the device-resident hypothesis forest: Tracker.addMeasurementList end to end -----------------------------
  * Replaces steps 1-6 of tracker.py:162-307 (grow :207-209, cluster :220, optimise :228-236, terminate :252-253,
  * N-scan prune :258 = seam (iv) Tracker._nScanPruning, tracker.py:1219-1231 / pyTarget.py:343-356) without a host

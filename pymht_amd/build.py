@@ -13,7 +13,7 @@ def lib_path(nx=4):
     assert nx in (4, 6), "libmht_amd is built for 4 or 6 states"
     # (development: MHT_LIB_VARIANT=.name loads libmht_amd.so.name, an experiment build made by hand)
     return (LIB if nx == 4 else LIB6) + os.environ.get("MHT_LIB_VARIANT", "")
-SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_gatex.hip", "mht_fgrow.hip", "mht_cluster.hip", "mht_blp.hip", "mht_prune.hip", "mht_similar.hip", "mht_init.hip", "mht_forest.hip"]
+SOURCES = ["mht_api.hip", "mht_gate.hip", "mht_gatex.hip", "mht_fgrow.hip", "mht_cluster.hip", "mht_blp.hip", "mht_prune.hip", "mht_similar.hip", "mht_init.hip", "mht_ais.hip", "mht_forest.hip"]
 # -ffp-contract=off is REQUIRED: mht_math.h spells out every fused multiply-add of the reference's
 # BLAS evaluation order; letting the compiler contract anything else breaks bit-exact gating.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

@@ -1,0 +1,161 @@
+// AIS-aided children: Tracker.__fuseRadarAndAis (pymht/tracker.py:417-552) on the device.
+//
+// Stateless seam mht_fuse_ais: for L leaves (caller-owned SoA arrays, as mht_gate_scan_x takes them) and the AIS messages of a scan
+// in the reference's group order (pymht_amd/ais.py::group_messages) the fused / pure-AIS children of every leaf, CSR by leaf, in
+// the reference's order.  One thread per leaf: the work per leaf is a handful of 4x4 float64 products per message that gates with
+// it (a message gates with the ~30 leaves of its own ship's track and nobody else), then one pass over the scan's radar measurements
+// per gated message -- a few thousand leaves x a few gated messages per scan: latency of the longest leaf, not throughput, and it
+// runs only on scans that carry AIS messages.  Two passes (count, exclusive scan, emit) so that a leaf's children are contiguous.
+//
+// In the forest the same per-leaf function feeds the grow kernel (mht_forest.hip: forest_ais_*; fgrow_kernel<..., AIS>).
+#include "mht_kernels.h"
+#include "mht_ais_math.h"
+
+namespace mht {
+
+struct AisSeamArgs {
+    Model model;                                   // C, R, eta2, lambda_ex are read
+    int L; const double* x; const uint8_t* flags; const float* P; const double* pd; const int32_t* own;
+    const AisGroup* groups; int nG; const AisMsg* msgs;
+    double eta2_ais, lambda_ais;
+    const float* z; int M;
+    int32_t* cnt; const int32_t* child_ptr; int cap;
+    double* out_x; double* out_P; int32_t* out_radar; double* out_nllr; int32_t* out_msg;
+};
+
+struct CountOnly {
+    __device__ __forceinline__ void operator()(const double*, const double*, int, double, int) const {}
+};
+struct SeamEmit {
+    const AisSeamArgs* a; int c;
+    __device__ __forceinline__ void operator()(const double* x, const double* P, int radar, double nllr, int msg) {
+        if (c < a->cap) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a->out_x[(size_t)k * a->cap + c] = x[k];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a->out_P[(size_t)c * 16 + e] = P[e];
+            a->out_radar[c] = radar;
+            a->out_nllr[c] = nllr;
+            a->out_msg[c] = msg;
+        }
+        ++c;
+    }
+};
+
+template <typename EMIT>
+__device__ __forceinline__ int seam_leaf(const AisSeamArgs& a, int l, EMIT& e) {
+    float P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = a.P[(size_t)l * 16 + i];
+    const double pd = a.pd[l];
+    const int own = a.own ? a.own[l] : 0;
+    if (a.flags[l] & F_STATE_F32) {
+        float xs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k] = (float)a.x[(size_t)k * a.L + l];
+        return ais_fuse_leaf<float>(a.model, a.groups, a.nG, a.msgs, xs, P, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+    }
+    double xd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.L + l];
+    return ais_fuse_leaf<double>(a.model, a.groups, a.nG, a.msgs, xd, P, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+}
+
+__global__ __launch_bounds__(64) void ais_count_kernel(const AisSeamArgs a) {
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= a.L) return;
+    CountOnly e;
+    a.cnt[l] = seam_leaf(a, l, e);
+}
+__global__ __launch_bounds__(64) void ais_emit_kernel(const AisSeamArgs a) {
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= a.L) return;
+    SeamEmit e{&a, a.child_ptr[l]};
+    seam_leaf(a, l, e);
+}
+// exclusive scan of cnt[0..L) -> ptr[0..L]; one workgroup
+__global__ __launch_bounds__(1024) void ais_scan_kernel(const int32_t* cnt, int32_t* ptr, int L, int cap, DevStatus* status) {
+    __shared__ int s_w[16], s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < L; base += 1024) {
+        const int i = base + tid;
+        const int v = i < L ? cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (i < L) ptr[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_run = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ptr[L] = s_run;
+        status->n_children = s_run;
+        if (s_run > cap) status->overflow = 1;
+    }
+}
+
+}  // namespace mht
+
+using namespace mht;
+
+extern "C" int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const float* P, const double* pd,
+                            const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                            double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                            double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children) {
+    MHT_REQUIRE(NX == 4, "mht_fuse_ais: AIS messages report four states (models/ais.py); this is the %d-state build of the library", NX);
+    MHT_REQUIRE(ctx && model && child_ptr, "mht_fuse_ais: null argument");
+    MHT_REQUIRE(L >= 0 && M >= 0 && cap >= 0 && nG >= 0 && nA >= 0, "mht_fuse_ais: negative size");
+    MHT_REQUIRE(L == 0 || (x && flags && P && pd), "mht_fuse_ais: null leaf array");
+    MHT_REQUIRE(nG == 0 || (groups && msgs), "mht_fuse_ais: null message array");
+    MHT_REQUIRE(M == 0 || z, "mht_fuse_ais: z is null");
+    MHT_REQUIRE(cap == 0 || (out_x && out_P && out_radar && out_nllr && out_msg), "mht_fuse_ais: null output array");
+    MHT_REQUIRE(lambda_ais > 0.0, "mht_fuse_ais: lambda_ais must be positive (a tracker without a finite radarRange has none: tracker.py:438)");
+    for (int g = 0; g < nG; ++g)
+        MHT_REQUIRE(groups[g].first >= 0 && groups[g].count >= 0 && groups[g].first + groups[g].count <= nA, "mht_fuse_ais: group %d outside the message list", g);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    static_assert(sizeof(mht_ais_group) == sizeof(AisGroup) && sizeof(mht_ais_msg) == sizeof(AisMsg), "ABI structs");
+    AisSeamArgs a = {};
+#if MHT_NX == 4
+    for (int i = 0; i < 8; ++i) a.model.C[i] = model->C[i];
+    for (int i = 0; i < 4; ++i) a.model.R[i] = model->R[i];
+#endif
+    a.model.eta2 = model->eta2; a.model.lambda_ex = model->lambda_ex;
+    a.L = L; a.x = x; a.flags = flags; a.P = P; a.pd = pd; a.own = own;
+    a.nG = nG; a.eta2_ais = eta2_ais; a.lambda_ais = lambda_ais; a.z = z; a.M = M; a.cap = cap;
+    a.child_ptr = child_ptr; a.out_x = out_x; a.out_P = out_P; a.out_radar = out_radar; a.out_nllr = out_nllr; a.out_msg = out_msg;
+    // scratch: groups | messages | cnt[L]
+    const size_t gb = ((size_t)(nG > 0 ? nG : 1) * sizeof(AisGroup) + 15) & ~(size_t)15, mb = ((size_t)(nA > 0 ? nA : 1) * sizeof(AisMsg) + 15) & ~(size_t)15;
+    { const int rc = ctx->hitmask.ensure(gb + mb + (size_t)(L + 1) * 4 + 64); if (rc) return rc; }
+    char* q = static_cast<char*>(ctx->hitmask.ptr);
+    if (nG) MHT_HIP_CHECK(hipMemcpyAsync(q, groups, (size_t)nG * sizeof(AisGroup), hipMemcpyHostToDevice, ctx->stream));
+    if (nA) MHT_HIP_CHECK(hipMemcpyAsync(q + gb, msgs, (size_t)nA * sizeof(AisMsg), hipMemcpyHostToDevice, ctx->stream));
+    a.groups = reinterpret_cast<const AisGroup*>(q);
+    a.msgs = reinterpret_cast<const AisMsg*>(q + gb);
+    a.cnt = reinterpret_cast<int32_t*>(q + gb + mb);
+    MHT_HIP_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(DevStatus), ctx->stream));
+#if MHT_NX == 4
+    if (L > 0) hipLaunchKernelGGL(ais_count_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(ais_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.cnt, child_ptr, L, cap, ctx->status);
+    if (L > 0) hipLaunchKernelGGL(ais_emit_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, a);
+#endif
+    MHT_HIP_CHECK(hipGetLastError());
+    DevStatus st;
+    MHT_HIP_CHECK(hipMemcpyAsync(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // (also: the host arrays behind the two copies may be reused now)
+    if (n_children) *n_children = st.n_children;
+    if (st.overflow) {
+        set_error("mht_fuse_ais: %d children exceed the capacity of the output arrays (%d)", st.n_children, cap);
+        return MHT_E_CAPACITY;
+    }
+    return MHT_OK;
+}

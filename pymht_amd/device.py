@@ -160,3 +160,43 @@ def process_leaf_nodes_x(ctx, A, Q, Cm, R, eta2, lambda_ex, x, P, pd, flags, z):
     return dict(x_bar=T(x_bar, nx)[:n], P_bar=T(P_bar, nx, nx)[:n], P_hat=T(P_hat, nx, nx)[:n], S=T(S, 2, 2)[:n], S_inv=T(S_inv, 2, 2)[:n],
                 K=T(K, nx, 2)[:n], row_ptr=row_ptr.cpu().numpy().astype(np.int64), col_idx=col_idx[:g].cpu().numpy().astype(np.int64),
                 x_hat=x_hat[:, :g].cpu().numpy().T.copy(), nllr=nllr[:g].cpu().numpy())
+
+
+def fuse_radar_and_ais(ctx, model, eta2, lambda_ex, x, P, pd, flags, own, ais_list, leaf_time, scan_time, eta2_ais, lambda_ais, z):
+    """The stateless AIS seam (`mht_fuse_ais`): Tracker.__fuseRadarAndAis (tracker.py:417-552) for n leaves of one time against
+    the AIS messages and the radar measurements of a scan.  Host arrays in (x (n,4) float64 holding float32 values where flags
+    says so, P (n,4,4) float32, own (n,) identity the leaf's track is bound to or 0), host arrays out: child_ptr (n+1), x (g,4),
+    P (g,4,4) float64, radar (g,) 0-based index or -1, nllr (g,), mmsi (g,) -- the children of leaf i are child_ptr[i] .. child_ptr[i+1]-1
+    in the reference's order."""
+    from .ais import group_messages
+    lib, dev = ctx.lib, ctx.device
+    n, M = x.shape[0], z.shape[0]
+    groups, nG, msgs, order = group_messages(ais_list, float(leaf_time), float(scan_time), model)
+    m = make_model(model.Phi(scan_time - leaf_time), model.Q(scan_time - leaf_time), model.C_RADAR, model.R_RADAR(), eta2, lambda_ex, 0.8)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    xd = t(np.asarray(x, dtype=np.float64).reshape(n, 4).T, np.float64) if n else torch.zeros((4, 0), dtype=torch.float64, device=dev)
+    Pd = t(np.asarray(P, dtype=np.float32).reshape(n, 16), np.float32)
+    pdd, fd = t(np.asarray(pd, dtype=np.float64), np.float64), t(np.asarray(flags, dtype=np.uint8), np.uint8)
+    od = t(np.asarray(own, dtype=np.int32), np.int32)
+    zd = t(np.asarray(z, dtype=np.float32).reshape(-1, 2), np.float32)
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    cap = max(8 * n + 64, 64)
+    while True:
+        ox = torch.zeros((4, cap), dtype=torch.float64, device=dev)
+        oP = torch.zeros((cap, 16), dtype=torch.float64, device=dev)
+        orad, omsg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        onl = torch.zeros(cap, dtype=torch.float64, device=dev)
+        total = C.c_int32(0)
+        rc = lib.mht_fuse_ais(ctx.handle, C.byref(m), n, xd.data_ptr(), fd.data_ptr(), Pd.data_ptr(), pdd.data_ptr(), od.data_ptr(),
+                              C.byref(groups), nG, C.byref(msgs), len(order), float(eta2_ais), float(lambda_ais), zd.data_ptr(), M,
+                              ptr.data_ptr(), ox.data_ptr(), oP.data_ptr(), orad.data_ptr(), onl.data_ptr(), omsg.data_ptr(), cap, C.byref(total))
+        if rc == _lib.MHT_E_CAPACITY:
+            cap = total.value + 64
+            continue
+        _lib.check(rc)
+        break
+    g = total.value
+    mi = omsg[:g].cpu().numpy()
+    return dict(child_ptr=ptr.cpu().numpy().astype(np.int64), x=ox[:, :g].cpu().numpy().T.copy(), P=oP[:g].cpu().numpy().reshape(-1, 4, 4),
+                radar=orad[:g].cpu().numpy().astype(np.int64), nllr=onl[:g].cpu().numpy(),
+                mmsi=np.array([ais_list[order[i]].mmsi for i in mi], dtype=np.int64))
