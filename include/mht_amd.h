@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MHT_ABI_VERSION 2
+#define MHT_ABI_VERSION 3
 
 /* State dimension of the library build the header is used with: 4 (libmht_amd.so: the reference's CV model, models/pv.py) or 6
  * (libmht_amd6.so: the same sources compiled with -DMHT_NX=6 for BASELINE config 5's six-state model).  It sizes the model matrices
@@ -216,6 +216,22 @@ typedef struct mht_forest_config {
     double radar_x, radar_y, radar_range; /* Tracker.position / radarRange (tracker.py:44-45), range may be +inf */
     double merge_threshold; /* Tracker.mergeThreshold (tracker.py:65) used by initiateTarget */
 } mht_forest_config;
+
+/* ---- AIS-aided forest (Tracker.addMeasurementList(scanList, aisList), tracker.py:162, :394-396, :417-552) ---------------------
+ * mht_forest_create_ex(..., MHT_FOREST_AIS): a forest whose nodes also carry the identity of the AIS message they were updated
+ * with and the identity their track is bound to (pyTarget.py:34, :297-302) and whose ILP rows include the AIS messages
+ * (tracker.py:1057-1064, :1083-1090).  4-state build, n_scan <= 7 (n_scan <= 3: 8-entry path records, the ILPs stay in LDS;
+ * above: 16-entry records, the ILPs run on the HBM policy).  mht_forest_set_ais hands over the messages of the NEXT scan, grouped as
+ * for mht_fuse_ais; the next mht_forest_step / _step_host / _scan consumes them: radar M + nA <= max_meas (rounded up to a multiple
+ * of 64).  A scan without messages needs no call.  AIS messages start no tracks here (the reference's aisInitialization=False).
+ * Not available to members of a group or to the cluster-sharded step.
+ * mht_forest_read_mmsi: identities of the nodes [first, first + count) of the layer of `scan` (host arrays out, either may be null):
+ * mmsi[i] = the message node first + i was updated with (0: none; with measurement number 0 that is a child WITHOUT a radar
+ * measurement, the reference's measurementNumber None), hist[i] = Target._getHistoricalMmsi(). */
+#define MHT_FOREST_AIS 1u
+int mht_forest_create_ex(mht_ctx* ctx, const mht_model* model, const struct mht_forest_config* cfg, uint32_t flags);
+int mht_forest_set_ais(mht_ctx* ctx, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais, double lambda_ais);
+int mht_forest_read_mmsi(mht_ctx* ctx, int32_t scan, int32_t first, int32_t count, int32_t* mmsi, int32_t* hist);
 
 /* per-target record of the scan report (old target-list order) */
 typedef struct mht_target_report {

@@ -104,6 +104,91 @@ __global__ __launch_bounds__(1024) void ais_scan_kernel(const int32_t* cnt, int3
     }
 }
 
+// ---- the forest: fused children of every leaf of the newest layer, in front of the scan's grow launch ----------------------------
+// One workgroup (a wavefront) per target slot of the COMMITTED table, lane = leaf.  Per leaf: count, take a slice of the record
+// pool (one returning atomic), emit.  The covariance of the children of a (leaf, message) pair is a value like any other
+// (mht_vtab.h): rounded to float32, found or inserted, and given a key of its own -- a pseudo parent whose miss child it is, as a
+// root's or a merged hypothesis' (mht_similar.hip) -- with the gains the children need as leaves of the next scan.
+struct ForestEmit {
+    const AisForestArgs* a; int c; double pd; int last_msg, key;
+    __device__ __forceinline__ void operator()(const double* x, const double* P, int radar, double nllr, int msg) {
+        if (msg != last_msg) {
+            last_msg = msg;
+            float Pf[NP];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) Pf[e] = (float)P[e < 16 ? e : 0];
+            const int id0 = vt_find_or_insert(a->vt, Pf, pd);
+            const unsigned pid = atomicAdd(a->vt.count, 1u);
+            if (pid >= (unsigned)a->vt.vcap || id0 < 0) { *a->vt.overflow = 1; key = 0; }
+            else {
+                key = 2 * (int)pid;
+                float4 rec[GKQ];
+                vt_gains(a->model, Pf, pd, rec);
+#pragma unroll
+                for (int e = 0; e < GKQ; ++e) a->vt.Gk[(size_t)key * GKQ + e] = rec[e];
+                a->vt.child[key] = id0;
+            }
+        }
+        AisRec r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.x[k] = x[k];
+        r.nllr = nllr; r.radar = radar; r.msg = msg; r.key = key; r.mmsi = a->msgs[msg].mmsi;
+        a->rec[c++] = r;
+    }
+};
+
+template <typename EMIT>
+__device__ __forceinline__ int forest_leaf(const AisForestArgs& a, int src, uint8_t fl, const float* P, double pd, int own, EMIT& e) {
+    if (fl & F_STATE_F32) {
+        float xs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k] = (float)a.x[(size_t)k * a.cap + src];
+        return ais_fuse_leaf<float>(a.model, a.groups, a.nG, a.msgs, xs, P, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+    }
+    double xd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
+    return ais_fuse_leaf<double>(a.model, a.groups, a.nG, a.msgs, xd, P, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+}
+
+__global__ __launch_bounds__(64) void forest_ais_kernel(const AisForestArgs a) {
+#if MHT_NX == 4
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.nT_dev[0]) return;
+    const int first = a.t_first[t], cnt = a.t_leaf_off[t + 1] - a.t_leaf_off[t];
+    for (int i = lane; i < cnt; i += 64) {
+        const int src = first + i;
+        const uint8_t fl = a.flags[src];
+        int n = 0, o = 0;
+        if (!(fl & F_DEAD)) {
+            float P[NP];
+            vt_load(a.vt, a.vt.child[a.cov[src]], P);
+            const double pd = a.pd[src];
+            const int own = a.hmmsi[src];
+            CountOnly ce;
+            n = forest_leaf(a, src, fl, P, pd, own, ce);
+            if (n > 0) {
+                o = (int)atomicAdd(a.rec_count, (unsigned)n);
+                if (o + n > a.rec_cap) { a.status->overflow = 1; n = 0; }
+            }
+            if (n > 0) {
+                ForestEmit fe{&a, o, pd, -1, 0};
+                forest_leaf(a, src, fl, P, pd, own, fe);
+            }
+        }
+        a.nf[src] = n;
+        a.off[src] = o;
+    }
+#endif
+}
+
+int launch_forest_ais(mht_ctx* ctx, const AisForestArgs& a, int n_targets_ub) {
+    const int grid = n_targets_ub < 1 ? 1 : n_targets_ub;
+    hipLaunchKernelGGL(forest_ais_kernel, dim3(grid), dim3(64), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
 }  // namespace mht
 
 using namespace mht;

@@ -169,7 +169,57 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb)
 // the work -- role 0: x[0..1], cumulativeNLLR; 1: x[2..3], P_d, parent; 2: measurement number, covariance column, flags, ILP
 // cost, used-measurement byte; 3: path and ancestor records.  (One wavefront doing everything was a ~1500-instruction serial
 // stream, 2.9 us; what every role needs -- which hit, z_tilde, NIS, the score -- is recomputed by each.)
-template <typename TS, int PQ, typename ARGS>
+// AIS forest: the two records of child c.  A path record has two halves of `half` levels: radar measurement nodes, AIS message nodes;
+// the parent's entries from the new root on (level + shift) in both, the child's own rows at level `depth`.
+template <int PQ, typename ARGS>
+__device__ __forceinline__ void fg_emit_records_ais(const ARGS& a, int l, int c, int depth, int shift, int radar_row, int ais_row, const int* s_pp, const int* s_ap) {
+    const int half = a.ais.half;
+    const int* pl = s_pp + l * (PQ * 4);
+    const int* al = s_ap + l * (PQ * 4);
+    int4* po = reinterpret_cast<int4*>(a.out_path + (size_t)c * (PQ * 4));
+    int4* ao = reinterpret_cast<int4*>(a.out_apath + (size_t)c * (PQ * 4));
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        int pe[4], ae[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = q * 4 + e;
+            const int hb = (i >= half) ? half : 0, lvl = i - hb;
+            const bool in_rec = i < 2 * half;
+            const int src_p = (in_rec && lvl < depth) ? hb + lvl + shift : 0;
+            const int src_a = (i < depth) ? i + shift : 0;
+            const int pvv = pl[src_p], avv = al[src_a];
+            pe[e] = !in_rec ? -1 : (lvl < depth) ? pvv : ((lvl == depth) ? (hb ? ais_row : radar_row) : -1);
+            ae[e] = (i < depth) ? avv : ((i == depth) ? c : -1);
+        }
+        po[q] = make_int4(pe[0], pe[1], pe[2], pe[3]);
+        ao[q] = make_int4(ae[0], ae[1], ae[2], ae[3]);
+    }
+}
+
+// AIS forest: fused child f of a leaf -- everything comes out of the record forest_ais_kernel left (mht_ais.hip); float64 state and
+// score whatever the leaf's chains are (tracker.py:484-500: ais.C and the message are float64)
+template <int PQ, typename ARGS>
+__device__ __forceinline__ void fg_emit_fused(const ARGS& a, const FDyn& d, const FLeaf& g, int l, int c, const AisRec& r, const int* s_pp, const int* s_ap,
+                                              int depth, int shift, double rootc) {
+    const size_t cap = a.cap;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.ox[(size_t)i * cap + c] = r.x[i];
+    const double cnl = g.cn + r.nllr;
+    a.ocnllr[c] = cnl;
+    a.opd[c] = g.pd;
+    a.oparent[c] = g.src;
+    a.omeas[c] = r.radar + 1;          // 0 with an identity = a child without a radar measurement (measurementNumber None)
+    a.ocov[c] = r.key;
+    a.oflags[c] = 0;
+    a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
+    a.ais.ommsi[c] = r.mmsi;
+    a.ais.ohmmsi[c] = r.mmsi;
+    // (no used-measurement byte: tracker.py:333-334 marks the measurements of the pure radar gate only)
+    fg_emit_records_ais<PQ>(a, l, c, depth, shift, r.radar >= 0 ? a.cur_slot_base + r.radar : -1, a.cur_slot_base + d.M + r.msg, s_pp, s_ap);
+}
+
+template <typename TS, int PQ, int AIS = 0, typename ARGS = void>
 __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, int nh, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
                                               double rootc, int root_f32, const unsigned short* cand = nullptr, const float2* zg = nullptr) {
@@ -194,7 +244,9 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         hit = 1;
     }
     FG_STAMPX(2);
-    if (role == 3 || role < 0) {
+    if (AIS) {
+        fg_emit_records_ais<PQ>(a, l, c, depth, shift, meas > 0 ? a.cur_slot_base + meas - 1 : -1, -1, s_pp, s_ap);
+    } else if (role == 3 || role < 0) {
         // path / ancestor records of the child: the parent's entries from the new root on (d + shift), its own at level `depth`
         const int* pl = s_pp + l * (PQ * 4);
         const int* al = s_ap + l * (PQ * 4);
@@ -312,7 +364,7 @@ __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32s
 // PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
 // a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
 // edge of its budget (128 for four workgroups per CU in the batched launch).
-template <int PQ, int CAP>
+template <int PQ, int CAP, int AIS = 0>
 __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem) {
     constexpr int PDS = PQ * 4;
     const auto& a = *ap0;
@@ -330,6 +382,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     int* s_misc = s_pref + CAP + 4;                                                      // [32]
     unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
     unsigned char* s_map = reinterpret_cast<unsigned char*>(cand + Mpad);                   // [FG_MAP] leaf of the chunk's r-th child
+    int* s_ais = reinterpret_cast<int*>(s_map + FG_MAP);                                    // AIS forest: [CAP][4] fused children (count, first record), bound identity
     int& s_ncand = s_misc[0];
     int& s_base = s_misc[1];
     int& s_ebase = s_misc[2];
@@ -399,7 +452,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             // ---- phase 1: predict, one leaf per lane of wavefronts 0 and 1; the gains come from the table -----------------------
             for (int w = tid; w < CAP * W; w += FG_THREADS) hw[w] = 0ull;
             if (tid == 0) s_ncand = 0;
-            int last = -1;
+            int last = -1, last2 = -1, nfv = 0, offv = 0;      // (last2, nfv, offv: AIS forest)
             if (wave < 2) {          // (both wavefronts whole: the box reduction below runs over all their lanes)
                 const bool keep = tid < CAP;
                 FLeaf g;
@@ -445,10 +498,25 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int i = q * 4 + e;
-                            if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
+                            if (!AIS) {
+                                if (i >= shift && i < shift + depth && pe[e] >= 0) last = pe[e];
+                            } else {      // two halves: the deepest level that has a row contributes its row(s); lvl_* ride in nfv / offv until the loads below
+                                const int half = a.ais.half;
+                                const int hb = (i >= half) ? half : 0, lvl = i - hb - shift;
+                                if (i < 2 * half && lvl >= 0 && lvl < depth && pe[e] >= 0) {
+                                    if (hb) { last2 = pe[e]; offv = lvl + 1; } else { last = pe[e]; nfv = lvl + 1; }
+                                }
+                            }
                         }
                     }
-                if (!valid) last = -1;
+                if (AIS) {
+                    if (nfv < offv) last = -1;          // (a deeper AIS-only level: the radar row further up belongs to an ancestor's own all-miss leaf)
+                    if (offv < nfv) last2 = -1;
+                    nfv = 0; offv = 0;
+                    if (valid && d.ais_on) { nfv = a.ais.nf[src]; offv = a.ais.off[src]; }
+                    if (keep) { s_ais[tid * 4] = nfv; s_ais[tid * 4 + 1] = offv; s_ais[tid * 4 + 2] = a.ais.hmmsi_in[src]; s_ais[tid * 4 + 3] = 0; }
+                }
+                if (!valid) { last = -1; last2 = -1; }
                 Model mdl;          // (only A and C are used: uniform registers)
 #pragma unroll
                 for (int e = 0; e < NP; ++e) mdl.A[e] = a.model.A[e];
@@ -519,6 +587,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             }
             // ---- phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront) -----
             if (last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));      // (the bitset was cleared in front of the barrier)
+            if (AIS) {
+                if (last2 >= 0) atomicOr(&tb[last2 >> 6], 1ull << (last2 & 63));
+                for (int f = 0; f < nfv; ++f) {      // the messages of the leaf's fused children (pyTarget.py:292-295: NOT their radar measurements)
+                    const int j = M + a.ais.rec[offv + f].msg;
+                    atomicOr(&tb[curw + (j >> 6)], 1ull << (j & 63));
+                }
+            }
             const int x0 = min(s_boxp[0], s_boxp[4]), x1 = max(s_boxp[1], s_boxp[5]);
             const int y0 = min(s_boxp[2], s_boxp[6]), y1 = max(s_boxp[3], s_boxp[7]);
             for (int j0 = 0; j0 < Mpad; j0 += FG_THREADS) {
@@ -570,6 +645,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                 int h0 = 0, h1 = 0;
                 const int l1 = (lane + 64 < CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
                 for (int w = 0; w < W; ++w) { h0 += __popcll(hw[(size_t)lane * W + w]); h1 += __popcll(hw[(size_t)l1 * W + w]); }
+                if (AIS) { h0 += s_ais[lane * 4]; h1 += s_ais[l1 * 4]; }      // (fused children behind the radar children)
                 const int m0 = (lane < n && lg[lane].valid) ? 1 + h0 : 0, m1 = (lane + 64 < n && lg[l1].valid) ? 1 + h1 : 0;
                 int i0 = m0, i1 = m1;
 #pragma unroll
@@ -691,7 +767,17 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    if (AIS) {
+                        const int nf = s_ais[l * 4], nhr = nh - nf;      // (nh counted the fused children too)
+                        if (k > nhr) {
+                            fg_emit_fused<PQ>(a, d, g, l, c, a.ais.rec[s_ais[l * 4 + 1] + (k - nhr - 1)], s_pp, s_ap, depth, shift, rootc);
+                        } else {
+                            a.ais.ommsi[c] = 0;
+                            a.ais.ohmmsi[c] = s_ais[l * 4 + 2];
+                            if (g.f32state) fg_emit_child<float, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                            else fg_emit_child<double, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                        }
+                    } else if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                     else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                 }
                 run += ctot;
@@ -1130,7 +1216,7 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w) {
     for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
 }
 
-template <int PQ, int CAP, typename CARGS>
+template <int PQ, int CAP, typename CARGS, int AIS = 0>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
     int bid = blockIdx.x;
     // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
@@ -1151,7 +1237,7 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (t >= d.n_tgt) return;
         target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
     } else {
-        target_part<PQ, (CAP == 0 ? FG_CAP : CAP)>(ap, d, bid, smem);
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS>(ap, d, bid, smem);
     }
 }
 
@@ -1162,6 +1248,15 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
     const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
     fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+}
+
+// AIS forest (mht_forest_create_ex with MHT_FOREST_AIS): split path records, identities per node, fused children on scans with messages
+template <int PQ>
+__global__ __launch_bounds__(FG_THREADS, 2) void fgrow_ais_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_grow = d.fused + d.n_main + d.n_chain;
+    if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }
+    fgrow_body<PQ, FG_CAP, CommitArgs, 1>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
@@ -1206,6 +1301,8 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
     return MHT_OK;
@@ -1230,6 +1327,19 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave) {
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
     static int wave_solo = -1;      // development: MHT_FG_WAVE_SOLO=1 runs the wavefront-per-target variant in the one-sector launch too
     if (wave_solo < 0) { const char* e = getenv("MHT_FG_WAVE_SOLO"); wave_solo = (e && e[0] == '1') ? 1 : 0; }
+    if (a.ais.half > 0) {      // AIS forest: its own kernel on every scan (records in two halves, identities per node)
+        fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
+        const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP) + (size_t)FG_CAP * 16;
+        { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+        const bool pub = publish && publish->dst;
+        const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
+        const PublishArgs pa = pub ? *publish : PublishArgs{};
+        const CommitArgs cm = commit ? *commit : CommitArgs{};
+        if (a.pds == 8) hipLaunchKernelGGL(fgrow_ais_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        else hipLaunchKernelGGL(fgrow_ais_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
     fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, wave_solo != 0);
     if (wave_solo) {
         const size_t lds = fgrow_wave_lds_bytes(d.W, a.pds, a.AW);

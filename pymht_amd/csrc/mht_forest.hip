@@ -82,6 +82,7 @@ struct AddArgs {
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
     Model model; VTab vt; int root_base;
     const int32_t* n_dev;      // number of candidates in device memory (or null: n)
+    int32_t* mmsi; int32_t* hmmsi;      // AIS forest: identities of the newest layer's nodes (a root has none), else null
     ReportHeader* hdr; mht_birth_report* births;      // report block of the device initiator's candidates (or null)   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
 };
 
@@ -153,6 +154,7 @@ static __device__ void add_targets_body(const AddArgs& a) {
                 a.layer.meas[idx] = a.meas[q];
                 a.layer.cov[idx] = -1;                     // (its key is made below, once the admissions are known)
                 a.layer.flags[idx] = a.flags[q];
+                if (a.mmsi) { a.mmsi[idx] = 0; a.hmmsi[idx] = 0; }
                 for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
                 a.tab.id[t] = a.cnt->id_counter;
                 a.tab.window[t] = a.Nwin;
@@ -296,6 +298,13 @@ struct Forest {
     mht_nodes layer[MAXR];
     int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
     int pds = 8;                      // ints per path / ancestor record (8 or 16)
+    // AIS forest (mht_forest_create_ex, MHT_FOREST_AIS; mht_kernels.h: AisGrow): identities per node, record pool of the fused children,
+    // the messages of the next scan (mht_forest_set_ais arms them, the next step consumes them)
+    bool ais = false; int ais_half = 0;
+    int32_t* l_mmsi[MAXR] = {}; int32_t* l_hmmsi[MAXR] = {};
+    int32_t* ais_nf = nullptr; int32_t* ais_off = nullptr; AisRec* ais_rec = nullptr; int ais_rec_cap = 0; unsigned* ais_count = nullptr;
+    char* ais_groups_dev = nullptr; char* ais_msgs_dev = nullptr; int ais_group_cap = 64, ais_msg_cap = 0;
+    bool ais_armed = false; int ais_nG = 0, ais_nA = 0; double ais_eta2 = 0.0, ais_lambda = 0.0;
     unsigned* alloc; int block_cap = 0, over_base = 0, region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
     TTable tab[2];
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
@@ -373,6 +382,14 @@ struct Forest {
             l.x = ar.take<double>((size_t)NX * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
             l.parent = ar.take<int32_t>(Ncap); l.meas = ar.take<int32_t>(Ncap); l.cov = ar.take<int32_t>(Ncap);
             l.flags = ar.take<uint8_t>(Ncap); l.P = nullptr;
+        }
+        if (ais) {
+            for (int s = 0; s < R; ++s) { l_mmsi[s] = ar.take<int32_t>(Ncap); l_hmmsi[s] = ar.take<int32_t>(Ncap); }
+            ais_nf = ar.take<int32_t>(Ncap); ais_off = ar.take<int32_t>(Ncap);
+            ais_rec_cap = Ncap; ais_rec = ar.take<AisRec>(ais_rec_cap); ais_count = ar.take<unsigned>(16);
+            ais_msg_cap = Mpad;
+            ais_groups_dev = ar.take<char>((size_t)ais_group_cap * sizeof(mht_ais_group));
+            ais_msgs_dev = ar.take<char>((size_t)ais_msg_cap * sizeof(mht_ais_msg));
         }
         for (int b = 0; b < 2; ++b) {
             path[b] = ar.take<int32_t>((size_t)pds * Ncap);
@@ -490,8 +507,13 @@ static LayerView view_of(const mht_nodes& l) { return LayerView{l.x, l.cnllr, l.
 
 using namespace mht;
 
-extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg) {
+static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg, uint32_t flags) {
     MHT_REQUIRE(ctx && model && cfg, "mht_forest_create: null argument");
+    MHT_REQUIRE((flags & ~(uint32_t)MHT_FOREST_AIS) == 0, "mht_forest_create_ex: unknown flags 0x%x", flags);
+    if (flags & MHT_FOREST_AIS) {
+        MHT_REQUIRE(NX == 4, "mht_forest_create_ex: AIS messages report four states (models/ais.py); this is the %d-state build", NX);
+        MHT_REQUIRE(cfg->n_scan <= 7, "mht_forest_create_ex: an AIS forest keeps two rows per level in a 16-entry path record: n_scan must be <= 7 (got %d)", cfg->n_scan);
+    }
     MHT_REQUIRE(!ctx->forest, "mht_forest_create: the ctx already owns a forest");
     MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 3 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 3);
     MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
@@ -542,6 +564,11 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
     f->pds = f->PD <= 8 ? 8 : 16;
+    if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
+        f->ais = true;
+        f->ais_half = f->PD <= 4 ? 4 : 8;
+        f->pds = 2 * f->ais_half;
+    }
 
     f->used_off = sizeof(ReportHeader);
     f->birth_off = (f->used_off + (size_t)(f->Mpad / 64) * 8 + 15) & ~(size_t)15;
@@ -608,6 +635,50 @@ extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht
     return MHT_OK;
 }
 
+extern "C" int mht_forest_create(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg) { return forest_create_impl(ctx, model, cfg, 0u); }
+extern "C" int mht_forest_create_ex(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg, uint32_t flags) {
+    return forest_create_impl(ctx, model, cfg, flags);
+}
+
+// The AIS messages of the NEXT scan (Tracker.addMeasurementList(scanList, aisList), tracker.py:162): grouped as the reference walks
+// them (include/mht_amd.h: mht_fuse_ais), copied to the device now, consumed -- and disarmed -- by the next step.  nA = 0 disarms.
+extern "C" int mht_forest_set_ais(mht_ctx* ctx, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                                  double lambda_ais) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_set_ais: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->ais, "mht_forest_set_ais: the forest was not created with MHT_FOREST_AIS (mht_forest_create_ex)");
+    if (f->in_groups > 0) { set_error("mht_forest_set_ais: the forest is a member of a group (mht_group_step takes no AIS messages)"); return MHT_E_STATE; }
+    MHT_REQUIRE(nG >= 0 && nA >= 0 && nG <= f->ais_group_cap && nA <= f->ais_msg_cap, "mht_forest_set_ais: %d groups / %d messages exceed the capacity (%d / %d)",
+                nG, nA, f->ais_group_cap, f->ais_msg_cap);
+    if (nA == 0 || nG == 0) { f->ais_armed = false; f->ais_nG = f->ais_nA = 0; return MHT_OK; }
+    MHT_REQUIRE(groups && msgs, "mht_forest_set_ais: null argument");
+    MHT_REQUIRE(lambda_ais > 0.0 && eta2_ais > 0.0, "mht_forest_set_ais: eta2_ais and lambda_ais must be positive (tracker.py:438 needs a finite radarRange)");
+    for (int g = 0; g < nG; ++g)
+        MHT_REQUIRE(groups[g].first >= 0 && groups[g].count >= 0 && groups[g].first + groups[g].count <= nA, "mht_forest_set_ais: group %d outside the message list", g);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    // (pageable sources: the runtime stages them before the call returns, the caller's arrays are free again)
+    MHT_HIP_CHECK(hipMemcpyAsync(f->ais_groups_dev, groups, (size_t)nG * sizeof(mht_ais_group), hipMemcpyHostToDevice, ctx->stream));
+    MHT_HIP_CHECK(hipMemcpyAsync(f->ais_msgs_dev, msgs, (size_t)nA * sizeof(mht_ais_msg), hipMemcpyHostToDevice, ctx->stream));
+    f->ais_armed = true; f->ais_nG = nG; f->ais_nA = nA; f->ais_eta2 = eta2_ais; f->ais_lambda = lambda_ais;
+    return MHT_OK;
+}
+
+// identities of the nodes [first, first + count) of the layer of scan `scan` (the last scan or one of the window before it): mmsi = the AIS
+// message a node was updated with (0: none), hist = the identity its track is bound to (pyTarget.py:297-302).  Synchronous.
+extern "C" int mht_forest_read_mmsi(mht_ctx* ctx, int32_t scan, int32_t first, int32_t count, int32_t* mmsi, int32_t* hist) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_read_mmsi: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->ais, "mht_forest_read_mmsi: the forest was not created with MHT_FOREST_AIS");
+    MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R - 1, "mht_forest_read_mmsi: scan %d is outside the ring (last scan %d)", scan, f->scan);
+    MHT_REQUIRE(first >= 0 && count >= 0 && (long long)first + count <= f->Ncap, "mht_forest_read_mmsi: node range outside the layer");
+    if (count == 0) return MHT_OK;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (mmsi) MHT_HIP_CHECK(hipMemcpyAsync(mmsi, f->l_mmsi[scan % f->R] + first, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hist) MHT_HIP_CHECK(hipMemcpyAsync(hist, f->l_hmmsi[scan % f->R] + first, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHT_OK;
+}
+
 extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
                                           const double* pd, const int32_t* meas, int32_t check_neighbours,
                                           uint8_t* accepted, int32_t* ids) {
@@ -627,6 +698,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
     fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
+    if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
@@ -715,6 +787,10 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
     g.used_bytes = f->used_bytes[s & 1];
     g.status = f->status2 + (s & 1); g.prev_status = f->status2 + ((s - 1) & 1); g.sticky_overflow = &f->cnt->overflow;
+    if (f->ais) {
+        g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
+        g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
+    }
 }
 
 static void fill_cluster(const Forest* f, int s, ClusterArgs& c) {
@@ -738,7 +814,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
     b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state; b.team_res = f->team_res; b.team_prob = f->team_prob;
     b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
-    b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->PD; b.pds = f->pds;
+    b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->ais ? f->pds : f->PD; b.pds = f->pds;      // (AIS forest: every entry of a record can be a row)
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
     b.bb_snap = f->bb_snap; b.bb_busy = f->bb_busy; b.bb_snap_rows = f->bb_snap_rows;
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
@@ -775,6 +851,7 @@ static void fill_similar(const Forest* f, int s, SimilarArgs& a) {
     fill_model_only(a.model, &f->model);
     a.thr = f->prune_thr;
     a.status = f->status2 + (s & 1);
+    a.mmsi = f->ais ? f->l_mmsi[s % f->R] : nullptr;
 }
 
 // N-scan prune (tracker.py:256-259), target side: surviving leaf ranges -> target table / roots / report, for scan s
@@ -909,8 +986,16 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
     Forest* f = ctx->forest;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool ais = f->ais && f->ais_armed;
+    if (ais) {      // the fused children are made from the leaves of the COMMITTED table, in front of the grow launch
+        MHT_REQUIRE(M + f->ais_nA <= f->Mpad, "mht_forest_step: %d radar measurements + %d AIS messages exceed max_meas=%d (rounded up to %d measurement nodes per scan)",
+                    M, f->ais_nA, f->cfg.max_meas, f->Mpad);
+        const int rc = flush_commit(ctx, f);
+        if (rc) return rc;
+    }
     StepPlan pl;
     { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl); if (rc) return rc; }
+    if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
     hipStream_t st = ctx->stream;
     hipEvent_t* ev = nullptr;
     if (f->timing) {
@@ -922,12 +1007,29 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
 #define MHT_STEP_CHECK(expr) do { const int rc_ = (expr); if (rc_) { f->dead = true; return rc_; } } while (0)
 #define MHT_STEP_HIP(expr) do { if ((expr) != hipSuccess) { f->dead = true; set_error("mht_forest_step: %s failed", #expr); return MHT_E_HIP; } } while (0)
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[0], st));
+    // ---- 0: AIS-aided children of every leaf (tracker.py:394-396, :417-552), only on scans that carry messages ----------------
+    if (ais) {
+        AisForestArgs aa = {};
+        const mht_nodes& in = f->layer[(pl.s - 1) % f->R];
+        fill_model_only(aa.model, &f->model);
+        aa.nT_dev = &f->cnt->nT; aa.t_first = f->tab[pl.s & 1].first; aa.t_leaf_off = f->tab[pl.s & 1].leaf_off;
+        aa.x = in.x; aa.pd = in.pd; aa.cov = in.cov; aa.flags = in.flags; aa.hmmsi = f->l_hmmsi[(pl.s - 1) % f->R]; aa.cap = f->Ncap;
+        aa.vt = f->vt;
+        aa.groups = reinterpret_cast<const AisGroup*>(f->ais_groups_dev); aa.nG = f->ais_nG; aa.msgs = reinterpret_cast<const AisMsg*>(f->ais_msgs_dev);
+        aa.eta2_ais = f->ais_eta2; aa.lambda_ais = f->ais_lambda; aa.z = z; aa.M = M;
+        aa.nf = f->ais_nf; aa.off = f->ais_off; aa.rec = f->ais_rec; aa.rec_cap = f->ais_rec_cap; aa.rec_count = f->ais_count;
+        aa.status = f->status2 + (pl.s & 1);
+        MHT_STEP_HIP(hipMemsetAsync(f->ais_count, 0, sizeof(unsigned), st));
+        MHT_STEP_CHECK(launch_forest_ais(ctx, aa, pl.n_ub));
+        f->ais_armed = false;
+    }
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
         FGrowArgs g;
         fill_fgrow(f, pl.s, pl.fused, g);
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.ais_on = ais ? 1 : 0;
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr));
@@ -994,6 +1096,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     StepPlan pl;
+    if (f->ais_armed) { set_error("mht_forest_step_sharded_begin: the cluster-sharded step takes no AIS messages (mht_forest_set_ais armed some)"); return MHT_E_STATE; }
     { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) return rc; }
     int rc;
     {
@@ -1271,6 +1374,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
     fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
+    if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     a.hdr = reinterpret_cast<ReportHeader*>(report_dev);
     a.births = reinterpret_cast<mht_birth_report*>(report_dev + f->birth_off);
     // commit (if it is still pending: the used-measurement mask of the scan is part of it) + initiator + admission: one launch

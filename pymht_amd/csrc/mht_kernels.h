@@ -33,6 +33,28 @@ struct CommitArgs;
 struct FDyn;
 struct FBatch;
 
+// AIS-aided children in the forest (tracker.py:417-552; mht_ais.hip).  A forest made with MHT_FOREST_AIS keeps two more words per
+// node -- the identity of the AIS message the node was updated with (mmsi, 0 = none) and the identity its track is bound to (hmmsi:
+// its own or its nearest AIS-updated ancestor's, pyTarget.py:297-302) -- and splits a path record in two halves: entries
+// [0, half) are the radar measurement nodes per level, [half, 2 half) the AIS message nodes (a fused child has both at its level;
+// to the ILP they are all rows, tracker.py:1046-1090).  On a scan with messages forest_ais_kernel runs in front of the grow launch
+// and leaves, per leaf of the newest layer, the number of its fused children and where their records start; the grow kernel appends
+// them behind the leaf's radar children (pyTarget.py:260-295).
+struct AisRec {
+    double x[4];        // state (float64: ais.C is float64)
+    double nllr;        // score increment (nllr_ais + nllr_radar) / 2, or nllr_ais alone
+    int32_t radar;      // 0-based radar measurement or -1
+    int32_t msg;        // index of the message in the scan's (grouped) list: its measurement node is M + msg
+    int32_t key;        // covariance key in the value table (a pseudo parent's miss child, like a root's)
+    int32_t mmsi;
+};
+struct AisGrow {
+    const int32_t* nf; const int32_t* off; const AisRec* rec;      // [cap] by node of the input layer; record pool
+    const int32_t* hmmsi_in;                                       // input layer
+    int32_t* ommsi; int32_t* ohmmsi;                               // output layer
+    int half;                                                      // levels per half of a path record (0: not an AIS forest)
+};
+
 // fgrow_kernel (mht_fgrow.hip): the grow stage of the forest, one workgroup per target + covariance-chain workgroups
 struct FGrowArgs {
     Model model;
@@ -63,6 +85,7 @@ struct FGrowArgs {
     unsigned char* used_bytes;
     DevStatus* status;             // this scan's status word: n_children is accumulated here
     const DevStatus* prev_status; const int32_t* sticky_overflow;
+    AisGrow ais;                   // (fgrow_kernel<..., AIS = 1> only)
 };
 // What changes from scan to scan (everything in FGrowArgs repeats with period 2 x ring length, for fused = 0 and 1): passed by
 // value next to the argument block (one launch per sector) or to a pointer to it (one launch for a group of sectors).
@@ -73,6 +96,7 @@ struct FDyn {
     int n_tgt, n_chain;            // target slots covered; covariance-chain workgroups (two targets each)
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
+    int ais_on;                    // AIS forest: this scan carries messages (AisGrow::nf / off / rec are valid)
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
 };
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.
@@ -199,8 +223,23 @@ struct SimilarArgs {
     VTab vt; Model model;
     float thr;                                              // Tracker.pruneThreshold (tracker.py:117), compared in float32
     const DevStatus* status;
+    const int32_t* mmsi;                                    // AIS forest: children updated with an AIS message are not merged (pyTarget.py:371-375), else null
 };
 
+// forest_ais_kernel (mht_ais.hip): the fused children of every leaf of the newest layer, in front of the grow launch of a scan with AIS messages
+struct AisGroup; struct AisMsg;
+struct AisForestArgs {
+    Model model;
+    const int32_t* nT_dev; const int32_t* t_first; const int32_t* t_leaf_off;      // the committed target table
+    const double* x; const double* pd; const int32_t* cov; const uint8_t* flags; const int32_t* hmmsi; int cap;      // newest layer
+    VTab vt;
+    const AisGroup* groups; int nG; const AisMsg* msgs;
+    double eta2_ais, lambda_ais;
+    const float* z; int M;
+    int32_t* nf; int32_t* off; AisRec* rec; int rec_cap; unsigned* rec_count;      // rec_count: zero at launch
+    DevStatus* status;
+};
+int launch_forest_ais(mht_ctx* ctx, const AisForestArgs& a, int n_targets_ub);
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr);

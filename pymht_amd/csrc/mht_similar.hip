@@ -43,6 +43,7 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
     bool score_f32 = false;
     Sum1D<double> sd; Sum1D<float> sf;
     for (int g = h + 1; g < ce && a.meas[g] > 0; ++g) {
+        if (a.mmsi && a.mmsi[g] != 0) break;      // (fused children come behind the radar children and are never merged)
         if (!is_near(a, g, p0x, p0y)) continue;
         const uint8_t fg = a.flags[g];
         float P[NP];
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(256) void prune_similar_kernel(const SimilarArgs a)
         const int cb = a.tchild[t], ce = a.tcend[t];
         for (int h = cb + lane; h < ce; h += 64) {
             if (a.meas[h] != 0) continue;              // (a node's children start with its missed-detection child)
+            if (a.mmsi && a.mmsi[h] != 0) continue;    // (a child with an AIS message and no radar measurement is not one)
             const float p0x = (float)a.x[h], p0y = (float)a.x[(size_t)a.cap + h];
             int n = 0;
-            for (int g = h + 1; g < ce && a.meas[g] > 0; ++g) n += is_near(a, g, p0x, p0y) ? 1 : 0;
+            for (int g = h + 1; g < ce && a.meas[g] > 0 && !(a.mmsi && a.mmsi[g] != 0); ++g) n += is_near(a, g, p0x, p0y) ? 1 : 0;
             if (n == 0) continue;
             if (a.flags[h] & F_STATE_F32) fuse_group<float>(a, t, h, ce, n, p0x, p0y);
             else fuse_group<double>(a, t, h, ce, n, p0x, p0y);

@@ -74,7 +74,7 @@ class Target:
         self.status = kwargs.get("status", activeTag)
         assert 0 <= self.P_d <= 1
         assert self._parent is None or isinstance(self._parent, Target)
-        assert self.mmsi is None, "AIS-fused hypotheses are out of scope of pymht_amd"
+        assert (self.mmsi is None) or (self.mmsi > 1e8)      # pyTarget.py:40
 
     # ---- tree links (lazy for device-backed views) ------------------------------------------
     @property

@@ -127,7 +127,20 @@ class Tracker():
         cfg.radar_range = float(self.radarRange)
         cfg.merge_threshold = float(self.mergeThreshold)
         self._cfg = cfg
-        _lib.check(self._lib.mht_forest_create(self._ctx.handle, C.byref(self._model), C.byref(cfg)))
+        # AIS-aided tracking (tracker.py:394-396, :417-552): the forest has to be made for it (identities per node, AIS rows in the ILP);
+        # `aisAided=True` is the switch -- the reference decides per call by looking at its aisList, a device forest cannot
+        self._ais = bool(kwargs.get('aisAided', False))
+        self._model_mod = model
+        self.P_ais = 0.5                                    # tracker.py:109
+        self._leaf_time = None                              # time of the current leaves (the last scan's, or the initial targets')
+        if self._ais:
+            if self.nx != 4:
+                raise NotImplementedError("AIS messages report four states (models/ais.py): aisAided needs a 4-state model")
+            if int(N) > 7:
+                raise NotImplementedError("aisAided: N-scan window of at most 7")
+            _lib.check(self._lib.mht_forest_create_ex(self._ctx.handle, C.byref(self._model), C.byref(cfg), 1))      # MHT_FOREST_AIS
+        else:
+            _lib.check(self._lib.mht_forest_create(self._ctx.handle, C.byref(self._model), C.byref(cfg)))
         if self._blp_time_limit is not None:
             _lib.check(self._lib.mht_forest_set_blp_time_limit(self._ctx.handle, 1e3 * float(self._blp_time_limit)))
         # Target initiator (tracker.py:61-72): on the device, behind every scan's commit (mht_forest_initiate)
@@ -192,6 +205,8 @@ class Tracker():
         for t, i in zip(out, ids[ok]):
             self._birth[int(i)] = (t.time, scan, t.x_0, t.P_0, t.measurementNumber, t.measurement, t.status)
             t.ID = int(i)
+        if scan == 0 and self._leaf_time is None:
+            self._leaf_time = float(out[0].time)
         self.trackIdCounter = int(ids[ok].max()) + 1
         self._views.clear()
         return out
@@ -208,6 +223,8 @@ class Tracker():
         z = self._accept_scan(scanList, aisList, kwargs)
         tic['_print'] = {k: v for k, v in kwargs.items() if k in ("printTime", "printCluster", "printInfo", "on_color") and v}
         self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
+        if aisList is not None and len(aisList) > 0:
+            self._arm_ais(scanList, aisList, z.shape[0])
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
         try:
@@ -219,7 +236,29 @@ class Tracker():
                 self._dead = True
             raise
         tic['_call'] = time.perf_counter() - tic['_call']      # host time of this call up to here (the scan is queued; nothing waited)
+        self._leaf_time = float(scanList.time)
         self._queue_report(scanList, z, aisList, tic)
+
+    def _arm_ais(self, scanList, aisList, nRadarMeas):
+        """The AIS messages of this scan, handed to the device in the order the reference walks them (pymht_amd/ais.py).  Needs the
+        folded state of the scan before (lambda_ais counts the targets, tracker.py:438), so a scan with messages does not overlap
+        with its predecessor's report."""
+        from .ais import group_messages
+        self._drain()
+        scanTime = float(scanList.time)
+        assert all(float(m.time) < scanTime for m in aisList)                                   # tracker.py:180-182
+        assert all(float(m.time) > scanTime - self.radarPeriod for m in aisList), str(scanTime) + str([m.time for m in aisList])
+        mmsi = [m.mmsi for m in aisList]
+        assert len(mmsi) == len(set(mmsi)), "Duplicate MMSI in aisList"                          # tracker.py:183-185
+        if not np.isfinite(self.radarRange):
+            raise ValueError("AIS-aided tracking needs a finite radarRange (lambda_ais = nTargets * P_ais / (pi * radarRange^2), tracker.py:438; "
+                             "with the default inf the reference itself fails in kalman.nllr)")
+        nT = len(self._tbl_)
+        if nT == 0 or self._leaf_time is None:
+            return                                                                               # (no leaves: nothing to fuse)
+        lambda_ais = (nT * self.P_ais) / (np.pi * self.radarRange ** 2)
+        groups, nG, msgs, order = group_messages(aisList, self._leaf_time, scanTime, self._model_mod)
+        _lib.check(self._lib.mht_forest_set_ais(self._ctx.handle, C.byref(groups), nG, C.byref(msgs), len(order), float(self.eta2_ais), float(lambda_ais)))
 
     def _set_prune_similar(self, want):
         if want != self._prune_similar_on:
@@ -256,7 +295,11 @@ class Tracker():
         if self._dead:
             raise RuntimeError("this Tracker's device forest is dead (an earlier scan failed); create a new Tracker")
         if aisList is not None and len(aisList) > 0:
-            raise NotImplementedError("AIS fusion (tracker.py:417-552) is outside the MI355X hot path")
+            if not self._ais:
+                raise NotImplementedError("this Tracker was not made for AIS messages: pass aisAided=True to the constructor (tracker.py:417-552)")
+            if kwargs.get('aisInitialization', True):
+                raise NotImplementedError("tracks started from AIS messages (m_of_n.py:262-280) are not built: pass aisInitialization=False "
+                                          "(tracker.py:271-272)")
         if kwargs.get('dynamicWindow', False):
             raise NotImplementedError("dynamicWindow is not supported by pymht_amd")
         m = np.asarray(scanList.measurements)
@@ -443,10 +486,26 @@ class Tracker():
         return self._tbl_
 
     # ---- lazily built views (the reference's attributes, tracker.py:74-84) -----------------------------------------
+    def _mmsi_layer(self, scanNumber):
+        """AIS forest: (mmsi, bound identity) of every node of a layer of the window, read once per scan and cached with the views."""
+        key = ("_mmsi", scanNumber)
+        v = self._views.get(key)
+        if v is None:
+            n = int(self._cfg.max_nodes)
+            mm, hist = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+            _lib.check(self._lib.mht_forest_read_mmsi(self._ctx.handle, int(scanNumber), 0, n, mm.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p)))
+            v = self._views[key] = (mm, hist)
+        return v
+
     def _node_view(self, r, scanTime, scanNumber, z):
         m = int(r["sel_meas"])
+        mmsi = None
+        if self._ais and int(r["sel_node"]) >= 0 and scanNumber == len(self.__scanHistory__):
+            mm = int(self._mmsi_layer(scanNumber)[0][int(r["sel_node"])])
+            if mm:
+                mmsi, m = mm, (m if m > 0 else None)      # (an AIS-updated node without a radar measurement: measurementNumber None, tracker.py:520)
         node = DeviceTarget(scanTime, scanNumber, np.array(r["sel_x"]), self.P_0, ID=int(r["id"]), P_d=self.default_P_d,
-                            measurementNumber=m, measurement=(z[m - 1] if m > 0 else None),
+                            measurementNumber=m, measurement=(z[m - 1] if m else None), mmsi=mmsi,
                             cumulativeNLLR=float(r["sel_cnllr"]), status=_STATUS_TAG[int(r["status"])])
         node._tracker, node._node = self, int(r["sel_node"])
         node._lazy_parent = self._make_parent_loader(int(r["id"]))
@@ -639,8 +698,13 @@ class Tracker():
         if n.value > cap and cap < self._cfg.max_nodes:
             return None      # (more leaves than the estimate -- the export is truncated to the capacity: the caller retries with the full one)
         k = min(n.value, cap)
-        return dict(x=x[:k], P=P[:k].reshape(k, self.nx, self.nx), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
-                    node=node[:k], flags=fl[:k])
+        out = dict(x=x[:k], P=P[:k].reshape(k, self.nx, self.nx), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
+                   node=node[:k], flags=fl[:k])
+        if self._ais:      # identities; a node with one and no radar measurement gets meas = -1 (measurementNumber None)
+            scan = len(self.__scanHistory__)
+            out["mmsi"] = self._mmsi_layer(scan)[0][out["node"]].astype(np.int64) if scan > 0 else np.zeros(k, dtype=np.int64)
+            out["meas"] = np.where((out["meas"] == 0) & (out["mmsi"] != 0), -1, out["meas"]).astype(np.int32)
+        return out
 
     def leafBatch(self):
         """All current leaves in target-list / DFS order (what the next scan will gate): dict of arrays."""
@@ -655,8 +719,11 @@ class Tracker():
             if int(snap["node"][i]) == root._node and root.scanNumber == scan:
                 out.append(root)
                 continue
+            m, mmsi = int(snap["meas"][i]), None
+            if self._ais and int(snap["mmsi"][i]):
+                mmsi, m = int(snap["mmsi"][i]), (m if m > 0 else None)
             v = DeviceTarget(t, scan, snap["x"][i].copy(), snap["P"][i].copy(), ID=root.ID, P_d=self.default_P_d,
-                             measurementNumber=int(snap["meas"][i]), cumulativeNLLR=float(snap["cnllr"][i]))
+                             measurementNumber=m, mmsi=mmsi, cumulativeNLLR=float(snap["cnllr"][i]))
             v._tracker, v._node = self, int(snap["node"][i])
             v._lazy_parent = self._make_parent_loader(root.ID)
             out.append(v)

@@ -31,9 +31,5 @@ class MeasurementList:
         return self.measurements
 
 
-class AisMessageList(list):
-    """AIS fusion is out of scope for the MI355X path (SURVEY.md section 2 #1d); the type exists because
-    it is the default argument of `addMeasurementList`.  A non-empty list is rejected there."""
-
-    def filterUnused(self, usedMmsiSet):
-        return [m for m in self if getattr(m, "mmsi", None) not in usedMmsiSet]
+from ..ais import AisMessage, AisMessageList      # noqa: E402,F401  (classDefinitions.py:428-434, :597-622)
+AIS_message = AisMessage                            # (the reference's name)

@@ -54,3 +54,72 @@ def test_fuse_seam_edge_cases(gpu_ctx):
     # a message on top of the leaf, no radar measurement at all: one pure-AIS child
     r = fuse_radar_and_ais(gpu_ctx, pv, 5.99, 1e-4, x, P, [0.9], [0], [0], [AisMessage(1.0, [11.0, 19.0, 1.0, -1.0], 257000001, True)], 0.0, 2.5, 9.45, 1e-7, z)
     assert list(r["child_ptr"]) == [0, 1] and list(r["radar"]) == [-1] and list(r["mmsi"]) == [257000001]
+
+
+# ---- the AIS-aided path through the forest and the drop-in Tracker ---------------------------------------------------------------
+# Decisions -- which children exist, in which order, with which radar measurement and which identity; clusters; selections; target
+# lists; births and terminations -- are compared exactly.  Values are compared to the north star's tolerance: the reference keeps
+# the covariances of AIS-updated nodes (and, through NumPy's promotion of a mixed batch, of their whole target from then on) in
+# float64, the forest stores every covariance as float32 (csrc/mht_ais_math.h) -- a 1e-8 relative difference in the gains.
+X_REL = 1e-6          # states, relative to the largest component of the state vector (BASELINE.json north_star)
+P_RTOL = 1e-5         # covariances, relative to the largest entry of the matrix: float32 chains here against the reference's float64 ones
+SCORE_ATOL = 2e-5     # cumulative scores (NLLR constant: float32 log, see test_tracker_gpu.py)
+
+
+def _close_states(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1, 4), np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    if a.shape != b.shape:
+        return False
+    scale = np.maximum(np.abs(b).max(axis=1, keepdims=True), 1.0) if len(b) else 1.0
+    return bool(np.all(np.abs(a - b) <= X_REL * scale))
+
+
+@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense"])
+def test_tracker_replays_reference_ais_trace(name, gold_dir):
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    trk = Tracker(pv, float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]), N=int(g["N"]), eta2=float(g["eta2"]),
+                  eta2_ais=float(g["eta2_ais"]), radarRange=float(g["radar_range"]), position=g["position"], aisAided=True,
+                  useInitiator=bool(g["with_initiator"]), maxTargets=256, maxNodes=1 << 16, maxMeasurements=256)
+    try:
+        for x, ok in zip(g["x0"], g["accepted"]):
+            n0 = trk.nTargets
+            trk.initiateTarget(Target(float(g["t0"]), None, x.copy(), pv.P0, status="preinitialized"))
+            assert (trk.nTargets > n0) == bool(ok)
+        n_fused = n_pure = 0
+        for k in range(int(g["n_scans"])):
+            p = "s%02d_" % k
+            msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
+                                   zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
+            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=False)
+            nodes = list(trk.getTrackNodes())
+            assert np.array_equal([n.ID for n in nodes], g[p + "sel_ID"]), k
+            assert np.array_equal([r.ID for r in trk.__targetList__], g[p + "ids"]), k
+            meas = np.array([-1 if n.measurementNumber is None else n.measurementNumber for n in nodes], dtype=np.int64)
+            mmsi = np.array([0 if n.mmsi is None else n.mmsi for n in nodes], dtype=np.int64)
+            assert np.array_equal(meas, g[p + "sel_meas"]) and np.array_equal(mmsi, g[p + "sel_mmsi"]), (k, meas, g[p + "sel_meas"], mmsi, g[p + "sel_mmsi"])
+            assert _close_states([n.x_0 for n in nodes], g[p + "sel_x"]), k
+            assert np.allclose([float(n.cumulativeNLLR) for n in nodes], g[p + "sel_cnllr"], rtol=0, atol=SCORE_ATOL), k
+            st = trk.lastScanStats
+            assert st["L"] == int(g[p + "LGM"][0]) and np.array_equal(st["unused"], g[p + "unused"]), k
+            ptr, mem = g[p + "cl_ptr"], g[p + "cl_members"]
+            cl = trk.__clusterList__
+            assert len(cl) == len(ptr) - 1 and all(np.array_equal(np.asarray(c), mem[ptr[i]:ptr[i + 1]]) for i, c in enumerate(cl)), k
+            lb = trk.leafBatch()
+            assert np.array_equal(lb["ID"], g[p + "leaf_ID"]) and np.array_equal(lb["meas"], g[p + "leaf_meas"]), k
+            assert np.array_equal(lb["mmsi"], g[p + "leaf_mmsi"]), k
+            assert _close_states(lb["x"], g[p + "leaf_x"]), k
+            Pref = g[p + "leaf_P"]
+            pscale = np.abs(Pref).reshape(len(Pref), -1).max(axis=1).reshape(-1, 1, 1) if len(Pref) else 1.0
+            perr = np.abs(lb["P"] - Pref) / pscale
+            assert perr.max(initial=0.0) <= P_RTOL, (k, float(perr.max()))      # (relative to the largest entry of each covariance)
+            assert np.allclose(lb["cnllr"], g[p + "leaf_cnllr"], rtol=0, atol=SCORE_ATOL), k
+            n_fused += int((lb["mmsi"] != 0).sum())
+            n_pure += int((lb["meas"] < 0).sum())
+        assert n_fused > 50          # (the trace does exercise fused children)
+    finally:
+        trk.close()
