@@ -385,7 +385,7 @@ def main():
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
 
 
-def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=True):
+def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=True, prune_similar=False):
     """G18: reference and oracle side by side on a scenario WITH AIS traffic (Tracker.addMeasurementList(scan, aisList,
     aisInitialization=False): tracker.py:162-307 with the fusion of :417-552); every scan compared bitwise; fixture = the scans,
     the messages and what came out.  The tracker needs a finite radarRange here (tracker.py:438 divides by its square; with the
@@ -414,7 +414,8 @@ def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=Tr
     K = len(sc["scans"]) if n_scans is None else n_scans
     fx = dict(x0=sc["x0"], accepted=np.array(accepted), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"], lambda_phi=sc["lambda_phi"],
               lambda_nu=LAMBDA_NU, N=sc["N"], eta2=5.99, eta2_ais=trk.eta2_ais, times=sc["times"][:K], n_scans=K,
-              radar_range=float(sc["radius"]), position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=bool(with_initiator))
+              radar_range=float(sc["radius"]), position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=bool(with_initiator),
+              prune_similar=bool(prune_similar))
 
     def leaf_rows(roots, leaves_of, get):
         rows = [l for r in roots for l in leaves_of(r)]
@@ -433,8 +434,9 @@ def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=Tr
         msgs = ais_scans[k]
         ids_before = [r.ID for r in trk.__targetList__]
         trk.addMeasurementList(ML_of(mods)(t, z), cd.AisMessageList([cd.AIS_message(time=m[0], state=m[1].copy(), mmsi=m[2], highAccuracy=m[3]) for m in msgs]),
-                               aisInitialization=False, checkIntegrity=True)
-        info = o.add_scan(t, z, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs])
+                               aisInitialization=False, checkIntegrity=True, pruneSimilar=prune_similar)
+        info = o.add_scan(t, z, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs], prune_similar=prune_similar,
+                          prune_threshold=trk.pruneThreshold)
         rb = leaf_rows(trk.__targetList__, lambda r: r.getLeafNodes(), lambda l, f: getattr(l, ref_names[f]))
         ob = leaf_rows(o.targets, lambda r: r.leaves(), lambda l, f: getattr(l, f))
         for key in rb:
@@ -490,6 +492,12 @@ def gen_g18(mods):
     run_trace_ais(mods, sc, make_ais(sc, seed=3, equipped=1.0, p_report=0.8), "g18_trace_ais_cfg1")
     sc = make_config("dense", seed=1234)
     run_trace_ais(mods, sc, make_ais(sc, seed=77), "g18b_trace_ais_dense")
+    # a window of 5 scans (16-entry path records: radar rows + AIS rows; the ILPs on the HBM policy), a wider scene so that fewer tracks leave it
+    sc = make_config("dense", seed=4321, N=5, n_scans=10, radius=700.0, T=24)
+    run_trace_ais(mods, sc, make_ais(sc, seed=5, equipped=0.6), "g18c_trace_ais_n5")
+    # similar-state pruning on every scan (pyTarget.py:371-375: AIS-updated children are never merged)
+    sc = make_config("dense", seed=99, n_scans=10, radius=600.0)
+    run_trace_ais(mods, sc, make_ais(sc, seed=8, equipped=0.5), "g18d_trace_ais_similar", prune_similar=True)
 
 
 def gen_g19(mods):

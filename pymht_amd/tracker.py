@@ -46,6 +46,13 @@ class DeviceTarget(Target):
     """A `Target` that mirrors one node of the device forest (`scanNumber`, `_node` locate it)."""
     _tracker = None
     _node = -1
+    _hist_mmsi = None      # AIS forest: the identity the node's track is bound to, as the device keeps it per node
+
+    def _getHistoricalMmsi(self):
+        """pyTarget.py:297-302; the device carries the answer with every node (own identity, else the nearest AIS-updated ancestor's)."""
+        if self._hist_mmsi is not None:
+            return self._hist_mmsi
+        return Target._getHistoricalMmsi(self)
 
     def getLeafNodes(self):
         if self._children is None and self.isRoot and self._tracker is not None:
@@ -499,15 +506,16 @@ class Tracker():
 
     def _node_view(self, r, scanTime, scanNumber, z):
         m = int(r["sel_meas"])
-        mmsi = None
+        mmsi = hist = None
         if self._ais and int(r["sel_node"]) >= 0 and scanNumber == len(self.__scanHistory__):
-            mm = int(self._mmsi_layer(scanNumber)[0][int(r["sel_node"])])
+            layer = self._mmsi_layer(scanNumber)
+            mm, hist = int(layer[0][int(r["sel_node"])]), (int(layer[1][int(r["sel_node"])]) or None)
             if mm:
                 mmsi, m = mm, (m if m > 0 else None)      # (an AIS-updated node without a radar measurement: measurementNumber None, tracker.py:520)
         node = DeviceTarget(scanTime, scanNumber, np.array(r["sel_x"]), self.P_0, ID=int(r["id"]), P_d=self.default_P_d,
                             measurementNumber=m, measurement=(z[m - 1] if m else None), mmsi=mmsi,
                             cumulativeNLLR=float(r["sel_cnllr"]), status=_STATUS_TAG[int(r["status"])])
-        node._tracker, node._node = self, int(r["sel_node"])
+        node._tracker, node._node, node._hist_mmsi = self, int(r["sel_node"]), hist
         node._lazy_parent = self._make_parent_loader(int(r["id"]))
         return node
 

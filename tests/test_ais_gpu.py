@@ -62,7 +62,8 @@ def test_fuse_seam_edge_cases(gpu_ctx):
 # the covariances of AIS-updated nodes (and, through NumPy's promotion of a mixed batch, of their whole target from then on) in
 # float64, the forest stores every covariance as float32 (csrc/mht_ais_math.h) -- a 1e-8 relative difference in the gains.
 X_REL = 1e-6          # states, relative to the largest component of the state vector (BASELINE.json north_star)
-P_RTOL = 1e-5         # covariances, relative to the largest entry of the matrix: float32 chains here against the reference's float64 ones
+P_RTOL = 5e-5         # covariances, relative to the largest entry of the matrix: float32 chains here against the reference's float64 ones
+                      # (NumPy's own float32 recursion drifts 1.2e-5 from its float64 one over six scans of this model)
 SCORE_ATOL = 2e-5     # cumulative scores (NLLR constant: float32 log, see test_tracker_gpu.py)
 
 
@@ -74,7 +75,7 @@ def _close_states(a, b):
     return bool(np.all(np.abs(a - b) <= X_REL * scale))
 
 
-@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense"])
+@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense", "g18c_trace_ais_n5", "g18d_trace_ais_similar"])
 def test_tracker_replays_reference_ais_trace(name, gold_dir):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
@@ -95,7 +96,7 @@ def test_tracker_replays_reference_ais_trace(name, gold_dir):
             p = "s%02d_" % k
             msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
                                    zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
-            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=False)
+            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=False, pruneSimilar=bool(g["prune_similar"]))
             nodes = list(trk.getTrackNodes())
             assert np.array_equal([n.ID for n in nodes], g[p + "sel_ID"]), k
             assert np.array_equal([r.ID for r in trk.__targetList__], g[p + "ids"]), k

@@ -152,7 +152,7 @@ def replay_oracle_ais(path):
     o = make_oracle_ais(g)
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
-        info = o.add_scan(float(g["times"][k]), g[p + "z"], ais=ais_messages(g, k))
+        info = o.add_scan(float(g["times"][k]), g[p + "z"], ais=ais_messages(g, k), prune_similar=bool(g["prune_similar"]))
         leaves = oracle_rows([l for r in o.targets for l in r.leaves()])
         sel = oracle_rows(o.track_nodes)
         for key, v in leaves.items():
