@@ -1,4 +1,4 @@
-"""`Tracker`: drop-in for `pymht.tracker.Tracker` on the radar-only path, running on one MI355X.
+"""`Tracker`: drop-in for `pymht.tracker.Tracker`, running on one MI355X.
 
 Same constructor, `preInitialize`, `initiateTarget`, `addMeasurementList(scanList, aisList=AisMessageList(), **kw)`,
 `getTrackNodes`, `getRuntimeAverage`, `runtimeLog`/`toc` keys and double-underscore attributes as the reference
@@ -7,7 +7,9 @@ prune) run as three HIP launches (+ one for the report) on the device-resident h
 the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
 
 XML result export: `getScenarioElement` / `_storeTrackerArgs` / `_storeRun` (tracker.py:1469-1545).
-Not supported (raise): AIS fusion (`aisList` non-empty; tracker.py:417-552), `dynamicWindow`.
+AIS-aided tracking (tracker.py:394-396, :417-552): construct with `aisAided=True` (and a finite `radarRange`), then
+`addMeasurementList(scan, aisList, aisInitialization=False)`.  Not supported (raise): tracks started from AIS messages
+(`aisInitialization=True`, m_of_n.py:262-280), `dynamicWindow`.
 There is no CPU fallback: without the HIP library or without a GPU the constructor raises.
 """
 import ctypes as C
