@@ -63,3 +63,85 @@ def run_case(seed, max_leaves=2000, budget_s=15.0, similar=False):
         return True, desc, msg + ' L=%d ilp=%d %.1fs' % (st["L"], o.n_ilp, time.time() - t0)
     finally:
         trk.close()
+
+
+# AIS-aided scenarios: the reference carries the covariances of a target that has met an AIS message in float64, the forest in float32
+# ("AIS-aided children"): gains differ by ~1e-5 relative, states by ~1e-5 m where innovations are metres.  That
+# is 1e-6 of a coordinate of tens of metres and above; the fuzz scenes are centred on the origin, so an absolute floor is needed.
+AIS_X_REL, AIS_X_ATOL, AIS_SCORE_ATOL = 1e-6, 1e-4, 1e-4
+
+
+def ais_states_close(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1, 4), np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    if a.shape != b.shape:
+        return False
+    if a.size == 0:
+        return True
+    scale = np.abs(a).max(axis=1, keepdims=True)
+    return bool(np.all(np.abs(a - b) <= AIS_X_REL * scale + AIS_X_ATOL))
+
+
+def run_case_ais(seed, max_leaves=2500, budget_s=20.0):
+    """AIS-aided variant (Tracker(aisAided=True), addMeasurementList(scan, aisList, aisInitialization=False); tracker.py:417-552): random
+    scenario with N <= 7 and a finite radar range, random AIS traffic (share of equipped targets, report probability), similar-state
+    pruning on some scans.  Decisions exact; states to 1e-6 relative + 1e-4 m (the covariances of AIS-updated targets are float64 in the
+    reference, float32 in the forest: never bit for bit, see AIS_X_ATOL)."""
+    from test_tracker_gpu import states_close, SCORE_ATOL
+    from trace_util import make_oracle_ais
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_ais
+    import mht_oracle as orc
+    sc, N, eta2, desc = scenario_of(seed)
+    N = min(N, 7)
+    prng = np.random.default_rng(seed + 1234)
+    equipped, p_report = float(prng.choice([0.3, 0.6, 1.0])), float(prng.choice([0.4, 0.8]))
+    ais = make_ais(sc, seed=seed + 5, equipped=equipped, p_report=p_report)
+    rr = 1.5 * sc["radius"]
+    desc += ' AIS equipped=%.1f p=%.1f N=%d' % (equipped, p_report, N)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, eta2_ais=9.45, x0=sc["x0"], t0=sc["t0"],
+             radar_range=rr, position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=True, accepted=None)
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2, radarRange=rr, position=g["position"], aisAided=True,
+                  maxTargets=512, maxNodes=1 << 19, maxMeasurements=512)
+    t0 = time.time()
+    try:
+        acc = []
+        for x in sc["x0"]:
+            n0 = trk.nTargets
+            trk.initiateTarget(Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized"))
+            acc.append(trk.nTargets > n0)
+        g["accepted"] = acc
+        o = make_oracle_ais(g)
+        st, msg, nf = {"L": 0}, '', 0
+        for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+            if time.time() - t0 > budget_s or (k > 0 and st["L"] > max_leaves):
+                msg = 'stopped after scan %d' % k
+                break
+            on = bool(prng.uniform() < 0.3)
+            msgs = ais[k] if prng.uniform() < 0.85 else []
+            info = o.add_scan(float(t), z, prune_similar=on, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs])
+            trk.addMeasurementList(MeasurementList(float(t), z), AisMessageList([AisMessage(*m) for m in msgs]), aisInitialization=False, pruneSimilar=on)
+            st = trk.lastScanStats
+            nodes = list(trk.getTrackNodes())
+            lb, tb = o.leaf_batch(), trk.leafBatch()
+            os_ = o.selected()
+            t_mmsi = np.array([0 if n.mmsi is None else n.mmsi for n in nodes], dtype=np.int64)
+            # (None without an identity: a merged new target, m_of_n.py:150 -- 0 in the oracle's table; None with one: no radar measurement)
+            t_meas = np.array([(-1 if n.mmsi is not None else 0) if n.measurementNumber is None else n.measurementNumber for n in nodes], dtype=np.int64)
+            nf += info["n_fused"]
+            checks = [st["L"] == info["L"], np.array_equal(st["unused"], info["unused"]),
+                      [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__],
+                      np.array_equal(os_["ID"], [n.ID for n in nodes]) and np.array_equal(os_["meas"], t_meas) and np.array_equal(os_["mmsi"], t_mmsi),
+                      ais_states_close(os_["x"], [n.x_0 for n in nodes]) and np.allclose(os_["cnllr"], [float(n.cumulativeNLLR) for n in nodes], rtol=0, atol=AIS_SCORE_ATOL),
+                      len(o.clusters) == len(trk.__clusterList__) and all(np.array_equal(a, np.asarray(b)) for a, b in zip(o.clusters, trk.__clusterList__)),
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and np.array_equal(lb["mmsi"], tb["mmsi"])
+                      and ais_states_close(lb["x"], tb["x"]) and np.allclose(lb["cnllr"], tb["cnllr"], rtol=0, atol=AIS_SCORE_ATOL),
+                      o.n_ilp == trk.nOptimSolved]
+            if not all(checks):
+                return False, desc, 'MISMATCH at scan %d: L %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))
+        return True, desc, msg + ' L=%d fused=%d ilp=%d %.1fs' % (st["L"], nf, o.n_ilp, time.time() - t0)
+    finally:
+        trk.close()

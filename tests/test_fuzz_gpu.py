@@ -31,3 +31,20 @@ def test_fuzz_slice_with_similar_state_pruning():
         if not ok:
             bad.append(desc + ' ' + msg)
     assert not bad, "\n".join(bad)
+
+
+def test_fuzz_slice_ais_aided():
+    """AIS-aided tracking (tracker.py:417-552) on random scenarios with random AIS traffic, against the live oracle: decisions exact,
+    states 1e-6 (fuzz_util.run_case_ais)."""
+    from fuzz_util import run_case_ais
+    n = int(os.environ.get("MHT_FUZZ_AIS_CASES", "60"))
+    seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000")) + 900000
+    bad, fused = [], 0
+    for case in range(n):
+        ok, desc, msg = run_case_ais(seed0 + case, max_leaves=1500, budget_s=8.0)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+        elif 'fused=' in msg:
+            fused += int(msg.split('fused=')[1].split()[0])
+    assert not bad, "\n".join(bad)
+    assert fused > 1000 or n < 20
