@@ -29,14 +29,21 @@ __device__ __forceinline__ unsigned cl_edge(const unsigned* eL, const ClusterArg
     return ((unsigned)a.edge_t[e - a.elds] << 16) | (unsigned)a.edge_m[e - a.elds];
 }
 
+// BIG: the tables (4 ints per target + one per measurement node) do not fit LDS -- thousands of targets x tens of thousands of
+// measurement nodes -- and live in HBM scratch (ClusterArgs::gtab); the edge list, the pending pairs and the member scratch stay in
+// LDS.  Same phases, same results; the barriers between the phases carry an agent-scope fence (the tables are written with
+// atomics that live in L2 and read with plain loads that may sit in the CU's L1), and within a phase the union-find tolerates stale
+// parents (a parent is only ever replaced by a smaller member of the same component, and every hook is a compare-and-swap in L2).
+template <bool BIG>
 __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char* smem) {
-    int* tlabel = reinterpret_cast<int*>(smem);          // [Tcap]  union-find parent of a target
+#define __syncthreads() do { if (BIG) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); if (BIG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+    int* tlabel = BIG ? a.gtab : reinterpret_cast<int*>(smem);          // [Tcap]  union-find parent of a target
     int* lab = tlabel + a.Tcap;                          // [Tcap]  final label = smallest target of the component
     int* cnt = lab + a.Tcap;                             // [Tcap]  by head: members of its cluster
     int* fill = cnt + a.Tcap;                            // [Tcap]  by head: member slots handed out
     int* mlabel = fill + a.Tcap;                         // [n_mnodes] smallest target that uses the measurement node
     const int mslots = a.n_mnodes > 2 * a.Tcap ? a.n_mnodes : 2 * a.Tcap;   // re-used for the cluster tables afterwards
-    unsigned* eL = reinterpret_cast<unsigned*>(mlabel + mslots);   // [a.elds]
+    unsigned* eL = BIG ? reinterpret_cast<unsigned*>(smem) : reinterpret_cast<unsigned*>(mlabel + mslots);   // [a.elds]
     unsigned* pend = eL + a.elds;                                  // [a.pcap] (owner << 16 | user) pairs still to be united
     __shared__ int s_pend;
     __shared__ int s_edges, s_changed, s_scan[CL_THREADS / 64], s_scan2[CL_THREADS / 64], s_total, s_total2;
@@ -328,7 +335,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
     // in ascending target order: every member takes a slot of its cluster's segment with an LDS atomic (arbitrary order),
     // then finds its rank by counting the smaller members -- O(cluster size) per thread, all targets in parallel.
     // (the scratch lives in the LDS edge list, which is dead by now; Tcap <= elds is checked at launch)
-    int* tmp = reinterpret_cast<int*>(eL);     // [T] every cluster owns the segment [cstart, cstart + cnt)
+    int* tmp = BIG ? mlabel + mslots : reinterpret_cast<int*>(eL);     // [T] every cluster owns the segment [cstart, cstart + cnt)
     for (int t = tid; t < T; t += CL_THREADS) {
         const int h = lab[t];
         const int c = cidx[h], base = cstart[h], K = cnt[h];
@@ -403,11 +410,16 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
         a.counts[2] = s_changed;
         if (a.team_list) a.counts[5] = s_team < TEAM_MAX ? s_team : TEAM_MAX;
     }
+#undef __syncthreads
 }
 
 __global__ __launch_bounds__(CL_THREADS) void cluster_kernel(const ClusterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cluster_body(a, smem);
+    cluster_body<false>(a, smem);
+}
+__global__ __launch_bounds__(CL_THREADS) void cluster_big_kernel(const ClusterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cluster_body<true>(a, smem);
 }
 // Streaming API path: step 7 of the scan (the M-of-N initiator, tracker.py:264-278) needs nothing of steps 2-6 -- only which
 // measurements the grow kernel gated -- so it runs as a SECOND workgroup of this launch, next to the clustering, instead of behind
@@ -420,14 +432,14 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_init_kernel(const ClusterA
         initiator_body(in);
         return;
     }
-    cluster_body(a, smem);
+    cluster_body<false>(a, smem);
 }
 // a group of sectors per launch: blockIdx.y = sector, its argument block is read from HBM (two variants by scan parity)
 __global__ __launch_bounds__(CL_THREADS) void cluster_batch_kernel(const PBatch av) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ClusterArgs a;
     load_args(a, static_cast<const ClusterArgs*>(av.p[blockIdx.y]));
-    cluster_body(a, smem);
+    cluster_body<false>(a, smem);
 }
 
 constexpr size_t CL_LDS_BUDGET = 150 * 1024;
@@ -447,6 +459,9 @@ int cluster_elds(int Tcap, int n_mnodes) {
     cluster_carve(Tcap, n_mnodes, elds, pcap);
     return elds;
 }
+// the tables fit LDS (cluster_kernel), or they go to HBM scratch (cluster_big_kernel: gtab of cluster_big_ints() ints)
+bool cluster_fits_lds(int Tcap, int n_mnodes) { const int e = cluster_elds(Tcap, n_mnodes); return e >= Tcap && e >= 1024; }
+size_t cluster_big_ints(int Tcap, int n_mnodes) { return (size_t)5 * Tcap + (size_t)(n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap); }
 size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
     const size_t mslots = n_mnodes > 2 * Tcap ? n_mnodes : 2 * Tcap;
     int elds, pcap;
@@ -457,13 +472,30 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes) {
 int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in, const InitArgs* init, const int32_t* sticky_overflow) {
     ClusterArgs a = a_in;
     size_t& attr_bytes = ctx->lds_attr_cluster;
-    cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap);
-    const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
-    if (a.elds < a.Tcap || a.elds < 1024 || a.n_mnodes > 65536) {
-        set_error("cluster: Tcap=%d and %d measurement nodes do not fit the clustering kernel's LDS budget (%zu KiB)", a.Tcap, a.n_mnodes,
-                  CL_LDS_BUDGET / 1024);
+    if (a.n_mnodes > 65536 || a.Tcap > 65536) {
+        set_error("cluster: %d targets / %d measurement nodes exceed the 16 + 16 bits of an edge record", a.Tcap, a.n_mnodes);
         return MHT_E_CAPACITY;
     }
+    if (!cluster_fits_lds(a.Tcap, a.n_mnodes)) {      // tables in HBM scratch
+        if (!a.gtab) {
+            set_error("cluster: Tcap=%d and %d measurement nodes do not fit the clustering kernel's LDS budget (%zu KiB) and no HBM table was provided", a.Tcap,
+                      a.n_mnodes, CL_LDS_BUDGET / 1024);
+            return MHT_E_CAPACITY;
+        }
+        a.elds = CL_ELDS_MAX; a.pcap = CL_PEND_MAX;
+        const size_t lds_big = (size_t)(a.elds + a.pcap) * 4;
+        static size_t attr_big = 0;
+        if (lds_big > 48 * 1024 && lds_big > attr_big) {
+            MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+            attr_big = lds_big;
+        }
+        // (the initiator, if one was handed in, does not ride along: the caller runs it behind the scan, mht_forest.hip)
+        hipLaunchKernelGGL(cluster_big_kernel, dim3(1), dim3(CL_THREADS), lds_big, ctx->stream, a);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
+    cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap);
+    const size_t lds = cluster_lds_bytes(a.Tcap, a.n_mnodes);
     if (lds > 48 * 1024 && lds > attr_bytes) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -478,7 +510,10 @@ int launch_cluster(mht_ctx* ctx, const ClusterArgs& a_in, const InitArgs* init, 
 }
 
 // the LDS carve (elds, pcap) of a forest's argument block, as launch_cluster sets it
-void cluster_prepare(ClusterArgs& a) { cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap); }
+void cluster_prepare(ClusterArgs& a) {
+    if (cluster_fits_lds(a.Tcap, a.n_mnodes)) cluster_carve(a.Tcap, a.n_mnodes, a.elds, a.pcap);
+    else { a.elds = CL_ELDS_MAX; a.pcap = CL_PEND_MAX; }
+}
 
 int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes) {
     const size_t lds = cluster_lds_bytes(Tcap, n_mnodes);
@@ -503,7 +538,8 @@ extern "C" int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     size_t ecap = (size_t)T * words * 64;
     if (ecap > (1u << 22)) ecap = 1u << 22;
-    const size_t ints = 2 * ecap + 6 * (size_t)T + 32;
+    const bool big = !cluster_fits_lds(T, words * 64);
+    const size_t ints = 2 * ecap + 6 * (size_t)T + 32 + (big ? cluster_big_ints(T, words * 64) : 0);
     int rc = ctx->counts.ensure(ints * 4);
     if (rc) return rc;
     int32_t* base = static_cast<int32_t*>(ctx->counts.ptr);
@@ -520,6 +556,7 @@ extern "C" int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_
     a.single_list = q + 4 * T + 1; a.counts = q + 5 * T + 8;
     int32_t* nT_dev = q + 5 * T + 16;
     a.nT_dev = nT_dev;
+    if (big) a.gtab = q + 6 * T + 32;
     MHT_HIP_CHECK(hipMemsetAsync(a.counts, 0, 8 * 4, ctx->stream));
     MHT_HIP_CHECK(hipMemcpyAsync(nT_dev, &T, 4, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_cluster(ctx, a);

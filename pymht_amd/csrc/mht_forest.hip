@@ -312,6 +312,7 @@ struct Forest {
     unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
     int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
+    int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
     int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
@@ -420,6 +421,7 @@ struct Forest {
         cl_members = ar.take<int32_t>(Tcap); multi_list = ar.take<int32_t>(Tcap); single_list = ar.take<int32_t>(Tcap);
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
         cl_owner = ar.take<int32_t>(Tcap);
+        if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
         team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         team_prob = ar.take<TeamProblem>(TEAM_MAX);
         u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
@@ -564,6 +566,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
     f->pds = f->PD <= 8 ? 8 : 16;
+    f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -623,14 +626,8 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
-    // cluster-kernel LDS budget check up front
-    if (cluster_elds(f->Tcap, f->n_mnodes) < f->Tcap || cluster_elds(f->Tcap, f->n_mnodes) < 1024) {
-        set_error("mht_forest_create: max_targets=%d and (n_scan+3) x max_meas = %d measurement nodes do not fit the clustering "
-                  "kernel's LDS budget (150 KiB: 16 B per target + 4 B per node, and three quarters of the rest must hold max(1024, max_targets) edges): lower max_targets / max_meas",
-                  f->Tcap, f->n_mnodes);
-        forest_destroy(ctx);
-        return MHT_E_CAPACITY;
-    }
+    // (a forest whose clustering tables -- 16 B per target + 4 B per measurement node -- do not fit the kernel's 150 KiB of LDS keeps them
+    // in HBM: cluster_big_kernel)
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHT_OK;
 }
@@ -804,6 +801,7 @@ static void fill_cluster(const Forest* f, int s, ClusterArgs& c) {
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
     c.team_list = f->teams ? f->team_list : nullptr; c.team_state = f->teams ? f->team_state : nullptr;
+    c.gtab = f->cl_gtab;
     cluster_prepare(c);
 }
 
@@ -1045,13 +1043,13 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     {
         ClusterArgs c;
         fill_cluster(f, pl.s, c);
-        if (init) {
+        if (init && !f->cluster_big) {
             InitArgs ia;
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
             MHT_STEP_CHECK(launch_cluster(ctx, c, &ia, &f->cnt->overflow));
             f->init_ran_scan = pl.s;
-        } else {
+        } else {      // (no initiator, or the HBM-table clustering kernel: the initiator then runs behind the scan, in post_scan_kernel)
             MHT_STEP_CHECK(launch_cluster(ctx, c));
         }
     }
@@ -1190,6 +1188,8 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     MHT_REQUIRE(out && ctxs && n >= 1 && n <= GROUP_MAX, "mht_group_create: need 1 <= n <= %d contexts", GROUP_MAX);
     for (int i = 0; i < n; ++i) {
         MHT_REQUIRE(ctxs[i] && ctxs[i]->forest, "mht_group_create: context %d has no forest", i);
+        MHT_REQUIRE(!ctxs[i]->forest->cluster_big && !ctxs[i]->forest->ais, "mht_group_create: context %d's forest is too large for the batched clustering kernel "
+                    "(its tables live in HBM) or is an AIS forest: step it on its own", i);
         const Forest *a = ctxs[0]->forest, *b = ctxs[i]->forest;
         MHT_REQUIRE(ctxs[i]->device == ctxs[0]->device && ctxs[i]->stream == ctxs[0]->stream,
                     "mht_group_create: the members must share one device and one stream (context %d does not)", i);

@@ -151,6 +151,7 @@ struct ClusterArgs {
     // Longest-processing-time rule on the clusters' column counts (largest first, each to the least loaded device; ties: lower cluster
     // index / lower device) -- every device computes the same table from the same data.
     int shard_n; const int32_t* tchild; const int32_t* tcend; int32_t* cl_owner;      // [T] by cluster index, or null / shard_n <= 1: off
+    int32_t* gtab;         // cluster_big_kernel: the tables in HBM (cluster_big_ints() ints), or null
     int32_t* team_list;    // [TEAM_MAX] or null: clusters of >= TEAM_MIN_K targets (searched by teams of workgroups, see BlpArgs)
     TeamState* team_state; // [TEAM_MAX] reset here for this scan
 };
@@ -259,6 +260,8 @@ int launch_cluster(mht_ctx* ctx, const ClusterArgs& a, const InitArgs* init = nu
 void cluster_prepare(ClusterArgs& a);
 size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
+bool cluster_fits_lds(int Tcap, int n_mnodes);
+size_t cluster_big_ints(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);

@@ -16,11 +16,11 @@ def _model(nx):
     return pv if nx == 4 else ca
 
 
-def _tracker(sc, nx):
+def _tracker(sc, nx, max_targets=2304):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
     model = _model(nx)
-    trk = Tracker(model, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=2304, maxNodes=1 << 20,
+    trk = Tracker(model, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=max_targets, maxNodes=1 << 20,
                   maxMeasurements=2048, useInitiator=False)
     x0 = sc["x0"] if nx == 4 else np.concatenate([sc["x0"], np.zeros((len(sc["x0"]), 2))], axis=1)      # [x, y, vx, vy, ax = 0, ay = 0]
     cands = [Target(sc["t0"], None, x.copy(), model.P0, status="preinitialized") for x in x0]
@@ -28,11 +28,11 @@ def _tracker(sc, nx):
     return trk, np.array([id(t) in admitted for t in cands]), x0
 
 
-def _run(n_scans, oracle_scans=0, nx=6):
+def _run(n_scans, oracle_scans=0, nx=6, max_targets=2304):
     from pymht_amd.utils.scenario import make_config
     from pymht_amd.utils.classDefinitions import MeasurementList
     sc = make_config("cfg5", seed=907, n_scans=n_scans)
-    trk, acc, x0 = _tracker(sc, nx)
+    trk, acc, x0 = _tracker(sc, nx, max_targets)
     assert trk.nx == nx
     o = None
     if oracle_scans:
@@ -85,3 +85,11 @@ def test_cfg5_four_state_size():
     """The same size with the reference's own 4-state CV model (what round 2 ran): first scans against the oracle."""
     d = _run(4, oracle_scans=4, nx=4)
     assert d[-1][0] >= 12000
+
+
+def test_forest_with_cluster_tables_beyond_lds():
+    """A forest made for 8 192 targets x 2 048 measurements, N = 6: its clustering tables (16 B per target + 4 B per measurement node =
+    205 KB) do not fit the 150 KiB of LDS and live in HBM (cluster_big_kernel; the round-2 build refused such a forest).  The config-5
+    scene through it, first scans against the oracle like the others."""
+    d = _run(3, oracle_scans=3, nx=4, max_targets=8192)
+    assert d[-1][0] >= 6000

@@ -27,7 +27,10 @@ def gpu_cluster(ctx, sets, n_nodes):
 
 @pytest.mark.parametrize("T,n_nodes,deg,seed", [(1, 64, 3, 0), (7, 100, 2, 1), (300, 3000, 4, 2), (2000, 9000, 3, 3),
                                                  (500, 200, 1, 4), (64, 64, 0, 5),
-                                                 (3000, 9000, 9, 6)])       # > 16384 edges: the LDS edge list spills to HBM
+                                                 (3000, 9000, 9, 6),        # > 16384 edges: the LDS edge list spills to HBM
+                                                 # tables beyond LDS (cluster_big_kernel, tables in HBM): 8 k targets x 4 k measurements, N-scan 6
+                                                 # = 9 x 4096 measurement nodes (the round-2 review's size), sparse and dense; and the 16-bit limits
+                                                 (8192, 36864, 5, 7), (8192, 36864, 24, 8), (6000, 65536, 3, 9), (20000, 4096, 2, 10)])
 def test_cluster_matches_oracle(gpu_ctx, T, n_nodes, deg, seed):
     rng = np.random.default_rng(seed)
     sets = [set(int(v) for v in rng.integers(0, n_nodes, size=rng.integers(0, deg + 1))) for _ in range(T)]

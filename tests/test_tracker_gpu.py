@@ -49,17 +49,22 @@ def tracker_selected(trk, nx=4):
 
 
 @pytest.mark.parametrize("name", ["g2_trace_cfg1", "g3_trace_dense", "g3b_trace_cfg2", "g6_trace_cfg3", "g6b_trace_cfg3_long",
-                                  "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3", "g16_fgrow_kat"])
+                                  "g13_trace_similar", "g13b_trace_similar_cfg2", "g13c_trace_similar_cfg3", "g16_fgrow_kat",
+                                  # the same trace in a forest made for 8 192 targets: clustering tables in HBM (cluster_big_kernel), the
+                                  # device initiator behind the scan instead of next to the clustering
+                                  "g3_trace_dense:big", "g13_trace_similar:big"])
 def test_tracker_replays_reference_trace(name, gold_dir):
     """Every scan of a trace recorded from the real reference: gating counts, unused measurements, selections, clusters, target lists,
     terminations -- and the states and covariances of ALL leaves bit for bit (np.array_equal, or sha-256 over all leaves for the hashed
     traces), both dtype chains, births of the device initiator included.  g16 is the known-answer trace of fgrow_kernel itself: roots
     with their own covariances and float32 states (oracle/gen_golden.py::gen_g16)."""
     from pymht_amd.utils.classDefinitions import MeasurementList
-    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    big = name.endswith(":big")
+    g = np.load(os.path.join(gold_dir, name.split(":")[0] + ".npz"))
     trk, acc = make_tracker(float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), float(g["P_d"]),
                             int(g["N"]), float(g["eta2"]), g["x0"], float(g["t0"]),
-                            P0s=g["P0s"] if "P0s" in g.files else None, x0_f32=g["x0_f32"] if "x0_f32" in g.files else None)
+                            P0s=g["P0s"] if "P0s" in g.files else None, x0_f32=g["x0_f32"] if "x0_f32" in g.files else None,
+                            **(dict(maxTargets=8192, maxNodes=1 << 18) if big else {}))
     assert acc == [bool(a) for a in g["accepted"]]
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
