@@ -372,6 +372,8 @@ def main():
         gen_g18(mods)
     if "g19" in which:
         gen_g19(mods)
+    if "g20" in which:
+        gen_g20()
     if "g13" in which:
         # similar-state pruning (addMeasurementList(pruneSimilar=True); tracker.py:230-231, pyTarget.py:358-412) on the dense and
         # the config-2 stream: ~100 / ~170 fusions, initiator births (float32 chains) included
@@ -599,6 +601,34 @@ def gen_g19(mods):
         print("  g19 case %d: leaves %d (f32 %s)  msgs %d  radar %d  children %d (pure AIS %d)" % (ci, n_leaf, f32, len(ais), len(z), len(ax), int((np.array(ar) < 0).sum())))
     fx["n_cases"] = len(cases)
     np.savez_compressed(os.path.join(GOLD, "g19_ais_fusion.npz"), **fx)
+
+
+def gen_g20():
+    """The giant cluster that reduced-cost fixing cannot cut down to what LDS holds (found by the fuzzer: scenario 90266 of
+    tests/fuzz_util.py -- 67 targets inside a 231 m radius, P_d 0.72, a 4 s radar; its fourth scan ties 44 of them into one cluster of
+    7 831 columns with a wide LP gap): the instance as the oracle builds it (tracker.py:1029-1136), exact optimum by HiGHS, uniqueness."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fuzz_util import scenario_of
+    from trace_util import make_oracle
+    sc, N, eta2, desc = scenario_of(90266)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, x0=sc["x0"], t0=sc["t0"],
+             accepted=None)
+    # (which candidates the neighbour test admits: decided by the oracle itself)
+    from m_of_n_oracle import Initiator
+    from pymht_amd.utils.classDefinitions import MeasurementList as MyML
+    from pymht_amd.models import pv as mypv
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2,
+                          initiator=OracleInitiatorAdapter(Initiator(2, 3, 20, mypv.C_RADAR, mypv.R_RADAR(), 4 * 2.5 ** 2), MyML))
+    for x in sc["x0"]:
+        o.initiate_target(sc["t0"], x.copy(), orc.model_P0(), status="preinitialized")
+    o.ilp_recorder = []
+    for k in range(4):
+        o.add_scan(float(sc["times"][k]), sc["scans"][k])
+        print("  g20 scan %d: clusters %s" % (k, sorted((len(c) for c in o.clusters), reverse=True)[:3]))
+    big = max(o.ilp_recorder, key=lambda i: len(i["cols"]))
+    print("  g20 instance: %d targets, %d columns" % (len(big["sizes"]), len(big["cols"])))
+    assert len(big["sizes"]) == 44 and len(big["cols"]) == 7831
+    gen_g4([big], name="g20_ilp_hbm_team")
 
 
 def gen_g14(mods):

@@ -139,14 +139,15 @@ __device__ __forceinline__ void block_min_pair(double& v, int& i, Red* r) {
 // Columns are addressed by a policy-local index; rows by a policy-local id in [0, nrows()).
 struct GStore {      // HBM: column = global child index, row = global measurement-node id, row set = LDS bitset
     const BlpArgs* a; const int32_t* mem; const unsigned long long* uw; int UW, PD; size_t cap;
+    double* pu; int32_t* pusage; int32_t* pmark;      // prices / usage / marks by measurement node: the workgroup's own copy (a team member's, or the shared one)
     int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
     __device__ __forceinline__ int col_begin(int k) const { return a->tchild[mem[k]]; }
     __device__ __forceinline__ int col_end(int k) const { return a->tcend[mem[k]]; }
     __device__ __forceinline__ double cost(int h) const { return a->cost[h]; }
     __device__ __forceinline__ int ent(int d, int h) const { return a->pds ? a->path[(size_t)h * a->pds + d] : a->path[(size_t)d * cap + h]; }
-    __device__ __forceinline__ double& u(int m) const { return a->u[m]; }
-    __device__ __forceinline__ int32_t& usage(int m) const { return a->usage[m]; }
-    __device__ __forceinline__ int32_t& mark(int m) const { return a->mark[m]; }
+    __device__ __forceinline__ double& u(int m) const { return pu[m]; }
+    __device__ __forceinline__ int32_t& usage(int m) const { return pusage[m]; }
+    __device__ __forceinline__ int32_t& mark(int m) const { return pmark[m]; }
     __device__ __forceinline__ int to_global(int h) const { return h; }
     template <typename F> __device__ __forceinline__ void for_rows(F f) const {
         for (int w = threadIdx.x; w < UW; w += BLP_THREADS) {
@@ -994,6 +995,14 @@ struct Team { int q, W; unsigned long long* gub; };
 constexpr int TEAM_LEVEL = MHT_TEAM_LEVEL;      // the search is dealt out at this level (0-based): the members all walk the levels above it (a few dozen nodes),
                                                 // below it each descends only into its own subtrees.  G9's 147 ms instance, 32 members: level 1 80 ms (two members hold half of the nodes),
                                                 // 3: 53, 4: 46, 5: 35, 6: 64 ms (the shared levels grow).
+// On HBM scratch a node costs ~0.25 ms instead of ~5 us and every node above the deal-out level is walked by ALL members: G20 (44 targets,
+// 7 831 columns, not reducible), 32 members: level 2: 521 ms (9.1 k nodes in all, badly balanced), 3: 232 ms (11.4 k), 5: 865 ms (74.7 k),
+// 8: 2 146 ms (195 k); one workgroup: 3 740 ms (14.9 k).
+#ifndef MHT_TEAM_LEVEL_HBM
+#define MHT_TEAM_LEVEL_HBM 3
+#endif
+__device__ __forceinline__ constexpr int team_level(const LStore&) { return TEAM_LEVEL; }
+__device__ __forceinline__ constexpr int team_level(const GStore&) { return MHT_TEAM_LEVEL_HBM; }
 __device__ __forceinline__ unsigned team_hash(int c0, int c1) {      // (level-0 column, level-1 column) -> member: price-independent
     unsigned h = (unsigned)c0 * 0x9E3779B1u ^ ((unsigned)c1 * 0x85EBCA6Bu + 0x7F4A7C15u);
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
@@ -1420,9 +1429,9 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             continue;
         }
         bool foreign = false;
-        if (team && level == TEAM_LEVEL) {      // the columns fixed at levels 0 .. TEAM_LEVEL name the subtree: whose is it?
+        if (team && level == team_level(s)) {      // the columns fixed at levels 0 .. team_level name the subtree: whose is it?
             unsigned hsh = 0x9E3779B9u;
-            for (int l = 0; l < TEAM_LEVEL; ++l) hsh = team_hash((int)hsh, s.to_global(s.ch[l]));
+            for (int l = 0; l < team_level(s); ++l) hsh = team_hash((int)hsh, s.to_global(s.ch[l]));
             hsh = team_hash((int)hsh, s.to_global(bi));
             foreign = hsh % (unsigned)tm.W != (unsigned)tm.q;
         }
@@ -1744,79 +1753,68 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
     // a team searches a cluster that is solved out of LDS from the start (every member holds its own copy); a cluster on HBM scratch
     // (shared) is its owner's alone
     bool team = tm.W > 1 && use_lds;
-    // ... or that reduced-cost fixing cuts down to what LDS holds: the owner runs the HBM phase alone, files the reduced problem,
-    // and the members (waiting for it) join the search from there
-    const bool team_hbm = tm.W > 1 && !use_lds && a.team_prob != nullptr && K <= TEAM_SEL && K <= L_MAXK;
+    // ... and a cluster on HBM scratch when every member has a copy of that scratch to itself (BlpArgs::tm_sm / tm_ss: prices, usage and
+    // marks by measurement node, the per-member tables): the members replicate the HBM dual phase as well, reach the same decision about
+    // reduced-cost fixing (same prices, same feasible point), rebuild the same LDS problem or -- if the survivors do not fit -- share the
+    // branch and bound on HBM.  (Round 3 first handed the owner's reduced problem over to waiting members; a cluster that could not be
+    // reduced -- 44 targets, 7 831 columns: 14 900 nodes at 0.25 ms -- stayed with one workgroup for 3.7 s.)
+    const bool team_hbm = tm.W > 1 && !use_lds && a.tm_sm > 0 && K <= TEAM_SEL;
     if (tm.q > 0 && !team && !team_hbm) return;
     const int32_t* final_sel = nullptr;      // team search: the best member's selection (global columns), read by the last finisher
     int32_t team_nodes = 0;
     int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
     double ub_reduced = DINF;
-    if (!use_lds && tm.q > 0) {
-        // ---- member of a giant cluster's team: wait for the owner's reduced problem, build it in LDS ---------------------------
-        // (the owner -- a workgroup with a lower block index -- was dispatched before this one and finishes whatever this one does:
-        // the wait ends; it is bounded anyway, and a member that gives up files an empty result so that the count stays complete)
-        TeamState* ts = a.team_state + team_idx;
-        TeamProblem* pb = a.team_prob + team_idx;
-        int ready = 0;
-        if (tid == 0) {
-            const unsigned long long w0 = wall_clock64();
-            while ((ready = __hip_atomic_load(&ts->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - w0 < 1000000000ull) __builtin_amdgcn_s_sleep(127);
-            r->i[0] = ready;
-        }
-        __syncthreads();
-        ready = r->i[0];
-        __syncthreads();
-        if (ready == 2) return;      // the owner finished without a reduction: nothing to share, no report expected
-        if (ready == 0) {            // gave up waiting (the owner's HBM phase takes longer than the bound): an empty result keeps the count complete
-            if (tid == 0) {
-                TeamResult& me = a.team_res[(size_t)team_idx * TEAM_W + tm.q];
-                me.ub = DINF; me.status = MHT_BLP_BRANCHED; me.nodes = 0; me.iters = 0;
-                __threadfence();
-                atomicAdd(&ts->done, 1);
-            }
-            return;
-        }
+    // every member of a team files what it found (global columns); the LAST one to finish takes the best of all -- value, then the lowest
+    // member -- and goes on to the cluster's epilogue (true), the others are done (false).  Nobody waits.
+    auto team_file = [&](const Team& tmm, int tidx, int Kk, auto sel_of, double ubv, int& st_io, int& it_io, int& nd_io, const int32_t*& fsel) -> bool {
+        TeamResult* res = a.team_res + (size_t)tidx * TEAM_W;
+        TeamResult& me = res[tmm.q];
+        for (int k = tid; k < Kk; k += BLP_THREADS) me.sel[k] = sel_of(k);
+        if (tid == 0) { me.ub = ubv; me.status = st_io; me.nodes = nd_io; me.iters = it_io; }
         __threadfence();
-        auto ld = [](int32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        nHl = ld(&pb->nH);
-        ub_reduced = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&pb->ub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        for (int k = tid; k <= K; k += BLP_THREADS) s.colb[k] = ld(&pb->colb[k]);
-        for (int k = tid; k < K; k += BLP_THREADS) s.ub_sel[k] = ld(&pb->ubpos[k]);
-        for (int w = tid; w < UW; w += BLP_THREADS) uw[w] = 0ull;
-        if (tid == 0) s_nH = nHl;
         __syncthreads();
-        for (int pos = tid; pos < nHl; pos += BLP_THREADS) {
-            const int h = ld(&pb->gcol[pos]);
-            int lo = 0, hi = K;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= pos) lo = mid; else hi = mid; }
-            s.gcolL[pos] = h;
-            s.membL[pos] = (unsigned short)lo;
-            s.costL[pos] = a.cost[h];
-            for (int d = 0; d < 8; ++d) {
-                const int e = d < a.PD ? (a.pds ? a.path[(size_t)h * a.pds + d] : a.path[(size_t)d * a.cap + h]) : -1;
-                s.entL[pos * 8 + d] = (unsigned short)(e < 0 ? 0xffff : e);      // global node id for now
-                if (e >= 0) atomicOr(&uw[e >> 6], 1ull << (e & 63));
+        if (tid == 0) r->i[0] = atomicAdd(&a.team_state[tidx].done, 1);
+        __syncthreads();
+        const int before = r->i[0];
+        __syncthreads();
+        if (before != tmm.W - 1) return false;
+        __threadfence();
+        if (tid == 0) {
+            int bq = 0, any_limit = 0, nsum = 0, itmax = 0;
+            double bub = DINF;
+            for (int q = 0; q < tmm.W; ++q) {
+                const double u = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&res[q].ub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int st = __hip_atomic_load(&res[q].status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nsum += __hip_atomic_load(&res[q].nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int itq = __hip_atomic_load(&res[q].iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                itmax = itq > itmax ? itq : itmax;
+                any_limit |= (st == MHT_BLP_NODE_LIMIT);
+                if (u < bub) { bub = u; bq = q; }      // (ties: the lowest member)
             }
+            r->i[0] = bq; r->i[1] = any_limit; r->i[2] = nsum; r->i[3] = itmax;
         }
-        row_prefix();
-        nR = s_nR;
-        s.reduced = true;
-        s.nH = nHl;
-        use_lds = true;
-        team = true;
-    } else if (!use_lds) {
+        __syncthreads();
+        fsel = res[r->i[0]].sel;
+        st_io = r->i[1] ? MHT_BLP_NODE_LIMIT : MHT_BLP_BRANCHED;
+        nd_io = r->i[2];
+        it_io = r->i[3];
+        __syncthreads();
+        return true;
+    };
+    if (!use_lds) {
         // ---- HBM scratch: the same solver, generic column access ----------------------------------------------------
         GStore gs;
         gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
-        gs.best_h = a.best_h + slot; gs.best_rc = a.best_rc + slot; gs.ub_sel = a.bb_best + slot; gs.ch = a.bb_ch + slot;
-        gs.cst = a.bb_cost + slot; gs.uus = a.bb_uused + slot; gs.lrc = a.bb_last_rc + slot; gs.lix = a.bb_last_idx + slot;
-        gs.rest = a.bb_rest + slot; gs.mn = a.bb_min + slot;
-        gs.for_rows([&](int m) { a.u[m] = 0.0; });
+        const size_t om = team_hbm ? (size_t)tm.q * a.tm_sm : 0, os = (team_hbm ? (size_t)tm.q * a.tm_ss : 0) + (size_t)slot;      // this member's copies
+        gs.pu = a.u + om; gs.pusage = a.usage + om; gs.pmark = a.mark + om;
+        gs.best_h = a.best_h + os; gs.best_rc = a.best_rc + os; gs.ub_sel = a.bb_best + os; gs.ch = a.bb_ch + os;
+        gs.cst = a.bb_cost + os; gs.uus = a.bb_uused + os; gs.lrc = a.bb_last_rc + os; gs.lix = a.bb_last_idx + os;
+        gs.rest = a.bb_rest + os; gs.mn = a.bb_min + os;
+        gs.for_rows([&](int m) { gs.pu[m] = 0.0; gs.pusage[m] = 0; gs.pmark[m] = 0; });      // (usage / marks are zero between uses; a member's copy may never have been touched)
         __threadfence_block();
         __syncthreads();
         double ub = DINF;
-        solve_core(a, gs, K, r, status, iters, nodes, stamp, ub);
+        solve_core(a, gs, K, r, status, iters, nodes, stamp, ub, team_hbm ? tm : Team{0, 1, nullptr});
         ub_reduced = ub;
 #ifdef MHT_BLP_TRACE
         if (tid == 0) printf("[blp] cluster %d K=%d nH=%d: HBM phase status %d iters %d nodes %d, %.2f ms (setup %.2f)\n", c, K, nH, status, iters, nodes,
@@ -1868,24 +1866,17 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             s.reduced = true;
             s.nH = nHl;
             use_lds = true;
-            if (team_hbm && nHl <= TEAM_COLS) {      // file the reduced problem for the team, then search it together
-                TeamProblem* pb = a.team_prob + team_idx;
-                for (int pos = tid; pos < nHl; pos += BLP_THREADS) pb->gcol[pos] = s.gcolL[pos];
-                for (int k = tid; k <= K; k += BLP_THREADS) pb->colb[k] = s.colb[k];
-                for (int k = tid; k < K; k += BLP_THREADS) pb->ubpos[k] = s.ub_sel[k];
-                if (tid == 0) { pb->nH = nHl; pb->ub = ub_reduced; }
-                __threadfence();
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(&a.team_state[team_idx].ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                team = true;
-            } else if (team_hbm && tid == 0) {
-                __hip_atomic_store(&a.team_state[team_idx].ready, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            team = team_hbm;      // (every member rebuilt the same problem from its own copy of the HBM phase: the search is shared from here)
         } else {
-            if (team_hbm && tid == 0) __hip_atomic_store(&a.team_state[team_idx].ready, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // solved without a reduction
+            // solved on HBM scratch: by this workgroup alone, or -- a team -- every member files what it found and the last one finishes
+            if (team_hbm && status == MHT_BLP_CERTIFIED) {
+                if (tm.q > 0) return;      // (the dual phase is deterministic: every member holds the same certificate, the owner finishes)
+            } else if (team_hbm) {
+                if (!team_file(tm, team_idx, K, [&](int k) { return gs.ub_sel[k]; }, ub, status, iters, nodes, final_sel)) return;
+            }
             stamp[4] = wall_clock64();
             for (int k = tid; k < K; k += BLP_THREADS) {
-                const int h = gs.ub_sel[k];
+                const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs.ub_sel[k];
                 a.sel[mem[k]] = h;
                 if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
                 if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
@@ -1920,40 +1911,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
         if (team && status == MHT_BLP_CERTIFIED) {
             if (tm.q > 0) return;      // the dual phase is deterministic: every member holds the same certificate, the owner finishes
         } else if (team) {
-            // every member files what it found; the LAST one to finish takes the best and runs the cluster's epilogue.  Nobody waits.
-            TeamResult* res = a.team_res + (size_t)team_idx * TEAM_W;
-            TeamResult& me = res[tm.q];
-            for (int k = tid; k < K; k += BLP_THREADS) me.sel[k] = s.to_global(s.ub_sel[k]);
-            if (tid == 0) { me.ub = ub; me.status = status; me.nodes = nodes; me.iters = iters; }
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) r->i[0] = atomicAdd(&a.team_state[team_idx].done, 1);
-            __syncthreads();
-            const int before = r->i[0];
-            __syncthreads();
-            if (before != tm.W - 1) return;
-            __threadfence();
-            if (tid == 0) {
-                int bq = 0, any_limit = 0, nsum = 0, itmax = 0;
-                double bub = DINF;
-                for (int q = 0; q < tm.W; ++q) {
-                    const double u = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&res[q].ub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const int st = __hip_atomic_load(&res[q].status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nsum += __hip_atomic_load(&res[q].nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int itq = __hip_atomic_load(&res[q].iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    itmax = itq > itmax ? itq : itmax;
-                    any_limit |= (st == MHT_BLP_NODE_LIMIT);
-                    if (u < bub) { bub = u; bq = q; }      // (ties: the lowest member)
-                }
-                r->i[0] = bq; r->i[1] = any_limit; r->i[2] = nsum; r->i[3] = itmax;
-            }
-            __syncthreads();
-            final_sel = res[r->i[0]].sel;
-            status = r->i[1] ? MHT_BLP_NODE_LIMIT : MHT_BLP_BRANCHED;
-            team_nodes = r->i[2];
-            nodes = team_nodes;
-            iters = r->i[3];
-            __syncthreads();
+            if (!team_file(tm, team_idx, K, [&](int k) { return s.to_global(s.ub_sel[k]); }, ub, status, iters, nodes, final_sel)) return;
+            team_nodes = nodes;
         }
         stamp[4] = wall_clock64();
         for (int k = tid; k < K; k += BLP_THREADS) {
@@ -2223,10 +2182,16 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     MHT_REQUIRE(nT >= 1 && nHyp >= nT && nRows >= 0 && depth >= 0 && depth <= MAXPD, "mht_solve_blp: bad sizes");
     MHT_REQUIRE(rows || depth == 0, "mht_solve_blp: rows is null");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t S = (size_t)2 * nT + 2;
-    const size_t nR = (size_t)(nRows > 0 ? nRows : 1);
+    // one cluster holding all targets; a large one is searched by a team of workgroups (mht_kernels.h: TEAM_*), as in the forest: the launch
+    // gets TEAM_W - 1 workgroups without a cluster of their own, and the HBM scratch is laid out in TEAM_W copies
+    bool seam_team = nT >= TEAM_MIN_K && nT <= TEAM_SEL;
+    { const char* e = getenv("MHT_BLP_NO_TEAMS"); if (e && e[0] == '1') seam_team = false; }
+    const size_t W1 = seam_team ? (size_t)TEAM_W : 1;
+    const size_t S1 = (size_t)2 * nT + 2, nR1 = (size_t)(nRows > 0 ? nRows : 1);
+    const size_t S = S1 * W1;
+    const size_t nR = nR1 * W1;
     // doubles: u[nR] best_rc bb_cost bb_uused bb_last_rc bb_rest bb_min [S each] out[4] snapshots[BB_SLOTS][BB_RE_LEVELS][snap_rows]
-    const size_t snap_rows = nR > (size_t)BIG_MAXR ? nR : (size_t)BIG_MAXR;
+    const size_t snap_rows = nR1 > (size_t)BIG_MAXR ? nR1 : (size_t)BIG_MAXR;
     const size_t n_d = nR + 6 * S + 4 + (size_t)BB_SLOTS * BB_RE_LEVELS * snap_rows;
     // ints: usage[nR] mark[nR] best_h bb_ch bb_best bb_last_idx [S each] cl_ptr[2] members[nT] multi[1] single[1] counts[4] st it nd busy[BB_SLOTS]
     const size_t n_i = 2 * nR + 4 * S + 2 + nT + 2 + 8 + 3 + BB_SLOTS;
@@ -2250,7 +2215,8 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.cl_ptr = cl_ptr; a.cl_members = members; a.multi_list = multi; a.single_list = single; a.counts = counts;
     a.cl_status = st; a.cl_iters = st + 1; a.cl_nodes = st + 2;
     a.bb_busy = st + 3;
-    a.tchild = group_ptr; a.tcend = group_ptr + 1; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR;
+    a.tchild = group_ptr; a.tcend = group_ptr + 1; a.cost = cost; a.cnllr = cost; a.path = rows; a.cap = nHyp; a.PD = depth; a.n_mnodes = (int)nR1;
+    if (seam_team) { a.tm_sm = nR1; a.tm_ss = S1; }
     a.sel = selected;
     a.max_iter = max_iter < 0 ? 200 : max_iter;
     { const char* e = getenv("MHT_BLP_NO_ENUM"); a.no_enum = (e && e[0] == '1') ? 1 : 0; }
@@ -2258,11 +2224,6 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     a.node_limit = node_limit <= 0 ? (1 << 20) : node_limit;
     { const char* e = getenv("MHT_BLP_TIME_LIMIT_US"); a.time_limit = e ? atoll(e) * 100 : 0; }      // testing: wall-clock budget per cluster (10 ns ticks)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
-    // one cluster holding all targets
-    // a large cluster is searched by a team of workgroups (mht_kernels.h: TEAM_*), as in the forest: the launch gets TEAM_W - 1
-    // workgroups without a cluster of their own
-    bool seam_team = nT >= TEAM_MIN_K && nT <= TEAM_SEL;
-    { const char* e = getenv("MHT_BLP_NO_TEAMS"); if (e && e[0] == '1') seam_team = false; }
     if (seam_team) {
         const size_t tb = 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W + sizeof(TeamProblem);
         rc = ctx->counts.ensure(tb);

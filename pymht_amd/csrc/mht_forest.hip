@@ -424,10 +424,11 @@ struct Forest {
         if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
         team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         team_prob = ar.take<TeamProblem>(TEAM_MAX);
-        u = ar.take<double>(n_mnodes); usage = ar.take<int32_t>(n_mnodes); mark = ar.take<int32_t>(n_mnodes);
+        // (TEAM_W copies of the ILP kernel's HBM scratch: a team member of a giant cluster works on its own, mht_blp.hip)
+        u = ar.take<double>((size_t)n_mnodes * TEAM_W); usage = ar.take<int32_t>((size_t)n_mnodes * TEAM_W); mark = ar.take<int32_t>((size_t)n_mnodes * TEAM_W);
         bb_snap_rows = n_mnodes > 1024 ? n_mnodes : 1024;
         bb_snap = ar.take<double>((size_t)BB_SLOTS * BB_RE_LEVELS * bb_snap_rows); bb_busy = ar.take<int32_t>(BB_SLOTS);
-        const size_t S = (size_t)2 * Tcap + 2;
+        const size_t S = ((size_t)2 * Tcap + 2) * TEAM_W;
         best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
@@ -814,6 +815,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->ais ? f->pds : f->PD; b.pds = f->pds;      // (AIS forest: every entry of a record can be a row)
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
+    if (f->teams) { b.tm_sm = (size_t)f->n_mnodes; b.tm_ss = (size_t)2 * f->Tcap + 2; }
     b.bb_snap = f->bb_snap; b.bb_busy = f->bb_busy; b.bb_snap_rows = f->bb_snap_rows;
     b.best_h = f->best_h; b.best_rc = f->best_rc; b.bb_ch = f->bb_ch; b.bb_best = f->bb_best; b.bb_cost = f->bb_cost;
     b.bb_uused = f->bb_uused; b.bb_last_rc = f->bb_last_rc; b.bb_last_idx = f->bb_last_idx; b.bb_rest = f->bb_rest; b.bb_min = f->bb_min;

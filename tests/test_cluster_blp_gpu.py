@@ -149,6 +149,24 @@ def test_blp_clusters_without_certificate(gpu_ctx, gold_dir):
         assert gpu_blp.last_call_s < 0.060, "a giant cluster took %.1f ms (round-3 bar: < 50 ms device time; the call adds launches and a read-back)" % (1e3 * gpu_blp.last_call_s)
 
 
+def test_blp_team_on_hbm_scratch(gpu_ctx, gold_dir, monkeypatch):
+    """G20: the giant cluster of fuzz scenario 90266 (44 targets, 7 831 columns) that reduced-cost fixing cannot cut down to what LDS
+    holds, so that its branch and bound stays on HBM scratch (0.25 ms per node): a team of workgroups, each with its own copy of that
+    scratch, replicates the dual phase and shares the search.  Exact optimum (HiGHS, unique), same selection with and without the team;
+    the single workgroup needs 3.7 s (14.9 k nodes), the team well under a second."""
+    inst = load_instances(os.path.join(gold_dir, "g20_ilp_hbm_team.npz"))[0]
+    assert inst["unique"] and len(inst["sizes"]) == 44 and len(inst["cols"]) == 7831
+    monkeypatch.setenv("MHT_BLP_NO_TEAMS", "0")
+    sel, obj, status, iters, nodes = gpu_blp(gpu_ctx, inst, max_iter=200, node_limit=1 << 22)
+    t_team = gpu_blp.last_call_s
+    assert sel == inst["sel"].tolist() and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(inst["obj"])) and status == 2
+    assert t_team < 1.5, "the HBM team needed %.2f s" % t_team
+    monkeypatch.setenv("MHT_BLP_NO_TEAMS", "1")
+    sel1, obj1, status1, _, nodes1 = gpu_blp(gpu_ctx, inst, max_iter=200, node_limit=1 << 22)
+    assert sel1 == sel and status1 == 2
+    assert t_team < 0.5 * gpu_blp.last_call_s, "team %.2f s vs single workgroup %.2f s" % (t_team, gpu_blp.last_call_s)
+
+
 def test_blp_team_search_equals_single_workgroup_search(gpu_ctx, gold_dir, monkeypatch):
     """Branch and bound by a team of workgroups (csrc/mht_kernels.h: TEAM_*; tracker.py:1155-1217 is one CBC call): every member
     replicates the deterministic dual phase, the subtrees below the deal-out level are dealt out by a hash of their columns, the
