@@ -79,9 +79,9 @@ class OracleInitiatorAdapter:
     def __init__(self, initiator, make_list):
         self.initiator, self.make_list = initiator, make_list
 
-    def processMeasurements(self, time_, z):
+    def processMeasurements(self, time_, z, ais=()):
         return [(t.x_0, t.P_0, t.measurementNumber, t.measurement)
-                for t in self.initiator.processMeasurements(self.make_list(time_, z))]
+                for t in self.initiator.processMeasurements(self.make_list(time_, z), ais)]
 
 
 def run_trace(mods, sc, out_name, n_scans=None, record_ilp=None, store_leaves=True, prune_similar=False):
@@ -370,6 +370,8 @@ def main():
         gen_g14(mods)
     if "g18" in which:
         gen_g18(mods)
+    if "g18e" in which and "g18" not in which:
+        gen_g18e(mods)
     if "g19" in which:
         gen_g19(mods)
     if "g20" in which:
@@ -387,7 +389,7 @@ def main():
         run_trace(mods, make_config("cfg3", seed=5446, n_scans=22), "g6b_trace_cfg3_long", n_scans=22, store_leaves=False)
 
 
-def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=True, prune_similar=False):
+def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=True, prune_similar=False, ais_init=False):
     """G18: reference and oracle side by side on a scenario WITH AIS traffic (Tracker.addMeasurementList(scan, aisList,
     aisInitialization=False): tracker.py:162-307 with the fusion of :417-552); every scan compared bitwise; fixture = the scans,
     the messages and what came out.  The tracker needs a finite radarRange here (tracker.py:438 divides by its square; with the
@@ -417,7 +419,7 @@ def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=Tr
     fx = dict(x0=sc["x0"], accepted=np.array(accepted), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"], lambda_phi=sc["lambda_phi"],
               lambda_nu=LAMBDA_NU, N=sc["N"], eta2=5.99, eta2_ais=trk.eta2_ais, times=sc["times"][:K], n_scans=K,
               radar_range=float(sc["radius"]), position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=bool(with_initiator),
-              prune_similar=bool(prune_similar))
+              prune_similar=bool(prune_similar), ais_init=bool(ais_init))
 
     def leaf_rows(roots, leaves_of, get):
         rows = [l for r in roots for l in leaves_of(r)]
@@ -436,9 +438,9 @@ def run_trace_ais(mods, sc, ais_scans, out_name, n_scans=None, with_initiator=Tr
         msgs = ais_scans[k]
         ids_before = [r.ID for r in trk.__targetList__]
         trk.addMeasurementList(ML_of(mods)(t, z), cd.AisMessageList([cd.AIS_message(time=m[0], state=m[1].copy(), mmsi=m[2], highAccuracy=m[3]) for m in msgs]),
-                               aisInitialization=False, checkIntegrity=True, pruneSimilar=prune_similar)
+                               aisInitialization=ais_init, checkIntegrity=True, pruneSimilar=prune_similar)
         info = o.add_scan(t, z, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs], prune_similar=prune_similar,
-                          prune_threshold=trk.pruneThreshold)
+                          prune_threshold=trk.pruneThreshold, ais_initialization=ais_init)
         rb = leaf_rows(trk.__targetList__, lambda r: r.getLeafNodes(), lambda l, f: getattr(l, ref_names[f]))
         ob = leaf_rows(o.targets, lambda r: r.leaves(), lambda l, f: getattr(l, f))
         for key in rb:
@@ -500,6 +502,21 @@ def gen_g18(mods):
     # similar-state pruning on every scan (pyTarget.py:371-375: AIS-updated children are never merged)
     sc = make_config("dense", seed=99, n_scans=10, radius=600.0)
     run_trace_ais(mods, sc, make_ais(sc, seed=8, equipped=0.5), "g18d_trace_ais_similar", prune_similar=True)
+    if "g18e" in sys.argv:
+        gen_g18e(mods)
+
+
+def gen_g18e(mods):
+    """The reference's default: messages no track took start preliminary tracks (aisInitialization=True; tracker.py:267-273,
+    m_of_n.py:262-280).  Scenes in which a good share of the equipped ships have no track at the start (half of the initial targets are
+    withheld from the tracker), so that AIS-started tracks get confirmed by the radar."""
+    from pymht_amd.utils.scenario import make_ais
+    for seed, name, kw in ((4321, "g18e_trace_ais_init", dict(N=3, n_scans=12, radius=700.0, T=24)),
+                           (99, "g18f_trace_ais_init_dense", dict(n_scans=10, radius=500.0, T=20))):
+        sc = make_config("dense", seed=seed, **kw)
+        ais = make_ais(sc, seed=seed + 1, equipped=0.8, p_report=0.8)
+        sc["x0"] = sc["x0"][::2].copy()                       # the tracker starts with every other ship only
+        run_trace_ais(mods, sc, ais, name, ais_init=True)
 
 
 def gen_g19(mods):

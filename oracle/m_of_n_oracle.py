@@ -109,8 +109,9 @@ class Initiator:
         self.last_timestamp = None
 
     def processMeasurements(self, radar_measurement_list, ais_measurement_list=()):
-        assert len(ais_measurement_list) == 0, "AIS initiation is out of scope of pymht_amd"
-        unused, born = self._advance_preliminary(radar_measurement_list)
+        """ais_measurement_list: the scan's AIS messages no track took (objects with time, state, mmsi): each starts a preliminary track
+        unless one with its identity exists or an existing one is too similar (m_of_n.py:262-280)."""
+        unused, born = self._advance_preliminary(radar_measurement_list, ais_measurement_list)
         unused = self._pair_with_seeds(unused, radar_measurement_list)
         z = radar_measurement_list.measurements
         self.initiators = [_Seed(z[i], radar_measurement_list.time) for i in unused]
@@ -118,7 +119,7 @@ class Initiator:
         return merge_close_targets(born, self.merge_threshold)
 
     # m_of_n.py:246-378
-    def _advance_preliminary(self, mlist):
+    def _advance_preliminary(self, mlist, ais=()):
         born, now = [], mlist.time
         z = np.array(mlist.measurements, dtype=np.float32)
         tracks = self.preliminary_tracks
@@ -130,11 +131,23 @@ class Initiator:
                 t.covariance = F.dot(t.covariance).dot(F.T) + Qm
         else:
             assert not tracks
+        have = {t.mmsi for t in tracks if t.mmsi is not None}             # m_of_n.py:262-264
+        for m in ais:                                                      # m_of_n.py:265-280
+            if m.mmsi in have:
+                continue
+            dT = now - m.time
+            Phi = pv.Phi(dT)                                               # (models/ais.py:15-20 is the same matrix)
+            state = Phi.dot(m.state)                                       # classDefinitions.py:470-475
+            cov = Phi.dot(pv.P0).dot(Phi.T) + pv.Q(dT)
+            cand = PreliminaryTrack(state, cov, m.mmsi)
+            cand.predicted_state = state
+            if not any(p.similarity(cand) <= 1.0 for p in tracks):
+                tracks.append(cand)
         pred = np.array([np.copy(t.predicted_state) for t in tracks], ndmin=2, dtype=np.float32)
         for t in tracks:
             t.predicted_state = None
         n1, n2 = len(tracks), z.shape[0]
-        if n1 == 0 or n2 == 0 or z.size == 0:
+        if n1 == 0 or (len(ais) == 0 and (n2 == 0 or z.size == 0)):      # m_of_n.py:289-292
             return np.arange(n2).tolist(), born
         delta = np.ones((n1, n2), dtype=np.float32) * np.inf
         for i in range(n1):

@@ -72,7 +72,8 @@ def test_scan_trace_replay(gold_dir, name):
     replay_oracle(os.path.join(gold_dir, name + ".npz"))
 
 
-@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense", "g18c_trace_ais_n5", "g18d_trace_ais_similar"])
+@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense", "g18c_trace_ais_n5", "g18d_trace_ais_similar",
+                                  "g18e_trace_ais_init", "g18f_trace_ais_init_dense"])      # (e, f: messages no track took start tracks, m_of_n.py:262-280)
 def test_ais_trace_replay(gold_dir, name):
     """The AIS-aided path (tracker.py:417-552; messages start no tracks: aisInitialization=False): the oracle replays the traces
     recorded from the reference bit for bit -- fused and pure-AIS children, their float64 covariances and the float64 contagion of

@@ -11,9 +11,9 @@ class OracleInitiatorAdapter:
     def __init__(self, initiator, make_list):
         self.initiator, self.make_list = initiator, make_list
 
-    def processMeasurements(self, time_, z):
+    def processMeasurements(self, time_, z, ais=()):
         return [(t.x_0, t.P_0, t.measurementNumber, t.measurement)
-                for t in self.initiator.processMeasurements(self.make_list(time_, z))]
+                for t in self.initiator.processMeasurements(self.make_list(time_, z), ais)]
 
 
 def sha(a):
@@ -152,7 +152,8 @@ def replay_oracle_ais(path):
     o = make_oracle_ais(g)
     for k in range(int(g["n_scans"])):
         p = "s%02d_" % k
-        info = o.add_scan(float(g["times"][k]), g[p + "z"], ais=ais_messages(g, k), prune_similar=bool(g["prune_similar"]))
+        info = o.add_scan(float(g["times"][k]), g[p + "z"], ais=ais_messages(g, k), prune_similar=bool(g["prune_similar"]),
+                          ais_initialization=bool(g["ais_init"]) if "ais_init" in g.files else False)
         leaves = oracle_rows([l for r in o.targets for l in r.leaves()])
         sel = oracle_rows(o.track_nodes)
         for key, v in leaves.items():
