@@ -223,7 +223,7 @@ typedef struct mht_forest_config {
  * (tracker.py:1057-1064, :1083-1090).  4-state build, n_scan <= 7 (n_scan <= 3: 8-entry path records, the ILPs stay in LDS;
  * above: 16-entry records, the ILPs run on the HBM policy).  mht_forest_set_ais hands over the messages of the NEXT scan, grouped as
  * for mht_fuse_ais; the next mht_forest_step / _step_host / _scan consumes them: radar M + nA <= max_meas (rounded up to a multiple
- * of 64).  A scan without messages needs no call.  AIS messages start no tracks here (the reference's aisInitialization=False).
+ * of 64).  A scan without messages needs no call.  Messages start tracks through the initiator (mht_initiator_set_ais).
  * Not available to members of a group or to the cluster-sharded step.
  * mht_forest_read_mmsi: identities of the nodes [first, first + count) of the layer of `scan` (host arrays out, either may be null):
  * mmsi[i] = the message node first + i was updated with (0: none; with measurement number 0 that is a child WITHOUT a radar
@@ -374,6 +374,13 @@ int mht_initiator_destroy(mht_initiator* in);
  * used dev [ceil(M/64)] uint64 or NULL: bit j set = measurement j was gated by a track and is not offered to the initiator
  * (tracker.py:266, MeasurementList.filterUnused); now = scan time stamp. */
 int mht_initiator_step(mht_initiator* in, const float* z, int32_t M, const uint64_t* used, double now);
+/* AIS messages for the initiator (Initiator.processMeasurements(radar, ais), m_of_n.py:233, :262-280): the messages of the scan it runs on
+ * next, host array in LIST order (dT = time of the scan - time of the message); the ones no track took start preliminary tracks unless a
+ * track with that identity exists or an existing one is too similar.  `used` (host, one byte per message) marks the taken ones for the
+ * stand-alone mht_initiator_step; mht_forest_scan works them out itself (tracker.py:267-270: the identities still in an association set
+ * behind the scan's pruning) and then runs the initiator behind the scan instead of next to the clustering. */
+typedef struct mht_ais_init_msg { double state[4]; double dT; int32_t mmsi; int32_t pad; } mht_ais_init_msg;
+int mht_initiator_set_ais(mht_initiator* in, const mht_ais_init_msg* msgs, int32_t nA, const uint8_t* used);
 /* The targets the last step gave birth to (host arrays, any may be NULL): x0 [n][4] (float32 values), P0 [n][16],
  * meas [n] measurementNumber (1-based index among the UNUSED measurements, 0 for a merged target) -- and the sizes of the
  * initiator's lists.  Synchronises. */

@@ -71,3 +71,17 @@ def group_messages(ais_list, leaf_time, scan_time, model):
         marr[i].state[:] = np.asarray(m.state, dtype=np.float64).tolist()
         marr[i].mmsi = int(m.mmsi)
     return garr, len(groups), marr, order
+
+
+class MhtAisInitMsg(C.Structure):
+    _fields_ = [("state", C.c_double * 4), ("dT", C.c_double), ("mmsi", C.c_int32), ("pad", C.c_int32)]
+
+
+def initiator_messages(ais_list, scan_time):
+    """The scan's messages for the initiator (m_of_n.py:265-280), in LIST order: ctypes array of MhtAisInitMsg."""
+    arr = (MhtAisInitMsg * max(len(ais_list), 1))()
+    for i, m in enumerate(ais_list):
+        arr[i].state[:] = np.asarray(m.state, dtype=np.float64).tolist()
+        arr[i].dT = float(scan_time) - float(m.time)
+        arr[i].mmsi = int(m.mmsi)
+    return arr

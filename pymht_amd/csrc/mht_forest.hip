@@ -212,8 +212,29 @@ __global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { ad
 // The end of a scan in the drop-in API path, ONE launch of one workgroup instead of three: the scan's commit (target table, report),
 // step 7 on the measurements the commit found unused (initiator_body), Tracker.initiateTarget for what it confirmed.
 static_assert(INIT_THREADS == 1024, "post_scan_kernel runs commit, initiator and admission with one block size");
+// Which of the scan's AIS messages a track took (tracker.py:267-270: the identities in an association set behind the scan's termination
+// and N-scan pruning): a target whose root moved has its set rebuilt from the surviving tree, one whose root did not move has lost
+// nothing -- either way: the identities of the SURVIVING leaves of the targets that are still alive.  Runs behind the commit.
+struct AisUsedArgs { const int32_t* mmsi; const int32_t* first; const int32_t* leaf_off; const FCounts* cnt; const AisInitMsg* msgs; int nA; unsigned char* used; };
+static __device__ void ais_used_body(const AisUsedArgs& u) {
+    const int tid = threadIdx.x;
+    for (int q = tid; q < u.nA; q += 1024) u.used[q] = 0;
+    __threadfence_block();
+    __syncthreads();
+    const int nT = u.cnt->nT;
+    for (int t = tid; t < nT; t += 1024) {
+        const int f0 = u.first[t], n = u.leaf_off[t + 1] - u.leaf_off[t];
+        for (int i = 0; i < n; ++i) {
+            const int mm = u.mmsi[f0 + i];
+            if (mm == 0) continue;
+            for (int q = 0; q < u.nA; ++q) if (u.msgs[q].mmsi == mm) { u.used[q] = 1; break; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
 __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit,
-                                                         const PublishArgs pub, const int run_init) {
+                                                         const PublishArgs pub, const int run_init, const AisUsedArgs au) {
     __shared__ int s_commit[2 * (1024 / 64) + 8];
     if (do_commit) {
         commit_body<1024>(cm, dyn, s_commit);
@@ -222,6 +243,7 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
     }
     if (!cm.hdr->error) {      // (void scan: nothing to initiate)
         if (run_init) {        // (streaming: the initiator already ran next to the scan's clustering, cluster_init_kernel)
+            if (au.nA > 0) ais_used_body(au);
             initiator_body(in);
             __threadfence_block();
             __syncthreads();
@@ -979,6 +1001,8 @@ namespace mht {
 void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now, InitArgs& a);
 void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
                          const int32_t** n, int* cap, mht_ctx** ctx);
+int initiator_ais_pending(const mht_initiator* in);
+void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned char** used);
 }
 
 // init != null (mht_forest_scan): the scan's step 7 rides in the cluster launch (cluster_init_kernel)
@@ -1365,6 +1389,13 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     InitArgs ia = {};
     char* report_dev = f->report_dev2[f->scan & 1];
     const bool init_done = f->init_ran_scan == f->scan;      // (mht_forest_scan: it ran inside this scan's cluster launch)
+    AisUsedArgs au = {};
+    if (!init_done && f->ais && initiator_ais_pending(in) > 0) {      // messages for the initiator: which of them a track took is decided here, behind the commit
+        const int nb_ = (f->scan + 1) & 1;
+        au.nA = initiator_ais_pending(in);
+        initiator_ais_ptrs(in, &au.msgs, &au.used);
+        au.mmsi = f->l_mmsi[f->scan % f->R]; au.first = f->tab[nb_].first; au.leaf_off = f->tab[nb_].leaf_off; au.cnt = f->cnt;
+    }
     if (!init_done) initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia);
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
@@ -1385,7 +1416,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     PublishArgs pub = publish_args(f);
     if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
     hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
-                       init_done ? 0 : 1);
+                       init_done ? 0 : 1, au);
     f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;
@@ -1453,7 +1484,10 @@ extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_h
         MHT_REQUIRE(ictx == ctx, "mht_forest_scan: the initiator belongs to another context");
         MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_scan: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     }
-    int rc = step_host_impl(ctx, z_host, M, false, in, now);
+    // (messages waiting for the initiator: which of them a track took is known behind the scan's pruning only -- the initiator then runs in
+    // post_scan_kernel, not next to the clustering)
+    const bool ais_init = in && initiator_ais_pending(in) > 0;
+    int rc = step_host_impl(ctx, z_host, M, false, ais_init ? nullptr : in, now);
     if (rc) return rc;
     if (!in) return mht_forest_report_begin(ctx);
     rc = forest_initiate_impl(ctx, in, nullptr, M, now, true);

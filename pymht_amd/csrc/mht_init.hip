@@ -32,6 +32,9 @@ struct mht_initiator {
     mht::InitArgs args = {};          // pointers into the arena (pstate/pstate2 ... are swapped every step)
     int flip = 0;
     void* host = nullptr; size_t host_bytes = 0;      // pinned staging for mht_initiator_born / _counts
+    int ais_pending = 0;              // messages handed in for the next run (mht_initiator_set_ais)
+    bool ais_used_valid = false;      // ... with caller-provided used flags (else: the forest computes them, or none was taken)
+    bool ais_used_by_forest = false;
 };
 
 namespace mht {
@@ -58,6 +61,9 @@ static void init_layout(mht_initiator* in, IArena& ar) {
     a.K = ar.take<float>(8 * Pc); a.pred = ar.take<float>(4 * Pc); a.tmeas = ar.take<int32_t>(Pc);
     a.born_x = ar.take<double>(4 * Bc); a.born_P = ar.take<float>(16 * Bc); a.born_flags = ar.take<uint8_t>(Bc); a.born_pd = ar.take<double>(Bc);
     a.born_meas = ar.take<int32_t>(Bc); a.born_n = ar.take<int32_t>(4);
+    a.pmmsi = ar.take<int32_t>(Pc); a.pmmsi2 = ar.take<int32_t>(Pc);
+    a.Acap = (int)Mc;
+    a.ais = ar.take<AisInitMsg>(Mc); a.ais_used = ar.take<unsigned char>(Mc); a.ais_x64 = ar.take<double>(4 * Mc);
 }
 
 // launch one scan of the initiator on the ctx stream (used: device bit mask or null)
@@ -70,9 +76,18 @@ void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigne
         t = a.pcov; a.pcov = a.pcov2; a.pcov2 = t;
         u = a.pn; a.pn = a.pn2; a.pn2 = u;
         u = a.pm; a.pm = a.pm2; a.pm2 = u;
+        u = a.pmmsi; a.pmmsi = a.pmmsi2; a.pmmsi2 = u;
     }
     in->flip ^= 1;
     a.z = z; a.M = M; a.used = used; a.now = now;
+    a.nA = in->ais_pending;               // (consumed by this run)
+    if (!in->ais_used_valid && !in->ais_used_by_forest) a.ais_used = nullptr;
+    in->ais_pending = 0; in->ais_used_valid = false; in->ais_used_by_forest = false;
+}
+int initiator_ais_pending(const mht_initiator* in) { return in->ais_pending; }
+void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned char** used) {      // the forest fills the used flags behind its commit
+    *msgs = in->args.ais; *used = const_cast<unsigned char*>(in->args.ais_used);
+    in->ais_used_by_forest = true;
 }
 
 int initiator_launch(mht_initiator* in, const float* z, int M, const unsigned long long* used, double now) {
@@ -132,6 +147,21 @@ extern "C" int mht_initiator_create(mht_ctx* ctx, mht_initiator** out, const mht
     MHT_HIP_CHECK(hipHostMalloc(&in->host, in->host_bytes, hipHostMallocDefault));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *out = in;
+    return MHT_OK;
+}
+
+// The AIS messages of the scan the initiator runs on next (Initiator.processMeasurements(radar, ais), m_of_n.py:233): host array in LIST
+// order; `used` (host, one byte per message, or null = none) marks the ones a track took -- the forest (mht_forest_scan) works that out
+// itself behind its commit and ignores it.
+extern "C" int mht_initiator_set_ais(mht_initiator* in, const mht_ais_init_msg* msgs, int32_t nA, const uint8_t* used) {
+    MHT_REQUIRE(in && nA >= 0 && (msgs || nA == 0), "mht_initiator_set_ais: null argument");
+    MHT_REQUIRE(nA <= in->args.Acap, "mht_initiator_set_ais: %d messages exceed max_meas=%d", nA, in->args.Acap);
+    static_assert(sizeof(mht_ais_init_msg) == sizeof(AisInitMsg), "ABI struct");
+    MHT_HIP_CHECK(hipSetDevice(in->ctx->device));
+    if (nA) MHT_HIP_CHECK(hipMemcpyAsync(const_cast<AisInitMsg*>(in->args.ais), msgs, (size_t)nA * sizeof(AisInitMsg), hipMemcpyHostToDevice, in->ctx->stream));
+    if (nA && used) MHT_HIP_CHECK(hipMemcpyAsync(const_cast<unsigned char*>(in->args.ais_used), used, (size_t)nA, hipMemcpyHostToDevice, in->ctx->stream));
+    in->ais_pending = nA;
+    in->ais_used_valid = nA > 0 && used != nullptr;
     return MHT_OK;
 }
 

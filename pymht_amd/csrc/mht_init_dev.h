@@ -14,6 +14,10 @@ struct InitDev {                        // device-resident state of one initiato
     int n_born, n_unused_out, pad0, pad1;
 };
 
+// An AIS message on its way to the initiator (m_of_n.py:265-280): the messages of the scan in LIST order; the ones no track took (used
+// flag 0) start preliminary tracks.
+struct AisInitMsg { double state[4]; double dT; int32_t mmsi; int32_t pad; };      // dT = time of the scan - time of the message
+
 struct InitArgs {
     InitDev* st;
     float* seeds;                       // [Mcap][2] last scan's leftovers
@@ -35,6 +39,12 @@ struct InitArgs {
     float* K;                           // [Pcap][8]
     float* pred;                        // [Pcap][4]
     int32_t* tmeas;                     // [Pcap] matched unused-list index of the track or -1
+    // AIS-started preliminary tracks (null / 0: none)
+    int32_t* pmmsi; int32_t* pmmsi2;    // [Pcap] identity of a track an AIS message started (0: a radar track), compacted with the others
+    const AisInitMsg* ais; int nA;      // this scan's messages
+    const unsigned char* ais_used;      // [nA] 1 = a track took the message (tracker.py:267-270), or null: none was taken
+    double* ais_x64;                    // [Acap][4] float64 states of the tracks started in this scan (they are float32 from the update on)
+    int Acap;
     // output: born candidates, in the reference's order
     double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
 };
@@ -215,8 +225,15 @@ static __device__ void initiator_body(const InitArgs& a) {
     __threadfence_block();
     __syncthreads();
     // ---- (1) preliminary tracks (m_of_n.py:246-378) --------------------------------------------------------------------------------
+    // AIS messages no track took (in list order): they start preliminary tracks below, and with any of them the scan is processed even
+    // without a single unused radar measurement (m_of_n.py:289-292)
+    int nAu = 0;
+    for (int q = 0; q < a.nA; ++q) nAu += (a.ais_used && a.ais_used[q]) ? 0 : 1;      // (uniform; a few dozen messages)
+    const bool frozen = (nU == 0 && nAu == 0);
     int E = 0;
-    if (n_pre > 0 && have_last) {
+    const int n_pre0 = n_pre;
+    int n_pre_all = n_pre0;
+    if (n_pre0 > 0 && have_last) {
         const double dt = a.now - last;
         // pv.Phi(dt), pv.Q(dt): float64 arithmetic cast to float32, Q then scaled by sigmaQ in float32 (models/pv.py:17-34)
         float F[16] = {1, 0, (float)dt, 0, 0, 1, 0, (float)dt, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -243,15 +260,97 @@ static __device__ void initiator_body(const InitArgs& a) {
             gemm_chain<float, float, float, 4, 2, 2>(PCt, Sinv, K);
             for (int e = 0; e < 4; ++e) a.pred[(size_t)i * 4 + e] = xp[e];
             for (int e = 0; e < 16; ++e) a.pcov[(size_t)i * 16 + e] = Pb[e];      // (covariance = P_bar until the update below)
-            if (nU == 0) continue;      // (see below: an empty list leaves state and counters alone)
+            if (frozen) continue;      // (see below: an empty list leaves state and counters alone)
             for (int e = 0; e < 8; ++e) a.K[(size_t)i * 8 + e] = K[e];
             a.tmeas[i] = -1;
         }
         __threadfence_block();
         __syncthreads();
-        // The reference returns from __processPreliminaryTracks right after the prediction when the list of unused measurements is
-        // empty (m_of_n.py:276-278): the covariances have been propagated, states, counters and the track list stay as they are.
-        if (nU > 0) {
+    }
+    // ---- (1b) messages no track took start preliminary tracks (m_of_n.py:262-280), one after the other: each is tested against every
+    //      track there is by then, the ones started a moment ago included -------------------------------------------------------------
+    if (nAu > 0) {
+        __shared__ int s_hit, s_nall;
+        if (tid == 0) s_nall = n_pre0;
+        __syncthreads();
+        for (int q = 0; q < a.nA; ++q) {
+            if (a.ais_used && a.ais_used[q]) continue;                     // (uniform)
+            const AisInitMsg m = a.ais[q];
+            if (tid == 0) s_hit = 0;
+            __syncthreads();
+            const int nall = s_nall;
+            for (int p = tid; p < n_pre0; p += INIT_THREADS) if (a.pmmsi[p] == m.mmsi) s_hit = 1;      // a track with this identity exists (m_of_n.py:262-267)
+            __syncthreads();
+            if (s_hit) { __syncthreads(); continue; }
+            // state = Phi(dT) m.state (float32 matrix x float64 vector = float64 gemv), covariance = Phi P0 Phi^T + Q (classDefinitions.py:470-475)
+            const double dT = m.dT;
+            const float Ff[16] = {1, 0, (float)dT, 0, 0, 1, 0, (float)dT, 0, 0, 1, 0, 0, 0, 0, 1};
+            double cs[4];
+            for (int r = 0; r < 4; ++r) {
+                const double p0 = (double)Ff[r * 4] * m.state[0], p1 = (double)Ff[r * 4 + 1] * m.state[1], p2 = (double)Ff[r * 4 + 2] * m.state[2], p3 = (double)Ff[r * 4 + 3] * m.state[3];
+                cs[r] = (p0 + p2) + (p1 + p3);
+            }
+            for (int p = tid; p < nall; p += INIT_THREADS) {               // PreliminaryTrack.compareSimilarity (m_of_n.py:196-201) of every track with the candidate
+                double d[4];
+                for (int e = 0; e < 4; ++e) d[e] = (p < n_pre0 ? (double)a.pstate[(size_t)p * 4 + e] : a.ais_x64[(size_t)(p - n_pre0) * 4 + e]) - cs[e];
+                float S[16], Si[16];
+                for (int e = 0; e < 16; ++e) S[e] = a.pcov[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
+                if (inv_small(S, 4, Si)) {
+                    double t[4];
+                    for (int c = 0; c < 4; ++c) t[c] = fma(d[2], (double)Si[8 + c], d[0] * (double)Si[c]) + fma(d[3], (double)Si[12 + c], d[1] * (double)Si[4 + c]);
+                    const double sim = ((t[0] * d[0] + t[1] * d[1]) + t[2] * d[2]) + t[3] * d[3];
+                    if (sim <= 1.0) s_hit = 1;
+                }
+            }
+            __syncthreads();
+            if (!s_hit) {
+                if (nall < a.Pcap && nall - n_pre0 < a.Acap) {
+                    if (tid == 0) {
+                        float Q[16], Ft[16], FP[16], Pb[16];
+                        for (int i = 0; i < 16; ++i) Q[i] = 0.f;
+                        const float q4 = (float)(dT * dT * dT * dT / 4.0) * a.sigma_q, q3 = (float)(dT * dT * dT / 3.0) * a.sigma_q, q2 = (float)(dT * dT) * a.sigma_q;
+                        Q[0] = Q[5] = q4; Q[2] = Q[8] = Q[7] = Q[13] = q3; Q[10] = Q[15] = q2;
+                        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[r * 4 + c] = Ff[c * 4 + r];
+                        gemm_chain<float, float, float, 4, 4, 4>(Ff, a.P0, FP);
+                        gemm_chain<float, float, float, 4, 4, 4>(FP, Ft, Pb);
+                        for (int e = 0; e < 16; ++e) Pb[e] += Q[e];
+                        float Ct[8], CP[8], S2[4], Sinv[4], PCt[8], K[8];
+                        for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
+                        gemm_chain<float, float, float, 2, 4, 4>(a.C, Pb, CP);
+                        gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, S2);
+                        for (int e = 0; e < 4; ++e) S2[e] += a.R[e];
+                        inv2(S2, Sinv);
+                        gemm_chain<float, float, float, 4, 4, 2>(Pb, Ct, PCt);
+                        gemm_chain<float, float, float, 4, 2, 2>(PCt, Sinv, K);
+                        for (int e = 0; e < 4; ++e) {
+                            a.ais_x64[(size_t)(nall - n_pre0) * 4 + e] = cs[e];
+                            a.pstate[(size_t)nall * 4 + e] = (float)cs[e];
+                            a.pred[(size_t)nall * 4 + e] = (float)cs[e];      // np.array(predicted_states, dtype=float32) (m_of_n.py:282-284)
+                        }
+                        for (int e = 0; e < 16; ++e) a.pcov[(size_t)nall * 16 + e] = Pb[e];
+                        for (int e = 0; e < 8; ++e) a.K[(size_t)nall * 8 + e] = K[e];
+                        a.pn[nall] = 0; a.pm[nall] = 0; a.pmmsi[nall] = m.mmsi; a.tmeas[nall] = -1;
+                        s_nall = nall + 1;
+                    }
+                } else if (tid == 0) st.overflow = 1;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        n_pre_all = s_nall;
+        __syncthreads();
+    }
+    {
+        const int n_pre = n_pre_all;      // (from here on: the tracks of this scan, AIS-started ones included)
+        // The reference returns from __processPreliminaryTracks right after the prediction when there is nothing to work on -- no unused
+        // measurement and no unused message (m_of_n.py:289-292): the covariances have been propagated, states, counters and the track
+        // list stay as they are.
+        if (n_pre > 0 && !frozen) {
+        if (nU == 0) {
+            for (int i = tid; i < n_pre; i += INIT_THREADS) a.match_row[i] = -1;
+            __threadfence_block();
+            __syncthreads();
+        } else {
         // gate: (track, unused measurement) pairs with NIS <= gamma -> edges with the Euclidean distance as cost
         const long long npairs = (long long)n_pre * nU;
         for (long long w = tid; w < npairs; w += INIT_THREADS) {
@@ -280,6 +379,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         __threadfence_block();
         __syncthreads();
         gnn_solve(a, n_pre, nU, E);
+        }
         // Kalman update of the matched tracks, counters
         for (int i = tid; i < n_pre; i += INIT_THREADS) {
             const int k = a.match_row[i];
@@ -309,10 +409,11 @@ static __device__ void initiator_body(const InitArgs& a) {
         __threadfence_block();
         __syncthreads();
     }
-    const bool frozen = (nU == 0);      // (no verdicts either: see above)
-    // verdicts, births (in track order), compaction of the surviving preliminary tracks into the second buffer
+    // verdicts (none when the scan was not processed, see above), births (in track order), compaction of the surviving preliminary tracks
+    // into the second buffer
     int n_keep = 0, n_born = 0;
     {
+        const int n_pre = n_pre_all;
         int run_keep = 0, run_born = 0;
         for (int base = 0; base < n_pre; base += INIT_THREADS) {
             const int i = base + tid;
@@ -340,6 +441,7 @@ static __device__ void initiator_body(const InitArgs& a) {
                 for (int e = 0; e < 4; ++e) a.pstate2[(size_t)p * 4 + e] = a.pstate[(size_t)i * 4 + e];
                 for (int e = 0; e < 16; ++e) a.pcov2[(size_t)p * 16 + e] = a.pcov[(size_t)i * 16 + e];
                 a.pn2[p] = a.pn[i]; a.pm2[p] = a.pm[i];
+                if (a.pmmsi) a.pmmsi2[p] = a.pmmsi[i];
             }
             if (born) {
                 const int p = offb + __popcll(bb & ((1ull << lane) - 1ull));
@@ -360,7 +462,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     int nU2 = 0;
     {
         int running = 0;
-        const bool any_match = n_pre > 0 && have_last;
+        const bool any_match = n_pre_all > 0 && nU > 0;      // (the assignment ran: match_col is this scan's)
         for (int base = 0; base < nU; base += INIT_THREADS) {
             const int k = base + tid;
             const bool free = k < nU && !(any_match && a.match_col[k] >= 0);
@@ -435,7 +537,7 @@ static __device__ void initiator_body(const InitArgs& a) {
                 if (np < a.Pcap) {
                     if (tid < 4) a.pstate2[(size_t)np * 4 + tid] = cand[tid];
                     if (tid < 16) a.pcov2[(size_t)np * 16 + tid] = a.P0[tid];
-                    if (tid == 0) { a.pn2[np] = 0; a.pm2[np] = 0; s_np = np + 1; }
+                    if (tid == 0) { a.pn2[np] = 0; a.pm2[np] = 0; if (a.pmmsi2) a.pmmsi2[np] = 0; s_np = np + 1; }
                 } else if (tid == 0) st.overflow = 1;
             }
             __threadfence_block();

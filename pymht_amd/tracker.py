@@ -7,9 +7,8 @@ prune) run as three HIP launches (+ one for the report) on the device-resident h
 the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
 
 XML result export: `getScenarioElement` / `_storeTrackerArgs` / `_storeRun` (tracker.py:1469-1545).
-AIS-aided tracking (tracker.py:394-396, :417-552): construct with `aisAided=True` (and a finite `radarRange`), then
-`addMeasurementList(scan, aisList, aisInitialization=False)`.  Not supported (raise): tracks started from AIS messages
-(`aisInitialization=True`, m_of_n.py:262-280), `dynamicWindow`.
+AIS-aided tracking (tracker.py:394-396, :417-552; tracks started from AIS messages m_of_n.py:262-280): construct with
+`aisAided=True` (and a finite `radarRange`), then `addMeasurementList(scan, aisList)`.  Not supported (raise): `dynamicWindow`.
 There is no CPU fallback: without the HIP library or without a GPU the constructor raises.
 """
 import ctypes as C
@@ -233,7 +232,7 @@ class Tracker():
         tic['_print'] = {k: v for k, v in kwargs.items() if k in ("printTime", "printCluster", "printInfo", "on_color") and v}
         self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
         if aisList is not None and len(aisList) > 0:
-            self._arm_ais(scanList, aisList, z.shape[0])
+            self._arm_ais(scanList, aisList, z.shape[0], bool(kwargs.get('aisInitialization', True)))
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
         try:
@@ -248,11 +247,11 @@ class Tracker():
         self._leaf_time = float(scanList.time)
         self._queue_report(scanList, z, aisList, tic)
 
-    def _arm_ais(self, scanList, aisList, nRadarMeas):
+    def _arm_ais(self, scanList, aisList, nRadarMeas, ais_init):
         """The AIS messages of this scan, handed to the device in the order the reference walks them (pymht_amd/ais.py).  Needs the
         folded state of the scan before (lambda_ais counts the targets, tracker.py:438), so a scan with messages does not overlap
         with its predecessor's report."""
-        from .ais import group_messages
+        from .ais import group_messages, initiator_messages
         self._drain()
         scanTime = float(scanList.time)
         assert all(float(m.time) < scanTime for m in aisList)                                   # tracker.py:180-182
@@ -262,6 +261,9 @@ class Tracker():
         if not np.isfinite(self.radarRange):
             raise ValueError("AIS-aided tracking needs a finite radarRange (lambda_ais = nTargets * P_ais / (pi * radarRange^2), tracker.py:438; "
                              "with the default inf the reference itself fails in kalman.nllr)")
+        if ais_init and self.useInitiator:      # the messages no track takes start preliminary tracks (tracker.py:267-273, m_of_n.py:262-280)
+            msgs_i = initiator_messages(aisList, scanTime)
+            _lib.check(self._lib.mht_initiator_set_ais(self.initiator.handle, C.byref(msgs_i), len(aisList), None))
         nT = len(self._tbl_)
         if nT == 0 or self._leaf_time is None:
             return                                                                               # (no leaves: nothing to fuse)
@@ -306,9 +308,8 @@ class Tracker():
         if aisList is not None and len(aisList) > 0:
             if not self._ais:
                 raise NotImplementedError("this Tracker was not made for AIS messages: pass aisAided=True to the constructor (tracker.py:417-552)")
-            if kwargs.get('aisInitialization', True):
-                raise NotImplementedError("tracks started from AIS messages (m_of_n.py:262-280) are not built: pass aisInitialization=False "
-                                          "(tracker.py:271-272)")
+            if kwargs.get('aisInitialization', True) and not self.useInitiator:
+                pass      # (no initiator: nothing starts tracks, like a reference tracker whose initiator was taken out)
         if kwargs.get('dynamicWindow', False):
             raise NotImplementedError("dynamicWindow is not supported by pymht_amd")
         m = np.asarray(scanList.measurements)

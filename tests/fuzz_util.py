@@ -101,7 +101,10 @@ def run_case_ais(seed, max_leaves=2500, budget_s=20.0):
     equipped, p_report = float(prng.choice([0.3, 0.6, 1.0])), float(prng.choice([0.4, 0.8]))
     ais = make_ais(sc, seed=seed + 5, equipped=equipped, p_report=p_report)
     rr = 1.5 * sc["radius"]
-    desc += ' AIS equipped=%.1f p=%.1f N=%d' % (equipped, p_report, N)
+    ais_init = bool(prng.uniform() < 0.6)          # the reference's default: messages no track took start tracks
+    if ais_init and prng.uniform() < 0.5:
+        sc["x0"] = sc["x0"][::2].copy()            # (half of the ships have no track at the start)
+    desc += ' AIS equipped=%.1f p=%.1f N=%d init=%d' % (equipped, p_report, N, ais_init)
     g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, eta2_ais=9.45, x0=sc["x0"], t0=sc["t0"],
              radar_range=rr, position=np.asarray(sc["centre"], dtype=np.float64), with_initiator=True, accepted=None)
     trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2, radarRange=rr, position=g["position"], aisAided=True,
@@ -122,8 +125,8 @@ def run_case_ais(seed, max_leaves=2500, budget_s=20.0):
                 break
             on = bool(prng.uniform() < 0.3)
             msgs = ais[k] if prng.uniform() < 0.85 else []
-            info = o.add_scan(float(t), z, prune_similar=on, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs])
-            trk.addMeasurementList(MeasurementList(float(t), z), AisMessageList([AisMessage(*m) for m in msgs]), aisInitialization=False, pruneSimilar=on)
+            info = o.add_scan(float(t), z, prune_similar=on, ais=[orc.AisMessage(m[0], m[1].copy(), m[2], m[3]) for m in msgs], ais_initialization=ais_init)
+            trk.addMeasurementList(MeasurementList(float(t), z), AisMessageList([AisMessage(*m) for m in msgs]), aisInitialization=ais_init, pruneSimilar=on)
             st = trk.lastScanStats
             nodes = list(trk.getTrackNodes())
             lb, tb = o.leaf_batch(), trk.leafBatch()

@@ -75,7 +75,9 @@ def _close_states(a, b):
     return bool(np.all(np.abs(a - b) <= X_REL * scale))
 
 
-@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense", "g18c_trace_ais_n5", "g18d_trace_ais_similar"])
+@pytest.mark.parametrize("name", ["g18_trace_ais_cfg1", "g18b_trace_ais_dense", "g18c_trace_ais_n5", "g18d_trace_ais_similar",
+                                  # the reference's default: messages no track took start tracks (aisInitialization=True, m_of_n.py:262-280)
+                                  "g18e_trace_ais_init", "g18f_trace_ais_init_dense"])
 def test_tracker_replays_reference_ais_trace(name, gold_dir):
     from pymht_amd.tracker import Tracker
     from pymht_amd.pyTarget import Target
@@ -96,7 +98,8 @@ def test_tracker_replays_reference_ais_trace(name, gold_dir):
             p = "s%02d_" % k
             msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
                                    zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
-            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=False, pruneSimilar=bool(g["prune_similar"]))
+            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=bool(g["ais_init"]) if "ais_init" in g.files else False,
+                                   pruneSimilar=bool(g["prune_similar"]))
             nodes = list(trk.getTrackNodes())
             assert np.array_equal([n.ID for n in nodes], g[p + "sel_ID"]), k
             assert np.array_equal([r.ID for r in trk.__targetList__], g[p + "ids"]), k
