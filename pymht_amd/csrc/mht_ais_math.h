@@ -94,8 +94,10 @@ struct AisPre {
     double Sinv[16];
     double lnc1;       // ln(lambda_ais sqrt(det(2 pi S1)))
 };
+// (a): the prediction at the message's time -- cheap; (b): S^-1 and the score constant -- two thirds of the work of a (leaf, group) pair,
+// only done when a message of the group lies inside the gate's bounding box (for a positive definite S: dz_i^2 <= nis * S_ii)
 template <typename TS>
-MHT_HD void ais_pre(const AisGroup& g, const TS* x, const float* P, double lambda_ais, AisPre& o) {
+MHT_HD void ais_pre_a(const AisGroup& g, const TS* x, const float* P, AisPre& o) {
     TS x1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {      // A.dot(x): matrix x ONE column (kalman.py:68) -> BLAS gemv order (mht_math.h::gemv_row)
@@ -111,17 +113,19 @@ MHT_HD void ais_pre(const AisGroup& g, const TS* x, const float* P, double lambd
     gemm_chain<float, float, float, 4, 4, 4>(t, at, o.P1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) o.P1[e] = o.P1[e] + g.Q1[e];
-    double S[16], S2[16];
+}
+MHT_HD void ais_pre_b(const AisGroup& g, double lambda_ais, AisPre& o) {
+    double S[16];
     const double two_pi = 6.283185307179586;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        S[e] = (double)o.P1[e] + (((e >> 2) == (e & 3)) ? (double)g.r_diag : 0.0);
-        S2[e] = two_pi * S[e];
-    }
-    inv4(S, o.Sinv);
-    double dummy[16];
-    const double det = inv4(S2, dummy);
-    o.lnc1 = log((lambda_ais * sqrt(det)) / 1.0);
+    for (int e = 0; e < 16; ++e) S[e] = (double)o.P1[e] + (((e >> 2) == (e & 3)) ? (double)g.r_diag : 0.0);
+    const double det = inv4(S, o.Sinv);      // det(2 pi S) = (2 pi)^4 det(S): the same elimination serves both (kalman.py:19 scales first: 1e-16 relative)
+    o.lnc1 = log((lambda_ais * sqrt((two_pi * two_pi) * (two_pi * two_pi) * det)) / 1.0);
+}
+template <typename TS>
+MHT_HD void ais_pre(const AisGroup& g, const TS* x, const float* P, double lambda_ais, AisPre& o) {
+    ais_pre_a<TS>(g, x, P, o);
+    ais_pre_b(g, lambda_ais, o);
 }
 
 MHT_HD double ais_nis(const AisPre& p, const double* m, double* zt) {
@@ -230,10 +234,22 @@ MHT_HD int ais_fuse_leaf(const Model& mdl, const AisGroup* groups, int nG, const
         for (int q = 0; q < g.count && !any; ++q) any = (own == 0) || (msgs[g.first + q].mmsi == own);
         if (!any) continue;
         AisPre pre;
-        ais_pre<TS>(g, x, P, lambda_ais, pre);
+        ais_pre_a<TS>(g, x, P, pre);
+        // the gate's bounding box in position (a necessary condition, widened by far more than any rounding): most (leaf, group) pairs
+        // have no message near them and stop here
+        const double bx = sqrt(eta2_ais * ((double)pre.P1[0] + (double)g.r_diag)) * 1.000001 + 1e-9;
+        const double by = sqrt(eta2_ais * ((double)pre.P1[5] + (double)g.r_diag)) * 1.000001 + 1e-9;
+        any = false;
+        for (int q = 0; q < g.count && !any; ++q) {
+            const AisMsg& m = msgs[g.first + q];
+            any = (own == 0 || m.mmsi == own) && fabs(m.state[0] - pre.x1[0]) <= bx && fabs(m.state[1] - pre.x1[1]) <= by;
+        }
+        if (!any) continue;
+        ais_pre_b(g, lambda_ais, pre);
         for (int q = 0; q < g.count; ++q) {
             const AisMsg& m = msgs[g.first + q];
             if (own != 0 && m.mmsi != own) continue;
+            if (!(fabs(m.state[0] - pre.x1[0]) <= bx && fabs(m.state[1] - pre.x1[1]) <= by)) continue;
             double zt[4];
             const double nis1 = ais_nis(pre, m.state, zt);
             if (!(nis1 <= eta2_ais)) continue;

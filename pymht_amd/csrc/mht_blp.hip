@@ -2225,7 +2225,7 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
     { const char* e = getenv("MHT_BLP_TIME_LIMIT_US"); a.time_limit = e ? atoll(e) * 100 : 0; }      // testing: wall-clock budget per cluster (10 ns ticks)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); a.force_hbm = (e && e[0] == '1') ? 1 : 0; }
     if (seam_team) {
-        const size_t tb = 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W + sizeof(TeamProblem);
+        const size_t tb = 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W;
         rc = ctx->counts.ensure(tb);
         if (rc) return rc;
         char* tp = static_cast<char*>(ctx->counts.ptr);
@@ -2233,7 +2233,6 @@ extern "C" int mht_solve_blp(mht_ctx* ctx, int32_t nHyp, int32_t nT, int32_t nRo
         a.team_list = reinterpret_cast<int32_t*>(tp);                                  // [0] = cluster 0 (memset)
         a.team_state = reinterpret_cast<TeamState*>(tp + 64);
         a.team_res = reinterpret_cast<TeamResult*>(tp + 64 + sizeof(TeamState) * TEAM_MAX);
-        a.team_prob = reinterpret_cast<TeamProblem*>(tp + 64 + sizeof(TeamState) * TEAM_MAX + sizeof(TeamResult) * TEAM_W);
         const unsigned long long inf_key = ~0ull;
         MHT_HIP_CHECK(hipMemcpyAsync(&a.team_state[0].gub, &inf_key, 8, hipMemcpyHostToDevice, ctx->stream));
     }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
     for (int m = tid; m < a.n_mnodes; m += CL_THREADS) mlabel[m] = 0x7fffffff;
     __shared__ int s_team;
     if (tid == 0) { s_edges = 0; s_changed = 0; s_pend = 0; s_team = 0; a.counts[3] = 0; a.counts[4] = 0; }
-    if (a.team_state && tid < TEAM_MAX) { a.team_state[tid].gub = ~0ull; a.team_state[tid].done = 0; a.team_state[tid].ready = 0; }
+    if (a.team_state && tid < TEAM_MAX) { a.team_state[tid].gub = ~0ull; a.team_state[tid].done = 0; }
     __syncthreads();
     int E;
     unsigned long long* rows = const_cast<unsigned long long*>(a.assoc);

@@ -224,9 +224,11 @@ static __device__ void ais_used_body(const AisUsedArgs& u) {
     const int nT = u.cnt->nT;
     for (int t = tid; t < nT; t += 1024) {
         const int f0 = u.first[t], n = u.leaf_off[t + 1] - u.leaf_off[t];
+        int last = 0;      // (the leaves of a track carry one identity, or a few: look each up once)
         for (int i = 0; i < n; ++i) {
             const int mm = u.mmsi[f0 + i];
-            if (mm == 0) continue;
+            if (mm == 0 || mm == last) continue;
+            last = mm;
             for (int q = 0; q < u.nA; ++q) if (u.msgs[q].mmsi == mm) { u.used[q] = 1; break; }
         }
     }
@@ -335,7 +337,7 @@ struct Forest {
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
     int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
     int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
-    int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
+    int32_t* team_list; TeamState* team_state; TeamResult* team_res; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
@@ -445,7 +447,6 @@ struct Forest {
         cl_owner = ar.take<int32_t>(Tcap);
         if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
         team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
-        team_prob = ar.take<TeamProblem>(TEAM_MAX);
         // (TEAM_W copies of the ILP kernel's HBM scratch: a team member of a giant cluster works on its own, mht_blp.hip)
         u = ar.take<double>((size_t)n_mnodes * TEAM_W); usage = ar.take<int32_t>((size_t)n_mnodes * TEAM_W); mark = ar.take<int32_t>((size_t)n_mnodes * TEAM_W);
         bb_snap_rows = n_mnodes > 1024 ? n_mnodes : 1024;
@@ -833,7 +834,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     const int cb = s & 1;
     const mht_nodes& out = f->layer[s % f->R];
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
-    b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state; b.team_res = f->team_res; b.team_prob = f->team_prob;
+    b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state; b.team_res = f->team_res;
     b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->ais ? f->pds : f->PD; b.pds = f->pds;      // (AIS forest: every entry of a record can be a row)
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;

@@ -113,12 +113,9 @@ struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM)
 // epilogue (nobody waits for anybody).  At most TEAM_MAX clusters per scan form teams.
 constexpr int TEAM_MIN_K = 24, TEAM_MAX = 8, TEAM_W = 32, TEAM_SEL = 256;
 struct TeamResult { double ub; int32_t status, nodes, iters, pad; int32_t sel[TEAM_SEL]; };      // what a member found (global column per target)
-struct TeamState { unsigned long long gub; int32_t done, ready, pad[12]; };                    // per team: shared incumbent key, finished members, TeamProblem filed
-// (A giant cluster -- more columns than the LDS tables hold -- runs its dual phase on HBM scratch.  The first version handed the owner's
-// reduced problem to waiting members through this block; now every member has its own copy of the HBM scratch and replicates that
-// phase too, BlpArgs::tm_sm.  Kept for the layout of the seam's scratch.)
-constexpr int TEAM_COLS = 2048;      // (= BIG_MAXH: columns of an LDS-resident cluster)
-struct TeamProblem { double ub; int32_t nH, pad; int32_t colb[TEAM_SEL + 4]; int32_t ubpos[TEAM_SEL]; int32_t gcol[TEAM_COLS]; };
+struct TeamState { unsigned long long gub; int32_t done, pad[13]; };                    // per team: shared incumbent key, finished members, TeamProblem filed
+// (A giant cluster -- more columns than the LDS tables hold -- runs its dual phase on HBM scratch: every member has its own copy of that
+// scratch and replicates the phase, BlpArgs::tm_sm.)
 
 struct ClusterArgs {
     const unsigned long long* assoc;   // [T][AW]
@@ -194,7 +191,7 @@ struct BlpArgs {
     // beyond them run on HBM scratch.  tier 0: one launch; 1: small footprint, skips clusters with more than t1_h columns / t1_k
     // targets; 2: default footprint, takes exactly those
     int cap_h, cap_r, cap_k, cap_uw, tier, t1_h, t1_k;
-    const int32_t* team_list; TeamState* team_state; TeamResult* team_res; TeamProblem* team_prob;      // teams (null: off): [TEAM_MAX], [TEAM_MAX], [TEAM_MAX][TEAM_W], (unused)
+    const int32_t* team_list; TeamState* team_state; TeamResult* team_res;      // teams (null: off): [TEAM_MAX], [TEAM_MAX], [TEAM_MAX][TEAM_W]
     // HBM scratch of team members: u / usage / mark hold TEAM_W copies tm_sm elements apart, the per-member tables (best_h ... bb_min) TEAM_W
     // copies tm_ss elements apart (copy 0 = the owner's); 0: no copies, a cluster on HBM scratch is its owner's alone
     size_t tm_sm, tm_ss;
