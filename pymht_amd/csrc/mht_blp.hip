@@ -2058,6 +2058,96 @@ __device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, cons
     }
 }
 
+// ---- light pass (groups of sectors): one WAVEFRONT per multi-target cluster tries the certificate of round 0 ---------------------------
+// 96 % of the headline stream's ILPs are certified in the dual phase's first round, at zero prices: every member's cheapest column
+// (lowest index among equals) and no measurement node used by two of them -- conflict-free minimisers with nothing priced are optimal.
+// That test needs no LDS tables and no workgroup: a wavefront reads the members' costs, the eight rows of the K minimisers (lane =
+// (member, level)) and compares them; a certified cluster is finished right here (selection, termination, prune decision, surviving
+// leaf ranges -- what blp_singles does for a lone target), everything else goes to the list the full solver works through in a second,
+// narrow launch (BlpArgs::big_list).  The 155 KB workgroups, one per CU, then carry the few clusters that need them instead of every
+// cluster of every sector.  Results are the full solver's: same minimisers, same tie-break, status CERTIFIED after 0 rounds.
+constexpr int LIGHT_MAXK = 8;
+__device__ __forceinline__ void blp_light(const BlpArgs& a, const int bx, const int gx, const int nMulti) {
+    const int lane = threadIdx.x & 63;
+    const int gw = bx * (BLP_THREADS / 64) + (threadIdx.x >> 6), nw = gx * (BLP_THREADS / 64);
+    for (int i = gw; i < nMulti; i += nw) {
+        const int c = a.multi_list[i];
+        const int p0 = a.cl_ptr[c], K = a.cl_ptr[c + 1] - p0;
+        if (K > LIGHT_MAXK || a.pds != 8 || a.force_hbm) {
+            if (lane == 0) a.big_list[atomicAdd(a.big_count, 1)] = c;
+            continue;
+        }
+        // lane k < K holds member k: its target record first (one round trip for all members) ...
+        const int tk = a.cl_members[p0 + (lane < K ? lane : 0)];
+        const TgtPre pre = load_target(a, tk);
+        // ... then every member's cheapest column: the first 64 columns of all members in ONE batch of loads (a member has ~55), the
+        // rest in a loop; (value, lowest index) like compute_minimisers
+        double v[LIGHT_MAXK];
+        int cbk[LIGHT_MAXK], cek[LIGHT_MAXK];
+#pragma unroll
+        for (int k = 0; k < LIGHT_MAXK; ++k) {
+            cbk[k] = __shfl(pre.cb, k < K ? k : 0);
+            cek[k] = __shfl(pre.ce, k < K ? k : 0);
+            const int h = cbk[k] + lane;
+            v[k] = a.cost[(k < K && h < cek[k]) ? h : cbk[0]];
+        }
+        int best = -1;
+#pragma unroll
+        for (int k = 0; k < LIGHT_MAXK; ++k) {
+            if (k >= K) break;
+            const int h0 = cbk[k] + lane;
+            double bv = (h0 < cek[k]) ? v[k] : DINF;
+            int bi = (h0 < cek[k]) ? h0 : -1;
+            for (int h = h0 + 64; h < cek[k]; h += 64) {
+                const double w = a.cost[h];
+                if (bi < 0 || w < bv) { bv = w; bi = h; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == k) best = bi;
+        }
+        // rows of the minimisers: lane = member * 8 + level; a node used by two different members = conflict
+        const int mk = lane >> 3;
+        const int hk = __shfl(best, mk < K ? mk : 0);
+        int e = -1;
+        if (mk < K && hk >= 0) e = a.path[(size_t)hk * 8 + (lane & 7)];
+        // (issued with the row loads: what the sweep of the survivors needs of every member's first 64 children)
+        int va[LIGHT_MAXK];
+#pragma unroll
+        for (int k = 0; k < LIGHT_MAXK; ++k) {
+            const int jk = __shfl(pre.j, k < K ? k : 0);
+            va[k] = (k < K) ? sweep_prefetch(a, jk, cbk[k], cek[k], lane) : -1;
+        }
+        bool clash = false;
+        for (int q = 0; q < K * 8; ++q) {
+            const int eq = __shfl(e, q);
+            clash = clash || (eq >= 0 && eq == e && (q >> 3) != mk);
+        }
+        if (__any(clash) || __any(lane < K && best < 0)) {
+            if (lane == 0) a.big_list[atomicAdd(a.big_count, 1)] = c;
+            continue;
+        }
+        // certified: every member is finished like a lone target -- lane k its member's termination / prune decision / report row
+        // (finish_target is per-thread code), then the survivor sweeps, a wavefront pass per member
+        int key = KEY_DEAD;
+        if (lane < K) {
+            a.sel[tk] = best;
+            if (a.sel_rel) a.sel_rel[tk] = best - pre.cb;
+            key = finish_target(a, tk, best, pre, true);
+        }
+#pragma unroll
+        for (int k = 0; k < LIGHT_MAXK; ++k) {
+            if (k >= K) break;
+            sweep_survivors(a, __shfl(tk, k), __shfl(pre.j, k), cbk[k], cek[k], __shfl(key, k), va[k], lane);
+        }
+        if (lane == 0) { a.cl_status[c] = MHT_BLP_CERTIFIED; a.cl_iters[c] = 0; a.cl_nodes[c] = 0; }
+    }
+}
+
 // stage stamps of the scan (DevStatus::t, forest only): [2] = start of the first ILP launch, [4] = end of the last ILP workgroup
 __device__ __forceinline__ void blp_stamp_begin(const BlpArgs& a, int bx) {
     if (a.status && bx == 0 && threadIdx.x == 0) {
@@ -2088,6 +2178,25 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_batch_kernel(const PBatch av)
     blp_stamp_begin(a, bx);
     blp_body(a, lds, bx, gridDim.x);
     blp_stamp_end(a);
+}
+
+// the light pass of a group of sectors (no dynamic LDS: many workgroups per CU), followed by blp_batch_kernel on tier-2 argument blocks
+__global__ __launch_bounds__(BLP_THREADS) void blp_light_batch_kernel(const PBatch av) {
+    BlpArgs a;
+    const int n = gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int sector = lin % n, bx = lin / n;
+    load_args(a, static_cast<const BlpArgs*>(av.p[sector]));
+    blp_stamp_begin(a, bx);
+    if (!(a.status && a.status->overflow)) {
+        blp_light(a, bx, gridDim.x, a.counts[1]);
+        blp_singles(a, bx, gridDim.x, a.counts[2]);
+    }
+    blp_stamp_end(a);
+}
+int launch_blp_light_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x) {
+    hipLaunchKernelGGL(blp_light_batch_kernel, dim3(grid_x, n_sectors), dim3(BLP_THREADS), 0, ctx->stream, av);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
 }
 
 // Cluster-sharded trackers (several devices hold identical forests and solve disjoint sets of clusters): after the selections have

@@ -1191,6 +1191,7 @@ struct mht_group {
     BlpArgs* bl0 = nullptr;       // [n][period]: one launch, default footprint
     size_t blp_lds[3] = {0, 0, 0};
     bool two_tier = false;        // development: MHT_BLP_TWO_TIER=1
+    bool light = false;           // ILPs of a group: wavefront-per-cluster round-0 pass first (mht_blp.hip: blp_light), the full solver for what it leaves
     bool counted = false;         // the members' in_groups counters include this group
     bool wave = true;             // grow launch: wavefront per target (MHT_FG_WAVE=0: the workgroup-per-target kernel of the one-sector launch)
 };
@@ -1237,6 +1238,9 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     BlpArgs* hbl = new BlpArgs[(size_t)n * P * 2];
     BlpArgs* hbl0 = new BlpArgs[(size_t)n * P];
     { const char* e = getenv("MHT_BLP_TWO_TIER"); g->two_tier = e && e[0] == '1'; }
+    // (measured, headline config, two groups: 16 sectors 56.7 k -> 72.2 k scans/s with the light pass, 4 sectors 40.6 k -> 36.1 k: the second
+    // launch costs more than the narrow one saves while the full solver's workgroups still fit the machine in two rounds)
+    { const char* e = getenv("MHT_BLP_LIGHT"); g->light = e ? (e[0] != '0') : (n >= 6); }
     // grow launch of the group: wavefront per target from eight sectors on (measured, headline config: 4 sectors 49 us workgroup-
     // per-target vs 54 us; 16 sectors 136 vs 121 us -- the wavefront variant costs 5.6 us per further sector, the other 7.2)
     { const char* e = getenv("MHT_FG_WAVE"); g->wave = e ? (e[0] != '0') : (n >= 8); }
@@ -1362,7 +1366,10 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     }
     // ILPs in two LDS tiers: the small footprint (several workgroups per CU) takes the clusters that fit it and the single-target
     // clusters, a narrow launch with the default footprint takes the few that do not
-    if (g->two_tier) {
+    if (g->light && !g->two_tier) {
+        if (!rc) rc = launch_blp_light_batch(c0, bb, n, grid_b);
+        if (!rc) rc = launch_blp_batch(c0, bb2, n, 24, g->blp_lds[1]);
+    } else if (g->two_tier) {
         if (!rc) rc = launch_blp_batch(c0, bb, n, grid_b, g->blp_lds[0]);
         if (!rc) rc = launch_blp_batch(c0, bb2, n, 24, g->blp_lds[1]);
     } else {

@@ -252,6 +252,7 @@ int launch_fgrow_batch(mht_ctx* ctx, const FBatch& b, int n_sectors, int grid_x,
 int launch_cluster_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int Tcap, int n_mnodes);
 int launch_blp_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x, size_t lds);
 size_t blp_set_tier(BlpArgs& a, int tier);
+int launch_blp_light_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int grid_x);
 void fill_model(GateArgs& a, const mht_model* m);
 void fill_model_only(Model& o, const mht_model* m);
 struct InitArgs;

@@ -32,24 +32,27 @@ def _same_state(a, b, what):
         assert a.lastScanStats[k] == b.lastScanStats[k], (what, k)
 
 
-def test_four_headline_sectors_batched_equal_four_single_trackers():
-    """cfg4's workload on one device: 4 x (500 targets, ~500 measurements/scan, N-scan 5) through the drop-in API, with the
-    initiator giving birth to tracks (so deferred and immediate commits both occur inside the batch)."""
+@pytest.mark.parametrize("n_sec,n_scans", [(4, 9), (16, 7)])
+def test_headline_sectors_batched_equal_single_trackers(n_sec, n_scans):
+    """cfg4's workload on one device: n x (500 targets, ~500 measurements/scan, N-scan 5) through the drop-in API, with the
+    initiator giving birth to tracks (so deferred and immediate commits both occur inside the batch).  16 sectors in one group take the
+    wavefront-per-target grow kernel and the light ILP pass (wavefront per cluster, round-0 certificate) in front of the full solver:
+    every sector must come out as its own single tracker does."""
     from pymht_amd.sectors import SectorGroup
     from pymht_amd.utils.classDefinitions import MeasurementList
-    scs = _sectors(4, 9)
+    scs = _sectors(n_sec, n_scans)
     solo = [_tracker(sc) for sc in scs]
     grp_t = [_tracker(sc) for sc in scs]
     grp = SectorGroup(grp_t)
-    for k in range(9):
+    for k in range(n_scans):
         lists = [MeasurementList(float(sc["times"][k]), sc["scans"][k]) for sc in scs]
         for t, sl in zip(solo, lists):
             t.addMeasurementList(sl)
         grp.addMeasurementLists(lists)
-        for q in range(4):
+        for q in range(n_sec):
             _same_state(grp_t[q], solo[q], "scan %d sector %d" % (k, q))
     assert solo[0].lastScanStats["L"] > 10000 and solo[0].lastScanStats["ilp"] > 10      # the headline regime
-    for q in range(4):
+    for q in range(n_sec):
         la, lb = grp_t[q].leafBatch(), solo[q].leafBatch()
         for key in la:
             if key != "node":      # node indices are handles (block taken with an atomic)
