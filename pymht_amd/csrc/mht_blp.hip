@@ -1977,17 +1977,15 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [cap_uw]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)a.cap_uw * 8);                   // sizeof(Red) padded to RED_SLOT
     if (a.status && a.status->overflow) return;
-    const int nMulti = a.counts[1], nSingle = a.counts[2];
-    if (a.tier == 2) {            // what tier 1 left (the single-target clusters went with tier 1)
-        const int nBig = *a.big_count;
-        for (int i = bx; i < nBig; i += gx) solve_cluster(a, a.big_list[i], uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT);
-        return;
-    }
+    // tier 2: what the first launch left (big_list; the single-target clusters went with that launch) -- the same staged loop over that list
+    const bool rest = a.tier == 2;
+    const int32_t* work = rest ? a.big_list : a.multi_list;
+    const int nMulti = rest ? *a.big_count : a.counts[1], nSingle = rest ? 0 : a.counts[2];
     // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- cluster c is solved
     // where c % shard_n == shard_i, a single-target cluster where its target index says so; see blp_epilogue_kernel)
     // teams (mht_kernels.h: TEAM_*): the launch's workgroups without a cluster of their own (block index >= nMulti) are dealt out to
     // the clusters of the team list; member 0 of a team is the workgroup that owns the cluster anyway
-    const bool teams_on = a.team_list && a.tier == 0 && a.shard_n <= 1 && gx > nMulti;
+    const bool teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
     const int nTeam = teams_on ? a.counts[5] : 0;
     const int nIdle = gx - nMulti;
     auto team_W = [&](int ti) { const int w = 1 + (nIdle - ti + nTeam - 1) / nTeam; return w < TEAM_W ? w : TEAM_W; };
@@ -1999,7 +1997,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
         Team tm = Team{0, 1, nullptr};
         if (stage == 0) {
             if (own_i >= nMulti) { stage = 1; continue; }
-            c = a.multi_list[own_i];
+            c = work[own_i];
             own_i += gx;
             if (a.shard_n > 1 && (a.cl_owner ? a.cl_owner[c] : c % a.shard_n) != a.shard_i) continue;
             if (nTeam > 0 && a.cl_ptr[c + 1] - a.cl_ptr[c] >= TEAM_MIN_K)

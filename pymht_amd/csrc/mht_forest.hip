@@ -1368,7 +1368,7 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
     // clusters, a narrow launch with the default footprint takes the few that do not
     if (g->light && !g->two_tier) {
         if (!rc) rc = launch_blp_light_batch(c0, bb, n, grid_b);
-        if (!rc) rc = launch_blp_batch(c0, bb2, n, 24, g->blp_lds[1]);
+        if (!rc) rc = launch_blp_batch(c0, bb2, n, 8 + TEAM_W, g->blp_lds[1]);      // (the workgroups without a cluster join the teams of the giant ones)
     } else if (g->two_tier) {
         if (!rc) rc = launch_blp_batch(c0, bb, n, grid_b, g->blp_lds[0]);
         if (!rc) rc = launch_blp_batch(c0, bb2, n, 24, g->blp_lds[1]);
