@@ -62,7 +62,8 @@ def test_headline_sectors_batched_equal_single_trackers(n_sec, n_scans):
         t.close()
 
 
-def test_group_raw_replay_uneven_sectors():
+@pytest.mark.parametrize("light", ["0", "1"])
+def test_group_raw_replay_uneven_sectors(light, monkeypatch):
     """Raw C-ABI replay (nothing fetched between the scans: every commit rides in the next batched grow launch): sectors of
     different sizes, one of them with empty scans in between, compared with single-forest replays at the end."""
     import torch
@@ -70,6 +71,7 @@ def test_group_raw_replay_uneven_sectors():
     from pymht_amd.sectors import SectorGroup
     from pymht_amd.tracker import _REPORT_DTYPE
     from pymht_amd.utils.scenario import make_scenario
+    monkeypatch.setenv("MHT_BLP_LIGHT", light)      # (the light ILP pass of a group, forced on / off whatever the group's size)
     params = [dict(T=60, radius=500.0, lambda_phi=3e-5), dict(T=7, radius=300.0, lambda_phi=1e-5), dict(T=200, radius=2500.0, lambda_phi=2e-6)]
     scs = []
     for q, pr in enumerate(params):
@@ -175,11 +177,13 @@ def test_value_table_generations_with_similar_state_pruning(monkeypatch):
     small.close()
 
 
-def test_grouped_sectors_with_similar_state_pruning():
+@pytest.mark.parametrize("light", ["0", "1"])
+def test_grouped_sectors_with_similar_state_pruning(light, monkeypatch):
     """Similar-state pruning (tracker.py:230-231) inside a group: members 0 and 2 prune on most scans, members 1 and 3 never; every
     member must end up exactly where a single tracker with the same switch sequence does."""
     from pymht_amd.sectors import SectorGroup
     from pymht_amd.utils.classDefinitions import MeasurementList
+    monkeypatch.setenv("MHT_BLP_LIGHT", light)
     n_scans, S = 14, 4
     scs = _sectors(S, n_scans, name="cfg2")
     solo = [_tracker(sc) for sc in scs]
