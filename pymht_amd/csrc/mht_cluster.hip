@@ -429,7 +429,7 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_init_kernel(const ClusterA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x == 1) {
         if ((a.status && a.status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
-        initiator_body(in);
+        initiator_body<false>(in);      // (a scan with messages for the initiator runs it behind the scan: mht_forest_scan)
         return;
     }
     cluster_body<false>(a, smem);

@@ -235,6 +235,7 @@ static __device__ void ais_used_body(const AisUsedArgs& u) {
     __threadfence_block();
     __syncthreads();
 }
+template <bool AIS>
 __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit,
                                                          const PublishArgs pub, const int run_init, const AisUsedArgs au) {
     __shared__ int s_commit[2 * (1024 / 64) + 8];
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
     }
     if (!cm.hdr->error) {      // (void scan: nothing to initiate)
         if (run_init) {        // (streaming: the initiator already ran next to the scan's clustering, cluster_init_kernel)
-            if (au.nA > 0) ais_used_body(au);
-            initiator_body(in);
+            if (AIS && au.nA > 0) ais_used_body(au);
+            initiator_body<AIS>(in);
             __threadfence_block();
             __syncthreads();
         }
@@ -1423,8 +1424,12 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     // the report goes to the host from this launch, or -- streaming: mht_forest_scan -- with the next scan's grow launch
     PublishArgs pub = publish_args(f);
     if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
-    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
-                       init_done ? 0 : 1, au);
+    if (au.nA > 0 || ia.nA > 0)
+        hipLaunchKernelGGL(post_scan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
+                           init_done ? 0 : 1, au);
+    else
+        hipLaunchKernelGGL(post_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
+                           init_done ? 0 : 1, au);
     f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
     f->commit_pending = false;

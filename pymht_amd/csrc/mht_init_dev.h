@@ -194,6 +194,9 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
 
 // One scan of the initiator, by ONE workgroup of INIT_THREADS threads (initiator_kernel; the forest runs it inside post_scan_kernel,
 // between the scan's commit and the admission of the new targets).
+// AIS = false compiles the seeding phase (1b) out: the kernels on the path of every streamed scan (cluster_init_kernel; post_scan_kernel
+// without messages) keep the register budget they had -- 1024 threads leave 128 registers, the phase's matrices spill 400 bytes per lane.
+template <bool AIS = true>
 static __device__ void initiator_body(const InitArgs& a) {
     __shared__ int s_cnt[8], s_scan[INIT_THREADS / 64 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -228,7 +231,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     // AIS messages no track took (in list order): they start preliminary tracks below, and with any of them the scan is processed even
     // without a single unused radar measurement (m_of_n.py:289-292)
     int nAu = 0;
-    for (int q = 0; q < a.nA; ++q) nAu += (a.ais_used && a.ais_used[q]) ? 0 : 1;      // (uniform; a few dozen messages)
+    if (AIS) for (int q = 0; q < a.nA; ++q) nAu += (a.ais_used && a.ais_used[q]) ? 0 : 1;      // (uniform; a few dozen messages)
     const bool frozen = (nU == 0 && nAu == 0);
     int E = 0;
     const int n_pre0 = n_pre;
@@ -269,7 +272,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     }
     // ---- (1b) messages no track took start preliminary tracks (m_of_n.py:262-280), one after the other: each is tested against every
     //      track there is by then, the ones started a moment ago included -------------------------------------------------------------
-    if (nAu > 0) {
+    if (AIS && nAu > 0) {
         __shared__ int s_hit, s_nall;
         if (tid == 0) s_nall = n_pre0;
         __syncthreads();
@@ -286,18 +289,18 @@ static __device__ void initiator_body(const InitArgs& a) {
             const double dT = m.dT;
             const float Ff[16] = {1, 0, (float)dT, 0, 0, 1, 0, (float)dT, 0, 0, 1, 0, 0, 0, 0, 1};
             double cs[4];
-            for (int r = 0; r < 4; ++r) {
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {
                 const double p0 = (double)Ff[r * 4] * m.state[0], p1 = (double)Ff[r * 4 + 1] * m.state[1], p2 = (double)Ff[r * 4 + 2] * m.state[2], p3 = (double)Ff[r * 4 + 3] * m.state[3];
                 cs[r] = (p0 + p2) + (p1 + p3);
             }
             for (int p = tid; p < nall; p += INIT_THREADS) {               // PreliminaryTrack.compareSimilarity (m_of_n.py:196-201) of every track with the candidate
                 double d[4];
-                for (int e = 0; e < 4; ++e) d[e] = (p < n_pre0 ? (double)a.pstate[(size_t)p * 4 + e] : a.ais_x64[(size_t)(p - n_pre0) * 4 + e]) - cs[e];
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = (p < n_pre0 ? (double)a.pstate[(size_t)p * 4 + e] : a.ais_x64[(size_t)(p - n_pre0) * 4 + e]) - cs[e];
                 float S[16], Si[16];
-                for (int e = 0; e < 16; ++e) S[e] = a.pcov[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) S[e] = a.pcov[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
                 if (inv_small(S, 4, Si)) {
                     double t[4];
-                    for (int c = 0; c < 4; ++c) t[c] = fma(d[2], (double)Si[8 + c], d[0] * (double)Si[c]) + fma(d[3], (double)Si[12 + c], d[1] * (double)Si[4 + c]);
+                    _Pragma("unroll") for (int c = 0; c < 4; ++c) t[c] = fma(d[2], (double)Si[8 + c], d[0] * (double)Si[c]) + fma(d[3], (double)Si[12 + c], d[1] * (double)Si[4 + c]);
                     const double sim = ((t[0] * d[0] + t[1] * d[1]) + t[2] * d[2]) + t[3] * d[3];
                     if (sim <= 1.0) s_hit = 1;
                 }
@@ -307,28 +310,28 @@ static __device__ void initiator_body(const InitArgs& a) {
                 if (nall < a.Pcap && nall - n_pre0 < a.Acap) {
                     if (tid == 0) {
                         float Q[16], Ft[16], FP[16], Pb[16];
-                        for (int i = 0; i < 16; ++i) Q[i] = 0.f;
+                        _Pragma("unroll") for (int i = 0; i < 16; ++i) Q[i] = 0.f;
                         const float q4 = (float)(dT * dT * dT * dT / 4.0) * a.sigma_q, q3 = (float)(dT * dT * dT / 3.0) * a.sigma_q, q2 = (float)(dT * dT) * a.sigma_q;
                         Q[0] = Q[5] = q4; Q[2] = Q[8] = Q[7] = Q[13] = q3; Q[10] = Q[15] = q2;
-                        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[r * 4 + c] = Ff[c * 4 + r];
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ft[r * 4 + c] = Ff[c * 4 + r];
                         gemm_chain<float, float, float, 4, 4, 4>(Ff, a.P0, FP);
                         gemm_chain<float, float, float, 4, 4, 4>(FP, Ft, Pb);
-                        for (int e = 0; e < 16; ++e) Pb[e] += Q[e];
+                        _Pragma("unroll") for (int e = 0; e < 16; ++e) Pb[e] += Q[e];
                         float Ct[8], CP[8], S2[4], Sinv[4], PCt[8], K[8];
-                        for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
+                        _Pragma("unroll") for (int r = 0; r < 2; ++r) for (int c = 0; c < 4; ++c) Ct[c * 2 + r] = a.C[r * 4 + c];
                         gemm_chain<float, float, float, 2, 4, 4>(a.C, Pb, CP);
                         gemm_chain<float, float, float, 2, 4, 2>(CP, Ct, S2);
-                        for (int e = 0; e < 4; ++e) S2[e] += a.R[e];
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) S2[e] += a.R[e];
                         inv2(S2, Sinv);
                         gemm_chain<float, float, float, 4, 4, 2>(Pb, Ct, PCt);
                         gemm_chain<float, float, float, 4, 2, 2>(PCt, Sinv, K);
-                        for (int e = 0; e < 4; ++e) {
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
                             a.ais_x64[(size_t)(nall - n_pre0) * 4 + e] = cs[e];
                             a.pstate[(size_t)nall * 4 + e] = (float)cs[e];
                             a.pred[(size_t)nall * 4 + e] = (float)cs[e];      // np.array(predicted_states, dtype=float32) (m_of_n.py:282-284)
                         }
-                        for (int e = 0; e < 16; ++e) a.pcov[(size_t)nall * 16 + e] = Pb[e];
-                        for (int e = 0; e < 8; ++e) a.K[(size_t)nall * 8 + e] = K[e];
+                        _Pragma("unroll") for (int e = 0; e < 16; ++e) a.pcov[(size_t)nall * 16 + e] = Pb[e];
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) a.K[(size_t)nall * 8 + e] = K[e];
                         a.pn[nall] = 0; a.pm[nall] = 0; a.pmmsi[nall] = m.mmsi; a.tmeas[nall] = -1;
                         s_nall = nall + 1;
                     }

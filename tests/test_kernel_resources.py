@@ -17,9 +17,11 @@ CSRC = os.path.join(ROOT, "pymht_amd", "csrc")
 BUDGET = {
     "mht_gate.hip": {"grow_kernel": (0, 128)},
     "mht_blp.hip": {"blp_kernel": (32, 256)},
-    "mht_cluster.hip": {"cluster_kernel": (0, 128)},
-    "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 128), "post_scan_kernel": (64, 128)},      # (1024 threads: 4 waves per SIMD; one workgroup:
-    # the initiator's small dense inverses index their scratch arrays dynamically)
+    # cluster_init_kernel / post_scan_kernel<false> are on the path of every streamed scan: the initiator in them is compiled WITHOUT the AIS
+    # seeding phase (its matrices spill 400 bytes per lane at the 128 registers 1024 threads leave); <true> only runs on scans with messages
+    "mht_cluster.hip": {"cluster_kernel": (0, 128), "cluster_init_kernel": (160, 128)},
+    "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 128), "post_scan_kernelILb0": (64, 128), "post_scan_kernelILb1": (512, 128)},
+    # (1024 threads: 4 waves per SIMD; one workgroup: the initiator's small dense inverses index their scratch arrays dynamically)
     "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128)},      # 3 / 4 workgroups per CU
 }
 
