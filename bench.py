@@ -446,14 +446,15 @@ def main():
     def run_multi(S):
         from pymht_amd.sectors import SectorGroup
         Km = min(K, 200 if S <= 4 else 100)
-        scs, brs, sts = [sc], [births], [stats]
+        scs, brs, sts, fins = [sc], [births], [stats], [None]      # (sector 0 = the main sector, replayed to W + K scans there: its final state is of another scan)
         for q in range(1, S):
             sq = make_config(args.config, seed=parallel.sector_seed(5446, rank) + 17 * q, n_scans=W + Km,
                              centre=(parallel.sector_centre(rank)[0], 20000.0 * q), confine=True)
-            bq, stq, _, _, _ = prepass(sq, local)
+            bq, stq, fq, _, _ = prepass(sq, local)
             scs.append(sq)
             brs.append(bq)
             sts.append(stq)
+            fins.append(fq)
         # the sectors form NG groups, each on its own HIP stream: one batched launch set per group and scan; two groups' chains of
         # dependent kernels interleave on the device (while one group's ILP kernel holds a workgroup per CU, the other's grow runs)
         NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "2")), S))
@@ -490,9 +491,12 @@ def main():
         barrier()
         okm = True
         t_grow = []
-        for r in rps:
-            repm, _ = r.report()
+        for q, r in enumerate(rps):
+            repm, recm = r.report()
             okm = okm and repm.error == 0
+            if fins[q] is not None:      # the sector must end where its own single tracker ended (same scans, same births): selections of every live track
+                gotm = [(int(x["id"]), int(x["sel_meas"])) for x in recm if int(x["status"]) == 0]
+                okm = okm and gotm == fins[q]
             t_grow.append(repm.t_process * 1e-8)      # device stamps of the LAST scan's launches: grow start -> cluster start of this sector's group
         for gq in grps:
             gq.close()

@@ -51,6 +51,7 @@ struct CommitArgs {
     const unsigned* vcount;        // value ids handed out by the covariance table of the forest (mht_vtab.h), published in hint[1]
     unsigned long long* hint;      // host-mapped word or null: {scan, targets alive after it}, so that the host can size the next grids
                                    // without fetching a report
+    int32_t* log;                  // development: 16 words per scan (ring of 64 scans), read with mht_forest_debug_read("commit_log")
 };
 
 // Target side of termination + N-scan pruning (tracker.py:353-381, :1219-1231): compact the target table, move the
@@ -189,6 +190,12 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
             const unsigned long long to = (t3 && t3 < t2) ? t3 : t2;      // the optimisation stage starts with similar-state pruning when it ran
             auto ticks = [](unsigned long long b, unsigned long long e) { return (e > b && e - b < 0x7fffffffull) ? (int32_t)(e - b) : 0; };
             h.t_process = ticks(t0, t1); h.t_cluster = ticks(t1, to); h.t_optim = ticks(to, t4); h.t_scan = ticks(t0, t4);
+        }
+        if (a.log) {
+            int32_t* g = a.log + (dyn.scan & 63) * 16;
+            g[0] = dyn.scan; g[1] = nT; g[2] = nAlive; g[3] = L_in; g[4] = nCh; g[5] = Lnext; g[6] = nC; g[7] = n_ilp;
+            g[8] = s_branched; g[9] = s_limit; g[10] = s_itmax; g[11] = e_over; g[12] = a.cl_counts[2]; g[13] = a.cl_counts[5];
+            g[14] = a.status->n_dead; g[15] = dyn.M;
         }
         a.cnt->L_in = L_in;
         a.cnt->n_children = nCh;

@@ -341,7 +341,7 @@ struct Forest {
     int32_t* team_list; TeamState* team_state; TeamResult* team_res; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
-    int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
+    int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; int32_t* commit_log; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
@@ -456,7 +456,7 @@ struct Forest {
         best_h = ar.take<int32_t>(S); bb_ch = ar.take<int32_t>(S); bb_best = ar.take<int32_t>(S); bb_last_idx = ar.take<int32_t>(S);
         best_rc = ar.take<double>(S); bb_cost = ar.take<double>(S); bb_uused = ar.take<double>(S); bb_last_rc = ar.take<double>(S);
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
-        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32 + 16 * 4000);
+        sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32 + 16 * 4000); commit_log = ar.take<int32_t>(64 * 16);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
         new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
         w_root_scan = ar.take<int32_t>(Tcap); w_root_node = ar.take<int32_t>(Tcap); w_root_cnllr = ar.take<double>(Tcap); w_root_f32 = ar.take<uint8_t>(Tcap);
@@ -892,6 +892,7 @@ static void fill_commit(const Forest* f, int s, CommitArgs& p) {
     p.used_bytes = f->used_bytes[s & 1]; p.used_words = reinterpret_cast<unsigned long long*>(f->report_dev2[s & 1] + f->used_off);
     p.hdr = reinterpret_cast<ReportHeader*>(f->report_dev2[s & 1]); p.hint = f->hint_dev; p.vcount = f->vt.count;
     p.rec = reinterpret_cast<mht_target_report*>(f->report_dev2[s & 1] + f->rec_off);
+    p.log = f->commit_log;
 }
 
 // Host-side bookkeeping of a step.  begin: every check that can fail comes BEFORE the scan counter moves (a refused step must not
@@ -1788,6 +1789,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "vcount")) { src = f->vt.count; avail = 4; }                                 // value ids handed out (current generation)
     else if (!strcmp(name, "cov")) { src = f->layer[f->scan % f->R].cov; avail = (size_t)f->Ncap * 4; }     // keys of the newest layer's nodes
     else if (!strcmp(name, "grow_dbg")) { src = f->grow_dbg; avail = (32 + 16 * 4000) * 8; }
+    else if (!strcmp(name, "commit_log")) { src = f->commit_log; avail = 64 * 16 * 4; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     else if (!strcmp(name, "path")) { src = f->path[f->scan & 1]; avail = (size_t)f->pds * f->Ncap * 4; }      // records of the newest layer
     else if (!strcmp(name, "cost")) { src = f->cost; avail = (size_t)f->Ncap * 8; }
