@@ -35,6 +35,7 @@ extern "C" int mht_create(mht_ctx** out, int device, void* stream) {
         return MHT_E_HIP;
     }
     (void)hipMemset(ctx->status, 0, sizeof(mht::DevStatus));
+    (void)hipStreamSynchronize(nullptr);      // (null-stream work: a non-blocking `stream` would not wait for it)
     *out = ctx;
     return MHT_OK;
 }

@@ -39,7 +39,10 @@ struct Scratch {
         bytes = 0;
         size_t want = need + need / 2 + 4096;
         MHT_HIP_CHECK(hipMalloc(&ptr, want));
+        // (hipMemset on device memory goes out on the NULL stream and returns before it has run; the caller's stream may be a
+        // non-blocking one that does not wait for the null stream -- the zeros must not land behind what that stream writes here)
         MHT_HIP_CHECK(hipMemset(ptr, 0, want));
+        MHT_HIP_CHECK(hipStreamSynchronize(nullptr));
         bytes = want;
         return MHT_OK;
     }

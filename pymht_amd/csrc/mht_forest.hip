@@ -1276,6 +1276,7 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     if (e == hipSuccess) e = hipMemcpy(g->cl, hcl, sizeof(ClusterArgs) * n * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->bl, hbl, sizeof(BlpArgs) * n * P * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->bl0, hbl0, sizeof(BlpArgs) * n * P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (the members' streams do not wait for the null stream)
     delete[] hga; delete[] hca; delete[] hcl; delete[] hbl; delete[] hbl0;
     if (e != hipSuccess) {
         set_error("mht_group_create: %s", hipGetErrorString(e));
@@ -1303,6 +1304,7 @@ static int group_refresh_member(mht_group* g, int i) {
     hipError_t e = hipStreamSynchronize(g->ctx[0]->stream);      // (launches still reading the old blocks)
     if (e == hipSuccess) e = hipMemcpy(g->ga + (size_t)i * P * 2, hga, sizeof(FGrowArgs) * P * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->ca + (size_t)i * P, hca, sizeof(CommitArgs) * P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     delete[] hga; delete[] hca;
     if (e != hipSuccess) { set_error("mht_group_step: %s", hipGetErrorString(e)); return MHT_E_HIP; }
     return MHT_OK;

@@ -226,3 +226,29 @@ def test_toc_is_the_scans_own_cost_not_the_hosts_idle_time(caplog):
     assert np.all(proc > 1e-6) and np.all(proc < 1e-3) and np.all(clu > 1e-6) and np.all(clu < 1e-3) and np.all(opt > 1e-6) and np.all(opt < 5e-3)
     assert np.all(tot >= proc + clu + opt - 1e-9)
     trk.close()
+
+
+def test_batch_admission_on_a_non_blocking_stream():
+    """A tracker made while a non-blocking stream is current (torch's side streams are) admits the same batch of initial targets every
+    time: nothing the library does on the way (growing a staging buffer, clearing it) may go out on the NULL stream, which such a stream
+    does not wait for -- zeros landing behind the staged candidates put them all at the origin, where all but one are refused as
+    neighbours (Tracker.initiateTarget, tracker.py:147-160)."""
+    import torch
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.utils.scenario import make_scenario
+    sc = make_scenario(T=500, radius=9000.0, lambda_phi=3e-6, n_scans=1, P_d=0.9, seed=11)
+    want = None
+    for rep in range(200):
+        side = torch.cuda.Stream(device=0, priority=-1 if rep % 2 else 0)
+        with torch.cuda.stream(side):
+            trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99, useInitiator=False,
+                          maxTargets=1024, maxNodes=1 << 16, maxMeasurements=1024)
+            out = trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+            ids = [t.ID for t in out]
+            trk.close()
+        if want is None:
+            want = ids
+            assert len(want) > 400
+        assert ids == want, (rep, len(ids), len(want))
