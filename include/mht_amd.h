@@ -312,7 +312,10 @@ int mht_forest_report_begin(mht_ctx* ctx);
 /* Wait for the last step (or for the transfer mht_forest_report_begin started) and expose its report (pointers stay valid until
  * the next but one mht_forest_report_begin on this ctx). */
 int mht_forest_report(mht_ctx* ctx, mht_scan_report* out);
-/* The report whose transfer the last (which = 0) or the last but one (which = 1) mht_forest_report_begin started. */
+/* The report whose transfer the last (which = 0) or the last but one (which = 1) mht_forest_report_begin started.
+ * which = 2 (streaming with mht_forest_scan and an initiator only): the report of the scan TWO before the last one, while the last
+ * scan's own report has not left the device yet -- a host that queues scan k before it folds the report of scan k - 2 never waits for
+ * the device unless it is two scans ahead (MHT_E_STATE when that report is not in a host block any more). */
 int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out);
 /* Snapshot of the current leaves in target-list / DFS order (pyTarget.getLeafNodes order): any pointer may be
  * NULL.  x host [n][4], P host [n][16], cnllr host [n], meas/target/id/node host [n] int32, flags host [n] uint8.

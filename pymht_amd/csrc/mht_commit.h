@@ -20,6 +20,11 @@ struct FCounts {          // device-side counters of the forest
     int L_in;             // leaves gated in the last scan
     int nTv[2];           // nT by table version: nTv[s & 1] = targets in the table scan s runs on.  The tiles of a grow_kernel that
                           // carries the previous scan's commit read the OLD count here while that commit rewrites nT
+    // a grow launch that also carries the ADMISSION of what the initiator gave birth to (mht_fgrow.hip: fgrow_adm_kernel): workgroup 0
+    // posts the committed scan's number, the first newborn slot and the number of newborn targets here; the workgroups that would grow
+    // newborn targets wait for it (and leave at once when nothing was born: no fence on either side then)
+    int pad_;
+    unsigned long long adm_flag;      // scan << 32 | first newborn slot << 16 | number of newborn targets
 };
 
 struct TTable {           // one buffer of the target table

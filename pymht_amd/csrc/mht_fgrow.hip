@@ -22,6 +22,7 @@
 // Algorithmic bytes of the stage: 280 B per leaf + 48 B per gated pair + 8 B per measurement.
 #include "mht_kernels.h"
 #include "mht_commit.h"
+#include "mht_admit.h"
 
 namespace mht {
 
@@ -126,12 +127,12 @@ __device__ __forceinline__ void chain_resolve(const ARGS& a, int id, int h, doub
 }
 
 template <typename ARGS>
-__device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb) {
+__device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb, const int t_off = 0, const int born = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nT = a.nT_dev[0];
+    const int nT = born ? a.nT_new[0] : a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
     // wavefront = (target, hit/miss), lane = leaf: two targets per workgroup
-    const int t = cb * FG_CHAIN_TARGETS + (wave >> 1), h = wave & 1;
+    const int t = t_off + cb * FG_CHAIN_TARGETS + (wave >> 1), h = wave & 1;
     const TInfo ti = target_info(a, d, t, nT);
     if (po || so) return;
     FG_STAMP(0);
@@ -364,8 +365,11 @@ __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32s
 // PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
 // a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
 // edge of its budget (128 for four workgroups per CU in the batched launch).
+// bslot: the slot whose static block of the node index space the target's children take (its own; a target admitted inside this launch
+// takes one behind the slots of the uncommitted table, which the other workgroups of the launch are using).  born = 1: such a target --
+// slot t of the COMMITTED table (d.fused = 0 for it), count and root columns of that table
 template <int PQ, int CAP, int AIS = 0>
-__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem) {
+__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem, const int bslot, const int born = 0) {
     constexpr int PDS = PQ * 4;
     const auto& a = *ap0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,12 +397,12 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
 
     FG_STAMP(0);
     // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
-    const int nT = a.nT_dev[0];
+    const int nT = born ? a.nT_new[0] : a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
     const TInfo ti = target_info(a, d, t, nT);
     const int tc = (t < a.Tcap) ? t : 0;
-    const double rootc = a.t_root_cnllr[tc];
-    const int root_f32 = a.t_root_f32[tc];
+    const double rootc = born ? a.b_root_cnllr[tc] : a.t_root_cnllr[tc];
+    const int root_f32 = born ? a.b_root_f32[tc] : a.t_root_f32[tc];
     int acc = 0;
     if (d.fused)          // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
         for (int i = tid; i < t; i += FG_THREADS) acc += (a.p_status[i] == 0) ? 1 : 0;
@@ -667,8 +671,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                     // dense numbering, the index space is sized for 288 GB of HBM) or, for a target with more children than that, a
                     // piece of this XCD's region of the overflow area (one returning atomic; next region if full)
                     int b = -1;
-                    if (tot <= a.block_cap) {
-                        b = t * a.block_cap;
+                    if (tot <= a.block_cap && bslot < a.Tcap) {
+                        b = bslot * a.block_cap;
                     } else {
                         int r = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // XCC_ID[3:0]
                         for (int tries = 0; tries < FG_REGIONS && b < 0; ++tries) {
@@ -1204,21 +1208,21 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
 // tree -- in the kernel that completed the report the copy sat on the critical path of every scan (~10 us).  The host waits for an
 // event recorded behind this launch.
 constexpr int FG_PUB_WGS = 8;
-__device__ __forceinline__ void publish_part(const PublishArgs& p, int w) {
+__device__ __forceinline__ void publish_part(const PublishArgs& p, int w, int n_wgs = FG_PUB_WGS) {
     const ReportHeader* h = reinterpret_cast<const ReportHeader*>(p.src);
     const int n_births = h->n_births, nT = h->n_targets;
     const uint4* s4 = reinterpret_cast<const uint4*>(p.src);
     uint4* d4 = reinterpret_cast<uint4*>(p.dst);
     const int head = (p.birth_off + n_births * (int)sizeof(mht_birth_report) + 15) / 16;      // header + mask + births present
     const int r0 = p.rec_off / 16, rn = (nT * (int)sizeof(mht_target_report) + 15) / 16;
-    const int i0 = w * FG_THREADS + threadIdx.x, st = FG_PUB_WGS * FG_THREADS;
+    const int i0 = w * FG_THREADS + threadIdx.x, st = n_wgs * FG_THREADS;
     for (int i = i0; i < head; i += st) d4[i] = s4[i];
     for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
 }
 
 template <int PQ, int CAP, typename CARGS, int AIS = 0>
-__device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) {
-    int bid = blockIdx.x;
+__device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem, const int bid0 = (int)blockIdx.x) {
+    int bid = bid0;
     // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
     // register budget -- the commit workgroup (first of the launch) or, without one, the first chain workgroup (the whole launch is
     // co-resident: it starts within a microsecond of the first target workgroup)
@@ -1237,7 +1241,7 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (t >= d.n_tgt) return;
         target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
     } else {
-        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS>(ap, d, bid, smem);
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS>(ap, d, bid, smem, bid);
     }
 }
 
@@ -1248,6 +1252,92 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
     const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
     fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+}
+
+// The streaming drop-in path (mht_forest_scan with the device initiator): the previous scan's commit, the admission of what its
+// initiator gave birth to (Tracker.initiateTarget, tracker.py:147-160 / :264-278) AND the report's push to the host ride in workgroup 0
+// of this launch instead of a launch of their own behind the ILPs (post_scan_kernel: ~10 us + a launch gap on the critical path of
+// every scan, for an admission that has nothing to admit on 98 % of the headline stream's scans).  The target workgroups of the
+// uncommitted table do not depend on any of it.  What does: the newborn targets (slots born0 .. nT - 1 of the committed table), grown
+// by FG_BORN_WGS workgroups at the end of the grid, their covariance transitions resolved by FG_BORN_CHAIN_WGS more.  They wait for
+// the word workgroup 0 posts in FCounts::adm_flag (scan, first newborn slot, count; workgroup 0 is the first of the grid and waits
+// for nobody) and leave at once when the count is zero.  Only a scan WITH births pays for device-scope fences (on this part a release
+// writes the XCD's dirty L2 lines back -- megabytes of children in the middle of a grow launch: 6 us when every scan did it).
+constexpr int FG_BORN_WGS = 16, FG_BORN_CHAIN_WGS = 8;
+template <int PQ, int CAP = FG_CAP_SOLO>
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub, const AddArgs ad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int bx = blockIdx.x, n_grow = 1 + d.n_main + d.n_chain;      // (d.fused = 1)
+    if (bx == 0) {
+        int* sm = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
+        commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, sm);
+        __threadfence_block();
+        __syncthreads();
+        const int born0 = cm.cnt->nT;
+        if (!cm.hdr->error) add_targets_body<FG_THREADS>(ad, sm + 64);      // (void scan: nothing is admitted)
+        __threadfence_block();
+        __syncthreads();
+        const int n_born = cm.cnt->nT - born0;
+        if (n_born > 0) __threadfence();      // the newborn targets' workgroups sit on other CUs / XCDs
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&cm.cnt->adm_flag, ((unsigned long long)(unsigned)d.c_scan << 32) | ((unsigned long long)born0 << 16) | (unsigned long long)n_born,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (pub.dst && !(d.xflags & 2)) {
+            // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words in the first
+            // 32 bytes of a row (new index, leaves kept), which the commit above filled in.  FG_PUB_WGS workgroups push everything
+            // BEHIND those 32 bytes of every row from the start of the launch; this workgroup pushes what it wrote itself -- header,
+            // used-measurement mask, births, the first 32 bytes of every row.  Disjoint bytes: nobody waits for anybody, no fences.
+            const ReportHeader* h = reinterpret_cast<const ReportHeader*>(pub.src);
+            const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
+            uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
+            const int head = (pub.birth_off + h->n_births * (int)sizeof(mht_birth_report) + 15) / 16, nTr = h->n_targets;
+            for (int i = threadIdx.x; i < head; i += FG_THREADS) d4[i] = s4[i];
+            constexpr int RQ = (int)sizeof(mht_target_report) / 16;
+            const int r0 = pub.rec_off / 16;
+            for (int i = threadIdx.x; i < 2 * nTr; i += FG_THREADS) { const int k = r0 + (i >> 1) * RQ + (i & 1); d4[k] = s4[k]; }
+        }
+        return;
+    }
+    if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report behind their first 32 bytes, as the previous launch left them (see workgroup 0)
+        if (d.xflags & 2) return;
+        constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 2;
+        const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
+        const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
+        uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
+        const int r0 = pub.rec_off / 16;
+        for (int i = (bx - 1) * FG_THREADS + threadIdx.x; i < nTr * RB; i += FG_PUB_WGS * FG_THREADS) { const int k = r0 + (i / RB) * RQ + 2 + (i % RB); d4[k] = s4[k]; }
+        return;
+    }
+    const int bg = bx - (pub.dst ? FG_PUB_WGS : 0);      // index among the grow workgroups
+    if (bg < n_grow) { fgrow_body<PQ, CAP>(ap, cm, d, smem, bg); return; }
+    const int w = bg - n_grow;
+    if (d.xflags & 1) return;
+    unsigned long long& s_flag = *reinterpret_cast<unsigned long long*>(smem);      // (no static LDS: it would shift the dynamic base off its alignment)
+    if (threadIdx.x == 0) {
+        unsigned long long v;
+        while (((v = __hip_atomic_load(&cm.cnt->adm_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned long long)(unsigned)d.c_scan) __builtin_amdgcn_s_sleep(8);
+        s_flag = v;
+    }
+    __syncthreads();
+    const unsigned long long fl = s_flag;
+    __syncthreads();                       // (the LDS is the target's from here on)
+    const int b0 = (int)((fl >> 16) & 0xffffu), nb = (int)(fl & 0xffffu);
+    if (nb == 0) return;                   // nothing was born (the usual case)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (every wavefront)
+    const int nT = b0 + nb;
+    FDyn db = d;
+    db.fused = 0;                          // (the newborn targets are slots of the COMMITTED table)
+    if (w < FG_BORN_WGS) {
+        const int n_old = ap->nT_dev[0];   // slots of the uncommitted table: the static blocks of the node index space behind them are free
+        for (int q = w; b0 + q < nT; q += FG_BORN_WGS) {
+            target_part<PQ, CAP>(ap, db, b0 + q, smem, n_old + q, 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = w - FG_BORN_WGS; b0 + c * FG_CHAIN_TARGETS < nT; c += FG_BORN_CHAIN_WGS) chain_part(*ap, db, c, b0, 1);
+    }
 }
 
 // AIS forest (mht_forest_create_ex with MHT_FOREST_AIS): split path records, identities per node, fused children on scans with messages
@@ -1301,6 +1391,10 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_batch_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_adm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_adm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_adm_kernel<2, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_adm_kernel<4, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
@@ -1324,9 +1418,29 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave) {
     d.n_chain = wave ? 0 : (n_tgt + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;      // (the wavefronts of the wave variant resolve their own transitions)
 }
 
-int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish) {
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish, const AddArgs* adm) {
     static int wave_solo = -1;      // development: MHT_FG_WAVE_SOLO=1 runs the wavefront-per-target variant in the one-sector launch too
     if (wave_solo < 0) { const char* e = getenv("MHT_FG_WAVE_SOLO"); wave_solo = (e && e[0] == '1') ? 1 : 0; }
+    if (adm) {      // the commit and the admission of the initiator's births ride along (fgrow_adm_kernel)
+        MHT_REQUIRE(commit && a.ais.half == 0, "launch_fgrow: the admission rides with the commit, in a forest without AIS records");
+        fgrow_plan(d, n_targets_ub, a.Tcap, true, false);
+        const size_t lds_hi = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP_SOLO), lds_lo = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP);
+        auto per_cu = [](size_t b) { const size_t n = (size_t)160 * 1024 / b; return n > 3 ? (size_t)3 : n; };
+        const bool wide = per_cu(lds_hi) >= per_cu(lds_lo);
+        size_t lds = wide ? lds_hi : lds_lo;
+        const size_t need0 = (size_t)(64 + ADM_LDS_INTS) * sizeof(int);      // workgroup 0: commit partials + admission list
+        if (lds < need0) lds = need0;
+        { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+        const bool pub = publish && publish->dst;
+        const int grid = fgrow_grid(d) + FG_BORN_WGS + FG_BORN_CHAIN_WGS + (pub ? FG_PUB_WGS : 0);
+        const PublishArgs pa = pub ? *publish : PublishArgs{};
+        if (a.pds == 8 && wide) hipLaunchKernelGGL(fgrow_adm_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
+        else if (a.pds == 8) hipLaunchKernelGGL((fgrow_adm_kernel<2, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
+        else if (wide) hipLaunchKernelGGL(fgrow_adm_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
+        else hipLaunchKernelGGL((fgrow_adm_kernel<4, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
     if (a.ais.half > 0) {      // AIS forest: its own kernel on every scan (records in two halves, identities per node)
         fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
         const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP) + (size_t)FG_CAP * 16;

@@ -20,6 +20,7 @@
 // committed state first (report, births, exports) -- see Forest::commit_pending.
 #include "mht_kernels.h"
 #include "mht_commit.h"
+#include "mht_admit.h"
 #include "mht_init_dev.h"
 #include <string.h>
 #include <math.h>
@@ -71,143 +72,10 @@ __global__ __launch_bounds__(COMMIT_THREADS) void commit_kernel(const CommitArgs
     commit_body<COMMIT_THREADS>(a, dyn, s_commit);
 }
 
-// Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
-struct AddArgs {
-    int n; const double* x0; const float* P0; const uint8_t* flags; const double* pd; const int32_t* meas;
-    int check; double thr;
-    mht_nodes layer;     // newest layer
-    TTable tab; int32_t* path; int32_t* apath; int PD;
-    FCounts* cnt; int scan; int Nwin; int Tcap;
-    int vidx;            // version index of `tab` (FCounts::nTv)
-    uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
-    Model model; VTab vt; int root_base;
-    const int32_t* n_dev;      // number of candidates in device memory (or null: n)
-    int32_t* mmsi; int32_t* hmmsi;      // AIS forest: identities of the newest layer's nodes (a root has none), else null
-    ReportHeader* hdr; mht_birth_report* births;      // report block of the device initiator's candidates (or null)   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
-};
-
-// Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates.  The test against the existing leaves
-// (pyTarget.haveNoNeightbours, pyTarget.py:181-189) runs for all candidates in one parallel sweep; the candidates are
-// then admitted sequentially, each also tested against the ones admitted before it, like the reference's loop.
-static __device__ void add_targets_body(const AddArgs& a) {
-    const int tid = threadIdx.x;
-    const int nT0 = a.cnt->nT, L0 = a.cnt->L, r0 = a.cnt->n_roots;
-    int an = a.n;
-    if (a.n_dev) { const int nd = *a.n_dev; an = nd < an ? nd : an; }
-    if (an <= 0) {          // nothing to admit (the usual case behind the device initiator)
-        if (a.hdr && tid == 0) a.hdr->n_births = 0;
-        return;
-    }
-    for (int q = tid; q < an; q += 1024) a.near[q] = 0;
-    __syncthreads();
-    if (a.check) {
-        for (int i = tid; i < L0; i += 1024) {
-            // leaf i -> node: linear scan over targets is avoided by walking the ranges: (first, leaf_off) lookup
-            int lo = 0, hi = nT0;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
-            const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
-            if (a.layer.flags[nd] & F_DEAD) continue;      // (taken out of the tree by similar-state pruning)
-            const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
-            for (int q = 0; q < an; ++q) {
-                const double dx = lx - a.x0[q * NX], dy = ly - a.x0[q * NX + 1];
-                if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // Sequential admission like the reference (a candidate is also tested against the candidates admitted before it in this
-    // call), but the test of one candidate against the admitted ones is spread over the workgroup: a batch of 500 initial
-    // targets took 33 ms with one thread walking the O(n^2) pairs.
-    __shared__ int s_near, s_nadm;
-    __shared__ int s_adm[2048];                 // candidate indices admitted so far (chunked if more)
-    if (tid == 0) s_nadm = 0;
-    __syncthreads();
-    for (int q = 0; q < an; ++q) {
-        if (tid == 0) s_near = a.near[q];
-        __syncthreads();
-        if (a.check && !s_near) {
-            const double qx = a.x0[q * NX], qy = a.x0[q * NX + 1];
-            const int na = s_nadm;
-            int hit = 0;
-            for (int i = tid; i < na; i += 1024) {
-                const int pc = s_adm[i & 2047];
-                const double dx = a.x0[pc * NX] - qx, dy = a.x0[pc * NX + 1] - qy;
-                if (sqrt(dx * dx + dy * dy) < a.thr) hit = 1;
-            }
-            if (hit) s_near = 1;
-        }
-        __syncthreads();
-        if (tid == 0) {   // (admission is sequential like the reference's loop)
-            const int near = s_near;
-            const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_roots < a.Tcap;
-            if (!near && !ok) a.cnt->overflow = 1;
-            if (ok) {
-                // roots born into a layer live at its end (node root_base + r): the children of a scan are spread over the regions
-                // of the node index space below it (fgrow_kernel)
-                const int r = a.cnt->n_roots, idx = a.root_base + r, t = a.cnt->nT, L = a.cnt->L;
-                const size_t cap = a.layer.cap;
-                for (int k = 0; k < NX; ++k) a.layer.x[k * cap + idx] = a.x0[q * NX + k];
-                a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
-                a.layer.pd[idx] = a.pd[q];
-                a.layer.parent[idx] = -1;
-                a.layer.meas[idx] = a.meas[q];
-                a.layer.cov[idx] = -1;                     // (its key is made below, once the admissions are known)
-                a.layer.flags[idx] = a.flags[q];
-                if (a.mmsi) { a.mmsi[idx] = 0; a.hmmsi[idx] = 0; }
-                for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
-                a.tab.id[t] = a.cnt->id_counter;
-                a.tab.window[t] = a.Nwin;
-                a.tab.depth[t] = 0;
-                a.tab.shift[t] = 0;
-                a.tab.root_scan[t] = a.scan;
-                a.tab.root_node[t] = idx;
-                a.tab.root_cnllr[t] = 0.0;
-                a.tab.root_f32[t] = (a.flags[q] & F_SCORE_F32) ? 1 : 0;
-                a.tab.first[t] = idx;
-                a.tab.leaf_off[t] = L;
-                a.tab.leaf_off[t + 1] = L + 1;
-                if (a.ids) a.ids[q] = a.cnt->id_counter;
-                a.cnt->id_counter += 1;
-                a.cnt->n_roots = r + 1;
-                a.cnt->nT = t + 1;
-                a.cnt->nTv[a.vidx] = t + 1;
-                a.cnt->L = L + 1;
-                s_adm[s_nadm & 2047] = q;
-                s_nadm += 1;
-            } else if (a.ids) {
-                a.ids[q] = -1;
-            }
-            if (a.accepted) a.accepted[q] = (uint8_t)ok;
-            if (a.births) {      // the candidate and its fate, for the host mirror (mht_scan_report::births)
-                mht_birth_report& b = a.births[q];
-                b.id = ok ? a.cnt->id_counter - 1 : -1;
-                b.meas = a.meas[q];
-                for (int k = 0; k < NX; ++k) b.x0[k] = a.x0[q * NX + k];
-                for (int e = 0; e < NP; ++e) b.P0[e] = a.P0[q * NP + e];
-            }
-        }
-        __syncthreads();
-    }
-    if (a.hdr && tid == 0) a.hdr->n_births = an;
-    // covariance and gains of the admitted roots (what fgrow_kernel's chain workgroups resolve for every other node one scan
-    // ahead): the root's covariance by value, and a key of its own -- a pseudo parent id whose miss child is that value
-    for (int k = tid; k < s_nadm; k += 1024) {
-        const int q = s_adm[k & 2047];
-        float P[NP];
-        for (int e = 0; e < NP; ++e) P[e] = a.P0[q * NP + e];
-        const int id0 = vt_find_or_insert(a.vt, P, a.pd[q]);
-        const unsigned pid = atomicAdd(a.vt.count, 1u);
-        if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; continue; }
-        const int key = 2 * (int)pid;
-        float4 rec[GKQ];
-        vt_gains(a.model, P, a.pd[q], rec);
-        for (int e = 0; e < GKQ; ++e) a.vt.Gk[(size_t)key * GKQ + e] = rec[e];
-        a.vt.child[key] = id0;
-        a.layer.cov[a.root_base + r0 + k] = key;      // (admissions are sequential: the k-th took root r0 + k)
-    }
+__global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) {
+    __shared__ int s_adm[ADM_LDS_INTS];
+    add_targets_body<1024>(a, s_adm);
 }
-__global__ __launch_bounds__(1024) void add_targets_kernel(const AddArgs a) { add_targets_body(a); }
 
 // The end of a scan in the drop-in API path, ONE launch of one workgroup instead of three: the scan's commit (target table, report),
 // step 7 on the measurements the commit found unused (initiator_body), Tracker.initiateTarget for what it confirmed.
@@ -239,6 +107,7 @@ template <bool AIS>
 __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, const CommitDyn dyn, const InitArgs in, const AddArgs ad, const int do_commit,
                                                          const PublishArgs pub, const int run_init, const AisUsedArgs au) {
     __shared__ int s_commit[2 * (1024 / 64) + 8];
+    __shared__ int s_adm[ADM_LDS_INTS];
     if (do_commit) {
         commit_body<1024>(cm, dyn, s_commit);
         __threadfence_block();
@@ -251,9 +120,18 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
             __threadfence_block();
             __syncthreads();
         }
-        add_targets_body(ad);
+        add_targets_body<1024>(ad, s_adm);
     }
     publish_report<1024>(pub);
+}
+
+// The device initiator as a launch of its own, on the forest's side stream: it needs the scan and the used-measurement bytes of the
+// scan's grow launch, nothing of the clustering or the ILPs, and what it gives birth to is admitted in the NEXT scan's grow launch --
+// so it runs next to the scan's cluster and ILP launches instead of lengthening the cluster launch (cluster_init_kernel: 15 us against
+// 8.7 for the clustering alone).
+__global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow) {
+    if ((status && status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
+    initiator_body<false>(in);
 }
 
 struct LeavesArgs {
@@ -356,7 +234,9 @@ struct Forest {
     int init_ran_scan = 0;       // last scan whose initiator ran inside its cluster launch (mht_forest_scan)
     const float* z_cur = nullptr;
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
+    int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
+    hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
@@ -368,6 +248,9 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
+    // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
+    // workgroup 0 of the next scan's grow launch (fgrow_adm_kernel), or run as post_scan_kernel when somebody needs the state first
+    bool adm_pending = false; AddArgs adm = {}; bool adm_fuse = true;      // MHT_ADM_FUSE=0: admission in a launch of its own behind every scan
     bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
     long long blp_time_limit = 0;   // wall-clock budget per ILP in 10 ns ticks, 0 = none (mht_forest_set_blp_time_limit)
     float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
@@ -381,9 +264,17 @@ struct Forest {
     // births issued behind scan s, before scan s+1 (ring by s % 64): host-driven ones exactly, the device initiator's as an upper
     // bound (its capacity) until the scan's report says how many candidates there were
     int births_after[64] = {}; int births_init_ub[64] = {};
+    unsigned long long* bhint_host = nullptr; unsigned long long* bhint_dev = nullptr;      // ring of 64: what the device initiator says it gave birth to (InitArgs::bhint)
     long long births_between(int k, int s) const {      // births issued behind scans k .. s-1
         long long b = 0;
-        for (int j = k; j < s; ++j) b += births_after[j % 64] + births_init_ub[j % 64];
+        for (int j = k; j < s; ++j) {
+            int ub = births_init_ub[j % 64];
+            if (ub > 0 && bhint_host) {      // the initiator of scan j has finished: its candidates are counted
+                const unsigned long long h = reinterpret_cast<volatile unsigned long long*>(bhint_host)[j % 64];
+                if ((int)(h >> 32) == j && (int)(h & 0xffffffffu) < ub) ub = (int)(h & 0xffffffffu);
+            }
+            b += births_after[j % 64] + ub;
+        }
         return b;
     }
     int targets_ub(int s_table) const {      // upper bound of the targets in the table scan `s_table` runs on
@@ -477,9 +368,12 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->z_host) (void)hipHostFree(f->z_host);
     for (int b = 0; b < Z_RING; ++b) if (f->z_ev[b]) (void)hipEventDestroy(f->z_ev[b]);
     if (f->hint_host) (void)hipHostFree(f->hint_host);
+    if (f->bhint_host) (void)hipHostFree(f->bhint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
+    if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
+    if (f->init_ev) (void)hipEventDestroy(f->init_ev);
     if (f->evp) {
         for (int k = 0; k < EV_POOL; ++k) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(f->evp[k][i]);
         delete[] f->evp;
@@ -506,6 +400,16 @@ static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan 
 }
 static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
     if (!f->commit_pending) return MHT_OK;
+    if (f->adm_pending) {      // commit + admission of the initiator's births, as one launch (what mht_forest_scan deferred)
+        if (f->init_ev_pending) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0)); f->init_ev_pending = false; }      // (the initiator ran on the side stream)
+        PublishArgs pub = publish ? publish_args(f) : PublishArgs{};
+        hipLaunchKernelGGL(post_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, InitArgs{}, f->adm, 1, pub, 0, AisUsedArgs{});
+        MHT_HIP_CHECK(hipGetLastError());
+        if (publish) f->published_scan = f->scan;
+        f->adm_pending = false;
+        f->commit_pending = false;
+        return MHT_OK;
+    }
     if (publish) {      // (the host block of this parity may still be in the host's hands: two scans ago)
         hipLaunchKernelGGL(commit_publish_kernel, dim3(1), dim3(COMMIT_THREADS), 0, ctx->stream, f->pending, f->pending_dyn, publish_args(f));
         f->published_scan = f->scan;
@@ -520,10 +424,12 @@ __global__ __launch_bounds__(1024) void publish_kernel(const PublishArgs pub) { 
 // the deferred report push (Forest::pub_deferred) now, as a launch of its own
 static int flush_publish(mht_ctx* ctx, Forest* f) {
     if (!f->pub_deferred) return MHT_OK;
+    if (f->adm_pending) { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // (the report is complete behind the commit and the admission)
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pub_args);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->pub_slot], ctx->stream));
     f->rep_started[f->pub_slot] = true;
+    f->host_block_scan[f->pub_slot] = f->scan;
     f->pub_deferred = false;
     return MHT_OK;
 }
@@ -590,6 +496,10 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
+    { const char* e = getenv("MHT_ADM_FUSE"); f->adm_fuse = !(e && e[0] == '0'); }
+    { const char* e = getenv("MHT_INIT_SIDE"); f->init_side = (e && e[0] == '1'); }      // (measured: the two event operations per scan cost the host more than the 6 us save the device -- 91 against 76 us per streamed scan)
+    MHT_HIP_CHECK(hipEventCreateWithFlags(&f->grow_ev, hipEventDisableTiming));
+    MHT_HIP_CHECK(hipEventCreateWithFlags(&f->init_ev, hipEventDisableTiming));
     f->pds = f->PD <= 8 ? 8 : 16;
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
@@ -651,6 +561,9 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
+    MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->bhint_host), 64 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(f->bhint_host, 0, 64 * sizeof(unsigned long long));
+    MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->bhint_dev), f->bhint_host, 0));
     // (a forest whose clustering tables -- 16 B per target + 4 B per measurement node -- do not fit the kernel's 150 KiB of LDS keeps them
     // in HBM: cluster_big_kernel)
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -800,6 +713,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
         g.t_root_cnllr = f->tab[cb].root_cnllr; g.t_root_f32 = f->tab[cb].root_f32;
     }
     g.t_first = f->tab[cb].first; g.t_leaf_off = f->tab[cb].leaf_off; g.t_depth = f->tab[cb].depth; g.t_shift = f->tab[cb].shift;
+    g.nT_new = &f->cnt->nT; g.b_root_cnllr = f->tab[cb].root_cnllr; g.b_root_f32 = f->tab[cb].root_f32;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
     g.oflags = out.flags;
     g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
@@ -944,7 +858,7 @@ static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
     f->rebuilds += 1;
     return MHT_OK;
 }
-static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl) {
+static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl, bool carries_admission = false) {
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "%s: M=%d exceeds max_meas=%d", who, M, f->cfg.max_meas);
     MHT_REQUIRE(z || M == 0, "%s: z is null", who);
     if (f->dead) {
@@ -952,6 +866,7 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
         return MHT_E_STATE;
     }
     if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
+    if (f->adm_pending && !carries_admission) { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // (only the one-sector grow launch takes the admission along)
     const int s = ++f->scan;
     pl.rebuilt = false;
     if (f->hint_host) {      // value table three quarters full (as of the last commit the host has seen) and the other generation free again?
@@ -976,6 +891,7 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     f->layer_gen[s % f->R] = f->vgen;
     f->births_after[s % 64] = 0; f->births_init_ub[s % 64] = 0;
     f->nT_ub_prev = f->nT_ub_step;      // slots of the table the previous scan ran on
+    if (s > 1) { const int again = f->targets_ub(s - 1); if (again < f->nT_ub_prev) f->nT_ub_prev = again; }      // (bounded again: the device's hints have moved on since)
     f->nT_ub_step = f->targets_ub(s);
     f->births_since_step = 0;
     f->last_M = M;
@@ -1021,7 +937,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         if (rc) return rc;
     }
     StepPlan pl;
-    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl); if (rc) return rc; }
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) return rc; }
     if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
     hipStream_t st = ctx->stream;
     hipEvent_t* ev = nullptr;
@@ -1057,12 +973,20 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
         d.ais_on = ais ? 1 : 0;
+        { static int xf = -1; if (xf < 0) { const char* e = getenv("MHT_ADM_X"); xf = e ? atoi(e) : 0; } d.xflags = xf; }
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
-        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr));
+        const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)
+        if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
+        { static int tr = -1; if (tr < 0) { const char* e = getenv("MHT_STEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
+          if (tr && pl.s > 40 && pl.s < 80) { const unsigned long long hh = f->hint_host ? *reinterpret_cast<volatile unsigned long long*>(f->hint_host) : 0ull;
+              fprintf(stderr, "[step %d] fused %d adm %d n_ub %d nT_ub_step %d nT_ub %d hint(k=%d na=%d)\n", pl.s, (int)pl.fused, (int)adm, pl.n_ub, f->nT_ub_step, f->nT_ub, (int)(hh >> 32), (int)(hh & 0xffffffffu)); } }
+        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr));
+        f->adm_pending = false;
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
             MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st));
             f->rep_started[f->pub_slot] = true;
+            f->host_block_scan[f->pub_slot] = pl.s - 1;
             f->pub_deferred = false;
         }
     }
@@ -1076,7 +1000,18 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             InitArgs ia;
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
-            MHT_STEP_CHECK(launch_cluster(ctx, c, &ia, &f->cnt->overflow));
+            ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
+            if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
+                MHT_STEP_HIP(hipEventRecord(f->grow_ev, st));                       // behind the grow launch
+                MHT_STEP_HIP(hipStreamWaitEvent(f->stage_stream, f->grow_ev, 0));
+                hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->stage_stream, ia, static_cast<const DevStatus*>(c.status), static_cast<const int32_t*>(&f->cnt->overflow));
+                MHT_STEP_HIP(hipGetLastError());
+                MHT_STEP_HIP(hipEventRecord(f->init_ev, f->stage_stream));
+                f->init_ev_pending = true;
+                MHT_STEP_CHECK(launch_cluster(ctx, c));
+            } else {
+                MHT_STEP_CHECK(launch_cluster(ctx, c, &ia, &f->cnt->overflow));
+            }
             f->init_ran_scan = pl.s;
         } else {      // (no initiator, or the HBM-table clustering kernel: the initiator then runs behind the scan, in post_scan_kernel)
             MHT_STEP_CHECK(launch_cluster(ctx, c));
@@ -1408,7 +1343,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
         initiator_ais_ptrs(in, &au.msgs, &au.used);
         au.mmsi = f->l_mmsi[f->scan % f->R]; au.first = f->tab[nb_].first; au.leaf_off = f->tab[nb_].leaf_off; au.cnt = f->cnt;
     }
-    if (!init_done) initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia);
+    if (!init_done) { initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia); ia.bhint = f->bhint_dev; ia.scan_no = f->scan; }
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
     a.check = 1; a.thr = f->cfg.merge_threshold;
@@ -1427,7 +1362,11 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     // the report goes to the host from this launch, or -- streaming: mht_forest_scan -- with the next scan's grow launch
     PublishArgs pub = publish_args(f);
     if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
-    if (au.nA > 0 || ia.nA > 0)
+    // streaming (mht_forest_scan) and nothing left to do here but the commit and the admission: both ride in the next scan's grow launch
+    const bool ride = defer_publish && init_done && f->adm_fuse && f->commit_pending && !f->ais && au.nA == 0 && ia.nA == 0;
+    if (!ride && f->init_ev_pending) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0)); f->init_ev_pending = false; }
+    if (ride) { f->adm = a; f->adm_pending = true; }
+    else if (au.nA > 0 || ia.nA > 0)
         hipLaunchKernelGGL(post_scan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
                            init_done ? 0 : 1, au);
     else
@@ -1435,7 +1374,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
                            init_done ? 0 : 1, au);
     f->published_scan = f->scan;
     MHT_HIP_CHECK(hipGetLastError());
-    f->commit_pending = false;
+    if (!ride) f->commit_pending = false;
     // the host does not know how many of the candidates exist: every bound moves by the most there can be
     f->nT_ub = (f->nT_ub + cap < f->Tcap) ? f->nT_ub + cap : f->Tcap;
     f->L_ub = (f->L_ub + cap < f->Ncap) ? f->L_ub + cap : f->Ncap;
@@ -1478,7 +1417,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
                            reinterpret_cast<float4*>(zd), n16);
         MHT_HIP_CHECK(hipGetLastError());
         MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run)
-        if (f->stage_stream) MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0));
+        if (f->stage_stream) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
         f->z_used[slot] = true;
         f->z_cur = zd;
         (void)mark_done;
@@ -1537,13 +1476,14 @@ extern "C" int mht_forest_report_begin(mht_ctx* ctx) {
         MHT_HIP_CHECK(hipMemcpyAsync(f->report_host2[f->rep_slot], f->report_dev2[f->scan & 1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->rep_slot], ctx->stream));
+    f->host_block_scan[f->rep_slot] = f->scan;
     f->report_pending = false;
     f->rep_inflight = true;
     f->rep_started[f->rep_slot] = true;
     return MHT_OK;
 }
 
-static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out);
+static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out, bool lagged = false);
 
 extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
     MHT_REQUIRE(ctx && ctx->forest && out, "mht_forest_report: null argument");
@@ -1557,21 +1497,35 @@ extern "C" int mht_forest_report(mht_ctx* ctx, mht_scan_report* out) {
 // The report whose transfer the last (which = 0) or the last but one (which = 1) mht_forest_report_begin started: a host that
 // begins the report of scan k+1 before it reads the one of scan k keeps two scans in flight.
 extern "C" int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out) {
-    MHT_REQUIRE(ctx && ctx->forest && out && (which == 0 || which == 1), "mht_forest_report_get: bad argument");
+    MHT_REQUIRE(ctx && ctx->forest && out && which >= 0 && which <= 2, "mht_forest_report_get: bad argument");
     Forest* f = ctx->forest;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (which == 2) {
+        // streaming (mht_forest_scan): the report of the last scan has not started its way to the host (it rides in the NEXT grow launch),
+        // and the host block it will go to still holds the report of the scan two before it
+        if (!(f->pub_deferred && f->pub_slot == f->rep_slot && f->host_block_scan[f->rep_slot] == f->scan - 2 && f->scan >= 3)) {
+            set_error("mht_forest_report_get: the report of scan %d is not in a host block any more (which = 2 reads it between two mht_forest_scan calls)", f->scan - 2);
+            return MHT_E_STATE;
+        }
+        return report_expose(ctx, f, f->rep_slot, out, true);
+    }
     return report_expose(ctx, f, f->rep_slot ^ which, out);
 }
 
-static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out) {
-    if (f->pub_deferred && slot == f->pub_slot) { const int rc = flush_publish(ctx, f); if (rc) return rc; }
-    if (f->rep_started[slot]) {
-        MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));
-        f->rep_started[slot] = false;
+static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out, bool lagged) {
+    if (lagged) {
+        MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));      // (recorded behind the grow launch that pushed it: the scan before the last)
+    } else {
+        if (f->pub_deferred && slot == f->pub_slot) { const int rc = flush_publish(ctx, f); if (rc) return rc; }
+        if (f->rep_started[slot]) {
+            MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));
+            f->rep_started[slot] = false;
+        }
+        if (slot == f->rep_slot) f->rep_inflight = false;
     }
-    if (slot == f->rep_slot) f->rep_inflight = false;
     f->report_host = f->report_host2[slot];
     const ReportHeader* h = reinterpret_cast<const ReportHeader*>(f->report_host);
+    if (lagged && h->scan != f->scan - 2) { set_error("mht_forest_report_get: the host block holds scan %d, not %d", h->scan, f->scan - 2); return MHT_E_STATE; }
     memcpy(out, h, sizeof(ReportHeader));
     out->used = reinterpret_cast<const uint64_t*>(f->report_host + f->used_off);
     out->targets = reinterpret_cast<const mht_target_report*>(f->report_host + f->rec_off);

@@ -47,6 +47,9 @@ struct InitArgs {
     int Acap;
     // output: born candidates, in the reference's order
     double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
+    // host-mapped ring (or null): word [scan & 63] = scan << 32 | candidates born in that scan, as soon as the number exists -- the
+    // forest's host side sizes the next grids with it instead of born_cap (mht_forest.hip: Forest::births_between)
+    unsigned long long* bhint; int scan_no;
 };
 
 // np.linalg.inv of the 4 x 4 float32 matrix of PreliminaryTrack.compareSimilarity (m_of_n.py:205-206): numpy.linalg computes in
@@ -617,6 +620,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         }
         for (int i = 0; i < out; ++i) { a.born_flags[i] = F_STATE_F32 | F_SCORE_F32; a.born_pd[i] = a.default_pd; }
         *a.born_n = out;
+        if (a.bhint) __hip_atomic_store(a.bhint + (a.scan_no & 63), ((unsigned long long)(unsigned)a.scan_no << 32) | (unsigned long long)(unsigned)out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         st.n_born = out;
         st.n_prelim = n_pre_now;
         st.n_seeds = n_left;

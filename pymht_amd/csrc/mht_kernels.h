@@ -73,6 +73,9 @@ struct FGrowArgs {
     const int32_t* p_status; const int32_t* p_count; const int32_t* p_jdrop; const int32_t* p_firstsurv; const int32_t* p_depth;
     const int32_t* t_first; const int32_t* t_leaf_off; const int32_t* t_depth; const int32_t* t_shift;
     const double* t_root_cnllr; const uint8_t* t_root_f32;      // by slot of the table named above
+    // targets admitted INSIDE this launch (fgrow_adm_kernel: workgroup 0 runs the previous scan's commit and the admission of what the
+    // initiator gave birth to; the newborn targets are slots of the committed table): its count and root columns
+    const int32_t* nT_new; const double* b_root_cnllr; const uint8_t* b_root_f32;
     // output layer
     double* ox; double* ocnllr; double* opd; int32_t* oparent; int32_t* omeas; int32_t* ocov; uint8_t* oflags;
     int32_t* out_path; int32_t* out_apath; double* ocost;
@@ -97,6 +100,7 @@ struct FDyn {
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     int ais_on;                    // AIS forest: this scan carries messages (AisGrow::nf / off / rec are valid)
+    int xflags;                    // development (MHT_ADM_X): 1 = the newborn-target workgroups leave at once, 2 = nobody pushes the report
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
 };
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.
@@ -243,7 +247,9 @@ struct AisForestArgs {
 int launch_forest_ais(mht_ctx* ctx, const AisForestArgs& a, int n_targets_ub);
 int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
-int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr);
+struct AddArgs;      // mht_admit.h
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr,
+                 const AddArgs* adm = nullptr);
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave);
 size_t fgrow_wave_lds_bytes(int W, int pds, int AW);

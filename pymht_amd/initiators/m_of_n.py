@@ -18,7 +18,8 @@ from ..pyTarget import Target
 
 GATE_PROBABILITY = 0.99
 GAMMA = float(chi2(df=2).ppf(GATE_PROBABILITY))      # m_of_n.py:12-16
-MAX_BORN = 128      # new targets one scan can give birth to (more: MHT_E_CAPACITY)
+import os
+MAX_BORN = int(os.environ.get("MHT_MAX_BORN", "128"))      # new targets one scan can give birth to (more: MHT_E_CAPACITY)
 
 
 class Initiator:

@@ -168,7 +168,7 @@ class Tracker():
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
         self.scanStatsLog = [] if kwargs.get('logScanStats', False) else None      # lastScanStats (+ nTargets) of every scan
-        self._pending = None        # the scan whose report is still on its way (folded by the next scan or by the first look)
+        self._pendq = []            # the scans whose reports are still on their way, oldest first (folded by later scans or by the first look)
         self._dead = False          # a device step failed: the forest cannot go on
         self._staged = self._staged_prev = self._staged_np = None
         self._stats_ = {}
@@ -288,18 +288,23 @@ class Tracker():
         self._queue_report(scanList, z, aisList, tic)
 
     def _queue_report(self, scanList, z, aisList, tic):
-        prev, self._pending = self._pending, (scanList, z, aisList, tic if tic is not None else {'Total': time.time()})
-        if prev is not None:      # the scan before: its report has arrived (or is about to) while the device works on this one
-            self._finish_scan(*prev, which=1)
+        self._pendq.append((scanList, z, aisList, tic if tic is not None else {'Total': time.time()}))
+        # With the device initiator the report of scan k leaves the device inside the grow launch of scan k + 1 (queued by the NEXT
+        # call): folding it in that next call would wait for that launch -- report -> fold -> queue -> launch -> report is a latency
+        # loop through the host, 85 us per scan whatever the device needs.  The call for scan k + 2 folds it instead, behind its own
+        # queueing: it arrived a scan ago and nobody waits.  (Without the initiator the report travels right behind its own scan.)
+        lag = 2 if (self.useInitiator and not self._timing) else 1
+        if len(self._pendq) > lag:
+            prev = self._pendq.pop(0)
+            self._finish_scan(*prev, which=len(self._pendq))
         if self._timing:          # (the stage times are read scan by scan)
             self._drain()
 
     def _drain(self):
-        """Fold the report of the scan that is still in flight (waits for it)."""
-        if self._pending is not None:
-            scanList, z, aisList, tic = self._pending
-            self._pending = None
-            self._finish_scan(scanList, z, aisList, tic)
+        """Fold the reports of the scans that are still in flight, oldest first (waits for them)."""
+        while self._pendq:
+            prev = self._pendq.pop(0)
+            self._finish_scan(*prev, which=len(self._pendq))
 
     def _accept_scan(self, scanList, aisList, kwargs):
         """Argument checks of addMeasurementList; returns the scan as the (M,2) float32 array the device gates."""
@@ -852,7 +857,7 @@ class Tracker():
         return self.__clusterList__
 
     def close(self):
-        self._pending = None
+        self._pendq = []
         if self.initiator is not None:
             self.initiator.close()
             self.initiator = None
