@@ -22,7 +22,7 @@ BUDGET = {
     "mht_cluster.hip": {"cluster_kernel": (0, 128), "cluster_init_kernel": (160, 128)},
     "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 128), "post_scan_kernelILb0": (64, 128), "post_scan_kernelILb1": (512, 128)},
     # (1024 threads: 4 waves per SIMD; one workgroup: the initiator's small dense inverses index their scratch arrays dynamically)
-    "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128)},      # 3 / 4 workgroups per CU
+    "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128), "fgrow_adm_kernel": (0, 168)},      # 3 / 4 workgroups per CU
 }
 
 
