@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         if (threadIdx.x == 0)
             __hip_atomic_store(&cm.cnt->adm_flag, ((unsigned long long)(unsigned)d.c_scan << 32) | ((unsigned long long)born0 << 16) | (unsigned long long)n_born,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (pub.dst && !(d.xflags & 2)) {
+        if (pub.dst) {
             // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words in the first
             // 32 bytes of a row (new index, leaves kept), which the commit above filled in.  FG_PUB_WGS workgroups push everything
             // BEHIND those 32 bytes of every row from the start of the launch; this workgroup pushes what it wrote itself -- header,
@@ -1301,7 +1301,6 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         return;
     }
     if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report behind their first 32 bytes, as the previous launch left them (see workgroup 0)
-        if (d.xflags & 2) return;
         constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 2;
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
         const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
@@ -1313,7 +1312,6 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
     const int bg = bx - (pub.dst ? FG_PUB_WGS : 0);      // index among the grow workgroups
     if (bg < n_grow) { fgrow_body<PQ, CAP>(ap, cm, d, smem, bg); return; }
     const int w = bg - n_grow;
-    if (d.xflags & 1) return;
     unsigned long long& s_flag = *reinterpret_cast<unsigned long long*>(smem);      // (no static LDS: it would shift the dynamic base off its alignment)
     if (threadIdx.x == 0) {
         unsigned long long v;

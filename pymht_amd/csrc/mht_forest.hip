@@ -973,7 +973,6 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
         d.ais_on = ais ? 1 : 0;
-        { static int xf = -1; if (xf < 0) { const char* e = getenv("MHT_ADM_X"); xf = e ? atoi(e) : 0; } d.xflags = xf; }
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)

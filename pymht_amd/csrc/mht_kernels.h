@@ -100,7 +100,6 @@ struct FDyn {
     int c_scan, c_M, c_W;          // CommitDyn of the commit that rides along
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     int ais_on;                    // AIS forest: this scan carries messages (AisGrow::nf / off / rec are valid)
-    int xflags;                    // development (MHT_ADM_X): 1 = the newborn-target workgroups leave at once, 2 = nobody pushes the report
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
 };
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.

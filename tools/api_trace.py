@@ -37,8 +37,8 @@ def run(n):
     trk.synchronize()
     dt = time.perf_counter() - t0
     print("%d scans streamed: %.1f us per scan = %.0f scans/s" % (n - 32, 1e6 * dt / (n - 32), (n - 32) / dt))
-    nb = np.array(nb)
-    print("births per scan: mean %.2f, scans with births %.0f %%, histogram %s" % (nb.mean(), 100.0 * (nb > 0).mean(), np.bincount(nb)[:8].tolist()))
+    nb = np.array(nb)      # (the hook only runs on scans whose report lists candidates)
+    print("scans whose initiator confirmed candidates: %d of %d (%.1f %%), admitted per such scan %s" % (len(nb), n, 100.0 * len(nb) / n, nb.tolist()))
     trk.close()
 
 
@@ -77,34 +77,8 @@ def report(d):
             print("  post_scan %s 12 us: %d scans, post_scan mean %.1f us, period mean %.1f us" % ("<=" if k == 0 else ">", len(a), a[:, 0].mean() / 1e3, a[:, 1].mean() / 1e3))
 
 
-def raw(n):
-    """the device side alone: mht_forest_scan queued back to back, no report is read"""
-    import time, ctypes as C
-    import torch
-    from pymht_amd.tracker import Tracker
-    from pymht_amd.pyTarget import Target
-    from pymht_amd.models import pv
-    from pymht_amd.utils.scenario import make_config
-    sc = make_config("cfg3", seed=5446, n_scans=n, confine=True)
-    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99)
-    trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
-    zs = [np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 2) for z in sc["scans"]]
-    lib, h, ih = trk._lib, trk._ctx.handle, trk.initiator.handle
-    for k in range(n):
-        if k == 32:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        rc = lib.mht_forest_scan(h, ih, zs[k].ctypes.data_as(C.c_void_p), zs[k].shape[0], float(sc["times"][k]))
-        assert rc == 0, rc
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print("%d scans queued back to back: %.1f us per scan = %.0f scans/s" % (n - 32, 1e6 * dt / (n - 32), (n - 32) / dt))
-
-
 if __name__ == "__main__":
-    if sys.argv[1] == "raw":
-        raw(int(sys.argv[2]) if len(sys.argv) > 2 else 432)
-    elif sys.argv[1] == "run":
+    if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 432)
     else:
         report(sys.argv[2])
