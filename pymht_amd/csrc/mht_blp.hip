@@ -22,6 +22,7 @@
 // is copied into LDS once (costs, rows as dense local ids, prices, usage counters, marks) and every dual step runs
 // out of LDS; larger clusters run the same code on HBM scratch (L2 resident).
 #include "mht_kernels.h"
+#include "mht_init_dev.h"
 #include <stdlib.h>
 
 namespace mht {
@@ -2252,7 +2253,24 @@ size_t blp_set_tier(BlpArgs& a, int tier) {
     return blp_lds_bytes(a.cap_h, a.cap_r, a.cap_k, a.cap_uw);
 }
 
-int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
+// The drop-in path's ILP launch: the device M-of-N initiator (step 7, tracker.py:264-278; mht_init_dev.h) rides along as ONE more
+// workgroup.  It needs the scan and the used-measurement bytes of the scan's grow launch, nothing of the clustering or the ILPs, and
+// what it gives birth to is admitted in the NEXT scan's grow launch -- next to the clustering (cluster_init_kernel) it made that
+// launch 15 us instead of 8.7; here its ~45 barrier-separated phases hide behind the slowest ILP of the scan.
+__global__ __launch_bounds__(BLP_THREADS) void blp_init_kernel(const BlpArgs a, const InitArgs in, const int32_t* sticky_overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int gx = (int)gridDim.x - 1;
+    if ((int)blockIdx.x == gx) {
+        if ((a.status && a.status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
+        initiator_body<false, BLP_THREADS>(in);
+        return;
+    }
+    blp_stamp_begin(a, blockIdx.x);
+    blp_body(a, lds, blockIdx.x, gx);
+    blp_stamp_end(a);
+}
+
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, const int32_t* sticky_overflow) {
     BlpArgs b = a;
     const size_t lds = blp_set_tier(b, 0);
     if (lds > 158 * 1024) {
@@ -2261,9 +2279,11 @@ int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
     }
     if (ctx->lds_attr_blp < lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_attr_blp = lds;
     }
-    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);
+    if (init) hipLaunchKernelGGL(blp_init_kernel, dim3(grid + 1), dim3(BLP_THREADS), lds, ctx->stream, b, *init, sticky_overflow);
+    else hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

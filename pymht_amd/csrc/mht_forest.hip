@@ -236,7 +236,7 @@ struct Forest {
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
-    hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
+    hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
@@ -497,6 +497,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
     { const char* e = getenv("MHT_ADM_FUSE"); f->adm_fuse = !(e && e[0] == '0'); }
+    { const char* e = getenv("MHT_INIT_IN_BLP"); f->init_in_blp = (e && e[0] == '1'); }      // (measured on the headline stream: at 256 threads the initiator needs 39 us, the ILPs 25 -- 84 us per streamed scan against 74; worth it where the ILP stage is long)
     { const char* e = getenv("MHT_INIT_SIDE"); f->init_side = (e && e[0] == '1'); }      // (measured: the two event operations per scan cost the host more than the 6 us save the device -- 91 against 76 us per streamed scan)
     MHT_HIP_CHECK(hipEventCreateWithFlags(&f->grow_ev, hipEventDisableTiming));
     MHT_HIP_CHECK(hipEventCreateWithFlags(&f->init_ev, hipEventDisableTiming));
@@ -992,6 +993,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     f->commit_pending = false;
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
+    InitArgs init_blp = {}; bool have_init_blp = false;
     {
         ClusterArgs c;
         fill_cluster(f, pl.s, c);
@@ -1000,7 +1002,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
-            if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
+            if (f->init_in_blp && f->adm_fuse && !f->ais) {      // the initiator rides in the ILP launch (blp_init_kernel): hidden behind the slowest ILP
+                init_blp = ia; have_init_blp = true;
+                MHT_STEP_CHECK(launch_cluster(ctx, c));
+            } else if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
                 MHT_STEP_HIP(hipEventRecord(f->grow_ev, st));                       // behind the grow launch
                 MHT_STEP_HIP(hipStreamWaitEvent(f->stage_stream, f->grow_ev, 0));
                 hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->stage_stream, ia, static_cast<const DevStatus*>(c.status), static_cast<const int32_t*>(&f->cnt->overflow));
@@ -1029,7 +1034,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         fill_blp(f, pl.s, b);
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
-        MHT_STEP_CHECK(launch_blp(ctx, b, grid));
+        MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
     }
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------

@@ -105,16 +105,17 @@ static __device__ inline bool inv_small(const float* s, int n, float* out) {
 // ---- GNN: minimum-cost maximum-cardinality matching of the allowed graph -------------------------------------------------------
 // rows 0..n1-1, columns 0..n2-1, edges (e_row, e_col, e_cost)[0..E).  One thread per connected component: successive shortest
 // augmenting paths (Bellman-Ford on the residual graph; components have a handful of nodes).  match_row[r] = column or -1.
+template <int NT>
 static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
     const int tid = threadIdx.x;
     const int V = n1 + n2;
-    for (int v = tid; v < V; v += INIT_THREADS) { a.node_parent[v] = v; a.row_head[v] = -1; a.comp_head[v] = -1; }
-    for (int r = tid; r < n1; r += INIT_THREADS) a.match_row[r] = -1;
-    for (int c = tid; c < n2; c += INIT_THREADS) a.match_col[c] = -1;
+    for (int v = tid; v < V; v += NT) { a.node_parent[v] = v; a.row_head[v] = -1; a.comp_head[v] = -1; }
+    for (int r = tid; r < n1; r += NT) a.match_row[r] = -1;
+    for (int c = tid; c < n2; c += NT) a.match_col[c] = -1;
     __threadfence_block();
     __syncthreads();
     auto find = [&](int v) { int p = a.node_parent[v]; while (p != v) { v = p; p = a.node_parent[v]; } return v; };
-    for (int e = tid; e < E; e += INIT_THREADS) {       // components: lock-free union (smaller root wins => the root is a row node)
+    for (int e = tid; e < E; e += NT) {       // components: lock-free union (smaller root wins => the root is a row node)
         int ra = find(a.e_row[e]), rb = find(n1 + a.e_col[e]);
         while (ra != rb) {
             if (ra > rb) { const int t = ra; ra = rb; rb = t; }
@@ -127,21 +128,21 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
     __threadfence_block();
     __syncthreads();
     int myroot[2] = {-1, -1};                            // (at most 2048 nodes: two per thread)
-    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += INIT_THREADS) myroot[q] = find(v);
+    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += NT) myroot[q] = find(v);
     __syncthreads();
-    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += INIT_THREADS) a.node_parent[v] = myroot[q];      // flattened: node -> root
-    for (int v = tid + 2 * INIT_THREADS; v < V; v += INIT_THREADS) a.node_parent[v] = find(v);            // (larger problems: racy but benign: roots are fixed points)
+    for (int q = 0, v = tid; q < 2 && v < V; ++q, v += NT) a.node_parent[v] = myroot[q];      // flattened: node -> root
+    for (int v = tid + 2 * NT; v < V; v += NT) a.node_parent[v] = find(v);            // (larger problems: racy but benign: roots are fixed points)
     // adjacency: edges chained per row (row_head / e_next), rows with edges chained per component (comp_head / row_next)
-    for (int e = tid; e < E; e += INIT_THREADS) a.e_next[e] = atomicExch(&a.row_head[a.e_row[e]], e);
+    for (int e = tid; e < E; e += NT) a.e_next[e] = atomicExch(&a.row_head[a.e_row[e]], e);
     __threadfence_block();
     __syncthreads();
-    for (int r = tid; r < n1; r += INIT_THREADS)
+    for (int r = tid; r < n1; r += NT)
         if (a.row_head[r] >= 0) a.row_next[r] = atomicExch(&a.comp_head[a.node_parent[r]], r);
     __threadfence_block();
     __syncthreads();
     // one thread per component: successive shortest augmenting paths.  repeat { Bellman-Ford over the residual graph from all
     // free rows; the free column with the smallest distance; augment } until no free column is reachable
-    for (int root = tid; root < n1; root += INIT_THREADS) {
+    for (int root = tid; root < n1; root += NT) {
         if (a.comp_head[root] < 0) continue;
         for (int guard_aug = 0; guard_aug <= n1; ++guard_aug) {
             for (int r = a.comp_head[root]; r >= 0; r = a.row_next[r]) {
@@ -195,13 +196,14 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
     __syncthreads();
 }
 
-// One scan of the initiator, by ONE workgroup of INIT_THREADS threads (initiator_kernel; the forest runs it inside post_scan_kernel,
+// One scan of the initiator, by ONE workgroup of NT threads (INIT_THREADS in initiator_kernel; the forest runs it inside post_scan_kernel,
 // between the scan's commit and the admission of the new targets).
 // AIS = false compiles the seeding phase (1b) out: the kernels on the path of every streamed scan (cluster_init_kernel; post_scan_kernel
 // without messages) keep the register budget they had -- 1024 threads leave 128 registers, the phase's matrices spill 400 bytes per lane.
-template <bool AIS = true>
+// NT = threads of the workgroup (1024 in the kernels of its own; 256 when it rides in the ILP launch, mht_blp.hip: blp_init_kernel)
+template <bool AIS = true, int NT = INIT_THREADS>
 static __device__ void initiator_body(const InitArgs& a) {
-    __shared__ int s_cnt[8], s_scan[INIT_THREADS / 64 + 1];
+    __shared__ int s_cnt[8], s_scan[(NT / 64 + 1 + 3) & ~3];      // (multiples of 16 bytes: the dynamic LDS of the kernel this is inlined into stays aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     InitDev& st = *a.st;
     const int n_pre = st.n_prelim, n_seed = st.n_seeds, have_last = st.have_last;
@@ -212,7 +214,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     int nU = 0;
     {
         int running = 0;
-        for (int base = 0; base < a.M; base += INIT_THREADS) {
+        for (int base = 0; base < a.M; base += NT) {
             const int j = base + tid;
             const bool un = j < a.M && !(a.used_b ? a.used_b[j] != 0 : (a.used && ((a.used[j >> 6] >> (j & 63)) & 1ull)));
             const unsigned long long bal = __ballot(un);
@@ -221,7 +223,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             int off = running;
             for (int w = 0; w < wave; ++w) off += s_scan[w];
             int tot = 0;
-            for (int w = 0; w < INIT_THREADS / 64; ++w) tot += s_scan[w];
+            for (int w = 0; w < NT / 64; ++w) tot += s_scan[w];
             if (un) a.upos[off + __popcll(bal & ((1ull << lane) - 1ull))] = j;
             running += tot;
             __syncthreads();
@@ -247,7 +249,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         for (int i = 0; i < 16; ++i) Q[i] = 0.f;
         const float q4 = (float)(dt * dt * dt * dt / 4.0) * a.sigma_q, q3 = (float)(dt * dt * dt / 3.0) * a.sigma_q, q2 = (float)(dt * dt) * a.sigma_q;
         Q[0] = Q[5] = q4; Q[2] = Q[8] = Q[7] = Q[13] = q3; Q[10] = Q[15] = q2;
-        for (int i = tid; i < n_pre; i += INIT_THREADS) {
+        for (int i = tid; i < n_pre; i += NT) {
             const float* x = a.pstate + (size_t)i * 4;
             const float* P = a.pcov + (size_t)i * 16;
             float xp[4], FP[16], Ft[16], Pb[16];
@@ -276,7 +278,9 @@ static __device__ void initiator_body(const InitArgs& a) {
     // ---- (1b) messages no track took start preliminary tracks (m_of_n.py:262-280), one after the other: each is tested against every
     //      track there is by then, the ones started a moment ago included -------------------------------------------------------------
     if (AIS && nAu > 0) {
-        __shared__ int s_hit, s_nall;
+        __shared__ int s_hn[4];
+        int& s_hit = s_hn[0];
+        int& s_nall = s_hn[1];
         if (tid == 0) s_nall = n_pre0;
         __syncthreads();
         for (int q = 0; q < a.nA; ++q) {
@@ -285,7 +289,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             if (tid == 0) s_hit = 0;
             __syncthreads();
             const int nall = s_nall;
-            for (int p = tid; p < n_pre0; p += INIT_THREADS) if (a.pmmsi[p] == m.mmsi) s_hit = 1;      // a track with this identity exists (m_of_n.py:262-267)
+            for (int p = tid; p < n_pre0; p += NT) if (a.pmmsi[p] == m.mmsi) s_hit = 1;      // a track with this identity exists (m_of_n.py:262-267)
             __syncthreads();
             if (s_hit) { __syncthreads(); continue; }
             // state = Phi(dT) m.state (float32 matrix x float64 vector = float64 gemv), covariance = Phi P0 Phi^T + Q (classDefinitions.py:470-475)
@@ -296,7 +300,7 @@ static __device__ void initiator_body(const InitArgs& a) {
                 const double p0 = (double)Ff[r * 4] * m.state[0], p1 = (double)Ff[r * 4 + 1] * m.state[1], p2 = (double)Ff[r * 4 + 2] * m.state[2], p3 = (double)Ff[r * 4 + 3] * m.state[3];
                 cs[r] = (p0 + p2) + (p1 + p3);
             }
-            for (int p = tid; p < nall; p += INIT_THREADS) {               // PreliminaryTrack.compareSimilarity (m_of_n.py:196-201) of every track with the candidate
+            for (int p = tid; p < nall; p += NT) {               // PreliminaryTrack.compareSimilarity (m_of_n.py:196-201) of every track with the candidate
                 double d[4];
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = (p < n_pre0 ? (double)a.pstate[(size_t)p * 4 + e] : a.ais_x64[(size_t)(p - n_pre0) * 4 + e]) - cs[e];
                 float S[16], Si[16];
@@ -353,13 +357,13 @@ static __device__ void initiator_body(const InitArgs& a) {
         // list stay as they are.
         if (n_pre > 0 && !frozen) {
         if (nU == 0) {
-            for (int i = tid; i < n_pre; i += INIT_THREADS) a.match_row[i] = -1;
+            for (int i = tid; i < n_pre; i += NT) a.match_row[i] = -1;
             __threadfence_block();
             __syncthreads();
         } else {
         // gate: (track, unused measurement) pairs with NIS <= gamma -> edges with the Euclidean distance as cost
         const long long npairs = (long long)n_pre * nU;
-        for (long long w = tid; w < npairs; w += INIT_THREADS) {
+        for (long long w = tid; w < npairs; w += NT) {
             const int i = (int)(w / nU), k = (int)(w % nU);
             const int j = a.upos[k];
             const float* xp = a.pred + (size_t)i * 4;
@@ -384,10 +388,10 @@ static __device__ void initiator_body(const InitArgs& a) {
         if (E > INIT_ECAP) { if (tid == 0) st.overflow = 1; E = INIT_ECAP; }
         __threadfence_block();
         __syncthreads();
-        gnn_solve(a, n_pre, nU, E);
+        gnn_solve<NT>(a, n_pre, nU, E);
         }
         // Kalman update of the matched tracks, counters
-        for (int i = tid; i < n_pre; i += INIT_THREADS) {
+        for (int i = tid; i < n_pre; i += NT) {
             const int k = a.match_row[i];
             float* x = a.pstate + (size_t)i * 4;
             const float* xp = a.pred + (size_t)i * 4;
@@ -421,7 +425,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     {
         const int n_pre = n_pre_all;
         int run_keep = 0, run_born = 0;
-        for (int base = 0; base < n_pre; base += INIT_THREADS) {
+        for (int base = 0; base < n_pre; base += NT) {
             const int i = base + tid;
             int keep = 0, born = 0;
             if (i < n_pre && frozen) keep = 1;
@@ -437,7 +441,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             if (lane == 0) { s_scan[wave] = __popcll(bk) | (__popcll(bb) << 16); }
             __syncthreads();
             int offk = run_keep, offb = run_born, totk = 0, totb = 0;
-            for (int w = 0; w < INIT_THREADS / 64; ++w) {
+            for (int w = 0; w < NT / 64; ++w) {
                 const int v = s_scan[w];
                 if (w < wave) { offk += v & 0xffff; offb += v >> 16; }
                 totk += v & 0xffff; totb += v >> 16;
@@ -469,14 +473,14 @@ static __device__ void initiator_body(const InitArgs& a) {
     {
         int running = 0;
         const bool any_match = n_pre_all > 0 && nU > 0;      // (the assignment ran: match_col is this scan's)
-        for (int base = 0; base < nU; base += INIT_THREADS) {
+        for (int base = 0; base < nU; base += NT) {
             const int k = base + tid;
             const bool free = k < nU && !(any_match && a.match_col[k] >= 0);
             const unsigned long long bal = __ballot(free);
             if (lane == 0) s_scan[wave] = __popcll(bal);
             __syncthreads();
             int off = running, tot = 0;
-            for (int w = 0; w < INIT_THREADS / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
+            for (int w = 0; w < NT / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
             if (free) a.comp_nodes[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
             running += tot;
             __syncthreads();
@@ -493,7 +497,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         const double dts = a.now - last;                       // (all initiators carry last scan's time stamp)
         const double gate = a.v_max * dts;
         const long long npairs = (long long)n_seed * nU2;
-        for (long long w = tid; w < npairs; w += INIT_THREADS) {
+        for (long long w = tid; w < npairs; w += NT) {
             const int i = (int)(w / nU2), q = (int)(w % nU2);
             const int j = a.upos[a.comp_nodes[q]];
             const float dx = a.z[2 * j] - a.seeds[2 * i], dy = a.z[2 * j + 1] - a.seeds[2 * i + 1];      // float32 differences ...
@@ -508,9 +512,11 @@ static __device__ void initiator_body(const InitArgs& a) {
         if (E2 > INIT_ECAP) { if (tid == 0) st.overflow = 1; E2 = INIT_ECAP; }
         __threadfence_block();
         __syncthreads();
-        gnn_solve(a, n_seed, nU2, E2);
+        gnn_solve<NT>(a, n_seed, nU2, E2);
         // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference)
-        __shared__ int s_similar, s_np;
+        __shared__ int s_sn[4];      // (16 bytes, see s_cnt)
+        int& s_similar = s_sn[0];
+        int& s_np = s_sn[1];
         if (tid == 0) s_np = n_keep;
         __syncthreads();
         for (int i = 0; i < n_seed; ++i) {
@@ -523,7 +529,7 @@ static __device__ void initiator_body(const InitArgs& a) {
             if (tid == 0) s_similar = 0;
             __syncthreads();
             const int np = s_np;
-            for (int p = tid; p < np; p += INIT_THREADS) {     // PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1
+            for (int p = tid; p < np; p += NT) {     // PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1
                 float d[4], S[16], Si[16];
                 for (int e = 0; e < 4; ++e) d[e] = a.pstate2[(size_t)p * 4 + e] - cand[e];
                 for (int e = 0; e < 16; ++e) S[e] = a.pcov2[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
@@ -556,14 +562,14 @@ static __device__ void initiator_body(const InitArgs& a) {
     {
         int running = 0;
         const bool paired = n_seed > 0 && nU2 > 0;
-        for (int base = 0; base < nU2; base += INIT_THREADS) {
+        for (int base = 0; base < nU2; base += NT) {
             const int q = base + tid;
             const bool left = q < nU2 && !(paired && a.match_col[q] >= 0);
             const unsigned long long bal = __ballot(left);
             if (lane == 0) s_scan[wave] = __popcll(bal);
             __syncthreads();
             int off = running, tot = 0;
-            for (int w = 0; w < INIT_THREADS / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
+            for (int w = 0; w < NT / 64; ++w) { if (w < wave) off += s_scan[w]; tot += s_scan[w]; }
             if (left) {
                 const int p = off + __popcll(bal & ((1ull << lane) - 1ull));
                 const int j = a.upos[a.comp_nodes[q]];
@@ -577,7 +583,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     }
     __threadfence_block();
     __syncthreads();
-    for (int p = tid; p < n_left; p += INIT_THREADS) { a.seeds[2 * p] = (float)a.bf_dist[2 * p]; a.seeds[2 * p + 1] = (float)a.bf_dist[2 * p + 1]; }
+    for (int p = tid; p < n_left; p += NT) { a.seeds[2 * p] = (float)a.bf_dist[2 * p]; a.seeds[2 * p + 1] = (float)a.bf_dist[2 * p + 1]; }
     // ---- merge confirmed candidates closer than the threshold (m_of_n.py:133-154): greedy, in order; a handful at most -------------
     if (tid == 0) {
         int nb = n_born, out = 0;

@@ -268,7 +268,7 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
 bool cluster_fits_lds(int Tcap, int n_mnodes);
 size_t cluster_big_ints(int Tcap, int n_mnodes);
-int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init = nullptr, const int32_t* sticky_overflow = nullptr);      // init: the initiator rides as one more workgroup
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);
 
