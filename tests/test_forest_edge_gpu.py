@@ -467,3 +467,44 @@ def test_console_log_of_the_reference(capsys):
     trk.printTimeLogHeader(); trk.printTargetList()
     assert "TargetList:" in capsys.readouterr().out
     trk.close()
+
+
+def test_report_two_scans_back_raw_abi():
+    """C-ABI order of a streaming host with the device initiator: mht_forest_scan(k) queues scan k, the report of scan k - 1 leaves
+    the device inside scan k's grow launch -- a host that folds the report of scan k - 2 behind its call for scan k
+    (mht_forest_report_get(which = 2)) never waits for that launch.  Every report is that of its scan; which = 2 is refused
+    (MHT_E_STATE) once the last scan's report has been flushed to the host block of the same parity."""
+    import ctypes as C
+    from pymht_amd import _lib
+    sc = _scenario(T=30, n_scans=7, seed=12)
+    trk = _mk(sc, N=3)
+    lib, h, ih = trk._lib, trk._ctx.handle, trk.initiator.handle
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    z = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in sc["scans"]]
+
+    def get(which):
+        rep = _lib.MhtScanReport()
+        rc = lib.mht_forest_report_get(h, which, C.byref(rep))
+        return rc, rep.scan, rep.n_targets, rep.n_alive
+
+    seen = {}
+    for k in range(1, 7):
+        _lib.check(lib.mht_forest_scan(h, ih, p(z[k - 1]), len(z[k - 1]), float(sc["times"][k - 1])))
+        if k >= 3:
+            rc, s_, nT, na = get(2)
+            assert rc == 0 and s_ == k - 2, (k, rc, s_)
+            seen[s_] = (nT, na)
+        else:
+            assert get(2)[0] == _lib.MHT_E_STATE          # (no scan two back yet)
+    rc, s_, nT, na = get(1)
+    assert rc == 0 and s_ == 5
+    rc, s_, nT6, na6 = get(0)                              # (flushes scan 6's commit, admission and report)
+    assert rc == 0 and s_ == 6 and nT6 >= na6 > 0
+    assert get(2)[0] == _lib.MHT_E_STATE                   # scan 4's block now holds scan 6
+    assert sorted(seen) == [1, 2, 3, 4] and all(nT >= na > 0 for nT, na in seen.values())
+    # the tracker object is still usable: its own bookkeeping was bypassed, so only the library is exercised from here on
+    _lib.check(lib.mht_forest_scan(h, ih, p(z[6]), len(z[6]), float(sc["times"][6])))
+    rc, s_, _, _ = get(0)
+    assert rc == 0 and s_ == 7
+    trk._pendq = []
+    trk.close()
