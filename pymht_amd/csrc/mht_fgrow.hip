@@ -23,6 +23,7 @@
 #include "mht_kernels.h"
 #include "mht_commit.h"
 #include "mht_admit.h"
+#include <stddef.h>
 
 namespace mht {
 
@@ -1264,6 +1265,8 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
 // for nobody) and leave at once when the count is zero.  Only a scan WITH births pays for device-scope fences (on this part a release
 // writes the XCD's dirty L2 lines back -- megabytes of children in the middle of a grow launch: 6 us when every scan did it).
 constexpr int FG_BORN_WGS = 16, FG_BORN_CHAIN_WGS = 8;
+static_assert(offsetof(mht_target_report, new_index) >= 16 && offsetof(mht_target_report, n_leaves) + 4 <= 32 && offsetof(mht_target_report, root_node) < 32,
+              "what the commit writes of a report row sits in its second 16 bytes (fgrow_adm_kernel pushes the row in two pieces)");
 template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub, const AddArgs ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1285,10 +1288,10 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
             __hip_atomic_store(&cm.cnt->adm_flag, ((unsigned long long)(unsigned)d.c_scan << 32) | ((unsigned long long)born0 << 16) | (unsigned long long)n_born,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (pub.dst) {
-            // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words in the first
-            // 32 bytes of a row (new index, leaves kept), which the commit above filled in.  FG_PUB_WGS workgroups push everything
-            // BEHIND those 32 bytes of every row from the start of the launch; this workgroup pushes what it wrote itself -- header,
-            // used-measurement mask, births, the first 32 bytes of every row.  Disjoint bytes: nobody waits for anybody, no fences.
+            // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words in the second
+            // 16 bytes of a row (new index, leaves kept), which the commit above filled in.  FG_PUB_WGS workgroups push everything
+            // but those 16 bytes of every row from the start of the launch; this workgroup pushes what it wrote itself -- header,
+            // used-measurement mask, births, the second 16 bytes of every row.  Disjoint bytes: nobody waits for anybody, no fences.
             const ReportHeader* h = reinterpret_cast<const ReportHeader*>(pub.src);
             const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
             uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
@@ -1296,17 +1299,17 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
             for (int i = threadIdx.x; i < head; i += FG_THREADS) d4[i] = s4[i];
             constexpr int RQ = (int)sizeof(mht_target_report) / 16;
             const int r0 = pub.rec_off / 16;
-            for (int i = threadIdx.x; i < 2 * nTr; i += FG_THREADS) { const int k = r0 + (i >> 1) * RQ + (i & 1); d4[k] = s4[k]; }
+            for (int i = threadIdx.x; i < nTr; i += FG_THREADS) { const int k = r0 + i * RQ + 1; d4[k] = s4[k]; }
         }
         return;
     }
-    if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report behind their first 32 bytes, as the previous launch left them (see workgroup 0)
-        constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 2;
+    if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report without their second 16 bytes, as the previous launch left them (see workgroup 0)
+        constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 1;
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
         const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
         uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
         const int r0 = pub.rec_off / 16;
-        for (int i = (bx - 1) * FG_THREADS + threadIdx.x; i < nTr * RB; i += FG_PUB_WGS * FG_THREADS) { const int k = r0 + (i / RB) * RQ + 2 + (i % RB); d4[k] = s4[k]; }
+        for (int i = (bx - 1) * FG_THREADS + threadIdx.x; i < nTr * RB; i += FG_PUB_WGS * FG_THREADS) { const int c = i % RB, k = r0 + (i / RB) * RQ + (c ? c + 1 : 0); d4[k] = s4[k]; }
         return;
     }
     const int bg = bx - (pub.dst ? FG_PUB_WGS : 0);      // index among the grow workgroups

@@ -114,6 +114,7 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
     for (int c = tid; c < n2; c += NT) a.match_col[c] = -1;
     __threadfence_block();
     __syncthreads();
+    if (E == 0) return;      // (uniform) nothing is allowed: nothing is matched -- the usual scan of a stream whose leftovers are clutter
     auto find = [&](int v) { int p = a.node_parent[v]; while (p != v) { v = p; p = a.node_parent[v]; } return v; };
     for (int e = tid; e < E; e += NT) {       // components: lock-free union (smaller root wins => the root is a row node)
         int ra = find(a.e_row[e]), rb = find(n1 + a.e_col[e]);
@@ -201,8 +202,17 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
 // AIS = false compiles the seeding phase (1b) out: the kernels on the path of every streamed scan (cluster_init_kernel; post_scan_kernel
 // without messages) keep the register budget they had -- 1024 threads leave 128 registers, the phase's matrices spill 400 bytes per lane.
 // NT = threads of the workgroup (1024 in the kernels of its own; 256 when it rides in the ILP launch, mht_blp.hip: blp_init_kernel)
+#ifdef MHT_INIT_STAMPS
+#define INIT_STAMP(k) do { if (threadIdx.x == 0) init_t[k] = wall_clock64(); } while (0)
+#else
+#define INIT_STAMP(k)
+#endif
 template <bool AIS = true, int NT = INIT_THREADS>
 static __device__ void initiator_body(const InitArgs& a) {
+#ifdef MHT_INIT_STAMPS
+    unsigned long long init_t[10] = {};
+#endif
+    INIT_STAMP(0);
     __shared__ int s_cnt[8], s_scan[(NT / 64 + 1 + 3) & ~3];      // (multiples of 16 bytes: the dynamic LDS of the kernel this is inlined into stays aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     InitDev& st = *a.st;
@@ -232,6 +242,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     }
     __threadfence_block();
     __syncthreads();
+    INIT_STAMP(1);
     // ---- (1) preliminary tracks (m_of_n.py:246-378) --------------------------------------------------------------------------------
     // AIS messages no track took (in list order): they start preliminary tracks below, and with any of them the scan is processed even
     // without a single unused radar measurement (m_of_n.py:289-292)
@@ -468,6 +479,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     }
     __threadfence_block();
     __syncthreads();
+    INIT_STAMP(2);
     // ---- unused' = unused measurements no preliminary track took (ascending) -> comp_nodes[0..nU2) holds their unused-list indices
     int nU2 = 0;
     {
@@ -489,6 +501,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     }
     __threadfence_block();
     __syncthreads();
+    INIT_STAMP(3);
     // ---- (2) pair the leftovers with last scan's initiators (m_of_n.py:380-478) ---------------------------------------------------
     int n_pre_now = n_keep;
     if (n_seed > 0 && nU2 > 0) {
@@ -512,20 +525,33 @@ static __device__ void initiator_body(const InitArgs& a) {
         if (E2 > INIT_ECAP) { if (tid == 0) st.overflow = 1; E2 = INIT_ECAP; }
         __threadfence_block();
         __syncthreads();
+        INIT_STAMP(4);
         gnn_solve<NT>(a, n_seed, nU2, E2);
+        INIT_STAMP(5);
         // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference)
         __shared__ int s_sn[4];      // (16 bytes, see s_cnt)
         int& s_similar = s_sn[0];
         int& s_np = s_sn[1];
         if (tid == 0) s_np = n_keep;
         __syncthreads();
-        for (int i = 0; i < n_seed; ++i) {
-            const int q = a.match_row[i];
-            if (q < 0) continue;                               // uniform (global memory, written before the barrier)
-            const int j = a.upos[a.comp_nodes[q]];
+        // (the matches are fetched 64 initiators at a time -- every wavefront reads the same words -- and each lane forms its own
+        // candidate: walking match_row[] one element at a time was one dependent global round trip per initiator, matched or not,
+        // and four more per match: half of the kernel's time on the headline stream with its ~40 initiators per scan)
+        for (int base = 0; base < n_seed; base += 64) {
+          const int i_l = base + lane;
+          const int qv = (i_l < n_seed) ? a.match_row[i_l] : -1;      // (global memory, written before the barrier)
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+          if (qv >= 0) {
+              const int j = a.upos[a.comp_nodes[qv]];
+              c0 = a.z[2 * j]; c1 = a.z[2 * j + 1];
+              c2 = (c0 - a.seeds[2 * i_l]) / (float)dts; c3 = (c1 - a.seeds[2 * i_l + 1]) / (float)dts;
+          }
+          unsigned long long todo = __ballot(qv >= 0);
+          while (todo) {                                        // uniform: initiator order
+            const int bsel = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
             float cand[4];
-            cand[0] = a.z[2 * j]; cand[1] = a.z[2 * j + 1];
-            cand[2] = (cand[0] - a.seeds[2 * i]) / (float)dts; cand[3] = (cand[1] - a.seeds[2 * i + 1]) / (float)dts;
+            cand[0] = __shfl(c0, bsel); cand[1] = __shfl(c1, bsel); cand[2] = __shfl(c2, bsel); cand[3] = __shfl(c3, bsel);
             if (tid == 0) s_similar = 0;
             __syncthreads();
             const int np = s_np;
@@ -554,9 +580,11 @@ static __device__ void initiator_body(const InitArgs& a) {
             }
             __threadfence_block();
             __syncthreads();
+          }
         }
         n_pre_now = s_np;
     }
+    INIT_STAMP(6);
     // ---- (3) next scan's initiators = leftovers nobody paired (ascending) ----------------------------------------------------------
     int n_left = 0;
     {
@@ -584,6 +612,7 @@ static __device__ void initiator_body(const InitArgs& a) {
     __threadfence_block();
     __syncthreads();
     for (int p = tid; p < n_left; p += NT) { a.seeds[2 * p] = (float)a.bf_dist[2 * p]; a.seeds[2 * p + 1] = (float)a.bf_dist[2 * p + 1]; }
+    INIT_STAMP(7);
     // ---- merge confirmed candidates closer than the threshold (m_of_n.py:133-154): greedy, in order; a handful at most -------------
     if (tid == 0) {
         int nb = n_born, out = 0;
@@ -633,6 +662,13 @@ static __device__ void initiator_body(const InitArgs& a) {
         st.have_last = 1;
         st.last_time = a.now;
         st.n_unused_out = nU;
+#ifdef MHT_INIT_STAMPS
+        init_t[8] = wall_clock64();
+        if (a.scan_no == 200 || a.scan_no == 201)
+            printf("[init %d] nU %d n_seed %d: head %.2f | phase1 %.2f | unused' %.2f | pairs %.2f | gnn %.2f | new tracks %.2f | leftovers %.2f | merge+end %.2f | total %.2f us\n", a.scan_no, nU, n_seed,
+                   1e-2 * (double)(init_t[1] - init_t[0]), 1e-2 * (double)(init_t[2] - init_t[1]), 1e-2 * (double)(init_t[3] - init_t[2]), 1e-2 * (double)(init_t[4] - init_t[3]),
+                   1e-2 * (double)(init_t[5] - init_t[4]), 1e-2 * (double)(init_t[6] - init_t[5]), 1e-2 * (double)(init_t[7] - init_t[6]), 1e-2 * (double)(init_t[8] - init_t[7]), 1e-2 * (double)(init_t[8] - init_t[0]));
+#endif
     }
 }
 
