@@ -561,7 +561,7 @@ def main():
         "multi_sector_all": multi_all,
         "ilp": ilp_acc,
         "api_scans_per_sec": 1.0 / api_s,
-        "api_note": "drop-in Tracker.addMeasurementList, streaming (scan k+1 is queued while the report of scan k is folded; results "
+        "api_note": "drop-in Tracker.addMeasurementList, streaming (scan k+2 is queued before the report of scan k is folded; results "
                     "read after the last scan): PCIe copy of every scan, steps 1-7 on the device (M-of-N initiator included), "
                     "report D2H + host mirror per scan; same scans as `value` (pre-roll and warm-up untimed)",
         "roofline": {"bound": "hbm", "achieved": gate_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
