@@ -63,8 +63,9 @@ struct CommitArgs {
 // roots, build the next scan's leaf ranges, write the scan report.  One workgroup: everything here is O(targets).
 // NT = threads of the workgroup; `sm` = 2 * NT / 64 + 8 ints of LDS scratch (handed in by the kernel: a static __shared__
 // here would shift the dynamic LDS base of the kernels this is inlined into off its 16-byte alignment).
+// Returns the number of targets alive behind the scan (every thread), -1 for a void scan.
 template <int NT, typename CARGS>
-__device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn, int* sm) {
+__device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, int* sm) {
     constexpr int PRUNE_THREADS = NT;
     int* s_scan = sm;
     int* s_scan2 = sm + NT / 64;
@@ -84,6 +85,9 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
     int v_rs = a.w_root_scan[tcl], v_rn = a.w_root_node[tcl];
     double v_rc = a.w_root_cnllr[tcl];
     uint8_t v_rf = a.w_root_f32[tcl];
+    // (the ILP statistics' first batch of look-ups goes out with the above and its dependent one behind it, instead of as two more
+    // round trips at the end of the workgroup's critical path; entries of multi_list beyond this scan's count are stale but valid ids)
+    const int c_first = a.multi_list[tcl];
     if (s_over || c_over) {        // void scan: report the error, leave the forest alone (it must be recreated)
         if (tid == 0) {
             ReportHeader& h = *a.hdr;
@@ -93,10 +97,12 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
             h.t_process = h.t_cluster = h.t_optim = h.t_scan = 0;
             a.cnt->overflow = 1;
         }
-        return;
+        return -1;
     }
     const int L_in = a.cur.leaf_off[nT] - a.status->n_dead;      // (only needed at the very end; slots minus what similar-state pruning emptied)
     if (tid == 0) { s_branched = 0; s_limit = 0; s_itmax = 0; }
+    const int cf = (c_first >= 0 && c_first < a.Tcap) ? c_first : 0;
+    const int st_first = a.cl_status[cf], it_first = a.cl_iters[cf];
     int running = 0, lrun = 0;
     for (int base = 0; base < nT; base += PRUNE_THREADS) {
         const int t = base + tid;
@@ -157,7 +163,12 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
     }
     const int nAlive = running, Lnext = lrun;
     // ILP statistics
-    for (int i = tid; i < n_ilp; i += PRUNE_THREADS) {      // only this scan's ILPs: the entries of other clusters are stale
+    if (tid < n_ilp) {                                      // only this scan's ILPs: the entries of other clusters are stale
+        if (st_first == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
+        if (st_first == MHT_BLP_NODE_LIMIT) atomicAdd(&s_limit, 1);
+        if (st_first) atomicMax(&s_itmax, it_first);
+    }
+    for (int i = tid + PRUNE_THREADS; i < n_ilp; i += PRUNE_THREADS) {
         const int c = a.multi_list[i];
         const int st = a.cl_status[c];
         if (st == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
@@ -214,6 +225,7 @@ __device__ __forceinline__ void commit_body(const CARGS& a, const CommitDyn dyn,
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a
         // commit that rides in the next grow_kernel must not touch what that kernel's tiles are reading)
     }
+    return nAlive;
 }
 
 }  // namespace mht

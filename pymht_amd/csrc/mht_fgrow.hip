@@ -1265,8 +1265,8 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
 // for nobody) and leave at once when the count is zero.  Only a scan WITH births pays for device-scope fences (on this part a release
 // writes the XCD's dirty L2 lines back -- megabytes of children in the middle of a grow launch: 6 us when every scan did it).
 constexpr int FG_BORN_WGS = 16, FG_BORN_CHAIN_WGS = 8;
-static_assert(offsetof(mht_target_report, new_index) >= 16 && offsetof(mht_target_report, n_leaves) + 4 <= 32 && offsetof(mht_target_report, root_node) < 32,
-              "what the commit writes of a report row sits in its second 16 bytes (fgrow_adm_kernel pushes the row in two pieces)");
+static_assert(offsetof(mht_target_report, new_index) == 16 && offsetof(mht_target_report, n_leaves) == 28,
+              "what the commit writes of a report row are the first and the last word of its second 16 bytes (fgrow_adm_kernel forms them for the host block itself)");
 template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub, const AddArgs ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1275,41 +1275,87 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
     if (bx == 0) {
         int* sm = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
-        commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, sm);
+        // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
+        int n_cand = ad.n;
+        if (ad.n_dev) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }
+#ifdef MHT_ADM_STAMPS
+        const unsigned long long ts0 = wall_clock64();
+#endif
+        const int born0 = commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, sm);      // targets alive behind the scan, -1: void scan
         __threadfence_block();
         __syncthreads();
-        const int born0 = cm.cnt->nT;
-        if (!cm.hdr->error) add_targets_body<FG_THREADS>(ad, sm + 64);      // (void scan: nothing is admitted)
-        __threadfence_block();
-        __syncthreads();
-        const int n_born = cm.cnt->nT - born0;
+#ifdef MHT_ADM_STAMPS
+        const unsigned long long ts1 = wall_clock64();
+#endif
+        int n_born = 0;
+        if (born0 >= 0 && n_cand > 0) {                      // (void scan: nothing is admitted; no candidates: the usual scan)
+            add_targets_body<FG_THREADS>(ad, sm + 64);
+            __threadfence_block();
+            __syncthreads();
+            n_born = cm.cnt->nT - born0;
+        }
         if (n_born > 0) __threadfence();      // the newborn targets' workgroups sit on other CUs / XCDs
         if (threadIdx.x == 0)
-            __hip_atomic_store(&cm.cnt->adm_flag, ((unsigned long long)(unsigned)d.c_scan << 32) | ((unsigned long long)born0 << 16) | (unsigned long long)n_born,
+            __hip_atomic_store(&cm.cnt->adm_flag, ((unsigned long long)(unsigned)d.c_scan << 32) | ((unsigned long long)(born0 < 0 ? 0 : born0) << 16) | (unsigned long long)n_born,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (pub.dst) {
-            // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words in the second
-            // 16 bytes of a row (new index, leaves kept), which the commit above filled in.  FG_PUB_WGS workgroups push everything
-            // but those 16 bytes of every row from the start of the launch; this workgroup pushes what it wrote itself -- header,
-            // used-measurement mask, births, the second 16 bytes of every row.  Disjoint bytes: nobody waits for anybody, no fences.
-            const ReportHeader* h = reinterpret_cast<const ReportHeader*>(pub.src);
+            // the report: its rows were written by the previous launch (blp_kernel: per-target results) except two words (new index,
+            // leaves kept), which the commit above filled in -- and which follow from that launch's results as well.  FG_PUB_WGS
+            // workgroups push the rows from the start of the launch, each forming those two words for its rows itself; this workgroup
+            // pushes the rest of what it wrote: header, used-measurement mask, births.  Disjoint bytes: nobody waits for anybody.
             const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
             uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
-            const int head = (pub.birth_off + h->n_births * (int)sizeof(mht_birth_report) + 15) / 16, nTr = h->n_targets;
+            const int nb_rep = (born0 >= 0 && n_cand > 0) ? reinterpret_cast<const ReportHeader*>(pub.src)->n_births : 0;
+            const int head = (pub.birth_off + nb_rep * (int)sizeof(mht_birth_report) + 15) / 16;      // (head <= rec_off / 16)
             for (int i = threadIdx.x; i < head; i += FG_THREADS) d4[i] = s4[i];
-            constexpr int RQ = (int)sizeof(mht_target_report) / 16;
-            const int r0 = pub.rec_off / 16;
-            for (int i = threadIdx.x; i < nTr; i += FG_THREADS) { const int k = r0 + i * RQ + 1; d4[k] = s4[k]; }
         }
+#ifdef MHT_ADM_STAMPS
+        __syncthreads();
+        if (threadIdx.x == 0 && cm.log) { int32_t* g = cm.log + (d.c_scan & 63) * 16; const unsigned long long ts3 = wall_clock64();
+            g[12] = (int)(ts1 - ts0); g[13] = (int)(ts3 - ts1); g[14] = (int)(ts0 - ap->status->t[0]); g[15] = (int)(ts3 & 0x7fffffff); }
+#endif
         return;
     }
-    if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report without their second 16 bytes, as the previous launch left them (see workgroup 0)
+    if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report (see workgroup 0): workgroup w the rows [w, w + 1) * ceil(nT / FG_PUB_WGS)
         constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 1;
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
         const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
         uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
         const int r0 = pub.rec_off / 16;
-        for (int i = (bx - 1) * FG_THREADS + threadIdx.x; i < nTr * RB; i += FG_PUB_WGS * FG_THREADS) { const int c = i % RB, k = r0 + (i / RB) * RQ + (c ? c + 1 : 0); d4[k] = s4[k]; }
+        const int per = (nTr + FG_PUB_WGS - 1) / FG_PUB_WGS, t0 = (bx - 1) * per, t1 = (t0 + per < nTr) ? t0 + per : nTr;
+        // everything but the second 16 bytes of a row, as the previous launch left it
+        for (int i = threadIdx.x; i < (t1 - t0) * RB; i += FG_THREADS) { const int c = i % RB, k = r0 + (t0 + i / RB) * RQ + (c ? c + 1 : 0); d4[k] = s4[k]; }
+        // the second 16 bytes = {new index, root scan, root node, leaves kept}: what commit_body computes for the device block (compacted
+        // index = targets alive before this one, -1 for a terminated target; its surviving leaves), from the same per-target results
+        int* sw = reinterpret_cast<int*>(smem);      // [FG_THREADS / 64 + 1]
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        int before = 0;
+        for (int i = tid; i < t0; i += FG_THREADS) before += (ap->p_status[i] == 0) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+        if (lane == 0) sw[wv] = before;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < FG_THREADS / 64; ++q) base += sw[q];
+        for (int c0 = t0; c0 < t1; c0 += FG_THREADS) {
+            const int t = c0 + tid;
+            const bool in = t < t1;
+            const int al = (in && ap->p_status[in ? t : 0] == 0) ? 1 : 0;
+            const int leaves = al ? ap->p_count[t] : 0;
+            const unsigned long long bal = __ballot(al);
+            __syncthreads();
+            if (lane == 0) sw[wv] = __popcll(bal);
+            __syncthreads();
+            int off = base, tot = 0;
+            for (int q = 0; q < FG_THREADS / 64; ++q) { if (q < wv) off += sw[q]; tot += sw[q]; }
+            if (in) {
+                uint4 v = s4[r0 + t * RQ + 1];
+                v.x = (unsigned)(al ? off + __popcll(bal & ((1ull << lane) - 1ull)) : -1);
+                v.w = (unsigned)leaves;
+                d4[r0 + t * RQ + 1] = v;
+            }
+            base += tot;
+        }
         return;
     }
     const int bg = bx - (pub.dst ? FG_PUB_WGS : 0);      // index among the grow workgroups

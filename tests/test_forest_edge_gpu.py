@@ -482,9 +482,18 @@ def test_report_two_scans_back_raw_abi():
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     z = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in sc["scans"]]
 
+    from pymht_amd.tracker import _REPORT_DTYPE
+
     def get(which):
         rep = _lib.MhtScanReport()
         rc = lib.mht_forest_report_get(h, which, C.byref(rep))
+        if rc == 0 and rep.n_targets:      # the rows: compacted index and leaves kept are consistent with the statuses (whoever pushed the rows)
+            recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(rep.n_targets * _REPORT_DTYPE.itemsize,)).view(_REPORT_DTYPE)
+            alive = recs["status"] == 0
+            assert int(alive.sum()) == rep.n_alive
+            assert np.array_equal(recs["new_index"], np.where(alive, np.cumsum(alive) - 1, -1))
+            assert np.all(recs["n_leaves"][alive] >= 1) and np.all(recs["n_leaves"][~alive] == 0)
+            assert int(recs["n_leaves"].sum()) == rep.n_leaves_out
         return rc, rep.scan, rep.n_targets, rep.n_alive
 
     seen = {}
