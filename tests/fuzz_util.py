@@ -22,6 +22,43 @@ def scenario_of(seed):
     return sc, N, eta2, desc
 
 
+def run_case_streamed(seed, max_leaves=2000, budget_s=15.0):
+    """The same scenarios with a host that streams the scans in and looks at the end: commit and admission of the initiator's births ride
+    in the next scan's grow launch (fgrow_adm_kernel), reports are folded two scans late.  The oracle runs first (it decides where the
+    scenario stops); per-scan statistics (from the tracker's log) and the final state are compared."""
+    from test_tracker_gpu import make_tracker, tracker_selected, states_close, SCORE_ATOL
+    from trace_util import make_oracle
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc, N, eta2, desc = scenario_of(seed)
+    g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, x0=sc["x0"], t0=sc["t0"], accepted=None)
+    t0 = time.time()
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], N, eta2, sc["x0"], sc["t0"], logScanStats=True)
+    try:
+        g["accepted"] = acc
+        o = make_oracle(g)
+        infos = []
+        for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+            if time.time() - t0 > budget_s or (k > 0 and infos[-1]["L"] > max_leaves):
+                break
+            infos.append(dict(o.add_scan(float(t), z), n_ilp=o.n_ilp, n_targets=len(o.targets)))
+        for z, t in zip(sc["scans"][:len(infos)], sc["times"][:len(infos)]):
+            trk.addMeasurementList(MeasurementList(float(t), z))          # (nothing is looked at in between)
+        os_, ts = o.selected(), tracker_selected(trk)
+        lb, tb = o.leaf_batch(), trk.leafBatch()
+        log = trk.scanStatsLog
+        checks = [len(log) == len(infos) and all((s["L"], s["G"], s["ilp"], s["nTargets"]) == (i["L"], i["G"], i["n_ilp"], i["n_targets"]) and np.array_equal(s["unused"], i["unused"])
+                                                   for s, i in zip(log, infos)),
+                  [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__],
+                  np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
+                  states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
+                  np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=FUZZ_REL)]
+        if not all(checks):
+            return False, desc, 'MISMATCH (streamed): per-scan statistics %s targets %s selection %s states %s leaves %s' % tuple(checks)
+        return True, desc, ' streamed %d scans, %d targets, %.1fs' % (len(infos), len(o.targets), time.time() - t0)
+    finally:
+        trk.close()
+
+
 def run_case(seed, max_leaves=2000, budget_s=15.0, similar=False):
     """Returns (ok, description, message).  similar=True: similar-state pruning (addMeasurementList(pruneSimilar=True)) switched on
     and off at random from scan to scan, with a random pruneThreshold."""

@@ -48,3 +48,18 @@ def test_fuzz_slice_ais_aided():
             fused += int(msg.split('fused=')[1].split()[0])
     assert not bad, "\n".join(bad)
     assert fused > 1000 or n < 20
+
+
+def test_fuzz_slice_streamed():
+    """The same kind of scenarios with a host that streams the scans in and looks once at the end: the scan's commit and the admission of
+    what its initiator gave birth to ride in the next scan's grow launch, the reports are folded two scans late (fuzz_util.run_case_streamed):
+    per-scan statistics from the tracker's log and the final state against the oracle."""
+    from fuzz_util import run_case_streamed
+    n = int(os.environ.get("MHT_FUZZ_STREAM_CASES", "80"))
+    seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000")) + 500000
+    bad = []
+    for case in range(n):
+        ok, desc, msg = run_case_streamed(seed0 + case, max_leaves=1200, budget_s=6.0)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+    assert not bad, "\n".join(bad)
