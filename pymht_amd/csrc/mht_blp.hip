@@ -1582,18 +1582,30 @@ __device__ __forceinline__ void prune_members(const BlpArgs& a, const int32_t* m
     }
 }
 
-__device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned long long* uw, Red* r, unsigned char* lds,
-                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1) {
+// a cluster as the solver sees it: index among all clusters (by smallest member), offset of its (ascending) member list in cl_members,
+// size, smallest member (= its label; only filled in when the clusters come from the union-find)
+struct ClRef { int c, p0, K, root; };
+__device__ __forceinline__ ClRef cl_ref(const BlpArgs& a, int c) { const int p0 = a.cl_ptr[c]; return ClRef{c, p0, a.cl_ptr[c + 1] - p0, -1}; }
+// (clusters from the union-find: t_label is written by ONE workgroup of the launch, for the host -- the label travels with the ClRef)
+__device__ __forceinline__ TgtPre load_target_cr(const BlpArgs& a, int t, const ClRef& cr) {
+    TgtPre p = load_target(a, t);
+    if (a.uf_epoch) p.lab = cr.root;
+    return p;
+}
+// my_t: member `threadIdx.x` of the cluster if the caller has it at hand (-1: read from the member list), pre_in: its record if already fetched
+__device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, unsigned long long* uw, Red* r, unsigned char* lds,
+                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr) {
     const int tid = threadIdx.x;
-    const int K = a.cl_ptr[c + 1] - a.cl_ptr[c];
-    const int32_t* mem = a.cl_members + a.cl_ptr[c];
-    const int slot = a.cl_ptr[c] + c;
+    const int c = cr.c;
+    const int K = cr.K;
+    const int32_t* mem = a.cl_members + cr.p0;
+    const int slot = cr.p0 + c;
     const int UW = (a.n_mnodes + 63) >> 6;
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = clock64();
     TgtPre pre = {};      // per-member data of the prune epilogue, fetched now so that its latency hides behind the solve
     const bool pre_ok = a.t_alive && K <= BLP_THREADS;
-    if (pre_ok && tid < K) pre = load_target(a, mem[tid]);
+    if (pre_ok && tid < K) { if (pre_in && my_t >= 0) pre = *pre_in; else pre = load_target_cr(a, my_t >= 0 ? my_t : mem[tid], cr); }
     // LDS carve: every block below is a multiple of 16 bytes and the dynamic segment starts at offset 0 (the kernel has
     // no static __shared__), so the 16-byte column records stay aligned without integer round trips -- those would
     // make the compiler lose the LDS address space and emit slow flat accesses.
@@ -1638,7 +1650,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             for (int base = 0; base < K; base += 64) {
                 const int k = base + tid;
                 int gb = 0, n = 0;
-                if (k < K) { const int t = mem[k]; gb = a.tchild[t]; n = a.tcend[t] - gb; }
+                if (k < K) {
+                    if (pre_ok && K <= 64) { gb = pre.cb; n = pre.ce - gb; }      // (k = tid: the member's record is at hand)
+                    else { const int t = mem[k]; gb = a.tchild[t]; n = a.tcend[t] - gb; }
+                }
                 int incl = n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -1880,7 +1895,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
                 const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs.ub_sel[k];
                 a.sel[mem[k]] = h;
                 if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
-                if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target(a, mem[k]), true);
+                if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target_cr(a, mem[k], cr), true);
             }
             prune_members(a, mem, K, gs.ch);
         }
@@ -1921,7 +1936,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             a.sel[mem[k]] = h;
             if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
             if (a.t_alive) {
-                const TgtPre q = pre_ok ? pre : load_target(a, mem[k]);
+                const TgtPre q = pre_ok ? pre : load_target_cr(a, mem[k], cr);
                 s.ch[k] = finish_target(a, mem[k], h, q, true);
                 s.ub_sel[k] = q.j;             // the solver's tables are free now: prune depth, survivor count, first survivor
                 s.lix[k] = 0;
@@ -1949,6 +1964,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, int c, unsigned 
             }
         }
     }
+    if (tid == 0 && a.dbg && blockIdx.x < 3900 && tm.q == 0) {
+        unsigned long long* g = a.dbg + 32 + (size_t)blockIdx.x * 16;
+        g[8] = t_begin; g[9] = t_setup; g[10] = stamp[4]; g[11] = wall_clock64();
+    }
     if (tid == 0) {
         a.cl_status[c] = status;
         a.cl_iters[c] = iters;
@@ -1973,41 +1992,274 @@ static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
            2 * (size_t)cap_r * 4 + 6 * kpad * 4 + (size_t)cap_h * 2 * 2 + ENUM_LDS + (size_t)cap_h * 16 + (size_t)cap_h * 4;
 }
 
-__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle);
-__device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx) {      // workgroup bx of gx
+// ---- clusters from the grow launch's union-find (BlpArgs::uf_epoch; mht_kernels.h: FDyn::uf_epoch) -------------------------------------
+// What a workgroup keeps of the cluster tables it derived (uf_prologue) once the solver's tables overlay them: its own clusters, the
+// teams, the single-target clusters of its wavefronts.  Lives behind the solver's LDS (BLP_UF_PERSIST bytes).
+struct UfPersist {
+    int nT, nC, nMulti, nSingle, nTeam, my_t, pad[2];
+    ClRef own[4];                          // multi-target clusters bx, bx + gx, ... (by rank among the multi-target clusters)
+    ClRef team[TEAM_MAX];
+    unsigned short single[BLP_THREADS / 64][8];      // wavefront w: targets alone in their cluster, i = gw + j * nw
+};
+constexpr size_t BLP_UF_PERSIST = (sizeof(UfPersist) + 15) & ~(size_t)15;
+constexpr int UF_SPEC = 4;      // parent words per thread fetched together with the target count (1 024 targets in the first round trip)
+// LDS of the prologue for T targets (overlaid by the solver afterwards): see the carve below
+__host__ __device__ constexpr size_t uf_prologue_bytes(size_t T) { return ((T + 7) & ~(size_t)7) * 18 + 256; }
+
+// Every workgroup of the launch derives the cluster tables for itself, in LDS, from the parents the grow launch left (one global round
+// trip, seven barriers): labels = roots = smallest members, member counts, ONE block scan for cluster index / member offset / rank among
+// the multi-target, single-target and team-sized clusters, ascending member lists (slot by LDS atomic, rank by counting the smaller
+// members -- as cluster_kernel).  Same tables, same order as the clustering kernel's; workgroup `writer` files them in global memory
+// for the commit's statistics and the host.  Returns false for a void scan.
+// the prologue's one global round trip, issued at the very start of the kernel: status word, target count and -- speculatively, the first
+// UF_SPEC x 256 of them -- the parents (the solver's own scalar set-up, ~2 us of argument loads, runs while they are in flight)
+struct UfFetch { int s_over, nT; unsigned long long pw[UF_SPEC]; };
+__device__ __forceinline__ UfFetch uf_prefetch(const BlpArgs& a) {
+    UfFetch f;
+    f.s_over = a.status ? a.status->overflow : 0;
+    f.nT = *a.nT_dev;
+#pragma unroll
+    for (int q = 0; q < UF_SPEC; ++q) {
+        const int t = (int)threadIdx.x + q * BLP_THREADS;
+        f.pw[q] = a.uf_parent[(t < a.uf_cap) ? t : 0];
+    }
+    return f;
+}
+__device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe, unsigned char* lds, UfPersist* ps, const int bx, const int gx, int& my_t_out, TgtPre& pre_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define UF_STAMP(k) do { if (a.dbg && tid == 0 && bx < 3900) a.dbg[32 + (size_t)bx * 16 + (k)] = wall_clock64(); } while (0)
+    UF_STAMP(0);
+    const int s_over = fe.s_over;
+    const int nT = fe.nT;
+    unsigned long long pw[UF_SPEC];
+#pragma unroll
+    for (int q = 0; q < UF_SPEC; ++q) pw[q] = fe.pw[q];
+    if (s_over) return false;
+    const int Tp = (nT + 7) & ~7;
+    unsigned short* par = reinterpret_cast<unsigned short*>(lds);            // [Tp] union-find parent; later: cluster index by head
+    unsigned short* lab = par + Tp;                                          // [Tp] root = smallest member = label
+    unsigned short* hp = lab + Tp;                                           // [Tp] by head: offset of the member list
+    unsigned short* tmp = hp + Tp;                                           // [Tp] members by slot
+    unsigned short* ms = tmp + Tp;                                           // [Tp] members ascending (cl_members)
+    unsigned short* ml = ms + Tp;                                            // [Tp / 2] heads of the multi-target clusters
+    unsigned short* sl = ml + Tp / 2;                                        // [Tp] targets alone in their cluster
+    int* cnt = reinterpret_cast<int*>(sl + Tp);                              // [Tp] by head: members | slots handed out << 16
+    unsigned long long* s_w = reinterpret_cast<unsigned long long*>(cnt + Tp);   // [4] wave totals of the scan, [4] totals
+    int* s_tl = reinterpret_cast<int*>(s_w + 8);                             // [TEAM_MAX] heads of the team-sized clusters
+#pragma unroll
+    for (int q = 0; q < UF_SPEC; ++q) {
+        const int t = tid + q * BLP_THREADS;
+        if (t < nT) { par[t] = (unsigned short)(((unsigned)(pw[q] >> 32) == a.uf_epoch) ? 0xffffffffu - (unsigned)pw[q] : (unsigned)t); cnt[t] = 0; }
+    }
+    for (int t = tid + UF_SPEC * BLP_THREADS; t < nT; t += BLP_THREADS) {
+        const unsigned long long w = a.uf_parent[t];
+        par[t] = (unsigned short)(((unsigned)(w >> 32) == a.uf_epoch) ? 0xffffffffu - (unsigned)w : (unsigned)t);
+        cnt[t] = 0;
+    }
+    __syncthreads();
+    UF_STAMP(1);
+    for (int t = tid; t < nT; t += BLP_THREADS) {
+        int r = t, p = par[r];
+        while (p != r) { r = p; p = par[r]; }
+        lab[t] = (unsigned short)r;
+        atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    UF_STAMP(2);
+    // ONE block scan over the targets in index order (thread = a run of E consecutive targets): heads -> cluster index, their sizes ->
+    // member offset, ranks among the multi-target / single-target / team-sized clusters, packed 14 + 14 + 14 + 14 + 8 bits
+    const int E = (nT + BLP_THREADS - 1) / BLP_THREADS;
+    auto pack_of = [&](int t) -> unsigned long long {
+        if (t >= nT || lab[t] != t) return 0ull;
+        const unsigned long long K = (unsigned long long)cnt[t];
+        return 1ull | ((K >= 2 ? 1ull : 0ull) << 14) | ((K == 1 ? 1ull : 0ull) << 28) | (K << 42) | ((K >= (unsigned long long)TEAM_MIN_K ? 1ull : 0ull) << 56);
+    };
+    unsigned long long mine = 0ull;
+    for (int e = 0; e < E; ++e) mine += pack_of(tid * E + e);
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    UF_STAMP(3);
+    unsigned long long run = incl - mine, total = 0ull;
+#pragma unroll
+    for (int w = 0; w < BLP_THREADS / 64; ++w) { const unsigned long long v = s_w[w]; if (w < wave) run += v; total += v; }
+    const int nC = (int)(total & 0x3fffu), nMulti = (int)((total >> 14) & 0x3fffu), nSingle = (int)((total >> 28) & 0x3fffu);
+    const int nTeamAll = (int)(total >> 56), nTeam = (a.team_list && nTeamAll > 0) ? (nTeamAll < TEAM_MAX ? nTeamAll : TEAM_MAX) : 0;
+    for (int e = 0; e < E; ++e) {
+        const int t = tid * E + e;
+        const unsigned long long pk = pack_of(t);
+        if (pk) {
+            const int c = (int)(run & 0x3fffu), mr = (int)((run >> 14) & 0x3fffu), sr = (int)((run >> 28) & 0x3fffu), p0 = (int)((run >> 42) & 0x3fffu), tr = (int)(run >> 56);
+            const int K = cnt[t];
+            par[t] = (unsigned short)c;       // (the parents are dead: cluster index by head)
+            hp[t] = (unsigned short)p0;
+            if (K >= 2) ml[mr] = (unsigned short)t; else sl[sr] = (unsigned short)t;
+            if (K >= TEAM_MIN_K && tr < TEAM_MAX) s_tl[tr] = t;
+            run += pk;
+        }
+    }
+    __syncthreads();
+    UF_STAMP(4);
+    // Member lists.  A workgroup usually needs ONE: that of its own cluster -- wavefront 0 collects it in ascending order with ballots, no
+    // barrier, while the others file the single-target clusters.  All lists at once (a slot by LDS atomic, then the ascending rank by
+    // counting the smaller members, as cluster_kernel) only where they are needed: the workgroup that files the tables in global
+    // memory, teams (every member needs the team clusters' lists), several clusters per workgroup, a cluster of more than 64 targets.
+    const int writer = nMulti < gx - 1 ? nMulti : gx - 1;      // (the first workgroup without an ILP of its own)
+    const int own_root = bx < nMulti ? (int)ml[bx] : 0;
+    const int own_K = bx < nMulti ? (cnt[own_root] & 0xffff) : 0;
+    const bool full = bx == writer || nTeam > 0 || bx + gx < nMulti || own_K > 64;      // (uniform in the workgroup)
+    auto ref_of = [&](int h) { return ClRef{(int)par[h], (int)hp[h], cnt[h] & 0xffff, h}; };
+    int32_t* gmem = const_cast<int32_t*>(a.cl_members);
+    if (tid == 0) { ps->nT = nT; ps->nC = nC; ps->nMulti = nMulti; ps->nSingle = nSingle; ps->nTeam = nTeam; ps->my_t = -1; }
+    if (tid >= 64 && tid < 64 + BLP_THREADS / 64 * 8) {
+        const int w = (tid - 64) >> 3, j = (tid - 64) & 7;
+        const int i = (gx - 1 - bx) * (BLP_THREADS / 64) + w + j * gx * (BLP_THREADS / 64);
+        ps->single[w][j] = (i < nSingle) ? sl[i] : (unsigned short)0xffff;
+    }
+    int my_t = -1;
+    if (full) {
+        for (int t = tid; t < nT; t += BLP_THREADS) {
+            const int h = lab[t];
+            const int K = cnt[h] & 0xffff;
+            if (K == 1) ms[hp[h]] = (unsigned short)t;
+            else tmp[hp[h] + (atomicAdd(&cnt[h], 1 << 16) >> 16)] = (unsigned short)t;
+        }
+        __syncthreads();
+        UF_STAMP(5);
+        for (int t = tid; t < nT; t += BLP_THREADS) {
+            const int h = lab[t];
+            const int K = cnt[h] & 0xffff, base = hp[h];
+            if (K == 1) continue;
+            int rank = 0;
+            for (int i = 0; i < K; ++i) rank += (tmp[base + i] < t) ? 1 : 0;
+            ms[base + rank] = (unsigned short)t;
+        }
+        __syncthreads();
+        UF_STAMP(6);
+        // the member lists of the workgroup's clusters (and of the teams' clusters: the same values from every member of a team) go to
+        // cl_members, where the solver reads them as before
+        for (int q = 0; q < 4; ++q) {
+            const int i = bx + q * gx;
+            if (i >= nMulti) break;
+            const ClRef cr = ref_of(ml[i]);
+            if (tid == 0) ps->own[q] = cr;
+            for (int k = tid; k < cr.K; k += BLP_THREADS) gmem[cr.p0 + k] = ms[cr.p0 + k];
+        }
+        for (int q = 0; q < nTeam; ++q) {
+            const ClRef cr = ref_of(s_tl[q]);
+            if (tid == 0) ps->team[q] = cr;
+            if (bx >= nMulti) for (int k = tid; k < cr.K; k += BLP_THREADS) gmem[cr.p0 + k] = ms[cr.p0 + k];      // (members of teams; the owner wrote it above)
+        }
+        if (bx == writer) {
+            int32_t* t_label = const_cast<int32_t*>(a.t_label);
+            int32_t* cl_ptr = const_cast<int32_t*>(a.cl_ptr);
+            int32_t* multi = const_cast<int32_t*>(a.multi_list);
+            int32_t* single = const_cast<int32_t*>(a.single_list);
+            int32_t* counts = const_cast<int32_t*>(a.counts);
+            for (int t = tid; t < nT; t += BLP_THREADS) {
+                const int h = lab[t];
+                t_label[t] = h;
+                if (a.t_cluster) a.t_cluster[t] = par[h];
+                gmem[t] = ms[t];
+                if (h == t) cl_ptr[par[h]] = hp[h];
+            }
+            for (int i = tid; i < nMulti; i += BLP_THREADS) multi[i] = par[ml[i]];
+            for (int i = tid; i < nSingle; i += BLP_THREADS) single[i] = sl[i];
+            if (a.team_list && tid < nTeam) const_cast<int32_t*>(a.team_list)[tid] = par[s_tl[tid]];
+            if (tid == 0) {
+                cl_ptr[nC] = nT;
+                counts[0] = nC; counts[1] = nMulti; counts[2] = nSingle; counts[3] = 0; counts[4] = 0; counts[5] = nTeam;
+                // (what the cluster kernel cleared for the scan after this one: the other parity's status word, the grow kernel's child counters)
+                if (a.status_other) { a.status_other->overflow = 0; a.status_other->n_children = 0; a.status_other->n_dead = 0; }
+            }
+            if (a.alloc_reset && tid >= 64 && tid < 64 + FG_REGIONS) a.alloc_reset[(tid - 64) * 32] = 0u;
+        }
+        if (bx < nMulti && tid < own_K) my_t = ms[hp[own_root] + tid];
+    } else if (wave == 0 && bx < nMulti) {
+        const int p0 = hp[own_root];
+        int n = 0;
+        for (int t0 = 0; t0 < nT && n < own_K; t0 += 64) {
+            const int t = t0 + lane;
+            const bool m = t < nT && lab[t] == own_root;
+            const unsigned long long bal = __ballot(m);
+            if (m) ms[p0 + n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)t;
+            n += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ps->own[0] = ref_of(own_root);
+        if (lane < own_K) { my_t = ms[p0 + lane]; gmem[p0 + lane] = my_t; }
+    }
+    // member `tid` of the workgroup's first cluster: its record is on its way while the solver sets itself up
+    if (my_t >= 0) { pre_out = load_target(a, my_t); pre_out.lab = own_root; }
+    __threadfence_block();
+    __syncthreads();
+    UF_STAMP(7);
+    my_t_out = my_t;
+    return true;
+}
+
+template <bool UF> __device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps = nullptr);
+__device__ __forceinline__ void blp_stamp_begin(const BlpArgs& a, int bx);
+template <bool UF = false>
+__device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx, UfPersist* ps = nullptr, const UfFetch* fe = nullptr) {      // workgroup bx of gx
     unsigned long long* uw = reinterpret_cast<unsigned long long*>(lds);           // [cap_uw]
     Red* red = reinterpret_cast<Red*>(lds + (size_t)a.cap_uw * 8);                   // sizeof(Red) padded to RED_SLOT
-    if (a.status && a.status->overflow) return;
+    if (!UF && a.dbg && threadIdx.x == 0 && bx < 3900) a.dbg[32 + (size_t)bx * 16 + 12] = wall_clock64();
+    if (!UF && a.status && a.status->overflow) return;
     // tier 2: what the first launch left (big_list; the single-target clusters went with that launch) -- the same staged loop over that list
-    const bool rest = a.tier == 2;
+    const bool rest = !UF && a.tier == 2;
     const int32_t* work = rest ? a.big_list : a.multi_list;
-    const int nMulti = rest ? *a.big_count : a.counts[1], nSingle = rest ? 0 : a.counts[2];
-    // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- cluster c is solved
-    // where c % shard_n == shard_i, a single-target cluster where its target index says so; see blp_epilogue_kernel)
+    int nMulti = UF ? 0 : (rest ? *a.big_count : a.counts[1]), nSingle = UF ? 0 : (rest ? 0 : a.counts[2]);
+    int my_t = -1;
+    TgtPre my_pre_v = {};
+    const TgtPre* my_pre = UF ? &my_pre_v : nullptr;
+    // (shard_n > 1: the clusters of one tracker are spread over shard_n devices that hold identical forests -- a multi-target cluster is
+    // solved on the device cl_owner names (placed by size by the cluster kernel), a single-target cluster where its target index says
+    // so; see blp_epilogue_kernel)
     // teams (mht_kernels.h: TEAM_*): the launch's workgroups without a cluster of their own (block index >= nMulti) are dealt out to
     // the clusters of the team list; member 0 of a team is the workgroup that owns the cluster anyway
-    const bool teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
-    const int nTeam = teams_on ? a.counts[5] : 0;
-    const int nIdle = gx - nMulti;
+    bool teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
+    int nTeam = teams_on ? (UF ? 0 : a.counts[5]) : 0;
+    int nIdle = gx - nMulti;
     auto team_W = [&](int ti) { const int w = 1 + (nIdle - ti + nTeam - 1) / nTeam; return w < TEAM_W ? w : TEAM_W; };
     // (ONE call site of the solver: the workgroup's own clusters first, then the single-target clusters, then -- if it has no cluster
     // of its own -- its share of a team's search)
-    int own_i = bx;
-    for (int stage = 0; stage < 3; ) {
-        int c = -1, ti = -1;
+    int own_i = bx, own_q = 0;
+    for (int stage = UF ? -1 : 0; stage < 3; ) {
+        ClRef cr = ClRef{-1, 0, 0, -1};
+        int ti = -1, mt = -1;
         Team tm = Team{0, 1, nullptr};
-        if (stage == 0) {
+        if (UF && stage == -1) {
+            // clusters from the grow launch's union-find: the tables first (INSIDE the staged loop: what the compiler hoists in front of the
+            // loop -- the solver's argument loads and address arithmetic, ~2 us -- then runs while the parents are on their way)
+            stage = 0;
+            if (!uf_prologue(a, *fe, lds, ps, bx, gx, my_t, my_pre_v)) return;      // (void scan)
+            blp_stamp_begin(a, bx);
+            if (a.dbg && threadIdx.x == 0 && bx < 3900) a.dbg[32 + (size_t)bx * 16 + 12] = wall_clock64();
+            nMulti = ps->nMulti; nSingle = ps->nSingle;
+            teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
+            nTeam = teams_on ? ps->nTeam : 0;
+            nIdle = gx - nMulti;
+            continue;
+        } else if (stage == 0) {
             if (own_i >= nMulti) { stage = 1; continue; }
-            c = work[own_i];
+            if (UF) { cr = ps->own[own_q]; mt = own_q == 0 ? my_t : -1; ++own_q; }
+            else cr = cl_ref(a, work[own_i]);
             own_i += gx;
-            if (a.shard_n > 1 && (a.cl_owner ? a.cl_owner[c] : c % a.shard_n) != a.shard_i) continue;
-            if (nTeam > 0 && a.cl_ptr[c + 1] - a.cl_ptr[c] >= TEAM_MIN_K)
-                for (int q = 0; q < nTeam; ++q) if (a.team_list[q] == c) ti = q;
+            if (a.shard_n > 1 && (a.cl_owner ? a.cl_owner[cr.c] : cr.c % a.shard_n) != a.shard_i) continue;
+            if (nTeam > 0 && cr.K >= TEAM_MIN_K)
+                for (int q = 0; q < nTeam; ++q) if ((UF ? ps->team[q].c : a.team_list[q]) == cr.c) ti = q;
             if (ti >= 0 && team_W(ti) > 1) tm = Team{0, team_W(ti), &a.team_state[ti].gub};
             else ti = -1;
         } else if (stage == 1) {
             stage = 2;
-            blp_singles(a, bx, gx, nSingle);
+            blp_singles<UF>(a, bx, gx, nSingle, ps);
             continue;
         } else {
             stage = 3;
@@ -2016,24 +2268,27 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             ti = j % nTeam;
             if (q >= team_W(ti)) break;
             __syncthreads();      // (the wavefronts of this workgroup are done with the single-target clusters)
-            c = a.team_list[ti];
+            cr = UF ? ps->team[ti] : cl_ref(a, a.team_list[ti]);
             tm = Team{q, team_W(ti), &a.team_state[ti].gub};
         }
-        solve_cluster(a, c, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti);
+        if (a.dbg && threadIdx.x == 0 && bx < 3900 && stage == 0) a.dbg[32 + (size_t)bx * 16 + 13] = wall_clock64();
+        solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr);
     }
 }
 
 // targets alone in their cluster: one wavefront each, dealt out from the END of the grid (the workgroups without an ILP)
-__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle) {
+template <bool UF>
+__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps) {
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
     const int gw = (gx - 1 - bx) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
-    for (int i = gw; i < nSingle; i += gx * (BLP_THREADS / 64)) {
-        const int t = a.single_list[i];
+    int j = 0;
+    for (int i = gw; i < nSingle; i += gx * (BLP_THREADS / 64), ++j) {
+        const int t = UF ? (int)ps->single[threadIdx.x >> 6][j & 7] : a.single_list[i];
         if (a.shard_n > 1 && t % a.shard_n != a.shard_i) continue;
         TgtPre pre = {};
         int cb, ce;
-        if (a.t_alive) { pre = load_target(a, t); cb = pre.cb; ce = pre.ce; }
+        if (a.t_alive) { pre = load_target(a, t); if (UF) pre.lab = t; cb = pre.cb; ce = pre.ce; }
         else { cb = a.tchild[t]; ce = a.tcend[t]; }
         double bv = DINF;
         int bi = -1;
@@ -2160,9 +2415,22 @@ __device__ __forceinline__ void blp_stamp_end(const BlpArgs& a) {
 
 __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16] = wall_clock64();
     blp_stamp_begin(a, blockIdx.x);
     blp_body(a, lds, blockIdx.x, gridDim.x);
     blp_stamp_end(a);
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 15] = wall_clock64();
+}
+// clusters from the grow launch's union-find: every workgroup derives the cluster tables for itself first (uf_prologue); no cluster kernel
+__global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    UfPersist* ps = reinterpret_cast<UfPersist*>(lds + a.uf_lds_off);
+    if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
+    const UfFetch fe = uf_prefetch(a);
+    blp_body<true>(a, lds, blockIdx.x, gridDim.x, ps, &fe);
+    if (fe.s_over) return;
+    blp_stamp_end(a);
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 15] = wall_clock64();
 }
 // a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out
 // sector-interleaved in dispatch order (blockIdx.x fastest): the first n * nMulti workgroups to reach the machine are the ones that
@@ -2188,7 +2456,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_light_batch_kernel(const PBat
     blp_stamp_begin(a, bx);
     if (!(a.status && a.status->overflow)) {
         blp_light(a, bx, gridDim.x, a.counts[1]);
-        blp_singles(a, bx, gridDim.x, a.counts[2]);
+        blp_singles<false>(a, bx, gridDim.x, a.counts[2]);
     }
     blp_stamp_end(a);
 }
@@ -2270,6 +2538,14 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_init_kernel(const BlpArgs a, 
     blp_stamp_end(a);
 }
 
+// can the ILP launch of a forest with this many target slots / measurement nodes derive its clusters itself (union-find prologue)?
+bool blp_uf_fits(int Tcap, int n_mnodes) {
+    BlpArgs b = {};
+    b.n_mnodes = n_mnodes;
+    const size_t lds = blp_set_tier(b, 0), pro = uf_prologue_bytes((size_t)Tcap);
+    return Tcap <= 8192 && (((lds > pro ? lds : pro) + 15) & ~(size_t)15) + BLP_UF_PERSIST <= 158 * 1024;
+}
+
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, const int32_t* sticky_overflow) {
     BlpArgs b = a;
     const size_t lds = blp_set_tier(b, 0);
@@ -2281,6 +2557,23 @@ int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, c
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_attr_blp = lds;
+    }
+    if (b.uf_epoch) {      // clusters from the grow launch's union-find
+        size_t body = lds > uf_prologue_bytes((size_t)b.uf_cap) ? lds : uf_prologue_bytes((size_t)b.uf_cap);
+        body = (body + 15) & ~(size_t)15;
+        b.uf_lds_off = (unsigned)body;
+        const size_t lds_uf = body + BLP_UF_PERSIST;
+        if (lds_uf > 158 * 1024 || init) {
+            set_error("blp: the union-find prologue of %d targets does not fit the launch's LDS (%zu bytes), or an initiator was handed in", b.uf_cap, lds_uf);
+            return MHT_E_CAPACITY;
+        }
+        if (ctx->lds_attr_blp_uf < lds_uf) {
+            MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_uf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_uf));
+            ctx->lds_attr_blp_uf = lds_uf;
+        }
+        hipLaunchKernelGGL(blp_uf_kernel, dim3(grid), dim3(BLP_THREADS), lds_uf, ctx->stream, b);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
     }
     if (init) hipLaunchKernelGGL(blp_init_kernel, dim3(grid + 1), dim3(BLP_THREADS), lds, ctx->stream, b, *init, sticky_overflow);
     else hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);

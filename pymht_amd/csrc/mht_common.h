@@ -112,5 +112,5 @@ struct mht_ctx {
     mht::DevStatus* status = nullptr;   // device
     mht::Forest* forest = nullptr;
     // dynamic-LDS limits already raised with hipFuncSetAttribute (per context: the attribute is per device)
-    size_t lds_attr_gate = 0, lds_attr_cluster = 0, lds_attr_blp = 0, lds_attr_fgrow = 0;
+    size_t lds_attr_gate = 0, lds_attr_cluster = 0, lds_attr_blp = 0, lds_attr_fgrow = 0, lds_attr_blp_uf = 0;
 };

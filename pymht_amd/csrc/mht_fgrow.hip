@@ -363,6 +363,65 @@ __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32s
     out.zhx = (float)zh[0]; out.zhy = (float)zh[1];
 }
 
+// ---- clustering inside the grow launch (FDyn::uf_epoch, mht_kernels.h) ------------------------------------------------------------
+// 64-bit words, all accesses agent-scope atomics (the workgroups of a launch sit on eight XCDs with non-coherent L2s); a word of an
+// earlier scan is "empty" (owner) / "no parent" (parent), nothing is cleared between scans.
+//   owner[node]  = {epoch, target}: exchanged by atomic max -- whoever finds a word of this scan there shares the node with the target named;
+//   parent[t]    = {epoch, ~p}: p < t, a member of t's component.  Linking is ONE returning atomic max per step, no look-ups: propose the
+//                  smaller of two targets as parent of the larger; if the larger had a parent already, the smaller of the two candidates
+//                  stays and the other one is linked to it next (indices only go down: it ends).  Every member of a component except its
+//                  smallest ends up with a parent, so following the parents from any member ends at the smallest member -- the cluster's
+//                  label in the reference's order (tracker.py:972-974).
+__device__ __forceinline__ void uf_link(unsigned long long* parent, unsigned epoch, int x, int y) {
+    int lo = x < y ? x : y, hi = x < y ? y : x;
+    while (lo != hi) {
+        const unsigned long long old = atomicMax(&parent[hi], ((unsigned long long)epoch << 32) | (unsigned long long)(0xffffffffu - (unsigned)lo));
+        if ((unsigned)(old >> 32) != epoch) break;          // hi had no parent
+        const int p = (int)(0xffffffffu - (unsigned)old);
+        if (p == lo) break;
+        hi = p > lo ? p : lo;
+        lo = p > lo ? lo : p;
+    }
+}
+// One wavefront, target `pos`: every measurement node of the association set (LDS bitset tb, AW words) exchanges its owner word; the
+// targets found there go to an LDS list (conf[0 .. cap), *nconf of them; beyond cap they are linked straight away).
+__device__ __forceinline__ void uf_claim(unsigned long long* owner, unsigned long long* parent, unsigned epoch, int pos, const unsigned long long* tb, int AW, int lane,
+                                         int* conf, int cap, int* nconf) {
+    const unsigned long long mine = ((unsigned long long)epoch << 32) | (unsigned)pos;
+    int n = 0;      // (wave-uniform)
+    for (int w0 = 0; w0 < AW; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned long long bits = (w < AW) ? tb[w] : 0ull;
+        while (__any(bits != 0ull)) {
+            // up to four nodes per lane and round: the atomics go out together, their answers are looked at afterwards
+            unsigned long long old[4];
+            bool has[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                has[q] = bits != 0ull;
+                old[q] = 0ull;
+                if (has[q]) {
+                    const int b = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    old[q] = atomicMax(&owner[w * 64 + b], mine);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool cf = has[q] && (unsigned)(old[q] >> 32) == epoch && (int)(unsigned)old[q] != pos;
+                const unsigned long long bal = __ballot(cf);
+                if (cf) {
+                    const int i = n + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (i < cap) conf[i] = (int)(unsigned)old[q];
+                    else uf_link(parent, epoch, pos, (int)(unsigned)old[q]);
+                }
+                n += __popcll(bal);
+            }
+        }
+    }
+    if (lane == 0) *nconf = n < cap ? n : cap;
+}
+
 // PQ = 16-byte pieces of a path / ancestor record (2: records of 8 ints, N-scan <= 7; 4: 16 ints) -- a template parameter because
 // a leaf's two records sit in registers between their load and their LDS store: 32 registers at PQ = 4, and the kernel is at the
 // edge of its budget (128 for four workgroups per CU in the batched launch).
@@ -685,7 +744,12 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                     if (b < 0) a.status->overflow = 1;      // every region is full: the scan is void (MHT_E_CAPACITY)
                     s_base = b;
                 }
-            } else if (wave == 1 && first_emit) {
+            } else if (wave == FG_THREADS / 64 - 1 && first_emit && d.uf_epoch) {
+                // no edge list: the target joins the device-wide union-find.  Its nodes' owner words are exchanged here, next to the
+                // counts (the answers are back before wavefront 0 is through its prefix); the links go out next to the emission
+                const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                uf_claim(a.uf_owner, a.uf_parent, d.uf_epoch, pos, tb, AW, lane, reinterpret_cast<int*>(cand), Mpad / 2, &s_misc[17]);
+            } else if (wave == 1 && first_emit && !d.uf_epoch) {
                 // edges of the clustering graph = set bits of the association bitset (complete here: every leaf's last real
                 // measurement and the hits; with two passes the count pass has seen all chunks)
                 int ne = 0;
@@ -718,7 +782,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
                     a.tcend[pos] = base < 0 ? 0 : base + tot;
                 }
                 if (base < 0) return;
-                if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
+                if (d.uf_epoch) {      // the targets this one shares a node with (uf_claim above): one link each (the last wavefront: emission reaches it last)
+                    if (wave == FG_THREADS / 64 - 1) {
+                        const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                        const int* conf = reinterpret_cast<const int*>(cand);
+                        for (int i = lane; i < s_misc[17]; i += 64) uf_link(a.uf_parent, d.uf_epoch, pos, conf[i]);
+                    }
+                } else if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
                     const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
                     const int seg = blockIdx.x & (EDGE_SEGS - 1);
                     int eb = s_ebase;
@@ -1229,6 +1299,8 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
     // co-resident: it starts within a microsecond of the first target workgroup)
     auto stamp = [&]() {
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
+        // (clusters from the union-find: what the cluster kernel reset for the scan's ILP launch)
+        if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
     };
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
         if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, reinterpret_cast<int*>(smem)); return; }
@@ -1275,6 +1347,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
     if (bx == 0) {
         int* sm = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
+        if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
         // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
         int n_cand = ad.n;
         if (ad.n_dev) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }

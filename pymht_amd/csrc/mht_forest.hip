@@ -215,6 +215,9 @@ struct Forest {
     unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
     int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
+    // clustering inside the grow launch (mht_kernels.h: FDyn::uf_epoch): owner word per measurement node, parent word per target; uf_ok:
+    // the ILP launch's workgroups can derive the cluster tables themselves (MHT_NO_UF=1: the clustering kernel on every scan, as before)
+    unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
     int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
     int32_t* team_list; TeamState* team_state; TeamResult* team_res; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
@@ -338,6 +341,7 @@ struct Forest {
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
         cl_owner = ar.take<int32_t>(Tcap);
         if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
+        uf_owner = ar.take<unsigned long long>(n_mnodes); uf_parent = ar.take<unsigned long long>(Tcap);
         team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         // (TEAM_W copies of the ILP kernel's HBM scratch: a team member of a giant cluster works on its own, mht_blp.hip)
         u = ar.take<double>((size_t)n_mnodes * TEAM_W); usage = ar.take<int32_t>((size_t)n_mnodes * TEAM_W); mark = ar.take<int32_t>((size_t)n_mnodes * TEAM_W);
@@ -503,6 +507,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     MHT_HIP_CHECK(hipEventCreateWithFlags(&f->init_ev, hipEventDisableTiming));
     f->pds = f->PD <= 8 ? 8 : 16;
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
+    { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -724,6 +729,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
     g.used_bytes = f->used_bytes[s & 1];
     g.status = f->status2 + (s & 1); g.prev_status = f->status2 + ((s - 1) & 1); g.sticky_overflow = &f->cnt->overflow;
+    g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent; g.uf_team_state = f->teams ? f->team_state : nullptr;
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
@@ -776,6 +782,10 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.t_alive = f->t_status; b.t_jdrop = f->t_jdrop; b.t_count = f->t_count; b.t_firstsurv = f->t_firstsurv; b.t_score = f->t_score;
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
+    // (clusters from the grow launch's union-find: switched on per scan by the caller, b.uf_epoch = scan number)
+    b.uf_parent = f->uf_parent; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc;
+    b.t_cluster = f->t_cluster;
+    { static int bs = -1; if (bs < 0) { const char* e = getenv("MHT_BLP_STAMPS"); bs = (e && e[0] == '1') ? 1 : 0; } b.dbg = (bs && f->debug) ? f->grow_dbg : nullptr; }
 }
 
 // similar-state pruning of scan s's children (between the cluster and the ILP kernel; tracker.py:230-231)
@@ -967,6 +977,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         MHT_STEP_CHECK(launch_forest_ais(ctx, aa, pl.n_ub));
         f->ais_armed = false;
     }
+    // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
+    // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
+    // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.
+    const bool use_uf = f->uf_ok && !(f->prune_thr > 0.f) && !init;
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
         FGrowArgs g;
@@ -976,6 +990,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.ais_on = ais ? 1 : 0;
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
+        d.uf_epoch = use_uf ? (unsigned)pl.s : 0u;
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)
         if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
         { static int tr = -1; if (tr < 0) { const char* e = getenv("MHT_STEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
@@ -994,7 +1009,8 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     InitArgs init_blp = {}; bool have_init_blp = false;
-    {
+    if (use_uf) f->uf_scans += 1;
+    else {
         ClusterArgs c;
         fill_cluster(f, pl.s, c);
         if (init && !f->cluster_big) {
@@ -1032,6 +1048,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     {
         BlpArgs b;
         fill_blp(f, pl.s, b);
+        b.uf_epoch = use_uf ? (unsigned)pl.s : 0u;
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));

@@ -32,6 +32,7 @@ struct GateArgs {
 struct CommitArgs;
 struct FDyn;
 struct FBatch;
+struct TeamState;
 
 // AIS-aided children in the forest (tracker.py:417-552; mht_ais.hip).  A forest made with MHT_FOREST_AIS keeps two more words per
 // node -- the identity of the AIS message the node was updated with (mmsi, 0 = none) and the identity its track is bound to (hmmsi:
@@ -89,6 +90,9 @@ struct FGrowArgs {
     DevStatus* status;             // this scan's status word: n_children is accumulated here
     const DevStatus* prev_status; const int32_t* sticky_overflow;
     AisGrow ais;                   // (fgrow_kernel<..., AIS = 1> only)
+    // clustering inside the grow launch (FDyn::uf_epoch != 0, see there): owner word per measurement node, parent word per target
+    unsigned long long* uf_owner; unsigned long long* uf_parent;
+    TeamState* uf_team_state;      // [TEAM_MAX] reset for this scan's ILP launch by the launch's first workgroup (the cluster kernel did it)
 };
 // What changes from scan to scan (everything in FGrowArgs repeats with period 2 x ring length, for fused = 0 and 1): passed by
 // value next to the argument block (one launch per sector) or to a pointer to it (one launch for a group of sectors).
@@ -101,7 +105,17 @@ struct FDyn {
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     int ais_on;                    // AIS forest: this scan carries messages (AisGrow::nf / off / rec are valid)
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
+    unsigned uf_epoch;             // != 0 (the scan number): no edge list -- the target workgroups hook their targets into a device-wide
+                                   // union-find over the measurement nodes they use, and the ILP launch derives the clusters from it
 };
+// Clustering without a clustering launch (tracker.py:961-974).  The connected components of targets <-> measurement nodes are the
+// fixed point of "two targets that use the same node belong together".  Every target workgroup of the grow launch already holds its
+// target's de-duplicated association set; per node it exchanges ONE 64-bit word {epoch, target} (agent-scope atomic max): whoever finds
+// a word of this scan there unites its target with the one named, in a lock-free union-find over the targets (64-bit words {epoch,
+// parent}, the larger root hooked under the smaller by compare-and-swap, so that a component's root is its smallest member -- the
+// reference's cluster order).  Words of earlier scans are "empty" / "root": nothing is cleared between scans.  The workgroups of the
+// ILP launch read the parents (a kernel boundary later) and each derives the cluster tables in LDS for itself (mht_blp.hip:
+// uf_prologue): no clustering kernel, no launch boundary, and three dependent look-ups fewer in front of every ILP.
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.
 struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; };      // dst = null: no host block (report fetched by memcpy)
 constexpr int GROUP_MAX = 32;      // sectors per batched launch
@@ -215,6 +229,12 @@ struct BlpArgs {
     RingLayer ring0; size_t ring_stride;      // layer k of the ring: every array of ring0 advanced by k * ring_stride BYTES
     const int32_t* t_id; const int32_t* t_root_scan; const int32_t* t_root_node; const int32_t* t_label;
     mht_target_report* rec; int32_t* w_root_scan; int32_t* w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
+    // clusters from the grow launch's union-find (uf_epoch != 0: blp_uf_kernel; see FDyn::uf_epoch): the parents, the target count of the
+    // table the scan ran on, and what the cluster kernel used to reset for the next scan
+    const unsigned long long* uf_parent; unsigned uf_epoch; const int32_t* nT_dev; int uf_cap;      // uf_cap: entries of uf_parent (max_targets)
+    DevStatus* status_other; unsigned* alloc_reset; int32_t* t_cluster;
+    unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
+    unsigned uf_lds_off;           // offset of the workgroup's UfPersist block in the dynamic LDS (behind the solver's tables; set by launch_blp)
 };
 
 // prune_similar_kernel (mht_similar.hip): similar-state pruning of the targets that are alone in their cluster, between the
@@ -269,6 +289,7 @@ int cluster_elds(int Tcap, int n_mnodes);
 bool cluster_fits_lds(int Tcap, int n_mnodes);
 size_t cluster_big_ints(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init = nullptr, const int32_t* sticky_overflow = nullptr);      // init: the initiator rides as one more workgroup
+bool blp_uf_fits(int Tcap, int n_mnodes);
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);
 
