@@ -170,7 +170,12 @@ class Replay:
         from pymht_amd import _lib
         self._lib_mod = _lib
         self.sc = sc
-        self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
+        if os.environ.get("MHT_BENCH_STREAM") == "1" and torch.cuda.current_stream(device).cuda_stream == 0:      # experiment: a stream of its own instead of the null stream
+            self._own_stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(self._own_stream):
+                self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
+        else:
+            self.trk = make_tracker(sc, device, useInitiator=False, deviceTiming=False)
         self.lib, self.h = self.trk._lib, self.trk._ctx.handle
         dev = self.trk._ctx.device
         self.M = [int(z.shape[0]) for z in sc["scans"]]
@@ -404,6 +409,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(K):
         one_scan()
+    t_enq = time.perf_counter()      # (the host has queued the K scans: how far ahead of the device it runs)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -411,6 +417,8 @@ def main():
     rep, recs = rp.report()
     got = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0]
     same_work = (got == final) and rep.error == 0
+    uf_ovl = np.zeros(2, dtype=np.int32)      # scans clustered inside the grow launch, grow launches that overlapped the previous scan's ILP launch
+    rp.lib.mht_forest_debug_read(rp.h, b"uf_ovl", uf_ovl.ctypes.data_as(C.c_void_p), 8)
     rp.close()
     elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
     # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
@@ -553,7 +561,7 @@ def main():
                                "one independent sector per GPU" + (" -- STRONG: the same sector on every GPU, ILPs spread by cluster" if strong else ""), "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
                    "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),
-                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work,
+                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work, "host_us_per_scan_queued": round(1e6 * (t_enq - t0) / K, 2), "scans_clustered_in_grow_launch": int(uf_ovl[0]), "grow_launches_overlapping_ilp": int(uf_ovl[1]),
                    "pre_roll_scans": PRE},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},

@@ -350,7 +350,7 @@ int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps);
  * "cl_counts", "tchild").  Synchronises. */
 int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t bytes);
 /* Ancestor chain of one node: walks parents from (scan, node) towards the root of time, at most max_len steps
- * (bounded by the ring: layers older than n_scan+2 scans are gone).  Outputs host arrays
+ * (bounded by the ring of n_scan + 4 layers: with k scans queued behind `scan`, n_scan + 4 - k layers are left).  Outputs host arrays
  * nodes/meas [max_len] int32, x [max_len][4], cnllr [max_len], P [max_len][16]; any may be NULL. */
 int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                      double* x, double* cnllr, float* P, int32_t* n_out);

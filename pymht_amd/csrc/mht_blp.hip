@@ -1482,7 +1482,14 @@ template <typename T> __device__ __forceinline__ const T* ring_ptr(const T* base
 constexpr int KEY_DEAD = -1, KEY_ALL = -2;
 // Returns the survival key of the target: KEY_DEAD (terminated), KEY_ALL (alive, root stays) or the node index of the
 // new root (children whose ancestor table holds it at level j-1 survive).
-__device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, const TgtPre& p, bool store) {
+// (publication for an overlapping grow launch, BlpArgs::rec0: the new root's cumulative score is written through here, the record that
+// names it valid follows from whoever knows the surviving leaf range: blp_publish)
+__device__ __forceinline__ void blp_publish(const BlpArgs& a, int t, int key, int j, int rf, int count, int first) {
+    if (!a.rec0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the root score's store has left)
+    __hip_atomic_store(&a.rec0[t], tgt_rec(a.pub_scan, key != -1, rf, j, count, count > 0 ? first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, const TgtPre& p, bool store, int* rf_out = nullptr) {
     const int kc = a.kc;
     const double cn = a.cnllr[s];
     const uint8_t fl = a.flags[s];
@@ -1525,7 +1532,9 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
         a.t_alive[t] = status;                 // 0 = alive, else the termination reason
         a.t_jdrop[t] = j;
         a.t_score[t] = score;
-        a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_cnllr[t] = rc; a.w_root_f32[t] = rf;
+        a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_f32[t] = rf;
+        if (a.rec0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.w_root_cnllr[t]), (unsigned long long)__double_as_longlong(rc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.w_root_cnllr[t] = rc;
         mht_target_report& r = a.rec[t];
         r.id = p.id;
         r.status = status;
@@ -1543,6 +1552,7 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
         r.root_meas = rmeas;
         r.cluster = p.lab;
     }
+    if (rf_out) *rf_out = rf;
     return status ? KEY_DEAD : (j > 0 ? anc : KEY_ALL);
 }
 
@@ -1552,7 +1562,7 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
 __device__ __forceinline__ int sweep_prefetch(const BlpArgs& a, int j, int cb, int ce, int lane) {
     return (j > 0 && cb + lane < ce) ? a.apath[(size_t)(cb + lane) * a.pds + (j - 1)] : -1;
 }
-__device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, int cb, int ce, int key, int va0, int lane) {
+__device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, int cb, int ce, int key, int va0, int lane, int rf = -1) {      // rf < 0: the target's root flag is read back
     int count = 0, first = 0x7fffffff;
     if (key == KEY_ALL) {
         count = ce - cb;
@@ -1566,7 +1576,10 @@ __device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, 
             count += __popcll(m);
         }
     }
-    if (lane == 0) { a.t_count[t] = count; a.t_firstsurv[t] = first; }
+    if (lane == 0) {
+        a.t_count[t] = count; a.t_firstsurv[t] = first;
+        if (a.rec0) blp_publish(a, t, key, j, rf >= 0 ? rf : (int)a.w_root_f32[t], count, first);
+    }
 }
 
 // surviving leaf ranges of the members of a cluster: one wavefront per target; key[k] = survival key from finish_target
@@ -1931,13 +1944,14 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
             team_nodes = nodes;
         }
         stamp[4] = wall_clock64();
+        int rf_mine = -1;
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
             if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
             if (a.t_alive) {
                 const TgtPre q = pre_ok ? pre : load_target_cr(a, mem[k], cr);
-                s.ch[k] = finish_target(a, mem[k], h, q, true);
+                s.ch[k] = finish_target(a, mem[k], h, q, true, &rf_mine);      // (K <= BLP_THREADS in LDS: one member per thread)
                 s.ub_sel[k] = q.j;             // the solver's tables are free now: prune depth, survivor count, first survivor
                 s.lix[k] = 0;
                 s.best_h[k] = 0x7fffffff;
@@ -1961,6 +1975,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
             for (int k = tid; k < K; k += BLP_THREADS) {
                 a.t_count[mem[k]] = s.lix[k];
                 a.t_firstsurv[mem[k]] = s.best_h[k];
+                blp_publish(a, mem[k], s.ch[k], s.ub_sel[k], rf_mine, s.lix[k], s.best_h[k]);
             }
         }
     }
@@ -2013,11 +2028,12 @@ __host__ __device__ constexpr size_t uf_prologue_bytes(size_t T) { return ((T + 
 // for the commit's statistics and the host.  Returns false for a void scan.
 // the prologue's one global round trip, issued at the very start of the kernel: status word, target count and -- speculatively, the first
 // UF_SPEC x 256 of them -- the parents (the solver's own scalar set-up, ~2 us of argument loads, runs while they are in flight)
-struct UfFetch { int s_over, nT; unsigned long long pw[UF_SPEC]; };
+struct UfFetch { int s_over, nT; unsigned long long nif; unsigned long long pw[UF_SPEC]; };
 __device__ __forceinline__ UfFetch uf_prefetch(const BlpArgs& a) {
     UfFetch f;
     f.s_over = a.status ? a.status->overflow : 0;
     f.nT = *a.nT_dev;
+    f.nif = a.uf_ovl ? *a.ni_flag : 0ull;
 #pragma unroll
     for (int q = 0; q < UF_SPEC; ++q) {
         const int t = (int)threadIdx.x + q * BLP_THREADS;
@@ -2031,6 +2047,8 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
     UF_STAMP(0);
     const int s_over = fe.s_over;
     const int nT = fe.nT;
+    // (an overlapping grow launch redid the union-find under the alternative epoch if a target had died in the scan before)
+    const unsigned epoch = (a.uf_ovl && (unsigned)fe.nif == (a.uf_epoch >> 1) - 1u && ((fe.nif >> 32) & 1ull)) ? (a.uf_epoch | 1u) : a.uf_epoch;
     unsigned long long pw[UF_SPEC];
 #pragma unroll
     for (int q = 0; q < UF_SPEC; ++q) pw[q] = fe.pw[q];
@@ -2049,11 +2067,11 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
 #pragma unroll
     for (int q = 0; q < UF_SPEC; ++q) {
         const int t = tid + q * BLP_THREADS;
-        if (t < nT) { par[t] = (unsigned short)(((unsigned)(pw[q] >> 32) == a.uf_epoch) ? 0xffffffffu - (unsigned)pw[q] : (unsigned)t); cnt[t] = 0; }
+        if (t < nT) { par[t] = (unsigned short)(((unsigned)(pw[q] >> 32) == epoch) ? 0xffffffffu - (unsigned)pw[q] : (unsigned)t); cnt[t] = 0; }
     }
     for (int t = tid + UF_SPEC * BLP_THREADS; t < nT; t += BLP_THREADS) {
         const unsigned long long w = a.uf_parent[t];
-        par[t] = (unsigned short)(((unsigned)(w >> 32) == a.uf_epoch) ? 0xffffffffu - (unsigned)w : (unsigned)t);
+        par[t] = (unsigned short)(((unsigned)(w >> 32) == epoch) ? 0xffffffffu - (unsigned)w : (unsigned)t);
         cnt[t] = 0;
     }
     __syncthreads();
@@ -2174,9 +2192,11 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
             if (tid == 0) {
                 cl_ptr[nC] = nT;
                 counts[0] = nC; counts[1] = nMulti; counts[2] = nSingle; counts[3] = 0; counts[4] = 0; counts[5] = nTeam;
-                // (what the cluster kernel cleared for the scan after this one: the other parity's status word, the grow kernel's child counters)
-                if (a.status_other) { a.status_other->overflow = 0; a.status_other->n_children = 0; a.status_other->n_dead = 0; }
+                // (the counters of the other parity's status word, which the cluster kernel cleared for the scan after this one, are zeroed by
+                // that word's commit: the next scan's grow launch may be running already)
             }
+            // slots beyond the table: "nobody" for the next scan's grow launch, whose grid is sized by the host's upper bound
+            if (a.rec0) for (int t = nT + tid; t < a.pub_ub; t += BLP_THREADS) __hip_atomic_store(&a.rec0[t], tgt_rec(a.pub_scan, 0, 0, 0, 0, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.alloc_reset && tid >= 64 && tid < 64 + FG_REGIONS) a.alloc_reset[(tid - 64) * 32] = 0u;
         }
         if (bx < nMulti && tid < own_K) my_t = ms[hp[own_root] + tid];
@@ -2306,8 +2326,9 @@ __device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, cons
         }
         if (lane == 0) { a.sel[t] = bi; if (a.sel_rel) a.sel_rel[t] = bi - cb; }
         if (a.t_alive) {      // wave-uniform: every lane evaluates the (broadcast) look-ups, lane 0 stores
-            const int key = finish_target(a, t, bi, pre, lane == 0);
-            sweep_survivors(a, t, pre.j, cb, ce, key, va0, lane);
+            int rf = 0;
+            const int key = finish_target(a, t, bi, pre, lane == 0, &rf);
+            sweep_survivors(a, t, pre.j, cb, ce, key, va0, lane, rf);
         }
     }
 }
@@ -2428,8 +2449,16 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     const UfFetch fe = uf_prefetch(a);
     blp_body<true>(a, lds, blockIdx.x, gridDim.x, ps, &fe);
-    if (fe.s_over) return;
-    blp_stamp_end(a);
+    if (!fe.s_over) blp_stamp_end(a);
+    if (a.blp_done) {
+        // the next scan's grow launch may be running: its commit waits until every workgroup of this launch has released what it wrote
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAdd(a.blp_done, 1ull);
+        }
+    }
     if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 15] = wall_clock64();
 }
 // a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out

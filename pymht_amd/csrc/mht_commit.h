@@ -25,7 +25,28 @@ struct FCounts {          // device-side counters of the forest
     // newborn targets wait for it (and leave at once when nothing was born: no fence on either side then)
     int pad_;
     unsigned long long adm_flag;      // scan << 32 | first newborn slot << 16 | number of newborn targets
+    // a grow launch that OVERLAPS the previous scan's ILP launch (launched any-order behind it, mht_forest.hip): the workgroups of
+    // blp_uf_kernel count themselves off here when their results are released (never reset: the host knows the total) ...
+    unsigned long long blp_done;
+    // ... and the commit that rides in that grow launch posts the scan whose compacted indices (new_index) are valid; bit 32: some target
+    // died in it (the indices differ from the slots)
+    unsigned long long ni_flag;
 };
+// Spin on a word another kernel / workgroup publishes (agent-scope loads, s_sleep between polls).  Bounded: a wait that does not end
+// within ~2 s gives up (returns false) instead of hanging the device; the caller voids the scan.
+constexpr unsigned long long SPIN_TICKS = 200000000ull;      // 10 ns ticks
+template <typename PRED>
+__device__ __forceinline__ bool spin_until(const unsigned long long* p, PRED ok, unsigned long long& v) {
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok(v)) return true;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok(v)) return true;
+        if (wall_clock64() - t0 > SPIN_TICKS) return false;
+    }
+}
 
 struct TTable {           // one buffer of the target table
     int32_t* id; int32_t* window; int32_t* depth; int32_t* shift; int32_t* root_scan; int32_t* root_node;
@@ -40,7 +61,7 @@ struct ReportHeader {     // device image of mht_scan_report up to the host poin
     int32_t t_process, t_cluster, t_optim, t_scan;      // device time of the stages in 10 ns ticks (mht_scan_report)
 };
 
-struct CommitDyn { int scan, M, W; };      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
+struct CommitDyn { int scan, M, W; unsigned long long wait_done; };      // wait_done != 0: the scan's ILP launch may still be running -- wait until FCounts::blp_done has reached it      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
 
 struct CommitArgs {
     TTable cur, nxt;
@@ -75,6 +96,14 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
     int& s_limit = sm[2 * (NT / 64) + 3];
     int& s_itmax = sm[2 * (NT / 64) + 4];
     const int tid = threadIdx.x;
+    if (dyn.wait_done) {
+        // this grow launch overlaps the scan's ILP launch: its workgroups count themselves off behind an agent-scope release of what they
+        // wrote; every wavefront waits for the last of them, then drops what its CU may have cached
+        unsigned long long v;
+        const bool ok = spin_until(&a.cnt->blp_done, [&](unsigned long long x) { return x >= dyn.wait_done; }, v);
+        if (!ok && tid == 0) a.status->overflow = 2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // first round trip, everything at once: the scalars and the first chunk of per-target look-ups (index clamped by the
     // table's capacity; entries beyond the real count are masked afterwards)
     const int s_over = a.status->overflow, c_over = a.cnt->overflow, nT = a.cnt->nT, nCh = a.status->n_children;
@@ -145,7 +174,7 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
             mht_target_report& r = a.rec[t];
             r.new_index = al ? pos : -1;
             r.n_leaves = leaves;
-            a.new_index[t] = al ? pos : -1;
+            __hip_atomic_store(&a.new_index[t], al ? pos : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (written through: read by the launch's other workgroups, see ni_flag)
             if (al) {
                 a.nxt.id[pos] = id;
                 a.nxt.window[pos] = win;
@@ -162,6 +191,13 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
         if (base + PRUNE_THREADS < nT) __syncthreads();      // s_scan is re-used by the next chunk
     }
     const int nAlive = running, Lnext = lrun;
+    if (dyn.wait_done) {
+        // the compacted indices are what the launch's target workgroups are waiting for (tchild / tcend and the union-find are indexed by
+        // them): posted as soon as they are out, the rest of the commit follows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&a.cnt->ni_flag, (unsigned long long)(unsigned)dyn.scan | ((unsigned long long)(nAlive != nT ? 1 : 0) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ILP statistics
     if (tid < n_ilp) {                                      // only this scan's ILPs: the entries of other clusters are stale
         if (st_first == MHT_BLP_BRANCHED) atomicAdd(&s_branched, 1);
@@ -222,6 +258,9 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
         if (a.hint && a.vcount) __hip_atomic_store(a.hint + 1, (unsigned long long)*a.vcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // fill of the value table
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
+        // the counters of this scan's status word have been read: zero for the scan after the next (its grow launch may start before the
+        // next scan's ILP launch has ended, so nobody else can do it; the overflow flag stays -- a void scan kills the forest)
+        a.status->n_children = 0; a.status->n_dead = 0;
         // (the per-scan status word -- one of two, by scan parity -- is cleared by the cluster kernel of the next scan: a
         // commit that rides in the next grow_kernel must not touch what that kernel's tiles are reading)
     }

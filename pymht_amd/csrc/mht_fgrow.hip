@@ -24,6 +24,7 @@
 #include "mht_commit.h"
 #include "mht_admit.h"
 #include <stddef.h>
+#include <hip/hip_ext.h>
 
 namespace mht {
 
@@ -46,11 +47,32 @@ typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the ke
 
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
 // loads go out unconditionally (one round trip), dead or out-of-range slots are masked afterwards
-template <typename ARGS>
-__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT) {
+template <bool OVL = true, typename ARGS = void>
+__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT, int* rf_out = nullptr, const int void_scan = 0) {
     TInfo r;
     const int tc = (t < a.Tcap) ? t : 0;
-    if (d.fused) {      // the previous scan's commit has not run: its per-target results, indexed by old slot
+    if (OVL && d.fused && d.ovl) {
+        // the previous scan's ILP launch may still be running: the target's record (mht_kernels.h: TGT_REC_*) is published the moment the
+        // target is finished there -- wait for it, for nothing else (slots up to the launch's grid bound all get one)
+        const int dep = a.p_depth[tc];
+        const unsigned tag = (unsigned)d.c_scan & 0xffu;
+        unsigned long long w = 0ull;
+        bool ok = t < d.n_tgt;
+        if (ok) {
+            w = __hip_atomic_load(&a.rec0[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> TGT_REC_TAG) != tag) {
+                if (void_scan) ok = false;      // (a void scan publishes nothing: the caller leaves)
+                else {
+                    ok = spin_until(&a.rec0[tc], [&](unsigned long long x) { return (unsigned)(x >> TGT_REC_TAG) == tag; }, w);
+                    if (!ok && (threadIdx.x & 63) == 0) a.status->overflow = 2;      // (the wait timed out: the scan is void)
+                }
+            }
+        }
+        const int j = (int)((w >> TGT_REC_J) & 15ull);
+        r.alive = ok && ((w >> TGT_REC_ALIVE) & 1ull) != 0ull;
+        r.first = (int)(w & 0x7ffffffull); r.cnt = (int)((w >> TGT_REC_CNT) & 0x7fffffull); r.depth = dep + 1 - j; r.shift = j;
+        if (rf_out) *rf_out = (int)((w >> TGT_REC_RF) & 1ull);
+    } else if (d.fused) {      // the previous scan's commit has not run: its per-target results, indexed by old slot
         const int st = a.p_status[tc], cnt = a.p_count[tc], j = a.p_jdrop[tc], first = a.p_firstsurv[tc], dep = a.p_depth[tc];
         r.alive = (t < nT) && st == 0;
         r.first = first; r.cnt = cnt; r.depth = dep + 1 - j; r.shift = j;
@@ -127,14 +149,14 @@ __device__ __forceinline__ void chain_resolve(const ARGS& a, int id, int h, doub
     a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
 }
 
-template <typename ARGS>
+template <bool OVL = true, typename ARGS = void>
 __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb, const int t_off = 0, const int born = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = born ? a.nT_new[0] : a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
     // wavefront = (target, hit/miss), lane = leaf: two targets per workgroup
     const int t = t_off + cb * FG_CHAIN_TARGETS + (wave >> 1), h = wave & 1;
-    const TInfo ti = target_info(a, d, t, nT);
+    const TInfo ti = target_info<OVL>(a, d, t, nT, nullptr, po | so);
     if (po || so) return;
     FG_STAMP(0);
     for (int l0 = 0; l0 < ti.cnt; l0 += 64) {
@@ -428,8 +450,12 @@ __device__ __forceinline__ void uf_claim(unsigned long long* owner, unsigned lon
 // bslot: the slot whose static block of the node index space the target's children take (its own; a target admitted inside this launch
 // takes one behind the slots of the uncommitted table, which the other workgroups of the launch are using).  born = 1: such a target --
 // slot t of the COMMITTED table (d.fused = 0 for it), count and root columns of that table
-template <int PQ, int CAP, int AIS = 0>
-__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, unsigned char* smem, const int bslot, const int born = 0) {
+// LEAN: the batched launches (groups of sectors) -- no union-find, no overlap with the previous scan's ILP launch: compiled out (the
+// batched kernel sits at 128 registers for four workgroups per CU)
+template <int PQ, int CAP, int AIS = 0, bool LEAN = false>
+__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, unsigned char* smem, const int bslot, const int born = 0) {
+    FDyn d = d0;
+    if (LEAN) { d.uf_epoch = 0u; d.ovl = 0; d.stamp_end = 0; }
     constexpr int PDS = PQ * 4;
     const auto& a = *ap0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -459,19 +485,31 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     // ---- first round trip: everything that is addressed by the target slot alone -----------------------------------------
     const int nT = born ? a.nT_new[0] : a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
-    const TInfo ti = target_info(a, d, t, nT);
-    const int tc = (t < a.Tcap) ? t : 0;
-    const double rootc = born ? a.b_root_cnllr[tc] : a.t_root_cnllr[tc];
-    const int root_f32 = born ? a.b_root_f32[tc] : a.t_root_f32[tc];
-    int acc = 0;
-    if (d.fused)          // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
-        for (int i = tid; i < t; i += FG_THREADS) acc += (a.p_status[i] == 0) ? 1 : 0;
+    const bool ovl = !LEAN && d.fused && d.ovl;      // (the previous scan's ILP launch may still be running)
+    int rf_rec = 0;
     const float2* z2 = reinterpret_cast<const float2*>(d.z);
-    for (int j = tid; j < Mpad; j += FG_THREADS) {
-        const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
-        zx[j] = v.x;
-        zy[j] = v.y;
-    }
+    if (ovl)              // (the wait for the target's record comes behind everything that does not depend on it)
+        for (int j = tid; j < Mpad; j += FG_THREADS) {
+            const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
+            zx[j] = v.x;
+            zy[j] = v.y;
+        }
+    const TInfo ti = target_info<!LEAN>(a, d, t, nT, &rf_rec, po | so);
+    const int tc = (t < a.Tcap) ? t : 0;
+    // (overlapping launch: the root's score was written through in front of the target's record)
+    const double rootc = born ? a.b_root_cnllr[tc]
+                              : (ovl ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(&a.t_root_cnllr[tc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                     : a.t_root_cnllr[tc]);
+    const int root_f32 = born ? a.b_root_f32[tc] : (ovl ? rf_rec : a.t_root_f32[tc]);
+    int acc = 0;
+    if (d.fused && !ovl)  // compacted index of this target = alive slots before it (the commit computes the same in workgroup 0)
+        for (int i = tid; i < t; i += FG_THREADS) acc += (a.p_status[i] == 0) ? 1 : 0;
+    if (!ovl)
+        for (int j = tid; j < Mpad; j += FG_THREADS) {
+            const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
+            zx[j] = v.x;
+            zy[j] = v.y;
+        }
     if (po || so) {          // a scan that overflowed its pools voids every scan after it
         if (t == 0 && tid == 0) a.status->overflow = po ? po : 1;
         return;
@@ -500,7 +538,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
     // A chunk = CAP leaves, one per lane of wavefronts 0 and 1.  A target with more leaves runs the chunk loop twice: pass 0
     // only counts, pass 1 emits.
     const bool two_pass = cnt > CAP;
-    int total = 0, run = 0, base = 0;
+    int total = 0, run = 0, base = 0, fin_tot = 0;
     for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
         for (int c0 = 0; c0 < cnt; c0 += CAP) {
             // (the loops exist for targets with more than CAP leaves only.  The argument block is re-read through an opaque
@@ -747,7 +785,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             } else if (wave == FG_THREADS / 64 - 1 && first_emit && d.uf_epoch) {
                 // no edge list: the target joins the device-wide union-find.  Its nodes' owner words are exchanged here, next to the
                 // counts (the answers are back before wavefront 0 is through its prefix); the links go out next to the emission
-                const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                // (overlapping launch: the compacted index is not known yet -- hooked under the SLOT, which is the index unless a target died in
+                // the previous scan; the end of the workgroup redoes it in that case)
+                const int pos = ovl ? t : (d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t);
                 uf_claim(a.uf_owner, a.uf_parent, d.uf_epoch, pos, tb, AW, lane, reinterpret_cast<int*>(cand), Mpad / 2, &s_misc[17]);
             } else if (wave == 1 && first_emit && !d.uf_epoch) {
                 // edges of the clustering graph = set bits of the association bitset (complete here: every leaf's last real
@@ -772,19 +812,22 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
             }
             if (first_emit) {
                 base = s_base;
+                fin_tot = two_pass ? total : s_total;
                 // the target's entries of the child tables go out behind the barrier: in front of it the barrier's release waited for
                 // the acknowledgement of these global stores (~1 us on the workgroup's critical path)
                 if (tid == 0) {
-                    const int tot = two_pass ? total : s_total;
-                    const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                    const int tot = fin_tot;
                     atomicAdd(&a.status->n_children, tot);
-                    a.tchild[pos] = base < 0 ? 0 : base;
-                    a.tcend[pos] = base < 0 ? 0 : base + tot;
+                    if (!ovl) {      // (overlapping launch: the compacted index is not known yet -- at the end of the workgroup)
+                        const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                        a.tchild[pos] = base < 0 ? 0 : base;
+                        a.tcend[pos] = base < 0 ? 0 : base + tot;
+                    }
                 }
                 if (base < 0) return;
                 if (d.uf_epoch) {      // the targets this one shares a node with (uf_claim above): one link each (the last wavefront: emission reaches it last)
                     if (wave == FG_THREADS / 64 - 1) {
-                        const int pos = d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t;
+                        const int pos = ovl ? t : (d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t);
                         const int* conf = reinterpret_cast<const int*>(cand);
                         for (int i = lane; i < s_misc[17]; i += 64) uf_link(a.uf_parent, d.uf_epoch, pos, conf[i]);
                     }
@@ -861,6 +904,29 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d, int t, uns
         }
     }
     FG_STAMP(7);
+    if (ovl) {
+        // Overlapping launch: the target's compacted index -- tchild / tcend and the union-find are indexed by it -- comes from the commit
+        // in workgroup 0 of this launch, which had to wait for the LAST workgroup of the previous scan's ILP launch.  Everything else of
+        // the target is done; its entries and its links follow the moment the index is there.
+        // (Nearly always the index IS the slot -- no target died in the previous scan, the commit's word says so -- and the target's
+        // place in the union-find, taken under the slot next to the emission, stands.  Otherwise: once more, under the compacted index and
+        // the scan's alternative epoch, which the ILP launch then reads.)
+        __syncthreads();      // (the candidate list's LDS is free: the union-find's list goes there)
+        unsigned long long v;
+        const bool ok = spin_until(a.ni_flag, [&](unsigned long long x) { return (unsigned)x == (unsigned)d.c_scan; }, v);
+        const bool moved = ok && ((v >> 32) & 1ull);      // some target died: slots and compacted indices differ
+        const int pos = !ok ? -1 : (moved ? __hip_atomic_load(&a.new_index[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t);
+        if (pos < 0) { if (tid == 0) a.status->overflow = 2; return; }      // (timed out; a live target always has an index)
+        if (tid == 0) { a.tchild[pos] = base; a.tcend[pos] = base + fin_tot; }
+        if (moved && d.uf_epoch && wave == FG_THREADS / 64 - 1) {
+            const unsigned alt = d.uf_epoch | 1u;      // (epochs are 2 x scan: the alternative one lies between this scan's and the next scan's, the words are updated by atomic max)
+            uf_claim(a.uf_owner, a.uf_parent, alt, pos, tb, AW, lane, reinterpret_cast<int*>(cand), Mpad / 2, &s_misc[17]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int* conf = reinterpret_cast<const int*>(cand);
+            for (int i = lane; i < s_misc[17]; i += 64) uf_link(a.uf_parent, alt, pos, conf[i]);
+        }
+    }
 }
 
 // ---- wavefront-per-target variant (batched launches: several sectors' targets resident at once) -----------------------------
@@ -928,7 +994,7 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
     FW_STAMP(0);
     const int nT = a.nT_dev[0];
     const int po = a.prev_status->overflow, so = *a.sticky_overflow;
-    const TInfo ti = target_info(a, d, t, nT);
+    const TInfo ti = target_info<false>(a, d, t, nT);
     const int tc = (t < a.Tcap) ? t : 0;
     const double rootc = a.t_root_cnllr[tc];
     const int root_f32 = a.t_root_f32[tc];
@@ -1291,7 +1357,7 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w, int n_
     for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
 }
 
-template <int PQ, int CAP, typename CARGS, int AIS = 0>
+template <int PQ, int CAP, typename CARGS, int AIS = 0, bool LEAN = false>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem, const int bid0 = (int)blockIdx.x) {
     int bid = bid0;
     // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
@@ -1303,10 +1369,10 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
     };
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
-        if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, reinterpret_cast<int*>(smem)); return; }
+        if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull}, reinterpret_cast<int*>(smem)); return; }
         bid -= 1;
     }
-    if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part(*ap, d, bid - d.n_main); return; }
+    if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part<!LEAN>(*ap, d, bid - d.n_main); return; }
     if (CAP == 0) {          // wavefront-per-target variant: four targets per workgroup, each wavefront on its own LDS slice
         const int wave = threadIdx.x >> 6;
         const int t = bid * (FG_THREADS / 64) + wave;
@@ -1314,9 +1380,13 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (t >= d.n_tgt) return;
         target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
     } else {
-        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS>(ap, d, bid, smem, bid);
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS, LEAN>(ap, d, bid, smem, bid);
+        if (d.stamp_end && threadIdx.x == 0) atomicMax(&ap->status->t[5], (unsigned long long)wall_clock64());
     }
 }
+
+template <int PQ, int CAP, typename CARGS>
+__device__ __forceinline__ void fgrow_body_lean(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) { fgrow_body<PQ, CAP, CARGS, 0, true>(ap, cm, d, smem); }
 
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
 template <int PQ, int CAP = FG_CAP_SOLO>
@@ -1354,7 +1424,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
 #ifdef MHT_ADM_STAMPS
         const unsigned long long ts0 = wall_clock64();
 #endif
-        const int born0 = commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W}, sm);      // targets alive behind the scan, -1: void scan
+        const int born0 = commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull}, sm);      // targets alive behind the scan, -1: void scan
         __threadfence_block();
         __syncthreads();
 #ifdef MHT_ADM_STAMPS
@@ -1478,7 +1548,7 @@ __global__ __launch_bounds__(FG_THREADS, NX == 4 ? 4 : 3) void fgrow_batch_kerne
     const int y = blockIdx.y;
     const FDyn d = b.d[y];
     if ((int)blockIdx.x >= d.fused + d.n_main + d.n_chain) return;
-    fgrow_body<PQ, CAP>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
+    fgrow_body_lean<PQ, CAP>((KArgs)b.ga[y], *(KCommit)b.ca[y], d, smem);
 }
 
 static size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap) {
@@ -1538,7 +1608,9 @@ void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave) {
     d.n_chain = wave ? 0 : (n_tgt + FG_CHAIN_TARGETS - 1) / FG_CHAIN_TARGETS;      // (the wavefronts of the wave variant resolve their own transitions)
 }
 
-int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish, const AddArgs* adm) {
+// any_order: the launch may start while the launch in front of it in the stream -- the previous scan's ILP launch -- is still running
+// (hipExtAnyOrderLaunch; FDyn::ovl: what it needs of that launch it waits for itself, target by target)
+int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish, const AddArgs* adm, bool any_order) {
     static int wave_solo = -1;      // development: MHT_FG_WAVE_SOLO=1 runs the wavefront-per-target variant in the one-sector launch too
     if (wave_solo < 0) { const char* e = getenv("MHT_FG_WAVE_SOLO"); wave_solo = (e && e[0] == '1') ? 1 : 0; }
     if (adm) {      // the commit and the admission of the initiator's births ride along (fgrow_adm_kernel)
@@ -1598,6 +1670,15 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
     const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
     const PublishArgs pa = pub ? *publish : PublishArgs{};
     const CommitArgs cm = commit ? *commit : CommitArgs{};
+    if (any_order && d.fused && d.ovl && !pub) {
+        const dim3 g(grid), b(FG_THREADS);
+        if (a.pds == 8 && wide) hipExtLaunchKernelGGL((fgrow_kernel<2>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, cm, d, pa);
+        else if (a.pds == 8) hipExtLaunchKernelGGL((fgrow_kernel<2, FG_CAP>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, cm, d, pa);
+        else if (wide) hipExtLaunchKernelGGL((fgrow_kernel<4>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, cm, d, pa);
+        else hipExtLaunchKernelGGL((fgrow_kernel<4, FG_CAP>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, cm, d, pa);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
     if (a.pds == 8 && wide) hipLaunchKernelGGL(fgrow_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
     else if (a.pds == 8) hipLaunchKernelGGL((fgrow_kernel<2, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
     else if (wide) hipLaunchKernelGGL(fgrow_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);

@@ -2,8 +2,8 @@
 // round trips between the stages.
 //
 // Data layout in HBM (all structure-of-arrays, owned by the ctx):
-//   layers[R]      ring of mht_nodes, one per scan of the N-scan window and one to spare (R = N+3: a host that folds the report of
-//                  scan k while scan k+1 is already running still finds all N+2 levels above a leaf of scan k): layer s % R holds every
+//   layers[R]      ring of mht_nodes, one per scan of the N-scan window and two to spare (R = N+4, RING_EXTRA below: a host that folds
+//                  the report of scan k while scan k+2 is already queued still finds all N+2 levels above a leaf of scan k): layer s % R holds every
 //                  hypothesis created at scan s (children of that scan, then roots born after it).  A node refers
 //                  to its parent by index into the previous layer (pyTarget.Target.parent).
 //   leaves         implicit: target t owns the nodes first[t] .. first[t]+count-1 of the newest layer (contiguous, in
@@ -30,6 +30,11 @@
 namespace mht {
 
 constexpr int MAXR = 16;
+// Layers of the node ring beyond the N-scan window.  A leaf's chain back to its root spans N + 2 layers; the streaming drop-in path folds
+// the report of scan k while scan k + 2 is queued (tracker.py here: _queue_report), and a track that DIED in scan k keeps its root where
+// it was -- its history is fetched at that fold (mht_forest_chain), so the layer of scan k - 1 - N must still be there when scan k + 2
+// has been written: N + 4 layers (round 3 had N + 3: the root and the committed history of tracks that died mid-stream were lost).
+constexpr int RING_EXTRA = 4;
 constexpr int EV_POOL = 64;
 constexpr int Z_RING = 4;           // pinned staging buffers of mht_forest_step_host
 constexpr int BIRTH_CAP = 256;      // candidates of the device initiator per scan that the report can hold
@@ -199,7 +204,7 @@ struct Forest {
     unsigned long long vt_used_seen = 0, vt_rate = 0;      // ids in use at the last commit the host saw; largest per-commit consumption seen (a burst predicts the next)
     Arena arena;
     mht_nodes layer[MAXR];
-    int32_t* path[2]; int32_t* apath[2]; double* cost; int32_t* tchild; int32_t* tcend;
+    int32_t* path[2]; int32_t* apath[2]; double* cost2[2]; int32_t* tchild; int32_t* tcend;      // cost2: ILP costs of the newest layer's nodes, by scan parity (the next scan's grow launch may overlap this scan's ILP launch)
     int pds = 8;                      // ints per path / ancestor record (8 or 16)
     // AIS forest (mht_forest_create_ex, MHT_FOREST_AIS; mht_kernels.h: AisGrow): identities per node, record pool of the fused children,
     // the messages of the next scan (mht_forest_set_ais arms them, the next step consumes them)
@@ -208,7 +213,7 @@ struct Forest {
     int32_t* ais_nf = nullptr; int32_t* ais_off = nullptr; AisRec* ais_rec = nullptr; int ais_rec_cap = 0; unsigned* ais_count = nullptr;
     char* ais_groups_dev = nullptr; char* ais_msgs_dev = nullptr; int ais_group_cap = 64, ais_msg_cap = 0;
     bool ais_armed = false; int ais_nG = 0, ais_nA = 0; double ais_eta2 = 0.0, ais_lambda = 0.0;
-    unsigned* alloc; int block_cap = 0, over_base = 0, region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
+    unsigned* alloc2[2]; int block_cap = 0, over_base = 0, region_cap = 0, root_base = 0;   // child counters of the regions of the node index space
     TTable tab[2];
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
@@ -218,8 +223,11 @@ struct Forest {
     // clustering inside the grow launch (mht_kernels.h: FDyn::uf_epoch): owner word per measurement node, parent word per target; uf_ok:
     // the ILP launch's workgroups can derive the cluster tables themselves (MHT_NO_UF=1: the clustering kernel on every scan, as before)
     unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
+    // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
+    // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
+    unsigned long long* rec0 = nullptr; int pub_scan = 0; unsigned long long blp_done_total = 0; bool ovl_ok = true; int ovl_launches = 0;
     int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
-    int32_t* team_list; TeamState* team_state; TeamResult* team_res; bool teams = true;      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
+    int32_t* team_list; TeamState* team_state2[2]; TeamResult* team_res; bool teams = true;      // (team_state2: by scan parity)      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
     double* u; int32_t* usage; int32_t* mark;
     int32_t *best_h, *bb_ch, *bb_best, *bb_last_idx; double *best_rc, *bb_cost, *bb_uused, *bb_last_rc, *bb_rest, *bb_min;
     int32_t *sel, *cl_status, *cl_iters, *cl_nodes, *cl_time; unsigned long long* grow_dbg; int32_t* commit_log; double* bb_snap; int32_t* bb_busy; int bb_snap_rows = 0;
@@ -320,7 +328,7 @@ struct Forest {
             t.root_cnllr = ar.take<double>(Tcap); t.root_f32 = ar.take<uint8_t>(Tcap);
             t.first = ar.take<int32_t>(Tcap); t.leaf_off = ar.take<int32_t>((size_t)Tcap + 1);
         }
-        cost = ar.take<double>(Ncap);
+        cost2[0] = ar.take<double>(Ncap); cost2[1] = ar.take<double>(Ncap);
         tchild = ar.take<int32_t>((size_t)Tcap + 1); tcend = ar.take<int32_t>((size_t)Tcap + 1);
         for (int g = 0; g < 2; ++g) {
             VTab& v = vts[g];
@@ -330,7 +338,7 @@ struct Forest {
             v.slots = ar.take<unsigned long long>((size_t)v.hmask + 1); v.count = ar.take<unsigned>(16);
         }
         vt_remap = ar.take<int32_t>((size_t)2 * vt.vcap);
-        alloc = ar.take<unsigned>((size_t)FG_REGIONS * 32);
+        alloc2[0] = ar.take<unsigned>((size_t)FG_REGIONS * 32); alloc2[1] = ar.take<unsigned>((size_t)FG_REGIONS * 32);
         used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
         status2 = ar.take<DevStatus>(2);
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
@@ -341,8 +349,8 @@ struct Forest {
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
         cl_owner = ar.take<int32_t>(Tcap);
         if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
-        uf_owner = ar.take<unsigned long long>(n_mnodes); uf_parent = ar.take<unsigned long long>(Tcap);
-        team_list = ar.take<int32_t>(TEAM_MAX); team_state = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
+        uf_owner = ar.take<unsigned long long>(n_mnodes); uf_parent = ar.take<unsigned long long>(Tcap); rec0 = ar.take<unsigned long long>(Tcap);
+        team_list = ar.take<int32_t>(TEAM_MAX); team_state2[0] = ar.take<TeamState>(TEAM_MAX); team_state2[1] = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         // (TEAM_W copies of the ILP kernel's HBM scratch: a team member of a giant cluster works on its own, mht_blp.hip)
         u = ar.take<double>((size_t)n_mnodes * TEAM_W); usage = ar.take<int32_t>((size_t)n_mnodes * TEAM_W); mark = ar.take<int32_t>((size_t)n_mnodes * TEAM_W);
         bb_snap_rows = n_mnodes > 1024 ? n_mnodes : 1024;
@@ -452,12 +460,12 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
         MHT_REQUIRE(cfg->n_scan <= 7, "mht_forest_create_ex: an AIS forest keeps two rows per level in a 16-entry path record: n_scan must be <= 7 (got %d)", cfg->n_scan);
     }
     MHT_REQUIRE(!ctx->forest, "mht_forest_create: the ctx already owns a forest");
-    MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + 3 <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - 3);
+    MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + RING_EXTRA <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - RING_EXTRA);
     MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
     MHT_REQUIRE(cfg->max_targets >= 1 && cfg->max_targets <= 8192, "mht_forest_create: max_targets must be in [1, 8192]");
     MHT_REQUIRE(cfg->max_nodes >= 2 * cfg->max_targets + 512, "mht_forest_create: max_nodes must be at least 2 * max_targets + 512");
-    MHT_REQUIRE((cfg->n_scan + 3) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,
-                "mht_forest_create: (n_scan + 3) x max_meas = %d measurement nodes exceed the 16 bits of an edge record", (cfg->n_scan + 3) * (((cfg->max_meas + 63) / 64) * 64));
+    MHT_REQUIRE((cfg->n_scan + RING_EXTRA) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,
+                "mht_forest_create: (n_scan + %d) x max_meas = %d measurement nodes exceed the 16 bits of an edge record", RING_EXTRA, (cfg->n_scan + RING_EXTRA) * (((cfg->max_meas + 63) / 64) * 64));
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     Forest* f = new (std::nothrow) Forest();
     MHT_REQUIRE(f, "mht_forest_create: out of host memory");
@@ -468,7 +476,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->Tcap = cfg->max_targets;
     f->Ncap = cfg->max_nodes;
     f->Mpad = ((cfg->max_meas + 63) / 64) * 64;
-    f->R = cfg->n_scan + 3;
+    f->R = cfg->n_scan + RING_EXTRA;
     f->PD = cfg->n_scan + 1;
     f->n_mnodes = f->R * f->Mpad;
     f->AW = f->n_mnodes / 64;
@@ -508,6 +516,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->pds = f->PD <= 8 ? 8 : 16;
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
+    { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -722,14 +731,15 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.nT_new = &f->cnt->nT; g.b_root_cnllr = f->tab[cb].root_cnllr; g.b_root_f32 = f->tab[cb].root_f32;
     g.ox = out.x; g.ocnllr = out.cnllr; g.opd = out.pd; g.oparent = out.parent; g.omeas = out.meas; g.ocov = out.cov;
     g.oflags = out.flags;
-    g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost;
+    g.out_path = f->path[s & 1]; g.out_apath = f->apath[s & 1]; g.ocost = f->cost2[s & 1];
     g.tchild = f->tchild; g.tcend = f->tcend;
     g.PD = f->PD; g.Nwin = f->cfg.n_scan; g.cur_slot_base = (s % f->R) * f->Mpad; g.AW = f->AW;
-    g.alloc = f->alloc; g.block_cap = f->block_cap; g.over_base = f->over_base; g.region_cap = f->region_cap;
+    g.alloc = f->alloc2[s & 1]; g.block_cap = f->block_cap; g.over_base = f->over_base; g.region_cap = f->region_cap;
     g.edges = f->edges; g.edge_count = f->edge_count; g.edge_cap = f->SegCap;
     g.used_bytes = f->used_bytes[s & 1];
     g.status = f->status2 + (s & 1); g.prev_status = f->status2 + ((s - 1) & 1); g.sticky_overflow = &f->cnt->overflow;
-    g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent; g.uf_team_state = f->teams ? f->team_state : nullptr;
+    g.rec0 = f->rec0; g.new_index = f->new_index; g.ni_flag = &f->cnt->ni_flag;
+    g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent; g.uf_team_state = f->teams ? f->team_state2[s & 1] : nullptr;
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
@@ -740,13 +750,13 @@ static void fill_cluster(const Forest* f, int s, ClusterArgs& c) {
     c = ClusterArgs{};
     c.assoc = nullptr; c.AW = f->AW; c.nT_dev = &f->cnt->nT; c.Tcap = f->Tcap;
     c.edge_t = f->edge_t; c.edge_m = f->edge_m; c.Ecap = f->Ecap; c.n_mnodes = f->n_mnodes; c.clear_rows = 0;
-    c.alloc_reset = f->alloc;
+    c.alloc_reset = f->alloc2[s & 1];
     c.edges_in = f->edges; c.edge_count = f->edge_count; c.ticket_reset = nullptr; c.seg_cap = f->SegCap;
     c.status = f->status2 + (s & 1); c.status_other = f->status2 + ((s - 1) & 1);
     c.dbg = f->debug ? reinterpret_cast<int32_t*>(f->grow_dbg) + 16 : nullptr;
     c.t_label = f->t_label; c.t_cluster = f->t_cluster; c.cl_ptr = f->cl_ptr; c.cl_members = f->cl_members;
     c.multi_list = f->multi_list; c.single_list = f->single_list; c.counts = f->cl_counts;
-    c.team_list = f->teams ? f->team_list : nullptr; c.team_state = f->teams ? f->team_state : nullptr;
+    c.team_list = f->teams ? f->team_list : nullptr; c.team_state = f->teams ? f->team_state2[s & 1] : nullptr;
     c.gtab = f->cl_gtab;
     cluster_prepare(c);
 }
@@ -756,8 +766,8 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     const int cb = s & 1;
     const mht_nodes& out = f->layer[s % f->R];
     b.cl_ptr = f->cl_ptr; b.cl_members = f->cl_members; b.multi_list = f->multi_list; b.single_list = f->single_list;
-    b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state; b.team_res = f->team_res;
-    b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost; b.cnllr = out.cnllr;
+    b.team_list = f->teams ? f->team_list : nullptr; b.team_state = f->team_state2[s & 1]; b.team_res = f->team_res;
+    b.counts = f->cl_counts; b.big_count = f->cl_counts + 4; b.big_list = f->big_list; b.tchild = f->tchild; b.tcend = f->tcend; b.cost = f->cost2[s & 1]; b.cnllr = out.cnllr;
     b.path = f->path[s & 1]; b.cap = f->Ncap; b.PD = f->ais ? f->pds : f->PD; b.pds = f->pds;      // (AIS forest: every entry of a record can be a row)
     b.u = f->u; b.usage = f->usage; b.mark = f->mark; b.n_mnodes = f->n_mnodes;
     if (f->teams) { b.tm_sm = (size_t)f->n_mnodes; b.tm_ss = (size_t)2 * f->Tcap + 2; }
@@ -783,7 +793,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
     // (clusters from the grow launch's union-find: switched on per scan by the caller, b.uf_epoch = scan number)
-    b.uf_parent = f->uf_parent; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc;
+    b.uf_parent = f->uf_parent; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc2[s & 1];
     b.t_cluster = f->t_cluster;
     { static int bs = -1; if (bs < 0) { const char* e = getenv("MHT_BLP_STAMPS"); bs = (e && e[0] == '1') ? 1 : 0; } b.dbg = (bs && f->debug) ? f->grow_dbg : nullptr; }
 }
@@ -794,7 +804,7 @@ static void fill_similar(const Forest* f, int s, SimilarArgs& a) {
     const int cb = s & 1;
     const mht_nodes& out = f->layer[s % f->R];
     a.single_list = f->single_list; a.counts = f->cl_counts; a.tchild = f->tchild; a.tcend = f->tcend;
-    a.x = out.x; a.cnllr = out.cnllr; a.pd = out.pd; a.meas = out.meas; a.cov = out.cov; a.flags = out.flags; a.cost = f->cost; a.cap = f->Ncap;
+    a.x = out.x; a.cnllr = out.cnllr; a.pd = out.pd; a.meas = out.meas; a.cov = out.cov; a.flags = out.flags; a.cost = f->cost2[s & 1]; a.cap = f->Ncap;
     a.t_root_cnllr = f->tab[cb].root_cnllr; a.t_root_f32 = f->tab[cb].root_f32; a.Nwin = f->cfg.n_scan;
     a.vt = f->vt;
     fill_model_only(a.model, &f->model);
@@ -981,6 +991,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
     // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.
     const bool use_uf = f->uf_ok && !(f->prune_thr > 0.f) && !init;
+    bool grow_ovl = false;      // this scan's grow launch took the previous scan's results target by target (FDyn::ovl)
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
         FGrowArgs g;
@@ -990,13 +1001,22 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.ais_on = ais ? 1 : 0;
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         d.dbg = f->debug ? f->grow_dbg : nullptr;
-        d.uf_epoch = use_uf ? (unsigned)pl.s : 0u;
+        d.uf_epoch = use_uf ? 2u * (unsigned)pl.s : 0u;      // (2 x scan: the odd value in between is the epoch of a union-find that had to be redone, mht_fgrow.hip)
+        // the previous scan's ILP launch published per-target records and its commit rides here: this launch takes what it needs of that
+        // launch target by target -- and may start while it is still running
+        d.ovl = (pl.fused && f->pub_scan == pl.s - 1 && f->pending_dyn.scan == pl.s - 1) ? 1 : 0;
+        d.c_wait = f->blp_done_total;
+        grow_ovl = d.ovl != 0;
+        { static int os = -1; if (os < 0) { const char* e = getenv("MHT_OVL_STAMPS"); os = (e && e[0] == '1') ? 1 : 0; } d.stamp_end = os; }
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)
+        static int ovl_force = -1; if (ovl_force < 0) { const char* e = getenv("MHT_OVL_FORCE"); ovl_force = (e && e[0] == '1') ? 1 : 0; }      // (development: any-order launches with the debug stamps on)
+        const bool any_order = d.ovl && f->ovl_ok && !adm && !f->pub_deferred && !ais && !f->timing && (!f->debug || ovl_force);
+        if (any_order) f->ovl_launches += 1;
         if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
         { static int tr = -1; if (tr < 0) { const char* e = getenv("MHT_STEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
           if (tr && pl.s > 40 && pl.s < 80) { const unsigned long long hh = f->hint_host ? *reinterpret_cast<volatile unsigned long long*>(f->hint_host) : 0ull;
               fprintf(stderr, "[step %d] fused %d adm %d n_ub %d nT_ub_step %d nT_ub %d hint(k=%d na=%d)\n", pl.s, (int)pl.fused, (int)adm, pl.n_ub, f->nT_ub_step, f->nT_ub, (int)(hh >> 32), (int)(hh & 0xffffffffu)); } }
-        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr));
+        MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         f->adm_pending = false;
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
             MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st));
@@ -1048,10 +1068,17 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     {
         BlpArgs b;
         fill_blp(f, pl.s, b);
-        b.uf_epoch = use_uf ? (unsigned)pl.s : 0u;
+        b.uf_epoch = use_uf ? 2u * (unsigned)pl.s : 0u;
+        b.ni_flag = &f->cnt->ni_flag; b.uf_ovl = grow_ovl ? 1 : 0;
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
+        { static int gcap = -1; if (gcap < 0) { const char* e = getenv("MHT_BLP_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && use_uf && grid > gcap) grid = gcap; }      // (development)
+        if (use_uf) {
+            b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s;
+            b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
+        }
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
+        if (use_uf) { f->pub_scan = pl.s; f->blp_done_total += (unsigned long long)grid; }
     }
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------
@@ -1750,7 +1777,13 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
         *static_cast<int32_t*>(host) = f->rebuilds;
         return MHT_OK;
     }
-    if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
+    if (!strcmp(name, "uf_ovl")) {      // (host-side counters: scans clustered by the union-find, grow launches made any-order)
+        MHT_REQUIRE(bytes == 8, "mht_forest_debug_read: 'uf_ovl' is two int32");
+        static_cast<int32_t*>(host)[0] = f->uf_scans; static_cast<int32_t*>(host)[1] = f->ovl_launches;
+        return MHT_OK;
+    }
+    if (!strcmp(name, "status2")) { src = f->status2; avail = 2 * sizeof(DevStatus); }
+    else if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
     else if (!strcmp(name, "cl_iters")) { src = f->cl_iters; avail = T * 4; }
     else if (!strcmp(name, "cl_nodes")) { src = f->cl_nodes; avail = T * 4; }
     else if (!strcmp(name, "cl_time")) { src = f->cl_time; avail = 8 * T * 4; }
@@ -1769,7 +1802,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "commit_log")) { src = f->commit_log; avail = 64 * 16 * 4; }
     else if (!strcmp(name, "cluster_dbg")) { src = reinterpret_cast<int32_t*>(f->grow_dbg) + 16; avail = 8 * 4; }
     else if (!strcmp(name, "path")) { src = f->path[f->scan & 1]; avail = (size_t)f->pds * f->Ncap * 4; }      // records of the newest layer
-    else if (!strcmp(name, "cost")) { src = f->cost; avail = (size_t)f->Ncap * 8; }
+    else if (!strcmp(name, "cost")) { src = f->cost2[f->scan & 1]; avail = (size_t)f->Ncap * 8; }
     MHT_REQUIRE(src, "mht_forest_debug_read: unknown array '%s'", name);
     MHT_REQUIRE(offset <= avail && (size_t)bytes <= avail - offset, "mht_forest_debug_read: '%s' holds %zu bytes", name, avail);
     src = static_cast<const char*>(src) + offset;

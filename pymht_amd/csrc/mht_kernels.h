@@ -93,7 +93,19 @@ struct FGrowArgs {
     // clustering inside the grow launch (FDyn::uf_epoch != 0, see there): owner word per measurement node, parent word per target
     unsigned long long* uf_owner; unsigned long long* uf_parent;
     TeamState* uf_team_state;      // [TEAM_MAX] reset for this scan's ILP launch by the launch's first workgroup (the cluster kernel did it)
+    // a grow launch that overlaps the previous scan's ILP launch (FDyn::ovl): that launch's per-target records (TGT_REC_*), the compacted
+    // indices its commit -- workgroup 0 of THIS launch -- computes, and the word that commit posts when they are valid
+    const unsigned long long* rec0; const int32_t* new_index; const unsigned long long* ni_flag;
 };
+// The per-target record blp_uf_kernel publishes for the NEXT scan's grow launch the moment a target is finished (one 8-byte store, written
+// through; the root's cumulative score goes out in front of it): the next grow launch may be running already (FDyn::ovl) and its
+// workgroup for the target waits for nothing else.  tag = scan & 0xff | alive | root score is float32 | layers the root advances | surviving
+// leaves | first surviving leaf
+constexpr int TGT_REC_TAG = 56, TGT_REC_ALIVE = 55, TGT_REC_RF = 54, TGT_REC_J = 50, TGT_REC_CNT = 27;
+__host__ __device__ __forceinline__ unsigned long long tgt_rec(unsigned scan, int alive, int rf, int j, int count, int first) {
+    return ((unsigned long long)(scan & 0xffu) << TGT_REC_TAG) | ((unsigned long long)(alive ? 1 : 0) << TGT_REC_ALIVE) | ((unsigned long long)(rf ? 1 : 0) << TGT_REC_RF) |
+           ((unsigned long long)(j & 15) << TGT_REC_J) | ((unsigned long long)(count & 0x7fffff) << TGT_REC_CNT) | (unsigned long long)(first & 0x7ffffff);
+}
 // What changes from scan to scan (everything in FGrowArgs repeats with period 2 x ring length, for fused = 0 and 1): passed by
 // value next to the argument block (one launch per sector) or to a pointer to it (one launch for a group of sectors).
 struct FDyn {
@@ -105,7 +117,12 @@ struct FDyn {
     int maybe_dead;                // similar-state pruning ran on the previous scan: leaves may carry F_DEAD (a target's LIVE leaf count decides gemm / gemv order)
     int ais_on;                    // AIS forest: this scan carries messages (AisGrow::nf / off / rec are valid)
     unsigned long long* dbg;       // development only (-DMHT_GROW_STAMPS): [workgroup][16] wall-clock ticks at phase boundaries
-    unsigned uf_epoch;             // != 0 (the scan number): no edge list -- the target workgroups hook their targets into a device-wide
+    int ovl;                       // fused = 1 only: the previous scan's ILP launch may still be running.  Target and chain workgroups take their
+                                   // target's results from its record (FGrowArgs::rec0, waiting for it), the commit waits for that launch's
+                                   // workgroups (c_wait) and posts the compacted indices the target workgroups end with
+    int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)
+    unsigned long long c_wait;     // FCounts::blp_done the commit waits for (0: the ILP launch has ended, as stream order says)
+    unsigned uf_epoch;             // != 0 (2 x the scan number): no edge list -- the target workgroups hook their targets into a device-wide
                                    // union-find over the measurement nodes they use, and the ILP launch derives the clusters from it
 };
 // Clustering without a clustering launch (tracker.py:961-974).  The connected components of targets <-> measurement nodes are the
@@ -233,7 +250,12 @@ struct BlpArgs {
     // table the scan ran on, and what the cluster kernel used to reset for the next scan
     const unsigned long long* uf_parent; unsigned uf_epoch; const int32_t* nT_dev; int uf_cap;      // uf_cap: entries of uf_parent (max_targets)
     DevStatus* status_other; unsigned* alloc_reset; int32_t* t_cluster;
+    // publication for an overlapping grow launch of the next scan (null: off): per-target records, written for slots [0, pub_ub); the
+    // counter the workgroups count themselves off on when they leave; the scan's tag
+    unsigned long long* rec0; int pub_ub; unsigned long long* blp_done; unsigned pub_scan;
     unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
+    const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
+                                                        // target died in the previous scan, the union-find was redone under epoch | 1
     unsigned uf_lds_off;           // offset of the workgroup's UfPersist block in the dynamic LDS (behind the solver's tables; set by launch_blp)
 };
 
@@ -268,7 +290,7 @@ int launch_gate(mht_ctx* ctx, GateArgs& a, int grid_leaves_hint);
 int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
 struct AddArgs;      // mht_admit.h
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr,
-                 const AddArgs* adm = nullptr);
+                 const AddArgs* adm = nullptr, bool any_order = false);
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave);
 size_t fgrow_wave_lds_bytes(int W, int pds, int AW);

@@ -677,7 +677,7 @@ class Tracker():
     def _make_parent_loader(self, target_id):
         def load(view):
             # ancestors inside the device window, then the committed root history kept on the host
-            if len(self.__scanHistory__) - view.scanNumber >= self._cfg.n_scan + 3:      # (the device ring holds N+3 scans)
+            if len(self.__scanHistory__) - view.scanNumber >= self._cfg.n_scan + 4:      # (the device ring holds N+4 scans: mht_forest.hip RING_EXTRA)
                 return None
             chain = self._window_chain(view.scanNumber, view._node)
             hit = np.where(self._tbl_["id"] == target_id)[0]
