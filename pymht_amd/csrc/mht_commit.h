@@ -31,6 +31,9 @@ struct FCounts {          // device-side counters of the forest
     // ... and the commit that rides in that grow launch posts the scan whose compacted indices (new_index) are valid; bit 32: some target
     // died in it (the indices differ from the slots)
     unsigned long long ni_flag;
+    // the scan whose initiator (initiator_side_kernel, launched any-order behind the scan's ILP launch) has finished: the admission in the
+    // next grow launch waits for it when that launch overlaps (FDyn::adm_wait)
+    unsigned long long init_flag;
 };
 // Spin on a word another kernel / workgroup publishes (agent-scope loads, s_sleep between polls).  Bounded: a wait that does not end
 // within ~2 s gives up (returns false) instead of hanging the device; the caller voids the scan.

@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
         // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
         int n_cand = ad.n;
-        if (ad.n_dev) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }
+        if (ad.n_dev && !d.adm_wait) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }
 #ifdef MHT_ADM_STAMPS
         const unsigned long long ts0 = wall_clock64();
 #endif
@@ -1431,6 +1431,13 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         const unsigned long long ts1 = wall_clock64();
 #endif
         int n_born = 0;
+        if (d.adm_wait) {      // overlapping launch: the previous scan's initiator may still be running
+            unsigned long long v;
+            const bool ok = spin_until(&cm.cnt->init_flag, [&](unsigned long long x) { return x == (unsigned long long)(unsigned)d.c_scan; }, v);
+            if (!ok && threadIdx.x == 0) ap->status->overflow = 2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (ad.n_dev) { const int nd = __hip_atomic_load(ad.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); n_cand = nd < n_cand ? nd : n_cand; }
+        }
         if (born0 >= 0 && n_cand > 0) {                      // (void scan: nothing is admitted; no candidates: the usual scan)
             add_targets_body<FG_THREADS>(ad, sm + 64);
             __threadfence_block();
@@ -1461,6 +1468,11 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
     }
     if (pub.dst && bx <= FG_PUB_WGS) {      // the rows of the report (see workgroup 0): workgroup w the rows [w, w + 1) * ceil(nT / FG_PUB_WGS)
         constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 1;
+        if (d.adm_wait && d.c_wait) {      // overlapping launch: the rows are the previous scan's ILP launch's, which may still be running
+            unsigned long long v;
+            (void)spin_until(&cm.cnt->blp_done, [&](unsigned long long x) { return x >= d.c_wait; }, v);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
         const uint4* s4 = reinterpret_cast<const uint4*>(pub.src);
         uint4* d4 = reinterpret_cast<uint4*>(pub.dst);
@@ -1519,6 +1531,10 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
     const int nT = b0 + nb;
     FDyn db = d;
     db.fused = 0;                          // (the newborn targets are slots of the COMMITTED table)
+    if (d.ovl && d.uf_epoch) {             // (the old targets redo their union-find under the alternative epoch when a target died: the newborn ones join that one)
+        const unsigned long long ni = __hip_atomic_load(ap->ni_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (posted by the commit, in front of the admission's flag)
+        if ((unsigned)ni == (unsigned)d.c_scan && ((ni >> 32) & 1ull)) db.uf_epoch = d.uf_epoch | 1u;
+    }
     if (w < FG_BORN_WGS) {
         const int n_old = ap->nT_dev[0];   // slots of the uncommitted table: the static blocks of the node index space behind them are free
         for (int q = w; b0 + q < nT; q += FG_BORN_WGS) {
@@ -1626,6 +1642,15 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
         const bool pub = publish && publish->dst;
         const int grid = fgrow_grid(d) + FG_BORN_WGS + FG_BORN_CHAIN_WGS + (pub ? FG_PUB_WGS : 0);
         const PublishArgs pa = pub ? *publish : PublishArgs{};
+        if (any_order && d.ovl && d.adm_wait) {
+            const dim3 g(grid), b(FG_THREADS);
+            if (a.pds == 8 && wide) hipExtLaunchKernelGGL((fgrow_adm_kernel<2>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, *commit, d, pa, *adm);
+            else if (a.pds == 8) hipExtLaunchKernelGGL((fgrow_adm_kernel<2, FG_CAP>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, *commit, d, pa, *adm);
+            else if (wide) hipExtLaunchKernelGGL((fgrow_adm_kernel<4>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, *commit, d, pa, *adm);
+            else hipExtLaunchKernelGGL((fgrow_adm_kernel<4, FG_CAP>), g, b, lds, ctx->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a, *commit, d, pa, *adm);
+            MHT_HIP_CHECK(hipGetLastError());
+            return MHT_OK;
+        }
         if (a.pds == 8 && wide) hipLaunchKernelGGL(fgrow_adm_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
         else if (a.pds == 8) hipLaunchKernelGGL((fgrow_adm_kernel<2, FG_CAP>), dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);
         else if (wide) hipLaunchKernelGGL(fgrow_adm_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, *commit, d, pa, *adm);

@@ -20,6 +20,7 @@
 // committed state first (report, births, exports) -- see Forest::commit_pending.
 #include "mht_kernels.h"
 #include "mht_commit.h"
+#include <hip/hip_ext.h>
 #include "mht_admit.h"
 #include "mht_init_dev.h"
 #include <string.h>
@@ -134,9 +135,16 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
 // scan's grow launch, nothing of the clustering or the ILPs, and what it gives birth to is admitted in the NEXT scan's grow launch --
 // so it runs next to the scan's cluster and ILP launches instead of lengthening the cluster launch (cluster_init_kernel: 15 us against
 // 8.7 for the clustering alone).
-__global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow) {
-    if ((status && status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
-    initiator_body<false>(in);
+__global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow, unsigned long long* done_flag = nullptr) {
+    if (!((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
+    if (done_flag) {      // the next scan's grow launch may be running already: its admission waits for this word (FCounts::init_flag)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(done_flag, (unsigned long long)(unsigned)in.scan_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 struct LeavesArgs {
@@ -225,6 +233,7 @@ struct Forest {
     unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
     // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
     // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
+    int init_flag_scan = 0;      // last scan whose initiator posts FCounts::init_flag
     unsigned long long* rec0 = nullptr; int pub_scan = 0; unsigned long long blp_done_total = 0; bool ovl_ok = true; int ovl_launches = 0;
     int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
     int32_t* team_list; TeamState* team_state2[2]; TeamResult* team_res; bool teams = true;      // (team_state2: by scan parity)      // branch-and-bound teams (mht_blp.hip); MHT_BLP_NO_TEAMS=1: off
@@ -990,7 +999,8 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
     // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.
-    const bool use_uf = f->uf_ok && !(f->prune_thr > 0.f) && !init;
+    // (streamed path: the scan's initiator then runs as a launch of its own NEXT to the ILP launch -- launched any-order behind it)
+    const bool use_uf = f->uf_ok && !(f->prune_thr > 0.f) && (!init || (f->adm_fuse && !f->ais && !f->timing && !f->init_in_blp && !f->init_side));
     bool grow_ovl = false;      // this scan's grow launch took the previous scan's results target by target (FDyn::ovl)
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
@@ -1010,7 +1020,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         { static int os = -1; if (os < 0) { const char* e = getenv("MHT_OVL_STAMPS"); os = (e && e[0] == '1') ? 1 : 0; } d.stamp_end = os; }
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)
         static int ovl_force = -1; if (ovl_force < 0) { const char* e = getenv("MHT_OVL_FORCE"); ovl_force = (e && e[0] == '1') ? 1 : 0; }      // (development: any-order launches with the debug stamps on)
-        const bool any_order = d.ovl && f->ovl_ok && !adm && !f->pub_deferred && !ais && !f->timing && (!f->debug || ovl_force);
+        // (the streamed path's launch -- commit, admission of the initiator's births, report push -- overlaps too when that initiator posts its flag)
+        const bool adm_ovl = adm && f->init_flag_scan == pl.s - 1;
+        d.adm_wait = adm_ovl ? 1 : 0;
+        const bool any_order = d.ovl && f->ovl_ok && (!adm || adm_ovl) && (!f->pub_deferred || adm_ovl) && !ais && !f->timing && (!f->debug || ovl_force);
         if (any_order) f->ovl_launches += 1;
         if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
         { static int tr = -1; if (tr < 0) { const char* e = getenv("MHT_STEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
@@ -1079,6 +1092,19 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         }
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
         if (use_uf) { f->pub_scan = pl.s; f->blp_done_total += (unsigned long long)grid; }
+        if (use_uf && init) {
+            // step 7 (tracker.py:264-278) needs the scan and the used-measurement bytes of the grow launch, nothing of the ILPs: one
+            // workgroup, launched any-order behind the ILP launch -- it runs next to the ILPs' tail; what it gives birth to is admitted in
+            // the next scan's grow launch (which waits for both)
+            InitArgs ia;
+            initiator_scan_args(init, z, M, nullptr, now, ia);
+            ia.used_b = f->used_bytes[pl.s & 1];
+            ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
+            hipExtLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, ia,
+                                  static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag);
+            MHT_STEP_HIP(hipGetLastError());
+            f->init_ran_scan = pl.s; f->init_flag_scan = pl.s;
+        }
     }
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------

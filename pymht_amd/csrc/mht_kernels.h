@@ -120,6 +120,8 @@ struct FDyn {
     int ovl;                       // fused = 1 only: the previous scan's ILP launch may still be running.  Target and chain workgroups take their
                                    // target's results from its record (FGrowArgs::rec0, waiting for it), the commit waits for that launch's
                                    // workgroups (c_wait) and posts the compacted indices the target workgroups end with
+    int adm_wait;                  // fgrow_adm_kernel launched any-order: the admission waits for the previous scan's initiator (FCounts::init_flag), the
+                                   // report's workgroups for the previous scan's ILP launch (c_wait)
     int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)
     unsigned long long c_wait;     // FCounts::blp_done the commit waits for (0: the ILP launch has ended, as stream order says)
     unsigned uf_epoch;             // != 0 (2 x the scan number): no edge list -- the target workgroups hook their targets into a device-wide
