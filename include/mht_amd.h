@@ -398,8 +398,9 @@ int mht_initiator_born(mht_initiator* in, int32_t capacity, double* x0, float* P
 int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t M, double now);
 
 /* ---- one tracker on several devices: the independent per-cluster ILPs (tracker.py:228-236) are spread --------------------------------
- * Every device holds the same forest and is fed the same scans and births; device shard_i of shard_n solves the clusters c with
- * c % shard_n == shard_i.  sel_rel: dev [max_targets] int32 owned by the caller; after _begin it holds, for the targets whose
+ * Every device holds the same forest and is fed the same scans and births; the multi-target clusters are placed by size -- longest
+ * processing time first on their column counts, each to the least loaded device; every device computes the same table from the same
+ * data (cluster kernel: cl_owner) --, a single-target cluster goes to device (target index % shard_n).  sel_rel: dev [max_targets] int32 owned by the caller; after _begin it holds, for the targets whose
  * cluster this device solved, the selected child's ordinal inside the target's block, -1 elsewhere.  The caller combines the
  * devices' arrays with an element-wise MAX (all-reduce over RCCL) and calls _end, which finishes the scan for all targets.
  * Asynchronous on the ctx stream. */

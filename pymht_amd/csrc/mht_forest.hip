@@ -37,7 +37,8 @@ constexpr int MAXR = 16;
 // has been written: N + 4 layers (round 3 had N + 3: the root and the committed history of tracks that died mid-stream were lost).
 constexpr int RING_EXTRA = 4;
 constexpr int EV_POOL = 64;
-constexpr int Z_RING = 4;           // pinned staging buffers of mht_forest_step_host
+constexpr int Z_RING = 8;           // pinned staging buffers of mht_forest_step_host (a consumer guard every Z_GUARD scans, see step_host_impl)
+constexpr int Z_GUARD = 4;
 constexpr int BIRTH_CAP = 256;      // candidates of the device initiator per scan that the report can hold
 
 struct LayerView { const double* x; const double* cnllr; const int32_t* parent; const int32_t* meas; const uint8_t* flags; const int32_t* cov; const float* P; };
@@ -257,7 +258,8 @@ struct Forest {
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
     hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
-    float* z_dev; float* z_host; hipEvent_t z_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool z_used[4] = {false, false, false, false}; int z_slot = 0;
+    float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
+    hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0;      // consumer guard of the staging ring (step_host_impl)
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
@@ -388,6 +390,7 @@ void forest_destroy(mht_ctx* ctx) {
     }
     if (f->z_host) (void)hipHostFree(f->z_host);
     for (int b = 0; b < Z_RING; ++b) if (f->z_ev[b]) (void)hipEventDestroy(f->z_ev[b]);
+    for (int b = 0; b < 2; ++b) if (f->z_guard_ev[b]) (void)hipEventDestroy(f->z_guard_ev[b]);
     if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->bhint_host) (void)hipHostFree(f->bhint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
@@ -960,6 +963,9 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     Forest* f = ctx->forest;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     const bool ais = f->ais && f->ais_armed;
+    // (a refused step must not leave the messages armed: the tracker stays alive after MHT_E_INVALID, and the next accepted scan -- maybe
+    // one without messages -- would consume them with this scan's time steps)
+    if (ais && !(M + f->ais_nA <= f->Mpad)) f->ais_armed = false;
     if (ais) {      // the fused children are made from the leaves of the COMMITTED table, in front of the grow launch
         MHT_REQUIRE(M + f->ais_nA <= f->Mpad, "mht_forest_step: %d radar measurements + %d AIS messages exceed max_meas=%d (rounded up to %d measurement nodes per scan)",
                     M, f->ais_nA, f->cfg.max_meas, f->Mpad);
@@ -967,7 +973,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         if (rc) return rc;
     }
     StepPlan pl;
-    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) return rc; }
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) { f->ais_armed = false; return rc; } }
     if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
     hipStream_t st = ctx->stream;
     hipEvent_t* ev = nullptr;
@@ -1026,9 +1032,6 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         const bool any_order = d.ovl && f->ovl_ok && (!adm || adm_ovl) && (!f->pub_deferred || adm_ovl) && !ais && !f->timing && (!f->debug || ovl_force);
         if (any_order) f->ovl_launches += 1;
         if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
-        { static int tr = -1; if (tr < 0) { const char* e = getenv("MHT_STEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
-          if (tr && pl.s > 40 && pl.s < 80) { const unsigned long long hh = f->hint_host ? *reinterpret_cast<volatile unsigned long long*>(f->hint_host) : 0ull;
-              fprintf(stderr, "[step %d] fused %d adm %d n_ub %d nT_ub_step %d nT_ub %d hint(k=%d na=%d)\n", pl.s, (int)pl.fused, (int)adm, pl.n_ub, f->nT_ub_step, f->nT_ub, (int)(hh >> 32), (int)(hh & 0xffffffffu)); } }
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         f->adm_pending = false;
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
@@ -1118,7 +1121,7 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) { return
 // the gating graph actually partitions") ---------------------------------------------------------------------------------------
 // Every device holds the same forest and is fed the same scans.  Grow and clustering are replicated (17 + 9 us at the headline
 // size: less than moving a layer between devices would cost); the 0-1 ILPs -- independent per cluster, tracker.py:228-236 -- are
-// spread: device i of n solves the clusters c with c % n == i (and the single-target clusters of its targets).  The selections
+// spread by size (cluster kernel: cl_owner, longest-processing-time first on the column counts; a single-target cluster by t % n).  The selections
 // travel as child ordinals inside each target's block (sel_rel, [max_targets] int32 in caller-owned device memory, -1 = "not mine"):
 // one all-reduce(MAX) over them between _begin and _end gives every device every selection; _end then runs the per-target end of
 // the scan (termination, N-scan pruning) for all targets, so the forests stay identical.  A gating graph that is ONE component is
@@ -1487,6 +1490,18 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
             if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&f->stage_stream, hipStreamNonBlocking) != hipSuccess) f->stage_stream = nullptr;
         }
         hipStream_t sst = f->stage_stream ? f->stage_stream : ctx->stream;
+        // The slot's previous tenant (Z_RING scans ago) must have been CONSUMED -- grow, initiator, post-scan launches on the ctx stream --
+        // before the side stream overwrites it: z_ev only says that its pull had finished.  A host that loops over this call without ever
+        // reading a report can get that far ahead of the device.  Every Z_GUARD scans an event goes onto the ctx stream (behind everything
+        // queued for the scans so far) and the side stream waits for the one recorded Z_GUARD scans earlier: that covers the tenants of the
+        // next Z_GUARD slots (Z_RING = 2 x Z_GUARD), at one event operation per two scans.
+        if (f->stage_stream && f->z_count % Z_GUARD == 0) {
+            const int gi = (int)((f->z_count / Z_GUARD) & 1);
+            if (f->z_guard_ev[1 - gi]) MHT_HIP_CHECK(hipStreamWaitEvent(sst, f->z_guard_ev[1 - gi], 0));      // (recorded Z_GUARD scans ago: covers every scan up to then)
+            if (!f->z_guard_ev[gi]) MHT_HIP_CHECK(hipEventCreateWithFlags(&f->z_guard_ev[gi], hipEventDisableTiming));
+            MHT_HIP_CHECK(hipEventRecord(f->z_guard_ev[gi], ctx->stream));
+        }
+        f->z_count += 1;
         hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
                            reinterpret_cast<float4*>(zd), n16);
         MHT_HIP_CHECK(hipGetLastError());

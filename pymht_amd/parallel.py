@@ -5,7 +5,8 @@ Two levels, as the north star allows them:
    xGMI on the GPU box, gloo in the CPU tests) only carries the barrier / max-over-ranks clock of the benchmark and the gathering
    of the per-sector track lists into one picture (`gather_tracks`, KB-sized, latency bound);
  * ONE tracker on several GPUs when its gating graph partitions (`ClusterShardedTracker`): every rank holds the same forest and is
-   fed the same scans; the independent per-cluster ILPs (tracker.py:228-236) are spread over the ranks (cluster c -> rank c % n) and
+   fed the same scans; the independent per-cluster ILPs (tracker.py:228-236) are spread over the ranks (by size: longest-processing-time
+   first on the clusters' column counts, computed identically on every device -- `assign_clusters` below states the rule) and
    the selections travel in ONE all-reduce(MAX) of max_targets int32 per scan (child ordinals inside each target's block, -1 = not
    mine).  A graph that is one component is solved by one rank while the others wait: the one-GPU fallback."""
 import numpy as np
@@ -72,10 +73,11 @@ def gather_tracks(ids, states, dist=None, device="cpu", max_tracks=4096):
     return out
 
 
-def merge_selections(sel_rel, dist=None):
+def merge_selections(sel_rel, dist=None, always=False):
     """The exchange step of a cluster-sharded scan: element-wise MAX over the ranks of the per-target selections (-1 = not solved
-    here).  `sel_rel`: int32 tensor [max_targets] on the rank's device (cpu tensors with gloo).  In place."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    here).  `sel_rel`: int32 tensor [max_targets] on the rank's device (cpu tensors with gloo).  In place.  always=True: the collective
+    is issued with one rank too (tests / `bench.py` with MHT_BENCH_FORCE_DIST: the RCCL call itself on a one-GPU box)."""
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or always):
         dist.all_reduce(sel_rel, op=dist.ReduceOp.MAX)
     return sel_rel
 
@@ -88,10 +90,10 @@ class ClusterShardedTracker:
     run two shards inside one process pass a function that takes the element-wise maximum of the two tensors).
     Every rank must be given the same targets and the same scans; track initiation (step 7) runs replicated on every rank."""
 
-    def __init__(self, tracker, shard_n, shard_i, exchange=None, dist=None):
+    def __init__(self, tracker, shard_n, shard_i, exchange=None, dist=None, always_exchange=False):
         import torch
         self.trk, self.shard_n, self.shard_i = tracker, int(shard_n), int(shard_i)
-        self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist))
+        self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist, always_exchange))
         self.sel_rel = torch.full((tracker._cfg.max_targets,), -1, dtype=torch.int32, device=tracker._ctx.device)
 
     def begin(self, scanList, **kwargs):

@@ -242,6 +242,8 @@ class Tracker():
         except _lib.MhtError as e:
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
+            elif self._ais and self.useInitiator:      # (a refused scan must not leave its messages with the initiator for the next one)
+                self._lib.mht_initiator_set_ais(self.initiator.handle, None, 0, None)
             raise
         tic['_call'] = time.perf_counter() - tic['_call']      # host time of this call up to here (the scan is queued; nothing waited)
         self._leaf_time = float(scanList.time)

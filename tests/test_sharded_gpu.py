@@ -119,7 +119,7 @@ def _rccl_worker(rank, world, port, q):
     from pymht_amd.utils.classDefinitions import MeasurementList
     from pymht_amd.utils.scenario import make_config
     sc = make_config("cfg3", seed=5446, n_scans=6)
-    part = ClusterShardedTracker(_tracker(sc, device=rank), world, rank, dist=dist)
+    part = ClusterShardedTracker(_tracker(sc, device=rank), world, rank, dist=dist, always_exchange=True)      # (world 1: the all-reduce is issued all the same)
     solo = _tracker(sc, device=rank) if rank == 0 else None
     ok = True
     for k in range(6):
@@ -152,3 +152,20 @@ def test_cluster_sharded_two_processes_rccl():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res) and res[0][2] == res[1][2]
+
+
+@pytest.mark.gpu
+def test_cluster_sharded_rccl_world_size_one():
+    """The RCCL path on the hardware there is: one process, `torch.distributed` over the `nccl` backend (= RCCL) with world_size 1 --
+    communicator creation and the device-tensor all_reduce of `merge_selections` run on the MI355X (the two-process test above needs
+    a second GPU); the sharded tracker must equal a single forest scan by scan."""
+    import torch.multiprocessing as mp
+    port = 29533 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res[0] == 0 and res[1] and res[2] > 0

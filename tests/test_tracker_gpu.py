@@ -201,6 +201,34 @@ def test_terminated_tracks_keep_their_history():
     trk.close()
 
 
+def test_terminated_tracks_keep_their_history_streamed_with_the_device_initiator():
+    """The same with the default drop-in configuration -- device initiator, reports folded TWO scans late (tracker.py here:
+    _queue_report) -- and scans streamed in without a look in between: the window chain of a track that died in scan k is fetched when
+    scan k + 2 has been queued, so the ring must still hold the layer of its root (N + 4 layers; with N + 3 the root and the committed
+    history of tracks that die mid-stream were lost).  At least four more scans follow the deaths."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_scenario
+    from trace_util import make_oracle
+    sc = make_scenario(T=30, radius=400.0, lambda_phi=3e-5, n_scans=20, P_d=0.55, seed=3)      # low P_d: tracks die
+    trk, acc = make_tracker(sc["period"], sc["lambda_phi"], 1e-4, sc["P_d"], 3, 5.99, sc["x0"], sc["t0"])      # (useInitiator defaults to True)
+    o = make_oracle(dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=3, eta2=5.99, x0=sc["x0"], t0=sc["t0"], accepted=acc))
+    died_at = {}
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        o.add_scan(float(t), z)
+        for n in o.terminated:
+            died_at.setdefault(n.ID, k)
+        trk.addMeasurementList(MeasurementList(float(t), z))          # (streamed: nothing is looked at in between)
+    dead = trk.__terminatedTargets__
+    assert len(dead) == len(o.terminated) >= 3
+    assert sum(1 for k in died_at.values() if k <= len(sc["scans"]) - 5) >= 2, "the scenario must have deaths with >= 4 scans behind them"
+    want = {n.ID: n.history_meas() for n in o.terminated}
+    for v in dead:
+        nodes = v.backtrackNodes()
+        chain = [0 if m.measurementNumber is None else int(m.measurementNumber) for m in nodes]
+        assert chain == want[v.ID], v.ID
+    trk.close()
+
+
 def test_toc_is_the_scans_own_cost_not_the_hosts_idle_time(caplog):
     """addMeasurementList is pipelined (the report of scan k is folded by the call for scan k+1), so the wall time between a call and
     its fold is the host's idle time.  toc['Total'] must be what the scan cost -- host call + device stages + fold -- and the per-stage

@@ -43,9 +43,9 @@ def make_oracle(g, with_initiator=True, model=None):
 
 def states_close(a, b, rel=1e-6):
     """The north star's state tolerance (1e-6 relative): relative to the largest component of each state vector -- a velocity near
-    zero carries the rounding of the ~1e2..1e3 m positions it was differenced from.  Needed for float32 chains only: targets born
-    from the device initiator start from float32 states that agree with the reference's to an ulp, not bit for bit (its host BLAS
-    orders 4-term dot products its own way); float64 chains of pre-initialised targets are bit-exact."""
+    zero carries the rounding of the ~1e2..1e3 m positions it was differenced from.  Only used where a LIVE oracle on another host may
+    have picked other BLAS kernels, and for the AIS-aided traces; the recorded radar traces -- the float32 chains of targets born from
+    the device initiator included, since round 3 -- are compared with np.array_equal."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     nx = a.shape[-1] if a.ndim > 1 and a.shape[-1] in (4, 6) else 4
     a, b = a.reshape(-1, nx), b.reshape(-1, nx)
