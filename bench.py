@@ -356,6 +356,8 @@ def main():
     if world > 1 or os.environ.get("MHT_BENCH_FORCE_DIST"):      # (the env switch exercises the RCCL calls on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))      # (MHT_BENCH_FORCE_DIST on a one-GPU box: no launcher has set the rendezvous)
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON line,
         # so the banner is sent to stderr (fd level: it is written by the C library)
         sys.stdout.flush()
