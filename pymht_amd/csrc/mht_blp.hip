@@ -1607,7 +1607,7 @@ __device__ __forceinline__ TgtPre load_target_cr(const BlpArgs& a, int t, const 
 }
 // my_t: member `threadIdx.x` of the cluster if the caller has it at hand (-1: read from the member list), pre_in: its record if already fetched
 __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, unsigned long long* uw, Red* r, unsigned char* lds,
-                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr) {
+                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr, const int dbg_bx = -1) {
     const int tid = threadIdx.x;
     const int c = cr.c;
     const int K = cr.K;
@@ -1979,8 +1979,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
             }
         }
     }
-    if (tid == 0 && a.dbg && blockIdx.x < 3900 && tm.q == 0) {
-        unsigned long long* g = a.dbg + 32 + (size_t)blockIdx.x * 16;
+    if (tid == 0 && a.dbg && dbg_bx >= 0 && dbg_bx < 3900 && tm.q == 0) {
+        unsigned long long* g = a.dbg + 32 + (size_t)dbg_bx * 16;
         g[8] = t_begin; g[9] = t_setup; g[10] = stamp[4]; g[11] = wall_clock64();
     }
     if (tid == 0) {
@@ -2292,7 +2292,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             tm = Team{q, team_W(ti), &a.team_state[ti].gub};
         }
         if (a.dbg && threadIdx.x == 0 && bx < 3900 && stage == 0) a.dbg[32 + (size_t)bx * 16 + 13] = wall_clock64();
-        solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr);
+        solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr, bx);
     }
 }
 
@@ -2448,7 +2448,8 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
     UfPersist* ps = reinterpret_cast<UfPersist*>(lds + a.uf_lds_off);
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     const UfFetch fe = uf_prefetch(a);
-    blp_body<true>(a, lds, blockIdx.x, gridDim.x, ps, &fe);
+    const int gx = (int)gridDim.x, pb = (int)blockIdx.x, bx = pb;
+    blp_body<true>(a, lds, bx, gx, ps, &fe);
     if (!fe.s_over) blp_stamp_end(a);
     if (a.blp_done) {
         // the next scan's grow launch may be running: its commit waits until every workgroup of this launch has released what it wrote
@@ -2459,7 +2460,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
             atomicAdd(a.blp_done, 1ull);
         }
     }
-    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 15] = wall_clock64();
+    if (a.dbg && threadIdx.x == 0 && bx < 3900) { a.dbg[32 + (size_t)bx * 16 + 15] = wall_clock64(); a.dbg[32 + (size_t)bx * 16 + 14] = ((unsigned long long)pb << 8) | (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7); }
 }
 // a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out
 // sector-interleaved in dispatch order (blockIdx.x fastest): the first n * nMulti workgroups to reach the machine are the ones that

@@ -34,7 +34,24 @@ struct FCounts {          // device-side counters of the forest
     // the scan whose initiator (initiator_side_kernel, launched any-order behind the scan's ILP launch) has finished: the admission in the
     // next grow launch waits for it when that launch overlaps (FDyn::adm_wait)
     unsigned long long init_flag;
+    // the staging kernel's tag (stage_scan_kernel): the scan in the device buffer is complete when it equals FDyn::z_tag
+    unsigned long long z_flag;
+    unsigned long long role_tick, init_tick;      // tickets {scan, count}: FDyn::role_tick, initiator_side_kernel (first_come_ticket)
 };
+// Ticket among the few workgroups of a launch that may play a role: 0 for the first one to arrive in launch `tag`, 1, 2, ... for the
+// others.  The word carries the tag of the launch it was last used in, so nothing has to be reset (launches may skip the scheme).
+__device__ __forceinline__ unsigned first_come_ticket(unsigned long long* word, unsigned tag) {
+    unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if ((unsigned)(w >> 32) != tag) {
+            const unsigned long long old = atomicCAS(word, w, ((unsigned long long)tag << 32) | 1ull);
+            if (old == w) return 0u;
+            w = old;
+        } else {
+            return (unsigned)atomicAdd(word, 1ull);      // (low half: arrivals so far)
+        }
+    }
+}
 // Spin on a word another kernel / workgroup publishes (agent-scope loads, s_sleep between polls).  Bounded: a wait that does not end
 // within ~2 s gives up (returns false) instead of hanging the device; the caller voids the scan.
 constexpr unsigned long long SPIN_TICKS = 200000000ull;      // 10 ns ticks

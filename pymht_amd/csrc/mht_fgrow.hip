@@ -488,6 +488,10 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
     const bool ovl = !LEAN && d.fused && d.ovl;      // (the previous scan's ILP launch may still be running)
     int rf_rec = 0;
     const float2* z2 = reinterpret_cast<const float2*>(d.z);
+    if (d.z_tag) {        // (streamed path: the scan's staging kernel ran on another stream and nobody waited for it -- usually long done)
+        unsigned long long v;
+        if (!spin_until(d.z_flag, [&](unsigned long long x) { return x >= d.z_tag; }, v) && tid == 0) a.status->overflow = 2;      // (tags only grow: a later scan may have been staged already)
+    }
     if (ovl)              // (the wait for the target's record comes behind everything that does not depend on it)
         for (int j = tid; j < Mpad; j += FG_THREADS) {
             const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
@@ -1388,13 +1392,26 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
 template <int PQ, int CAP, typename CARGS>
 __device__ __forceinline__ void fgrow_body_lean(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) { fgrow_body<PQ, CAP, CARGS, 0, true>(ap, cm, d, smem); }
 
+// (see FDyn::role_tick) the role -- the block index the rest of the kernel works with -- of one of the launch's first eight workgroups
+__device__ __forceinline__ int fg_role_of_block(const FDyn& d, unsigned char* smem) {
+    int bx = (int)blockIdx.x;
+    if (d.role_tick && bx < 8 && (int)gridDim.x >= 8) {
+        int* s = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) s[0] = (int)first_come_ticket(d.role_tick, (unsigned)d.c_scan + 1u);
+        __syncthreads();
+        bx = s[0];
+        __syncthreads();      // (the LDS is the role's from here on)
+    }
+    return bx;
+}
+
 // one sector per launch: the argument blocks travel by value (FGrowArgs first: the workgroups re-read it through the kernarg pointer)
 template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
-    fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+    fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem, fg_role_of_block(d, smem));
 }
 
 // The streaming drop-in path (mht_forest_scan with the device initiator): the previous scan's commit, the admission of what its
@@ -1413,7 +1430,7 @@ template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub, const AddArgs ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    const int bx = blockIdx.x, n_grow = 1 + d.n_main + d.n_chain;      // (d.fused = 1)
+    const int bx = fg_role_of_block(d, smem), n_grow = 1 + d.n_main + d.n_chain;      // (d.fused = 1)
     if (bx == 0) {
         int* sm = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }

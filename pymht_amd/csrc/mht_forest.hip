@@ -64,8 +64,19 @@ template <int NT> __device__ __forceinline__ void publish_report(const PublishAr
 static_assert(sizeof(mht_target_report) % 16 == 0 && sizeof(mht_birth_report) % 8 == 0, "report blocks are copied in 16-byte pieces");
 
 // the scan from the pinned staging ring (device-mapped) to its device buffer: one small workgroup on the stream, no copy engine
-__global__ void stage_scan_kernel(const float4* src, float4* dst, int n16) {
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+// (flag != null: the consumers on the ctx stream do not wait for this launch through an event -- they poll the word: the scan is written
+// through, acknowledged, then the tag is posted)
+__global__ void stage_scan_kernel(const float4* src, float4* dst, int n16, unsigned long long* flag = nullptr, unsigned long long tag = 0) {
+    if (!flag) { for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i]; return; }
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) {
+        const float4 v = src[i];
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(dst + i);
+        __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(COMMIT_THREADS) void commit_publish_kernel(const CommitArgs a, const CommitDyn dyn, const PublishArgs pub) {
@@ -136,7 +147,16 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
 // scan's grow launch, nothing of the clustering or the ILPs, and what it gives birth to is admitted in the NEXT scan's grow launch --
 // so it runs next to the scan's cluster and ILP launches instead of lengthening the cluster launch (cluster_init_kernel: 15 us against
 // 8.7 for the clustering alone).
-__global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow, unsigned long long* done_flag = nullptr) {
+__global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow, unsigned long long* done_flag = nullptr,
+                                                                      const unsigned long long* z_flag = nullptr, unsigned long long z_tag = 0,
+                                                                      unsigned long long* tick = nullptr) {
+    if (tick) {      // launched with one workgroup per XCD: the first one to start (the XCD the ILP launch drained first) is the initiator
+        __shared__ unsigned s_r;
+        if (threadIdx.x == 0) s_r = first_come_ticket(tick, (unsigned)in.scan_no);
+        __syncthreads();
+        if (s_r != 0u) return;
+    }
+    if (z_tag) { unsigned long long v; (void)spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v); }      // (the scan's staging, see stage_scan_kernel)
     if (!((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
     if (done_flag) {      // the next scan's grow launch may be running already: its admission waits for this word (FCounts::init_flag)
         __syncthreads();
@@ -234,6 +254,8 @@ struct Forest {
     unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
     // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
     // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
+    unsigned long long z_tag_step = 0;      // != 0: the scan being stepped was staged without an event wait on the ctx stream (FDyn::z_tag); z_wait_slot: its slot
+    int z_wait_slot = -1;
     int init_flag_scan = 0;      // last scan whose initiator posts FCounts::init_flag
     unsigned long long* rec0 = nullptr; int pub_scan = 0; unsigned long long blp_done_total = 0; bool ovl_ok = true; int ovl_launches = 0;
     int32_t* cl_gtab = nullptr; bool cluster_big = false;      // the clustering tables in HBM when they do not fit LDS (mht_cluster.hip: cluster_big_kernel)
@@ -957,6 +979,16 @@ int initiator_ais_pending(const mht_initiator* in);
 void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned char** used);
 }
 
+// will a step with this initiator take the union-find path with the initiator as a launch of its own (forest_step_impl: use_uf)?
+static bool forest_streams_uf(const Forest* f, const mht_initiator* init) {
+    return f->uf_ok && !(f->prune_thr > 0.f) && (!init || (f->adm_fuse && !f->ais && !f->timing && !f->init_in_blp && !f->init_side));
+}
+// a reader of the staged scan other than the grow launch / the initiator's launch is about to be queued on the ctx stream: the event wait
+// the step skipped (step_host_impl)
+static int flush_z_wait(mht_ctx* ctx, Forest* f) {
+    if (f->z_wait_slot >= 0) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[f->z_wait_slot], 0)); f->z_wait_slot = -1; }
+    return MHT_OK;
+}
 // init != null (mht_forest_scan): the scan's step 7 rides in the cluster launch (cluster_init_kernel)
 static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiator* init, double now) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
@@ -1006,7 +1038,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
     // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.
     // (streamed path: the scan's initiator then runs as a launch of its own NEXT to the ILP launch -- launched any-order behind it)
-    const bool use_uf = f->uf_ok && !(f->prune_thr > 0.f) && (!init || (f->adm_fuse && !f->ais && !f->timing && !f->init_in_blp && !f->init_side));
+    const bool use_uf = forest_streams_uf(f, init);
     bool grow_ovl = false;      // this scan's grow launch took the previous scan's results target by target (FDyn::ovl)
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
@@ -1023,6 +1055,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.ovl = (pl.fused && f->pub_scan == pl.s - 1 && f->pending_dyn.scan == pl.s - 1) ? 1 : 0;
         d.c_wait = f->blp_done_total;
         grow_ovl = d.ovl != 0;
+        d.z_flag = &f->cnt->z_flag; d.z_tag = f->z_tag_step;
         { static int os = -1; if (os < 0) { const char* e = getenv("MHT_OVL_STAMPS"); os = (e && e[0] == '1') ? 1 : 0; } d.stamp_end = os; }
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)
         static int ovl_force = -1; if (ovl_force < 0) { const char* e = getenv("MHT_OVL_FORCE"); ovl_force = (e && e[0] == '1') ? 1 : 0; }      // (development: any-order launches with the debug stamps on)
@@ -1104,7 +1137,9 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             ia.used_b = f->used_bytes[pl.s & 1];
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
             hipExtLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, ia,
-                                  static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag);
+                                  static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag,
+                                  static_cast<const unsigned long long*>(f->z_tag_step ? &f->cnt->z_flag : nullptr), f->z_tag_step,
+                                  static_cast<unsigned long long*>(nullptr));      // (no ticket: one workgroup)
             MHT_STEP_HIP(hipGetLastError());
             f->init_ran_scan = pl.s; f->init_flag_scan = pl.s;
         }
@@ -1442,6 +1477,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     // streaming (mht_forest_scan) and nothing left to do here but the commit and the admission: both ride in the next scan's grow launch
     const bool ride = defer_publish && init_done && f->adm_fuse && f->commit_pending && !f->ais && au.nA == 0 && ia.nA == 0;
     if (!ride && f->init_ev_pending) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0)); f->init_ev_pending = false; }
+    if (!ride) { const int rc = flush_z_wait(ctx, f); if (rc) return rc; }      // (post_scan_kernel may read the scan)
     if (ride) { f->adm = a; f->adm_pending = true; }
     else if (au.nA > 0 || ia.nA > 0)
         hipLaunchKernelGGL(post_scan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, ia, a, f->commit_pending ? 1 : 0, pub,
@@ -1502,17 +1538,28 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
             MHT_HIP_CHECK(hipEventRecord(f->z_guard_ev[gi], ctx->stream));
         }
         f->z_count += 1;
+        // Streamed scans (device initiator, clusters from the union-find): the ctx stream does not wait for the staging kernel through an
+        // event -- an event wait is a barrier packet in the queue: it costs microseconds and ends the overlap of this scan's grow launch
+        // with the previous scan's ILP launch.  The kernel posts a tag behind its (written-through) stores instead, and the scan's first
+        // readers -- the grow launch's target workgroups, the initiator's launch -- wait for the tag (it is there long before: the host
+        // runs ahead).  Any other reader of this scan on the ctx stream gets the event wait first (z_wait_slot, flush_z_wait).
+        const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed);
+        f->z_tag_step = by_flag ? (unsigned long long)f->z_count : 0ull;
         hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
-                           reinterpret_cast<float4*>(zd), n16);
+                           reinterpret_cast<float4*>(zd), n16, by_flag ? &f->cnt->z_flag : nullptr, f->z_tag_step);
         MHT_HIP_CHECK(hipGetLastError());
         MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run)
-        if (f->stage_stream) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
+        if (f->stage_stream && !by_flag) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
+        f->z_wait_slot = by_flag ? slot : -1;
         f->z_used[slot] = true;
         f->z_cur = zd;
         (void)mark_done;
-        return forest_step_impl(ctx, zd, M, init, now);
+        const int rc = forest_step_impl(ctx, zd, M, init, now);
+        f->z_tag_step = 0;
+        return rc;
     }
     f->z_cur = f->z_dev;
+    f->z_tag_step = 0; f->z_wait_slot = -1;
     return forest_step_impl(ctx, f->z_dev, M, init, now);
 }
 extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M) { return step_host_impl(ctx, z_host, M, true); }

@@ -120,6 +120,13 @@ struct FDyn {
     int ovl;                       // fused = 1 only: the previous scan's ILP launch may still be running.  Target and chain workgroups take their
                                    // target's results from its record (FGrowArgs::rec0, waiting for it), the commit waits for that launch's
                                    // workgroups (c_wait) and posts the compacted indices the target workgroups end with
+    // the scan was staged by a small kernel on the forest's side stream and the ctx stream did NOT wait for it (streamed path): whoever
+    // reads the scan first waits until z_flag[0] == z_tag (stage_scan_kernel posts it behind its written-through stores); 0: nothing to wait for
+    const unsigned long long* z_flag; unsigned long long z_tag;
+    // overlapping launch: which of its first eight workgroups (one per XCD) plays workgroup 0 -- the commit -- is decided by a ticket: the
+    // first one to START (the XCD the previous scan's ILP launch drained first; the dispatcher's XCD rotation is not ours to know;
+    // mht_commit.h: first_come_ticket).  null: block 0 as ever
+    unsigned long long* role_tick;
     int adm_wait;                  // fgrow_adm_kernel launched any-order: the admission waits for the previous scan's initiator (FCounts::init_flag), the
                                    // report's workgroups for the previous scan's ILP launch (c_wait)
     int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)

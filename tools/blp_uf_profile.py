@@ -17,7 +17,7 @@ def rd(name, k, dt=np.int32):
     return a
 uf = os.environ.get('MHT_NO_UF') != '1'
 names = ['loads', 'chase', 'scan', 'tables', 'members', '->body', '->call', '->solve', 'setup', 'solve', 'epilogue', '->end'] if uf else ['->body', '->call', '->solve', 'setup', 'solve', 'epilogue', '->end']
-acc, spans, starts, ends = [], [], [], []
+acc, spans, starts, ends, drains, agree = [], [], [], [], [], []
 for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     trk.addMeasurementList(MeasurementList(float(t), z))
     if k < 25: continue
@@ -33,6 +33,9 @@ for k, (z, t) in enumerate(zip(sc['scans'], sc['times'])):
     allw = ts[(ts[:, 0] > 0) & (ts[:, 15] > 0)]
     allw = allw[np.abs(allw[:, 0] - np.median(w[:, 0])) < 20000]      # (rows of workgroups beyond this scan's grid are stale)
     t0 = allw[:, 0].min()
+    xcc = (allw[:, 14] & 7); phys = allw[:, 14] >> 8
+    drains.append([((allw[xcc == x, 15].max() - t0) / 100.0 if (xcc == x).any() else np.nan) for x in range(8)])
+    agree.append(float(np.mean((phys & 7) == xcc)))
     ends.append(np.percentile((allw[:, 15] - t0) / 100.0, [5, 25, 50, 75, 95, 100]))
     spans.append(((allw[:, 15].max() - t0) / 100.0, (w[:, 11].max() - t0) / 100.0, (allw[:, 0].max() - t0) / 100.0, (w[:, 8] - w[:, 0]).mean() / 100.0))
 m = np.mean(acc, axis=0)
@@ -40,3 +43,4 @@ print('workgroups with an ILP, mean us per phase: ' + '  '.join('%s %.2f' % (nm,
 s = np.mean(spans, axis=0)
 print('launch: first start -> last end %.1f us, -> last ILP end %.1f, last workgroup start %.1f; entry -> first solve %.1f' % tuple(s))
 print('workgroup end times (us from the first start), percentiles 5/25/50/75/95/100: ' + ' '.join('%.1f' % v for v in np.mean(ends, axis=0)))
+print('per-XCD drain time (us): ' + ' '.join('%.1f' % v for v in np.nanmean(drains, axis=0)) + ';  workgroups with XCC_ID == blockIdx %% 8: %.0f %%' % (100 * np.mean(agree)))
