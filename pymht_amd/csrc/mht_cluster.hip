@@ -13,6 +13,7 @@
 // member with ascending members -- the order scipy's labelling + np.where gives the reference (tracker.py:972-974).
 #include "mht_kernels.h"
 #include "mht_init_dev.h"
+#include "mht_uf.h"
 
 namespace mht {
 
@@ -442,6 +443,38 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_batch_kernel(const PBatch 
     cluster_body<false>(a, smem);
 }
 
+// ---- tables beyond LDS: the union-find of the forest's grow launch, as two ordinary launches (r4) -------------------------------------
+// cluster_big_kernel keeps the one-workgroup algorithm and moves its tables to HBM: correct at any size, but its phases become
+// milliseconds of L2 atomics from ONE workgroup.  The stateless seam uses what the forest uses instead (mht_uf.h): a thread per word of
+// the association bitsets exchanges the owner word of every measurement node in it and links the targets it meets there -- any number of
+// workgroups, no edge records (so neither the 16 + 16 bits of one nor the 65 536-node limit apply) --, then a thread per target follows
+// its parents to the smallest member of its component = the label.
+__global__ __launch_bounds__(256) void uf_seam_hook_kernel(const unsigned long long* assoc, long long n_words, int AW, unsigned long long* owner, unsigned long long* parent) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (long long)gridDim.x * blockDim.x) {
+        unsigned long long bits = assoc[i];
+        if (!bits) continue;
+        const int t = (int)(i / AW), w = (int)(i % AW);
+        const unsigned long long mine = (1ull << 32) | (unsigned)t;
+        while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const unsigned long long old = atomicMax(&owner[(size_t)w * 64 + b], mine);
+            if ((unsigned)(old >> 32) == 1u && (int)(unsigned)old != t) uf_link(parent, 1u, t, (int)(unsigned)old);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void uf_seam_label_kernel(const unsigned long long* parent, int T, int32_t* label) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        int r = t;
+        for (;;) {
+            const unsigned long long w = parent[r];
+            if ((unsigned)(w >> 32) != 1u) break;
+            r = (int)(0xffffffffu - (unsigned)w);
+        }
+        label[t] = r;
+    }
+}
+
 constexpr size_t CL_LDS_BUDGET = 150 * 1024;
 // LDS carve for a given table size: the pending-pair list gets a quarter of what the tables leave (at most CL_PEND_MAX), the
 // edge list the rest (at most CL_ELDS_MAX); elds < Tcap = does not fit
@@ -536,6 +569,23 @@ extern "C" int mht_cluster(mht_ctx* ctx, int32_t T, int32_t words, const uint64_
     MHT_REQUIRE(T >= 0 && words >= 1, "mht_cluster: bad sizes");
     if (T == 0) return MHT_OK;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!cluster_fits_lds(T, words * 64)) {      // tables beyond LDS: the device-wide union-find (any size)
+        const size_t nn = (size_t)words * 64;
+        int rc = ctx->counts.ensure((nn + (size_t)T) * 8);
+        if (rc) return rc;
+        unsigned long long* owner = static_cast<unsigned long long*>(ctx->counts.ptr);
+        unsigned long long* parent = owner + nn;
+        MHT_HIP_CHECK(hipMemsetAsync(owner, 0, (nn + (size_t)T) * 8, ctx->stream));
+        const long long n_words = (long long)T * words;
+        long long g = (n_words + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(uf_seam_hook_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long*>(assoc), n_words, (int)words, owner, parent);
+        MHT_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(uf_seam_label_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, static_cast<const unsigned long long*>(parent), (int)T, label);
+        MHT_HIP_CHECK(hipGetLastError());
+        MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MHT_OK;
+    }
     size_t ecap = (size_t)T * words * 64;
     if (ecap > (1u << 22)) ecap = 1u << 22;
     const bool big = !cluster_fits_lds(T, words * 64);

@@ -30,7 +30,9 @@ def gpu_cluster(ctx, sets, n_nodes):
                                                  (3000, 9000, 9, 6),        # > 16384 edges: the LDS edge list spills to HBM
                                                  # tables beyond LDS (cluster_big_kernel, tables in HBM): 8 k targets x 4 k measurements, N-scan 6
                                                  # = 9 x 4096 measurement nodes (the round-2 review's size), sparse and dense; and the 16-bit limits
-                                                 (8192, 36864, 5, 7), (8192, 36864, 24, 8), (6000, 65536, 3, 9), (20000, 4096, 2, 10)])
+                                                 (8192, 36864, 5, 7), (8192, 36864, 24, 8), (6000, 65536, 3, 9), (20000, 4096, 2, 10),
+                                                 # beyond every 16-bit limit (the seam's device-wide union-find, mht_uf.h: no edge records)
+                                                 (20000, 131072, 4, 11), (30000, 70000, 3, 12)])
 def test_cluster_matches_oracle(gpu_ctx, T, n_nodes, deg, seed):
     rng = np.random.default_rng(seed)
     sets = [set(int(v) for v in rng.integers(0, n_nodes, size=rng.integers(0, deg + 1))) for _ in range(T)]
