@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MHT_ABI_VERSION 3
+#define MHT_ABI_VERSION 4
 
 /* State dimension of the library build the header is used with: 4 (libmht_amd.so: the reference's CV model, models/pv.py) or 6
  * (libmht_amd6.so: the same sources compiled with -DMHT_NX=6 for BASELINE config 5's six-state model).  It sizes the model matrices
@@ -131,6 +131,13 @@ typedef struct mht_model_x {
     const float* C;         /* host [2*nx] measurement matrix */
     const float* R;         /* host [4] measurement noise */
     double eta2, lambda_ex;
+    /* transition = 0: the linear model above (A for every leaf: kalman.predict, kalman.py:55-64).
+     * transition = 1 (nx = 6 only; BASELINE config 5's constant-turn model, pymht_amd/models/ct.py): state = [x, y, vx, vy, w, a]; every
+     * leaf gets its OWN A = Phi(period, w of the leaf) -- velocity rotated by w * period, the arc integrated, w += period * a; A above is
+     * ignored -- and runs the reference's per-hypothesis form: kalman.predict_single (kalman.py:67-70), then kalman.precalc on a batch of
+     * one (kalman.py:82-101), i.e. the matrix x vector products in BLAS gemv order. */
+    int32_t transition;
+    double period;
 } mht_model_x;
 int mht_gate_scan_x(mht_ctx* ctx, const mht_model_x* model, int32_t L, const double* x, const uint8_t* flags, const float* P,
                     const double* pd, const float* z, int32_t M, double* x_bar, float* P_bar, float* P_hat, float* S, float* S_inv,

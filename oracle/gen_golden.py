@@ -360,6 +360,8 @@ def main():
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
     if "g11" in which:
         gen_g11(mods)
+    if "g21" in which:
+        gen_g21(mods)
     if "g15" in which:
         gen_g15(mods)
     if "g16" in which:
@@ -730,6 +732,75 @@ def gen_g11(mods):
     fx["n_cases"] = case
     np.savez_compressed(os.path.join(GOLD, "g11_kalman6.npz"), **fx)
     print("  g11_kalman6: %d cases" % case)
+
+
+def gen_g21(mods):
+    """Known-answer vectors for a STATE-DEPENDENT transition (BASELINE config 5: constant-turn, six states; pymht_amd/models/ct.py), made
+    with the reference's per-hypothesis functions -- kalman.predict_single (kalman.py:67-70) with the leaf's own A, kalman.precalc
+    (kalman.py:82-101) on a batch of one -- and z_tilde / NIS / numpyFilter / nllr as in g11; the oracle's restatement
+    (process_leaves_ct) must agree bit for bit."""
+    kal = mods["kalman"]
+    sys.path.insert(0, ROOT)
+    from pymht_amd.models import ct
+    rng = np.random.default_rng(20260930)
+    T = 2.5
+    Q, C, R = ct.Q(T), ct.C_RADAR, ct.R_RADAR()
+    fx = dict(Q=Q, C=C, R=R, eta2=5.99, lambda_ex=1e-4 + 2e-5, nx=6, period=T)
+    case = 0
+    for n, M in ((1, 1), (12, 40), (300, 500), (64, 129), (1500, 64)):
+        for f32state in (False, True):
+            x = np.concatenate([rng.uniform(-3000, 3000, size=(n, 2)), rng.normal(0, 8, size=(n, 2)), rng.normal(0, 0.05, size=(n, 1)), rng.normal(0, 1e-3, size=(n, 1))], axis=1)
+            x[rng.uniform(size=n) < 0.15, 4] = 0.0      # straight-line hypotheses: the limit branch of Phi
+            if f32state:
+                x = x.astype(np.float32)
+            P = np.array([ct.P0] * n)
+            for i in range(n):      # covariances reached after 0..5 steps of the leaf's own recursion with random hit/miss patterns
+                Pi, wi = ct.P0, x[i, 4]
+                for _ in range(int(rng.integers(0, 6))):
+                    xb, Pb = kal.predict_single(ct.Phi(T, wi), Q, np.zeros(6), Pi)
+                    Pi = kal.precalc(C, R, xb.reshape(1, 6), Pb.reshape(1, 6, 6))[4][0] if rng.uniform() < 0.7 else Pb
+                P[i] = Pi
+            xb_all = np.array([ct.Phi(T, x[i, 4]).dot(x[i]) for i in range(n)])
+            z = rng.uniform(-3000, 3000, size=(M, 2))
+            for j in range(M):
+                if rng.uniform() < 0.6:
+                    i = int(rng.integers(0, n))
+                    z[j] = xb_all[i, 0:2] + rng.normal(0, 6.0, size=2)
+            z = z.astype(np.float32)
+            P_d = 0.9
+            res = dict(x_bar=[], P_bar=[], P_hat=[], S=[], S_inv=[], K=[], idx=[], x_hat=[], nllr=[], margin=[])
+            for i in range(n):
+                A = ct.Phi(T, x[i, 4])
+                x_bar, P_bar = kal.predict_single(A, Q, x[i], P[i])
+                z_hat, S, S_inv, K, P_hat = kal.precalc(C, R, x_bar.reshape(1, 6), P_bar.reshape(1, 6, 6))
+                zt = kal.z_tilde(z, z_hat, 1, 2)
+                nis = kal.normalizedInnovationSquared(zt, S_inv)
+                gate = nis <= 5.99
+                idx = np.nonzero(gate[0])[0]
+                res["x_bar"].append(x_bar); res["P_bar"].append(P_bar); res["P_hat"].append(P_hat[0]); res["S"].append(S[0])
+                res["S_inv"].append(S_inv[0]); res["K"].append(K[0]); res["idx"].append(idx)
+                res["x_hat"].append(kal.numpyFilter(x_bar, K[0], zt[0, idx]))
+                res["nllr"].append(kal.nllr(fx["lambda_ex"], P_d, S[0], nis[0, gate[0]]))
+                res["margin"].append(float(np.min(np.abs(nis.astype(np.float64) - 5.99))))
+            r = orc.process_leaves_ct(ct.Phi, T, Q, C, R, 5.99, fx["lambda_ex"], x, P, [P_d] * n, z)
+            for k in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K"):
+                assert np.array_equal(r[k], np.array(res[k])), k
+            assert all(np.array_equal(a, b) for a, b in zip(r["idx"], res["idx"])) and all(np.array_equal(a, b) for a, b in zip(r["x_hat"], res["x_hat"]))
+            assert all(np.array_equal(a, b) for a, b in zip(r["nllr"], res["nllr"]))
+            p = "c%d_" % case
+            fx[p + "x"], fx[p + "P"], fx[p + "z"], fx[p + "P_d"] = x, P, z, P_d
+            for k in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K"):
+                fx[p + k] = np.array(res[k])
+            fx[p + "A"] = np.array([ct.Phi(T, x[i, 4]) for i in range(n)])
+            fx[p + "row_ptr"] = np.concatenate([[0], np.cumsum([len(i) for i in res["idx"]])]).astype(np.int64)
+            fx[p + "col_idx"] = np.concatenate(res["idx"]).astype(np.int64) if n else np.zeros(0, np.int64)
+            fx[p + "x_hat"] = np.concatenate(res["x_hat"], axis=0) if len(fx[p + "col_idx"]) else np.zeros((0, 6))
+            fx[p + "nllr"] = np.concatenate(res["nllr"]) if len(fx[p + "col_idx"]) else np.zeros(0)
+            fx[p + "gate_margin"] = float(np.min(res["margin"]))
+            case += 1
+    fx["n_cases"] = case
+    np.savez_compressed(os.path.join(GOLD, "g21_ct6.npz"), **fx)
+    print("  g21_ct6: %d cases" % case)
 
 
 def gen_g16(mods):

@@ -30,7 +30,8 @@ def model_type(nx):
 
 class MhtModelX(C.Structure):      # mht_model_x: dimension-generic model (nx = 4 or 6 states, 2 measurements)
     _fields_ = [("nx", C.c_int32), ("A", C.POINTER(C.c_float)), ("Q", C.POINTER(C.c_float)), ("C", C.POINTER(C.c_float)),
-                ("R", C.POINTER(C.c_float)), ("eta2", C.c_double), ("lambda_ex", C.c_double)]
+                ("R", C.POINTER(C.c_float)), ("eta2", C.c_double), ("lambda_ex", C.c_double),
+                ("transition", C.c_int32), ("period", C.c_double)]      # transition = 1: constant turn, A per leaf (models/ct.py)
 
 
 class MhtNodes(C.Structure):

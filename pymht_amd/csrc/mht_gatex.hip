@@ -36,7 +36,20 @@ __device__ __forceinline__ void gatex_leaf(const GateXArgs<NX>& a, int l) {
     for (int k = 0; k < NX; ++k) xs[k] = (TS)a.x[(size_t)k * L + l];
 #pragma unroll
     for (int e = 0; e < NX * NX; ++e) P[e] = a.P[(size_t)e * L + l];
-    predict_precalc_x<TS, NX>(a.model, xs, P, xb, zh, Pb, Ph, K, S, Si, a.L == 1);      // (one leaf in the call: gemv order)
+    bool done = false;
+    if constexpr (NX == 6) { if (a.model.ct) {
+        done = true;
+        // a state-dependent transition: the leaf's own A, and the reference's per-hypothesis form (kalman.predict_single + kalman.precalc
+        // on a batch of one: the matrix x vector products in gemv order)
+        ModelX<6> m;
+        for (int i = 0; i < 36; ++i) m.Q[i] = a.model.Q[i];
+        for (int i = 0; i < 12; ++i) m.C[i] = a.model.C[i];
+        for (int i = 0; i < 4; ++i) m.R[i] = a.model.R[i];
+        m.eta2 = a.model.eta2; m.lambda_ex = a.model.lambda_ex; m.ct = 1; m.T = a.model.T;
+        ct_phi(a.model.T, (double)xs[4 < NX ? 4 : 0], m.A);
+        predict_precalc_x<TS, 6>(m, reinterpret_cast<const TS*>(xs), P, reinterpret_cast<TS*>(xb), zh, Pb, Ph, K, S, Si, true);
+    } }
+    if (!done) predict_precalc_x<TS, NX>(a.model, xs, P, xb, zh, Pb, Ph, K, S, Si, a.L == 1);      // (one leaf in the call: gemv order)
 #pragma unroll
     for (int k = 0; k < NX; ++k) a.x_bar[(size_t)k * L + l] = (double)xb[k];
 #pragma unroll
@@ -170,10 +183,11 @@ static int run_gate_x(mht_ctx* ctx, const mht_model_x* m, int32_t L, const doubl
                       const float* z, int32_t M, double* x_bar, float* P_bar, float* P_hat, float* S, float* S_inv, float* K,
                       int32_t* row_ptr, int32_t* col_idx, double* x_hat, double* nllr, int32_t cap, int32_t* n_pairs) {
     GateXArgs<NX> a = {};
-    for (int i = 0; i < NX * NX; ++i) { a.model.A[i] = m->A[i]; a.model.Q[i] = m->Q[i]; }
+    for (int i = 0; i < NX * NX; ++i) { a.model.A[i] = m->A ? m->A[i] : 0.f; a.model.Q[i] = m->Q[i]; }
     for (int i = 0; i < 2 * NX; ++i) a.model.C[i] = m->C[i];
     for (int i = 0; i < 4; ++i) a.model.R[i] = m->R[i];
     a.model.eta2 = m->eta2; a.model.lambda_ex = m->lambda_ex;
+    a.model.ct = m->transition == 1 ? 1 : 0; a.model.T = m->period;
     a.L = L; a.M = M; a.W = (M + 63) / 64; a.cap = cap;
     a.x = x; a.flags = flags; a.P = P; a.pd = pd; a.z = z;
     a.x_bar = x_bar; a.P_bar = P_bar; a.P_hat = P_hat; a.S = S; a.S_inv = S_inv; a.K = K;
@@ -215,8 +229,9 @@ extern "C" int mht_gate_scan_x(mht_ctx* ctx, const mht_model_x* model, int32_t L
                                const double* pd, const float* z, int32_t M, double* x_bar, float* P_bar, float* P_hat, float* S,
                                float* S_inv, float* K, int32_t* row_ptr, int32_t* col_idx, double* x_hat, double* nllr, int32_t cap,
                                int32_t* n_pairs) {
-    MHT_REQUIRE(ctx && model && model->A && model->Q && model->C && model->R, "mht_gate_scan_x: null argument");
+    MHT_REQUIRE(ctx && model && (model->A || model->transition == 1) && model->Q && model->C && model->R, "mht_gate_scan_x: null argument");
     MHT_REQUIRE(model->nx == 4 || model->nx == 6, "mht_gate_scan_x: nx must be 4 or 6 (got %d)", model->nx);
+    MHT_REQUIRE(model->transition == 0 || (model->transition == 1 && model->nx == 6), "mht_gate_scan_x: transition %d needs the six-state constant-turn layout", model->transition);
     MHT_REQUIRE(L >= 0 && M >= 0 && cap >= 0, "mht_gate_scan_x: negative size");
     MHT_REQUIRE(row_ptr && (L == 0 || (x && flags && P && pd && x_bar && P_bar && P_hat && S && S_inv && K)), "mht_gate_scan_x: null array");
     MHT_REQUIRE(M == 0 || z, "mht_gate_scan_x: z is null");

@@ -122,7 +122,7 @@ def process_leaf_nodes(ctx, model, x, P, cnllr, pd, flags, z):
                 nllr=incs[hit], used=used.cpu().numpy().view(np.uint64))
 
 
-def process_leaf_nodes_x(ctx, A, Q, Cm, R, eta2, lambda_ex, x, P, pd, flags, z):
+def process_leaf_nodes_x(ctx, A, Q, Cm, R, eta2, lambda_ex, x, P, pd, flags, z, ct_period=None):
     """The dimension-generic form of seam (i) (`mht_gate_scan_x`: nx = 4 or 6 states): the reference's kalman module
     (predict, precalc, z_tilde, NIS, gate, numpyFilter, nllr -- kalman.py:14-101) for n leaves x M measurements in one call.
     Host arrays in (x (n,nx) f64|f32, P (n,nx,nx) f32), host arrays out, shaped like the oracle's process_leaves()."""
@@ -130,7 +130,9 @@ def process_leaf_nodes_x(ctx, A, Q, Cm, R, eta2, lambda_ex, x, P, pd, flags, z):
     n, nx, M = x.shape[0], x.shape[1], z.shape[0]
     keep = [np.ascontiguousarray(np.asarray(m, dtype=np.float32).ravel()) for m in (A, Q, Cm, R)]
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-    model = _lib.MhtModelX(nx, fp(keep[0]), fp(keep[1]), fp(keep[2]), fp(keep[3]), float(eta2), float(lambda_ex))
+    # (ct_period: the constant-turn model of models/ct.py -- A is rebuilt per leaf from its turn rate, the A passed in is ignored)
+    model = _lib.MhtModelX(nx, fp(keep[0]), fp(keep[1]), fp(keep[2]), fp(keep[3]), float(eta2), float(lambda_ex),
+                           0 if ct_period is None else 1, 0.0 if ct_period is None else float(ct_period))
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
     xd = t(np.asarray(x, dtype=np.float64).T, np.float64) if n else torch.zeros((nx, 0), dtype=torch.float64, device=dev)
     Pd = t(np.asarray(P, dtype=np.float32).reshape(n, nx * nx).T, np.float32) if n else torch.zeros((nx * nx, 0), dtype=torch.float32, device=dev)

@@ -32,6 +32,37 @@ def test_gate_x_matches_reference_vectors(gpu_ctx, gold_dir, fixture):
         _check(r, k, (fixture, c))
 
 
+def test_gate_x_constant_turn_matches_reference_vectors(gpu_ctx, gold_dir):
+    """BASELINE config 5's model family -- a STATE-DEPENDENT transition (constant turn, six states; pymht_amd/models/ct.py): every leaf its own
+    A and its own covariance chain.  Known answers made with the reference's per-hypothesis functions kalman.predict_single + kalman.precalc
+    (g21, oracle/gen_golden.py::gen_g21), through `mht_gate_scan_x` with mht_model_x.transition = 1: the gating index sets exactly; the
+    matrices and states bit for bit wherever the device's sin / cos agree with the host's to the last float32 bit of A (checked: A itself is
+    compared first), and to 1e-6 otherwise."""
+    from pymht_amd.device import process_leaf_nodes_x
+    from pymht_amd.models import ct
+    g = np.load(os.path.join(gold_dir, "g21_ct6.npz"))
+    T = float(g["period"])
+    n_exact = n_all = 0
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        x = k("x")
+        r = process_leaf_nodes_x(gpu_ctx, ct.Phi(T, 0.0), g["Q"], g["C"], g["R"], float(g["eta2"]), float(g["lambda_ex"]), x, k("P"),
+                                 np.full(len(x), float(k("P_d"))), flags_for(x), k("z"), ct_period=T)
+        assert np.array_equal(r["row_ptr"], k("row_ptr")) and np.array_equal(r["col_idx"], k("col_idx")), c      # gating: exact
+        exact = all(np.array_equal(r[name], k(name).astype(r[name].dtype)) for name in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K"))
+        n_exact += int(exact)
+        n_all += 1
+        if exact:
+            assert np.array_equal(r["x_hat"], k("x_hat").astype(np.float64)), c
+        else:      # (a last-bit difference of sin / cos that survived the rounding of A to float32)
+            assert np.allclose(r["x_bar"], k("x_bar").astype(np.float64), rtol=1e-6, atol=1e-9), c
+            for name in ("P_bar", "P_hat", "S", "S_inv", "K"):
+                assert np.allclose(r[name], k(name), rtol=1e-5, atol=1e-7), (c, name)
+            assert np.allclose(r["x_hat"], k("x_hat").astype(np.float64), rtol=1e-6, atol=1e-6), c
+        assert np.allclose(r["nllr"], k("nllr").astype(np.float64), rtol=0, atol=NLLR_ATOL if exact else 1e-5), c
+    assert n_exact >= n_all - 2, (n_exact, n_all)
+
+
 @pytest.mark.parametrize("n,M,seed", [(0, 5, 1), (3, 0, 2), (1, 1, 3), (700, 65, 4), (129, 2048, 5)])
 def test_gate_x_six_state_edge_shapes_vs_oracle(gpu_ctx, n, M, seed):
     from pymht_amd.device import process_leaf_nodes_x

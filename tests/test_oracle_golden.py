@@ -81,3 +81,26 @@ def test_ais_trace_replay(gold_dir, name):
     from trace_util import replay_oracle_ais
     o = replay_oracle_ais(os.path.join(gold_dir, name + ".npz"))
     assert o.n_scans > 0
+
+
+def test_constant_turn_vectors_g21(gold_dir):
+    """g21: the state-dependent transition of BASELINE config 5 (constant turn, six states) -- the oracle's per-leaf restatement
+    (process_leaves_ct: kalman.predict_single + kalman.precalc on a batch of one) against the vectors the reference's own functions gave."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pymht_amd.models import ct
+    g = np.load(os.path.join(gold_dir, "g21_ct6.npz"))
+    T = float(g["period"])
+    assert np.array_equal(ct.Q(T), g["Q"]) and np.array_equal(ct.C_RADAR, g["C"]) and np.array_equal(ct.R_RADAR(), g["R"])
+    for c in range(int(g["n_cases"])):
+        k = lambda s: g["c%d_%s" % (c, s)]
+        x = k("x")
+        assert np.array_equal(np.array([ct.Phi(T, w) for w in x[:, 4]]), k("A"))
+        r = orc.process_leaves_ct(ct.Phi, T, g["Q"], g["C"], g["R"], float(g["eta2"]), float(g["lambda_ex"]), x, k("P"), [float(k("P_d"))] * len(x), k("z"))
+        for name in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K"):
+            assert np.array_equal(r[name], k(name)), (c, name)
+        assert np.array_equal(np.concatenate([[0], np.cumsum([len(i) for i in r["idx"]])]), k("row_ptr"))
+        if len(k("col_idx")):
+            assert np.array_equal(np.concatenate(r["idx"]), k("col_idx"))
+            assert np.array_equal(np.concatenate(r["x_hat"], axis=0), k("x_hat")) and np.array_equal(np.concatenate(r["nllr"]), k("nllr"))
