@@ -214,7 +214,7 @@ int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* 
 typedef struct mht_forest_config {
     int32_t max_targets;  /* capacity of the target list */
     int32_t max_nodes;    /* hypotheses per scan layer (children of one scan + roots born in it) */
-    int32_t max_meas;     /* measurements per scan (<= 2048) */
+    int32_t max_meas;     /* measurements per scan (<= 4096; (n_scan + 4) x max_meas rounded up to 64 <= 65536) */
     int32_t n_scan;       /* Tracker.N: N-scan window (tracker.py:112-114) */
     int32_t blp_max_iter; /* dual-ascent steps before branch and bound (200 when < 0; 0 = branch and bound only) */
     int32_t blp_node_limit; /* branch-and-bound node budget per cluster (default 1<<20 when <= 0) */

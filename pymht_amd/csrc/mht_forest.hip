@@ -495,7 +495,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     }
     MHT_REQUIRE(!ctx->forest, "mht_forest_create: the ctx already owns a forest");
     MHT_REQUIRE(cfg->n_scan >= 1 && cfg->n_scan + RING_EXTRA <= MAXR, "mht_forest_create: n_scan must be in [1, %d]", MAXR - RING_EXTRA);
-    MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 2048, "mht_forest_create: max_meas must be in [1, 2048]");
+    MHT_REQUIRE(cfg->max_meas >= 1 && cfg->max_meas <= 4096, "mht_forest_create: max_meas must be in [1, 4096]");
     MHT_REQUIRE(cfg->max_targets >= 1 && cfg->max_targets <= 8192, "mht_forest_create: max_targets must be in [1, 8192]");
     MHT_REQUIRE(cfg->max_nodes >= 2 * cfg->max_targets + 512, "mht_forest_create: max_nodes must be at least 2 * max_targets + 512");
     MHT_REQUIRE((cfg->n_scan + RING_EXTRA) * (((cfg->max_meas + 63) / 64) * 64) <= 65536,

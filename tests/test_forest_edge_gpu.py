@@ -167,6 +167,32 @@ def test_many_targets_multi_chunk_paths():
     trk.close()
 
 
+def test_four_thousand_measurements_per_scan():
+    """max_meas = 4096 (the bound of the r3 build was 2048): 300 targets in ~3 600 measurements per scan, window 3 -- 64 association
+    words per leaf, 28 672 measurement nodes in the clustering graph -- against the oracle, scan by scan."""
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=300, radius=9000.0, lambda_phi=1.4e-5, n_scans=4, seed=33)
+    assert 3000 < max(len(z) for z in sc["scans"]) <= 4096
+    trk = _mk(sc, N=3, useInitiator=False, maxTargets=512, maxMeasurements=4096)
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99)
+    for x0 in sc["x0"]:
+        o.initiate_target(sc["t0"], x0.copy(), orc.model_P0())
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        info = o.add_scan(float(t), z)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+        st = trk.lastScanStats
+        assert (st["L"], st["G"]) == (info["L"], info["G"]), k
+        assert np.array_equal(st["unused"], info["unused"]), k
+        want = o.selected()
+        sel = trk._sel[0]
+        assert sel["id"].tolist() == want["ID"].tolist(), k
+        assert sel["sel_meas"].tolist() == want["meas"].tolist(), k
+        assert len(o.clusters) == st["clusters"], k
+        b, ob = trk.leafBatch(), o.leaf_batch()
+        assert np.array_equal(b["ID"], ob["ID"]) and np.array_equal(b["x"], ob["x"]), k
+    trk.close()
+
+
 def test_report_after_births_raw_abi():
     """C-ABI call order step -> add_targets -> report (what a streaming host does): the report of the scan has the rows of the
     targets that took part in it, and the targets added in between show up, with their ids, in the next report."""
