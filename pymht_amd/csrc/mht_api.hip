@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 void forest_destroy(mht_ctx* ctx);
+int forest_sync_side(mht_ctx* ctx);      // mht_forest.hip
 }  // namespace mht
 
 extern "C" int mht_abi_version(void) { return MHT_ABI_VERSION; }
@@ -55,5 +56,5 @@ extern "C" int mht_destroy(mht_ctx* ctx) {
 extern "C" int mht_synchronize(mht_ctx* ctx) {
     MHT_REQUIRE(ctx, "mht_synchronize: null ctx");
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return MHT_OK;
+    return mht::forest_sync_side(ctx);      // (the streamed scans' initiator launches run on a stream of the forest's own)
 }

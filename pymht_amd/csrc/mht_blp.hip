@@ -2447,6 +2447,8 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     UfPersist* ps = reinterpret_cast<UfPersist*>(lds + a.uf_lds_off);
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
+    // (this launch is ordered behind the scan's grow launch: whoever reads this word -- the scan's initiator on its own queue -- knows that launch is complete)
+    if (a.begun && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.begun, (unsigned long long)a.pub_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const UfFetch fe = uf_prefetch(a);
     const int gx = (int)gridDim.x, pb = (int)blockIdx.x, bx = pb;
     blp_body<true>(a, lds, bx, gx, ps, &fe);

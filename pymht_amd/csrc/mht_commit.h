@@ -37,6 +37,9 @@ struct FCounts {          // device-side counters of the forest
     // the staging kernel's tag (stage_scan_kernel): the scan in the device buffer is complete when it equals FDyn::z_tag
     unsigned long long z_flag;
     unsigned long long role_tick, init_tick;      // tickets {scan, count}: FDyn::role_tick, initiator_side_kernel (first_come_ticket)
+    // the scan whose ILP launch has begun, i.e. whose grow launch is complete (blp_uf_kernel, first workgroup): what the scan's initiator
+    // waits for when it is launched on a queue of its own (initiator_side_kernel)
+    unsigned long long ilp_begun;
 };
 // Ticket among the few workgroups of a launch that may play a role: 0 for the first one to arrive in launch `tag`, 1, 2, ... for the
 // others.  The word carries the tag of the launch it was last used in, so nothing has to be reset (launches may skip the scheme).

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
 // 8.7 for the clustering alone).
 __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow, unsigned long long* done_flag = nullptr,
                                                                       const unsigned long long* z_flag = nullptr, unsigned long long z_tag = 0,
-                                                                      unsigned long long* tick = nullptr) {
+                                                                      unsigned long long* tick = nullptr, const unsigned long long* begun = nullptr) {
     if (tick) {      // launched with one workgroup per XCD: the first one to start (the XCD the ILP launch drained first) is the initiator
         __shared__ unsigned s_r;
         if (threadIdx.x == 0) s_r = first_come_ticket(tick, (unsigned)in.scan_no);
@@ -157,6 +157,11 @@ __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const Init
         if (s_r != 0u) return;
     }
     if (z_tag) { unsigned long long v; (void)spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v); }      // (the scan's staging, see stage_scan_kernel)
+    if (begun) {      // on a queue of its own: nothing orders this launch behind the scan's grow launch but the word the scan's ILP launch posts when it starts
+        unsigned long long v;
+        (void)spin_until(begun, [&](unsigned long long x) { return x >= (unsigned long long)(unsigned)in.scan_no; }, v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     if (!((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
     if (done_flag) {      // the next scan's grow launch may be running already: its admission waits for this word (FCounts::init_flag)
         __syncthreads();
@@ -279,6 +284,7 @@ struct Forest {
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
+    hipStream_t init_stream = nullptr; bool init_stream_tried = false; bool init_ev_lazy = false;      // the streamed scans' initiator launches (a queue of their own)
     hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
     hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0;      // consumer guard of the staging ring (step_host_impl)
@@ -418,6 +424,7 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
+    if (f->init_stream) (void)hipStreamDestroy(f->init_stream);
     if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
     if (f->init_ev) (void)hipEventDestroy(f->init_ev);
     if (f->evp) {
@@ -438,6 +445,19 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
     return MHT_OK;
 }
 
+int forest_sync_side(mht_ctx* ctx) {
+    Forest* f = ctx ? ctx->forest : nullptr;
+    if (f && f->init_stream && f->init_ev_pending) MHT_HIP_CHECK(hipStreamSynchronize(f->init_stream));
+    return MHT_OK;
+}
+// the initiator's launch on another stream has to be complete for what is queued on the ctx stream next
+static int wait_init_ev(mht_ctx* ctx, Forest* f) {
+    if (!f->init_ev_pending) return MHT_OK;
+    if (f->init_ev_lazy) { MHT_HIP_CHECK(hipEventRecord(f->init_ev, f->init_stream)); f->init_ev_lazy = false; }
+    MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0));
+    f->init_ev_pending = false;
+    return MHT_OK;
+}
 // runs the pending commit now (see Forest::commit_pending)
 static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan goes to the pinned block of its parity
     PublishArgs p;
@@ -447,7 +467,7 @@ static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan 
 static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
     if (!f->commit_pending) return MHT_OK;
     if (f->adm_pending) {      // commit + admission of the initiator's births, as one launch (what mht_forest_scan deferred)
-        if (f->init_ev_pending) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0)); f->init_ev_pending = false; }      // (the initiator ran on the side stream)
+        { const int rc = wait_init_ev(ctx, f); if (rc) return rc; }      // (the initiator ran on the side stream)
         PublishArgs pub = publish ? publish_args(f) : PublishArgs{};
         hipLaunchKernelGGL(post_scan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, f->pending, f->pending_dyn, InitArgs{}, f->adm, 1, pub, 0, AisUsedArgs{});
         MHT_HIP_CHECK(hipGetLastError());
@@ -1064,7 +1084,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.adm_wait = adm_ovl ? 1 : 0;
         const bool any_order = d.ovl && f->ovl_ok && (!adm || adm_ovl) && (!f->pub_deferred || adm_ovl) && !ais && !f->timing && (!f->debug || ovl_force);
         if (any_order) f->ovl_launches += 1;
-        if (adm && f->init_ev_pending) { MHT_STEP_HIP(hipStreamWaitEvent(st, f->init_ev, 0)); f->init_ev_pending = false; }
+        if (adm && f->init_ev_pending) {
+            if (adm_ovl && f->init_ev_lazy) { f->init_ev_pending = false; f->init_ev_lazy = false; }      // (the admission waits for the initiator's flag itself)
+            else MHT_STEP_CHECK(wait_init_ev(ctx, f));
+        }
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         f->adm_pending = false;
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
@@ -1123,7 +1146,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         if (grid > 1024) grid = 1024;
         { static int gcap = -1; if (gcap < 0) { const char* e = getenv("MHT_BLP_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && use_uf && grid > gcap) grid = gcap; }      // (development)
         if (use_uf) {
-            b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s;
+            b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s; b.begun = &f->cnt->ilp_begun;
             b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
         }
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
@@ -1136,10 +1159,25 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
+            // On the ctx stream's queue it would sit between this scan's ILP launch and the next scan's grow launch: a queue hands an XCD its
+            // next dispatch only when the previous one has drained there, so that grow launch would start behind the initiator (ILP end + 12 us
+            // instead of ILP start + 25 us, tools/api_timeline.py).  On a queue of its own it waits for the word the ILP launch posts at entry.
+            if (!f->init_stream_tried) {
+                f->init_stream_tried = true;
+                const char* e = getenv("MHT_INIT_QUEUE");
+                if (!(e && e[0] == '0') && f->z_tag_step && hipStreamCreateWithFlags(&f->init_stream, hipStreamNonBlocking) != hipSuccess) f->init_stream = nullptr;
+            }
+            if (f->init_stream && f->z_tag_step) {
+                hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->init_stream, ia,
+                                   static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag,
+                                   static_cast<const unsigned long long*>(&f->cnt->z_flag), f->z_tag_step, static_cast<unsigned long long*>(nullptr),
+                                   static_cast<const unsigned long long*>(&f->cnt->ilp_begun));
+                f->init_ev_pending = true; f->init_ev_lazy = true;      // (whoever needs the births without the flag: init_ev, recorded then)
+            } else
             hipExtLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, ia,
                                   static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag,
                                   static_cast<const unsigned long long*>(f->z_tag_step ? &f->cnt->z_flag : nullptr), f->z_tag_step,
-                                  static_cast<unsigned long long*>(nullptr));      // (no ticket: one workgroup)
+                                  static_cast<unsigned long long*>(nullptr), static_cast<const unsigned long long*>(nullptr));      // (no ticket: one workgroup)
             MHT_STEP_HIP(hipGetLastError());
             f->init_ran_scan = pl.s; f->init_flag_scan = pl.s;
         }
@@ -1476,7 +1514,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     if (defer_publish) { f->pub_args = pub; pub.dst = nullptr; }
     // streaming (mht_forest_scan) and nothing left to do here but the commit and the admission: both ride in the next scan's grow launch
     const bool ride = defer_publish && init_done && f->adm_fuse && f->commit_pending && !f->ais && au.nA == 0 && ia.nA == 0;
-    if (!ride && f->init_ev_pending) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0)); f->init_ev_pending = false; }
+    if (!ride) { const int rc = wait_init_ev(ctx, f); if (rc) return rc; }
     if (!ride) { const int rc = flush_z_wait(ctx, f); if (rc) return rc; }      // (post_scan_kernel may read the scan)
     if (ride) { f->adm = a; f->adm_pending = true; }
     else if (au.nA > 0 || ia.nA > 0)
@@ -1549,7 +1587,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
                            reinterpret_cast<float4*>(zd), n16, by_flag ? &f->cnt->z_flag : nullptr, f->z_tag_step);
         MHT_HIP_CHECK(hipGetLastError());
         MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run)
-        if (f->stage_stream && !by_flag) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
+        if (f->stage_stream && !by_flag) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); if (!f->init_ev_lazy) f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
         f->z_wait_slot = by_flag ? slot : -1;
         f->z_used[slot] = true;
         f->z_cur = zd;

@@ -262,6 +262,7 @@ struct BlpArgs {
     // publication for an overlapping grow launch of the next scan (null: off): per-target records, written for slots [0, pub_ub); the
     // counter the workgroups count themselves off on when they leave; the scan's tag
     unsigned long long* rec0; int pub_ub; unsigned long long* blp_done; unsigned pub_scan;
+    unsigned long long* begun;             // != null: the launch's first workgroup posts pub_scan here at entry (FCounts::ilp_begun)
     unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
     const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
                                                         // target died in the previous scan, the union-find was redone under epoch | 1
@@ -300,6 +301,7 @@ int launch_prune_similar(mht_ctx* ctx, const SimilarArgs& a, int n_targets_ub);
 struct AddArgs;      // mht_admit.h
 int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, const CommitArgs* commit, const PublishArgs* publish = nullptr,
                  const AddArgs* adm = nullptr, bool any_order = false);
+int forest_sync_side(mht_ctx* ctx);      // mht_forest.hip: waits for what the forest queued on streams of its own
 size_t fgrow_lds_bytes(int W, int pds, int AW);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave);
 size_t fgrow_wave_lds_bytes(int W, int pds, int AW);

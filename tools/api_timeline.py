@@ -27,3 +27,6 @@ for r in range(30):
     rows.append([(new[0] - old[0]) / 100.0, (old[1] - old[0]) / 100.0, (old[4] - old[1]) / 100.0, (new[0] - old[1]) / 100.0, (new[5] - new[0]) / 100.0])
 a = np.array(rows[1:])
 print('streamed API, median us: period (grow k-1 start -> grow k start) %.1f | grow k-1 start -> ILP k-1 start %.1f | ILP k-1 duration %.1f | ILP k-1 start -> grow k start %.1f | grow k: start -> last target workgroup end %.1f' % tuple(np.median(a, axis=0)))
+u = np.zeros(2, dtype=np.int32)
+trk._lib.mht_forest_debug_read(trk._ctx.handle, b"uf_ovl", u.ctypes.data_as(C.c_void_p), 8)
+print('scans %d: clustered in the grow launch %d, grow launches any-order %d' % (k, u[0], u[1]))
