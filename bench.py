@@ -328,6 +328,9 @@ def cpu_baseline(sc, n_warm, n_timed):
                           1e3 * st[:, 3].mean(), 1e3 * st[:, 4].mean()))
 
 
+T_START = time.time()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -554,13 +557,15 @@ def main():
     traffic, traffic_src = PMC_TRAFFIC_BYTES.get(args.config), \
         "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)"
     if args.pmc == "auto" and rank == 0 and world == 1:
+        if os.environ.get("MHT_STALL_DEBUG") == "1": print("[bench] counter passes start at %.1f s" % (time.time() - T_START), file=sys.stderr, flush=True)
         live, note = pmc_traffic_live(args.config)
         if live is not None:
             traffic, traffic_src = live, note
         else:
             traffic_src += "; live counter passes unavailable (%s)" % note
     for m_ in multi_all:
-        m_["x_single_sector"] = m_["scans_per_sec"] / ((1 if strong else world) * K / elapsed)
+        if "scans_per_sec" in m_:      # (a failed extra carries its error instead)
+            m_["x_single_sector"] = m_["scans_per_sec"] / ((1 if strong else world) * K / elapsed)
     ilp_acc = ilp_accounting(sc, births, local, W, min(K, 32)) if rank == 0 else None
     out = {
         "metric": "scans/sec at ~5k+ leaf hypotheses x 500 measurements (per-scan gate + cluster + ILP + N-scan prune)",

@@ -124,7 +124,7 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
         // wrote; every wavefront waits for the last of them, then drops what its CU may have cached
         unsigned long long v;
         const bool ok = spin_until(&a.cnt->blp_done, [&](unsigned long long x) { return x >= dyn.wait_done; }, v);
-        if (!ok && tid == 0) a.status->overflow = 2;
+        if (!ok && tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 6); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     // first round trip, everything at once: the scalars and the first chunk of per-target look-ups (index clamped by the

@@ -65,7 +65,7 @@ __device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t
                 if (void_scan) ok = false;      // (a void scan publishes nothing: the caller leaves)
                 else {
                     ok = spin_until(&a.rec0[tc], [&](unsigned long long x) { return (unsigned)(x >> TGT_REC_TAG) == tag; }, w);
-                    if (!ok && (threadIdx.x & 63) == 0) a.status->overflow = 2;      // (the wait timed out: the scan is void)
+                    if (!ok && (threadIdx.x & 63) == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 1); }      // (the wait timed out: the scan is void)
                 }
             }
         }
@@ -432,7 +432,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
     const float2* z2 = reinterpret_cast<const float2*>(d.z);
     if (d.z_tag) {        // (streamed path: the scan's staging kernel ran on another stream and nobody waited for it -- usually long done)
         unsigned long long v;
-        if (!spin_until(d.z_flag, [&](unsigned long long x) { return x >= d.z_tag; }, v) && tid == 0) a.status->overflow = 2;      // (tags only grow: a later scan may have been staged already)
+        if (!spin_until(d.z_flag, [&](unsigned long long x) { return x >= d.z_tag; }, v) && tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 2); }      // (tags only grow: a later scan may have been staged already)
     }
     if (ovl)              // (the wait for the target's record comes behind everything that does not depend on it)
         for (int j = tid; j < Mpad; j += FG_THREADS) {
@@ -862,7 +862,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
         const bool ok = spin_until(a.ni_flag, [&](unsigned long long x) { return (unsigned)x == (unsigned)d.c_scan; }, v);
         const bool moved = ok && ((v >> 32) & 1ull);      // some target died: slots and compacted indices differ
         const int pos = !ok ? -1 : (moved ? __hip_atomic_load(&a.new_index[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t);
-        if (pos < 0) { if (tid == 0) a.status->overflow = 2; return; }      // (timed out; a live target always has an index)
+        if (pos < 0) { if (tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 3); } return; }      // (timed out; a live target always has an index)
         if (tid == 0) { a.tchild[pos] = base; a.tcend[pos] = base + fin_tot; }
         if (moved && d.uf_epoch && wave == FG_THREADS / 64 - 1) {
             const unsigned alt = d.uf_epoch | 1u;      // (epochs are 2 x scan: the alternative one lies between this scan's and the next scan's, the words are updated by atomic max)
@@ -1377,6 +1377,18 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         int* sm = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
         if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
+        if (d.stage_src) {      // the scan, out of pinned host memory (FDyn::stage_src): written through, acknowledged, then the tag the target workgroups wait for
+            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(d.z));
+            for (int i = threadIdx.x; i < d.stage_n16; i += FG_THREADS) {
+                const float4 v = d.stage_src[i];
+                unsigned long long* q = reinterpret_cast<unsigned long long*>(dst + i);
+                __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned long long*>(d.z_flag), d.z_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
         int n_cand = ad.n;
         if (ad.n_dev && !d.adm_wait) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }
@@ -1393,7 +1405,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         if (d.adm_wait) {      // overlapping launch: the previous scan's initiator may still be running
             unsigned long long v;
             const bool ok = spin_until(&cm.cnt->init_flag, [&](unsigned long long x) { return x == (unsigned long long)(unsigned)d.c_scan; }, v);
-            if (!ok && threadIdx.x == 0) ap->status->overflow = 2;
+            if (!ok && threadIdx.x == 0) { ap->status->overflow = 2; atomicOr(&ap->status->pad[0], 1 << 4); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (ad.n_dev) { const int nd = __hip_atomic_load(ad.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); n_cand = nd < n_cand ? nd : n_cand; }
         }
@@ -1429,7 +1441,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 1;
         if (d.adm_wait && d.c_wait) {      // overlapping launch: the rows are the previous scan's ILP launch's, which may still be running
             unsigned long long v;
-            (void)spin_until(&cm.cnt->blp_done, [&](unsigned long long x) { return x >= d.c_wait; }, v);
+            if (!spin_until(&cm.cnt->blp_done, [&](unsigned long long x) { return x >= d.c_wait; }, v) && threadIdx.x == 0) atomicOr(&ap->status->pad[0], 1 << 5);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)

@@ -149,17 +149,20 @@ __global__ __launch_bounds__(1024) void post_scan_kernel(const CommitArgs cm, co
 // 8.7 for the clustering alone).
 __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const InitArgs in, const DevStatus* status, const int32_t* sticky_overflow, unsigned long long* done_flag = nullptr,
                                                                       const unsigned long long* z_flag = nullptr, unsigned long long z_tag = 0,
-                                                                      unsigned long long* tick = nullptr, const unsigned long long* begun = nullptr) {
+                                                                      unsigned long long* tick = nullptr, const unsigned long long* begun = nullptr, unsigned long long* dbg = nullptr) {
     if (tick) {      // launched with one workgroup per XCD: the first one to start (the XCD the ILP launch drained first) is the initiator
         __shared__ unsigned s_r;
         if (threadIdx.x == 0) s_r = first_come_ticket(tick, (unsigned)in.scan_no);
         __syncthreads();
         if (s_r != 0u) return;
     }
-    if (z_tag) { unsigned long long v; (void)spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v); }      // (the scan's staging, see stage_scan_kernel)
+    if (z_tag) {      // (the scan's staging, see stage_scan_kernel)
+        unsigned long long v;
+        if (!spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v) && threadIdx.x == 0 && dbg) { dbg[0] = 1; dbg[1] = v; dbg[2] = z_tag; dbg[3] = (unsigned)in.scan_no; }
+    }
     if (begun) {      // on a queue of its own: nothing orders this launch behind the scan's grow launch but the word the scan's ILP launch posts when it starts
         unsigned long long v;
-        (void)spin_until(begun, [&](unsigned long long x) { return x >= (unsigned long long)(unsigned)in.scan_no; }, v);
+        if (!spin_until(begun, [&](unsigned long long x) { return x >= (unsigned long long)(unsigned)in.scan_no; }, v) && threadIdx.x == 0 && dbg) { dbg[0] = 2; dbg[1] = v; dbg[2] = (unsigned)in.scan_no; dbg[3] = wall_clock64(); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     if (!((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
@@ -251,6 +254,7 @@ struct Forest {
     TTable tab[2];
     unsigned char* used_bytes[2];     // by scan parity: the commit of scan s may run while scan s+1 is marking its own bytes
     DevStatus* status2;               // [2] per-scan status words, by scan parity (same reason)
+    unsigned long long* init_dbg;     // [8] initiator_side_kernel: which wait gave up (development)
     unsigned* edges; int32_t* edge_count;
     int32_t *edge_t, *edge_m, *t_label, *t_cluster, *cl_ptr, *cl_members, *multi_list, *single_list, *cl_counts, *big_list;
     int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
@@ -259,6 +263,7 @@ struct Forest {
     unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
     // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
     // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
+    const float* z_stage_src = nullptr; int z_stage_n16 = 0, z_stage_slot = -1;      // the scan being stepped still sits in pinned host memory: the grow launch pulls it itself (FDyn::stage_src), or a staging kernel in front of it
     unsigned long long z_tag_step = 0;      // != 0: the scan being stepped was staged without an event wait on the ctx stream (FDyn::z_tag); z_wait_slot: its slot
     int z_wait_slot = -1;
     int init_flag_scan = 0;      // last scan whose initiator posts FCounts::init_flag
@@ -284,7 +289,10 @@ struct Forest {
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
-    hipStream_t init_stream = nullptr; bool init_stream_tried = false; bool init_ev_lazy = false;      // the streamed scans' initiator launches (a queue of their own)
+    // the streamed scans' initiator launches go onto the SIDE stream, each one behind the staging kernel of the scan after its own (it is
+    // queued by the next call, or by whoever needs its births first: launch_deferred_init): see forest_step_impl
+    bool init_ev_lazy = false; bool init_deferred = false; bool init_side_q = true;
+    InitArgs init_def_args; const DevStatus* init_def_status = nullptr; unsigned long long init_def_ztag = 0;
     hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
     hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0;      // consumer guard of the staging ring (step_host_impl)
@@ -380,6 +388,7 @@ struct Forest {
         alloc2[0] = ar.take<unsigned>((size_t)FG_REGIONS * 32); alloc2[1] = ar.take<unsigned>((size_t)FG_REGIONS * 32);
         used_bytes[0] = ar.take<unsigned char>(Mpad); used_bytes[1] = ar.take<unsigned char>(Mpad);
         status2 = ar.take<DevStatus>(2);
+        init_dbg = ar.take<unsigned long long>(8);
         edge_t = ar.take<int32_t>(Ecap); edge_m = ar.take<int32_t>(Ecap);
         edges = ar.take<unsigned>((size_t)EDGE_SEGS * SegCap);
         edge_count = ar.take<int32_t>(EDGE_SEGS + 4);
@@ -411,6 +420,7 @@ struct Forest {
 void forest_destroy(mht_ctx* ctx) {
     Forest* f = ctx->forest;
     if (!f) return;
+    if (f->stage_stream) (void)hipStreamSynchronize(f->stage_stream);
     if (f->arena.base) (void)hipFree(f->arena.base);
     for (int b = 0; b < 2; ++b) {
         if (f->report_host2[b]) (void)hipHostFree(f->report_host2[b]);
@@ -424,7 +434,6 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
-    if (f->init_stream) (void)hipStreamDestroy(f->init_stream);
     if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
     if (f->init_ev) (void)hipEventDestroy(f->init_ev);
     if (f->evp) {
@@ -445,15 +454,35 @@ static int stage_host_ensure(Forest* f, size_t bytes) {
     return MHT_OK;
 }
 
+// The initiator of a streamed scan k: one workgroup on the side stream, queued BEHIND the staging kernel of scan k + 1 (by the call for that
+// scan, or here by whoever needs its births first).  Why not on the ctx stream: a queue hands an XCD its next dispatch only when the previous
+// one has drained there, so the next scan's grow launch would start behind the initiator (ILP end + 12 us instead of ILP start + 25 us,
+// tools/api_timeline.py).  Why not in front of that staging kernel: the next grow launch's target workgroups -- resident on every CU -- wait
+// for the staged scan; a staging kernel queued behind the initiator would wait for it, and the initiator (1024 threads) for a CU.
+// It waits itself for the word its scan's ILP launch posts at entry (= its scan's grow launch is complete).
+static int launch_deferred_init(mht_ctx* ctx, Forest* f) {
+    if (!f->init_deferred) return MHT_OK;
+    f->init_deferred = false;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->stage_stream, f->init_def_args, f->init_def_status,
+                       static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag, static_cast<const unsigned long long*>(&f->cnt->z_flag), f->init_def_ztag,
+                       static_cast<unsigned long long*>(nullptr), static_cast<const unsigned long long*>(&f->cnt->ilp_begun), f->init_dbg);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
 int forest_sync_side(mht_ctx* ctx) {
     Forest* f = ctx ? ctx->forest : nullptr;
-    if (f && f->init_stream && f->init_ev_pending) MHT_HIP_CHECK(hipStreamSynchronize(f->init_stream));
+    if (f && f->stage_stream && f->init_ev_pending) {
+        { const int rc = launch_deferred_init(ctx, f); if (rc) return rc; }
+        MHT_HIP_CHECK(hipStreamSynchronize(f->stage_stream));
+    }
     return MHT_OK;
 }
 // the initiator's launch on another stream has to be complete for what is queued on the ctx stream next
 static int wait_init_ev(mht_ctx* ctx, Forest* f) {
     if (!f->init_ev_pending) return MHT_OK;
-    if (f->init_ev_lazy) { MHT_HIP_CHECK(hipEventRecord(f->init_ev, f->init_stream)); f->init_ev_lazy = false; }
+    { const int rc = launch_deferred_init(ctx, f); if (rc) return rc; }
+    if (f->init_ev_lazy) { MHT_HIP_CHECK(hipEventRecord(f->init_ev, f->stage_stream)); f->init_ev_lazy = false; }
     MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->init_ev, 0));
     f->init_ev_pending = false;
     return MHT_OK;
@@ -571,6 +600,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
+    { const char* e = getenv("MHT_INIT_QUEUE"); f->init_side_q = !(e && e[0] == '0'); }
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -1084,12 +1114,23 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.adm_wait = adm_ovl ? 1 : 0;
         const bool any_order = d.ovl && f->ovl_ok && (!adm || adm_ovl) && (!f->pub_deferred || adm_ovl) && !ais && !f->timing && (!f->debug || ovl_force);
         if (any_order) f->ovl_launches += 1;
+        if (f->z_stage_src) {
+            if (adm) { d.stage_src = reinterpret_cast<const float4*>(f->z_stage_src); d.stage_n16 = f->z_stage_n16; }
+            else {      // (no commit + admission workgroup in this launch -- first scan, or the commit was flushed: a staging kernel in front of it)
+                hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float4*>(f->z_stage_src), reinterpret_cast<float4*>(const_cast<float*>(z)),
+                                   f->z_stage_n16, static_cast<unsigned long long*>(nullptr), 0ull);
+                MHT_STEP_HIP(hipGetLastError());
+                d.z_tag = 0; f->z_tag_step = 0;
+            }
+        }
+        MHT_STEP_CHECK(launch_deferred_init(ctx, f));      // (the previous scan's initiator: behind this scan's staging kernel, in front of this launch)
         if (adm && f->init_ev_pending) {
             if (adm_ovl && f->init_ev_lazy) { f->init_ev_pending = false; f->init_ev_lazy = false; }      // (the admission waits for the initiator's flag itself)
             else MHT_STEP_CHECK(wait_init_ev(ctx, f));
         }
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         f->adm_pending = false;
+        if (f->z_stage_slot >= 0) MHT_STEP_HIP(hipEventRecord(f->z_ev[f->z_stage_slot], st));      // (the host may refill the pinned slot once this launch has run)
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
             MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st));
             f->rep_started[f->pub_slot] = true;
@@ -1159,25 +1200,14 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
-            // On the ctx stream's queue it would sit between this scan's ILP launch and the next scan's grow launch: a queue hands an XCD its
-            // next dispatch only when the previous one has drained there, so that grow launch would start behind the initiator (ILP end + 12 us
-            // instead of ILP start + 25 us, tools/api_timeline.py).  On a queue of its own it waits for the word the ILP launch posts at entry.
-            if (!f->init_stream_tried) {
-                f->init_stream_tried = true;
-                const char* e = getenv("MHT_INIT_QUEUE");
-                if (!(e && e[0] == '0') && f->z_tag_step && hipStreamCreateWithFlags(&f->init_stream, hipStreamNonBlocking) != hipSuccess) f->init_stream = nullptr;
-            }
-            if (f->init_stream && f->z_tag_step) {
-                hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->init_stream, ia,
-                                   static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag,
-                                   static_cast<const unsigned long long*>(&f->cnt->z_flag), f->z_tag_step, static_cast<unsigned long long*>(nullptr),
-                                   static_cast<const unsigned long long*>(&f->cnt->ilp_begun));
+            if (f->init_side_q && f->stage_stream && f->z_tag_step && !f->z_stage_src) {      // (launch_deferred_init)
+                f->init_deferred = true; f->init_def_args = ia; f->init_def_status = f->status2 + (pl.s & 1); f->init_def_ztag = f->z_tag_step;
                 f->init_ev_pending = true; f->init_ev_lazy = true;      // (whoever needs the births without the flag: init_ev, recorded then)
             } else
             hipExtLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, ia,
                                   static_cast<const DevStatus*>(f->status2 + (pl.s & 1)), static_cast<const int32_t*>(&f->cnt->overflow), &f->cnt->init_flag,
                                   static_cast<const unsigned long long*>(f->z_tag_step ? &f->cnt->z_flag : nullptr), f->z_tag_step,
-                                  static_cast<unsigned long long*>(nullptr), static_cast<const unsigned long long*>(nullptr));      // (no ticket: one workgroup)
+                                  static_cast<unsigned long long*>(nullptr), static_cast<const unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr));      // (no ticket: one workgroup)
             MHT_STEP_HIP(hipGetLastError());
             f->init_ran_scan = pl.s; f->init_flag_scan = pl.s;
         }
@@ -1569,6 +1599,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // reading a report can get that far ahead of the device.  Every Z_GUARD scans an event goes onto the ctx stream (behind everything
         // queued for the scans so far) and the side stream waits for the one recorded Z_GUARD scans earlier: that covers the tenants of the
         // next Z_GUARD slots (Z_RING = 2 x Z_GUARD), at one event operation per two scans.
+        const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed);
         if (f->stage_stream && f->z_count % Z_GUARD == 0) {
             const int gi = (int)((f->z_count / Z_GUARD) & 1);
             if (f->z_guard_ev[1 - gi]) MHT_HIP_CHECK(hipStreamWaitEvent(sst, f->z_guard_ev[1 - gi], 0));      // (recorded Z_GUARD scans ago: covers every scan up to then)
@@ -1581,8 +1612,17 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // with the previous scan's ILP launch.  The kernel posts a tag behind its (written-through) stores instead, and the scan's first
         // readers -- the grow launch's target workgroups, the initiator's launch -- wait for the tag (it is there long before: the host
         // runs ahead).  Any other reader of this scan on the ctx stream gets the event wait first (z_wait_slot, flush_z_wait).
-        const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed);
         f->z_tag_step = by_flag ? (unsigned long long)f->z_count : 0ull;
+        static int in_launch = -1; if (in_launch < 0) { const char* e = getenv("MHT_STAGE_IN_LAUNCH"); in_launch = (e && e[0] == '1') ? 1 : 0; }
+        if (by_flag && in_launch) {      // (development) pulled by the grow launch itself (forest_step_impl, FDyn::stage_src: ~5 us in front of every grow launch); z_ev[slot] is recorded behind that launch
+            f->z_stage_src = f->z_host_dev + (size_t)slot * 2 * f->Mpad; f->z_stage_n16 = n16; f->z_stage_slot = slot;
+            f->z_wait_slot = -1;
+            f->z_used[slot] = true;
+            f->z_cur = zd;
+            const int rc = forest_step_impl(ctx, zd, M, init, now);
+            f->z_tag_step = 0; f->z_stage_src = nullptr; f->z_stage_slot = -1;
+            return rc;
+        }
         hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
                            reinterpret_cast<float4*>(zd), n16, by_flag ? &f->cnt->z_flag : nullptr, f->z_tag_step);
         MHT_HIP_CHECK(hipGetLastError());
@@ -1909,6 +1949,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
         return MHT_OK;
     }
     if (!strcmp(name, "status2")) { src = f->status2; avail = 2 * sizeof(DevStatus); }
+    else if (!strcmp(name, "init_dbg")) { src = f->init_dbg; avail = 64; }
     else if (!strcmp(name, "cl_status")) { src = f->cl_status; avail = T * 4; }
     else if (!strcmp(name, "cl_iters")) { src = f->cl_iters; avail = T * 4; }
     else if (!strcmp(name, "cl_nodes")) { src = f->cl_nodes; avail = T * 4; }

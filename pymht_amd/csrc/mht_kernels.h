@@ -123,6 +123,11 @@ struct FDyn {
     // the scan was staged by a small kernel on the forest's side stream and the ctx stream did NOT wait for it (streamed path): whoever
     // reads the scan first waits until z_flag[0] == z_tag (stage_scan_kernel posts it behind its written-through stores); 0: nothing to wait for
     const unsigned long long* z_flag; unsigned long long z_tag;
+    // ... or by this launch itself (fgrow_adm_kernel, streamed path): its first workgroup pulls the scan out of pinned host memory before it
+    // waits for the previous scan's ILP launch, and posts the tag -- no launch on another queue stands between the host and the target
+    // workgroups that wait for the scan (a staging kernel queued behind the initiator's launch on a shared hardware queue would wait for
+    // that launch, which waits for a CU, which the waiting target workgroups hold).  null: staged elsewhere
+    const float4* stage_src; int stage_n16;
     // overlapping launch: which of its first eight workgroups (one per XCD) plays workgroup 0 -- the commit -- is decided by a ticket: the
     // first one to START (the XCD the previous scan's ILP launch drained first; the dispatcher's XCD rotation is not ours to know;
     // mht_commit.h: first_come_ticket).  null: block 0 as ever

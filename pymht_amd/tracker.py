@@ -13,6 +13,7 @@ There is no CPU fallback: without the HIP library or without a GPU the construct
 """
 import ctypes as C
 import logging
+import os
 import time
 
 import numpy as np
@@ -405,6 +406,16 @@ class Tracker():
         # scan k+1 (or by the first look at the results), so that interval is the host's idle time between scans -- a real-time host
         # feeding one scan per radarPeriod would see Total ~ radarPeriod and a spurious "Did not pass real time demand".
         self._toc_['Total'] = float(tic.get('_call', 0.0)) + self._toc_['Device'] + (time.perf_counter() - t_fold)
+        if self._toc_['Total'] > 0.1 and os.environ.get("MHT_STALL_DEBUG") == "1":      # (development: which part of a scan was slow)
+            log.critical("scan %d slow: call %.1f ms, device %.1f ms (process %.1f, cluster %.1f, optim %.1f), fold + wait %.1f ms", scanNumber,
+                         1e3 * float(tic.get('_call', 0.0)), 1e3 * self._toc_['Device'], 1e3 * self._toc_['Process'], 1e3 * self._toc_['Cluster'],
+                         1e3 * self._toc_['Optim'], 1e3 * (time.perf_counter() - t_fold))
+            dbg = np.zeros(8, dtype=np.uint64)
+            self._lib.mht_forest_debug_read(self._ctx.handle, b"init_dbg", dbg.ctypes.data_as(C.c_void_p), 64)
+            log.critical("init_dbg %s at t = %.1f s (process clock), pid %d", dbg.tolist(), time.process_time(), os.getpid())
+            st2 = np.zeros(16, dtype=np.uint64)
+            self._lib.mht_forest_debug_read(self._ctx.handle, b"status2", st2.ctypes.data_as(C.c_void_p), 128)
+            log.critical("status2 words (overflow | n_children << 32, n_dead | timeout bits << 32): %s %s", [hex(int(x)) for x in st2[:2]], [hex(int(x)) for x in st2[8:10]])
         if self._toc_['Total'] > self.radarPeriod:
             log.critical("Did not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
                 self._toc_['Total'] * 1000, self.radarPeriod * 1000))
