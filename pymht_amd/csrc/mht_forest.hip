@@ -28,6 +28,7 @@
 #include <new>
 #include <stdlib.h>
 
+static void hp_print();      // (development, see forest_step_impl)
 namespace mht {
 
 constexpr int MAXR = 16;
@@ -420,6 +421,7 @@ struct Forest {
 void forest_destroy(mht_ctx* ctx) {
     Forest* f = ctx->forest;
     if (!f) return;
+    ::hp_print();
     if (f->stage_stream) (void)hipStreamSynchronize(f->stage_stream);
     if (f->arena.base) (void)hipFree(f->arena.base);
     for (int b = 0; b < 2; ++b) {
@@ -1039,6 +1041,20 @@ static int flush_z_wait(mht_ctx* ctx, Forest* f) {
     if (f->z_wait_slot >= 0) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[f->z_wait_slot], 0)); f->z_wait_slot = -1; }
     return MHT_OK;
 }
+// development: where the host time of a streamed scan goes (MHT_HOST_PROF=1: per-section means on stderr when the forest is destroyed)
+struct HostProf { bool on = false; bool asked = false; double acc[16] = {}; long n = 0; double t_last = 0.0; };
+static HostProf g_hp;
+static inline double hp_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+static inline void hp_begin() { if (!g_hp.asked) { g_hp.asked = true; const char* e = getenv("MHT_HOST_PROF"); g_hp.on = e && e[0] == '1'; } if (g_hp.on) { g_hp.t_last = hp_now(); g_hp.n += 1; } }
+static inline void hp_mark(int i) { if (g_hp.on) { const double t = hp_now(); g_hp.acc[i] += t - g_hp.t_last; g_hp.t_last = t; } }
+static void hp_print() {
+    if (!g_hp.on || !g_hp.n) return;
+    static const char* nm[16] = {"checks", "stage (memcpy, kernel, events)", "begin_step + deferred init", "fill grow args", "grow launch", "events behind grow", "fill blp", "blp launch", "initiator args / defer", "end_step", "initiate_impl (ride)", "", "", "", "", ""};
+    fprintf(stderr, "[mht host prof] %ld scans, us per scan:", g_hp.n);
+    for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.2f |", nm[i], g_hp.acc[i] / g_hp.n);
+    fprintf(stderr, "\n");
+    g_hp = HostProf();
+}
 // init != null (mht_forest_scan): the scan's step 7 rides in the cluster launch (cluster_init_kernel)
 static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiator* init, double now) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
@@ -1092,6 +1108,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     bool grow_ovl = false;      // this scan's grow launch took the previous scan's results target by target (FDyn::ovl)
     // ---- 1: grow every leaf (tracker.py:207-209) ---------------------------------------------------------------
     {
+        hp_mark(2);
         FGrowArgs g;
         fill_fgrow(f, pl.s, pl.fused, g);
         FDyn d = {};
@@ -1123,12 +1140,14 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
                 d.z_tag = 0; f->z_tag_step = 0;
             }
         }
+        hp_mark(3);
         MHT_STEP_CHECK(launch_deferred_init(ctx, f));      // (the previous scan's initiator: behind this scan's staging kernel, in front of this launch)
         if (adm && f->init_ev_pending) {
             if (adm_ovl && f->init_ev_lazy) { f->init_ev_pending = false; f->init_ev_lazy = false; }      // (the admission waits for the initiator's flag itself)
             else MHT_STEP_CHECK(wait_init_ev(ctx, f));
         }
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
+        hp_mark(4);
         f->adm_pending = false;
         if (f->z_stage_slot >= 0) MHT_STEP_HIP(hipEventRecord(f->z_ev[f->z_stage_slot], st));      // (the host may refill the pinned slot once this launch has run)
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
@@ -1139,6 +1158,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         }
     }
     f->commit_pending = false;
+    hp_mark(5);
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
     InitArgs init_blp = {}; bool have_init_blp = false;
@@ -1190,7 +1210,9 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s; b.begun = &f->cnt->ilp_begun;
             b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
         }
+        hp_mark(6);
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
+        hp_mark(7);
         if (use_uf) { f->pub_scan = pl.s; f->blp_done_total += (unsigned long long)grid; }
         if (use_uf && init) {
             // step 7 (tracker.py:264-278) needs the scan and the used-measurement bytes of the grow launch, nothing of the ILPs: one
@@ -1212,9 +1234,11 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             f->init_ran_scan = pl.s; f->init_flag_scan = pl.s;
         }
     }
+    hp_mark(8);
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[3], st));
     // ---- 4: N-scan prune (tracker.py:256-259), target side: deferred ------------------------------------------------------
     forest_end_step(f, pl, M);
+    hp_mark(9);
     if (f->timing) { MHT_STEP_HIP(hipEventRecord(ev[4], st)); f->timed_steps += 1; }
     return MHT_OK;
 }
@@ -1632,6 +1656,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         f->z_used[slot] = true;
         f->z_cur = zd;
         (void)mark_done;
+        hp_mark(1);
         const int rc = forest_step_impl(ctx, zd, M, init, now);
         f->z_tag_step = 0;
         return rc;
@@ -1645,6 +1670,7 @@ extern "C" int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M
 // One radar scan of the drop-in API path in one call: steps 1-6 (mht_forest_step_host), step 7 (mht_forest_initiate, if an
 // initiator is given) and the start of the report's way to the host (mht_forest_report_begin).  Nothing here waits for the device.
 extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now) {
+    hp_begin();
     if (in) {      // (checked before the scan is stepped: nothing may fail between the initiator's run and the admission of its births)
         MHT_REQUIRE(NX == 4, "mht_forest_scan: the M-of-N initiator is the reference's 4-state one (m_of_n.py imports models/pv); this is the %d-state build", NX);
         MHT_REQUIRE(ctx && ctx->forest, "mht_forest_scan: no forest");
@@ -1656,10 +1682,12 @@ extern "C" int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_h
     // (messages waiting for the initiator: which of them a track took is known behind the scan's pruning only -- the initiator then runs in
     // post_scan_kernel, not next to the clustering)
     const bool ais_init = in && initiator_ais_pending(in) > 0;
+    hp_mark(0);
     int rc = step_host_impl(ctx, z_host, M, false, ais_init ? nullptr : in, now);
     if (rc) return rc;
     if (!in) return mht_forest_report_begin(ctx);
     rc = forest_initiate_impl(ctx, in, nullptr, M, now, true);
+    hp_mark(10);
     if (rc) return rc;
     // the report is complete in its device block; its push to the host rides in the next scan's grow launch (or in a launch of its
     // own as soon as somebody asks for it: report_expose)
