@@ -84,7 +84,7 @@ struct ReportHeader {     // device image of mht_scan_report up to the host poin
     int32_t t_process, t_cluster, t_optim, t_scan;      // device time of the stages in 10 ns ticks (mht_scan_report)
 };
 
-struct CommitDyn { int scan, M, W; unsigned long long wait_done; };      // wait_done != 0: the scan's ILP launch may still be running -- wait until FCounts::blp_done has reached it      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
+struct CommitDyn { int scan, M, W; unsigned long long wait_done; int keep_used = 0; };      // keep_used: the used-measurement bytes are cleared by the caller (the scan's initiator may still be reading them)      // wait_done != 0: the scan's ILP launch may still be running -- wait until FCounts::blp_done has reached it      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
 
 struct CommitArgs {
     TTable cur, nxt;
@@ -238,7 +238,7 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
     for (int base = 0; base < dyn.W * 64; base += PRUNE_THREADS) {
         const int jm = base + tid;
         const int u = (jm < dyn.M) ? a.used_bytes[jm] : 0;
-        if (u) a.used_bytes[jm] = 0;
+        if (u && !dyn.keep_used) a.used_bytes[jm] = 0;
         const unsigned long long bits = __ballot(u != 0);
         if ((tid & 63) == 0 && jm < dyn.W * 64) a.used_words[jm >> 6] = bits;
     }

@@ -1392,26 +1392,28 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
         int n_cand = ad.n;
         if (ad.n_dev && !d.adm_wait) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }
-        if (d.adm_wait) {
-            // the previous scan's initiator may still be running (a launch of its own on another stream).  It reads the used-measurement bytes
-            // of its scan, which the commit below packs and clears: wait for it HERE, not just in front of the admission (a host that does
-            // not run ahead of the device queues that launch right in front of this one)
-            unsigned long long v;
-            const bool ok = spin_until(&cm.cnt->init_flag, [&](unsigned long long x) { return x == (unsigned long long)(unsigned)d.c_scan; }, v);
-            if (!ok && threadIdx.x == 0) { ap->status->overflow = 2; atomicOr(&ap->status->pad[0], 1 << 4); }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (ad.n_dev) { const int nd = __hip_atomic_load(ad.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); n_cand = nd < n_cand ? nd : n_cand; }
-        }
 #ifdef MHT_ADM_STAMPS
         const unsigned long long ts0 = wall_clock64();
 #endif
-        const int born0 = commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull}, sm);      // targets alive behind the scan, -1: void scan
+        const int born0 = commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull, d.adm_wait}, sm);      // targets alive behind the scan, -1: void scan
         __threadfence_block();
         __syncthreads();
 #ifdef MHT_ADM_STAMPS
         const unsigned long long ts1 = wall_clock64();
 #endif
         int n_born = 0;
+        if (d.adm_wait) {
+            // overlapping launch: the previous scan's initiator (a launch of its own on another stream) may still be running.  It reads the
+            // used-measurement bytes of its scan: the commit above left them alone (CommitDyn::keep_used), they are cleared behind the wait.
+            // (Not in front of the commit: the target workgroups of this launch hold the CUs until the commit has posted their indices, and
+            // the initiator's 1024-thread workgroup needs a CU.)
+            unsigned long long v;
+            const bool ok = spin_until(&cm.cnt->init_flag, [&](unsigned long long x) { return x == (unsigned long long)(unsigned)d.c_scan; }, v);
+            if (!ok && threadIdx.x == 0) { ap->status->overflow = 2; atomicOr(&ap->status->pad[0], 1 << 4); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (ad.n_dev) { const int nd = __hip_atomic_load(ad.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); n_cand = nd < n_cand ? nd : n_cand; }
+            for (int jm = threadIdx.x; jm < d.c_M; jm += FG_THREADS) cm.used_bytes[jm] = 0;
+        }
         if (born0 >= 0 && n_cand > 0) {                      // (void scan: nothing is admitted; no candidates: the usual scan)
             add_targets_body<FG_THREADS>(ad, sm + 64);
             __threadfence_block();
