@@ -292,7 +292,7 @@ struct Forest {
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
     // the streamed scans' initiator launches go onto the SIDE stream, each one behind the staging kernel of the scan after its own (it is
     // queued by the next call, or by whoever needs its births first: launch_deferred_init): see forest_step_impl
-    bool init_ev_lazy = false; bool init_deferred = false; bool init_side_q = true;
+    bool init_ev_lazy = false; bool init_deferred = false; bool init_side_q = true; bool serial_prof = false;      // serial_prof: no launch may wait for a launch on another queue (the staging goes by event too)
     InitArgs init_def_args; const DevStatus* init_def_status = nullptr; unsigned long long init_def_ztag = 0;
     hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
@@ -603,6 +603,9 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
     { const char* e = getenv("MHT_INIT_QUEUE"); f->init_side_q = !(e && e[0] == '0'); }
+    // (rocprofv3 --pmc runs ONE kernel at a time across all queues, in the order the queues happen to be served: a launch that waits for a
+    // launch on another queue never sees it start.  Under counter collection the initiator stays on the ctx stream.)
+    { const char* e = getenv("ROCPROF_COUNTER_COLLECTION"); if (e && e[0] == '1') { f->init_side_q = false; f->serial_prof = true; } }
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -1623,7 +1626,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // reading a report can get that far ahead of the device.  Every Z_GUARD scans an event goes onto the ctx stream (behind everything
         // queued for the scans so far) and the side stream waits for the one recorded Z_GUARD scans earlier: that covers the tenants of the
         // next Z_GUARD slots (Z_RING = 2 x Z_GUARD), at one event operation per two scans.
-        const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed);
+        const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed) && !f->serial_prof;
         if (f->stage_stream && f->z_count % Z_GUARD == 0) {
             const int gi = (int)((f->z_count / Z_GUARD) & 1);
             if (f->z_guard_ev[1 - gi]) MHT_HIP_CHECK(hipStreamWaitEvent(sst, f->z_guard_ev[1 - gi], 0));      // (recorded Z_GUARD scans ago: covers every scan up to then)
