@@ -1291,6 +1291,14 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
 // tree -- in the kernel that completed the report the copy sat on the critical path of every scan (~10 us).  The host waits for an
 // event recorded behind this launch.
 constexpr int FG_PUB_WGS = 8;
+static_assert(PUB_DONE_WORDS == FG_PUB_WGS + 1, "one word per pushing workgroup of fgrow_adm_kernel");
+// every thread has stored its share of the report into pinned host memory: release it to the host, then one thread posts the workgroup's word
+__device__ __forceinline__ void pub_done(const PublishArgs& pub, int w) {
+    if (!pub.done) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub.done + w, pub.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void publish_part(const PublishArgs& p, int w, int n_wgs = FG_PUB_WGS) {
     const ReportHeader* h = reinterpret_cast<const ReportHeader*>(p.src);
     const int n_births = h->n_births, nT = h->n_targets;
@@ -1434,6 +1442,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
             const int nb_rep = (born0 >= 0 && n_cand > 0) ? reinterpret_cast<const ReportHeader*>(pub.src)->n_births : 0;
             const int head = (pub.birth_off + nb_rep * (int)sizeof(mht_birth_report) + 15) / 16;      // (head <= rec_off / 16)
             for (int i = threadIdx.x; i < head; i += FG_THREADS) d4[i] = s4[i];
+            pub_done(pub, 0);
         }
 #ifdef MHT_ADM_STAMPS
         __syncthreads();
@@ -1487,6 +1496,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
             }
             base += tot;
         }
+        pub_done(pub, bx);
         return;
     }
     const int bg = bx - (pub.dst ? FG_PUB_WGS : 0);      // index among the grow workgroups

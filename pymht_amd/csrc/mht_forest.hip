@@ -277,7 +277,8 @@ struct Forest {
     int32_t *t_status, *t_jdrop, *t_count, *t_firstsurv, *new_index, *near; double* t_score;
     int32_t *w_root_scan, *w_root_node; double* w_root_cnllr; uint8_t* w_root_f32;
     FCounts* cnt;
-    char* report_dev2[2]; char* report_host; size_t report_bytes, rec_off, used_off, birth_off;      // device report blocks by scan parity
+    bool rep_by_flag[2] = {false, false}; unsigned long long rep_tag[2] = {0, 0}; bool rep_flag_ok = true;      // the host block's report is complete when its done words carry rep_tag (no event)
+    char* report_dev2[2]; char* report_host; size_t report_bytes, rec_off, used_off, birth_off, done_off;      // device report blocks by scan parity
     // no copy engine on the scan's path: a small kernel pulls the scan out of the pinned ring, the kernel that completes the report
     // pushes it into pinned host memory (publish_report)
     char* report_host_dev[2] = {nullptr, nullptr}; float* z_host_dev = nullptr;      // device addresses of the pinned host blocks
@@ -296,7 +297,7 @@ struct Forest {
     InitArgs init_def_args; const DevStatus* init_def_status = nullptr; unsigned long long init_def_ztag = 0;
     hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
-    hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0;      // consumer guard of the staging ring (step_host_impl)
+    hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0; int z_guard_due = -1;      // consumer guard of the staging ring (step_host_impl)
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
     // host-side mirrors
@@ -525,6 +526,7 @@ static int flush_publish(mht_ctx* ctx, Forest* f) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1024), 0, ctx->stream, f->pub_args);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipEventRecord(f->rep_ev[f->pub_slot], ctx->stream));
+    f->rep_by_flag[f->pub_slot] = false;
     f->rep_started[f->pub_slot] = true;
     f->host_block_scan[f->pub_slot] = f->scan;
     f->pub_deferred = false;
@@ -603,6 +605,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
     { const char* e = getenv("MHT_INIT_QUEUE"); f->init_side_q = !(e && e[0] == '0'); }
+    { const char* e = getenv("MHT_REPORT_FLAG"); f->rep_flag_ok = !(e && e[0] == '0'); }
     // (rocprofv3 --pmc runs ONE kernel at a time across all queues, in the order the queues happen to be served: a launch that waits for a
     // launch on another queue never sees it start.  Under counter collection the initiator stays on the ctx stream.)
     { const char* e = getenv("ROCPROF_COUNTER_COLLECTION"); if (e && e[0] == '1') { f->init_side_q = false; f->serial_prof = true; } }
@@ -615,7 +618,8 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->used_off = sizeof(ReportHeader);
     f->birth_off = (f->used_off + (size_t)(f->Mpad / 64) * 8 + 15) & ~(size_t)15;
     f->rec_off = f->birth_off + (size_t)BIRTH_CAP * sizeof(mht_birth_report);
-    f->report_bytes = f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report);
+    f->done_off = (f->rec_off + (size_t)f->Tcap * sizeof(mht_target_report) + 63) & ~(size_t)63;      // (PublishArgs::done: the pushing workgroups' words, a cache line of their own)
+    f->report_bytes = f->done_off + 128;
     Arena probe;
     f->layout(probe);                     // first pass: size
     const size_t total = probe.off + 4096;
@@ -1041,7 +1045,11 @@ static bool forest_streams_uf(const Forest* f, const mht_initiator* init) {
 // a reader of the staged scan other than the grow launch / the initiator's launch is about to be queued on the ctx stream: the event wait
 // the step skipped (step_host_impl)
 static int flush_z_wait(mht_ctx* ctx, Forest* f) {
-    if (f->z_wait_slot >= 0) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[f->z_wait_slot], 0)); f->z_wait_slot = -1; }
+    if (f->z_wait_slot >= 0) {      // (a streamed scan records no event of its own: one behind everything the side stream holds now)
+        MHT_HIP_CHECK(hipEventRecord(f->z_ev[f->z_wait_slot], f->stage_stream));
+        MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[f->z_wait_slot], 0));
+        f->z_wait_slot = -1;
+    }
     return MHT_OK;
 }
 // development: where the host time of a streamed scan goes (MHT_HOST_PROF=1: per-section means on stderr when the forest is destroyed)
@@ -1149,12 +1157,19 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             if (adm_ovl && f->init_ev_lazy) { f->init_ev_pending = false; f->init_ev_lazy = false; }      // (the admission waits for the initiator's flag itself)
             else MHT_STEP_CHECK(wait_init_ev(ctx, f));
         }
+        const bool pub_flag = f->pub_deferred && adm && f->pub_args.dst && f->rep_flag_ok && !f->serial_prof;      // (fgrow_adm_kernel pushes it: the host polls the pushing workgroups' words)
+        if (pub_flag) {
+            f->pub_args.done = reinterpret_cast<unsigned long long*>(f->report_host_dev[f->pub_slot] + f->done_off);
+            f->pub_args.tag = (unsigned long long)(pl.s - 1) | (1ull << 40);
+        } else { f->pub_args.done = nullptr; f->pub_args.tag = 0; }
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         hp_mark(4);
         f->adm_pending = false;
         if (f->z_stage_slot >= 0) MHT_STEP_HIP(hipEventRecord(f->z_ev[f->z_stage_slot], st));      // (the host may refill the pinned slot once this launch has run)
+        if (f->z_guard_due >= 0) { MHT_STEP_HIP(hipEventRecord(f->z_guard_ev[f->z_guard_due], st)); f->z_guard_due = -1; }      // (step_host_impl: consumer guard of the staging ring)
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
-            MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st));
+            if (pub_flag) { f->rep_by_flag[f->pub_slot] = true; f->rep_tag[f->pub_slot] = f->pub_args.tag; }
+            else { MHT_STEP_HIP(hipEventRecord(f->rep_ev[f->pub_slot], st)); f->rep_by_flag[f->pub_slot] = false; }
             f->rep_started[f->pub_slot] = true;
             f->host_block_scan[f->pub_slot] = pl.s - 1;
             f->pub_deferred = false;
@@ -1607,7 +1622,7 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // a ring of pinned staging buffers: the host only waits if the copy that used this slot Z_RING scans ago is still in flight
         const int slot = f->z_slot;
         f->z_slot = (slot + 1) % Z_RING;
-        if (f->z_used[slot]) MHT_HIP_CHECK(hipEventSynchronize(f->z_ev[slot]));
+        if (f->z_used[slot]) MHT_HIP_CHECK(hipEventSynchronize(f->z_ev[slot]));      // (recorded for the scans whose staging the ctx stream waited for; the streamed ones are covered by the guard below)
         float* zh = f->z_host + (size_t)slot * 2 * f->Mpad;
         float* zd = f->z_dev + (size_t)slot * 2 * f->Mpad;
         memcpy(zh, z_host, (size_t)M * 2 * sizeof(float));
@@ -1627,11 +1642,19 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // queued for the scans so far) and the side stream waits for the one recorded Z_GUARD scans earlier: that covers the tenants of the
         // next Z_GUARD slots (Z_RING = 2 x Z_GUARD), at one event operation per two scans.
         const bool by_flag = f->stage_stream && init && forest_streams_uf(f, init) && !(f->ais && f->ais_armed) && !f->serial_prof;
+        // (streamed scans: the HOST waits for that event -- long signalled -- instead of the side stream: it then also knows that the pinned slots
+        // were pulled, and no per-scan event is needed; and the new event is recorded BEHIND this scan's grow launch (forest_step_impl,
+        // z_guard_due), not in front of it: a marker packet in front of an any-order grow launch would end its overlap with the previous
+        // scan's ILP launch on every fourth scan)
         if (f->stage_stream && f->z_count % Z_GUARD == 0) {
             const int gi = (int)((f->z_count / Z_GUARD) & 1);
-            if (f->z_guard_ev[1 - gi]) MHT_HIP_CHECK(hipStreamWaitEvent(sst, f->z_guard_ev[1 - gi], 0));      // (recorded Z_GUARD scans ago: covers every scan up to then)
+            if (f->z_guard_ev[1 - gi]) {
+                if (by_flag) MHT_HIP_CHECK(hipEventSynchronize(f->z_guard_ev[1 - gi]));
+                else MHT_HIP_CHECK(hipStreamWaitEvent(sst, f->z_guard_ev[1 - gi], 0));      // (recorded Z_GUARD scans ago: covers every scan up to then)
+            }
             if (!f->z_guard_ev[gi]) MHT_HIP_CHECK(hipEventCreateWithFlags(&f->z_guard_ev[gi], hipEventDisableTiming));
-            MHT_HIP_CHECK(hipEventRecord(f->z_guard_ev[gi], ctx->stream));
+            if (by_flag) f->z_guard_due = gi;
+            else MHT_HIP_CHECK(hipEventRecord(f->z_guard_ev[gi], ctx->stream));
         }
         f->z_count += 1;
         // Streamed scans (device initiator, clusters from the union-find): the ctx stream does not wait for the staging kernel through an
@@ -1653,10 +1676,10 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
                            reinterpret_cast<float4*>(zd), n16, by_flag ? &f->cnt->z_flag : nullptr, f->z_tag_step);
         MHT_HIP_CHECK(hipGetLastError());
-        MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run)
+        if (!by_flag) MHT_HIP_CHECK(hipEventRecord(f->z_ev[slot], sst));      // (the host may refill this slot once the kernel has run; streamed scans: the guard)
         if (f->stage_stream && !by_flag) { MHT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->z_ev[slot], 0)); if (!f->init_ev_lazy) f->init_ev_pending = false; }      // (behind the side stream's initiator launch as well)
         f->z_wait_slot = by_flag ? slot : -1;
-        f->z_used[slot] = true;
+        f->z_used[slot] = !by_flag;
         f->z_cur = zd;
         (void)mark_done;
         hp_mark(1);
@@ -1712,7 +1735,7 @@ extern "C" int mht_forest_report_begin(mht_ctx* ctx) {
     Forest* f = ctx->forest;
     MHT_REQUIRE(f->scan > 0, "mht_forest_report_begin: no scan processed yet");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    if (!f->report_pending) return MHT_OK;
+    if (!f->report_pending) return flush_publish(ctx, f);      // (streaming: the last scan's report waits for a ride in the next grow launch -- it goes now, in a launch of its own)
     { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     { const int rc = flush_commit(ctx, f, true); if (rc) return rc; }
     f->rep_slot = f->scan & 1;      // host block = device block = scan parity
@@ -1757,13 +1780,32 @@ extern "C" int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_repor
     return report_expose(ctx, f, f->rep_slot ^ which, out);
 }
 
+// the host block `slot` holds its report: the words of the workgroups that pushed it (PublishArgs::done), or the event behind the launch
+static int report_wait(Forest* f, int slot) {
+    if (!f->rep_by_flag[slot]) { MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot])); return MHT_OK; }
+    const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(f->report_host2[slot] + f->done_off);
+    const unsigned long long tag = f->rep_tag[slot];
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spins = 0;; ++spins) {
+        bool all = true;
+        for (int q = 0; q < PUB_DONE_WORDS; ++q) all = all && (w[q] == tag);
+        if (all) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 10.0) { set_error("mht_forest_report_get: the report of the host block did not arrive within 10 s"); f->dead = true; return MHT_E_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return MHT_OK;
+}
 static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out, bool lagged) {
     if (lagged) {
-        MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));      // (recorded behind the grow launch that pushed it: the scan before the last)
+        { const int rc = report_wait(f, slot); if (rc) return rc; }      // (pushed by the grow launch of the scan before the last)
     } else {
         if (f->pub_deferred && slot == f->pub_slot) { const int rc = flush_publish(ctx, f); if (rc) return rc; }
         if (f->rep_started[slot]) {
-            MHT_HIP_CHECK(hipEventSynchronize(f->rep_ev[slot]));
+            { const int rc = report_wait(f, slot); if (rc) return rc; }
             f->rep_started[slot] = false;
         }
         if (slot == f->rep_slot) f->rep_inflight = false;

@@ -148,7 +148,11 @@ struct FDyn {
 // ILP launch read the parents (a kernel boundary later) and each derives the cluster tables in LDS for itself (mht_blp.hip:
 // uf_prologue): no clustering kernel, no launch boundary, and three dependent look-ups fewer in front of every ILP.
 // The scan report on its way to pinned, device-mapped host memory (mht_forest.hip: publish_report): device block -> host block.
-struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; };      // dst = null: no host block (report fetched by memcpy)
+struct PublishArgs { const char* src; char* dst; int rec_off, birth_off; unsigned long long* done = nullptr; unsigned long long tag = 0; };      // dst = null: no host block (report fetched by memcpy)
+// done != null (fgrow_adm_kernel): every workgroup that pushes a part of the report into the pinned host block posts `tag` in its word of
+// done[0 .. PUB_DONE_WORDS) (in the same block) behind a system-scope release of what it wrote: the host polls the words instead of waiting
+// for an event behind the whole launch (the report is complete when the ILP launch is, not when the grow launch it rides in is)
+constexpr int PUB_DONE_WORDS = 9;      // workgroup 0 (head) + FG_PUB_WGS (rows)
 constexpr int GROUP_MAX = 32;      // sectors per batched launch
 struct FBatch { const FGrowArgs* ga[GROUP_MAX]; const CommitArgs* ca[GROUP_MAX]; FDyn d[GROUP_MAX]; };
 struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM) per sector

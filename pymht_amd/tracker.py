@@ -305,6 +305,8 @@ class Tracker():
 
     def _drain(self):
         """Fold the reports of the scans that are still in flight, oldest first (waits for them)."""
+        if len(self._pendq) > 1:      # (the last scan's report would only start its way to the host when it is asked for: start it now, fold the older one meanwhile)
+            _lib.check(self._lib.mht_forest_report_begin(self._ctx.handle))
         while self._pendq:
             prev = self._pendq.pop(0)
             self._finish_scan(*prev, which=len(self._pendq))
