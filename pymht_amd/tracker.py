@@ -192,6 +192,13 @@ class Tracker():
         n = len(targets)
         if n == 0:
             return []
+        if self._ais:
+            # the AIS-aided update steps every leaf from ITS time to the message's (tracker.py:448: node.time); the device keeps one time for
+            # all leaves (the last scan's, or the initial targets'): a target of another time would get a wrong first time step
+            lt = self._leaf_time if self._leaf_time is not None else float(targets[0].time)
+            if any(float(t.time) != lt for t in targets):
+                raise ValueError("aisAided tracker: an initiated target's time differs from the time of the current leaves (%r): "
+                                 "the AIS time steps are built from one leaf time" % lt)
         x0 = np.ascontiguousarray(np.array([np.asarray(t.x_0, dtype=np.float64) for t in targets]).reshape(n, self.nx))
         P0 = np.ascontiguousarray(np.array([np.asarray(t.P_0, dtype=np.float32) for t in targets]).reshape(n, self.nx * self.nx))
         f32 = np.array([np.asarray(t.x_0).dtype == np.float32 for t in targets])
