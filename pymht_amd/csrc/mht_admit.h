@@ -6,7 +6,7 @@
 
 namespace mht {
 
-constexpr int ADM_LDS_INTS = 2 + 2048;      // LDS scratch of add_targets_body
+constexpr int ADM_LDS_INTS = 2 + 2048 + 2048;      // LDS scratch of add_targets_body: two scalars, [2048] admitted candidates / leaf offsets of a chunk of targets, [2048] their first nodes
 
 // Tracker.initiateTarget (tracker.py:147-160) for a batch of candidates, sequentially like the reference
 struct AddArgs {
@@ -39,18 +39,42 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
     for (int q = tid; q < an; q += NT) a.near[q] = 0;
     __syncthreads();
     if (a.check) {
-        for (int i = tid; i < L0; i += NT) {
-            // leaf i -> node: linear scan over targets is avoided by walking the ranges: (first, leaf_off) lookup
-            int lo = 0, hi = nT0;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
-            const int nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
-            if (a.layer.flags[nd] & F_DEAD) continue;      // (taken out of the tree by similar-state pruning)
-            const double lx = a.layer.x[nd], ly = a.layer.x[(size_t)a.layer.cap + nd];
-            for (int q = 0; q < an; ++q) {
-                const double dx = lx - a.x0[q * NX], dy = ly - a.x0[q * NX + 1];
-                if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
+        // every live leaf against every candidate.  The leaf -> node map (target ranges: leaf_off, first) goes through LDS, a chunk of
+        // 2047 targets at a time, and every thread has four leaves in flight: a binary search through global memory per leaf (nine
+        // dependent look-ups, then the node's) made this sweep 60 us at the headline size (13 k leaves) -- on every scan with a birth
+        int* s_off = sm + 2;            // [2048] leaf_off of the chunk (+ its end)
+        int* s_first = sm + 2 + 2048;   // [2047] first node of the chunk's targets
+        constexpr int CH = 2047, UN = 4;
+        for (int c0 = 0; c0 < nT0; c0 += CH) {
+            const int cn = nT0 - c0 < CH ? nT0 - c0 : CH;
+            __syncthreads();
+            for (int i = tid; i <= cn; i += NT) { s_off[i] = a.tab.leaf_off[c0 + i]; if (i < cn) s_first[i] = a.tab.first[c0 + i]; }
+            __syncthreads();
+            const int lbeg = s_off[0], lend = s_off[cn];
+            for (int i0 = lbeg + tid; i0 < lend; i0 += UN * NT) {
+                int nd[UN]; bool ok[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int i = i0 + u * NT;
+                    ok[u] = i < lend;
+                    int lo = 0, hi = cn;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+                    nd[u] = ok[u] ? s_first[lo] + (i - s_off[lo]) : 0;
+                }
+                uint8_t fl[UN]; double lx[UN], ly[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) { fl[u] = a.layer.flags[nd[u]]; lx[u] = a.layer.x[nd[u]]; ly[u] = a.layer.x[(size_t)a.layer.cap + nd[u]]; }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (!ok[u] || (fl[u] & F_DEAD)) continue;      // (F_DEAD: taken out of the tree by similar-state pruning)
+                    for (int q = 0; q < an; ++q) {
+                        const double dx = lx[u] - a.x0[q * NX], dy = ly[u] - a.x0[q * NX + 1];
+                        if (sqrt(dx * dx + dy * dy) < a.thr) a.near[q] = 1;
+                    }
+                }
             }
         }
+        (void)L0;
     }
     __threadfence_block();
     __syncthreads();
@@ -60,10 +84,15 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
     int& s_near = sm[0];
     int& s_nadm = sm[1];
     int* s_adm = sm + 2;                        // [2048] candidate indices admitted so far (chunked if more)
+    int* s_nearv = sm + 2 + 2048;               // [2048] the candidates' flags of the sweep above (one look-up for all, not one per candidate)
     if (tid == 0) s_nadm = 0;
+    for (int q = tid; q < an && q < 2048; q += NT) s_nearv[q] = a.near[q];
+    // the forest's counters live in thread 0's registers during the loop (they were a dozen dependent global look-ups per candidate)
+    int c_nT = nT0, c_roots = r0, c_L = L0, c_id = 0;
+    if (tid == 0) c_id = a.cnt->id_counter;
     __syncthreads();
     for (int q = 0; q < an; ++q) {
-        if (tid == 0) s_near = a.near[q];
+        if (tid == 0) s_near = q < 2048 ? s_nearv[q] : a.near[q];
         __syncthreads();
         if (a.check && !s_near) {
             const double qx = a.x0[q * NX], qy = a.x0[q * NX + 1];
@@ -79,39 +108,39 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
         __syncthreads();
         if (tid == 0) {   // (admission is sequential like the reference's loop)
             const int near = s_near;
-            const int ok = !near && a.cnt->nT < a.Tcap && a.cnt->n_roots < a.Tcap;
+            const int ok = !near && c_nT < a.Tcap && c_roots < a.Tcap;
             if (!near && !ok) a.cnt->overflow = 1;
+            double xq[NX];
+            for (int k = 0; k < NX; ++k) xq[k] = a.x0[q * NX + k];
+            const int mq = a.meas[q];
             if (ok) {
                 // roots born into a layer live at its end (node root_base + r): the children of a scan are spread over the regions
                 // of the node index space below it (fgrow_kernel)
-                const int r = a.cnt->n_roots, idx = a.root_base + r, t = a.cnt->nT, L = a.cnt->L;
+                const int r = c_roots, idx = a.root_base + r, t = c_nT, L = c_L;
                 const size_t cap = a.layer.cap;
-                for (int k = 0; k < NX; ++k) a.layer.x[k * cap + idx] = a.x0[q * NX + k];
+                const uint8_t fq = a.flags[q];
+                for (int k = 0; k < NX; ++k) a.layer.x[k * cap + idx] = xq[k];
                 a.layer.cnllr[idx] = 0.0;          // cumulativeNLLR = 0 (pyTarget.py:32)
                 a.layer.pd[idx] = a.pd[q];
                 a.layer.parent[idx] = -1;
-                a.layer.meas[idx] = a.meas[q];
+                a.layer.meas[idx] = mq;
                 a.layer.cov[idx] = -1;                     // (its key is made below, once the admissions are known)
-                a.layer.flags[idx] = a.flags[q];
+                a.layer.flags[idx] = fq;
                 if (a.mmsi) { a.mmsi[idx] = 0; a.hmmsi[idx] = 0; }
                 for (int d = 0; d < a.PD; ++d) { a.path[(size_t)idx * a.PD + d] = -1; a.apath[(size_t)idx * a.PD + d] = -1; }      // (PD = record length here)
-                a.tab.id[t] = a.cnt->id_counter;
+                a.tab.id[t] = c_id;
                 a.tab.window[t] = a.Nwin;
                 a.tab.depth[t] = 0;
                 a.tab.shift[t] = 0;
                 a.tab.root_scan[t] = a.scan;
                 a.tab.root_node[t] = idx;
                 a.tab.root_cnllr[t] = 0.0;
-                a.tab.root_f32[t] = (a.flags[q] & F_SCORE_F32) ? 1 : 0;
+                a.tab.root_f32[t] = (fq & F_SCORE_F32) ? 1 : 0;
                 a.tab.first[t] = idx;
                 a.tab.leaf_off[t] = L;
                 a.tab.leaf_off[t + 1] = L + 1;
-                if (a.ids) a.ids[q] = a.cnt->id_counter;
-                a.cnt->id_counter += 1;
-                a.cnt->n_roots = r + 1;
-                a.cnt->nT = t + 1;
-                a.cnt->nTv[a.vidx] = t + 1;
-                a.cnt->L = L + 1;
+                if (a.ids) a.ids[q] = c_id;
+                c_id += 1; c_roots = r + 1; c_nT = t + 1; c_L = L + 1;
                 s_adm[s_nadm & 2047] = q;
                 s_nadm += 1;
             } else if (a.ids) {
@@ -120,14 +149,15 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
             if (a.accepted) a.accepted[q] = (uint8_t)ok;
             if (a.births) {      // the candidate and its fate, for the host mirror (mht_scan_report::births)
                 mht_birth_report& b = a.births[q];
-                b.id = ok ? a.cnt->id_counter - 1 : -1;
-                b.meas = a.meas[q];
-                for (int k = 0; k < NX; ++k) b.x0[k] = a.x0[q * NX + k];
+                b.id = ok ? c_id - 1 : -1;
+                b.meas = mq;
+                for (int k = 0; k < NX; ++k) b.x0[k] = xq[k];
                 for (int e = 0; e < NP; ++e) b.P0[e] = a.P0[q * NP + e];
             }
         }
         __syncthreads();
     }
+    if (tid == 0) { a.cnt->id_counter = c_id; a.cnt->n_roots = c_roots; a.cnt->nT = c_nT; a.cnt->nTv[a.vidx] = c_nT; a.cnt->L = c_L; }
     if (a.hdr && tid == 0) a.hdr->n_births = an;
     // covariance and gains of the admitted roots (what fgrow_kernel's chain workgroups resolve for every other node one scan
     // ahead): the root's covariance by value, and a key of its own -- a pseudo parent id whose miss child is that value
