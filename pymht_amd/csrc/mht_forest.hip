@@ -730,7 +730,15 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     MHT_REQUIRE(n >= 0 && (n == 0 || (x0 && P0 && flags && pd && meas)), "mht_forest_add_targets_dev: null input");
     if (n == 0) return MHT_OK;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    { const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    // Candidates in device memory whose fate the caller does not ask for, behind a scan whose commit still waits for its ride in the next
+    // grow launch: the admission CAN ride along (fgrow_adm_kernel: workgroup 0 commits, then admits; the newborn targets are grown by extra
+    // workgroups of that launch) -- what the streamed path does with the initiator's births.  Measured on the headline replay and left
+    // off (MHT_ADD_RIDE=1): two launches less, but 256 threads instead of 1 024 for the neighbour sweep and the newborn targets' grow
+    // behind it inside the launch -- scans with a birth got longer (fgrow_adm_kernel p95 99 us), 19.1 k -> 18.5 k scans/s over 20 scans.
+    static int add_ride = -1; if (add_ride < 0) { const char* e = getenv("MHT_ADD_RIDE"); add_ride = (e && e[0] == '1') ? 1 : 0; }
+    const bool ride = add_ride && !ids && !accepted && n <= 256 && f->commit_pending && !f->adm_pending && f->adm_fuse && !f->ais && !f->timing && !f->pub_deferred &&
+                      f->uf_ok && !(f->prune_thr > 0.f);
+    if (!ride) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     AddArgs a = {};
     a.n = n; a.x0 = x0; a.pd = pd; a.P0 = P0; a.meas = meas; a.flags = flags; a.ids = ids; a.accepted = accepted;
     a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
@@ -743,6 +751,8 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
     if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
+    if (ride) { f->adm = a; f->adm_pending = true; }
+    else
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
     for (int c0 = 0; c0 < n; c0 += 2048) {
