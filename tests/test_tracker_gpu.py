@@ -318,3 +318,40 @@ def test_streamed_scans_equal_scans_looked_at_one_by_one(T, seed):
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
     assert ca == cb
+
+
+def test_streamed_headline_scans_with_many_streams_alive():
+    """A process that has made more streams than the device has hardware queues (PyTorch keeps a pool of 32 per priority once one is
+    asked for): the forest's side stream then SHARES a hardware queue with other streams.  The streamed path must not depend on which
+    -- with the initiator's launch queued in front of the next scan's staging kernel it deadlocked until the device-side spin timeouts
+    (2 s per scan) once every CU was held by target workgroups waiting for the staged scan (the headline size fills the machine).
+    Several trackers one after the other, each with streams of its own: every scan well inside a millisecond, same results each time."""
+    import time
+    import torch
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    keep = [torch.cuda.Stream(device=0, priority=p) for p in (0, -1) for _ in range(4)]      # (materialises both pools)
+    sc = make_config("cfg3", seed=5446, n_scans=48, confine=True)
+    lists = [MeasurementList(float(t), z) for z, t in zip(sc["scans"], sc["times"])]
+    finals = []
+    for rep in range(4):
+        trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=sc["N"], eta2=5.99, maxTargets=2048, maxNodes=1 << 19,
+                      maxMeasurements=1024)
+        trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+        trk.addMeasurementList(lists[0])
+        trk.synchronize()
+        t0 = time.perf_counter()
+        for sl in lists[1:]:
+            trk.addMeasurementList(sl)
+        trk.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 0.5, "47 streamed scans took %.3f s: a device-side wait timed out" % dt
+        finals.append(tracker_selected(trk))
+        trk.close()
+    for f in finals[1:]:
+        for k in finals[0]:
+            assert np.array_equal(f[k], finals[0][k]), k
+    del keep
