@@ -305,7 +305,8 @@ int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0, const floa
 int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double* x0, const float* P0, const uint8_t* flags,
                                const double* pd, const int32_t* meas, int32_t check_neighbours, uint8_t* accepted,
                                int32_t* ids);
-/* One scan, asynchronous: z dev (M,2) float32.  Three launches (grow, cluster, ILP + prune decisions); the target-side commit
+/* One scan, asynchronous: z dev (M,2) float32.  Two launches (grow with the clustering union-find, ILP + prune decisions; three with the
+ * clustering kernel on similar-state pruning scans); the target-side commit
  * of the scan (compacted target table, next leaf ranges, the report) is deferred: it rides in the next step's first launch,
  * or runs as a launch of its own as soon as the report, new targets or an export are asked for.  Either order leaves the same
  * forest (tests/test_forest_edge_gpu.py).  */
@@ -314,7 +315,8 @@ int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M);
 int mht_forest_step_host(mht_ctx* ctx, const float* z_host, int32_t M);
 /* Start the transfer of the last step's report into pinned host memory (runs the scan's commit first if it is still pending) and
  * return at once.  A host that issues the next step before it calls mht_forest_report overlaps its own work with the device's;
- * two transfers can be in flight. */
+ * two transfers can be in flight.  Behind mht_forest_scan (whose report waits for a ride in the NEXT scan's grow launch) it sends
+ * that report on its way now, in a launch of its own: what a host does that has no further scan to queue. */
 int mht_forest_report_begin(mht_ctx* ctx);
 /* Wait for the last step (or for the transfer mht_forest_report_begin started) and expose its report (pointers stay valid until
  * the next but one mht_forest_report_begin on this ctx). */
@@ -415,7 +417,11 @@ int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32
 int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel);
 
 /* One radar scan of Tracker.addMeasurementList (tracker.py:162-307) in one call, nothing waits for the device: steps 1-6
- * (mht_forest_step_host), step 7 (mht_forest_initiate, skipped when `in` is NULL), mht_forest_report_begin. */
+ * (mht_forest_step_host), step 7 (mht_forest_initiate, skipped when `in` is NULL), mht_forest_report_begin.
+ * With an initiator the scans are STREAMED: the scan's commit, the admission of what its initiator gave birth to and the report's push ride
+ * in the next scan's grow launch (which starts while this scan's ILP launch is still running); the initiator is a one-workgroup launch on a
+ * side stream of the forest's; the report is complete in its pinned host block when the words the pushing workgroups post there say so
+ * (mht_forest_report_get waits for them, not for an event).  mht_synchronize also waits for the side stream. */
 int mht_forest_scan(mht_ctx* ctx, mht_initiator* in, const float* z_host, int32_t M, double now);
 
 /* ---- a group of independent sectors on one device (BASELINE config 4: four sensor sectors = four independent Tracker
