@@ -40,11 +40,11 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
     __syncthreads();
     if (a.check) {
         // every live leaf against every candidate.  The leaf -> node map (target ranges: leaf_off, first) goes through LDS, a chunk of
-        // 2047 targets at a time, and every thread has four leaves in flight: a binary search through global memory per leaf (nine
+        // 2047 targets at a time, and every thread has eight leaves in flight: a binary search through global memory per leaf (nine
         // dependent look-ups, then the node's) made this sweep 60 us at the headline size (13 k leaves) -- on every scan with a birth
         int* s_off = sm + 2;            // [2048] leaf_off of the chunk (+ its end)
         int* s_first = sm + 2 + 2048;   // [2047] first node of the chunk's targets
-        constexpr int CH = 2047, UN = 4;
+        constexpr int CH = 2047, UN = 8;
         for (int c0 = 0; c0 < nT0; c0 += CH) {
             const int cn = nT0 - c0 < CH ? nT0 - c0 : CH;
             __syncthreads();

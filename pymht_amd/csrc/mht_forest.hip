@@ -738,7 +738,10 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     static int add_ride = -1; if (add_ride < 0) { const char* e = getenv("MHT_ADD_RIDE"); add_ride = (e && e[0] == '1') ? 1 : 0; }
     const bool ride = add_ride && !ids && !accepted && n <= 256 && f->commit_pending && !f->adm_pending && f->adm_fuse && !f->ais && !f->timing && !f->pub_deferred &&
                       f->uf_ok && !(f->prune_thr > 0.f);
-    if (!ride) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    // (not riding, but the scan's commit is still pending and the batch fits one launch: commit and admission as ONE launch -- post_scan_kernel,
+    // what flush_commit runs for a pending admission -- instead of a commit launch and an admission launch)
+    const bool fuse = !ride && n <= 2048 && f->commit_pending && !f->adm_pending && !f->ais && !f->pub_deferred;
+    if (!ride && !fuse) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     AddArgs a = {};
     a.n = n; a.x0 = x0; a.pd = pd; a.P0 = P0; a.meas = meas; a.flags = flags; a.ids = ids; a.accepted = accepted;
     a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
@@ -752,6 +755,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
     if (ride) { f->adm = a; f->adm_pending = true; }
+    else if (fuse) { f->adm = a; f->adm_pending = true; const int rc = flush_commit(ctx, f); if (rc) return rc; }
     else
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
