@@ -63,6 +63,56 @@ def test_gate_x_constant_turn_matches_reference_vectors(gpu_ctx, gold_dir):
     assert n_exact >= n_all - 2, (n_exact, n_all)
 
 
+def test_gate_x_constant_turn_at_config_5_size(gpu_ctx):
+    """The constant-turn seam at the size BASELINE config 5 names (2 000 targets' worth of leaves: 100 000 x 2 000 measurements, six
+    states, every leaf its own transition and covariance chain), checked through what does not depend on the size: a random sample of
+    300 leaves against the oracle's per-leaf restatement (same gating sets; values as in the known-answer test), and for EVERY gated pair
+    of the call the gate's own inequality recomputed in float64 from the returned S^-1 and predicted measurement; the CSR is ordered;
+    no pair of a sampled leaf is missing."""
+    from pymht_amd.device import process_leaf_nodes_x
+    from pymht_amd.models import ct
+    rng = np.random.default_rng(4242)
+    n, M, T, eta2, lam = 100_000, 2000, 2.5, 5.99, 2e-5
+    x = np.concatenate([rng.uniform(-20000, 20000, size=(n, 2)), rng.normal(0, 8, size=(n, 2)), rng.normal(0, 0.05, size=(n, 1)), rng.normal(0, 1e-3, size=(n, 1))], axis=1)
+    x[rng.uniform(size=n) < 0.15, 4] = 0.0
+    P = np.repeat(ct.P0[None].astype(np.float32), n, axis=0) * rng.uniform(0.5, 2.0, size=(n, 1, 1)).astype(np.float32)
+    P = (P + P.transpose(0, 2, 1)) / np.float32(2)
+    z = rng.uniform(-20000, 20000, size=(M, 2)).astype(np.float32)
+    near = rng.integers(0, n, size=M // 2)      # half of the measurements sit next to a predicted position
+    xb = np.array([ct.Phi(T, x[i, 4]).astype(np.float64).dot(x[i]) for i in near])
+    z[: M // 2] = (xb[:, :2] + rng.normal(0, 6.0, size=(M // 2, 2))).astype(np.float32)
+    Q, Cm, R = ct.Q(T), ct.C_RADAR, ct.R_RADAR()
+    pd = np.full(n, 0.9)
+    r = process_leaf_nodes_x(gpu_ctx, ct.Phi(T, 0.0), Q, Cm, R, eta2, lam, x, P, pd, flags_for(x), z, ct_period=T)
+    rp, ci = r["row_ptr"], r["col_idx"]
+    assert rp[0] == 0 and np.all(np.diff(rp) >= 0) and rp[-1] == len(ci) > M // 4
+    leaf_of = np.repeat(np.arange(n), np.diff(rp))
+    assert np.all((np.diff(ci) > 0) | (np.diff(leaf_of) > 0))                      # measurements ascending inside a leaf
+    # every gated pair passes the gate it was admitted by (float64 recomputation; a hair of slack for the float32 -> float64 path)
+    zh = r["x_bar"][:, :2]                                                          # (C picks the position)
+    zt = z.astype(np.float64)[ci] - zh[leaf_of]
+    Si = r["S_inv"].astype(np.float64)[leaf_of]
+    nis = np.einsum("pi,pij,pj->p", zt, Si, zt)
+    assert np.all(nis <= eta2 * (1 + 1e-5)), float(nis.max())
+    # a sample of leaves against the oracle's per-leaf restatement (kalman.predict_single + precalc on a batch of one)
+    pick = np.sort(np.concatenate([rng.choice(n, 250, replace=False), near[:50]]))
+    o = orc.process_leaves_ct(ct.Phi, T, Q, Cm, R, eta2, lam, x[pick], P[pick], [0.9] * len(pick), z)
+    n_exact = 0
+    for j, i in enumerate(pick):
+        got = ci[rp[i]:rp[i + 1]]
+        assert np.array_equal(got, np.asarray(o["idx"][j], dtype=np.int64)), (i, got, o["idx"][j])
+        exact = all(np.array_equal(r[name][i], np.asarray(o[name][j]).astype(r[name].dtype)) for name in ("x_bar", "P_bar", "P_hat", "S", "S_inv", "K"))
+        n_exact += int(exact)
+        assert np.allclose(r["x_bar"][i], o["x_bar"][j], rtol=1e-6, atol=1e-9)
+        for name in ("P_bar", "P_hat", "S", "S_inv", "K"):
+            assert np.allclose(r[name][i], o[name][j], rtol=1e-5, atol=1e-7), (i, name)
+        if len(got):
+            assert np.allclose(r["x_hat"][rp[i]:rp[i + 1]], o["x_hat"][j], rtol=1e-6, atol=1e-6)
+            assert np.allclose(r["nllr"][rp[i]:rp[i + 1]], o["nllr"][j], rtol=0, atol=1e-5)
+    assert n_exact >= len(pick) * 0.8, (n_exact, len(pick))                        # (bit for bit wherever sin / cos round to the same float32 A)
+    assert sum(len(v) for v in o["idx"]) >= 40                                     # (the sample does gate something)
+
+
 @pytest.mark.parametrize("n,M,seed", [(0, 5, 1), (3, 0, 2), (1, 1, 3), (700, 65, 4), (129, 2048, 5)])
 def test_gate_x_six_state_edge_shapes_vs_oracle(gpu_ctx, n, M, seed):
     from pymht_amd.device import process_leaf_nodes_x

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from fuzz_util import run_case_ais
 
-seed0, n = int(sys.argv[1]), int(sys.argv[2])
+seed0, n = int(sys.argv[1]), int(sys.argv[2])      # (note the order: first seed, then count)
 bad = 0
 for s in range(seed0, seed0 + n):
     ok, desc, msg = run_case_ais(s)

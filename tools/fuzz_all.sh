@@ -4,6 +4,6 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/fuzz
 timeout 900 python tools/fuzz_parity.py 500 91000 2>&1 | grep -v amdgpu | grep "BAD\|cases," > gpurun_out/fuzz/plain.txt
 timeout 900 python tools/fuzz_parity.py 400 92000 similar 2>&1 | grep -v amdgpu | grep "BAD\|cases," > gpurun_out/fuzz/similar.txt
-timeout 900 python tools/fuzz_ais.py 300 93000 2>&1 | grep -v amdgpu | grep "BAD\|cases\|bad" | tail -5 > gpurun_out/fuzz/ais.txt
+timeout 900 python tools/fuzz_ais.py 93000 300 2>&1 | grep -v amdgpu | grep "BAD\|cases\|bad" | tail -5 > gpurun_out/fuzz/ais.txt
 timeout 900 python tools/fuzz_streamed.py 600 94000 2>&1 | grep -v amdgpu | grep "BAD\|cases" > gpurun_out/fuzz/streamed.txt
 tail -2 gpurun_out/fuzz/*.txt
