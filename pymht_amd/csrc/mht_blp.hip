@@ -2029,26 +2029,38 @@ __host__ __device__ constexpr size_t uf_prologue_bytes(size_t T) { return ((T + 
 // the prologue's one global round trip, issued at the very start of the kernel: status word, target count and -- speculatively, the first
 // UF_SPEC x 256 of them -- the parents (the solver's own scalar set-up, ~2 us of argument loads, runs while they are in flight)
 struct UfFetch { int s_over, nT; unsigned long long nif; unsigned long long pw[UF_SPEC]; };
-__device__ __forceinline__ UfFetch uf_prefetch(const BlpArgs& a) {
+// what the prefetch needs of the argument block (the first arguments the kernel loads; everything else follows BEHIND the issue of these
+// loads, see blp_uf_kernel)
+struct UfHead { const DevStatus* status; const int32_t* nT_dev; const unsigned long long* ni_flag; const unsigned long long* uf_parent; int uf_cap, uf_ovl; };
+// Every load is a VECTOR load through an index the compiler cannot see through (zero): a load it knows to be uniform becomes
+// global_load + s_waitcnt vmcnt(0) + v_readfirstlane on the spot -- three dependent round trips in front of the parents' one (seen in the ISA
+// of the round-4 build).  Like this the seven loads leave together and nothing waits for them before the prologue's first use.
+__device__ __forceinline__ UfFetch uf_prefetch(const UfHead& a) {
     UfFetch f;
-    f.s_over = a.status ? a.status->overflow : 0;
-    f.nT = *a.nT_dev;
-    f.nif = a.uf_ovl ? *a.ni_flag : 0ull;
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    const int32_t* sp = a.status ? &a.status->overflow : a.nT_dev;
+    const int so = sp[z];
+    f.nT = a.nT_dev[z];
+    const unsigned long long nif = (a.uf_ovl ? a.ni_flag : a.uf_parent)[z];
 #pragma unroll
     for (int q = 0; q < UF_SPEC; ++q) {
         const int t = (int)threadIdx.x + q * BLP_THREADS;
-        f.pw[q] = a.uf_parent[(t < a.uf_cap) ? t : 0];
+        f.pw[q] = a.uf_parent[((t < a.uf_cap) ? t : 0) + z];
     }
+    f.s_over = a.status ? so : 0;
+    f.nif = a.uf_ovl ? nif : 0ull;
     return f;
 }
 __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe, unsigned char* lds, UfPersist* ps, const int bx, const int gx, int& my_t_out, TgtPre& pre_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define UF_STAMP(k) do { if (a.dbg && tid == 0 && bx < 3900) a.dbg[32 + (size_t)bx * 16 + (k)] = wall_clock64(); } while (0)
     UF_STAMP(0);
-    const int s_over = fe.s_over;
-    const int nT = fe.nT;
+    const int s_over = __builtin_amdgcn_readfirstlane(fe.s_over);
+    const int nT = __builtin_amdgcn_readfirstlane(fe.nT);
+    const unsigned long long nif = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fe.nif >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)fe.nif);
     // (an overlapping grow launch redid the union-find under the alternative epoch if a target had died in the scan before)
-    const unsigned epoch = (a.uf_ovl && (unsigned)fe.nif == (a.uf_epoch >> 1) - 1u && ((fe.nif >> 32) & 1ull)) ? (a.uf_epoch | 1u) : a.uf_epoch;
+    const unsigned epoch = (a.uf_ovl && (unsigned)nif == (a.uf_epoch >> 1) - 1u && ((nif >> 32) & 1ull)) ? (a.uf_epoch | 1u) : a.uf_epoch;
     unsigned long long pw[UF_SPEC];
 #pragma unroll
     for (int q = 0; q < UF_SPEC; ++q) pw[q] = fe.pw[q];
@@ -2443,13 +2455,21 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_kernel(const BlpArgs a) {
     if (a.dbg && threadIdx.x == 0 && blockIdx.x < 3900) a.dbg[32 + (size_t)blockIdx.x * 16 + 15] = wall_clock64();
 }
 // clusters from the grow launch's union-find: every workgroup derives the cluster tables for itself first (uf_prologue); no cluster kernel
-__global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a) {
+__global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // The prologue's round trip leaves FIRST, on the six arguments it needs.  The other ~200 argument words (which the compiler loads in
+    // ~30 dependent rounds of s_load + spill to VGPR lanes at the kernel's entry, ~2-3 us) are read through a pointer it cannot see
+    // through, i.e. behind the issue of those loads: the two overlap instead of adding up.
+    const UfFetch fe = uf_prefetch(UfHead{a_in.status, a_in.nT_dev, a_in.ni_flag, a_in.uf_parent, a_in.uf_cap, a_in.uf_ovl});
+    typedef const __attribute__((address_space(4))) BlpArgs* KArgP;
+    KArgP kp = (KArgP)__builtin_amdgcn_kernarg_segment_ptr();      // (the argument block is the kernel's only argument: offset 0)
+    asm volatile("" : "+s"(kp) : : "memory");
+    BlpArgs a;
+    __builtin_memcpy(&a, kp, sizeof(BlpArgs));
     UfPersist* ps = reinterpret_cast<UfPersist*>(lds + a.uf_lds_off);
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     // (this launch is ordered behind the scan's grow launch: whoever reads this word -- the scan's initiator on its own queue -- knows that launch is complete)
     if (a.begun && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.begun, (unsigned long long)a.pub_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const UfFetch fe = uf_prefetch(a);
     const int gx = (int)gridDim.x, pb = (int)blockIdx.x, bx = pb;
     blp_body<true>(a, lds, bx, gx, ps, &fe);
     if (!fe.s_over) blp_stamp_end(a);
