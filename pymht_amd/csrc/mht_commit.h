@@ -140,6 +140,9 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
     // (the ILP statistics' first batch of look-ups goes out with the above and its dependent one behind it, instead of as two more
     // round trips at the end of the workgroup's critical path; entries of multi_list beyond this scan's count are stale but valid ids)
     const int c_first = a.multi_list[tcl];
+    // (the compiler sinks the per-target look-ups above behind the branch below -- a second dependent round trip behind the overlapping
+    // launch's wait, seen in the ISA -- unless something that may touch memory stands between them and the branch)
+    asm volatile("" ::: "memory");
     if (s_over || c_over) {        // void scan: report the error, leave the forest alone (it must be recreated)
         if (tid == 0) {
             ReportHeader& h = *a.hdr;
