@@ -42,6 +42,11 @@ struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in L
 static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesses");
 
 struct TInfo { int alive, first, cnt, depth, shift; };
+// The first poll of a target's record and its depth, issued IN FRONT of the staging of the scan (overlapping launches): the compiler
+// makes a load it knows to be uniform a round trip of its own (global_load, s_waitcnt vmcnt(0), v_readfirstlane) and put this one behind the
+// staging loop's -- two dependent round trips at the head of the workgroups the launch ends with (seen in the ISA).  Through an index it
+// cannot see through they are vector loads nobody waits for until the staging loop's own wait, which covers them.
+struct TPre { unsigned long long w; int dep; };
 constexpr int FG_MAP = 1024;                          // entries of the child -> leaf table of a chunk (more children: binary search)
 constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128 > 0 ? FG_THREADS / 128 : 1;     // targets per chain workgroup: wavefront = (target, hit/miss)
 typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
@@ -49,18 +54,20 @@ typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the ke
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
 // loads go out unconditionally (one round trip), dead or out-of-range slots are masked afterwards
 template <bool OVL = true, typename ARGS = void>
-__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT, int* rf_out = nullptr, const int void_scan = 0) {
+__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT, int* rf_out = nullptr, const int void_scan = 0, const bool pre = false, const TPre pv = TPre{0ull, 0}) {
     TInfo r;
     const int tc = (t < a.Tcap) ? t : 0;
     if (OVL && d.fused && d.ovl) {
         // the previous scan's ILP launch may still be running: the target's record (mht_kernels.h: TGT_REC_*) is published the moment the
         // target is finished there -- wait for it, for nothing else (slots up to the launch's grid bound all get one)
-        const int dep = a.p_depth[tc];
+        // (pre: the first poll and the depth went out in front of the caller's staging loop, target_prefetch)
+        const int dep = pre ? __builtin_amdgcn_readfirstlane(pv.dep) : a.p_depth[tc];
         const unsigned tag = (unsigned)d.c_scan & 0xffu;
         unsigned long long w = 0ull;
         bool ok = t < d.n_tgt;
         if (ok) {
-            w = __hip_atomic_load(&a.rec0[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pre) w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv.w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pv.w);
+            else w = __hip_atomic_load(&a.rec0[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(w >> TGT_REC_TAG) != tag) {
                 if (void_scan) ok = false;      // (a void scan publishes nothing: the caller leaves)
                 else {
@@ -434,13 +441,21 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
         unsigned long long v;
         if (!spin_until(d.z_flag, [&](unsigned long long x) { return x >= d.z_tag; }, v) && tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 2); }      // (tags only grow: a later scan may have been staged already)
     }
+    TPre tpre = {0ull, 0};
+    if (ovl) {
+        int zo;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zo));
+        const int tcp = ((t < a.Tcap) ? t : 0) + zo;
+        tpre.w = __hip_atomic_load(&a.rec0[tcp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tpre.dep = a.p_depth[tcp];
+    }
     if (ovl)              // (the wait for the target's record comes behind everything that does not depend on it)
         for (int j = tid; j < Mpad; j += FG_THREADS) {
             const float2 v = (j < M) ? z2[j] : make_float2(3.0e38f, 3.0e38f);
             zx[j] = v.x;
             zy[j] = v.y;
         }
-    const TInfo ti = target_info<!LEAN>(a, d, t, nT, &rf_rec, po | so);
+    const TInfo ti = target_info<!LEAN>(a, d, t, nT, &rf_rec, po | so, ovl, tpre);
     const int tc = (t < a.Tcap) ? t : 0;
     // (overlapping launch: the root's score was written through in front of the target's record)
     const double rootc = born ? a.b_root_cnllr[tc]
