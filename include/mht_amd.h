@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MHT_ABI_VERSION 4
+#define MHT_ABI_VERSION 5
 
 /* State dimension of the library build the header is used with: 4 (libmht_amd.so: the reference's CV model, models/pv.py) or 6
  * (libmht_amd6.so: the same sources compiled with -DMHT_NX=6 for BASELINE config 5's six-state model).  It sizes the model matrices
@@ -49,6 +49,9 @@ enum {
 #define MHT_F_STATE_F32 1u /* state chain is float32 (targets born from the initiator, m_of_n.py:353-358) */
 #define MHT_F_SCORE_F32 2u /* cumulativeNLLR currently holds a float32 value */
 #define MHT_F_DEAD 8u      /* forest only: taken out of the tree by similar-state pruning (never set in what mht_forest_leaves returns) */
+#define MHT_F_COV_F64 16u  /* forest with MHT_FOREST_AIS only: the node's covariance is float64 -- an AIS-updated node (models/ais.py:4:
+                            * ais.C is float64, so P_hat of tracker.py:451-487 is) or a child of a batch NumPy promoted because one of its
+                            * members was (np.array of the leaves' P_0, tracker.py:859-870).  Such a node's state is float64 too. */
 
 /* ILP status (mht_solve_blp / forest step) */
 #define MHT_BLP_CERTIFIED 1   /* Lagrangian certificate: conflict-free minimisers + complementary slackness */
@@ -331,6 +334,11 @@ int mht_forest_report_get(mht_ctx* ctx, int32_t which, mht_scan_report* out);
  * capacity = length of the host arrays; *n_out = number of leaves.  Synchronises. */
 int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
                       int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
+/* The same with every covariance as float64, P host [n][16] double: the exact value of a float32 covariance, the reference's own float64
+ * one where flags carries MHT_F_COV_F64 (a forest with AIS: Target.P_0 keeps the dtype the reference gives it, pyTarget.py:16-40).
+ * mht_forest_leaves rounds those to float32. */
+int mht_forest_leaves_f64(mht_ctx* ctx, int32_t capacity, double* x, double* P, double* cnllr, int32_t* meas,
+                          int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out);
 /* Similar-state pruning -- Tracker._pruneSimilarState (tracker.py:1233-1239) -> Target.pruneSimilarState (pyTarget.py:358-412),
  * what addMeasurementList(..., pruneSimilar=True) asks for (tracker.py:230-231) -- for the scans stepped from now on: in every target
  * that is alone in its cluster, the hit children of a node that lie within `threshold` metres (Tracker.pruneThreshold,
@@ -363,6 +371,9 @@ int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t by
  * nodes/meas [max_len] int32, x [max_len][4], cnllr [max_len], P [max_len][16]; any may be NULL. */
 int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                      double* x, double* cnllr, float* P, int32_t* n_out);
+/* The same with float64 covariances (see mht_forest_leaves_f64) and the nodes' flag bytes, flags host [max_len] uint8 or NULL. */
+int mht_forest_chain_f64(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                         double* x, double* cnllr, double* P, uint8_t* flags, int32_t* n_out);
 
 /* ---- step 7 of a scan: M-of-N track initiation on the device (tracker.py:264-278 -> initiators/m_of_n.py:215-478) -------------
  * What Tracker.__init__ hands to m_of_n.Initiator (tracker.py:66-72) plus the model constants the initiator imports (pv.P0, pv.Q's

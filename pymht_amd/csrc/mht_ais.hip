@@ -107,27 +107,21 @@ __global__ __launch_bounds__(1024) void ais_scan_kernel(const int32_t* cnt, int3
 // ---- the forest: fused children of every leaf of the newest layer, in front of the scan's grow launch ----------------------------
 // One workgroup (a wavefront) per target slot of the COMMITTED table, lane = leaf.  Per leaf: count, take a slice of the record
 // pool (one returning atomic), emit.  The covariance of the children of a (leaf, message) pair is a value like any other
-// (mht_vtab.h): rounded to float32, found or inserted, and given a key of its own -- a pseudo parent whose miss child it is, as a
-// root's or a merged hypothesis' (mht_similar.hip) -- with the gains the children need as leaves of the next scan.
+// (mht_vtab.h) -- a FLOAT64 one, as the reference carries it (models/ais.py:4) -- found or inserted, and given a key of its own: a
+// pseudo parent whose miss child it is, as a root's or a merged hypothesis' (mht_similar.hip), with the float64 gains the children
+// need as leaves of the next scan.
 struct ForestEmit {
     const AisForestArgs* a; int c; double pd; int last_msg, key;
     __device__ __forceinline__ void operator()(const double* x, const double* P, int radar, double nllr, int msg) {
-        if (msg != last_msg) {
+        if (msg != last_msg) {      // (the children of one (leaf, message) pair share their covariance: float64, as the reference carries it)
             last_msg = msg;
-            float Pf[NP];
+            double P64[NP];
 #pragma unroll
-            for (int e = 0; e < NP; ++e) Pf[e] = (float)P[e < 16 ? e : 0];
-            const int id0 = vt_find_or_insert(a->vt, Pf, pd);
-            const unsigned pid = atomicAdd(a->vt.count, 1u);
-            if (pid >= (unsigned)a->vt.vcap || id0 < 0) { *a->vt.overflow = 1; key = 0; }
-            else {
-                key = 2 * (int)pid;
-                float4 rec[GKQ];
-                vt_gains(a->model, Pf, pd, rec);
-#pragma unroll
-                for (int e = 0; e < GKQ; ++e) a->vt.Gk[(size_t)key * GKQ + e] = rec[e];
-                a->vt.child[key] = id0;
-            }
+            for (int e = 0; e < NP; ++e) P64[e] = P[e < 16 ? e : 0];
+            const int id0 = vt_find_or_insert64(a->vt, P64, pd);
+            double row[GKF];
+            vt_gains64(a->model, P64, pd, row);
+            key = vt_pseudo_key64(a->vt, id0, row);
         }
         AisRec r;
 #pragma unroll
@@ -137,8 +131,8 @@ struct ForestEmit {
     }
 };
 
-template <typename EMIT>
-__device__ __forceinline__ int forest_leaf(const AisForestArgs& a, int src, uint8_t fl, const float* P, double pd, int own, EMIT& e) {
+template <typename TP, typename EMIT>
+__device__ __forceinline__ int forest_leaf(const AisForestArgs& a, int src, uint8_t fl, const TP* P, double pd, int own, EMIT& e) {
     if (fl & F_STATE_F32) {
         float xs[4];
 #pragma unroll
@@ -149,6 +143,22 @@ __device__ __forceinline__ int forest_leaf(const AisForestArgs& a, int src, uint
 #pragma unroll
     for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.cap + src];
     return ais_fuse_leaf<double>(a.model, a.groups, a.nG, a.msgs, xd, P, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+}
+// count, take a slice of the record pool, emit -- in the dtype of the leaf's OWN covariance (kalman.predict_single on node.P_0, tracker.py:449-450)
+template <typename TP>
+__device__ __forceinline__ void forest_leaf_run(const AisForestArgs& a, int src, uint8_t fl, const TP* P, int& n, int& o) {
+    const double pd = a.pd[src];
+    const int own = a.hmmsi[src];
+    CountOnly ce;
+    n = forest_leaf(a, src, fl, P, pd, own, ce);
+    if (n > 0) {
+        o = (int)atomicAdd(a.rec_count, (unsigned)n);
+        if (o + n > a.rec_cap) { a.status->overflow = 1; n = 0; }
+    }
+    if (n > 0) {
+        ForestEmit fe{&a, o, pd, -1, 0};
+        forest_leaf(a, src, fl, P, pd, own, fe);
+    }
 }
 
 __global__ __launch_bounds__(64) void forest_ais_kernel(const AisForestArgs a) {
@@ -161,19 +171,14 @@ __global__ __launch_bounds__(64) void forest_ais_kernel(const AisForestArgs a) {
         const uint8_t fl = a.flags[src];
         int n = 0, o = 0;
         if (!(fl & F_DEAD)) {
-            float P[NP];
-            vt_load(a.vt, a.vt.child[a.cov[src]], P);
-            const double pd = a.pd[src];
-            const int own = a.hmmsi[src];
-            CountOnly ce;
-            n = forest_leaf(a, src, fl, P, pd, own, ce);
-            if (n > 0) {
-                o = (int)atomicAdd(a.rec_count, (unsigned)n);
-                if (o + n > a.rec_cap) { a.status->overflow = 1; n = 0; }
-            }
-            if (n > 0) {
-                ForestEmit fe{&a, o, pd, -1, 0};
-                forest_leaf(a, src, fl, P, pd, own, fe);
+            if (fl & F_COV_F64) {
+                double P[NP];
+                vt_load64(a.vt, a.vt.child[a.cov[src]], P);
+                forest_leaf_run(a, src, fl, P, n, o);
+            } else {
+                float P[NP];
+                vt_load(a.vt, a.vt.child[a.cov[src]], P);
+                forest_leaf_run(a, src, fl, P, n, o);
             }
         }
         a.nf[src] = n;

@@ -11,14 +11,15 @@
 //   5. radar precalc + gate against all M radar measurements like any prediction              :488-496
 //   6. a child per gated radar measurement, score (nllr1 + nllr2) / 2; none gated: ONE child without a radar measurement,
 //      state x2, score nllr1                                                                  :497-526
-// dtypes as NumPy promotes them: step 1 in the leaf's state dtype (float64, or the float32 chain of initiator-born tracks) and
-// float32 covariances; from step 2 on everything is float64 (ais.C is float64), INCLUDING the children's covariance -- which the
-// forest then stores rounded to float32 like every other covariance (the reference keeps float64 and, through np.array's
-// promotion of a mixed batch, continues the whole target in float64: a 1e-8 relative difference, far inside the 1e-6 of the
-// north star; traces with AIS are compared to that tolerance, not bit for bit -- DESIGN.md).
-// The float64 part is written in the plain order (FMA chains, k ascending); OpenBLAS' dgesv on a 4x4 is not restated.
+// dtypes as NumPy promotes them: step 1 in the leaf's OWN dtypes (kalman.predict_single on node.x_0 / node.P_0: float64 state or the
+// float32 chain of initiator-born tracks; float32 covariance, or float64 once the target has been promoted); from step 2 on everything
+// is float64 (ais.C is float64), INCLUDING the children's covariance, which the forest keeps in float64 (mht_vtab.h: values of two ids).
+// Every float64 product is a dgemm / dgemv in OpenBLAS' order (FMA chains, k ascending; gemv: mht_math.h::gemv_row), the two inverses
+// are dgesv restated operation by operation (mht_la64.h::inv_lapack): states and covariances of the children are the reference's bit
+// for bit (tests/golden/g19_ais_fusion.npz), scores to the NLLR tolerance (numpy's det = exp(sum(log|u_ii|)), its SIMD log).
 #pragma once
 #include "mht_math.h"
+#include "mht_la64.h"
 
 namespace mht {
 
@@ -44,87 +45,44 @@ MHT_HD double dgemv4(const double* a, const double* x) {
 }
 MHT_HD double dgemv2(const double* a, const double* x) { return fma(a[0], x[0], a[1] * x[1]); }
 
-// Gauss-Jordan with partial pivoting on a 4x4 (S is symmetric positive definite here); returns the determinant.
-MHT_HD double inv4(const double* s, double* out) {
-    double a[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[i][j] = s[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
-    double det = 1.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        double best = fabs(a[c][c]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r > c && fabs(a[r][c]) > best) { best = fabs(a[r][c]); p = r; }
-        if (p != c) {
-            det = -det;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r == p)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const double t = a[c][j]; a[c][j] = a[r][j]; a[r][j] = t; }
-        }
-        const double piv = a[c][c];
-        det *= piv;
-        const double rp = 1.0 / piv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[c][j] *= rp;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[r][j] = fma(-f, a[c][j], a[r][j]);
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][4 + j];
-    return det;
-}
-
 // steps 1-2 of a (leaf, group): what the gate of step 3 needs
 struct AisPre {
     double x1[4];
-    float P1[16];
+    double P1[16];     // (float32 values when the leaf's covariance is float32)
     double Sinv[16];
     double lnc1;       // ln(lambda_ais sqrt(det(2 pi S1)))
 };
 // (a): the prediction at the message's time -- cheap; (b): S^-1 and the score constant -- two thirds of the work of a (leaf, group) pair,
 // only done when a message of the group lies inside the gate's bounding box (for a positive definite S: dz_i^2 <= nis * S_ii)
-template <typename TS>
-MHT_HD void ais_pre_a(const AisGroup& g, const TS* x, const float* P, AisPre& o) {
+template <typename TS, typename TP>
+MHT_HD void ais_pre_a(const AisGroup& g, const TS* x, const TP* P, AisPre& o) {
     TS x1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {      // A.dot(x): matrix x ONE column (kalman.py:68) -> BLAS gemv order (mht_math.h::gemv_row)
         x1[i] = gemv_row<TS, 4>(g.A1 + i * 4, x);
         o.x1[i] = (double)x1[i];
     }
-    float t[16], at[16];
+    TP t[16], at[16], p1[16];      // A.dot(P).dot(A.T) + Q (kalman.py:69) in the covariance's dtype (Phi, Q float32: promoted by NumPy)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) at[i * 4 + j] = g.A1[j * 4 + i];
-    gemm_chain<float, float, float, 4, 4, 4>(g.A1, P, t);
-    gemm_chain<float, float, float, 4, 4, 4>(t, at, o.P1);
+        for (int j = 0; j < 4; ++j) at[i * 4 + j] = (TP)g.A1[j * 4 + i];
+    gemm_chain<TP, float, TP, 4, 4, 4>(g.A1, P, t);
+    gemm_chain<TP, TP, TP, 4, 4, 4>(t, at, p1);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o.P1[e] = o.P1[e] + g.Q1[e];
+    for (int e = 0; e < 16; ++e) o.P1[e] = (double)(p1[e] + (TP)g.Q1[e]);
 }
 MHT_HD void ais_pre_b(const AisGroup& g, double lambda_ais, AisPre& o) {
     double S[16];
     const double two_pi = 6.283185307179586;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) S[e] = (double)o.P1[e] + (((e >> 2) == (e & 3)) ? (double)g.r_diag : 0.0);
-    const double det = inv4(S, o.Sinv);      // det(2 pi S) = (2 pi)^4 det(S): the same elimination serves both (kalman.py:19 scales first: 1e-16 relative)
+    for (int e = 0; e < 16; ++e) S[e] = o.P1[e] + (((e >> 2) == (e & 3)) ? (double)g.r_diag : 0.0);      // matmul(matmul(C, P), C.T) + R with C = I4: exact
+    const double det = inv_lapack<4>(S, o.Sinv);      // det(2 pi S) = (2 pi)^4 det(S): the same elimination serves both (kalman.py:19 scales first: 1e-16 relative)
     o.lnc1 = log((lambda_ais * sqrt((two_pi * two_pi) * (two_pi * two_pi) * det)) / 1.0);
 }
-template <typename TS>
-MHT_HD void ais_pre(const AisGroup& g, const TS* x, const float* P, double lambda_ais, AisPre& o) {
-    ais_pre_a<TS>(g, x, P, o);
+template <typename TS, typename TP>
+MHT_HD void ais_pre(const AisGroup& g, const TS* x, const TP* P, double lambda_ais, AisPre& o) {
+    ais_pre_a<TS, TP>(g, x, P, o);
     ais_pre_b(g, lambda_ais, o);
 }
 
@@ -150,9 +108,8 @@ struct AisPost {
     double lnc2;        // ln(lambda_ex sqrt(det(2 pi S2)) / P_d)
 };
 MHT_HD void ais_post(const AisGroup& g, const Model& mdl, const AisPre& p, const double* zt, double pd, AisPost& o) {
-    double P1[16], K1[16], P1h[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) P1[e] = (double)p.P1[e];
+    double K1[16], P1h[16];
+    const double* P1 = p.P1;
     gemm_chain<double, double, double, 4, 4, 4>(P1, p.Sinv, K1);            // K = (P C^T) S^-1, C = I
     gemm_chain<double, double, double, 4, 4, 4>(K1, P1, P1h);               // (K C) P
 #pragma unroll
@@ -181,21 +138,7 @@ MHT_HD void ais_post(const AisGroup& g, const Model& mdl, const AisPre& p, const
     gemm_chain<double, double, double, 2, 4, 2>(CP, Ct, S);
 #pragma unroll
     for (int e = 0; e < 4; ++e) S[e] = S[e] + (double)mdl.R[e];
-    const double det = S[0] * S[3] - S[1] * S[2];
-    {   // 2x2 inverse with partial pivoting, like inv2 but on float64 input
-        double a = S[0], b = S[1], c = S[2], d = S[3];
-        const bool sw = fabs(c) > fabs(a);
-        if (sw) { double q = a; a = c; c = q; q = b; b = d; d = q; }
-        const double l = c * (1.0 / a), u11 = fma(-l, b, d), r00 = 1.0 / a, r11 = 1.0 / u11;
-#pragma unroll
-        for (int col = 0; col < 2; ++col) {
-            double y0 = (col == 0) ? 1.0 : 0.0, y1 = (col == 1) ? 1.0 : 0.0;
-            if (sw) { const double q = y0; y0 = y1; y1 = q; }
-            y1 = fma(-l, y0, y1);
-            const double x1 = y1 * r11, x0 = fma(-b, x1, y0) * r00;
-            o.Sinv[col] = x0; o.Sinv[2 + col] = x1;
-        }
-    }
+    const double det = inv_lapack<2>(S, o.Sinv);      // np.linalg.inv (kalman.py:91); det(2 pi S) = (2 pi)^2 det(S)
     gemm_chain<double, double, double, 4, 4, 2>(P2, Ct, PCt);
     gemm_chain<double, double, double, 4, 2, 2>(PCt, o.Sinv, o.K2);
     gemm_chain<double, double, double, 4, 2, 4>(o.K2, C, KC);
@@ -224,8 +167,8 @@ MHT_HD void ais_child_state(const AisPost& p, const double* zt, double* x) {
 // All children of one leaf, in the reference's order; `emit(x[4], P[16], radar index or -1, nllr, message index)` is called once
 // per child (a counting pass hands in a functor that only counts).  `own` = the identity the track is bound to (0 = none):
 // messages of other ships are skipped (pyTarget.py:269-272).  Returns the number of children.
-template <typename TS, typename EMIT>
-MHT_HD int ais_fuse_leaf(const Model& mdl, const AisGroup* groups, int nG, const AisMsg* msgs, const TS* x, const float* P, double pd,
+template <typename TS, typename TP, typename EMIT>
+MHT_HD int ais_fuse_leaf(const Model& mdl, const AisGroup* groups, int nG, const AisMsg* msgs, const TS* x, const TP* P, double pd,
                          int own, double eta2_ais, double lambda_ais, const float* z, int M, EMIT&& emit) {
     int n = 0;
     for (int gi = 0; gi < nG; ++gi) {
@@ -234,11 +177,11 @@ MHT_HD int ais_fuse_leaf(const Model& mdl, const AisGroup* groups, int nG, const
         for (int q = 0; q < g.count && !any; ++q) any = (own == 0) || (msgs[g.first + q].mmsi == own);
         if (!any) continue;
         AisPre pre;
-        ais_pre_a<TS>(g, x, P, pre);
+        ais_pre_a<TS, TP>(g, x, P, pre);
         // the gate's bounding box in position (a necessary condition, widened by far more than any rounding): most (leaf, group) pairs
         // have no message near them and stop here
-        const double bx = sqrt(eta2_ais * ((double)pre.P1[0] + (double)g.r_diag)) * 1.000001 + 1e-9;
-        const double by = sqrt(eta2_ais * ((double)pre.P1[5] + (double)g.r_diag)) * 1.000001 + 1e-9;
+        const double bx = sqrt(eta2_ais * (pre.P1[0] + (double)g.r_diag)) * 1.000001 + 1e-9;
+        const double by = sqrt(eta2_ais * (pre.P1[5] + (double)g.r_diag)) * 1.000001 + 1e-9;
         any = false;
         for (int q = 0; q < g.count && !any; ++q) {
             const AisMsg& m = msgs[g.first + q];

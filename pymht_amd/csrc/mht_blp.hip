@@ -2097,12 +2097,13 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
     __syncthreads();
     UF_STAMP(2);
     // ONE block scan over the targets in index order (thread = a run of E consecutive targets): heads -> cluster index, their sizes ->
-    // member offset, ranks among the multi-target / single-target / team-sized clusters, packed 14 + 14 + 14 + 14 + 8 bits
+    // member offset, ranks among the multi-target / single-target / team-sized clusters, packed 14 + 13 + 14 + 14 + 9 bits (max_targets 8 192:
+    // at most 8 192 clusters, 4 096 of them with two or more targets, 341 with TEAM_MIN_K or more -- no field can wrap)
     const int E = (nT + BLP_THREADS - 1) / BLP_THREADS;
     auto pack_of = [&](int t) -> unsigned long long {
         if (t >= nT || lab[t] != t) return 0ull;
         const unsigned long long K = (unsigned long long)cnt[t];
-        return 1ull | ((K >= 2 ? 1ull : 0ull) << 14) | ((K == 1 ? 1ull : 0ull) << 28) | (K << 42) | ((K >= (unsigned long long)TEAM_MIN_K ? 1ull : 0ull) << 56);
+        return 1ull | ((K >= 2 ? 1ull : 0ull) << 14) | ((K == 1 ? 1ull : 0ull) << 27) | (K << 41) | ((K >= (unsigned long long)TEAM_MIN_K ? 1ull : 0ull) << 55);
     };
     unsigned long long mine = 0ull;
     for (int e = 0; e < E; ++e) mine += pack_of(tid * E + e);
@@ -2118,13 +2119,13 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
     unsigned long long run = incl - mine, total = 0ull;
 #pragma unroll
     for (int w = 0; w < BLP_THREADS / 64; ++w) { const unsigned long long v = s_w[w]; if (w < wave) run += v; total += v; }
-    const int nC = (int)(total & 0x3fffu), nMulti = (int)((total >> 14) & 0x3fffu), nSingle = (int)((total >> 28) & 0x3fffu);
-    const int nTeamAll = (int)(total >> 56), nTeam = (a.team_list && nTeamAll > 0) ? (nTeamAll < TEAM_MAX ? nTeamAll : TEAM_MAX) : 0;
+    const int nC = (int)(total & 0x3fffu), nMulti = (int)((total >> 14) & 0x1fffu), nSingle = (int)((total >> 27) & 0x3fffu);
+    const int nTeamAll = (int)(total >> 55), nTeam = (a.team_list && nTeamAll > 0) ? (nTeamAll < TEAM_MAX ? nTeamAll : TEAM_MAX) : 0;
     for (int e = 0; e < E; ++e) {
         const int t = tid * E + e;
         const unsigned long long pk = pack_of(t);
         if (pk) {
-            const int c = (int)(run & 0x3fffu), mr = (int)((run >> 14) & 0x3fffu), sr = (int)((run >> 28) & 0x3fffu), p0 = (int)((run >> 42) & 0x3fffu), tr = (int)(run >> 56);
+            const int c = (int)(run & 0x3fffu), mr = (int)((run >> 14) & 0x1fffu), sr = (int)((run >> 27) & 0x3fffu), p0 = (int)((run >> 41) & 0x3fffu), tr = (int)(run >> 55);
             const int K = cnt[t];
             par[t] = (unsigned short)c;       // (the parents are dead: cluster index by head)
             hp[t] = (unsigned short)p0;

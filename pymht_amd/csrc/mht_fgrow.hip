@@ -40,6 +40,15 @@ struct alignas(16) FLeaf {            // per-leaf results of phase 1 parked in L
     unsigned char flags, f32state, valid, pad;
 };
 static_assert(sizeof(FLeaf) % 16 == 0, "FLeaf is copied with 16-byte LDS accesses");
+// AIS forest only (fgrow_ais_kernel): the gains of a leaf whose target NumPy has promoted to float64 covariances (mht_vtab.h; models/ais.py:4,
+// tracker.py:859-870) -- a second per-leaf record next to FLeaf, so that the kernels of radar-only forests stay byte for byte what they were
+struct alignas(16) FLeafX {
+    double K[NK];
+    double sinv[4];
+    double lnc;
+    int f64, pad;                     // the gains above are valid (else: FLeaf's float32 ones)
+};
+static_assert(sizeof(FLeafX) % 16 == 0, "FLeafX is copied with 16-byte LDS accesses");
 
 struct TInfo { int alive, first, cnt, depth, shift; };
 // The first poll of a target's record and its depth, issued IN FRONT of the staging of the scan (overlapping launches): the compiler
@@ -157,7 +166,37 @@ __device__ __forceinline__ void chain_resolve(const ARGS& a, int id, int h, doub
     a.vt.child[ckey] = vt_find_or_insert(a.vt, Pc, pd);
 }
 
-template <bool OVL = true, typename ARGS = void>
+// the same for a float64 value (AIS forests, mht_vtab.h): dgemm chains and dgesv in OpenBLAS' order (mht_la64.h)
+template <typename ARGS>
+__device__ __forceinline__ void chain_resolve64(const ARGS& a, int id, int h, double pd) {
+    const int ckey = 2 * id + h;
+    if (atomicCAS(&a.vt.child[ckey], -1, VT_CLAIMED) != -1) return;
+    double P[NP];
+    vt_load64(a.vt, id, P);
+    Model mdl;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) { mdl.A[e] = a.model.A[e]; mdl.Q[e] = a.model.Q[e]; }
+#pragma unroll
+    for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mdl.R[e] = a.model.R[e];
+    mdl.eta2 = a.model.eta2; mdl.lambda_ex = a.model.lambda_ex;
+    double Pc[NP];
+    {
+        CovChain64 c;
+        cov_chain64(mdl, P, c, h != 0);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) Pc[e] = h ? c.P_hat[e] : c.P_bar[e];
+    }
+    {
+        double row[GKF];
+        vt_gains64(mdl, Pc, pd, row);
+        vt_store_gains64(a.vt, ckey, row);
+    }
+    a.vt.child[ckey] = vt_find_or_insert64(a.vt, Pc, pd);
+}
+
+template <bool OVL = true, int AIS = 0, typename ARGS = void>
 __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb, const int t_off = 0, const int born = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nT = born ? a.nT_new[0] : a.nT_dev[0];
@@ -167,6 +206,14 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb,
     const TInfo ti = target_info<OVL>(a, d, t, nT, nullptr, po | so);
     if (po || so) return;
     FG_STAMP(0);
+    // AIS forest: a target with a float64-covariance leaf is promoted as a whole (np.array of its leaves' P_0, tracker.py:859-862): its
+    // float32 leaves continue from their covariance converted to float64 -- the same value the target's workgroup finds or inserts
+    bool prom = false;
+    if (AIS)
+        for (int l0 = 0; l0 < ti.cnt; l0 += 64) {
+            const uint8_t f = (l0 + lane < ti.cnt) ? a.flags[ti.first + l0 + lane] : (uint8_t)0;
+            prom = prom || __any((f & F_COV_F64) && !(f & F_DEAD));
+        }
     for (int l0 = 0; l0 < ti.cnt; l0 += 64) {
         const bool v = l0 + lane < ti.cnt;
         const int src = ti.first + (v ? l0 + lane : 0);
@@ -182,7 +229,14 @@ __device__ __forceinline__ void chain_part(const ARGS& a, const FDyn& d, int cb,
             if (lane == j) { mykey = cv; mysrc = sv; }
         }
         if (mykey < 0) continue;
-        const int id = a.vt.child[mykey];          // (set when the leaf was made: by this code one scan ago, or at its birth)
+        int id = a.vt.child[mykey];                // (set when the leaf was made: by this code one scan ago, or at its birth)
+        if (AIS && prom) {
+            const double pd = a.pd[mysrc];
+            if (!(a.flags[mysrc] & F_COV_F64)) { double P64[NP]; id = vt_promote(a.vt, id, pd, P64); }
+            if (a.vt.child[2 * id + h] >= 0) continue;
+            chain_resolve64(a, id, h, pd);
+            continue;
+        }
         const int ckey = 2 * id + h;
         if (a.vt.child[ckey] >= 0) continue;       // the transition is known
         const double pd = a.pd[mysrc];
@@ -243,7 +297,7 @@ __device__ __forceinline__ void fg_emit_fused(const ARGS& a, const FDyn& d, cons
     a.oparent[c] = g.src;
     a.omeas[c] = r.radar + 1;          // 0 with an identity = a child without a radar measurement (measurementNumber None)
     a.ocov[c] = r.key;
-    a.oflags[c] = 0;
+    a.oflags[c] = F_COV_F64;      // (the key names a float64 value: tracker.py:451-487 carries the fused covariance in float64)
     a.ocost[c] = (cnl - rootc) / (double)a.Nwin;
     a.ais.ommsi[c] = r.mmsi;
     a.ais.ohmmsi[c] = r.mmsi;
@@ -254,7 +308,9 @@ __device__ __forceinline__ void fg_emit_fused(const ARGS& a, const FDyn& d, cons
 template <typename TS, int PQ, int AIS = 0, typename ARGS = void>
 __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int role, const FLeaf& g, int l, int c, int k, int nh, const unsigned long long* hwl,
                                               const float* zx, const float* zy, const int* s_pp, const int* s_ap, int depth, int shift,
-                                              double rootc, int root_f32, const unsigned short* cand = nullptr, const float2* zg = nullptr) {
+                                              double rootc, int root_f32, const unsigned short* cand = nullptr, const float2* zg = nullptr,
+                                              const FLeafX* gx = nullptr) {
+    // (gx != null && gx->f64 -- AIS forest, a promoted target: float64 gains, TS = double, the children's covariances are float64)
     // (cand != null -- the wavefront-per-target kernel: the hit words index the target's candidate list, and the scan is read from
     // global memory, zg, not from an LDS copy)
     const size_t cap = a.cap;
@@ -303,7 +359,8 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
     }
     FG_STAMPX(3);
     double cnl;
-    uint8_t cfl = (uint8_t)(fl & F_STATE_F32);
+    const bool g64 = AIS && gx && gx->f64;
+    uint8_t cfl = g64 ? (uint8_t)F_COV_F64 : (uint8_t)(fl & F_STATE_F32);
     TS zt[2] = {(TS)0, (TS)0};
     if (k == 0) {            // missed-detection child (pyTarget.py:319-328)
         const double inc = (g.pd == a.default_pd) ? a.default_miss_nllr : -log(1.0 - g.pd);
@@ -312,8 +369,9 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         float mx, my;
         if (zg) { const float2 v = zg[j]; mx = v.x; my = v.y; } else { mx = zx[j]; my = zy[j]; }
         TS zh[2] = {(TS)g.zhat[0], (TS)g.zhat[1]}, nis;
-        gate_pair<TS>(zh, g.sinv, mx, my, (TS)a.model.eta2, zt, nis);
-        const TS tinc = (TS)0.5 * nis + (TS)g.lnc;           // kalman.py:19
+        if (g64) gate_pair<TS>(zh, gx->sinv, mx, my, (TS)a.model.eta2, zt, nis);
+        else gate_pair<TS>(zh, g.sinv, mx, my, (TS)a.model.eta2, zt, nis);
+        const TS tinc = (TS)0.5 * nis + (g64 ? (TS)gx->lnc : (TS)g.lnc);           // kalman.py:19
         if (sizeof(TS) == 4 && (fl & F_SCORE_F32)) {          // float32 + float32 stays float32 (NumPy scalar rules)
             cnl = (double)((float)g.cn + (float)tinc);
             cfl |= F_SCORE_F32;
@@ -328,7 +386,9 @@ __device__ __forceinline__ void fg_emit_child(const ARGS& a, const FDyn& d, int 
         for (int i = 0; i < NX; ++i) xo[i] = g.xbar[i];
         if (k > 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xo[i] = (double)update_component_n<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt, nh == 1);      // (one hit: gemv, mht_math.h)
+            for (int i = 0; i < NX; ++i)      // (one hit: gemv, mht_math.h)
+                xo[i] = g64 ? (double)update_component_n<TS>((TS)g.xbar[i], gx->K[i * 2], gx->K[i * 2 + 1], zt, nh == 1)
+                            : (double)update_component_n<TS>((TS)g.xbar[i], g.K[i * 2], g.K[i * 2 + 1], zt, nh == 1);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) a.ox[(size_t)i * cap + c] = xo[i];
@@ -422,6 +482,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
     unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
     unsigned char* s_map = reinterpret_cast<unsigned char*>(cand + Mpad);                   // [FG_MAP] leaf of the chunk's r-th child
     int* s_ais = reinterpret_cast<int*>(s_map + FG_MAP);                                    // AIS forest: [CAP][4] fused children (count, first record), bound identity
+    FLeafX* lgx = reinterpret_cast<FLeafX*>(s_ais + 4 * CAP);                              // AIS forest: [CAP] float64 gains of a promoted target's leaves
     int& s_ncand = s_misc[0];
     int& s_base = s_misc[1];
     int& s_ebase = s_misc[2];
@@ -477,6 +538,15 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
     }
     if (!ti.alive) return;
     FG_STAMP(1);
+    // AIS forest: one LIVE leaf with a float64 covariance -- an AIS-updated node or a descendant of one -- and NumPy promotes the target's
+    // whole batch: np.array([node.P_0 ...]) and np.array([node.x_0 ...]) of a list with a float64 member are float64 (tracker.py:859-862), so
+    // every leaf's chain runs in float64 from its own (exactly converted) values and every child carries float64 state and covariance
+    bool prom = false;
+    if (AIS) {
+        int anyf = 0;
+        for (int i = tid; i < ti.cnt; i += FG_THREADS) { const uint8_t f = a.flags[ti.first + i]; anyf |= ((f & F_COV_F64) && !(f & F_DEAD)) ? 1 : 0; }
+        prom = __syncthreads_or(anyf) != 0;
+    }
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -543,11 +613,44 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 float4 gr[GKQ];
 #pragma unroll
                 for (int q = 0; q < GKQ; ++q) gr[q] = a.vt.Gk[(size_t)covc * GKQ + q];
-                const int cid = a.vt.child[covc];
+                int cid = a.vt.child[covc];
+                if (AIS) {
+                    FLeafX gx;
+                    gx.f64 = (prom && in_chunk) ? 1 : 0; gx.pad = 0;
+                    double row[GKF];
+#pragma unroll
+                    for (int e = 0; e < GKF; ++e) row[e] = 0.0;
+                    if (gx.f64) {
+                        if (fl & F_COV_F64) {
+                            vt_load_gains64(a.vt, covc, row);
+                        } else {      // a float32 leaf of a promoted target: its covariance converted (found or inserted as a float64 value), its gains from there
+                            double P64[NP];
+                            cid = vt_promote(a.vt, cid, pd, P64);
+                            Model mg;
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) { mg.A[e] = a.model.A[e]; mg.Q[e] = a.model.Q[e]; }
+#pragma unroll
+                            for (int e = 0; e < NK; ++e) mg.C[e] = a.model.C[e];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) mg.R[e] = a.model.R[e];
+                            mg.eta2 = a.model.eta2; mg.lambda_ex = a.model.lambda_ex;
+                            vt_gains64(mg, P64, pd, row);
+                        }
+                        // (the float32 fields of the leaf's record feed the pre-filter box only)
+                        float* grw = reinterpret_cast<float*>(gr);
+                        grw[GK_RX] = (float)row[GK_RX]; grw[GK_RY] = (float)row[GK_RY];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gx.sinv[e] = row[e];
+#pragma unroll
+                    for (int e = 0; e < NK; ++e) gx.K[e] = row[4 + e];
+                    gx.lnc = row[GK_LNC];
+                    if (keep) lgx[tid] = gx;
+                }
                 g.valid = valid;
                 g.src = src;
                 g.flags = fl;
-                g.f32state = (fl & F_STATE_F32) ? 1 : 0;
+                g.f32state = ((fl & F_STATE_F32) && !(AIS && prom)) ? 1 : 0;
                 g.cn = cn;
                 g.pd = pd;
                 // records parked raw (the root advance `shift` is applied when they are read back); last real measurement on the path
@@ -646,7 +749,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             if (__builtin_amdgcn_readfirstlane((cnt == 1 || (d.maybe_dead && cnt > 1 && s_live == 1)) ? 1 : 0) && tid < n) {
                 const int src1 = first + c0 + tid;
                 const uint8_t fl1 = a.flags[src1];
-                if (!(fl1 & F_DEAD)) fg_single_leaf(a, src1, (fl1 & F_STATE_F32) != 0, lg[tid]);
+                if (!(fl1 & F_DEAD)) fg_single_leaf(a, src1, (fl1 & F_STATE_F32) != 0 && !(AIS && prom), lg[tid]);
             }
             // ---- phase 2 (a): measurements inside the target's box -> candidate list (ballot + one LDS atomic per wavefront) -----
             if (last >= 0) atomicOr(&tb[last >> 6], 1ull << (last & 63));      // (the bitset was cleared in front of the barrier)
@@ -689,6 +792,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                         if (g.f32state) {
                             float zh[2] = {(float)g.zhat[0], (float)g.zhat[1]}, zt[2], nis;
                             hit = gate_pair<float>(zh, g.sinv, mx, my, (float)a.model.eta2, zt, nis);
+                        } else if (AIS && lgx[l].f64) {
+                            double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
+                            hit = gate_pair<double>(zh, lgx[l].sinv, mx, my, a.model.eta2, zt, nis);
                         } else {
                             double zh[2] = {g.zhat[0], g.zhat[1]}, zt[2], nis;
                             hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
@@ -853,8 +959,15 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                         } else {
                             a.ais.ommsi[c] = 0;
                             a.ais.ohmmsi[c] = s_ais[l * 4 + 2];
+                            FLeafX gx;
+                            {
+                                const uint4* srcq = reinterpret_cast<const uint4*>(lgx + l);
+                                uint4* dstq = reinterpret_cast<uint4*>(&gx);
+#pragma unroll
+                                for (int q = 0; q < (int)(sizeof(FLeafX) / 16); ++q) dstq[q] = srcq[q];
+                            }
                             if (g.f32state) fg_emit_child<float, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                            else fg_emit_child<double, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                            else fg_emit_child<double, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, nullptr, nullptr, &gx);
                         }
                     } else if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                     else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
@@ -1341,7 +1454,7 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull}, reinterpret_cast<int*>(smem)); return; }
         bid -= 1;
     }
-    if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part<!LEAN>(*ap, d, bid - d.n_main); return; }
+    if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part<!LEAN, AIS>(*ap, d, bid - d.n_main); return; }
     if (CAP == 0) {          // wavefront-per-target variant: four targets per workgroup, each wavefront on its own LDS slice
         const int wave = threadIdx.x >> 6;
         const int t = bid * (FG_THREADS / 64) + wave;
@@ -1470,7 +1583,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArg
         constexpr int RQ = (int)sizeof(mht_target_report) / 16, RB = RQ - 1;
         if (d.adm_wait && d.c_wait) {      // overlapping launch: the rows are the previous scan's ILP launch's, which may still be running
             unsigned long long v;
-            if (!spin_until(&cm.cnt->blp_done, [&](unsigned long long x) { return x >= d.c_wait; }, v) && threadIdx.x == 0) atomicOr(&ap->status->pad[0], 1 << 5);
+            if (!spin_until(&cm.cnt->blp_done, [&](unsigned long long x) { return x >= d.c_wait; }, v) && threadIdx.x == 0) { ap->status->overflow = 2; atomicOr(&ap->status->pad[0], 1 << 5); }      // (gave up: the rows may be incomplete -- this scan is void and the forest dead, like every other wait that times out)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int nTr = ap->nT_dev[0];      // (rows of the report = slots of the uncommitted table)
@@ -1661,7 +1774,7 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
     }
     if (a.ais.half > 0) {      // AIS forest: its own kernel on every scan (records in two halves, identities per node)
         fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
-        const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP) + (size_t)FG_CAP * 16;
+        const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP) + (size_t)FG_CAP * (16 + sizeof(FLeafX));      // (+ s_ais, lgx)
         { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
         const bool pub = publish && publish->dst;
         const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);

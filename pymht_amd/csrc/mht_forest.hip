@@ -157,16 +157,31 @@ __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const Init
         __syncthreads();
         if (s_r != 0u) return;
     }
+    // A wait that gives up (spin_until: ~2 s) voids the scan like the commit's and the target workgroups' waits do: the initiator must not
+    // read a scan that is not staged or the used-measurement bytes of a grow launch that has not finished.  The sticky error word is set
+    // (the forest is dead, every later call reports MHT_E_CAPACITY-class failure) and nothing is initiated.
+    __shared__ int s_gave_up;
+    if (threadIdx.x == 0) s_gave_up = 0;
+    __syncthreads();
     if (z_tag) {      // (the scan's staging, see stage_scan_kernel)
         unsigned long long v;
-        if (!spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v) && threadIdx.x == 0 && dbg) { dbg[0] = 1; dbg[1] = v; dbg[2] = z_tag; dbg[3] = (unsigned)in.scan_no; }
+        if (!spin_until(z_flag, [&](unsigned long long x) { return x >= z_tag; }, v)) {
+            s_gave_up = 1;
+            if (threadIdx.x == 0 && dbg) { dbg[0] = 1; dbg[1] = v; dbg[2] = z_tag; dbg[3] = (unsigned)in.scan_no; }
+        }
     }
     if (begun) {      // on a queue of its own: nothing orders this launch behind the scan's grow launch but the word the scan's ILP launch posts when it starts
         unsigned long long v;
-        if (!spin_until(begun, [&](unsigned long long x) { return x >= (unsigned long long)(unsigned)in.scan_no; }, v) && threadIdx.x == 0 && dbg) { dbg[0] = 2; dbg[1] = v; dbg[2] = (unsigned)in.scan_no; dbg[3] = wall_clock64(); }
+        if (!spin_until(begun, [&](unsigned long long x) { return x >= (unsigned long long)(unsigned)in.scan_no; }, v)) {
+            s_gave_up = 1;
+            if (threadIdx.x == 0 && dbg) { dbg[0] = 2; dbg[1] = v; dbg[2] = (unsigned)in.scan_no; dbg[3] = wall_clock64(); }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (!((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
+    __syncthreads();
+    const bool gave_up = s_gave_up != 0;
+    if (gave_up && threadIdx.x == 0 && sticky_overflow) *const_cast<int32_t*>(sticky_overflow) = 2;
+    if (!gave_up && !((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
     if (done_flag) {      // the next scan's grow launch may be running already: its admission waits for this word (FCounts::init_flag)
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -180,7 +195,21 @@ __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const Init
 struct LeavesArgs {
     mht_nodes layer; TTable tab; const FCounts* cnt; VTab vt;
     int capacity; double* x; float* P; double* cnllr; int32_t* meas; int32_t* target; int32_t* id; int32_t* node; uint8_t* flags;
+    double* P64;      // != null (mht_forest_leaves_f64): every covariance as float64 -- exact for the float32 ones, the reference's own for F_COV_F64 leaves
 };
+// the covariance of node nd of a layer whose keys belong to table v, as float32 (P) or float64 (P64)
+__device__ __forceinline__ void export_cov(const VTab& v, int key, uint8_t fl, float* P, double* P64) {
+    const int id = v.child[key];
+    if (fl & F_COV_F64) {
+        double t[NP];
+        vt_load64(v, id, t);
+        for (int e = 0; e < NP; ++e) { if (P64) P64[e] = t[e]; if (P) P[e] = (float)t[e]; }
+    } else {
+        float t[NP];
+        vt_load(v, id, t);
+        for (int e = 0; e < NP; ++e) { if (P64) P64[e] = (double)t[e]; if (P) P[e] = t[e]; }
+    }
+}
 __global__ void leaves_kernel(const LeavesArgs a) {
     const int nT = a.cnt->nT;
     const int L = a.cnt->L < a.capacity ? a.cnt->L : a.capacity;
@@ -189,7 +218,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
         const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
         for (int k = 0; k < NX; ++k) a.x[i * NX + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
-        vt_load(a.vt, a.vt.child[a.layer.cov[nd]], a.P + (size_t)i * NP);
+        export_cov(a.vt, a.layer.cov[nd], a.layer.flags[nd], a.P ? a.P + (size_t)i * NP : nullptr, a.P64 ? a.P64 + (size_t)i * NP : nullptr);
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
@@ -199,7 +228,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
     }
 }
 
-struct ChainArgs { mht_nodes layers[MAXR]; VTab vt[2]; int lgen[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; };
+struct ChainArgs { mht_nodes layers[MAXR]; VTab vt[2]; int lgen[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; double* P64; uint8_t* flags; };
 __global__ void chain_kernel(const ChainArgs a) {
     if (threadIdx.x || blockIdx.x) return;
     int nd = a.node, sc = a.scan, n = 0;
@@ -210,7 +239,8 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.cnllr[n] = l.cnllr[nd];
         for (int k = 0; k < NX; ++k) a.x[n * NX + k] = l.x[(size_t)k * l.cap + nd];
         const VTab& v = a.vt[a.lgen[sc % a.R]];      // (the generation of the value table this layer's keys belong to)
-        vt_load(v, v.child[l.cov[nd]], a.P + (size_t)n * NP);
+        export_cov(v, l.cov[nd], l.flags[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
+        if (a.flags) a.flags[n] = l.flags[nd];
         ++n;
         nd = l.parent[nd];
         --sc;
@@ -261,7 +291,7 @@ struct Forest {
     int32_t* cl_owner;      // [Tcap] cluster-sharded step: device of every multi-target cluster (LPT by column count)
     // clustering inside the grow launch (mht_kernels.h: FDyn::uf_epoch): owner word per measurement node, parent word per target; uf_ok:
     // the ILP launch's workgroups can derive the cluster tables themselves (MHT_NO_UF=1: the clustering kernel on every scan, as before)
-    unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent = nullptr; bool uf_ok = false; int uf_scans = 0;
+    unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent2[2] = {nullptr, nullptr}; bool uf_ok = false; int uf_scans = 0;
     // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
     // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
     const float* z_stage_src = nullptr; int z_stage_n16 = 0, z_stage_slot = -1;      // the scan being stepped still sits in pinned host memory: the grow launch pulls it itself (FDyn::stage_src), or a staging kernel in front of it
@@ -399,7 +429,7 @@ struct Forest {
         cl_counts = ar.take<int32_t>(8); big_list = ar.take<int32_t>(Tcap);
         cl_owner = ar.take<int32_t>(Tcap);
         if (cluster_big) cl_gtab = ar.take<int32_t>(cluster_big_ints(Tcap, n_mnodes));
-        uf_owner = ar.take<unsigned long long>(n_mnodes); uf_parent = ar.take<unsigned long long>(Tcap); rec0 = ar.take<unsigned long long>(Tcap);
+        uf_owner = ar.take<unsigned long long>(n_mnodes); uf_parent2[0] = ar.take<unsigned long long>(Tcap); uf_parent2[1] = ar.take<unsigned long long>(Tcap); rec0 = ar.take<unsigned long long>(Tcap);
         team_list = ar.take<int32_t>(TEAM_MAX); team_state2[0] = ar.take<TeamState>(TEAM_MAX); team_state2[1] = ar.take<TeamState>(TEAM_MAX); team_res = ar.take<TeamResult>((size_t)TEAM_MAX * TEAM_W);
         // (TEAM_W copies of the ILP kernel's HBM scratch: a team member of a giant cluster works on its own, mht_blp.hip)
         u = ar.take<double>((size_t)n_mnodes * TEAM_W); usage = ar.take<int32_t>((size_t)n_mnodes * TEAM_W); mark = ar.take<int32_t>((size_t)n_mnodes * TEAM_W);
@@ -797,6 +827,9 @@ extern "C" int mht_forest_add_targets(mht_ctx* ctx, int32_t n, const double* x0,
     memcpy(h + o_m, meas, (size_t)n * 4); memcpy(h + o_f, flags, n);
     char* d = static_cast<char*>(f->stage_dev.ptr);
     MHT_HIP_CHECK(hipMemcpyAsync(d, h, o_id, hipMemcpyHostToDevice, ctx->stream));
+    // (ids = -1, accepted = 0 unless the admission says otherwise: the fused commit + admission launch skips the admission on a void scan)
+    MHT_HIP_CHECK(hipMemsetAsync(d + o_id, 0xff, (size_t)n * 4, ctx->stream));
+    MHT_HIP_CHECK(hipMemsetAsync(d + o_acc, 0, (size_t)n + 16, ctx->stream));
     rc = mht_forest_add_targets_dev(ctx, n, (const double*)(d + o_x), (const float*)(d + o_P), (const uint8_t*)(d + o_f),
                                     (const double*)(d + o_pd), (const int32_t*)(d + o_m), check_neighbours,
                                     (uint8_t*)(d + o_acc), (int32_t*)(d + o_id));
@@ -846,7 +879,8 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.used_bytes = f->used_bytes[s & 1];
     g.status = f->status2 + (s & 1); g.prev_status = f->status2 + ((s - 1) & 1); g.sticky_overflow = &f->cnt->overflow;
     g.rec0 = f->rec0; g.new_index = f->new_index; g.ni_flag = &f->cnt->ni_flag;
-    g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent; g.uf_team_state = f->teams ? f->team_state2[s & 1] : nullptr;
+    g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent2[s & 1];      // (by scan parity: the grow launch of scan s + 1 links while the ILP launch of scan s still reads)
+     g.uf_team_state = f->teams ? f->team_state2[s & 1] : nullptr;
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
@@ -900,7 +934,7 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     b.Nwin = f->cfg.n_scan; b.score_limit = f->cfg.score_limit; b.cnllr_limit = f->cfg.cnllr_limit;
     b.radar_x = f->cfg.radar_x; b.radar_y = f->cfg.radar_y; b.radar_range = f->cfg.radar_range;
     // (clusters from the grow launch's union-find: switched on per scan by the caller, b.uf_epoch = scan number)
-    b.uf_parent = f->uf_parent; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc2[s & 1];
+    b.uf_parent = f->uf_parent2[s & 1]; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc2[s & 1];
     b.t_cluster = f->t_cluster;
     { static int bs = -1; if (bs < 0) { const char* e = getenv("MHT_BLP_STAMPS"); bs = (e && e[0] == '1') ? 1 : 0; } b.dbg = (bs && f->debug) ? f->grow_dbg : nullptr; }
 }
@@ -951,14 +985,24 @@ __global__ __launch_bounds__(256) void vt_rebuild_kernel(const RebuildArgs a) {
         const int k_old = a.layer.cov[nd];
         int k_new = __hip_atomic_load(&a.remap[k_old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k_new < 0) {
+            int mine;
+            if (a.layer.flags[nd] & F_COV_F64) {      // a float64 value: two ids, gains in the rows of the key and of its twin (mht_vtab.h)
+                double P[NP], row[GKF];
+                vt_load64(a.from, a.from.child[k_old], P);
+                const int id = vt_find_or_insert64(a.to, P, a.layer.pd[nd]);
+                vt_load_gains64(a.from, k_old, row);
+                mine = vt_pseudo_key64(a.to, id, row);
+                if (*a.to.overflow) continue;
+            } else {
             float P[NP];
             vt_load(a.from, a.from.child[k_old], P);
             const int id = vt_find_or_insert(a.to, P, a.layer.pd[nd]);
             const unsigned pid = atomicAdd(a.to.count, 1u);      // a pseudo parent, as for a root: its miss child is the leaf's value
             if (pid >= (unsigned)a.to.vcap) { *a.to.overflow = 1; continue; }
-            const int mine = 2 * (int)pid;
+            mine = 2 * (int)pid;
             for (int q = 0; q < GKQ; ++q) a.to.Gk[(size_t)mine * GKQ + q] = a.from.Gk[(size_t)k_old * GKQ + q];
             a.to.child[mine] = id;
+            }
             int expected = -1;
             k_new = __hip_atomic_compare_exchange_strong(&a.remap[k_old], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? mine : expected;
         }
@@ -1804,7 +1848,9 @@ static int report_wait(Forest* f, int slot) {
         bool all = true;
         for (int q = 0; q < PUB_DONE_WORDS; ++q) all = all && (w[q] == tag);
         if (all) break;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((spins & 0xfff) == 0xfff) {
             timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 10.0) { set_error("mht_forest_report_get: the report of the host block did not arrive within 10 s"); f->dead = true; return MHT_E_HIP; }
@@ -1878,8 +1924,9 @@ extern "C" int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold) {
     return MHT_OK;
 }
 
-extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
-                                 int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
+// PB = bytes per covariance entry of the export: 4 (mht_forest_leaves) or 8 (mht_forest_leaves_f64: exact for both kinds of value)
+static int forest_leaves_impl(mht_ctx* ctx, int32_t capacity, double* x, void* P, int PB, double* cnllr, int32_t* meas,
+                              int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
     MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_leaves: null argument");
     Forest* f = ctx->forest;
     MHT_REQUIRE(capacity >= 0, "mht_forest_leaves: negative capacity");
@@ -1891,7 +1938,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     *n_out = c.L;
     const int n = c.L < capacity ? c.L : capacity;
     if (n == 0) return MHT_OK;
-    const size_t o_x = 0, o_c = o_x + (size_t)n * (NX * 8), o_P = o_c + (size_t)n * 8, o_m = o_P + (size_t)n * (NP * 4),
+    const size_t o_x = 0, o_c = o_x + (size_t)n * (NX * 8), o_P = o_c + (size_t)n * 8, o_m = o_P + (size_t)n * ((size_t)NP * PB),
                  o_t = o_m + (size_t)n * 4, o_i = o_t + (size_t)n * 4, o_n = o_i + (size_t)n * 4, o_f = o_n + (size_t)n * 4,
                  total = o_f + n + 16;
     int rc = stage_host_ensure(f, total);
@@ -1902,8 +1949,8 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     char* h = static_cast<char*>(f->stage_host);
     const int nb = (f->scan + 1) & 1;
     LeavesArgs a = {f->layer[f->scan % f->R], f->tab[nb], f->cnt, f->vt, n,
-                    (double*)(d + o_x), (float*)(d + o_P), (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
-                    (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f)};
+                    (double*)(d + o_x), PB == 4 ? (float*)(d + o_P) : nullptr, (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
+                    (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f), PB == 8 ? (double*)(d + o_P) : nullptr};
     hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
@@ -1916,7 +1963,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
         if (live != i) {
             memmove(h + o_x + (size_t)live * (NX * 8), h + o_x + (size_t)i * (NX * 8), NX * 8);
             memmove(h + o_c + (size_t)live * 8, h + o_c + (size_t)i * 8, 8);
-            memmove(h + o_P + (size_t)live * (NP * 4), h + o_P + (size_t)i * (NP * 4), NP * 4);
+            memmove(h + o_P + (size_t)live * ((size_t)NP * PB), h + o_P + (size_t)i * ((size_t)NP * PB), (size_t)NP * PB);
             memmove(h + o_m + (size_t)live * 4, h + o_m + (size_t)i * 4, 4);
             memmove(h + o_t + (size_t)live * 4, h + o_t + (size_t)i * 4, 4);
             memmove(h + o_i + (size_t)live * 4, h + o_i + (size_t)i * 4, 4);
@@ -1928,7 +1975,7 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     *n_out = c.L - (n - live);
     if (x) memcpy(x, h + o_x, (size_t)live * (NX * 8));
     if (cnllr) memcpy(cnllr, h + o_c, (size_t)live * 8);
-    if (P) memcpy(P, h + o_P, (size_t)live * (NP * 4));
+    if (P) memcpy(P, h + o_P, (size_t)live * ((size_t)NP * PB));
     if (meas) memcpy(meas, h + o_m, (size_t)live * 4);
     if (target) memcpy(target, h + o_t, (size_t)live * 4);
     if (id) memcpy(id, h + o_i, (size_t)live * 4);
@@ -1937,8 +1984,17 @@ extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, floa
     return MHT_OK;
 }
 
-extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
-                                double* x, double* cnllr, float* P, int32_t* n_out) {
+extern "C" int mht_forest_leaves(mht_ctx* ctx, int32_t capacity, double* x, float* P, double* cnllr, int32_t* meas,
+                                 int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
+    return forest_leaves_impl(ctx, capacity, x, P, 4, cnllr, meas, target, id, node, flags, n_out);
+}
+extern "C" int mht_forest_leaves_f64(mht_ctx* ctx, int32_t capacity, double* x, double* P, double* cnllr, int32_t* meas,
+                                     int32_t* target, int32_t* id, int32_t* node, uint8_t* flags, int32_t* n_out) {
+    return forest_leaves_impl(ctx, capacity, x, P, 8, cnllr, meas, target, id, node, flags, n_out);
+}
+
+static int forest_chain_impl(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                             double* x, double* cnllr, void* P, int PB, uint8_t* flags, int32_t* n_out) {
     MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_chain: null argument");
     Forest* f = ctx->forest;
     MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R, "mht_forest_chain: scan %d is outside the window", scan);
@@ -1949,7 +2005,7 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     const int avail = f->R - (f->scan - scan);   // layers still in the ring going backwards
     if (len > avail) len = avail;
     const size_t o_n = 0, o_m = o_n + (size_t)len * 4, o_x = (o_m + (size_t)len * 4 + 7) & ~(size_t)7, o_c = o_x + (size_t)len * (NX * 8),
-                 o_P = o_c + (size_t)len * 8, o_k = o_P + (size_t)len * (NP * 4), total = o_k + 16;
+                 o_P = o_c + (size_t)len * 8, o_fl = o_P + (size_t)len * ((size_t)NP * PB), o_k = (o_fl + (size_t)len + 7) & ~(size_t)7, total = o_k + 16;
     int rc = stage_host_ensure(f, total);
     if (rc) return rc;
     rc = f->stage_dev.ensure(total);
@@ -1961,7 +2017,7 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     a.vt[0] = f->vts[0]; a.vt[1] = f->vts[1];
     a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
     a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
-    a.P = (float*)(d + o_P); a.n_out = (int32_t*)(d + o_k);
+    a.P = PB == 4 ? (float*)(d + o_P) : nullptr; a.P64 = PB == 8 ? (double*)(d + o_P) : nullptr; a.flags = (uint8_t*)(d + o_fl); a.n_out = (int32_t*)(d + o_k);
     hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
@@ -1972,8 +2028,17 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
     if (meas) memcpy(meas, h + o_m, (size_t)n * 4);
     if (x) memcpy(x, h + o_x, (size_t)n * (NX * 8));
     if (cnllr) memcpy(cnllr, h + o_c, (size_t)n * 8);
-    if (P) memcpy(P, h + o_P, (size_t)n * (NP * 4));
+    if (P) memcpy(P, h + o_P, (size_t)n * ((size_t)NP * PB));
+    if (flags) memcpy(flags, h + o_fl, (size_t)n);
     return MHT_OK;
+}
+extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                                double* x, double* cnllr, float* P, int32_t* n_out) {
+    return forest_chain_impl(ctx, scan, node, max_len, nodes, meas, x, cnllr, P, 4, nullptr, n_out);
+}
+extern "C" int mht_forest_chain_f64(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
+                                    double* x, double* cnllr, double* P, uint8_t* flags, int32_t* n_out) {
+    return forest_chain_impl(ctx, scan, node, max_len, nodes, meas, x, cnllr, P, 8, flags, n_out);
 }
 
 extern "C" int mht_forest_set_timing(mht_ctx* ctx, int32_t enable) {

@@ -232,8 +232,9 @@ MHT_HD float nllr_const(const float* S, double lambda_ex, double P_d) {
 }
 
 // kalman.py:36-40 + :25-28 + tracker.py:829 for one (leaf, measurement) pair.
-template <typename TS>
-MHT_HD bool gate_pair(const TS* z_hat, const float* S_inv, float zx, float zy, TS eta2, TS* zt, TS& nis) {
+// (TG: float32 gains, or the float64 ones of a target NumPy has promoted -- mht_la64.h)
+template <typename TS, typename TG = float>
+MHT_HD bool gate_pair(const TS* z_hat, const TG* S_inv, float zx, float zy, TS eta2, TS* zt, TS& nis) {
     zt[0] = (TS)zx - z_hat[0];
     zt[1] = (TS)zy - z_hat[1];
     TS t0 = fmaT(zt[1], (TS)S_inv[2], zt[0] * (TS)S_inv[0]);
@@ -258,8 +259,8 @@ MHT_HD TS update_component_single(TS x_bar_i, float k0, float k1, const TS* zt) 
 // either order from one multiply and one FMA (the kernels' emission is at the edge of its register budget: no second code path).
 // gemm: fma(k1, z1, k0 * z0).  gemv, float64: fma(k0, z0, k1 * z1); float32: k0 * z0 + k1 * z1 = fma(1, k0 * z0, k1 * z1) -- exact product
 // of 1 and an already rounded number, so the FMA rounds once, like the addition.
-template <typename TS>
-MHT_HD TS update_component_n(TS x_bar_i, float k0, float k1, const TS* zt, bool single_hit) {
+template <typename TS, typename TG = float>
+MHT_HD TS update_component_n(TS x_bar_i, TG k0, TG k1, const TS* zt, bool single_hit) {
     const TS p = single_hit ? (TS)k1 * zt[1] : (TS)k0 * zt[0];
     TS a = single_hit ? (TS)k0 : (TS)k1, b = single_hit ? zt[0] : zt[1];
     if (sizeof(TS) == 4 && single_hit) { a = (TS)1; b = (TS)k0 * zt[0]; }
@@ -358,7 +359,9 @@ enum : uint8_t {
     F_STATE_F32 = 1,   // state chain (x, z_hat, z_tilde, NIS, NLLR) is float32: tracks born from the initiator
     F_SCORE_F32 = 2,   // cumulativeNLLR currently holds a float32 value (all-hit path from an int-0 root)
     F_SCORE_INT0 = 4,  // cumulativeNLLR is the Python int 0 of a fresh root (weak scalar)
-    F_DEAD = 8         // taken out of the tree by similar-state pruning (mht_similar.hip): the slot stays, the hypothesis is gone
+    F_DEAD = 8,        // taken out of the tree by similar-state pruning (mht_similar.hip): the slot stays, the hypothesis is gone
+    F_COV_F64 = 16     // the covariance is float64 (AIS forests: an AIS-updated node, or a child of a batch NumPy promoted because one of its
+                       // members was -- models/ais.py:4, tracker.py:859-870): the node's key names a float64 value (mht_vtab.h)
 };
 
 }  // namespace mht

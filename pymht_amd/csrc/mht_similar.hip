@@ -30,14 +30,20 @@ __device__ __forceinline__ bool is_near(const SimilarArgs& a, int g, float p0x, 
     return d < a.thr;
 }
 
-template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarArgs& a, int t, int h, int ce, int n, float p0x, float p0y) {
+// TP: the dtype of the children's covariance -- float32, or the float64 of a promoted target (AIS forests, mht_vtab.h: F_COV_F64; the hit
+// children of one node share their dtypes, np.mean works in the array's)
+__device__ __forceinline__ void sim_load(const VTab& vt, int id, float* P) { vt_load(vt, id, P); }
+__device__ __forceinline__ void sim_load(const VTab& vt, int id, double* P) { vt_load64(vt, id, P); }
+__device__ __forceinline__ bool sim_same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool sim_same(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+template <typename TS, typename TP> __device__ __forceinline__ void fuse_group(const SimilarArgs& a, int t, int h, int ce, int n, float p0x, float p0y) {
     const size_t cap = a.cap;
     TS xs[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) xs[k] = (TS)0;
-    float Ps[NP], P1[NP];
+    TP Ps[NP], P1[NP];
 #pragma unroll
-    for (int e = 0; e < NP; ++e) Ps[e] = 0.f;
+    for (int e = 0; e < NP; ++e) Ps[e] = (TP)0;
     int first = -1, i = 0;
     uint8_t fl = 0;
     bool score_f32 = false;
@@ -46,8 +52,8 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
         if (a.mmsi && a.mmsi[g] != 0) break;      // (fused children come behind the radar children and are never merged)
         if (!is_near(a, g, p0x, p0y)) continue;
         const uint8_t fg = a.flags[g];
-        float P[NP];
-        vt_load(a.vt, a.vt.child[a.cov[g]], P);
+        TP P[NP];
+        sim_load(a.vt, a.vt.child[a.cov[g]], P);
         if (first < 0) {
             first = g; fl = fg;
             score_f32 = (fg & F_SCORE_F32) != 0;      // (the hit children of one node share their dtypes)
@@ -73,27 +79,39 @@ template <typename TS> __device__ __forceinline__ void fuse_group(const SimilarA
     bool same = true;
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
-        Ps[e] = __fdiv_rn(Ps[e], (float)n);
-        same = same && (__float_as_uint(Ps[e]) == __float_as_uint(P1[e]));
+        Ps[e] = div_rn(Ps[e], (TP)n);
+        same = same && sim_same(Ps[e], P1[e]);
     }
     const double cn = score_f32 ? (double)__fdiv_rn(sf.res, (float)n) : sd.res / (double)n;
     a.cnllr[h] = cn;
-    const uint8_t mfl = (uint8_t)(fl & (F_STATE_F32 | F_SCORE_F32));
+    const uint8_t mfl = (uint8_t)(fl & (F_STATE_F32 | F_SCORE_F32 | F_COV_F64));
     a.flags[h] = mfl;
     if (same) {
         a.cov[h] = a.cov[first];
     } else {
         const double pd = a.pd[h];
-        const int id0 = vt_find_or_insert(a.vt, Ps, pd);
-        const unsigned pid = atomicAdd(a.vt.count, 1u);      // a key of its own: a pseudo parent whose miss child is the mean
-        if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; return; }
-        const int key = 2 * (int)pid;
-        float4 rec[GKQ];
-        vt_gains(a.model, Ps, pd, rec);
+        if (sizeof(TP) == 8) {      // a float64 mean: two ids for the value, two for its pseudo parent (mht_vtab.h)
+            double P64[NP], row[GKF];
 #pragma unroll
-        for (int e = 0; e < GKQ; ++e) a.vt.Gk[(size_t)key * GKQ + e] = rec[e];
-        a.vt.child[key] = id0;
-        a.cov[h] = key;
+            for (int e = 0; e < NP; ++e) P64[e] = (double)Ps[e];
+            const int id0 = vt_find_or_insert64(a.vt, P64, pd);
+            vt_gains64(a.model, P64, pd, row);
+            a.cov[h] = vt_pseudo_key64(a.vt, id0, row);
+        } else {
+            float P32[NP];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) P32[e] = (float)Ps[e];
+            const int id0 = vt_find_or_insert(a.vt, P32, pd);
+            const unsigned pid = atomicAdd(a.vt.count, 1u);      // a key of its own: a pseudo parent whose miss child is the mean
+            if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; return; }
+            const int key = 2 * (int)pid;
+            float4 rec[GKQ];
+            vt_gains(a.model, P32, pd, rec);
+#pragma unroll
+            for (int e = 0; e < GKQ; ++e) a.vt.Gk[(size_t)key * GKQ + e] = rec[e];
+            a.vt.child[key] = id0;
+            a.cov[h] = key;
+        }
     }
     // its ILP cost, like any child's (fgrow_kernel; nothing reads it before the next scan overwrites the array, kept consistent)
     const double rootc = a.t_root_cnllr[t];
@@ -118,8 +136,11 @@ __global__ __launch_bounds__(256) void prune_similar_kernel(const SimilarArgs a)
             int n = 0;
             for (int g = h + 1; g < ce && a.meas[g] > 0 && !(a.mmsi && a.mmsi[g] != 0); ++g) n += is_near(a, g, p0x, p0y) ? 1 : 0;
             if (n == 0) continue;
-            if (a.flags[h] & F_STATE_F32) fuse_group<float>(a, t, h, ce, n, p0x, p0y);
-            else fuse_group<double>(a, t, h, ce, n, p0x, p0y);
+            // (dtypes of the HIT children: a promoted target's are float64 throughout, mht_fgrow.hip)
+            const uint8_t fh = a.flags[h];
+            if (fh & F_COV_F64) fuse_group<double, double>(a, t, h, ce, n, p0x, p0y);
+            else if (fh & F_STATE_F32) fuse_group<float, float>(a, t, h, ce, n, p0x, p0y);
+            else fuse_group<double, float>(a, t, h, ce, n, p0x, p0y);
         }
     }
 }

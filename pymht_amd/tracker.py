@@ -41,6 +41,7 @@ def _report_dtypes(nx):
 _REPORT_DTYPE, _BIRTH_DTYPE = _report_dtypes(4)
 assert _REPORT_DTYPE.itemsize == C.sizeof(_lib.MhtTargetReport) and _BIRTH_DTYPE.itemsize == C.sizeof(_lib.MhtBirthReport)
 assert _report_dtypes(6)[0].itemsize == C.sizeof(_lib.MhtTargetReport6) and _report_dtypes(6)[1].itemsize == C.sizeof(_lib.MhtBirthReport6)
+_F_COV_F64 = 16      # include/mht_amd.h: MHT_F_COV_F64
 _STATUS_TAG = {0: activeTag, 1: outofrangeTag, 2: toolowscoreTag, 3: toolowscoreTag}
 
 
@@ -662,9 +663,15 @@ class Tracker():
         meas = np.zeros(n_max, dtype=np.int32)
         x = np.zeros((n_max, self.nx))
         cn = np.zeros(n_max)
-        P = np.zeros((n_max, self.nx * self.nx), dtype=np.float32)
         n = C.c_int32(0)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
+        if self._ais:      # covariances in the dtype the reference gives every node: float64 behind an AIS update (MHT_F_COV_F64), float32 otherwise
+            P64 = np.zeros((n_max, self.nx * self.nx))
+            fl = np.zeros(n_max, dtype=np.uint8)
+            _lib.check(self._lib.mht_forest_chain_f64(self._ctx.handle, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P64), p(fl), C.byref(n)))
+            k = n.value
+            return nodes[:k], meas[:k], x[:k], cn[:k], [P64[i] if (fl[i] & _F_COV_F64) else P64[i].astype(np.float32) for i in range(k)]
+        P = np.zeros((n_max, self.nx * self.nx), dtype=np.float32)
         _lib.check(self._lib.mht_forest_chain(self._ctx.handle, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P), C.byref(n)))
         k = n.value
         return nodes[:k], meas[:k], x[:k], cn[:k], P[:k]
@@ -728,17 +735,21 @@ class Tracker():
 
     def _leaf_export(self, cap):
         n = C.c_int32(0)
-        x = np.zeros((cap, self.nx)); P = np.zeros((cap, self.nx * self.nx), dtype=np.float32); cn = np.zeros(cap)
+        x = np.zeros((cap, self.nx)); cn = np.zeros(cap)
+        P = np.zeros((cap, self.nx * self.nx), dtype=np.float64 if self._ais else np.float32)
         meas = np.zeros(cap, dtype=np.int32); tgt = np.zeros(cap, dtype=np.int32); ids = np.zeros(cap, dtype=np.int32)
         node = np.zeros(cap, dtype=np.int32); fl = np.zeros(cap, dtype=np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.mht_forest_leaves(self._ctx.handle, cap, p(x), p(P), p(cn), p(meas), p(tgt), p(ids), p(node), p(fl), C.byref(n)))
+        # (AIS forest: every covariance as float64 -- exact for the float32 ones; "Pf64" tells which leaves the reference carries in float64)
+        export = self._lib.mht_forest_leaves_f64 if self._ais else self._lib.mht_forest_leaves
+        _lib.check(export(self._ctx.handle, cap, p(x), p(P), p(cn), p(meas), p(tgt), p(ids), p(node), p(fl), C.byref(n)))
         if n.value > cap and cap < self._cfg.max_nodes:
             return None      # (more leaves than the estimate -- the export is truncated to the capacity: the caller retries with the full one)
         k = min(n.value, cap)
         out = dict(x=x[:k], P=P[:k].reshape(k, self.nx, self.nx), cnllr=cn[:k], meas=meas[:k], target=tgt[:k], ID=ids[:k],
                    node=node[:k], flags=fl[:k])
         if self._ais:      # identities; a node with one and no radar measurement gets meas = -1 (measurementNumber None)
+            out["Pf64"] = (out["flags"] & _F_COV_F64) != 0
             scan = len(self.__scanHistory__)
             out["mmsi"] = self._mmsi_layer(scan)[0][out["node"]].astype(np.int64) if scan > 0 else np.zeros(k, dtype=np.int64)
             out["meas"] = np.where((out["meas"] == 0) & (out["mmsi"] != 0), -1, out["meas"]).astype(np.int32)
@@ -760,7 +771,8 @@ class Tracker():
             m, mmsi = int(snap["meas"][i]), None
             if self._ais and int(snap["mmsi"][i]):
                 mmsi, m = int(snap["mmsi"][i]), (m if m > 0 else None)
-            v = DeviceTarget(t, scan, snap["x"][i].copy(), snap["P"][i].copy(), ID=root.ID, P_d=self.default_P_d,
+            Pi = snap["P"][i].copy() if (not self._ais or snap["Pf64"][i]) else snap["P"][i].astype(np.float32)
+            v = DeviceTarget(t, scan, snap["x"][i].copy(), Pi, ID=root.ID, P_d=self.default_P_d,
                              measurementNumber=m, mmsi=mmsi, cumulativeNLLR=float(snap["cnllr"][i]))
             v._tracker, v._node = self, int(snap["node"][i])
             v._lazy_parent = self._make_parent_loader(root.ID)

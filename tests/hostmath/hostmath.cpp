@@ -127,3 +127,20 @@ extern "C" int mht_host_fuse_ais(const float* Cm, const float* R, double eta2, d
     }
     return ais_fuse_leaf<double>(m, g, nG, ms, x, P, pd, own, eta2_ais, lambda_ais, z, M, e);
 }
+
+// ---- float64 covariance chain of a promoted target (csrc/mht_la64.h): against the reference's kalman.predict / precalc on float64 batches
+extern "C" void mht_host_cov_chain64(const float* A, const float* Q, const float* C, const float* R, int n, const double* P,
+                                     double* P_bar, double* P_hat, double* S, double* S_inv, double* K) {
+    Model m;
+    memset(&m, 0, sizeof(m));
+    memcpy(m.A, A, 64); memcpy(m.Q, Q, 64); memcpy(m.C, C, 32); memcpy(m.R, R, 16);
+    for (int i = 0; i < n; ++i) {
+        CovChain64 c;
+        cov_chain64(m, P + i * 16, c);
+        memcpy(P_bar + i * 16, c.P_bar, 128); memcpy(P_hat + i * 16, c.P_hat, 128);
+        memcpy(S + i * 4, c.S, 32); memcpy(S_inv + i * 4, c.S_inv, 32); memcpy(K + i * 8, c.K, 64);
+    }
+}
+extern "C" double mht_host_inv_lapack(int n, const double* s, double* out) {
+    return n == 2 ? inv_lapack<2>(s, out) : inv_lapack<4>(s, out);
+}
