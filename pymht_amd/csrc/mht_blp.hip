@@ -1469,7 +1469,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
 struct TgtPre { int j, rscan, rnode, id, lab, cb, ce; double rootc; uint8_t rootf; };
 __device__ __forceinline__ TgtPre load_target(const BlpArgs& a, int t) {
     TgtPre p;
-    const int dg = a.t_depth[t] + 1, w = a.t_window[t];
+    const int dg = a.t_depth[t] + 1, w = a.t_window[t] & 0xff;      // (bits 8..: mht_kernels.h WIN_REBUILT_*)
     p.j = dg > w ? dg - w : 0;             // layers the root advances (pyTarget.pruneDepth)
     p.rscan = a.t_root_scan[t]; p.rnode = a.t_root_node[t]; p.id = a.t_id[t]; p.lab = a.t_label[t];
     p.cb = a.tchild[t]; p.ce = a.tcend[t];

@@ -203,7 +203,7 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
             __hip_atomic_store(&a.new_index[t], al ? pos : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (written through: read by the launch's other workgroups, see ni_flag)
             if (al) {
                 a.nxt.id[pos] = id;
-                a.nxt.window[pos] = win;
+                a.nxt.window[pos] = (j > 0) ? ((win & 0xff) | (WIN_REBUILT_ALL << WIN_REBUILT_SHIFT)) : win;      // (the root advanced: the reference rebuilds the target's association set from its tree, tracker.py:1222-1227)
                 a.nxt.depth[pos] = dep + 1 - j;
                 a.nxt.shift[pos] = j;
                 a.nxt.root_scan[pos] = rs;

@@ -547,6 +547,12 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
         for (int i = tid; i < ti.cnt; i += FG_THREADS) { const uint8_t f = a.flags[ti.first + i]; anyf |= ((f & F_COV_F64) && !(f & F_DEAD)) ? 1 : 0; }
         prom = __syncthreads_or(anyf) != 0;
     }
+    // AIS forest: tree levels (below the root this scan runs on) the target's association set has been rebuilt from
+    int rebuilt_levels = 0;
+    if (AIS) {
+        const int rl = born ? 0 : (a.ais.t_window[tc] >> WIN_REBUILT_SHIFT) & 0xff;
+        rebuilt_levels = (ti.shift > 0 || rl == WIN_REBUILT_ALL) ? (1 << 20) : rl;      // (shift > 0: the root advanced in the scan before -- that commit may still be pending)
+    }
     for (int w = tid; w < AW; w += FG_THREADS) tb[w] = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -678,6 +684,12 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 if (AIS) {
                     if (nfv < offv) last = -1;          // (a deeper AIS-only level: the radar row further up belongs to an ancestor's own all-miss leaf)
                     if (offv < nfv) last2 = -1;
+                    // A target whose root has not advanced yet still carries the association set spawnNewNodes built incrementally -- which never
+                    // takes a fused child's RADAR measurement (pyTarget.py:292-295: only (scan, mmsi)); the set is rebuilt from the tree, fused
+                    // children's radar measurements included, when the root advances (tracker.py:1222-1227, pyTarget.py:414-430; every scan from
+                    // the first time on) or similar-state pruning meets the target alone in its cluster (tracker.py:1233-1239).  A fused level the
+                    // last rebuild has not seen gives its AIS row only (rebuilt_levels: mht_kernels.h WIN_REBUILT_*).
+                    if (nfv == offv && nfv > 0 && nfv > rebuilt_levels) last = -1;
                     nfv = 0; offv = 0;
                     if (valid && d.ais_on) { nfv = a.ais.nf[src]; offv = a.ais.off[src]; }
                     if (keep) { s_ais[tid * 4] = nfv; s_ais[tid * 4 + 1] = offv; s_ais[tid * 4 + 2] = a.ais.hmmsi_in[src]; s_ais[tid * 4 + 3] = 0; }

@@ -884,6 +884,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
+        g.ais.t_window = f->tab[fused ? ((s - 1) & 1) : cb].window;
     }
 }
 
@@ -952,6 +953,7 @@ static void fill_similar(const Forest* f, int s, SimilarArgs& a) {
     a.thr = f->prune_thr;
     a.status = f->status2 + (s & 1);
     a.mmsi = f->ais ? f->l_mmsi[s % f->R] : nullptr;
+    if (f->ais) { a.t_window = f->tab[cb].window; a.t_depth = f->tab[cb].depth; }
 }
 
 // N-scan prune (tracker.py:256-259), target side: surviving leaf ranges -> target table / roots / report, for scan s

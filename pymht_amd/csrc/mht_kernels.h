@@ -54,7 +54,16 @@ struct AisGrow {
     const int32_t* hmmsi_in;                                       // input layer
     int32_t* ommsi; int32_t* ohmmsi;                               // output layer
     int half;                                                      // levels per half of a path record (0: not an AIS forest)
+    // the window column of the target table the scan runs on (fused launch: the uncommitted one, by old slot): bits 8.. = levels of the
+    // target's tree its association set has been REBUILT from (mht_commit.h: WIN_REBUILT; pyTarget.py:292-295 vs :414-430)
+    const int32_t* t_window;
 };
+// The window column of the target table: bits 0-7 = the target's N-scan window; bits 8-15 = RL, the number of tree levels below the root
+// that the reference's association set of the target has been rebuilt from (Target.getMeasurementSet, tracker.py:1226 / :1238): 0 for a
+// target whose set is still the one spawnNewNodes built incrementally -- it lacks the radar measurements of fused children,
+// pyTarget.py:292-295 -- WIN_REBUILT_ALL once the root has advanced (rebuilt at the end of every scan from then on), the children's level
+// + 1 when similar-state pruning rebuilt it for a target alone in its cluster (tracker.py:1233-1239).  Only AIS forests look at RL.
+constexpr int WIN_REBUILT_SHIFT = 8, WIN_REBUILT_ALL = 255;
 
 // fgrow_kernel (mht_fgrow.hip): the grow stage of the forest, one workgroup per target + covariance-chain workgroups
 struct FGrowArgs {
@@ -289,6 +298,7 @@ struct SimilarArgs {
     float thr;                                              // Tracker.pruneThreshold (tracker.py:117), compared in float32
     const DevStatus* status;
     const int32_t* mmsi;                                    // AIS forest: children updated with an AIS message are not merged (pyTarget.py:371-375), else null
+    int32_t* t_window; const int32_t* t_depth;              // AIS forest (else null): the table the scan ran on -- the lone targets' association sets are rebuilt from their trees (WIN_REBUILT_*)
 };
 
 // forest_ais_kernel (mht_ais.hip): the fused children of every leaf of the newest layer, in front of the grow launch of a scan with AIS messages

@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256) void prune_similar_kernel(const SimilarArgs a)
     const int lane = threadIdx.x & 63, nw = gridDim.x * (blockDim.x >> 6);
     for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < nSingle; i += nw) {
         const int t = a.single_list[i];
+        // (AIS forest: the reference rebuilds the association set of every target that is alone in its cluster from its tree here,
+        // tracker.py:1233-1239 -- the children of this scan included; mht_kernels.h: WIN_REBUILT_*)
+        if (a.t_window && lane == 0) {
+            const int w = a.t_window[t];
+            if ((w >> WIN_REBUILT_SHIFT) != WIN_REBUILT_ALL) a.t_window[t] = (w & 0xff) | ((a.t_depth[t] + 1) << WIN_REBUILT_SHIFT);
+        }
         const int cb = a.tchild[t], ce = a.tcend[t];
         for (int h = cb + lane; h < ce; h += 64) {
             if (a.meas[h] != 0) continue;              // (a node's children start with its missed-detection child)

@@ -50,6 +50,26 @@ class DeviceTarget(Target):
     _tracker = None
     _node = -1
     _hist_mmsi = None      # AIS forest: the identity the node's track is bound to, as the device keeps it per node
+    _P_lazy = False        # the covariance handed to the constructor is a placeholder: the node's own is fetched from the device when somebody reads it
+    _P = None
+
+    @property
+    def P_0(self):
+        if self._P_lazy:
+            self._P_lazy = False
+            t = self._tracker
+            if t is not None and self._node >= 0 and self.scanNumber is not None and 0 <= len(t.__scanHistory__) - self.scanNumber < t._cfg.n_scan + 4:
+                try:
+                    P = t._window_chain(self.scanNumber, self._node)[4]
+                    if len(P):
+                        self._P = np.array(P[0]).reshape(t.nx, t.nx)
+                except _lib.MhtError:
+                    pass      # (the node has left the device ring: the placeholder stays)
+        return self._P
+
+    @P_0.setter
+    def P_0(self, value):
+        self._P, self._P_lazy = value, False
 
     def _getHistoricalMmsi(self):
         """pyTarget.py:297-302; the device carries the answer with every node (own identity, else the nearest AIS-updated ancestor's)."""
@@ -547,6 +567,7 @@ class Tracker():
                             measurementNumber=m, measurement=(z[m - 1] if m else None), mmsi=mmsi,
                             cumulativeNLLR=float(r["sel_cnllr"]), status=_STATUS_TAG[int(r["status"])])
         node._tracker, node._node, node._hist_mmsi = self, int(r["sel_node"]), hist
+        node._P_lazy = int(r["sel_node"]) >= 0
         node._lazy_parent = self._make_parent_loader(int(r["id"]))
         return node
 

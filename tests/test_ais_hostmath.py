@@ -44,4 +44,4 @@ def test_fusion_matches_reference_vectors(gold_dir, hostmath):
         a, b = int(c["ptr"][0]), int(c["ptr"][1])
         assert n_own == int((c["out_mmsi"][a:b] == own).sum())
     assert total == 590
-    print("worst relative state difference", worst)
+    print("worst score difference", worst)

@@ -35,13 +35,17 @@ def test_fuzz_slice_with_similar_state_pruning():
 
 def test_fuzz_slice_ais_aided():
     """AIS-aided tracking (tracker.py:417-552) on random scenarios with random AIS traffic, against the live oracle: decisions exact,
-    states 1e-6 (fuzz_util.run_case_ais)."""
+    states and covariances of all leaves bit for bit (fuzz_util.run_case_ais).  The first five seeds are the ones round 4's campaign
+    recorded against the float32 covariances the forest carried then (profiles/r04_fuzz_campaigns.txt): 1948 flipped a gate decision,
+    889 / 1412 / 2055 / 1331 drifted past the tolerances of the time."""
     from fuzz_util import run_case_ais
     n = int(os.environ.get("MHT_FUZZ_AIS_CASES", "60"))
     seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000")) + 900000
     bad, fused = [], 0
-    for case in range(n):
-        ok, desc, msg = run_case_ais(seed0 + case, max_leaves=1500, budget_s=8.0)
+    named = [1948, 889, 1412, 2055, 1331]
+    for seed in named + [seed0 + case for case in range(n)]:
+        # (the named seeds with the campaign's own limits: their differences showed in scans of several thousand leaves)
+        ok, desc, msg = run_case_ais(seed) if seed in named else run_case_ais(seed, max_leaves=1500, budget_s=8.0)
         if not ok:
             bad.append(desc + ' ' + msg)
         elif 'fused=' in msg:

@@ -169,3 +169,74 @@ def test_cluster_sharded_rccl_world_size_one():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert res[0] == 0 and res[1] and res[2] > 0
+
+
+def _gloo_worker(rank, world, port, q):
+    """Two PROCESSES on the one GPU there is: each rank its own HIP context and forest on device 0, the exchange over a gloo group with
+    the selections staged through host tensors (RCCL refuses two ranks on one device).  The real multi-process product path --
+    rendezvous, identical LPT tables on both ranks, begin -> exchange -> end -- against a single forest, scan by scan."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_config
+    n_scans = 6
+    sc = make_config("cfg3", seed=5446, n_scans=n_scans)
+
+    def exchange(t):      # device tensor -> host -> all-reduce(MAX) over gloo -> device
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+        return t
+    part = ClusterShardedTracker(_tracker(sc, device=0), world, rank, exchange=exchange)
+    solo = _tracker(sc, device=0) if rank == 0 else None
+    ok, n_mine, owners = True, 0, []
+    for k in range(n_scans):
+        sl = MeasurementList(float(sc["times"][k]), sc["scans"][k])
+        part.begin(sl)
+        n_mine += int((part.sel_rel >= 0).sum().item())      # targets whose cluster this rank solved
+        owners.append(_owner_table(part.trk))
+        part.exchange(part.sel_rel)
+        part.end()
+        if solo is not None:
+            solo.addMeasurementList(sl)
+            try:
+                _same(part.trk, solo, "scan %d" % k)
+            except AssertionError:
+                ok = False
+    # both ranks must have derived the same cluster -> rank table on their own devices
+    tabs = [None] * world
+    dist.all_gather_object(tabs, owners)
+    ok = ok and all(t == tabs[0] for t in tabs)
+    q.put((rank, ok, part.trk.nTargets, n_mine))
+    dist.barrier()
+    part.trk.close()
+    if solo is not None:
+        solo.close()
+    dist.destroy_process_group()
+
+
+def test_cluster_sharded_two_processes_one_gpu_gloo():
+    """The multi-process path on the hardware there is (a one-GPU box): two ranks, both on GPU 0, `ClusterShardedTracker` with the
+    exchange over gloo.  Every rank solved SOME of the clusters, none solved all, and the sharded tracker equals a single forest on
+    every scan (pymht/tracker.py:228-236: the per-cluster ILPs are independent)."""
+    import torch.multiprocessing as mp
+    world, port = 2, 29833 + os.getpid() % 100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] > 0
+    assert res[0][3] > 0 and res[1][3] > 0, "both ranks solved clusters: %r" % (res,)
