@@ -360,6 +360,8 @@ def main():
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
     if "g11" in which:
         gen_g11(mods)
+    if "g22" in which:
+        gen_g22(mods)
     if "g21" in which:
         gen_g21(mods)
     if "g15" in which:
@@ -732,6 +734,61 @@ def gen_g11(mods):
     fx["n_cases"] = case
     np.savez_compressed(os.path.join(GOLD, "g11_kalman6.npz"), **fx)
     print("  g11_kalman6: %d cases" % case)
+
+
+def gen_g22(mods):
+    """g22_cov64.npz: the covariance chain of a target NumPy has promoted to float64 (an AIS-updated node's P is float64, models/ais.py:4;
+    np.array of the leaves' P_0 promotes the whole batch, tracker.py:859-870) -- the reference's own kalman.predict / kalman.precalc on
+    float64 batches with the float32 model matrices of models/pv.py, and np.linalg.inv of float64 2x2 / 4x4 matrices as kalman.precalc
+    (kalman.py:91) calls it for the radar and the AIS innovation covariance.  Pins csrc/mht_la64.h (cov_chain64, inv_lapack)."""
+    kalman, pv = mods["kalman"], mods["pv"]
+    rng = np.random.default_rng(2222)
+    A, Q, C, R = pv.Phi(2.5), pv.Q(2.5), pv.C_RADAR, pv.R_RADAR()
+    fx = dict(A=A, Q=Q, C=C, R=R, n_cases=np.int64(0))
+    ci = 0
+    for n in (1, 2, 5, 33):
+        for rep in range(6):
+            Ps = []
+            for i in range(n):      # covariances as the tracker meets them: P0 through random hit / miss sequences in float64, some perturbed
+                P = pv.P0.astype(np.float64) * rng.uniform(0.5, 2.0)
+                if rng.uniform() < 0.5:
+                    a = rng.normal(size=(4, 4))
+                    P = P + a.dot(a.T) * rng.uniform(0.0, 3.0)
+                for k in range(int(rng.integers(0, 6))):
+                    xb, Pb = kalman.predict(A, Q, np.zeros((1, 4)), P[None])
+                    P = Pb[0] if rng.uniform() < 0.5 else kalman.precalc(C, R, xb, Pb)[4][0]
+                Ps.append(P)
+            P = np.ascontiguousarray(np.array(Ps))
+            assert P.dtype == np.float64
+            xb, Pb = kalman.predict(A, Q, np.zeros((n, 4)), P)
+            zh, S, Si, K, Ph = kalman.precalc(C, R, xb, Pb)
+            assert Pb.dtype == Ph.dtype == S.dtype == Si.dtype == K.dtype == np.float64
+            # the oracle's restatement must agree bit for bit
+            oxb, oPb = orc.kf_predict(A, Q, np.zeros((n, 4)), P)
+            _, oS, oSi, oK, oPh = orc.kf_precalc(C, R, oxb, oPb)
+            for a_, b_ in ((Pb, oPb), (Ph, oPh), (S, oS), (Si, oSi), (K, oK)):
+                assert np.array_equal(a_, b_)
+            p = "c%d_" % ci
+            fx[p + "P"], fx[p + "P_bar"], fx[p + "P_hat"], fx[p + "S"], fx[p + "S_inv"], fx[p + "K"] = P, Pb, Ph, S, Si, K
+            ci += 1
+    fx["n_cases"] = np.int64(ci)
+    # np.linalg.inv as kalman.precalc calls it (a batch of matrices): symmetric, nearly symmetric and general ones
+    for n in (2, 4):
+        mats = []
+        for i in range(400):
+            a = rng.normal(size=(n, n)) * rng.uniform(0.1, 10.0)
+            kind = i % 3
+            m = a.dot(a.T) + np.eye(n) * rng.uniform(0.01, 5.0)
+            if kind == 1:
+                m = m + rng.normal(size=(n, n)) * 1e-9
+            if kind == 2:
+                m = a + np.eye(n) * rng.uniform(0.0, 5.0)
+            mats.append(m)
+        mats = np.array(mats)
+        fx["inv%d_in" % n] = mats
+        fx["inv%d_out" % n] = np.linalg.inv(mats)
+    np.savez_compressed(os.path.join(GOLD, "g22_cov64.npz"), **fx)
+    print("g22: %d chain cases, 2 x 400 inverses" % ci)
 
 
 def gen_g21(mods):

@@ -15,8 +15,9 @@
 //   dgetrs: the exchanges applied to the identity (LASWP), then dtrsm_LNLU / dtrsm_LNUN, whose inner "solve" is RIGHT-looking with a
 //     pre-inverted diagonal (the packing routine stores 1 / u_ii): x_i = b_i * (1 / u_ii), then b_k = fma(-x_i, u_ki, b_k) for the rows
 //     still to solve (the compiler contracts `c -= bb * a` of kernel/generic/trsm_kernel_L?.c for an FMA target).
-// The Haswell / Zen kernel set of the same OpenBLAS differs in the last place (its trsm solve is not fused): tests/conftest.py pins
-// OPENBLAS_CORETYPE for the live-oracle comparisons on hosts that would pick it.
+// The Haswell / Zen kernel set of the same OpenBLAS differs in the last place (its trsm solve is not fused): the recorded fixtures
+// (tests/golden: G18-G18f, G19, G22) are what pins this header; comparisons against a LIVE oracle are exact on hosts whose numpy
+// runs the SkylakeX set and 1e-12 relative elsewhere (tests/util.py::live_numpy_f64_is_pinned).
 #pragma once
 #include "mht_math.h"
 

@@ -27,7 +27,7 @@ def hostmath():
     d = os.path.join(ROOT, "tests", "hostmath")
     so = os.path.join(d, "libhostmath.so")
     src = os.path.join(d, "hostmath.cpp")
-    hdrs = [os.path.join(ROOT, "pymht_amd", "csrc", h) for h in ("mht_math.h", "mht_ais_math.h")]
+    hdrs = [os.path.join(ROOT, "pymht_amd", "csrc", h) for h in ("mht_math.h", "mht_ais_math.h", "mht_la64.h")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", src, "-o", so])
     return ctypes.CDLL(so)

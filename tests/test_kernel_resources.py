@@ -16,13 +16,16 @@ CSRC = os.path.join(ROOT, "pymht_amd", "csrc")
 # of its 512-thread workgroups per CU resident, which the look-back of its tile prefix relies on.
 BUDGET = {
     "mht_gate.hip": {"grow_kernel": (0, 128)},
-    "mht_blp.hip": {"blp_kernel": (32, 256)},
+    # blp_uf_kernel = the ILP launch of the replay / streamed path since round 4 (cluster tables derived in its prologue): one 155 KB workgroup per
+    # CU, so all 256 registers are its to use -- what must not come back is scratch (spilled arguments in front of every workgroup)
+    "mht_blp.hip": {"blp_kernelE": (32, 256), "blp_uf_kernel": (0, 256)},
     # cluster_init_kernel / post_scan_kernel<false> are on the path of every streamed scan: the initiator in them is compiled WITHOUT the AIS
     # seeding phase (its matrices spill 400 bytes per lane at the 128 registers 1024 threads leave); <true> only runs on scans with messages
     "mht_cluster.hip": {"cluster_kernel": (0, 128), "cluster_init_kernel": (160, 128)},
     "mht_forest.hip": {"commit_kernel": (0, 128), "add_targets_kernel": (0, 128), "post_scan_kernelILb0": (64, 128), "post_scan_kernelILb1": (512, 128)},
     # (1024 threads: 4 waves per SIMD; one workgroup: the initiator's small dense inverses index their scratch arrays dynamically)
-    "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128), "fgrow_adm_kernel": (0, 168)},      # 3 / 4 workgroups per CU
+    # (fgrow_ais_kernel: two workgroups per CU -- 256 registers; the float64 chain of a promoted target's float32 leaves runs inline in it: its pivoted 2x2 / dynamic row exchanges take 400 B of scratch per lane)
+    "mht_fgrow.hip": {"fgrow_kernel": (0, 168), "fgrow_batch_kernel": (0, 128), "fgrow_adm_kernel": (0, 168), "fgrow_ais_kernel": (512, 256)},      # 3 / 4 workgroups per CU
 }
 
 
