@@ -98,10 +98,14 @@ def pmc_traffic_live(config, timeout_s=180.0):
 
 
 def model_of(sc):
-    """The tracking model of a config: the reference's 4-state CV model (models/pv.py), or -- BASELINE config 5 names a six-state model,
-    the reference ships none -- the constant-acceleration model pymht_amd/models/ca.py in the six-state build of the library."""
-    from pymht_amd.models import pv, ca
-    return ca if sc.get("name") == "cfg5" and os.environ.get("MHT_BENCH_CFG5_MODEL", "ca") == "ca" else pv
+    """The tracking model of a config: the reference's 4-state CV model (models/pv.py), or -- BASELINE config 5 names a six-state
+    constant-turn model, the reference ships none -- pymht_amd/models/ct.py in the six-state build of the library (a forest made with
+    MHT_FOREST_CT: every hypothesis its own Phi(T, w) and covariance chain).  MHT_BENCH_CFG5_MODEL=ca: the linear constant-acceleration
+    stand-in of rounds 3-4 (covariances shared by value); =pv: the 4-state model at config 5's size."""
+    from pymht_amd.models import pv, ca, ct
+    if sc.get("name") != "cfg5":
+        return pv
+    return {"ct": ct, "ca": ca, "pv": pv}[os.environ.get("MHT_BENCH_CFG5_MODEL", "ct")]
 
 
 def roots_of(sc, model):

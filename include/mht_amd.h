@@ -239,6 +239,12 @@ typedef struct mht_forest_config {
  * mmsi[i] = the message node first + i was updated with (0: none; with measurement number 0 that is a child WITHOUT a radar
  * measurement, the reference's measurementNumber None), hist[i] = Target._getHistoricalMmsi(). */
 #define MHT_FOREST_AIS 1u
+/* mht_forest_create_ex(..., MHT_FOREST_CT), six-state build (libmht_amd6.so) only: the constant-turn model BASELINE config 5 names
+ * (pymht_amd/models/ct.py; state [x, y, vx, vy, w, a]).  The transition is not model->A but Phi(T, w) rebuilt for every hypothesis from its
+ * own turn rate x[4], T = model->A[4][5] (give A = Phi(T, 0)); every leaf runs the reference's per-hypothesis form kalman.predict_single +
+ * kalman.precalc on a batch of one (kalman.py:67-70, :82-101) -- what mht_gate_scan_x does with mht_model_x.transition = 1 -- and nothing
+ * is shared by value: the forest keeps the children's covariances per node.  No device initiator, no similar-state pruning, no groups. */
+#define MHT_FOREST_CT 2u
 int mht_forest_create_ex(mht_ctx* ctx, const mht_model* model, const struct mht_forest_config* cfg, uint32_t flags);
 int mht_forest_set_ais(mht_ctx* ctx, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais, double lambda_ais);
 int mht_forest_read_mmsi(mht_ctx* ctx, int32_t scan, int32_t first, int32_t count, int32_t* mmsi, int32_t* hist);

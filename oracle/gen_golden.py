@@ -360,6 +360,8 @@ def main():
         gen_g4([big[i] for i in keep], name="g6_ilp_cfg3")
     if "g11" in which:
         gen_g11(mods)
+    if "g23" in which:
+        gen_g23(mods)
     if "g22" in which:
         gen_g22(mods)
     if "g21" in which:
@@ -941,6 +943,52 @@ def gen_g17(mods):
         fx[p + "leaf_P"] = lb["P"]
         print("  g17 scan %2d  M=%3d  T=%3d->%3d  L=%5d G=%5d leaves_after=%5d ilp=%d dead=%s" % (k, len(z), len(ids_before), len(o.targets), info["L"], info["G"], len(lb["ID"]), o.n_ilp, sorted(info["dead"])))
     np.savez_compressed(os.path.join(GOLD, "g17_trace_6state.npz"), **fx)
+
+
+def gen_g23(mods):
+    """g23_trace_ct6.npz: a scan trace of the CONSTANT-TURN forest (BASELINE config 5's model, pymht_amd/models/ct.py).  The reference has
+    no six-state model and its tracker is hard-wired to models/pv; what it offers for a state-dependent transition is
+    its per-hypothesis form.  So, like g17: the oracle tracker with every Kalman step REPLACED by the reference's own kalman functions --
+    predict_single (kalman.py:67-70) with the leaf's own Phi(T, w), precalc on a batch of one, z_tilde / normalizedInnovationSquared /
+    numpyFilter / nllr -- i.e. the G21-validated per-leaf arithmetic, through clustering, ILPs, termination and N-scan pruning.
+    40 targets in 500 m, 9 scans, N-scan 3; the initial turn rates are spread over +-0.05 rad/s so that every leaf has its own transition."""
+    kal = mods["kalman"]
+    from pymht_amd.models import ct
+    from pymht_amd.utils.scenario import make_scenario
+    orc.kf_predict_single = lambda A, Q, x, P: kal.predict_single(A, Q, x, P)
+    orc.kf_precalc = lambda C, R, xb, Pb: kal.precalc(C, R, xb, Pb)
+    orc.kf_innovations = lambda z, zh: kal.z_tilde(z, zh, zh.shape[0], zh.shape[1])
+    orc.kf_nis = lambda zt, Si: kal.normalizedInnovationSquared(zt, Si)
+    orc.kf_update = lambda xb, K, zt: kal.numpyFilter(xb, K, zt)
+    orc.kf_nllr = lambda lam, pd, S, nis: kal.nllr(lam, pd, S, nis)
+    sc = make_scenario(T=40, radius=500.0, lambda_phi=3e-5, n_scans=9, P_d=0.88, seed=2323)
+    N, eta2 = 3, 5.99
+    o = orc.OracleTracker(sc["period"], sc["lambda_phi"], LAMBDA_NU, P_d=sc["P_d"], N=N, eta2=eta2, model=ct)
+    rng = np.random.default_rng(23)
+    x0 = np.concatenate([sc["x0"], rng.uniform(-0.05, 0.05, size=(len(sc["x0"]), 1)), np.zeros((len(sc["x0"]), 1))], axis=1)      # [x, y, vx, vy, w, a = 0]
+    acc = [o.initiate_target(sc["t0"], x.copy(), ct.P0.copy(), status="preinitialized") for x in x0]
+    fx = dict(x0=x0, accepted=np.array(acc), t0=sc["t0"], period=sc["period"], P_d=sc["P_d"], lambda_phi=sc["lambda_phi"], lambda_nu=LAMBDA_NU,
+              N=N, eta2=eta2, times=sc["times"], n_scans=len(sc["scans"]), nx=6)
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        ids_before = [r.ID for r in o.targets]
+        info = o.add_scan(float(t), z)
+        p = "s%02d_" % k
+        lb, sel = o.leaf_batch(), o.selected()
+        fx[p + "z"], fx[p + "unused"] = z, info["unused"]
+        fx[p + "LGM"] = np.array([info["L"], info["G"], info["M"]], dtype=np.int64)
+        fx[p + "ids"] = np.array([r.ID for r in o.targets], dtype=np.int64)
+        fx[p + "dead"] = np.array(sorted(info["dead"]), dtype=np.int64)
+        fx[p + "new_ids"] = np.zeros(0, np.int64)
+        fx[p + "cl_members"] = np.concatenate(o.clusters) if o.clusters else np.zeros(0, np.int64)
+        fx[p + "cl_ptr"] = np.concatenate([[0], np.cumsum([len(c) for c in o.clusters])]).astype(np.int64)
+        fx[p + "n_ilp"] = o.n_ilp
+        for key in ("ID", "x", "cnllr", "meas"):
+            fx[p + "sel_" + key] = sel[key]
+            fx[p + "leaf_" + key] = lb[key]
+        fx[p + "leaf_P"] = lb["P"]
+        print("  g23 scan %2d  M=%3d  T=%3d->%3d  L=%5d G=%5d leaves_after=%5d ilp=%d dead=%s  |w| max %.3f" % (
+            k, len(z), len(ids_before), len(o.targets), info["L"], info["G"], len(lb["ID"]), o.n_ilp, sorted(info["dead"]), float(np.abs(lb["x"][:, 4]).max())))
+    np.savez_compressed(os.path.join(GOLD, "g23_trace_ct6.npz"), **fx)
 
 
 def gen_g15(mods):

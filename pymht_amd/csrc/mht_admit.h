@@ -18,6 +18,7 @@ struct AddArgs {
     int vidx;            // version index of `tab` (FCounts::nTv)
     uint8_t* accepted; int32_t* ids; int32_t* near;   // near: [n] scratch
     Model model; VTab vt; int root_base;
+    float* ct_Proot;     // constant-turn forest (mht_kernels.h: CtGrow): [Tcap][NP] covariances of the roots born into the newest layer, else null
     const int32_t* n_dev;      // number of candidates in device memory (or null: n)
     int32_t* mmsi; int32_t* hmmsi;      // AIS forest: identities of the newest layer's nodes (a root has none), else null
     ReportHeader* hdr; mht_birth_report* births;      // report block of the device initiator's candidates (or null)   // gains of the new roots (row cov_base + r of the newest layer's gain table); first root node
@@ -165,6 +166,11 @@ __device__ __forceinline__ void add_targets_body(const AddArgs& a, int* sm) {
         const int q = s_adm[k & 2047];
         float P[NP];
         for (int e = 0; e < NP; ++e) P[e] = a.P0[q * NP + e];
+        if (a.ct_Proot) {      // (nothing is shared by value: the root's covariance goes to its layer's root array, its key names the slot)
+            for (int e = 0; e < NP; ++e) a.ct_Proot[(size_t)(r0 + k) * NP + e] = P[e];
+            a.layer.cov[a.root_base + r0 + k] = -2 - (r0 + k);
+            continue;
+        }
         const int id0 = vt_find_or_insert(a.vt, P, a.pd[q]);
         const unsigned pid = atomicAdd(a.vt.count, 1u);
         if (pid >= (unsigned)a.vt.vcap) { *a.vt.overflow = 1; continue; }

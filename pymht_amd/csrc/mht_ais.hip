@@ -249,3 +249,71 @@ extern "C" int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, con
     }
     return MHT_OK;
 }
+
+// ---- constant-turn forest (six-state build, MHT_FOREST_CT; mht_kernels.h: CtGrow) -------------------------------------------------
+// Per leaf of the newest layer, in front of the grow launch: the leaf's own transition Phi(T, w) from its turn rate, the reference's
+// per-hypothesis form kalman.predict_single (kalman.py:67-70: A.dot(x), A.dot(P).dot(A.T) + Q) and kalman.precalc on a batch of ONE
+// (kalman.py:82-101) -- the arithmetic of the stateless seam mht_gate_scan_x with mht_model_x.transition = 1 (mht_gatex.hip,
+// tests/golden/g21_ct6.npz) -- leaving the prediction, the gains row and the children's covariances by leaf node.
+namespace mht {
+#if MHT_NX == 6
+__device__ __forceinline__ void ct_node_cov(const CtForestArgs& a, int key, float* P) {
+    const float* src = key < 0 ? a.Proot + (size_t)(-2 - key) * NP : ((key & 1) ? a.Phat_prev : a.Pbar_prev) + (size_t)(key >> 1) * NP;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) P[e] = src[e];
+}
+__global__ __launch_bounds__(64) void forest_ct_kernel(const CtForestArgs a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.nT_dev[0]) return;
+    const int first = a.t_first[t], cnt = a.t_leaf_off[t + 1] - a.t_leaf_off[t];
+    for (int i = lane; i < cnt; i += 64) {
+        const int nd = first + i;
+        if (a.flags[nd] & F_DEAD) continue;
+        double xs[6], xb[6], zh[2];
+        float P[36], Pb[36], Ph[36], K[12], S[4], Si[4];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xs[k] = a.x[(size_t)k * a.cap + nd];
+        ct_node_cov(a, a.cov[nd], P);
+        ModelX<6> m;
+#pragma unroll
+        for (int e = 0; e < 36; ++e) m.Q[e] = a.model.Q[e];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) m.C[e] = a.model.C[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m.R[e] = a.model.R[e];
+        m.eta2 = a.model.eta2; m.lambda_ex = a.model.lambda_ex; m.ct = 1; m.T = a.T;
+        ct_phi(a.T, xs[4], m.A);
+        predict_precalc_x<double, 6>(m, xs, P, xb, zh, Pb, Ph, K, S, Si, true);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.xbar[(size_t)k * a.cap + nd] = xb[k];
+        a.zhat[nd] = zh[0]; a.zhat[(size_t)a.cap + nd] = zh[1];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) { a.Pbar[(size_t)nd * 36 + e] = Pb[e]; a.Phat[(size_t)nd * 36 + e] = Ph[e]; }
+        float row[GKF];
+#pragma unroll
+        for (int e = 0; e < GKF; ++e) row[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) row[e] = Si[e];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) row[4 + e] = K[e];
+        row[GK_LNC] = nllr_const(S, a.model.lambda_ex, a.pd[nd]);
+        row[GK_RX] = sqrtf((float)a.model.eta2 * fabsf(S[0]));
+        row[GK_RY] = sqrtf((float)a.model.eta2 * fabsf(S[3]));
+#pragma unroll
+        for (int q = 0; q < GKQ; ++q) a.gains[(size_t)nd * GKQ + q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+    }
+}
+#endif
+int launch_forest_ct(mht_ctx* ctx, const CtForestArgs& a, int n_targets_ub) {
+#if MHT_NX == 6
+    const int grid = n_targets_ub < 1 ? 1 : n_targets_ub;
+    hipLaunchKernelGGL(forest_ct_kernel, dim3(grid), dim3(64), 0, ctx->stream, a);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+#else
+    (void)ctx; (void)a; (void)n_targets_ub;
+    set_error("the constant-turn forest needs the six-state build of the library");
+    return MHT_E_INVALID;
+#endif
+}
+}  // namespace mht

@@ -461,7 +461,7 @@ __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32s
 // slot t of the COMMITTED table (d.fused = 0 for it), count and root columns of that table
 // LEAN: the batched launches (groups of sectors) -- no union-find, no overlap with the previous scan's ILP launch: compiled out (the
 // batched kernel sits at 128 registers for four workgroups per CU)
-template <int PQ, int CAP, int AIS = 0, bool LEAN = false>
+template <int PQ, int CAP, int AIS = 0, bool LEAN = false, int CT = 0>
 __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, unsigned char* smem, const int bslot, const int born = 0) {
     FDyn d = d0;
     if (LEAN) { d.uf_epoch = 0u; d.ovl = 0; d.stamp_end = 0; }
@@ -618,8 +618,8 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 // batch B: the gains of the leaf's covariance column
                 float4 gr[GKQ];
 #pragma unroll
-                for (int q = 0; q < GKQ; ++q) gr[q] = a.vt.Gk[(size_t)covc * GKQ + q];
-                int cid = a.vt.child[covc];
+                for (int q = 0; q < GKQ; ++q) gr[q] = CT ? a.ct.gains[(size_t)src * GKQ + q] : a.vt.Gk[(size_t)covc * GKQ + q];
+                int cid = CT ? src : a.vt.child[covc];      // (constant-turn forest: the children's keys are 2 * (leaf node) + hit/miss, mht_kernels.h CtGrow)
                 if (AIS) {
                     FLeafX gx;
                     gx.f64 = (prom && in_chunk) ? 1 : 0; gx.pad = 0;
@@ -700,7 +700,11 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 for (int e = 0; e < NP; ++e) mdl.A[e] = a.model.A[e];
 #pragma unroll
                 for (int e = 0; e < NK; ++e) mdl.C[e] = a.model.C[e];
-                if (g.f32state) {
+                if (CT) {      // (the leaf's own Phi(T, w): predicted by forest_ct_kernel, in the reference's per-hypothesis order)
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) g.xbar[k] = a.ct.xbar[(size_t)k * a.cap + src];
+                    g.zhat[0] = a.ct.zhat[src]; g.zhat[1] = a.ct.zhat[(size_t)a.cap + src];
+                } else if (g.f32state) {
                     float xs[NX], xb[NX], zh[2];
 #pragma unroll
                     for (int k = 0; k < NX; ++k) xs[k] = (float)xd[k];
@@ -758,7 +762,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             // target's first scan): the leaf's prediction is redone here, outside phase 1's register peak, from a second load of its
             // state; phase 2 (b) reads it behind the next barrier.  (The gate boxes come from the FMA-chain prediction: an ulp away,
             // well inside their widening.)
-            if (__builtin_amdgcn_readfirstlane((cnt == 1 || (d.maybe_dead && cnt > 1 && s_live == 1)) ? 1 : 0) && tid < n) {
+            if (!CT && __builtin_amdgcn_readfirstlane((cnt == 1 || (d.maybe_dead && cnt > 1 && s_live == 1)) ? 1 : 0) && tid < n) {
                 const int src1 = first + c0 + tid;
                 const uint8_t fl1 = a.flags[src1];
                 if (!(fl1 & F_DEAD)) fg_single_leaf(a, src1, (fl1 & F_STATE_F32) != 0 && !(AIS && prom), lg[tid]);
@@ -1451,7 +1455,7 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w, int n_
     for (int i = i0; i < rn; i += st) d4[r0 + i] = s4[r0 + i];
 }
 
-template <int PQ, int CAP, typename CARGS, int AIS = 0, bool LEAN = false>
+template <int PQ, int CAP, typename CARGS, int AIS = 0, bool LEAN = false, int CT = 0>
 __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem, const int bid0 = (int)blockIdx.x) {
     int bid = bid0;
     // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
@@ -1474,7 +1478,8 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (t >= d.n_tgt) return;
         target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
     } else {
-        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS, LEAN>(ap, d, bid, smem, bid);
+        if (CT && !d.fused && bid == 0) stamp();      // (no commit and no chain workgroup in a constant-turn launch)
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS, LEAN, CT>(ap, d, bid, smem, bid);
         if (d.stamp_end && threadIdx.x == 0) atomicMax(&ap->status->t[5], (unsigned long long)wall_clock64());
     }
 }
@@ -1681,6 +1686,18 @@ __global__ __launch_bounds__(FG_THREADS, 2) void fgrow_ais_kernel(const FGrowArg
     fgrow_body<PQ, FG_CAP, CommitArgs, 1>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
+// Constant-turn forest (six-state build, MHT_FOREST_CT): predictions and gains per leaf come from forest_ct_kernel, the children's keys
+// name the leaf; no chain workgroups (nothing is shared by value)
+#if MHT_NX == 6
+template <int PQ>
+__global__ __launch_bounds__(FG_THREADS, 2) void fgrow_ct_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_grow = d.fused + d.n_main + d.n_chain;
+    if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }
+    fgrow_body<PQ, FG_CAP, CommitArgs, 0, false, 1>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
+}
+#endif
+
 // a group of sectors per launch (BASELINE config 4 on one GPU): blockIdx.y = sector, its argument blocks are read from HBM (they
 // repeat with period 2 x ring length and are written once, at group creation), only FDyn travels by value
 typedef const __attribute__((address_space(4))) CommitArgs* KCommit;
@@ -1729,6 +1746,10 @@ static int fgrow_lds_attr(mht_ctx* ctx, size_t lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_adm_kernel<4, FG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ais_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#if MHT_NX == 6
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ct_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fgrow_ct_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
         attr_bytes = lds;
     }
     return MHT_OK;
@@ -1784,6 +1805,22 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
         MHT_HIP_CHECK(hipGetLastError());
         return MHT_OK;
     }
+#if MHT_NX == 6
+    if (a.ct.on) {      // constant-turn forest: its own kernel, no chain workgroups
+        fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
+        d.n_chain = 0;
+        const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP);
+        { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
+        const bool pub = publish && publish->dst;
+        const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);
+        const PublishArgs pa = pub ? *publish : PublishArgs{};
+        const CommitArgs cm = commit ? *commit : CommitArgs{};
+        if (a.pds == 8) hipLaunchKernelGGL(fgrow_ct_kernel<2>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        else hipLaunchKernelGGL(fgrow_ct_kernel<4>, dim3(grid), dim3(FG_THREADS), lds, ctx->stream, a, cm, d, pa);
+        MHT_HIP_CHECK(hipGetLastError());
+        return MHT_OK;
+    }
+#endif
     if (a.ais.half > 0) {      // AIS forest: its own kernel on every scan (records in two halves, identities per node)
         fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
         const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP) + (size_t)FG_CAP * (16 + sizeof(FLeafX));      // (+ s_ais, lgx)

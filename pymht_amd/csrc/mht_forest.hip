@@ -192,11 +192,18 @@ __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const Init
     }
 }
 
+// constant-turn forest (mht_kernels.h: CtGrow): per ring layer the covariances of its nodes' children and of the roots born into it
+struct CtLayers { const float* Pbar[MAXR]; const float* Phat[MAXR]; const float* Proot[MAXR]; int on; };
+__device__ __forceinline__ void export_cov_ct(const CtLayers& c, int li, int lprev, int key, float* P, double* P64) {
+    const float* src = key < 0 ? c.Proot[li] + (size_t)(-2 - key) * NP : ((key & 1) ? c.Phat[lprev] : c.Pbar[lprev]) + (size_t)(key >> 1) * NP;
+    for (int e = 0; e < NP; ++e) { if (P64) P64[e] = (double)src[e]; if (P) P[e] = src[e]; }
+}
 struct LeavesArgs {
     mht_nodes layer; TTable tab; const FCounts* cnt; VTab vt;
     int capacity; double* x; float* P; double* cnllr; int32_t* meas; int32_t* target; int32_t* id; int32_t* node; uint8_t* flags;
     double* P64;      // != null (mht_forest_leaves_f64): every covariance as float64 -- exact for the float32 ones, the reference's own for F_COV_F64 leaves
 };
+struct LeavesCt { CtLayers c; int li, lprev; };
 // the covariance of node nd of a layer whose keys belong to table v, as float32 (P) or float64 (P64)
 __device__ __forceinline__ void export_cov(const VTab& v, int key, uint8_t fl, float* P, double* P64) {
     const int id = v.child[key];
@@ -210,7 +217,7 @@ __device__ __forceinline__ void export_cov(const VTab& v, int key, uint8_t fl, f
         for (int e = 0; e < NP; ++e) { if (P64) P64[e] = (double)t[e]; if (P) P[e] = t[e]; }
     }
 }
-__global__ void leaves_kernel(const LeavesArgs a) {
+__global__ void leaves_kernel(const LeavesArgs a, const LeavesCt ct) {
     const int nT = a.cnt->nT;
     const int L = a.cnt->L < a.capacity ? a.cnt->L : a.capacity;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
@@ -218,7 +225,8 @@ __global__ void leaves_kernel(const LeavesArgs a) {
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.tab.leaf_off[mid] <= i) lo = mid; else hi = mid; }
         const int t = lo, nd = a.tab.first[lo] + (i - a.tab.leaf_off[lo]);
         for (int k = 0; k < NX; ++k) a.x[i * NX + k] = a.layer.x[(size_t)k * a.layer.cap + nd];
-        export_cov(a.vt, a.layer.cov[nd], a.layer.flags[nd], a.P ? a.P + (size_t)i * NP : nullptr, a.P64 ? a.P64 + (size_t)i * NP : nullptr);
+        if (ct.c.on) export_cov_ct(ct.c, ct.li, ct.lprev, a.layer.cov[nd], a.P ? a.P + (size_t)i * NP : nullptr, a.P64 ? a.P64 + (size_t)i * NP : nullptr);
+        else export_cov(a.vt, a.layer.cov[nd], a.layer.flags[nd], a.P ? a.P + (size_t)i * NP : nullptr, a.P64 ? a.P64 + (size_t)i * NP : nullptr);
         a.cnllr[i] = a.layer.cnllr[nd];
         a.meas[i] = a.layer.meas[nd];
         a.target[i] = t;
@@ -229,7 +237,7 @@ __global__ void leaves_kernel(const LeavesArgs a) {
 }
 
 struct ChainArgs { mht_nodes layers[MAXR]; VTab vt[2]; int lgen[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; double* P64; uint8_t* flags; };
-__global__ void chain_kernel(const ChainArgs a) {
+__global__ void chain_kernel(const ChainArgs a, const CtLayers ct) {
     if (threadIdx.x || blockIdx.x) return;
     int nd = a.node, sc = a.scan, n = 0;
     while (nd >= 0 && n < a.max_len && sc >= 0) {
@@ -239,7 +247,8 @@ __global__ void chain_kernel(const ChainArgs a) {
         a.cnllr[n] = l.cnllr[nd];
         for (int k = 0; k < NX; ++k) a.x[n * NX + k] = l.x[(size_t)k * l.cap + nd];
         const VTab& v = a.vt[a.lgen[sc % a.R]];      // (the generation of the value table this layer's keys belong to)
-        export_cov(v, l.cov[nd], l.flags[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
+        if (ct.on) export_cov_ct(ct, sc % a.R, (sc + a.R - 1) % a.R, l.cov[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
+        else export_cov(v, l.cov[nd], l.flags[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
         if (a.flags) a.flags[n] = l.flags[nd];
         ++n;
         nd = l.parent[nd];
@@ -276,6 +285,11 @@ struct Forest {
     int pds = 8;                      // ints per path / ancestor record (8 or 16)
     // AIS forest (mht_forest_create_ex, MHT_FOREST_AIS; mht_kernels.h: AisGrow): identities per node, record pool of the fused children,
     // the messages of the next scan (mht_forest_set_ais arms them, the next step consumes them)
+    // constant-turn forest (six-state build, MHT_FOREST_CT; mht_kernels.h: CtGrow): per ring layer the covariances of its nodes' children and of
+    // the roots born into it; for the newest layer's leaves the predictions and gains forest_ct_kernel leaves for the grow launch
+    bool ct = false; double ct_T = 0.0;
+    float* ct_Pbar[MAXR] = {}; float* ct_Phat[MAXR] = {}; float* ct_Proot[MAXR] = {};
+    float4* ct_gains = nullptr; double* ct_xbar = nullptr; double* ct_zhat = nullptr;
     bool ais = false; int ais_half = 0;
     int32_t* l_mmsi[MAXR] = {}; int32_t* l_hmmsi[MAXR] = {};
     int32_t* ais_nf = nullptr; int32_t* ais_off = nullptr; AisRec* ais_rec = nullptr; int ais_rec_cap = 0; unsigned* ais_count = nullptr;
@@ -389,6 +403,10 @@ struct Forest {
             l.x = ar.take<double>((size_t)NX * Ncap); l.cnllr = ar.take<double>(Ncap); l.pd = ar.take<double>(Ncap);
             l.parent = ar.take<int32_t>(Ncap); l.meas = ar.take<int32_t>(Ncap); l.cov = ar.take<int32_t>(Ncap);
             l.flags = ar.take<uint8_t>(Ncap); l.P = nullptr;
+        }
+        if (ct) {
+            for (int s = 0; s < R; ++s) { ct_Pbar[s] = ar.take<float>((size_t)NP * Ncap); ct_Phat[s] = ar.take<float>((size_t)NP * Ncap); ct_Proot[s] = ar.take<float>((size_t)NP * Tcap); }
+            ct_gains = ar.take<float4>((size_t)GKQ * Ncap); ct_xbar = ar.take<double>((size_t)NX * Ncap); ct_zhat = ar.take<double>((size_t)2 * Ncap);
         }
         if (ais) {
             for (int s = 0; s < R; ++s) { l_mmsi[s] = ar.take<int32_t>(Ncap); l_hmmsi[s] = ar.take<int32_t>(Ncap); }
@@ -571,7 +589,7 @@ using namespace mht;
 
 static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_forest_config* cfg, uint32_t flags) {
     MHT_REQUIRE(ctx && model && cfg, "mht_forest_create: null argument");
-    MHT_REQUIRE((flags & ~(uint32_t)MHT_FOREST_AIS) == 0, "mht_forest_create_ex: unknown flags 0x%x", flags);
+    MHT_REQUIRE((flags & ~(uint32_t)(MHT_FOREST_AIS | MHT_FOREST_CT)) == 0, "mht_forest_create_ex: unknown flags 0x%x", flags);
     if (flags & MHT_FOREST_AIS) {
         MHT_REQUIRE(NX == 4, "mht_forest_create_ex: AIS messages report four states (models/ais.py); this is the %d-state build", NX);
         MHT_REQUIRE(cfg->n_scan <= 7, "mht_forest_create_ex: an AIS forest keeps two rows per level in a 16-entry path record: n_scan must be <= 7 (got %d)", cfg->n_scan);
@@ -639,6 +657,12 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     // (rocprofv3 --pmc runs ONE kernel at a time across all queues, in the order the queues happen to be served: a launch that waits for a
     // launch on another queue never sees it start.  Under counter collection the initiator stays on the ctx stream.)
     { const char* e = getenv("ROCPROF_COUNTER_COLLECTION"); if (e && e[0] == '1') { f->init_side_q = false; f->serial_prof = true; } }
+    if (flags & MHT_FOREST_CT) {       // the transition is rebuilt per hypothesis from its turn rate (pymht_amd/models/ct.py): T = A[4][5]
+        if (NX != 6 || (flags & MHT_FOREST_AIS)) { delete f; set_error("mht_forest_create_ex: MHT_FOREST_CT needs the six-state build of the library and no MHT_FOREST_AIS"); return MHT_E_INVALID; }
+        f->ct = true;
+        f->ct_T = (double)model->A[(NX >= 6 ? 4 : 0) * NX + (NX >= 6 ? 5 : 0)];
+        f->ovl_ok = false;
+    }
     if (flags & MHT_FOREST_AIS) {      // two halves per record: radar rows, AIS rows
         f->ais = true;
         f->ais_half = f->PD <= 4 ? 4 : 8;
@@ -781,7 +805,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
-    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
+    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base; a.ct_Proot = f->ct ? f->ct_Proot[f->scan % f->R] : nullptr;
     if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
     if (ride) { f->adm = a; f->adm_pending = true; }
@@ -881,6 +905,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.rec0 = f->rec0; g.new_index = f->new_index; g.ni_flag = &f->cnt->ni_flag;
     g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent2[s & 1];      // (by scan parity: the grow launch of scan s + 1 links while the ILP launch of scan s still reads)
      g.uf_team_state = f->teams ? f->team_state2[s & 1] : nullptr;
+    if (f->ct) { g.ct.on = 1; g.ct.gains = f->ct_gains; g.ct.xbar = f->ct_xbar; g.ct.zhat = f->ct_zhat; }
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
@@ -1141,6 +1166,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         const int rc = flush_commit(ctx, f);
         if (rc) return rc;
     }
+    if (f->ct) {     // constant-turn forest: forest_ct_kernel walks the leaves of the COMMITTED table in front of the grow launch
+        const int rc = flush_commit(ctx, f);
+        if (rc) return rc;
+    }
     StepPlan pl;
     { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) { f->ais_armed = false; return rc; } }
     if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
@@ -1170,6 +1199,18 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         MHT_STEP_HIP(hipMemsetAsync(f->ais_count, 0, sizeof(unsigned), st));
         MHT_STEP_CHECK(launch_forest_ais(ctx, aa, pl.n_ub));
         f->ais_armed = false;
+    }
+    if (f->ct) {      // ---- 0': the leaves' own transitions, predictions, gains and children covariances (mht_ais.hip: forest_ct_kernel)
+        CtForestArgs ca = {};
+        const int li = (pl.s - 1) % f->R, lp = (pl.s - 2 + f->R) % f->R;
+        const mht_nodes& in = f->layer[li];
+        fill_model_only(ca.model, &f->model); ca.T = f->ct_T;
+        ca.nT_dev = &f->cnt->nT; ca.t_first = f->tab[pl.s & 1].first; ca.t_leaf_off = f->tab[pl.s & 1].leaf_off;
+        ca.x = in.x; ca.pd = in.pd; ca.cov = in.cov; ca.flags = in.flags; ca.cap = f->Ncap;
+        ca.Pbar_prev = f->ct_Pbar[lp]; ca.Phat_prev = f->ct_Phat[lp]; ca.Proot = f->ct_Proot[li];
+        ca.Pbar = f->ct_Pbar[li]; ca.Phat = f->ct_Phat[li];
+        ca.gains = f->ct_gains; ca.xbar = f->ct_xbar; ca.zhat = f->ct_zhat;
+        MHT_STEP_CHECK(launch_forest_ct(ctx, ca, pl.n_ub));
     }
     // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
@@ -1336,6 +1377,7 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     MHT_REQUIRE(shard_n >= 1 && shard_i >= 0 && shard_i < shard_n, "mht_forest_step_sharded_begin: bad shard %d of %d", shard_i, shard_n);
     Forest* f = ctx->forest;
     MHT_REQUIRE(!f->timing, "mht_forest_step_sharded_begin: per-stage timing is not available for sharded steps");
+    MHT_REQUIRE(!f->ct, "mht_forest_step_sharded_begin: not available in a constant-turn forest (MHT_FOREST_CT)");
     MHT_REQUIRE(!f->shard_open, "mht_forest_step_sharded_begin: the previous sharded step has not been ended");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     { const int rc = flush_publish(ctx, f); if (rc) return rc; }
@@ -1435,6 +1477,7 @@ extern "C" int mht_group_create(mht_group** out, int32_t n, mht_ctx* const* ctxs
     MHT_REQUIRE(out && ctxs && n >= 1 && n <= GROUP_MAX, "mht_group_create: need 1 <= n <= %d contexts", GROUP_MAX);
     for (int i = 0; i < n; ++i) {
         MHT_REQUIRE(ctxs[i] && ctxs[i]->forest, "mht_group_create: context %d has no forest", i);
+        MHT_REQUIRE(!ctxs[i]->forest->ct, "mht_group_create: context %d's forest is a constant-turn one (MHT_FOREST_CT): not available to groups", i);
         MHT_REQUIRE(!ctxs[i]->forest->cluster_big && !ctxs[i]->forest->ais, "mht_group_create: context %d's forest is too large for the batched clustering kernel "
                     "(its tables live in HBM) or is an AIS forest: step it on its own", i);
         const Forest *a = ctxs[0]->forest, *b = ctxs[i]->forest;
@@ -1635,7 +1678,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     a.path = f->path[f->scan & 1]; a.apath = f->apath[f->scan & 1]; a.PD = f->pds;
     a.cnt = f->cnt; a.scan = f->scan; a.Nwin = f->cfg.n_scan; a.Tcap = f->Tcap;
     a.near = f->near;
-    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base;
+    fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base; a.ct_Proot = f->ct ? f->ct_Proot[f->scan % f->R] : nullptr;
     if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     a.hdr = reinterpret_cast<ReportHeader*>(report_dev);
     a.births = reinterpret_cast<mht_birth_report*>(report_dev + f->birth_off);
@@ -1922,6 +1965,7 @@ extern "C" int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold) {
     MHT_REQUIRE(!(threshold != threshold), "mht_forest_set_prune_similar: threshold is NaN");
     Forest* f = ctx->forest;
     MHT_REQUIRE(!f->shard_open, "mht_forest_set_prune_similar: a sharded step is open");
+    MHT_REQUIRE(!(f->ct && threshold > 0.0), "mht_forest_set_prune_similar: not available in a constant-turn forest (MHT_FOREST_CT)");
     f->prune_thr = threshold > 0.0 ? (float)threshold : 0.f;
     return MHT_OK;
 }
@@ -1953,7 +1997,12 @@ static int forest_leaves_impl(mht_ctx* ctx, int32_t capacity, double* x, void* P
     LeavesArgs a = {f->layer[f->scan % f->R], f->tab[nb], f->cnt, f->vt, n,
                     (double*)(d + o_x), PB == 4 ? (float*)(d + o_P) : nullptr, (double*)(d + o_c), (int32_t*)(d + o_m), (int32_t*)(d + o_t),
                     (int32_t*)(d + o_i), (int32_t*)(d + o_n), (uint8_t*)(d + o_f), PB == 8 ? (double*)(d + o_P) : nullptr};
-    hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+    LeavesCt lc = {};
+    if (f->ct) {
+        lc.c.on = 1; lc.li = f->scan % f->R; lc.lprev = (f->scan + f->R - 1) % f->R;
+        for (int k = 0; k < f->R; ++k) { lc.c.Pbar[k] = f->ct_Pbar[k]; lc.c.Phat[k] = f->ct_Phat[k]; lc.c.Proot[k] = f->ct_Proot[k]; }
+    }
+    hipLaunchKernelGGL(leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, lc);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -2020,7 +2069,12 @@ static int forest_chain_impl(mht_ctx* ctx, int32_t scan, int32_t node, int32_t m
     a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
     a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
     a.P = PB == 4 ? (float*)(d + o_P) : nullptr; a.P64 = PB == 8 ? (double*)(d + o_P) : nullptr; a.flags = (uint8_t*)(d + o_fl); a.n_out = (int32_t*)(d + o_k);
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    CtLayers cl = {};
+    if (f->ct) {
+        cl.on = 1;
+        for (int k = 0; k < f->R; ++k) { cl.Pbar[k] = f->ct_Pbar[k]; cl.Phat[k] = f->ct_Phat[k]; cl.Proot[k] = f->ct_Proot[k]; }
+    }
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a, cl);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));

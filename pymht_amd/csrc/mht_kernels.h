@@ -65,6 +65,28 @@ struct AisGrow {
 // + 1 when similar-state pruning rebuilt it for a target alone in its cluster (tracker.py:1233-1239).  Only AIS forests look at RL.
 constexpr int WIN_REBUILT_SHIFT = 8, WIN_REBUILT_ALL = 255;
 
+// Constant-turn forest (six-state build, mht_forest_create_ex with MHT_FOREST_CT; BASELINE config 5's model, pymht_amd/models/ct.py): the
+// transition Phi(T, w) depends on the hypothesis' own turn rate, so nothing is shared by value -- the reference's per-hypothesis form,
+// kalman.predict_single + kalman.precalc on a batch of one (kalman.py:67-70, :82-101), runs for every leaf in forest_ct_kernel in front
+// of the grow launch and leaves, per leaf NODE of the input layer: its prediction, its gains row (the layout of VTab::Gk) and the
+// covariances of its children (P_bar for the missed detection, P_hat for every hit).  A node names its covariance by
+// key = 2 * (parent node) + hit/miss into the parent LAYER's arrays; a root by -2 - r into its own layer's root array.
+struct CtGrow {
+    int on;
+    const float4* gains;      // [cap][GKQ]
+    const double* xbar;       // [NX][cap]
+    const double* zhat;       // [2][cap]
+};
+struct CtForestArgs {
+    Model model; double T;
+    const int32_t* nT_dev; const int32_t* t_first; const int32_t* t_leaf_off;      // the committed target table
+    const double* x; const double* pd; const int32_t* cov; const uint8_t* flags; int cap;      // the leaves' layer
+    const float* Pbar_prev; const float* Phat_prev; const float* Proot;      // what the leaves' keys resolve against: the layer before / their own layer's roots
+    float* Pbar; float* Phat;      // [cap][NP] out: the covariances of the leaves' children
+    float4* gains; double* xbar; double* zhat;
+};
+int launch_forest_ct(mht_ctx* ctx, const CtForestArgs& a, int n_targets_ub);
+
 // fgrow_kernel (mht_fgrow.hip): the grow stage of the forest, one workgroup per target + covariance-chain workgroups
 struct FGrowArgs {
     Model model;
@@ -99,6 +121,7 @@ struct FGrowArgs {
     DevStatus* status;             // this scan's status word: n_children is accumulated here
     const DevStatus* prev_status; const int32_t* sticky_overflow;
     AisGrow ais;                   // (fgrow_kernel<..., AIS = 1> only)
+    CtGrow ct;                     // (fgrow_ct_kernel only)
     // clustering inside the grow launch (FDyn::uf_epoch != 0, see there): owner word per measurement node, parent word per target
     unsigned long long* uf_owner; unsigned long long* uf_parent;
     TeamState* uf_team_state;      // [TEAM_MAX] reset for this scan's ILP launch by the launch's first workgroup (the cluster kernel did it)

@@ -16,6 +16,7 @@ def _selector():
     return c
 
 
+transition = "ct"      # Tracker: the transition is state dependent -- Phi(T, x[4]) per hypothesis (mht_forest_create_ex with MHT_FOREST_CT)
 C_RADAR = _selector()
 p = 2.5 ** 2
 P0 = np.diag(np.array([p, p, 0.3 * p, 0.3 * p, 1e-4, 1e-6])).astype(defaultType)
@@ -40,7 +41,11 @@ def Phi(T, w=0.0):
 
 
 def Q(T, sigmaQ=sigmaQ_tracker):
-    """White-noise acceleration on the velocity (as pv.Q) and white-noise jerk of the turn rate."""
+    """White-noise acceleration on the velocity and white-noise jerk of the turn rate.  NOT pv.Q's entries: the position / velocity cross
+    terms are T^3/2 here (G G^T with G = [T^2/2, T]) where pv.Q, following the reference, has T^3/3, and like pv.Q the whole matrix is
+    scaled by sigmaQ, not its square.  The covariance prediction uses Phi(T, w) as A without the Jacobian with respect to w (not an EKF):
+    the model is this build's own, validated against the reference's kalman functions fed with these matrices (G21, G23), not against
+    a reference model -- the reference has none."""
     q = np.zeros((6, 6), dtype=np.float64)
     for axis in (0, 1):
         i, j = axis, 2 + axis
