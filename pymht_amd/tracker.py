@@ -3,8 +3,8 @@
 Same constructor, `preInitialize`, `initiateTarget`, `addMeasurementList(scanList, aisList=AisMessageList(), **kw)`,
 `getTrackNodes`, `getRuntimeAverage`, `runtimeLog`/`toc` keys and double-underscore attributes as the reference
 (pymht/tracker.py:39-307).  Steps 1-6 of a scan (grow, cluster, optimise, terminate, N-scan
-prune) run as three HIP launches (+ one for the report) on the device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h);
-the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
+prune) run as two HIP launches (grow incl. the clustering's union-find, ILP; the report rides in the next scan's grow launch) on the
+device-resident hypothesis forest of libmht_amd.so (include/mht_amd.h); the host sees one report per scan.  Step 7 (M-of-N initiation) runs on the device as well (`useInitiator`).
 
 XML result export: `getScenarioElement` / `_storeTrackerArgs` / `_storeRun` (tracker.py:1469-1545).
 AIS-aided tracking (tracker.py:394-396, :417-552; tracks started from AIS messages m_of_n.py:262-280): construct with
@@ -191,15 +191,20 @@ class Tracker():
         self._tbl_ = np.zeros(0, dtype=self._REPORT_DTYPE)      # (only id, root_scan, root_node, root_meas, root_x, root_cnllr are read)
         self._sel_ = None            # report records of the live targets after the last scan (selected leaves)
         self._labels = np.zeros(0, np.int64)
+        self._labels_src = None      # the report rows of the last scan: their `cluster` column is read when somebody asks for the clusters
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
-        self.scanStatsLog = [] if kwargs.get('logScanStats', False) else None      # lastScanStats (+ nTargets) of every scan
+        self._scanStatsLog = [] if kwargs.get('logScanStats', False) else None      # lastScanStats (+ nTargets) of every scan (property scanStatsLog)
         self._pendq = []            # the scans whose reports are still on their way, oldest first (folded by later scans or by the first look)
         self._dead = False          # a device step failed: the forest cannot go on
         self._staged = self._staged_prev = self._staged_np = None
         self._stats_ = {}
+        self._scanrecs = []          # per-scan numbers of the folded reports that `toc` / `runtimeLog` / `lastScanStats` have not been built from yet
+        self._rep = _lib.MhtScanReport(); self._rep_ref = C.byref(self._rep)
+        self._rec_size = self._REPORT_DTYPE.itemsize
+        self._no_recs = np.zeros(0, dtype=self._REPORT_DTYPE)
 
     # ------------------------------------------------------------------------------------------------
     def preInitialize(self, simList):
@@ -273,7 +278,7 @@ class Tracker():
         try:
             self._staged, self._staged_np = None, z      # (the library stages the scan in pinned memory and copies it itself)
             _lib.check(self._lib.mht_forest_scan(self._ctx.handle, self.initiator.handle if self.useInitiator else None,
-                                                 z.ctypes.data_as(C.c_void_p), z.shape[0], float(scanList.time)))
+                                                 z.__array_interface__['data'][0], z.shape[0], float(scanList.time)))
         except _lib.MhtError as e:
             if e.code != _lib.MHT_E_INVALID:
                 self._dead = True
@@ -380,13 +385,16 @@ class Tracker():
         return self._staged[:z.shape[0]] if z.size else self._staged[:0]
 
     def _finish_scan(self, scanList, z, aisList, tic, which=0):
-        """The host side of a scan: wait for its report, fold it (and the device initiator's births) into the host mirror."""
-        self.tic = tic
-        self._toc_ = {}
-        self.tic['Init'] = time.time()
+        """The host side of a scan: wait for its report, fold it (and the device initiator's births) into the host mirror.
+
+        Only what later scans need is done here -- the report's rows become the table of the live targets, births and terminated tracks
+        are taken in -- and the scan's numbers are kept as one tuple; the dictionaries the reference exposes (`toc`, `runtimeLog`,
+        `lastScanStats`, the scan log) are built from those tuples when somebody reads them (`_materialise`): a host that streams scans
+        in pays a few microseconds per scan here, not thirty."""
         t_fold = time.perf_counter()
-        rep = _lib.MhtScanReport()
-        rc = self._lib.mht_forest_report_get(self._ctx.handle, which, C.byref(rep))
+        t_init = time.time()
+        rep = self._rep
+        rc = self._lib.mht_forest_report_get(self._ctx.handle, which, self._rep_ref)
         if rc == _lib.MHT_E_LIMIT:
             # soft: an ILP ran into the branch-and-bound node limit.  The selection it returned is feasible (not proven optimal)
             # and the device forest HAS advanced with it: fold the report like any other (the reference logs "Optim result NOT
@@ -396,86 +404,99 @@ class Tracker():
         elif rc:
             self._dead = True
             _lib.check(rc)
-        self.__scanHistory__.append(scanList)
-        if len(self.__scanHistory__) >= len(self._scan_times):
+        hist = self.__scanHistory__
+        hist.append(scanList)
+        scanNumber = len(hist)
+        if scanNumber >= len(self._scan_times):
             self._scan_times = np.concatenate([self._scan_times, np.zeros(len(self._scan_times))])
-        self._scan_times[len(self.__scanHistory__)] = float(scanList.time)
-        self.__aisHistory__.append(aisList)
         scanTime = scanList.time
-        scanNumber = len(self.__scanHistory__)
+        self._scan_times[scanNumber] = scanTime
+        self.__aisHistory__.append(aisList)
         nRadarMeas = z.shape[0]
         assert rep.scan == scanNumber
         nT = rep.n_targets
-        # (copied as bytes, viewed afterwards: NumPy copies a structured array field by field, 12x slower)
-        recs = np.ctypeslib.as_array(C.cast(rep.targets, C.POINTER(C.c_uint8)), shape=(nT * self._REPORT_DTYPE.itemsize,)) \
-            .copy().view(self._REPORT_DTYPE) if nT else np.zeros(0, dtype=self._REPORT_DTYPE)
-        used_words = np.ctypeslib.as_array(C.cast(rep.used, C.POINTER(C.c_uint64)), shape=(max(rep.used_words, 1),)).copy()
-        used = np.unpackbits(used_words.view(np.uint8), bitorder="little")[:nRadarMeas].astype(bool)
-        unusedRadarMeasurementIndices = ~used
-        # Per-stage times (tracker.py:192-294: the reference's own per-scan metric).  The kernels stamp the GPU's wall clock (10 ns ticks)
-        # at the start of every stage and the commit files the differences in the report: no HIP events, no host cost, present on every
-        # scan.  Track termination and the N-scan prune decision are part of the ILP launch (toc['Optim']); the target-side commit
-        # rides in the next scan's grow launch (toc['N-Prune'] = 0 unless deviceTiming measures it with HIP events).
-        self._toc_['Process'], self._toc_['Cluster'], self._toc_['Optim'] = rep.t_process * 1e-8, rep.t_cluster * 1e-8, rep.t_optim * 1e-8
-        self._toc_['Terminate'] = 0.0
-        self._toc_['N-Prune'] = 0.0
-        self._toc_['Device'] = rep.t_scan * 1e-8
-        if self._timing:
-            ms = (C.c_float * 5)()
-            _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms), None))
-            self._toc_['Process'], self._toc_['Cluster'], self._toc_['Optim'] = ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3
-            self._toc_['N-Prune'] = ms[3] * 1e-3
-            self._toc_['Device'] = ms[4] * 1e-3
-        self._toc_['ILP-Prune'] = 0.0
-        self._toc_['DynN'] = 0.0
-        self._nOptimSolved_ = rep.n_ilp
-        births = None
+        # (one memcpy of the rows out of the pinned block, viewed as records: NumPy copies a structured array field by field, 12x slower)
+        recs = np.frombuffer(C.string_at(rep.targets, nT * self._rec_size), dtype=self._REPORT_DTYPE) if nT else self._no_recs
+        used_raw = C.string_at(rep.used, 8 * max(rep.used_words, 1))
+        self._apply_report(recs, scanTime, scanNumber, z, rep.n_alive == nT)
         if rep.n_births:
-            births = np.ctypeslib.as_array(C.cast(rep.births, C.POINTER(C.c_uint8)), shape=(rep.n_births * self._BIRTH_DTYPE.itemsize,)) \
-                .copy().view(self._BIRTH_DTYPE)
-        self._apply_report(recs, scanTime, scanNumber, z)
-        if births is not None:
-            self._apply_births(births, scanTime, scanNumber, z[unusedRadarMeasurementIndices])
-        self._toc_['Init'] = time.time() - self.tic['Init']
+            births = np.frombuffer(C.string_at(rep.births, rep.n_births * self._BIRTH_DTYPE.itemsize), dtype=self._BIRTH_DTYPE)
+            self._apply_births(births, scanTime, scanNumber, z[self._unused_of(used_raw, nRadarMeas)])
         # toc['Total'] = what THIS scan cost: the host time of its addMeasurementList call + the device time of its stages + the host
         # time of folding its report.  NOT the wall time between the call and the fold: the report of scan k is folded by the call for
         # scan k+1 (or by the first look at the results), so that interval is the host's idle time between scans -- a real-time host
         # feeding one scan per radarPeriod would see Total ~ radarPeriod and a spurious "Did not pass real time demand".
-        self._toc_['Total'] = float(tic.get('_call', 0.0)) + self._toc_['Device'] + (time.perf_counter() - t_fold)
-        if self._toc_['Total'] > 0.1 and os.environ.get("MHT_STALL_DEBUG") == "1":      # (development: which part of a scan was slow)
-            log.critical("scan %d slow: call %.1f ms, device %.1f ms (process %.1f, cluster %.1f, optim %.1f), fold + wait %.1f ms", scanNumber,
-                         1e3 * float(tic.get('_call', 0.0)), 1e3 * self._toc_['Device'], 1e3 * self._toc_['Process'], 1e3 * self._toc_['Cluster'],
-                         1e3 * self._toc_['Optim'], 1e3 * (time.perf_counter() - t_fold))
-            dbg = np.zeros(8, dtype=np.uint64)
-            self._lib.mht_forest_debug_read(self._ctx.handle, b"init_dbg", dbg.ctypes.data_as(C.c_void_p), 64)
-            log.critical("init_dbg %s at t = %.1f s (process clock), pid %d", dbg.tolist(), time.process_time(), os.getpid())
-            st2 = np.zeros(16, dtype=np.uint64)
-            self._lib.mht_forest_debug_read(self._ctx.handle, b"status2", st2.ctypes.data_as(C.c_void_p), 128)
-            log.critical("status2 words (overflow | n_children << 32, n_dead | timeout bits << 32): %s %s", [hex(int(x)) for x in st2[:2]], [hex(int(x)) for x in st2[8:10]])
-        if self._toc_['Total'] > self.radarPeriod:
-            log.critical("Did not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
-                self._toc_['Total'] * 1000, self.radarPeriod * 1000))
-        elif self._toc_['Total'] > self.radarPeriod * 0.6:      # tracker.py:285-287
-            log.warning("Did almost not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(
-                self._toc_['Total'] * 1000, self.radarPeriod * 1000))
-        for k, v in self._runtimeLog_.items():
-            if k in self._toc_:
-                v.append(self._toc_[k])
-        self._stats_ = dict(L=rep.n_leaves_in, G=rep.n_children - rep.n_leaves_in, M=nRadarMeas,
-                                  leaves_out=rep.n_leaves_out, clusters=rep.n_clusters, ilp=rep.n_ilp,
-                                  branched=rep.n_branched, blp_iters_max=rep.blp_iters_max, limit=rep.n_limit,
-                                  unused=unusedRadarMeasurementIndices)
-        if self.scanStatsLog is not None:
-            self.scanStatsLog.append(dict(self._stats_, nTargets=len(self._tbl_)))
-        # the reference's per-scan console output (tracker.py:222-223, :296-301), when the scan is folded
-        kw = tic.get('_print')
-        if kw:
-            if kw.get("printCluster", False):
-                self.printClusterList(self.__clusterList__)
-            if kw.get("printInfo", False):
-                print("Added scan number:", len(self.__scanHistory__), " \tnRadarMeas ", nRadarMeas, sep="")
-            if kw.get("printTime", False):
-                self.printTimeLog(**kw)
+        call = tic.get('_call', 0.0)
+        stage = None
+        if self._timing:
+            ms = (C.c_float * 5)()
+            _lib.check(self._lib.mht_forest_stage_times(self._ctx.handle, C.byref(ms), None))
+            stage = (ms[0] * 1e-3, ms[1] * 1e-3, ms[2] * 1e-3, ms[3] * 1e-3, ms[4] * 1e-3)
+        device = stage[4] if stage is not None else rep.t_scan * 1e-8
+        now = time.perf_counter()
+        total = call + device + (now - t_fold)
+        # (rep is reused by the next fold: the numbers are taken out now)
+        self._scanrecs.append((tic, rep.t_process, rep.t_cluster, rep.t_optim, rep.t_scan, stage, rep.n_ilp, rep.n_leaves_in, rep.n_children,
+                               nRadarMeas, rep.n_leaves_out, rep.n_clusters, rep.n_branched, rep.blp_iters_max, rep.n_limit, used_raw,
+                               len(self._tbl_), time.time() - t_init, total))
+        if total > self.radarPeriod * 0.6 or tic.get('_print'):
+            self._materialise()
+            if total > 0.1 and os.environ.get("MHT_STALL_DEBUG") == "1":      # (development: which part of a scan was slow)
+                self._stall_debug(scanNumber, call, now - t_fold)
+            if total > self.radarPeriod:
+                log.critical("Did not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(total * 1000, self.radarPeriod * 1000))
+            elif total > self.radarPeriod * 0.6:      # tracker.py:285-287
+                log.warning("Did almost not pass real time demand! Used {0:.0f}ms of {1:.0f}ms".format(total * 1000, self.radarPeriod * 1000))
+            # the reference's per-scan console output (tracker.py:222-223, :296-301), when the scan is folded
+            kw = tic.get('_print')
+            if kw:
+                if kw.get("printCluster", False):
+                    self.printClusterList(self.__clusterList__)
+                if kw.get("printInfo", False):
+                    print("Added scan number:", len(self.__scanHistory__), " \tnRadarMeas ", nRadarMeas, sep="")
+                if kw.get("printTime", False):
+                    self.printTimeLog(**kw)
+
+    @staticmethod
+    def _unused_of(used_raw, nRadarMeas):
+        """bit j of the report's used-measurement words -> unused[j]"""
+        return ~np.unpackbits(np.frombuffer(used_raw, dtype=np.uint8), bitorder="little")[:nRadarMeas].astype(bool)
+
+    def _materialise(self):
+        """The per-scan tuples `_finish_scan` left -> the reference's `toc` / `runtimeLog` / `lastScanStats` (and the scan log)."""
+        recs, self._scanrecs = self._scanrecs, []
+        for (tic, t_process, t_cluster, t_optim, t_scan, stage, n_ilp, n_leaves_in, n_children, nRadarMeas, n_leaves_out, n_clusters, n_branched,
+             blp_iters_max, n_limit, used_raw, n_tbl, t_init, total) in recs:
+            self.tic = tic
+            # Per-stage times (tracker.py:192-294: the reference's own per-scan metric).  The kernels stamp the GPU's wall clock (10 ns
+            # ticks) at the start of every stage and the commit files the differences in the report: no HIP events, no host cost, present
+            # on every scan.  Track termination and the N-scan prune decision are part of the ILP launch (toc['Optim']); the target-side
+            # commit rides in the next scan's grow launch (toc['N-Prune'] = 0 unless deviceTiming measures it with HIP events).
+            toc = {'Process': t_process * 1e-8, 'Cluster': t_cluster * 1e-8, 'Optim': t_optim * 1e-8, 'Terminate': 0.0, 'N-Prune': 0.0,
+                   'Device': t_scan * 1e-8, 'ILP-Prune': 0.0, 'DynN': 0.0, 'Init': t_init, 'Total': total}
+            if stage is not None:
+                toc['Process'], toc['Cluster'], toc['Optim'], toc['N-Prune'], toc['Device'] = stage
+            self._toc_ = toc
+            self._nOptimSolved_ = n_ilp
+            for k, v in self._runtimeLog_.items():
+                if k in toc:
+                    v.append(toc[k])
+            self._stats_ = dict(L=n_leaves_in, G=n_children - n_leaves_in, M=nRadarMeas, leaves_out=n_leaves_out, clusters=n_clusters, ilp=n_ilp,
+                                branched=n_branched, blp_iters_max=blp_iters_max, limit=n_limit, unused=self._unused_of(used_raw, nRadarMeas))
+            if self._scanStatsLog is not None:
+                self._scanStatsLog.append(dict(self._stats_, nTargets=n_tbl))
+
+    def _stall_debug(self, scanNumber, call, fold):
+        self._materialise()
+        t = self._toc_
+        log.critical("scan %d slow: call %.1f ms, device %.1f ms (process %.1f, cluster %.1f, optim %.1f), fold + wait %.1f ms", scanNumber,
+                     1e3 * call, 1e3 * t['Device'], 1e3 * t['Process'], 1e3 * t['Cluster'], 1e3 * t['Optim'], 1e3 * fold)
+        dbg = np.zeros(8, dtype=np.uint64)
+        self._lib.mht_forest_debug_read(self._ctx.handle, b"init_dbg", dbg.ctypes.data_as(C.c_void_p), 64)
+        log.critical("init_dbg %s at t = %.1f s (process clock), pid %d", dbg.tolist(), time.process_time(), os.getpid())
+        st2 = np.zeros(16, dtype=np.uint64)
+        self._lib.mht_forest_debug_read(self._ctx.handle, b"status2", st2.ctypes.data_as(C.c_void_p), 128)
+        log.critical("status2 words (overflow | n_children << 32, n_dead | timeout bits << 32): %s %s", [hex(int(x)) for x in st2[:2]], [hex(int(x)) for x in st2[8:10]])
 
     def _apply_births(self, births, scanTime, scanNumber, z_unused):
         """The device initiator's candidates that Tracker.initiateTarget's device twin admitted: append them to the host mirror."""
@@ -495,17 +516,23 @@ class Tracker():
         self.trackIdCounter = int(b["id"].max()) + 1
         self._views.clear()
 
-    def _apply_report(self, recs, scanTime, scanNumber, z):
+    def _apply_report(self, recs, scanTime, scanNumber, z, all_alive=None):
         """Fold the scan report into the host tables (no per-target Python objects, no per-field copies: the table of the live
         targets IS the report's rows)."""
         prev = self._tbl_
-        self._views.clear()
-        self._labels = recs["cluster"]
-        alive = recs["status"] == 0
-        if alive.all():
+        if self._views:
+            self._views.clear()
+        self._labels_src = recs
+        alive = None
+        if all_alive is None:
+            alive = recs["status"] == 0
+            all_alive = bool(alive.all())
+        if all_alive:
             live = recs
             moved = live["root_scan"] != prev["root_scan"]
         else:
+            if alive is None:
+                alive = recs["status"] == 0
             # terminated tracks keep their whole history (the reference's _pruneEverythingExceptHistory): the window ancestors of the
             # last selected node are fetched now, while they are still in the device ring
             dead = recs[~alive]
@@ -522,21 +549,36 @@ class Tracker():
     @property
     def lastScanStats(self):
         self._drain()
+        if self._scanrecs:
+            self._materialise()
         return self._stats_
+
+    @property
+    def scanStatsLog(self):
+        self._drain()
+        if self._scanrecs:
+            self._materialise()
+        return self._scanStatsLog
 
     @property
     def toc(self):
         self._drain()
+        if self._scanrecs:
+            self._materialise()
         return self._toc_
 
     @property
     def runtimeLog(self):
         self._drain()
+        if self._scanrecs:
+            self._materialise()
         return self._runtimeLog_
 
     @property
     def nOptimSolved(self):
         self._drain()
+        if self._scanrecs:
+            self._materialise()
         return self._nOptimSolved_
 
     @property
@@ -626,7 +668,8 @@ class Tracker():
     @property
     def __clusterList__(self):
         self._drain()
-        return [np.where(self._labels == lab)[0] for lab in np.unique(self._labels)]
+        labels = self._labels_src["cluster"] if self._labels_src is not None else self._labels
+        return [np.where(labels == lab)[0] for lab in np.unique(labels)]
 
     @property
     def __terminatedTargets__(self):
@@ -751,7 +794,8 @@ class Tracker():
         snap = self._views.get("_leaves")
         if snap is not None:
             return snap
-        cap = int(min(self._cfg.max_nodes, max(4096, 2 * int(self._stats_.get("leaves_out", 0)) + 4 * len(self._tbl_) + 1024)))
+        leaves_out = self._scanrecs[-1][10] if self._scanrecs else self._stats_.get("leaves_out", 0)
+        cap = int(min(self._cfg.max_nodes, max(4096, 2 * int(leaves_out) + 4 * len(self._tbl_) + 1024)))
         while True:
             snap = self._leaf_export(cap)
             if snap is not None:
@@ -912,7 +956,7 @@ class Tracker():
         return run
 
     def getRuntimeAverage(self):
-        return {k: np.mean(np.array(v)) for k, v in self._runtimeLog_.items() if len(v)}
+        return {k: np.mean(np.array(v)) for k, v in self.runtimeLog.items() if len(v)}
 
     def _findClustersFromSets(self):
         return self.__clusterList__
