@@ -2471,6 +2471,7 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a_in)
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     // (this launch is ordered behind the scan's grow launch: whoever reads this word -- the scan's initiator on its own queue -- knows that launch is complete)
     if (a.begun && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.begun, (unsigned long long)a.pub_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.started && threadIdx.x == 0) atomicAdd(a.started, 1ull);      // (resident: the gate in front of the next grow launch counts these)
     const int gx = (int)gridDim.x, pb = (int)blockIdx.x, bx = pb;
     blp_body<true>(a, lds, bx, gx, ps, &fe);
     if (!fe.s_over) blp_stamp_end(a);

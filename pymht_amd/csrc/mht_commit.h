@@ -40,6 +40,10 @@ struct FCounts {          // device-side counters of the forest
     // the scan whose ILP launch has begun, i.e. whose grow launch is complete (blp_uf_kernel, first workgroup): what the scan's initiator
     // waits for when it is launched on a queue of its own (initiator_side_kernel)
     unsigned long long ilp_begun;
+    // workgroups of blp_uf_kernel that have STARTED, over all launches (never reset: the host knows the total).  Two-queue mode
+    // (Forest::tq_on): the next scan's grow launch sits on another hardware queue behind a gate kernel that waits for this count -- its
+    // 43 KB workgroups must not take a CU before every 155 KB ILP workgroup of the scan before has one
+    unsigned long long ilp_started;
 };
 // Ticket among the few workgroups of a launch that may play a role: 0 for the first one to arrive in launch `tag`, 1, 2, ... for the
 // others.  The word carries the tag of the launch it was last used in, so nothing has to be reset (launches may skip the scheme).

@@ -335,6 +335,14 @@ struct Forest {
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
+    // Two-queue mode (MHT_TWO_QUEUES=1; replay path; an EXPERIMENT that lost, kept behind its switch -- profiles/r05_two_queue_ab.txt): the
+    // overlapping grow launch of scan k + 1 goes onto a stream of its own -- another hardware queue shares the CUs with the ILP launch of
+    // scan k workgroup by workgroup, where the same queue hands over an XCD only when it has drained (profiles/r04_anyorder_ubench.txt) --
+    // behind a one-workgroup gate that waits until every ILP workgroup is resident (without it the 43 KB grow workgroups take CUs the
+    // 155 KB ILP workgroups still need, and wait for them: deadlock, seen); the ILP launch of scan k + 1 waits for it through an event
+    // (61 us per scan) or through a posted word and a gate kernel on the ctx stream (MHT_TQ_FLAGS=1: 51.4-52.4 us) against 49.3 us on one
+    // queue: what the CU-granular overlap buys, the extra launch boundaries take
+    bool tq_on = false; hipStream_t tq_stream = nullptr; hipEvent_t tq_ev = nullptr; unsigned long long ilp_started_total = 0; int tq_launches = 0;
     // the streamed scans' initiator launches go onto the SIDE stream, each one behind the staging kernel of the scan after its own (it is
     // queued by the next call, or by whoever needs its births first: launch_deferred_init): see forest_step_impl
     bool init_ev_lazy = false; bool init_deferred = false; bool init_side_q = true; bool serial_prof = false;      // serial_prof: no launch may wait for a launch on another queue (the staging goes by event too)
@@ -472,6 +480,7 @@ void forest_destroy(mht_ctx* ctx) {
     if (!f) return;
     ::hp_print();
     if (f->stage_stream) (void)hipStreamSynchronize(f->stage_stream);
+    if (f->tq_stream) (void)hipStreamSynchronize(f->tq_stream);
     if (f->arena.base) (void)hipFree(f->arena.base);
     for (int b = 0; b < 2; ++b) {
         if (f->report_host2[b]) (void)hipHostFree(f->report_host2[b]);
@@ -485,6 +494,8 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
+    if (f->tq_stream) (void)hipStreamDestroy(f->tq_stream);
+    if (f->tq_ev) (void)hipEventDestroy(f->tq_ev);
     if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
     if (f->init_ev) (void)hipEventDestroy(f->init_ev);
     if (f->evp) {
@@ -652,6 +663,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
+    { const char* e = getenv("MHT_TWO_QUEUES"); f->tq_on = (e && e[0] == '1'); }
     { const char* e = getenv("MHT_INIT_QUEUE"); f->init_side_q = !(e && e[0] == '0'); }
     { const char* e = getenv("MHT_REPORT_FLAG"); f->rep_flag_ok = !(e && e[0] == '0'); }
     // (rocprofv3 --pmc runs ONE kernel at a time across all queues, in the order the queues happen to be served: a launch that waits for a
@@ -1037,6 +1049,16 @@ __global__ __launch_bounds__(256) void vt_rebuild_kernel(const RebuildArgs a) {
     }
 }
 
+// two-queue mode: the gate in front of a grow launch on the forest's second queue (Forest::tq_on)
+__global__ __launch_bounds__(64) void tq_gate_kernel(const unsigned long long* started, unsigned long long want, int32_t* sticky_overflow) {
+    unsigned long long v;
+    if (!spin_until(started, [&](unsigned long long x) { return x >= want; }, v) && threadIdx.x == 0) *sticky_overflow = 2;
+}
+// (experiment MHT_TQ_FLAGS=1: instead of an event from the second queue, a one-thread kernel behind the grow launch posts a word and a gate in
+// front of the ILP launch on the ctx stream waits for it: two in-queue boundaries instead of a cross-queue barrier packet)
+__global__ void tq_post_kernel(unsigned long long* word, unsigned long long v) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct StepPlan { int s; bool fused; int n_ub; int W; bool rebuilt; };
 // Switches the forest to the other generation of its value table in front of scan s (the newest layer is s - 1).
 static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
@@ -1263,6 +1285,30 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             f->pub_args.done = reinterpret_cast<unsigned long long*>(f->report_host_dev[f->pub_slot] + f->done_off);
             f->pub_args.tag = (unsigned long long)(pl.s - 1) | (1ull << 40);
         } else { f->pub_args.done = nullptr; f->pub_args.tag = 0; }
+        const bool tq = any_order && f->tq_on && !adm && !f->pub_deferred && !init && f->ilp_started_total > 0;
+        if (tq) {
+            if (!f->tq_stream) {
+                MHT_STEP_HIP(hipStreamCreateWithFlags(&f->tq_stream, hipStreamNonBlocking));
+                MHT_STEP_HIP(hipEventCreateWithFlags(&f->tq_ev, hipEventDisableTiming));
+            }
+            static int flags = -1; if (flags < 0) { const char* e = getenv("MHT_TQ_FLAGS"); flags = (e && e[0] == '1') ? 1 : 0; }
+            hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, f->tq_stream, static_cast<const unsigned long long*>(&f->cnt->ilp_started), f->ilp_started_total, &f->cnt->overflow);
+            MHT_STEP_HIP(hipGetLastError());
+            hipStream_t keep = ctx->stream;
+            ctx->stream = f->tq_stream;
+            const int rc_grow = launch_fgrow(ctx, g, d, pl.n_ub, &f->pending, nullptr, nullptr, false);
+            ctx->stream = keep;
+            MHT_STEP_CHECK(rc_grow);
+            if (flags) {
+                hipLaunchKernelGGL(tq_post_kernel, dim3(1), dim3(64), 0, f->tq_stream, &f->cnt->role_tick, (unsigned long long)pl.s);
+                hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(&f->cnt->role_tick), (unsigned long long)pl.s, &f->cnt->overflow);
+                MHT_STEP_HIP(hipGetLastError());
+            } else {
+            MHT_STEP_HIP(hipEventRecord(f->tq_ev, f->tq_stream));
+            MHT_STEP_HIP(hipStreamWaitEvent(st, f->tq_ev, 0));      // (this scan's ILP launch, next on the ctx stream, needs the whole grow launch)
+            }
+            f->tq_launches += 1;
+        } else
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
         hp_mark(4);
         f->adm_pending = false;
@@ -1325,6 +1371,11 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
         { static int gcap = -1; if (gcap < 0) { const char* e = getenv("MHT_BLP_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && use_uf && grid > gcap) grid = gcap; }      // (development)
+        if (use_uf && f->tq_on && !init) {      // (two-queue mode: every ILP workgroup resident at once -- one per CU -- and counted in)
+            if (grid > ctx->n_cu) grid = ctx->n_cu;
+            b.started = &f->cnt->ilp_started;
+            f->ilp_started_total += (unsigned long long)grid;
+        }
         if (use_uf) {
             b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s; b.begun = &f->cnt->ilp_begun;
             b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
@@ -2149,6 +2200,11 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     if (!strcmp(name, "vt_rebuilds")) {      // (host-side counter: generation switches of the covariance-value table so far)
         MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'vt_rebuilds' is one int32");
         *static_cast<int32_t*>(host) = f->rebuilds;
+        return MHT_OK;
+    }
+    if (!strcmp(name, "tq_launches")) {      // (host-side counter: grow launches that went onto the second queue)
+        MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'tq_launches' is one int32");
+        *static_cast<int32_t*>(host) = f->tq_launches;
         return MHT_OK;
     }
     if (!strcmp(name, "uf_ovl")) {      // (host-side counters: scans clustered by the union-find, grow launches made any-order)

@@ -304,6 +304,7 @@ struct BlpArgs {
     // counter the workgroups count themselves off on when they leave; the scan's tag
     unsigned long long* rec0; int pub_ub; unsigned long long* blp_done; unsigned pub_scan;
     unsigned long long* begun;             // != null: the launch's first workgroup posts pub_scan here at entry (FCounts::ilp_begun)
+    unsigned long long* started;           // != null: every workgroup counts itself in at entry (FCounts::ilp_started; two-queue mode)
     unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
     const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
                                                         // target died in the previous scan, the union-find was redone under epoch | 1
