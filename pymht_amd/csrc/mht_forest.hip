@@ -1173,6 +1173,19 @@ static void hp_print() {
     fprintf(stderr, "\n");
     g_hp = HostProf();
 }
+// constant-turn forest: forest_ct_kernel (mht_ais.hip) over the leaves of the committed table, in front of scan s's grow launch
+static int forest_ct_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub) {
+    CtForestArgs ca = {};
+    const int li = (s - 1) % f->R, lp = (s - 2 + f->R) % f->R;
+    const mht_nodes& in = f->layer[li];
+    fill_model_only(ca.model, &f->model); ca.T = f->ct_T;
+    ca.nT_dev = &f->cnt->nT; ca.t_first = f->tab[s & 1].first; ca.t_leaf_off = f->tab[s & 1].leaf_off;
+    ca.x = in.x; ca.pd = in.pd; ca.cov = in.cov; ca.flags = in.flags; ca.cap = f->Ncap;
+    ca.Pbar_prev = f->ct_Pbar[lp]; ca.Phat_prev = f->ct_Phat[lp]; ca.Proot = f->ct_Proot[li];
+    ca.Pbar = f->ct_Pbar[li]; ca.Phat = f->ct_Phat[li];
+    ca.gains = f->ct_gains; ca.xbar = f->ct_xbar; ca.zhat = f->ct_zhat;
+    return launch_forest_ct(ctx, ca, n_ub);
+}
 // init != null (mht_forest_scan): the scan's step 7 rides in the cluster launch (cluster_init_kernel)
 static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiator* init, double now) {
     MHT_REQUIRE(ctx && ctx->forest, "mht_forest_step: no forest");
@@ -1222,18 +1235,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         MHT_STEP_CHECK(launch_forest_ais(ctx, aa, pl.n_ub));
         f->ais_armed = false;
     }
-    if (f->ct) {      // ---- 0': the leaves' own transitions, predictions, gains and children covariances (mht_ais.hip: forest_ct_kernel)
-        CtForestArgs ca = {};
-        const int li = (pl.s - 1) % f->R, lp = (pl.s - 2 + f->R) % f->R;
-        const mht_nodes& in = f->layer[li];
-        fill_model_only(ca.model, &f->model); ca.T = f->ct_T;
-        ca.nT_dev = &f->cnt->nT; ca.t_first = f->tab[pl.s & 1].first; ca.t_leaf_off = f->tab[pl.s & 1].leaf_off;
-        ca.x = in.x; ca.pd = in.pd; ca.cov = in.cov; ca.flags = in.flags; ca.cap = f->Ncap;
-        ca.Pbar_prev = f->ct_Pbar[lp]; ca.Phat_prev = f->ct_Phat[lp]; ca.Proot = f->ct_Proot[li];
-        ca.Pbar = f->ct_Pbar[li]; ca.Phat = f->ct_Phat[li];
-        ca.gains = f->ct_gains; ca.xbar = f->ct_xbar; ca.zhat = f->ct_zhat;
-        MHT_STEP_CHECK(launch_forest_ct(ctx, ca, pl.n_ub));
-    }
+    if (f->ct) MHT_STEP_CHECK(forest_ct_prepass(ctx, f, pl.s, pl.n_ub));      // ---- 0': the leaves' own transitions, predictions, gains and children covariances
     // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
     // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.
@@ -1428,14 +1430,15 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     MHT_REQUIRE(shard_n >= 1 && shard_i >= 0 && shard_i < shard_n, "mht_forest_step_sharded_begin: bad shard %d of %d", shard_i, shard_n);
     Forest* f = ctx->forest;
     MHT_REQUIRE(!f->timing, "mht_forest_step_sharded_begin: per-stage timing is not available for sharded steps");
-    MHT_REQUIRE(!f->ct, "mht_forest_step_sharded_begin: not available in a constant-turn forest (MHT_FOREST_CT)");
     MHT_REQUIRE(!f->shard_open, "mht_forest_step_sharded_begin: the previous sharded step has not been ended");
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     StepPlan pl;
     if (f->ais_armed) { set_error("mht_forest_step_sharded_begin: the cluster-sharded step takes no AIS messages (mht_forest_set_ais armed some)"); return MHT_E_STATE; }
+    if (f->ct) { const int rcf = flush_commit(ctx, f); if (rcf) return rcf; }      // (forest_ct_kernel walks the leaves of the COMMITTED table)
     { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) return rc; }
     int rc;
+    if (f->ct) { rc = forest_ct_prepass(ctx, f, pl.s, pl.n_ub); if (rc) { f->dead = true; return rc; } }
     {
         FGrowArgs g;
         fill_fgrow(f, pl.s, pl.fused, g);

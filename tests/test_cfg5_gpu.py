@@ -104,3 +104,42 @@ def test_forest_with_cluster_tables_beyond_lds():
     scene through it, first scans against the oracle like the others."""
     d = _run(3, oracle_scans=3, nx=4, max_targets=8192)
     assert d[-1][0] >= 6000
+
+
+def test_cfg5_cluster_sharded_two_shards_equal_single_forest():
+    """config 5 names 8 GPUs: with the constant-turn model as named the scene PARTITIONS (hundreds of multi-target clusters per scan, where
+    the constant-acceleration stand-in of rounds 3-4 tied it into one component), so the cluster-sharded step applies as it is: two shards
+    (two contexts on the one GPU, the all-reduce(MAX) replaced by an element-wise maximum) against a single forest, scan by scan -- every
+    shard solves some of the ILPs, none all, and the forests stay identical (pymht/tracker.py:228-236: the per-cluster ILPs are independent)."""
+    import torch
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.utils.scenario import make_config
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = make_config("cfg5", seed=907, n_scans=5)
+    solo, _, _ = _tracker(sc, 6)
+    parts = [ClusterShardedTracker(_tracker(sc, 6)[0], 2, i, exchange=lambda t: None) for i in range(2)]
+    solved = [0, 0]
+    try:
+        for k in range(5):
+            sl = MeasurementList(float(sc["times"][k]), sc["scans"][k])
+            solo.addMeasurementList(sl)
+            for p in parts:
+                p.begin(sl)
+            both = torch.stack([(p.sel_rel >= 0).int() for p in parts])
+            assert int(both.sum(dim=0).max()) <= 1, "a target was solved by two shards"
+            for i in range(2):
+                solved[i] += int(both[i].sum())
+            merged = torch.stack([p.sel_rel for p in parts]).max(dim=0).values
+            for p in parts:
+                p.sel_rel.copy_(merged)
+                p.end()
+            for p in parts:
+                sa, sb = p.trk._sel[0], solo._sel[0]
+                for name in ("id", "status", "sel_meas", "sel_x", "sel_cnllr", "n_leaves", "cluster"):
+                    assert np.array_equal(sa[name], sb[name]), (k, name)
+                assert p.trk.lastScanStats["ilp"] == solo.lastScanStats["ilp"]
+        assert solo.lastScanStats["ilp"] > 50 and min(solved) > 500, (solo.lastScanStats["ilp"], solved)
+    finally:
+        solo.close()
+        for p in parts:
+            p.trk.close()
