@@ -3,9 +3,12 @@
 
 A "step" = one radar scan through steps 1-6 of Tracker.addMeasurementList (grow/gate/score every leaf against
 every measurement, cluster, per-cluster 0-1 ILP, track termination, N-scan pruning) on the device-resident
-hypothesis forest -- three HIP launches (grow, cluster, blp incl. the per-target prune epilogue; the target-side commit of a
-scan rides in the next scan's grow launch [+ commit and add_targets launches when tracks are born]), no memsets, no host
-round trip.  stage_ms therefore shows the commit inside "gate"; "prune" is what two back-to-back event records cost.  Workload = BASELINE.json configs[2] (headline):
+hypothesis forest -- TWO HIP launches since round 4: the grow launch (gate + update + score + child creation; its target workgroups hook
+their targets into a device-wide union-find = the clustering; the target-side commit of the previous scan rides in it) and the ILP launch
+(cluster tables derived per workgroup, the ILPs, the per-target termination / prune epilogue), the grow launch of scan k + 1 launched
+any-order behind the ILP launch of scan k [+ commit and add_targets launches when tracks are born]; no memsets, no host round trip.
+stage_ms therefore shows the commit inside "gate", no "cluster" launch ("cluster" = two back-to-back event records), and "prune" is
+what two back-to-back event records cost.  Workload = BASELINE.json configs[2] (headline):
 500 targets, ~500 measurements/scan, N-scan = 5, synthetic scans from pymht_amd/utils/scenario.py.
 
 Protocol
@@ -37,9 +40,9 @@ import torch  # noqa: E402
 LAMBDA_NU = 1e-4
 ETA2 = 5.99
 # HBM bytes per fgrow_kernel launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes on this
-# workload, full-size scans): profiles/r02_pmc_hbm_traffic.txt.  NOT measured by this run (the counters need the profiler): the
-# bench line says so.  Keyed by config name; None = not profiled.
-PMC_TRAFFIC_BYTES = {"cfg3": (1706 + 3625) * 1024}      # (median launch of 252; the transient scans of the first N+2 reach 2622 + 4647)
+# workload, full-size scans): profiles/r04_pmc_hbm_traffic.txt.  Only quoted when the run's own counter passes are off or fail (--pmc off),
+# and labelled as not measured by this run.  Keyed by config name; None = not profiled.
+PMC_TRAFFIC_BYTES = {"cfg3": (1686 + 3681) * 1024}      # (round 4's steady-state launch; the transient scans of the first N+2 are larger)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured achievable copy rate
 
 
@@ -94,7 +97,10 @@ def pmc_traffic_live(config, timeout_s=180.0):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return tot, "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over a 64-scan replay of the same stream on this GPU, " \
-                "KiB per fgrow_kernel dispatch, mean of the last quarter of the launches (steady state)"
+                "KiB per fgrow_kernel dispatch, mean of the last quarter of the launches (steady state).  Under counter collection " \
+                "(ROCPROF_COUNTER_COLLECTION=1) rocprofv3 runs one kernel at a time, so the library keeps the initiator on the ctx stream and " \
+                "every launch wait is satisfied by stream order: the counted grow launch does the same loads and stores as the timed one, its " \
+                "waits for the previous scan's ILP launch return at once (the counters profile the event-synchronised variant of the path)"
 
 
 def model_of(sc):
@@ -559,7 +565,7 @@ def main():
     b_gate = float(per_leaf) * Lm + float(per_pair) * Gm + 8.0 * Mm
     gate_gbs = b_gate / (ms[0] * 1e-3) / 1e9
     traffic, traffic_src = PMC_TRAFFIC_BYTES.get(args.config), \
-        "from profiles/r02_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)"
+        "from profiles/r04_pmc_hbm_traffic.txt, not this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes per full-size launch)"
     if args.pmc == "auto" and rank == 0 and world == 1:
         if os.environ.get("MHT_STALL_DEBUG") == "1": print("[bench] counter passes start at %.1f s" % (time.time() - T_START), file=sys.stderr, flush=True)
         live, note = pmc_traffic_live(args.config)

@@ -43,7 +43,9 @@ class Initiator:
     def processMeasurements(self, radar_measurement_list, ais_measurement_list=()):
         """m_of_n.py:233-244: the list holds the measurements no track gated; returns the new `Target`s."""
         import torch
-        assert len(ais_measurement_list) == 0, "AIS initiation is out of scope of pymht_amd"
+        # (tracks started from AIS messages, m_of_n.py:262-280, go through the device initiator inside the forest: Tracker(aisAided=True)
+        # hands the messages over with mht_initiator_set_ais; this host-driven seam of the initiator takes radar measurements only)
+        assert len(ais_measurement_list) == 0, "Initiator.processMeasurements takes radar measurements; AIS-started tracks run through Tracker(aisAided=True)"
         z = np.ascontiguousarray(np.asarray(radar_measurement_list.measurements, dtype=np.float32)).reshape(-1, 2)
         zd = torch.from_numpy(z if len(z) else np.zeros((1, 2), np.float32)).to(self._ctx.device)
         _lib.check(self._lib.mht_initiator_step(self.handle, zd.data_ptr(), len(z), None, float(radar_measurement_list.time)))

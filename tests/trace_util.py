@@ -1,4 +1,5 @@
-"""Replay helpers for the golden scan traces (tests/golden/g2,g3,g3b,g13)."""
+"""Replay helpers for the golden scan traces recorded from the reference (tests/golden: the radar traces g2, g3, g3b, g6, g6b, g13*, g16,
+the six-state g17, the AIS-aided g18-g18f) and for the oracle side of the live comparisons."""
 import hashlib
 import numpy as np
 
