@@ -193,6 +193,7 @@ class Tracker():
         self._labels = np.zeros(0, np.int64)
         self._labels_src = None      # the report rows of the last scan: their `cluster` column is read when somebody asks for the clusters
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
+        self._history_mmsi = []     # AIS forest: the identities of those roots, chunk by chunk (0 = none)
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
@@ -541,7 +542,16 @@ class Tracker():
             live = recs[alive]
             moved = live["root_scan"] != prev["root_scan"][alive]
         if moved.any():      # the root of these targets advanced: the new roots join the committed history
-            self._history.append(live if moved.all() else live[moved])
+            chunk = live if moved.all() else live[moved]
+            self._history.append(chunk)
+            if self._ais:        # their identities (pyTarget.py:34: Target.mmsi), read while their layers are still in the device ring
+                mm = np.zeros(len(chunk), dtype=np.int64)
+                for sc in np.unique(chunk["root_scan"]):
+                    if sc >= 0 and scanNumber - int(sc) < self._cfg.n_scan + 4:
+                        rows = np.where((chunk["root_scan"] == sc) & (chunk["root_node"] >= 0))[0]
+                        if len(rows):
+                            mm[rows] = self._mmsi_layer(int(sc))[0][chunk["root_node"][rows]]
+                self._history_mmsi.append(mm)
         self._tbl_ = live
         self._sel_ = (live, scanTime, scanNumber, z)
 
@@ -656,9 +666,16 @@ class Tracker():
                     root = DeviceTarget(b[0], b[1], b[2], b[3], ID=tid, P_d=self.default_P_d, measurementNumber=b[4],
                                         measurement=b[5], status=b[6])
                 else:
-                    root = DeviceTarget(float(self._scan_times[max(int(tb["root_scan"][i]), 0)]), int(tb["root_scan"][i]), tb["root_x"][i].copy(), self.P_0,
-                                        ID=tid, P_d=self.default_P_d, measurementNumber=int(tb["root_meas"][i]),
+                    rs, rm, r_mmsi, r_hist = int(tb["root_scan"][i]), int(tb["root_meas"][i]), None, None
+                    if self._ais and rs >= 1 and int(tb["root_node"][i]) >= 0 and len(self.__scanHistory__) - rs < self._cfg.n_scan + 4:
+                        layer = self._mmsi_layer(rs)      # (the root's own identity and the one its track is bound to: per node on the device)
+                        mm, r_hist = int(layer[0][int(tb["root_node"][i])]), (int(layer[1][int(tb["root_node"][i])]) or None)
+                        if mm:
+                            r_mmsi, rm = mm, (rm if rm > 0 else None)
+                    root = DeviceTarget(float(self._scan_times[max(rs, 0)]), rs, tb["root_x"][i].copy(), self.P_0,
+                                        ID=tid, P_d=self.default_P_d, measurementNumber=rm, mmsi=r_mmsi,
                                         cumulativeNLLR=float(tb["root_cnllr"][i]))
+                    root._hist_mmsi = r_hist
                     root._lazy_parent = self._history_parent_loader(tid)
                 root.isRoot, root._tracker, root._node = True, self, int(tb["root_node"][i])
                 v.append(root)
@@ -706,13 +723,16 @@ class Tracker():
                                  measurement=b[5], status=b[6])
             first._tracker = self
             chain.append(first)
-        for ch in self._history:
+        for ci, ch in enumerate(self._history):
             for k in np.where(ch["id"] == target_id)[0]:
                 sc = int(ch["root_scan"][k])
                 zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
                 m = int(ch["root_meas"][k])
+                mmsi = None
+                if self._ais and ci < len(self._history_mmsi) and int(self._history_mmsi[ci][k]):
+                    mmsi, m = int(self._history_mmsi[ci][k]), (m if m > 0 else None)      # (an AIS-updated node without a radar measurement: measurementNumber None)
                 v = DeviceTarget(float(self._scan_times[max(sc, 0)]), sc, ch["root_x"][k].copy(), self.P_0, ID=target_id, P_d=self.default_P_d,
-                                 measurementNumber=m, measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
+                                 measurementNumber=m, measurement=(np.asarray(zz)[m - 1] if (zz is not None and m) else None), mmsi=mmsi,
                                  cumulativeNLLR=float(ch["root_cnllr"][k]))
                 v._tracker, v._node = self, int(ch["root_node"][k])
                 v.parent = chain[-1] if chain else None
@@ -763,11 +783,17 @@ class Tracker():
                 break
             zz = self.__scanHistory__[sc - 1].measurements if sc >= 1 else None
             m = int(meas[k])
+            mmsi = hist = None
+            if self._ais and sc >= 1:      # the ancestor's own identity and the one its track is bound to (pyTarget.py:34, :297-302), per node on the device
+                layer = self._mmsi_layer(sc)
+                mm, hist = int(layer[0][int(nodes[k])]), (int(layer[1][int(nodes[k])]) or None)
+                if mm:
+                    mmsi, m = mm, (m if m > 0 else None)
             a = DeviceTarget(self.__scanHistory__[sc - 1].time if sc >= 1 else view.time, sc, x[k].copy(),
                              P[k].reshape(self.nx, self.nx).copy(), ID=target_id, P_d=self.default_P_d, measurementNumber=m,
-                             measurement=(np.asarray(zz)[m - 1] if (zz is not None and m > 0) else None),
+                             measurement=(np.asarray(zz)[m - 1] if (zz is not None and m) else None), mmsi=mmsi,
                              cumulativeNLLR=float(cn[k]))
-            a._tracker, a._node = self, int(nodes[k])
+            a._tracker, a._node, a._hist_mmsi = self, int(nodes[k]), hist
             prev._parent, prev._lazy_parent = a, None
             prev = a
         prev._lazy_parent = None

@@ -117,3 +117,53 @@ def test_tracker_replays_reference_ais_trace(name, gold_dir):
         assert n_fused > 50          # (the trace does exercise fused children)
     finally:
         trk.close()
+
+
+@pytest.mark.parametrize("name", ["g18b_trace_ais_dense", "g18c_trace_ais_n5"])
+def test_identities_on_ancestor_views(name, gold_dir):
+    """`Target.mmsi` of EVERY node of a track's history (pyTarget.py:34), not only of the selected nodes and the leaves: the ancestors inside
+    the device window and the committed roots behind it carry the identity of the AIS message they were updated with (and a measurement
+    number of None where they have no radar measurement, tracker.py:520), as the oracle's trees -- pinned bit for bit to the reference by
+    tests/test_oracle_golden.py on the same fixture -- have them."""
+    from trace_util import make_oracle_ais, ais_messages
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    trk = Tracker(pv, float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]), N=int(g["N"]), eta2=float(g["eta2"]),
+                  eta2_ais=float(g["eta2_ais"]), radarRange=float(g["radar_range"]), position=g["position"], aisAided=True,
+                  useInitiator=bool(g["with_initiator"]), maxTargets=256, maxNodes=1 << 16, maxMeasurements=256)
+    o = make_oracle_ais(g)
+    try:
+        for x in g["x0"]:
+            trk.initiateTarget(Target(float(g["t0"]), None, x.copy(), pv.P0, status="preinitialized"))
+        n_hist_ids = 0
+        for k in range(int(g["n_scans"])):
+            p = "s%02d_" % k
+            msgs = ais_messages(g, k)
+            o.add_scan(float(g["times"][k]), g[p + "z"], ais=msgs, prune_similar=bool(g["prune_similar"]),
+                       ais_initialization=bool(g["ais_init"]) if "ais_init" in g.files else False)
+            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]),
+                                   AisMessageList([AisMessage(float(m.time), m.state, int(m.mmsi), bool(m.highAccuracy)) for m in msgs]),
+                                   aisInitialization=bool(g["ais_init"]) if "ais_init" in g.files else False, pruneSimilar=bool(g["prune_similar"]))
+            if k % 3 != 2 and k != int(g["n_scans"]) - 1:
+                continue
+            nodes = list(trk.getTrackNodes())
+            assert [n.ID for n in nodes] == [n.ID for n in o.track_nodes]
+            for tn, on in zip(nodes, o.track_nodes):
+                got, want = [], []
+                a = tn
+                while a is not None:
+                    got.append((int(a.scanNumber), a.measurementNumber if a.measurementNumber is None else int(a.measurementNumber), a.mmsi))
+                    a = a.parent
+                b = on
+                while b is not None:
+                    want.append((int(b.scan), b.meas if b.meas is None else int(b.meas), b.mmsi))
+                    b = b.parent
+                assert got == want, (k, tn.ID, got, want)
+                n_hist_ids += sum(1 for q in got[1:] if q[2] is not None)
+        assert n_hist_ids > 20      # (identities were found on ancestors, inside and behind the window)
+    finally:
+        trk.close()
