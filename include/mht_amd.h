@@ -209,6 +209,14 @@ int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* 
                  double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
                  double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children);
 
+/* The same for leaves whose covariance the reference carries in float64 (ABI 5): P dev [L][16] float64 -- the leaves with MHT_F_COV_F64 in
+ * `flags` are fused from it as it is (kalman.predict_single on a float64 node.P_0, tracker.py:449-450: nodes behind an AIS update and their
+ * targets' later leaves), the others from its values rounded to float32 (exact when they ARE float32 values). */
+int mht_fuse_ais_f64(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const double* P, const double* pd,
+                     const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                     double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                     double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children);
+
 /* ---- the device-resident hypothesis forest: Tracker.addMeasurementList end to end -----------------------------
  * Replaces steps 1-6 of tracker.py:162-307 (grow :207-209, cluster :220, optimise :228-236, terminate :252-253,
  * N-scan prune :258 = seam (iv) Tracker._nScanPruning, tracker.py:1219-1231 / pyTarget.py:343-356) without a host

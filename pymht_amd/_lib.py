@@ -143,6 +143,7 @@ def _declare(lib, nx=4):
         "mht_forest_read_mmsi": [vp, i32, i32, i32, vp, vp],
         "mht_initiator_set_ais": [vp, vp, i32, vp],
         "mht_fuse_ais": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, dbl, dbl, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp],
+        "mht_fuse_ais_f64": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, dbl, dbl, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp],
         "mht_forest_create": [vp, C.POINTER(MhtModel), C.POINTER(MhtForestConfig)],
         "mht_forest_add_targets": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],
         "mht_forest_add_targets_dev": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp],

@@ -15,7 +15,7 @@ namespace mht {
 
 struct AisSeamArgs {
     Model model;                                   // C, R, eta2, lambda_ex are read
-    int L; const double* x; const uint8_t* flags; const float* P; const double* pd; const int32_t* own;
+    int L; const double* x; const uint8_t* flags; const float* P; const double* P64; const double* pd; const int32_t* own;      // P64 != null (mht_fuse_ais_f64): [L][16] doubles, float64 covariances where flags carries F_COV_F64
     const AisGroup* groups; int nG; const AisMsg* msgs;
     double eta2_ais, lambda_ais;
     const float* z; int M;
@@ -44,11 +44,19 @@ struct SeamEmit {
 
 template <typename EMIT>
 __device__ __forceinline__ int seam_leaf(const AisSeamArgs& a, int l, EMIT& e) {
-    float P[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) P[i] = a.P[(size_t)l * 16 + i];
     const double pd = a.pd[l];
     const int own = a.own ? a.own[l] : 0;
+    if (a.P64 && (a.flags[l] & F_COV_F64)) {      // a node the reference carries in float64 (state and covariance: a promoted target's)
+        double Pd[16], xd[4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Pd[i] = a.P64[(size_t)l * 16 + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xd[k] = a.x[(size_t)k * a.L + l];
+        return ais_fuse_leaf<double>(a.model, a.groups, a.nG, a.msgs, xd, Pd, pd, own, a.eta2_ais, a.lambda_ais, a.z, a.M, e);
+    }
+    float P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = a.P64 ? (float)a.P64[(size_t)l * 16 + i] : a.P[(size_t)l * 16 + i];
     if (a.flags[l] & F_STATE_F32) {
         float xs[4];
 #pragma unroll
@@ -198,14 +206,14 @@ int launch_forest_ais(mht_ctx* ctx, const AisForestArgs& a, int n_targets_ub) {
 
 using namespace mht;
 
-extern "C" int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const float* P, const double* pd,
-                            const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
-                            double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
-                            double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children) {
+static int fuse_ais_impl(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const float* P, const double* P64, const double* pd,
+                         const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                         double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                         double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children) {
     MHT_REQUIRE(NX == 4, "mht_fuse_ais: AIS messages report four states (models/ais.py); this is the %d-state build of the library", NX);
     MHT_REQUIRE(ctx && model && child_ptr, "mht_fuse_ais: null argument");
     MHT_REQUIRE(L >= 0 && M >= 0 && cap >= 0 && nG >= 0 && nA >= 0, "mht_fuse_ais: negative size");
-    MHT_REQUIRE(L == 0 || (x && flags && P && pd), "mht_fuse_ais: null leaf array");
+    MHT_REQUIRE(L == 0 || (x && flags && (P || P64) && pd), "mht_fuse_ais: null leaf array");
     MHT_REQUIRE(nG == 0 || (groups && msgs), "mht_fuse_ais: null message array");
     MHT_REQUIRE(M == 0 || z, "mht_fuse_ais: z is null");
     MHT_REQUIRE(cap == 0 || (out_x && out_P && out_radar && out_nllr && out_msg), "mht_fuse_ais: null output array");
@@ -220,7 +228,7 @@ extern "C" int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, con
     for (int i = 0; i < 4; ++i) a.model.R[i] = model->R[i];
 #endif
     a.model.eta2 = model->eta2; a.model.lambda_ex = model->lambda_ex;
-    a.L = L; a.x = x; a.flags = flags; a.P = P; a.pd = pd; a.own = own;
+    a.L = L; a.x = x; a.flags = flags; a.P = P; a.P64 = P64; a.pd = pd; a.own = own;
     a.nG = nG; a.eta2_ais = eta2_ais; a.lambda_ais = lambda_ais; a.z = z; a.M = M; a.cap = cap;
     a.child_ptr = child_ptr; a.out_x = out_x; a.out_P = out_P; a.out_radar = out_radar; a.out_nllr = out_nllr; a.out_msg = out_msg;
     // scratch: groups | messages | cnt[L]
@@ -317,3 +325,18 @@ int launch_forest_ct(mht_ctx* ctx, const CtForestArgs& a, int n_targets_ub) {
 #endif
 }
 }  // namespace mht
+
+extern "C" int mht_fuse_ais(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const float* P, const double* pd,
+                            const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                            double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                            double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children) {
+    return fuse_ais_impl(ctx, model, L, x, flags, P, nullptr, pd, own, groups, nG, msgs, nA, eta2_ais, lambda_ais, z, M, child_ptr, out_x, out_P, out_radar, out_nllr,
+                         out_msg, cap, n_children);
+}
+extern "C" int mht_fuse_ais_f64(mht_ctx* ctx, const mht_model* model, int32_t L, const double* x, const uint8_t* flags, const double* P, const double* pd,
+                                const int32_t* own, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais,
+                                double lambda_ais, const float* z, int32_t M, int32_t* child_ptr, double* out_x, double* out_P, int32_t* out_radar,
+                                double* out_nllr, int32_t* out_msg, int32_t cap, int32_t* n_children) {
+    return fuse_ais_impl(ctx, model, L, x, flags, nullptr, P, pd, own, groups, nG, msgs, nA, eta2_ais, lambda_ais, z, M, child_ptr, out_x, out_P, out_radar, out_nllr,
+                         out_msg, cap, n_children);
+}

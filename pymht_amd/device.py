@@ -177,7 +177,11 @@ def fuse_radar_and_ais(ctx, model, eta2, lambda_ex, x, P, pd, flags, own, ais_li
     m = make_model(model.Phi(scan_time - leaf_time), model.Q(scan_time - leaf_time), model.C_RADAR, model.R_RADAR(), eta2, lambda_ex, 0.8)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
     xd = t(np.asarray(x, dtype=np.float64).reshape(n, 4).T, np.float64) if n else torch.zeros((4, 0), dtype=torch.float64, device=dev)
-    Pd = t(np.asarray(P, dtype=np.float32).reshape(n, 16), np.float32)
+    # (P float64: `mht_fuse_ais_f64` -- the leaves flagged MHT_F_COV_F64 are fused from their float64 covariance, as the reference does with
+    # a node whose P_0 is float64)
+    f64 = np.asarray(P).dtype == np.float64
+    Pd = t(np.asarray(P).reshape(n, 16), np.float64 if f64 else np.float32)
+    fuse = lib.mht_fuse_ais_f64 if f64 else lib.mht_fuse_ais
     pdd, fd = t(np.asarray(pd, dtype=np.float64), np.float64), t(np.asarray(flags, dtype=np.uint8), np.uint8)
     od = t(np.asarray(own, dtype=np.int32), np.int32)
     zd = t(np.asarray(z, dtype=np.float32).reshape(-1, 2), np.float32)
@@ -189,7 +193,7 @@ def fuse_radar_and_ais(ctx, model, eta2, lambda_ex, x, P, pd, flags, own, ais_li
         orad, omsg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
         onl = torch.zeros(cap, dtype=torch.float64, device=dev)
         total = C.c_int32(0)
-        rc = lib.mht_fuse_ais(ctx.handle, C.byref(m), n, xd.data_ptr(), fd.data_ptr(), Pd.data_ptr(), pdd.data_ptr(), od.data_ptr(),
+        rc = fuse(ctx.handle, C.byref(m), n, xd.data_ptr(), fd.data_ptr(), Pd.data_ptr(), pdd.data_ptr(), od.data_ptr(),
                               C.byref(groups), nG, C.byref(msgs), len(order), float(eta2_ais), float(lambda_ais), zd.data_ptr(), M,
                               ptr.data_ptr(), ox.data_ptr(), oP.data_ptr(), orad.data_ptr(), onl.data_ptr(), omsg.data_ptr(), cap, C.byref(total))
         if rc == _lib.MHT_E_CAPACITY:

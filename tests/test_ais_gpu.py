@@ -167,3 +167,96 @@ def test_identities_on_ancestor_views(name, gold_dir):
         assert n_hist_ids > 20      # (identities were found on ancestors, inside and behind the window)
     finally:
         trk.close()
+
+
+@pytest.mark.parametrize("name", ["g18b_trace_ais_dense", "g18f_trace_ais_init_dense", "g18d_trace_ais_similar"])
+def test_ais_trace_across_value_table_generations(name, gold_dir, monkeypatch):
+    """float64 covariances are values of the forest's table like the float32 ones (two ids each, csrc/mht_vtab.h).  These streams take 1-2 k ids
+    per scan (a fused child's covariance and its pseudo parent; the per-leaf values of promoted targets); with a table of 16 384 ids the host
+    sees it filling after four scans and the live leaves -- float32 and float64 ones, pseudo-parent keys of fused children and of merged
+    hypotheses included -- are re-keyed into the other generation (vt_rebuild_kernel; a switch at most every R + 2 scans, so a smaller table
+    would overflow before the second one).  The trace recorded from the reference must still come out bit for bit."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    monkeypatch.setenv("MHT_VTAB_CAP", "16384")
+    trk = Tracker(pv, float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]), N=int(g["N"]), eta2=float(g["eta2"]),
+                  eta2_ais=float(g["eta2_ais"]), radarRange=float(g["radar_range"]), position=g["position"], aisAided=True,
+                  useInitiator=bool(g["with_initiator"]), maxTargets=256, maxNodes=1 << 16, maxMeasurements=256)
+    monkeypatch.delenv("MHT_VTAB_CAP")
+    try:
+        for x in g["x0"]:
+            trk.initiateTarget(Target(float(g["t0"]), None, x.copy(), pv.P0, status="preinitialized"))
+        for k in range(int(g["n_scans"])):
+            p = "s%02d_" % k
+            msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
+                                   zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
+            trk.addMeasurementList(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, aisInitialization=bool(g["ais_init"]) if "ais_init" in g.files else False,
+                                   pruneSimilar=bool(g["prune_similar"]))
+            lb = trk.leafBatch()
+            assert np.array_equal(lb["ID"], g[p + "leaf_ID"]) and np.array_equal(lb["meas"], g[p + "leaf_meas"]) and np.array_equal(lb["mmsi"], g[p + "leaf_mmsi"]), k
+            assert np.array_equal(lb["x"], g[p + "leaf_x"]) and np.array_equal(lb["Pf64"], g[p + "leaf_Pf64"]) and np.array_equal(lb["P"], g[p + "leaf_P"]), k
+            assert np.array_equal([r.ID for r in trk.__targetList__], g[p + "ids"]), k
+        r = np.zeros(1, np.int32)
+        _lib.check(trk._lib.mht_forest_debug_read(trk._ctx.handle, b"vt_rebuilds", r.ctypes.data_as(C.c_void_p), 4))
+        assert r[0] >= 1, "the table was meant to fill: %d generation switches" % int(r[0])
+    finally:
+        trk.close()
+
+
+def test_fuse_seam_float64_covariances_match_live_oracle(gpu_ctx, gold_dir):
+    """`mht_fuse_ais_f64`: leaves the reference carries in float64 (node.P_0 float64 behind an AIS update, tracker.py:449-450 runs
+    kalman.predict_single on it as it is).  The G19 leaves with their covariances perturbed to values float32 cannot hold, against the
+    oracle's `fuse_radar_ais` (the reference's NumPy expressions) evaluated HERE: children and order exact; states and covariances bit for bit
+    where this host's numpy runs the kernel set csrc/mht_la64.h restates, 1e-12 otherwise."""
+    import mht_oracle as orc
+    from ais_util import g19_case
+    from util import live_numpy_f64_is_pinned
+    from pymht_amd.device import fuse_radar_and_ais
+    from pymht_amd.models import pv
+    g = np.load(os.path.join(gold_dir, "g19_ais_fusion.npz"))
+    lam = float(g["lambda_phi"]) + float(g["lambda_nu"])
+    exact = live_numpy_f64_is_pinned()
+    rng = np.random.default_rng(64)
+    total = 0
+    for ci in range(min(int(g["n_cases"]), 6)):
+        c = g19_case(g, ci)
+        n = len(c["x"])
+        keep = [l for l in range(n) if not c["xf32"][l]]      # (a float64-covariance node has a float64 state)
+        if not keep:
+            continue
+        x = np.asarray(c["x"], dtype=np.float64)[keep]
+        P = np.asarray(c["P"], dtype=np.float64)[keep]
+        P = P * (1.0 + 1e-9 * rng.uniform(-1, 1, size=(len(keep), 1, 1))) + np.eye(4)[None] * 1e-7 * rng.uniform(0, 1, size=(len(keep), 1, 1))
+        pd = np.asarray(c["pd"], dtype=np.float64)[keep]
+        flags = np.full(len(keep), 16, dtype=np.uint8)          # MHT_F_COV_F64
+        t_leaf, t_scan = float(g[c["p"] + "t_leaf"]), float(g[c["p"] + "t_scan"])
+        r = fuse_radar_and_ais(gpu_ctx, pv, float(g["eta2"]), lam, x, P, pd, flags, np.zeros(len(keep), dtype=np.int32), c["msgs"], t_leaf, t_scan,
+                               c["eta2_ais"], c["lambda_ais"], c["z"])
+
+        class Leaf:
+            pass
+        leaves = []
+        for i in range(len(keep)):
+            lf = Leaf()
+            lf.time, lf.x, lf.P, lf.P_d = t_leaf, x[i], P[i], float(pd[i])
+            leaves.append(lf)
+        msgs = [orc.AisMessage(float(m.time), np.asarray(m.state, dtype=np.float64), int(m.mmsi), bool(m.highAccuracy)) for m in c["msgs"]]
+        want = orc.fuse_radar_ais(leaves, msgs, c["z"], t_scan, orc.model_C(), orc.model_R(), float(g["eta2"]), c["eta2_ais"], lam, c["lambda_ais"])
+        for i, kids in enumerate(want):
+            a, b = int(r["child_ptr"][i]), int(r["child_ptr"][i + 1])
+            assert b - a == len(kids), (ci, i)
+            for q, (xk, Pk, rk, nk, mk) in enumerate(kids):
+                assert (r["radar"][a + q] == (-1 if rk is None else rk)) and r["mmsi"][a + q] == mk
+                if exact:
+                    assert np.array_equal(r["x"][a + q], xk) and np.array_equal(r["P"][a + q], Pk), (ci, i, q)
+                else:
+                    assert np.allclose(r["x"][a + q], xk, rtol=1e-12, atol=1e-12) and np.allclose(r["P"][a + q], Pk, rtol=1e-12, atol=1e-12)
+                assert abs(r["nllr"][a + q] - nk) < 1e-11
+            total += len(kids)
+    assert total > 100
