@@ -242,7 +242,7 @@ typedef struct mht_forest_config {
  * above: 16-entry records, the ILPs run on the HBM policy).  mht_forest_set_ais hands over the messages of the NEXT scan, grouped as
  * for mht_fuse_ais; the next mht_forest_step / _step_host / _scan consumes them: radar M + nA <= max_meas (rounded up to a multiple
  * of 64).  A scan without messages needs no call.  Messages start tracks through the initiator (mht_initiator_set_ais).
- * Not available to members of a group or to the cluster-sharded step.
+ * Not available to members of a group.  The cluster-sharded step takes the messages (ABI 5): every shard makes the fused children itself.
  * mht_forest_read_mmsi: identities of the nodes [first, first + count) of the layer of `scan` (host arrays out, either may be null):
  * mmsi[i] = the message node first + i was updated with (0: none; with measurement number 0 that is a child WITHOUT a radar
  * measurement, the reference's measurementNumber None), hist[i] = Target._getHistoricalMmsi(). */

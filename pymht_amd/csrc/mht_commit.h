@@ -44,6 +44,7 @@ struct FCounts {          // device-side counters of the forest
     // (Forest::tq_on): the next scan's grow launch sits on another hardware queue behind a gate kernel that waits for this count -- its
     // 43 KB workgroups must not take a CU before every 155 KB ILP workgroup of the scan before has one
     unsigned long long ilp_started;
+    unsigned long long tq_flag;      // (MHT_TQ_FLAGS=1: the scan whose grow launch on the second queue is complete, posted by tq_post_kernel)
 };
 // Ticket among the few workgroups of a launch that may play a role: 0 for the first one to arrive in launch `tag`, 1, 2, ... for the
 // others.  The word carries the tag of the launch it was last used in, so nothing has to be reset (launches may skip the scheme).

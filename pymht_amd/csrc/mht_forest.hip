@@ -1173,6 +1173,23 @@ static void hp_print() {
     fprintf(stderr, "\n");
     g_hp = HostProf();
 }
+// AIS forest: forest_ais_kernel (mht_ais.hip) over the leaves of the committed table, in front of scan s's grow launch; disarms the messages
+static int forest_ais_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub, const float* z, int M) {
+    AisForestArgs aa = {};
+    const mht_nodes& in = f->layer[(s - 1) % f->R];
+    fill_model_only(aa.model, &f->model);
+    aa.nT_dev = &f->cnt->nT; aa.t_first = f->tab[s & 1].first; aa.t_leaf_off = f->tab[s & 1].leaf_off;
+    aa.x = in.x; aa.pd = in.pd; aa.cov = in.cov; aa.flags = in.flags; aa.hmmsi = f->l_hmmsi[(s - 1) % f->R]; aa.cap = f->Ncap;
+    aa.vt = f->vt;
+    aa.groups = reinterpret_cast<const AisGroup*>(f->ais_groups_dev); aa.nG = f->ais_nG; aa.msgs = reinterpret_cast<const AisMsg*>(f->ais_msgs_dev);
+    aa.eta2_ais = f->ais_eta2; aa.lambda_ais = f->ais_lambda; aa.z = z; aa.M = M;
+    aa.nf = f->ais_nf; aa.off = f->ais_off; aa.rec = f->ais_rec; aa.rec_cap = f->ais_rec_cap; aa.rec_count = f->ais_count;
+    aa.status = f->status2 + (s & 1);
+    if (hipMemsetAsync(f->ais_count, 0, sizeof(unsigned), ctx->stream) != hipSuccess) { set_error("forest_ais_prepass: hipMemsetAsync failed"); return MHT_E_HIP; }
+    const int rc = launch_forest_ais(ctx, aa, n_ub);
+    f->ais_armed = false;
+    return rc;
+}
 // constant-turn forest: forest_ct_kernel (mht_ais.hip) over the leaves of the committed table, in front of scan s's grow launch
 static int forest_ct_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub) {
     CtForestArgs ca = {};
@@ -1220,21 +1237,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
 #define MHT_STEP_HIP(expr) do { if ((expr) != hipSuccess) { f->dead = true; set_error("mht_forest_step: %s failed", #expr); return MHT_E_HIP; } } while (0)
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[0], st));
     // ---- 0: AIS-aided children of every leaf (tracker.py:394-396, :417-552), only on scans that carry messages ----------------
-    if (ais) {
-        AisForestArgs aa = {};
-        const mht_nodes& in = f->layer[(pl.s - 1) % f->R];
-        fill_model_only(aa.model, &f->model);
-        aa.nT_dev = &f->cnt->nT; aa.t_first = f->tab[pl.s & 1].first; aa.t_leaf_off = f->tab[pl.s & 1].leaf_off;
-        aa.x = in.x; aa.pd = in.pd; aa.cov = in.cov; aa.flags = in.flags; aa.hmmsi = f->l_hmmsi[(pl.s - 1) % f->R]; aa.cap = f->Ncap;
-        aa.vt = f->vt;
-        aa.groups = reinterpret_cast<const AisGroup*>(f->ais_groups_dev); aa.nG = f->ais_nG; aa.msgs = reinterpret_cast<const AisMsg*>(f->ais_msgs_dev);
-        aa.eta2_ais = f->ais_eta2; aa.lambda_ais = f->ais_lambda; aa.z = z; aa.M = M;
-        aa.nf = f->ais_nf; aa.off = f->ais_off; aa.rec = f->ais_rec; aa.rec_cap = f->ais_rec_cap; aa.rec_count = f->ais_count;
-        aa.status = f->status2 + (pl.s & 1);
-        MHT_STEP_HIP(hipMemsetAsync(f->ais_count, 0, sizeof(unsigned), st));
-        MHT_STEP_CHECK(launch_forest_ais(ctx, aa, pl.n_ub));
-        f->ais_armed = false;
-    }
+    if (ais) MHT_STEP_CHECK(forest_ais_prepass(ctx, f, pl.s, pl.n_ub, z, M));
     if (f->ct) MHT_STEP_CHECK(forest_ct_prepass(ctx, f, pl.s, pl.n_ub));      // ---- 0': the leaves' own transitions, predictions, gains and children covariances
     // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
@@ -1302,8 +1305,8 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             ctx->stream = keep;
             MHT_STEP_CHECK(rc_grow);
             if (flags) {
-                hipLaunchKernelGGL(tq_post_kernel, dim3(1), dim3(64), 0, f->tq_stream, &f->cnt->role_tick, (unsigned long long)pl.s);
-                hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(&f->cnt->role_tick), (unsigned long long)pl.s, &f->cnt->overflow);
+                hipLaunchKernelGGL(tq_post_kernel, dim3(1), dim3(64), 0, f->tq_stream, &f->cnt->tq_flag, (unsigned long long)pl.s);
+                hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(&f->cnt->tq_flag), (unsigned long long)pl.s, &f->cnt->overflow);
                 MHT_STEP_HIP(hipGetLastError());
             } else {
             MHT_STEP_HIP(hipEventRecord(f->tq_ev, f->tq_stream));
@@ -1434,16 +1437,26 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
     { const int rc = flush_publish(ctx, f); if (rc) return rc; }
     StepPlan pl;
-    if (f->ais_armed) { set_error("mht_forest_step_sharded_begin: the cluster-sharded step takes no AIS messages (mht_forest_set_ais armed some)"); return MHT_E_STATE; }
-    if (f->ct) { const int rcf = flush_commit(ctx, f); if (rcf) return rcf; }      // (forest_ct_kernel walks the leaves of the COMMITTED table)
-    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) return rc; }
+    // (AIS messages: the fused children are made on every shard, like grow and clustering -- forest_ais_kernel walks the leaves of the COMMITTED
+    // table, as forest_ct_kernel does)
+    const bool ais = f->ais && f->ais_armed;
+    if (ais && !(M + f->ais_nA <= f->Mpad)) {
+        f->ais_armed = false;
+        set_error("mht_forest_step_sharded_begin: %d radar measurements + %d AIS messages exceed max_meas=%d", M, f->ais_nA, f->cfg.max_meas);
+        return MHT_E_INVALID;
+    }
+    if (f->ct || ais) { const int rcf = flush_commit(ctx, f); if (rcf) return rcf; }
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step_sharded_begin", pl); if (rc) { f->ais_armed = false; return rc; } }
+    if (ais) pl.W = (M + f->ais_nA + 63) / 64;
     int rc;
+    if (ais) { rc = forest_ais_prepass(ctx, f, pl.s, pl.n_ub, z, M); if (rc) { f->dead = true; return rc; } }
     if (f->ct) { rc = forest_ct_prepass(ctx, f, pl.s, pl.n_ub); if (rc) { f->dead = true; return rc; } }
     {
         FGrowArgs g;
         fill_fgrow(f, pl.s, pl.fused, g);
         FDyn d = {};
         d.z = z; d.M = M; d.W = pl.W; d.c_scan = f->pending_dyn.scan; d.c_M = f->pending_dyn.M; d.c_W = f->pending_dyn.W;
+        d.ais_on = ais ? 1 : 0;
         d.maybe_dead = (f->similar_ran_scan == pl.s - 1);
         rc = launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr);
     }

@@ -96,15 +96,19 @@ class ClusterShardedTracker:
         self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist, always_exchange))
         self.sel_rel = torch.full((tracker._cfg.max_targets,), -1, dtype=torch.int32, device=tracker._ctx.device)
 
-    def begin(self, scanList, **kwargs):
+    def begin(self, scanList, aisList=None, **kwargs):
         """Grow, cluster and this rank's share of the ILPs (asynchronous).  `pruneSimilar=True` (tracker.py:230): similar-state
-        pruning of the lone targets, replicated on every rank like grow and clustering."""
+        pruning of the lone targets, replicated on every rank like grow and clustering.  `aisList` (a Tracker made with aisAided=True):
+        the AIS-aided children (tracker.py:417-552) are made on every rank as well -- every rank must be given the same messages."""
         from . import _lib
         trk = self.trk
         trk._drain()
         self._tic = {'Total': __import__('time').time()}
-        self._z = trk._accept_scan(scanList, None, kwargs)
+        self._ais_list = aisList
+        self._z = trk._accept_scan(scanList, aisList, kwargs)
         trk._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))
+        if aisList is not None and len(aisList) > 0:
+            trk._arm_ais(scanList, aisList, self._z.shape[0], bool(kwargs.get('aisInitialization', True)))
         zd = trk._upload_scan(self._z)
         self.sel_rel.fill_(-1)      # (the device resets the live targets' entries itself; this also clears slots of targets long gone)
         _lib.check(trk._lib.mht_forest_step_sharded_begin(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,
@@ -116,9 +120,10 @@ class ClusterShardedTracker:
         from . import _lib
         trk = self.trk
         _lib.check(trk._lib.mht_forest_step_sharded_end(trk._ctx.handle, self.sel_rel.data_ptr()))
-        trk._after_step(self._scan, self._z, None, self._tic)
+        trk._leaf_time = float(self._scan.time)      # (what the next scan's AIS messages are timed against, tracker.py:449)
+        trk._after_step(self._scan, self._z, self._ais_list, self._tic)
 
-    def addMeasurementList(self, scanList, **kwargs):
-        self.begin(scanList, **kwargs)
+    def addMeasurementList(self, scanList, aisList=None, **kwargs):
+        self.begin(scanList, aisList, **kwargs)
         self.exchange(self.sel_rel)
         self.end()

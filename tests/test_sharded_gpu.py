@@ -240,3 +240,57 @@ def test_cluster_sharded_two_processes_one_gpu_gloo():
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] > 0
     assert res[0][3] > 0 and res[1][3] > 0, "both ranks solved clusters: %r" % (res,)
+
+
+@pytest.mark.parametrize("name", ["g18b_trace_ais_dense", "g18f_trace_ais_init_dense"])
+def test_cluster_sharded_ais_trace_equals_reference(name):
+    """AIS-aided scans through the cluster-sharded step (two shards on one GPU): the fused children (tracker.py:417-552) are made on every
+    shard like grow and clustering, the ILPs -- with their AIS rows -- are spread by cluster.  Every shard must reproduce the trace recorded
+    from the reference bit for bit (states and covariances of all leaves in the reference's dtypes), AIS-started tracks included."""
+    import torch
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+    def mk():
+        trk = Tracker(pv, float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]), N=int(g["N"]), eta2=float(g["eta2"]),
+                      eta2_ais=float(g["eta2_ais"]), radarRange=float(g["radar_range"]), position=g["position"], aisAided=True,
+                      useInitiator=bool(g["with_initiator"]), maxTargets=256, maxNodes=1 << 16, maxMeasurements=256)
+        for x in g["x0"]:
+            trk.initiateTarget(Target(float(g["t0"]), None, x.copy(), pv.P0, status="preinitialized"))
+        return trk
+    parts = [ClusterShardedTracker(mk(), 2, i, exchange=lambda t: None) for i in range(2)]
+    solved = [0, 0]
+    try:
+        for k in range(int(g["n_scans"])):
+            p = "s%02d_" % k
+            kw = dict(aisInitialization=bool(g["ais_init"]) if "ais_init" in g.files else False, pruneSimilar=bool(g["prune_similar"]))
+            for q in parts:
+                msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
+                                       zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
+                q.begin(MeasurementList(float(g["times"][k]), g[p + "z"]), msgs, **kw)
+            both = torch.stack([(q.sel_rel >= 0).int() for q in parts])
+            assert int(both.sum(dim=0).max()) <= 1
+            for i in range(2):
+                solved[i] += int(both[i].sum())
+            merged = torch.stack([q.sel_rel for q in parts]).max(dim=0).values
+            for q in parts:
+                q.sel_rel.copy_(merged)
+                q.end()
+            for q in parts:
+                trk = q.trk
+                assert np.array_equal([r.ID for r in trk.__targetList__], g[p + "ids"]), k
+                nodes = list(trk.getTrackNodes())
+                assert np.array_equal([n.ID for n in nodes], g[p + "sel_ID"]), k
+                assert np.array_equal([0 if n.mmsi is None else n.mmsi for n in nodes], g[p + "sel_mmsi"]), k
+                lb = trk.leafBatch()
+                assert np.array_equal(lb["ID"], g[p + "leaf_ID"]) and np.array_equal(lb["meas"], g[p + "leaf_meas"]) and np.array_equal(lb["mmsi"], g[p + "leaf_mmsi"]), k
+                assert np.array_equal(lb["x"], g[p + "leaf_x"]) and np.array_equal(lb["Pf64"], g[p + "leaf_Pf64"]) and np.array_equal(lb["P"], g[p + "leaf_P"]), k
+        assert min(solved) > 0, solved
+    finally:
+        for q in parts:
+            q.trk.close()
