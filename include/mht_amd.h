@@ -256,6 +256,9 @@ typedef struct mht_forest_config {
 int mht_forest_create_ex(mht_ctx* ctx, const mht_model* model, const struct mht_forest_config* cfg, uint32_t flags);
 int mht_forest_set_ais(mht_ctx* ctx, const mht_ais_group* groups, int32_t nG, const mht_ais_msg* msgs, int32_t nA, double eta2_ais, double lambda_ais);
 int mht_forest_read_mmsi(mht_ctx* ctx, int32_t scan, int32_t first, int32_t count, int32_t* mmsi, int32_t* hist);
+/* the same for n given nodes of the layer (host array `nodes`; a node outside the layer gives 0): a gather on the device, for callers that
+ * need a few scattered nodes -- e.g. the roots that join a track's committed history -- and not a whole layer (ABI 5) */
+int mht_forest_read_mmsi_nodes(mht_ctx* ctx, int32_t scan, int32_t n, const int32_t* nodes, int32_t* mmsi, int32_t* hist);
 
 /* per-target record of the scan report (old target-list order) */
 typedef struct mht_target_report {

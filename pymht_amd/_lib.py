@@ -141,6 +141,7 @@ def _declare(lib, nx=4):
         "mht_forest_create_ex": [vp, vp, vp, C.c_uint32],
         "mht_forest_set_ais": [vp, vp, i32, vp, i32, dbl, dbl],
         "mht_forest_read_mmsi": [vp, i32, i32, i32, vp, vp],
+        "mht_forest_read_mmsi_nodes": [vp, i32, i32, vp, vp, vp],
         "mht_initiator_set_ais": [vp, vp, i32, vp],
         "mht_fuse_ais": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, dbl, dbl, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp],
         "mht_fuse_ais_f64": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, dbl, dbl, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp],

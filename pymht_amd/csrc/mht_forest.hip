@@ -631,6 +631,11 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
         long long vc = 2ll * f->Ncap;
         if (vc < (1 << 16)) vc = 1 << 16;
         if (vc > (1 << 20)) vc = 1 << 20;
+        // (an AIS forest: the float64 covariances of AIS-updated targets are target specific -- nothing is shared across targets behind
+        // a message -- and take two ids each, as do their pseudo parents: ~4 ids per leaf of a promoted target and scan, 200 k per scan at
+        // the headline size with half of the ships reporting, and a generation must last R + 2 scans.  1.9 GB per generation at 8 M ids:
+        // sized for the 288 GB part)
+        if (flags & MHT_FOREST_AIS) { vc = 16ll * f->Ncap; if (vc < (1 << 20)) vc = 1 << 20; if (vc > (1 << 23)) vc = 1 << 23; }
         if (const char* e = getenv("MHT_VTAB_CAP")) vc = atoll(e);
         f->vt.vcap = (int)vc;
         unsigned hs = 1;
@@ -785,6 +790,43 @@ extern "C" int mht_forest_read_mmsi(mht_ctx* ctx, int32_t scan, int32_t first, i
     if (mmsi) MHT_HIP_CHECK(hipMemcpyAsync(mmsi, f->l_mmsi[scan % f->R] + first, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (hist) MHT_HIP_CHECK(hipMemcpyAsync(hist, f->l_hmmsi[scan % f->R] + first, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHT_OK;
+}
+
+// the identities of n given nodes of one layer (a gather: the roots that join a track's committed history sit all over the layer's index space)
+__global__ void mmsi_gather_kernel(const int32_t* l_mmsi, const int32_t* l_hmmsi, const int32_t* nodes, int n, int cap, int32_t* out_mmsi, int32_t* out_hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nd = nodes[i];
+    const bool ok = nd >= 0 && nd < cap;
+    out_mmsi[i] = ok ? l_mmsi[nd] : 0;
+    out_hist[i] = ok ? l_hmmsi[nd] : 0;
+}
+extern "C" int mht_forest_read_mmsi_nodes(mht_ctx* ctx, int32_t scan, int32_t n, const int32_t* nodes, int32_t* mmsi, int32_t* hist) {
+    MHT_REQUIRE(ctx && ctx->forest, "mht_forest_read_mmsi_nodes: no forest");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(f->ais, "mht_forest_read_mmsi_nodes: the forest was not created with MHT_FOREST_AIS");
+    MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R - 1, "mht_forest_read_mmsi_nodes: scan %d is outside the ring (last scan %d)", scan, f->scan);
+    MHT_REQUIRE(n >= 0 && (n == 0 || nodes), "mht_forest_read_mmsi_nodes: bad node list");
+    if (n == 0) return MHT_OK;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * 4;
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // (the staging buffers are reused)
+    int rc = stage_host_ensure(f, 3 * bytes + 64);
+    if (rc) return rc;
+    rc = f->stage_dev.ensure(3 * bytes + 64);
+    if (rc) return rc;
+    char* h = static_cast<char*>(f->stage_host);
+    char* d = static_cast<char*>(f->stage_dev.ptr);
+    memcpy(h, nodes, bytes);
+    MHT_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mmsi_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f->l_mmsi[scan % f->R], f->l_hmmsi[scan % f->R],
+                       reinterpret_cast<const int32_t*>(d), n, f->Ncap, reinterpret_cast<int32_t*>(d + bytes), reinterpret_cast<int32_t*>(d + 2 * bytes));
+    MHT_HIP_CHECK(hipGetLastError());
+    MHT_HIP_CHECK(hipMemcpyAsync(h + bytes, d + bytes, 2 * bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mmsi) memcpy(mmsi, h + bytes, bytes);
+    if (hist) memcpy(hist, h + 2 * bytes, bytes);
     return MHT_OK;
 }
 

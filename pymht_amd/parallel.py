@@ -109,6 +109,7 @@ class ClusterShardedTracker:
         trk._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))
         if aisList is not None and len(aisList) > 0:
             trk._arm_ais(scanList, aisList, self._z.shape[0], bool(kwargs.get('aisInitialization', True)))
+            trk._last_ais_scan = len(trk.__scanHistory__) + 1
         zd = trk._upload_scan(self._z)
         self.sel_rel.fill_(-1)      # (the device resets the live targets' entries itself; this also clears slots of targets long gone)
         _lib.check(trk._lib.mht_forest_step_sharded_begin(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,

@@ -194,6 +194,7 @@ class Tracker():
         self._labels_src = None      # the report rows of the last scan: their `cluster` column is read when somebody asks for the clusters
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
         self._history_mmsi = []     # AIS forest: the identities of those roots, chunk by chunk (0 = none)
+        self._last_ais_scan = -(1 << 30)      # last scan that carried AIS messages
         self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
@@ -274,6 +275,7 @@ class Tracker():
         self._set_prune_similar(bool(kwargs.get('pruneSimilar', False)))      # tracker.py:230: a per-scan switch (the constructor's copy is never read)
         if aisList is not None and len(aisList) > 0:
             self._arm_ais(scanList, aisList, z.shape[0], bool(kwargs.get('aisInitialization', True)))
+            self._last_ais_scan = len(self.__scanHistory__) + len(self._pendq) + 1
         # The host mirror is only touched once the device has accepted the scan: a rejected step (too many measurements, dead
         # forest) leaves the tracker exactly as it was.
         try:
@@ -546,11 +548,17 @@ class Tracker():
             self._history.append(chunk)
             if self._ais:        # their identities (pyTarget.py:34: Target.mmsi), read while their layers are still in the device ring
                 mm = np.zeros(len(chunk), dtype=np.int64)
-                for sc in np.unique(chunk["root_scan"]):
-                    if sc >= 0 and scanNumber - int(sc) < self._cfg.n_scan + 4:
-                        rows = np.where((chunk["root_scan"] == sc) & (chunk["root_node"] >= 0))[0]
-                        if len(rows):
-                            mm[rows] = self._mmsi_layer(int(sc))[0][chunk["root_node"][rows]]
+                # (no message in the last n_scan + 4 scans: no node of the window was updated with one -- nothing to read)
+                if scanNumber - self._last_ais_scan <= self._cfg.n_scan + 4:
+                    for sc in np.unique(chunk["root_scan"]):
+                        if sc >= 1 and scanNumber - int(sc) < self._cfg.n_scan + 3:
+                            rows = np.where((chunk["root_scan"] == sc) & (chunk["root_node"] >= 0))[0]
+                            if len(rows):      # a gather of these nodes on the device (they sit all over the layer's index space)
+                                nodes = np.ascontiguousarray(chunk["root_node"][rows], dtype=np.int32)
+                                got = np.zeros(len(rows), dtype=np.int32)
+                                _lib.check(self._lib.mht_forest_read_mmsi_nodes(self._ctx.handle, int(sc), len(rows), nodes.ctypes.data_as(C.c_void_p),
+                                                                                got.ctypes.data_as(C.c_void_p), None))
+                                mm[rows] = got
                 self._history_mmsi.append(mm)
         self._tbl_ = live
         self._sel_ = (live, scanTime, scanNumber, z)
