@@ -1717,7 +1717,11 @@ extern "C" int mht_group_step(mht_group* g, const float* const* z, const int32_t
         bb0.p[i] = g->bl0 + (size_t)i * P + v;
         const int gg = fgrow_grid_of(d);
         if (gg > grid_g) grid_g = gg;
-        int gbl = f->nT_ub_step / 2 + 8;
+        // (a quarter of the targets, not half as in the one-sector launch: the 155 KB workgroups of S sectors share the CUs one at a time, and one
+        // without a multi-target cluster still costs its entry; measured, headline config, two groups: S = 4 39.1 -> 42.3 k scans/s, S = 16 74.1 -> 75.2 k;
+        // an eighth: 39.7 / 74.8 k.  MHT_GROUP_BLP_DIV overrides)
+        static int gdiv = -1; if (gdiv < 0) { const char* e = getenv("MHT_GROUP_BLP_DIV"); gdiv = e ? atoi(e) : 4; if (gdiv < 1) gdiv = 4; }
+        int gbl = f->nT_ub_step / gdiv + 8;
         if (gbl > 1024) gbl = 1024;
         if (gbl > grid_b) grid_b = gbl;
         const size_t l = g->wave ? fgrow_wave_lds_bytes(d.W, f->pds, f->AW) : fgrow_lds_bytes(d.W, f->pds, f->AW);

@@ -13,18 +13,25 @@ from . import _lib
 
 
 class SectorGroup:
-    """trackers: `pymht_amd.tracker.Tracker` objects on the same device with the same maxTargets / maxNodes / maxMeasurements / N."""
+    """trackers: `pymht_amd.tracker.Tracker` objects on the same device; the radar-only ones (which share the batched launches) with
+    the same maxTargets / maxNodes / maxMeasurements / N."""
 
     def __init__(self, trackers):
         self.trackers = list(trackers)
-        n = len(self.trackers)
-        assert n >= 1
-        self._lib = self.trackers[0]._lib
-        handles = (C.c_void_p * n)(*[t._ctx.handle for t in self.trackers])
+        assert len(self.trackers) >= 1
+        # AIS-aided trackers (path records in two halves, identities per node: `fgrow_ais_kernel`) and constant-turn ones (per-hypothesis
+        # transitions) have launches of their own: they are members of the group for the caller, and stepped one by one behind the
+        # batched launch set of the others (nothing couples two sectors: the order does not matter)
+        self._own = [bool(getattr(t, "_ais", False)) or getattr(getattr(t, "_model_mod", None), "transition", None) == "ct" for t in self.trackers]
+        self._batched = [i for i, o in enumerate(self._own) if not o]
+        n = len(self._batched)
+        self._lib = self.trackers[self._batched[0] if n else 0]._lib      # (four- and six-state members load different libraries)
         self._h = C.c_void_p()
-        _lib.check(self._lib.mht_group_create(C.byref(self._h), n, handles))
-        self._zp = (C.c_void_p * n)()
-        self._M = (C.c_int32 * n)()
+        if n:
+            handles = (C.c_void_p * n)(*[self.trackers[i]._ctx.handle for i in self._batched])
+            _lib.check(self._lib.mht_group_create(C.byref(self._h), n, handles))
+        self._zp = (C.c_void_p * max(n, 1))()
+        self._M = (C.c_int32 * max(n, 1))()
 
     def step_dev(self, z_ptrs, Ms):
         """Raw replay: device pointers (ints) and measurement counts, one per sector; asynchronous, nothing is fetched."""
@@ -35,16 +42,31 @@ class SectorGroup:
         if rc:
             _lib.check(rc)
 
-    def addMeasurementLists(self, scanLists, pruneSimilar=False):
+    def addMeasurementLists(self, scanLists, aisLists=None, pruneSimilar=False, **kwargs):
         """One `MeasurementList` per sector: all sectors' steps 1-6 in one batched launch set, then every tracker folds its own
         report and runs its own step 7 -- the result for every sector is what `Tracker.addMeasurementList` gives.
-        pruneSimilar: bool or one bool per sector (tracker.py:230)."""
+        aisLists: None, or one AIS message list (or None) per sector -- only for members made with aisAided=True (tracker.py:417-552).
+        pruneSimilar: bool or one bool per sector (tracker.py:230).  Further keyword arguments (e.g. aisInitialization) go to the
+        AIS-aided members' `addMeasurementList`."""
         assert len(scanLists) == len(self.trackers)
         ps = list(pruneSimilar) if hasattr(pruneSimilar, "__len__") else [bool(pruneSimilar)] * len(self.trackers)
-        zs = [trk._stage_scan(sl, pruneSimilar=p) for trk, sl, p in zip(self.trackers, scanLists, ps)]
-        self.step_dev([z.data_ptr() for z in zs], [int(z.shape[0]) for z in zs])
-        for trk, sl in zip(self.trackers, scanLists):
-            trk._after_step(sl, trk._staged_np, None)
+        ais = list(aisLists) if aisLists is not None else [None] * len(self.trackers)
+        assert len(ais) == len(self.trackers)
+        for i in self._batched:
+            if ais[i] is not None and len(ais[i]) > 0:
+                raise NotImplementedError("sector %d was not made for AIS messages: pass aisAided=True to its Tracker" % i)
+        if self._batched:
+            zs = [self.trackers[i]._stage_scan(scanLists[i], pruneSimilar=ps[i]) for i in self._batched]
+            self.step_dev([z.data_ptr() for z in zs], [int(z.shape[0]) for z in zs])
+        for i, trk in enumerate(self.trackers):      # (the members with launches of their own queue theirs behind the group's)
+            if self._own[i]:
+                if getattr(trk, "_ais", False):
+                    trk.addMeasurementList(scanLists[i], ais[i], pruneSimilar=ps[i], **kwargs)
+                else:
+                    trk.addMeasurementList(scanLists[i], pruneSimilar=ps[i])
+        for i in self._batched:
+            trk = self.trackers[i]
+            trk._after_step(scanLists[i], trk._staged_np, None)
 
     def close(self):
         if self._h:

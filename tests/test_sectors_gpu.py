@@ -204,3 +204,50 @@ def test_grouped_sectors_with_similar_state_pruning(light, monkeypatch):
     grp.close()
     for t in solo + grouped:
         t.close()
+
+
+def test_group_with_an_ais_aided_member(gold_dir):
+    """A group whose sectors are not all radar-only: two cfg2 sectors share the batched launches, the third is an AIS-aided tracker fed
+    the reference's recorded G18b trace (tracker.py:417-552) -- stepped with launches of its own behind the group's.  The radar sectors
+    must equal single trackers, the AIS sector its fixture (leaf identities, states and covariances bit for bit)."""
+    import os
+    from pymht_amd.sectors import SectorGroup
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.ais import AisMessage, AisMessageList
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    g = np.load(os.path.join(gold_dir, "g18b_trace_ais_dense.npz"))
+    n_scans = int(g["n_scans"])
+    scs = _sectors(2, n_scans, name="cfg2")
+    solo = [_tracker(sc) for sc in scs]
+    grouped = [_tracker(sc) for sc in scs]
+    ais_trk = Tracker(pv, float(g["period"]), float(g["lambda_phi"]), float(g["lambda_nu"]), P_d=float(g["P_d"]), N=int(g["N"]), eta2=float(g["eta2"]),
+                      eta2_ais=float(g["eta2_ais"]), radarRange=float(g["radar_range"]), position=g["position"], aisAided=True,
+                      useInitiator=bool(g["with_initiator"]), maxTargets=256, maxNodes=1 << 16, maxMeasurements=256)
+    for x in g["x0"]:
+        ais_trk.initiateTarget(Target(float(g["t0"]), None, x.copy(), pv.P0, status="preinitialized"))
+    grp = SectorGroup([grouped[0], ais_trk, grouped[1]])
+    try:
+        with pytest.raises(NotImplementedError):      # (messages for a sector that was not made for them)
+            grp.addMeasurementLists([MeasurementList(0.0, np.zeros((0, 2), np.float32))] * 3,
+                                    aisLists=[AisMessageList([AisMessage(0.0, np.zeros(4), 1, True)]), None, None])
+        for k in range(n_scans):
+            p = "s%02d_" % k
+            msgs = AisMessageList([AisMessage(float(t), s, int(m), bool(h)) for t, s, m, h in
+                                   zip(g[p + "ais_time"], g[p + "ais_state"], g[p + "ais_mmsi"], g[p + "ais_high"])])
+            lists = [MeasurementList(float(sc["times"][k]), sc["scans"][k]) for sc in scs]
+            for q in range(2):
+                solo[q].addMeasurementList(lists[q])
+            grp.addMeasurementLists([lists[0], MeasurementList(float(g["times"][k]), g[p + "z"]), lists[1]], aisLists=[None, msgs, None],
+                                    pruneSimilar=[False, bool(g["prune_similar"]), False],
+                                    aisInitialization=bool(g["ais_init"]) if "ais_init" in g.files else False)
+            for q in range(2):
+                _same_state(grouped[q], solo[q], "scan %d sector %d" % (k, q))
+            lb = ais_trk.leafBatch()
+            assert np.array_equal(lb["ID"], g[p + "leaf_ID"]) and np.array_equal(lb["meas"], g[p + "leaf_meas"]) and np.array_equal(lb["mmsi"], g[p + "leaf_mmsi"]), k
+            assert np.array_equal(lb["x"], g[p + "leaf_x"]) and np.array_equal(lb["P"], g[p + "leaf_P"]), k
+    finally:
+        grp.close()
+        for t in solo + grouped + [ais_trk]:
+            t.close()
