@@ -420,11 +420,15 @@ def main():
         one_scan = rp.step
     for _ in range(W):
         one_scan()
+    # (one launch per scan: a step leaves its ILP launch for the next step's launch -- mht_synchronize queues it.  Called in front of the clock
+    # and behind the last timed step, so that the timed region holds exactly K grow stages and K ILP stages, the last ILP launch included)
+    rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         one_scan()
     t_enq = time.perf_counter()      # (the host has queued the K scans: how far ahead of the device it runs)
+    rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -434,6 +438,8 @@ def main():
     same_work = (got == final) and rep.error == 0
     uf_ovl = np.zeros(2, dtype=np.int32)      # scans clustered inside the grow launch, grow launches that overlapped the previous scan's ILP launch
     rp.lib.mht_forest_debug_read(rp.h, b"uf_ovl", uf_ovl.ctypes.data_as(C.c_void_p), 8)
+    merged = np.zeros(1, dtype=np.int32)      # scans whose ILP launch went out as ONE launch with the next scan's grow stage (blp_grow_kernel)
+    rp.lib.mht_forest_debug_read(rp.h, b"merged_launches", merged.ctypes.data_as(C.c_void_p), 4)
     rp.close()
     elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
     # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
@@ -489,13 +495,14 @@ def main():
         # (streams of DIFFERENT priority: the runtime maps streams to a few hardware queues, and two streams of equal priority may land on
         # the same one -- the groups then run one after the other instead of side by side: 43 k instead of 74 k scans/s at 16 sectors,
         # decided by chance per process)
-        streams = [torch.cuda.Stream(device=local, priority=(-1 if (q % 2) else 0)) for q in range(NG)]
+        prios = [int(v) for v in os.environ.get("MHT_BENCH_PRIOS", "0,-1").split(",")]
+        streams = [torch.cuda.Stream(device=local, priority=prios[q % len(prios)]) for q in range(NG)]
         rps = []
         for q in range(S):
             with torch.cuda.stream(streams[q % NG]):
                 rps.append(Replay(scs[q], brs[q], local))
-        grps = [SectorGroup([r.trk for r in rps[gi::NG]]) for gi in range(NG)]
         solo = os.environ.get("MHT_BENCH_SOLO") == "1"      # development: every sector stepped on its own (needs MHT_BENCH_GROUPS = sectors)
+        grps = [] if solo else [SectorGroup([r.trk for r in rps[gi::NG]]) for gi in range(NG)]
 
         def group_step():
             if solo:
@@ -587,7 +594,7 @@ def main():
                                "one independent sector per GPU" + (" -- STRONG: the same sector on every GPU, ILPs spread by cluster" if strong else ""), "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
                    "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),
-                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work, "host_us_per_scan_queued": round(1e6 * (t_enq - t0) / K, 2), "scans_clustered_in_grow_launch": int(uf_ovl[0]), "grow_launches_overlapping_ilp": int(uf_ovl[1]),
+                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work, "host_us_per_scan_queued": round(1e6 * (t_enq - t0) / K, 2), "scans_clustered_in_grow_launch": int(uf_ovl[0]), "grow_launches_overlapping_ilp": int(uf_ovl[1]), "scans_as_one_launch": int(merged[0]),
                    "pre_roll_scans": PRE},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},

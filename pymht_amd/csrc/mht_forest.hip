@@ -360,6 +360,10 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
+    // one launch per scan (mht_blp.hip: blp_grow_kernel): the ILP launch of the last scan has NOT been queued -- it rides in front of the next
+    // scan's grow roles (forest_step_impl), or is launched alone by whoever needs its results first (flush_ilp, at the head of flush_commit).
+    // MHT_MERGE=1 at creation turns it on: measured slower than the launch pair, so the pair stays the default
+    bool merge_on = false; bool ilp_pending = false; BlpArgs pending_blp = {}; int pending_blp_grid = 0; int merged_launches = 0; unsigned long long role_tick_total = 0;
     // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
     // workgroup 0 of the next scan's grow launch (fgrow_adm_kernel), or run as post_scan_kernel when somebody needs the state first
     bool adm_pending = false; AddArgs adm = {}; bool adm_fuse = true;      // MHT_ADM_FUSE=0: admission in a launch of its own behind every scan
@@ -555,7 +559,18 @@ static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan 
     p.src = f->report_dev2[f->scan & 1]; p.dst = f->report_host_dev[f->scan & 1]; p.rec_off = (int)f->rec_off; p.birth_off = (int)f->birth_off;
     return p;
 }
+// the ILP launch a step left for the next step's launch (Forest::ilp_pending), now and alone
+static int flush_ilp(mht_ctx* ctx, Forest* f) {
+    if (!f->ilp_pending) return MHT_OK;
+    f->ilp_pending = false;
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    const int rc = launch_blp(ctx, f->pending_blp, f->pending_blp_grid, nullptr, &f->cnt->overflow);
+    if (rc) f->dead = true;
+    return rc;
+}
+int forest_flush_ilp(mht_ctx* ctx) { return (ctx && ctx->forest) ? flush_ilp(ctx, ctx->forest) : MHT_OK; }
 static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
+    { const int rc = flush_ilp(ctx, f); if (rc) return rc; }      // (the commit reads what that launch writes)
     if (!f->commit_pending) return MHT_OK;
     if (f->adm_pending) {      // commit + admission of the initiator's births, as one launch (what mht_forest_scan deferred)
         { const int rc = wait_init_ev(ctx, f); if (rc) return rc; }      // (the initiator ran on the side stream)
@@ -656,6 +671,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
         f->root_base = f->over_base + FG_REGIONS * f->region_cap;
     }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
+    { const char* e = getenv("MHT_MERGE"); f->merge_on = e && e[0] == '1'; }      // (one launch per scan, blp_grow_kernel: built, correct, SLOWER than the launch pair -- DESIGN section 4; off unless asked for)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
@@ -1121,7 +1137,7 @@ static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
     f->rebuilds += 1;
     return MHT_OK;
 }
-static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl, bool carries_admission = false) {
+static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl, bool carries_admission = false, bool keeps_ilp = false) {
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "%s: M=%d exceeds max_meas=%d", who, M, f->cfg.max_meas);
     MHT_REQUIRE(z || M == 0, "%s: z is null", who);
     if (f->dead) {
@@ -1130,6 +1146,7 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     }
     if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
     if (f->adm_pending && !carries_admission) { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // (only the one-sector grow launch takes the admission along)
+    if (!keeps_ilp) { const int rc = flush_ilp(ctx, f); if (rc) return rc; }      // (only forest_step_impl lets a pending ILP launch ride in its own launch)
     const int s = ++f->scan;
     pl.rebuilt = false;
     if (f->hint_host) {      // value table three quarters full (as of the last commit the host has seen) and the other generation free again?
@@ -1265,7 +1282,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         if (rc) return rc;
     }
     StepPlan pl;
-    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) { f->ais_armed = false; return rc; } }
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais, true); if (rc) { f->ais_armed = false; return rc; } }
     if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
     hipStream_t st = ctx->stream;
     hipEvent_t* ev = nullptr;
@@ -1334,6 +1351,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         } else { f->pub_args.done = nullptr; f->pub_args.tag = 0; }
         const bool tq = any_order && f->tq_on && !adm && !f->pub_deferred && !init && f->ilp_started_total > 0;
         if (tq) {
+            MHT_STEP_CHECK(flush_ilp(ctx, f));
             if (!f->tq_stream) {
                 MHT_STEP_HIP(hipStreamCreateWithFlags(&f->tq_stream, hipStreamNonBlocking));
                 MHT_STEP_HIP(hipEventCreateWithFlags(&f->tq_ev, hipEventDisableTiming));
@@ -1355,8 +1373,16 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             MHT_STEP_HIP(hipStreamWaitEvent(st, f->tq_ev, 0));      // (this scan's ILP launch, next on the ctx stream, needs the whole grow launch)
             }
             f->tq_launches += 1;
-        } else
+        } else if (f->ilp_pending && d.ovl && pl.fused && !adm && !f->pub_deferred && !ais && !f->ct && !f->timing && !init && !f->z_stage_src && !d.z_tag &&
+                   g.ais.half == 0 && blp_grow_fits(ctx, f->pending_blp, f->pending_blp_grid, d.W, g.pds, g.AW)) {
+            // the previous scan's ILP launch has not been queued: ONE launch, its workgroups take this scan's grow roles when their clusters are done
+            f->ilp_pending = false;
+            MHT_STEP_CHECK(launch_blp_grow(ctx, f->pending_blp, f->pending_blp_grid, g, d, pl.n_ub, f->pending, &f->cnt->role_tick, &f->role_tick_total));
+            f->merged_launches += 1;
+        } else {
+        MHT_STEP_CHECK(flush_ilp(ctx, f));
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
+        }
         hp_mark(4);
         f->adm_pending = false;
         if (f->z_stage_slot >= 0) MHT_STEP_HIP(hipEventRecord(f->z_ev[f->z_stage_slot], st));      // (the host may refill the pinned slot once this launch has run)
@@ -1428,6 +1454,14 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
         }
         hp_mark(6);
+        // one launch per scan: this ILP launch waits for the next step, whose grow roles its workgroups will take (blp_grow_kernel) -- when the
+        // next call is not a plain step, or somebody asks for results first, flush_ilp launches it alone
+        const bool defer_ilp = use_uf && f->merge_on && !init && !have_init_blp && !ais && !f->ct && !f->timing && (!f->debug || getenv("MHT_OVL_FORCE")) && !f->tq_on && !(f->prune_thr > 0.f) && !f->in_groups &&
+                               !f->adm_pending && !f->pub_deferred && f->ovl_ok && f->ais == false;
+        if (defer_ilp) {
+            if (grid > ctx->n_cu) grid = ctx->n_cu;      // (every workgroup resident: a grow role may wait for a record of any of them)
+            f->pending_blp = b; f->pending_blp_grid = grid; f->ilp_pending = true;
+        } else
         MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
         hp_mark(7);
         if (use_uf) { f->pub_scan = pl.s; f->blp_done_total += (unsigned long long)grid; }
@@ -1771,6 +1805,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
     MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    { const int rc = flush_ilp(ctx, f); if (rc) return rc; }
     InitArgs ia = {};
     char* report_dev = f->report_dev2[f->scan & 1];
     const bool init_done = f->init_ran_scan == f->scan;      // (mht_forest_scan: it ran inside this scan's cluster launch)
@@ -2272,6 +2307,11 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     if (!strcmp(name, "uf_ovl")) {      // (host-side counters: scans clustered by the union-find, grow launches made any-order)
         MHT_REQUIRE(bytes == 8, "mht_forest_debug_read: 'uf_ovl' is two int32");
         static_cast<int32_t*>(host)[0] = f->uf_scans; static_cast<int32_t*>(host)[1] = f->ovl_launches;
+        return MHT_OK;
+    }
+    if (!strcmp(name, "merged_launches")) {      // (host-side counter: scans whose ILP launch and the next scan's grow launch went out as ONE launch)
+        MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'merged_launches' is one int32");
+        *static_cast<int32_t*>(host) = f->merged_launches;
         return MHT_OK;
     }
     if (!strcmp(name, "status2")) { src = f->status2; avail = 2 * sizeof(DevStatus); }

@@ -167,6 +167,7 @@ struct FDyn {
     int adm_wait;                  // fgrow_adm_kernel launched any-order: the admission waits for the previous scan's initiator (FCounts::init_flag), the
                                    // report's workgroups for the previous scan's ILP launch (c_wait)
     int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)
+    int gentle;                    // blp_grow_kernel: waits may be long and many at once -- poll sparingly (mht_commit.h: spin_until)
     unsigned long long c_wait;     // FCounts::blp_done the commit waits for (0: the ILP launch has ended, as stream order says)
     unsigned uf_epoch;             // != 0 (2 x the scan number): no edge list -- the target workgroups hook their targets into a device-wide
                                    // union-find over the measurement nodes they use, and the ILP launch derives the clusters from it
@@ -308,6 +309,7 @@ struct BlpArgs {
     unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
     const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
                                                         // target died in the previous scan, the union-find was redone under epoch | 1
+    int wt_commit;                 // blp_grow_kernel: what the commit reads of this launch is written through (mht_blp.hip: st_commit)
     unsigned uf_lds_off;           // offset of the workgroup's UfPersist block in the dynamic LDS (behind the solver's tables; set by launch_blp)
 };
 
@@ -346,6 +348,7 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
                  const AddArgs* adm = nullptr, bool any_order = false);
 int forest_sync_side(mht_ctx* ctx);      // mht_forest.hip: waits for what the forest queued on streams of its own
 size_t fgrow_lds_bytes(int W, int pds, int AW);
+size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap);
 void fgrow_plan(FDyn& d, int n_targets_ub, int Tcap, bool fused, bool wave);
 size_t fgrow_wave_lds_bytes(int W, int pds, int AW);
 int fgrow_grid_of(const FDyn& d);
@@ -366,6 +369,9 @@ bool cluster_fits_lds(int Tcap, int n_mnodes);
 size_t cluster_big_ints(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init = nullptr, const int32_t* sticky_overflow = nullptr);      // init: the initiator rides as one more workgroup
 bool blp_uf_fits(int Tcap, int n_mnodes);
+// ILP launch k and grow launch k + 1 as ONE launch (mht_blp.hip: blp_grow_kernel)
+bool blp_grow_fits(mht_ctx* ctx, const BlpArgs& a, int grid, int W, int pds, int AW);
+int launch_blp_grow(mht_ctx* ctx, const BlpArgs& a, int grid, const FGrowArgs& g, FDyn& d, int n_targets_ub, const CommitArgs& cm, unsigned long long* tick, unsigned long long* tick_total);
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);
 

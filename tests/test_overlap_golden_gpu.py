@@ -75,10 +75,13 @@ def test_streamed_api_last_scan_equals_reference(name, gold_dir):
     trk.close()
 
 
-@pytest.mark.parametrize("name", ["g6b_trace_cfg3_long"])
-def test_raw_replay_last_scan_equals_reference(name, gold_dir):
+@pytest.mark.parametrize("name,one_launch", [("g6b_trace_cfg3_long", False), ("g6b_trace_cfg3_long", True), ("g6_trace_cfg3", True)])
+def test_raw_replay_last_scan_equals_reference(name, one_launch, gold_dir, monkeypatch):
     """(ii) what bench.py times: `mht_forest_step` on scans resident in HBM, the births of an untimed pre-pass through the API replayed with
-    `mht_forest_add_targets_dev`, no report read until the end."""
+    `mht_forest_add_targets_dev`, no report read until the end.
+    one_launch: the same through the one-launch-per-scan kernel (MHT_MERGE=1 at creation: `blp_grow_kernel`, the ILP workgroups of scan k
+    play the grow roles of scan k + 1; the ILP launch of a step is left for the next step's launch or flushed by whoever reads first) --
+    slower than the launch pair and therefore off by default, but built and pinned against the same traces."""
     import torch
     from pymht_amd import _lib
     from pymht_amd.utils.classDefinitions import MeasurementList
@@ -104,7 +107,10 @@ def test_raw_replay_last_scan_equals_reference(name, gold_dir):
             assert np.array_equal(np.array([b[1] for b in births[k]], dtype=np.float64), g["s%02d_born_P" % k])
     pre.close()
     # raw replay
+    if one_launch:
+        monkeypatch.setenv("MHT_MERGE", "1")      # (read when the forest is created)
     trk = _make(g, useInitiator=False)
+    monkeypatch.delenv("MHT_MERGE", raising=False)
     lib, h, dev = trk._lib, trk._ctx.handle, trk._ctx.device
     zs = [np.ascontiguousarray(g["s%02d_z" % k], dtype=np.float32) for k in range(n)]
     zall = torch.from_numpy(np.concatenate(zs, axis=0)).to(dev)
@@ -125,6 +131,9 @@ def test_raw_replay_last_scan_equals_reference(name, gold_dir):
             _lib.check(lib.mht_forest_add_targets_dev(h, nb, bx.data_ptr() + o * 32, bP.data_ptr() + o * 64, bf.data_ptr() + o, bpd.data_ptr() + o * 8,
                                                       bm.data_ptr() + o * 4, 1, None, None))
     uf, ovl = _uf_ovl(trk)
+    merged = np.zeros(1, dtype=np.int32)
+    lib.mht_forest_debug_read(h, b"merged_launches", merged.ctypes.data_as(C.c_void_p), 4)
+    assert (int(merged[0]) > n // 2) if one_launch else (int(merged[0]) == 0), "scans whose ILP launch and the next grow launch were ONE launch: %d" % int(merged[0])
     rep = _lib.MhtScanReport()
     _lib.check(lib.mht_forest_report(h, C.byref(rep)))
     assert rep.error == 0
