@@ -491,11 +491,13 @@ def main():
             fins.append(fq)
         # the sectors form NG groups, each on its own HIP stream: one batched launch set per group and scan; two groups' chains of
         # dependent kernels interleave on the device (while one group's ILP kernel holds a workgroup per CU, the other's grow runs)
-        NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "2")), S))
+        # (up to four sectors: a group per sector -- four launch chains side by side, 45.6 k scans/s against 41.8 k in two groups of two;
+        # sixteen sectors: two groups of eight, 75 k against 58 k in four groups and 53 k in eight -- profiles/r05_merge_ab.txt, "groups")
+        NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "4" if S <= 4 else "2")), S))
         # (streams of DIFFERENT priority: the runtime maps streams to a few hardware queues, and two streams of equal priority may land on
         # the same one -- the groups then run one after the other instead of side by side: 43 k instead of 74 k scans/s at 16 sectors,
         # decided by chance per process)
-        prios = [int(v) for v in os.environ.get("MHT_BENCH_PRIOS", "0,-1").split(",")]
+        prios = [int(v) for v in os.environ.get("MHT_BENCH_PRIOS", "0,-1,1,0" if NG > 2 else "0,-1").split(",")]
         streams = [torch.cuda.Stream(device=local, priority=prios[q % len(prios)]) for q in range(NG)]
         rps = []
         for q in range(S):
