@@ -196,7 +196,10 @@ struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM)
 // only into the (level-0 column, level-1 column) pairs whose hash is q mod W; the value of the best selection found anywhere is
 // shared through one 64-bit atomic-min word; the member that finishes LAST takes the best selection and runs the cluster's
 // epilogue (nobody waits for anybody).  At most TEAM_MAX clusters per scan form teams.
-constexpr int TEAM_MIN_K = 24, TEAM_MAX = 8, TEAM_W = 32, TEAM_SEL = 256;
+#ifndef MHT_TEAM_W
+#define MHT_TEAM_W 32
+#endif
+constexpr int TEAM_MIN_K = 24, TEAM_MAX = 8, TEAM_W = MHT_TEAM_W, TEAM_SEL = 256;
 struct TeamResult { double ub; int32_t status, nodes, iters, pad; int32_t sel[TEAM_SEL]; };      // what a member found (global column per target)
 struct TeamState { unsigned long long gub; int32_t done, pad[13]; };                    // per team: shared incumbent key, finished members, TeamProblem filed
 // (A giant cluster -- more columns than the LDS tables hold -- runs its dual phase on HBM scratch: every member has its own copy of that

@@ -7,4 +7,4 @@ timeout 900 python tools/fuzz_parity.py 500 $((91000 + O)) 2>&1 | grep -v amdgpu
 timeout 900 python tools/fuzz_parity.py 400 $((92000 + O)) similar 2>&1 | grep -v amdgpu | grep "BAD\|cases," > gpurun_out/fuzz/similar.txt
 timeout 900 python tools/fuzz_ais.py $((93000 + O)) 300 2>&1 | grep -v amdgpu | grep "BAD\|cases\|bad" | tail -5 > gpurun_out/fuzz/ais.txt
 timeout 900 python tools/fuzz_streamed.py 600 $((94000 + O)) 2>&1 | grep -v amdgpu | grep "BAD\|cases" > gpurun_out/fuzz/streamed.txt
-tail -2 gpurun_out/fuzz/*.txt
+for f in gpurun_out/fuzz/*.txt; do echo "== $f"; tail -n 2 $f; done
