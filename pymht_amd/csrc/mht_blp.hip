@@ -415,7 +415,10 @@ __device__ __forceinline__ void argmin_member(const LStore& s, int k, bool need_
 // decreases.  Priced rows nobody uses any more are lowered to just below the cheapest taker.  Nothing here affects
 // exactness: the certificate (no conflict, no priced-but-unused row) is what proves optimality, and clusters that are
 // not certified after CA_ROUNDS go to the branch and bound.
-constexpr int BB_NODE_STEPS = 4;   // subgradient steps per such node
+#ifndef MHT_BB_NODE_STEPS
+#define MHT_BB_NODE_STEPS 4
+#endif
+constexpr int BB_NODE_STEPS = MHT_BB_NODE_STEPS;   // subgradient steps per such node
 constexpr int CA_ROUNDS = 16;      // coordinate rounds before the branch and bound takes over
 constexpr int CA_ROUNDS_PAIR = 6;  // ... for two-target clusters: their branch and bound is ~5 nodes, cheaper than more rounds
 __device__ __forceinline__ bool scratch_is_private(const GStore&) { return false; }
@@ -1180,6 +1183,9 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         __syncthreads();
         if (done) break;
     }
+#ifdef MHT_BLP_TRACE
+    if (tid == 0 && tm.q == 0) printf("[blp] dual phase: %d iterations, status %d, at %.2f ms\n", iters, status, 1e-5 * (double)(wall_clock64() - stamp[0]));
+#endif
     if (status != 0) return;
     // ---- depth-first branch and bound -------------------------------------------------------------------------------
     // Positions 0..K-1 of the search are the cluster's targets in "hot first" order (ord[]): targets whose minimiser touches
