@@ -420,15 +420,18 @@ def main():
         one_scan = rp.step
     for _ in range(W):
         one_scan()
-    # (one launch per scan: a step leaves its ILP launch for the next step's launch -- mht_synchronize queues it.  Called in front of the clock
-    # and behind the last timed step, so that the timed region holds exactly K grow stages and K ILP stages, the last ILP launch included)
-    rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
+    # (MHT_MERGE=1, one launch per scan: a step leaves its ILP launch for the next step's launch -- mht_synchronize queues it.  Called in front
+    # of the clock and behind the last timed step, so that the timed region holds exactly K grow stages and K ILP stages, the last ILP launch included)
+    one_launch = os.environ.get("MHT_MERGE") == "1"
+    if one_launch:
+        rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         one_scan()
     t_enq = time.perf_counter()      # (the host has queued the K scans: how far ahead of the device it runs)
-    rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
+    if one_launch:
+        rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
