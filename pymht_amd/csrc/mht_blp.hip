@@ -28,7 +28,10 @@
 
 namespace mht {
 
-constexpr int BLP_THREADS = 256;
+#ifndef MHT_BLP_THREADS
+#define MHT_BLP_THREADS 256
+#endif
+constexpr int BLP_THREADS = MHT_BLP_THREADS;
 constexpr int FUSED_K = 8;           // clusters of up to this many targets: a wavefront per target for minimisers / usage / regrets
 constexpr double DINF = 1.0e300;
 constexpr int BIG_MAXH = 2048, BIG_MAXR = 1024, BIG_MAXK = 256;      // default LDS tier: columns, rows, targets of a cluster solved out of LDS
@@ -709,7 +712,7 @@ __device__ __forceinline__ double enum_val(unsigned long long k) {
 }
 __device__ __forceinline__ bool enumerate_small(const GStore&, int, Red*, int&, unsigned long long*, double&) { return false; }
 constexpr int ENUM_W = BLP_THREADS / 64;
-constexpr size_t ENUM_LDS = 768;             // search state of the wavefronts + scalars (see the carve in enumerate_small)
+constexpr size_t ENUM_LDS = BLP_THREADS <= 256 ? 768 : 768 * (BLP_THREADS / 256);             // search state of the wavefronts + scalars (see the carve in enumerate_small)
 struct alignas(16) EnumEnt { double rc; unsigned long long sig; };      // reduced cost and contested-row signature of a ranked column
 template <typename S> __device__ __forceinline__ double greedy_dive(const S& s, int K, int32_t* out_sel, Red* r);
 __device__ __forceinline__ bool enumerate_small(const LStore& s, int K, Red* r, int& nodes_out, unsigned long long* stamp, double& ub_known) {
@@ -2015,7 +2018,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
     __syncthreads();
 }
 
-constexpr size_t RED_SLOT = 512;      // LDS bytes reserved for the reduction scratch (multiple of 16)
+constexpr size_t RED_SLOT = BLP_THREADS <= 512 ? 512 : 1024;      // LDS bytes reserved for the reduction scratch (multiple of 16)
 static_assert(sizeof(Red) <= RED_SLOT, "Red must fit its LDS slot");
 static size_t blp_lds_bytes(int cap_h, int cap_r, int cap_k, int cap_uw) {
     const size_t kpad = (size_t)cap_k + 4;
@@ -2524,7 +2527,7 @@ struct ScanArgs {
     unsigned tail_off;               // offset of the parked ends' LDS block (behind the grow roles' own LDS)
 };
 constexpr int SCAN_CONF_CAP = 256;
-static_assert(FG_THREADS == BLP_THREADS, "blp_grow_kernel: the grow roles run on the ILP workgroups");
+constexpr bool SCAN_KERNEL_OK = FG_THREADS == BLP_THREADS;      // blp_grow_kernel: the grow roles run on the ILP workgroups
 __host__ __device__ constexpr size_t scan_tail_bytes(int AW) { return 64 + (size_t)TAIL_MAX * 16 + (size_t)SCAN_CONF_CAP * 4 + (size_t)TAIL_MAX * AW * 8; }
 typedef const __attribute__((address_space(4))) BlpArgs* KBlp;
 __device__ __forceinline__ void load_kernarg_blp(BlpArgs& a, KBlp p) { __builtin_memcpy(&a, p, sizeof(BlpArgs)); }
@@ -2765,6 +2768,7 @@ static size_t scan_set_tier(BlpArgs& b) {
     return lds0;
 }
 bool blp_grow_fits(mht_ctx* ctx, const BlpArgs& a, int grid, int W, int pds, int AW) {
+    if (!SCAN_KERNEL_OK) return false;
     BlpArgs b = a;
     const size_t lds = scan_set_tier(b);
     size_t body = lds > uf_prologue_bytes((size_t)b.uf_cap) ? lds : uf_prologue_bytes((size_t)b.uf_cap);
