@@ -309,6 +309,10 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
         a.cnt->L = Lnext;
         if (a.hint) __hip_atomic_store(a.hint, ((unsigned long long)(unsigned)dyn.scan << 32) | (unsigned)nAlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a.hint && a.vcount) __hip_atomic_store(a.hint + 1, (unsigned long long)*a.vcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // fill of the value table
+        // (the scan's cluster statistics, for the size of the next ILP launches: scan | multi-target clusters | single-target clusters | team-sized ones)
+        if (a.hint) __hip_atomic_store(a.hint + 2, ((unsigned long long)((unsigned)dyn.scan & 0xffffu) << 48) | ((unsigned long long)((unsigned)n_ilp & 0xffffu) << 32) |
+                                                   ((unsigned long long)((unsigned)a.cl_counts[2] & 0xffffffu) << 8) | (unsigned long long)((unsigned)a.cl_counts[5] & 0xffu),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         a.cnt->n_nodes = nCh;
         a.cnt->n_roots = 0;        // roots born after this scan go to the end of the layer: node root_base + n_roots
         // the counters of this scan's status word have been read: zero for the scan after the next (its grow launch may start before the

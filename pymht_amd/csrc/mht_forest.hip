@@ -363,6 +363,7 @@ struct Forest {
     // one launch per scan (mht_blp.hip: blp_grow_kernel): the ILP launch of the last scan has NOT been queued -- it rides in front of the next
     // scan's grow roles (forest_step_impl), or is launched alone by whoever needs its results first (flush_ilp, at the head of flush_commit).
     // MHT_MERGE=1 at creation turns it on: measured slower than the launch pair, so the pair stays the default
+    bool grid_by_hint = true;      // MHT_BLP_GRID_HINT=0 at creation: the ILP launch sized by the target count alone, as until round 5
     bool merge_on = false; bool ilp_pending = false; BlpArgs pending_blp = {}; int pending_blp_grid = 0; int merged_launches = 0; unsigned long long role_tick_total = 0;
     // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
     // workgroup 0 of the next scan's grow launch (fgrow_adm_kernel), or run as post_scan_kernel when somebody needs the state first
@@ -671,6 +672,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
         f->root_base = f->over_base + FG_REGIONS * f->region_cap;
     }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
+    { const char* e = getenv("MHT_BLP_GRID_HINT"); f->grid_by_hint = !(e && e[0] == '0'); }
     { const char* e = getenv("MHT_MERGE"); f->merge_on = e && e[0] == '1'; }      // (one launch per scan, blp_grow_kernel: built, correct, SLOWER than the launch pair -- DESIGN section 4; off unless asked for)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
@@ -1443,6 +1445,23 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         b.ni_flag = &f->cnt->ni_flag; b.uf_ovl = grow_ovl ? 1 : 0;
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
+        // Clusters from the union-find: a workgroup per multi-target cluster and a wavefront per single-target one is all the launch needs
+        // (the loops of blp_body take more of either) -- every further workgroup runs the prologue for nothing and loads the fabric the
+        // others work through: at the headline size 160-192 workgroups instead of 258 are 1 us per scan (profiles/r05_merge_ab.txt, "ILP grid").
+        // The commit leaves the last scan's counts in the host-mapped hint block; a scan with a team-sized cluster keeps the workgroups
+        // without a cluster (they are the teams).
+        if (use_uf && f->hint_host && f->grid_by_hint) {
+            const unsigned long long hh = reinterpret_cast<volatile unsigned long long*>(f->hint_host)[2];
+            const int h_scan = (int)(hh >> 48), h_multi = (int)((hh >> 32) & 0xffffu), h_single = (int)((hh >> 8) & 0xffffffu), h_team = (int)(hh & 0xffu);
+            const int age = (pl.s - h_scan) & 0xffff;
+            // (a host that queues scans far ahead of the device -- the replay -- sees counts that are hundreds of scans old: a stationary
+            // stream's statistics; what the launch is too small for, it loops over)
+            if (hh != 0ull && age >= 1 && age <= 8192 && h_team == 0) {
+                int gh = h_multi + h_multi / 8 + (h_single + 3) / 4 + 8;      // (an eighth more multi-target clusters than last time; the rest loops)
+                if (gh < 32) gh = 32;
+                if (gh < grid) grid = gh;
+            }
+        }
         { static int gcap = -1; if (gcap < 0) { const char* e = getenv("MHT_BLP_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && use_uf && grid > gcap) grid = gcap; }      // (development)
         if (use_uf && f->tq_on && !init) {      // (two-queue mode: every ILP workgroup resident at once -- one per CU -- and counted in)
             if (grid > ctx->n_cu) grid = ctx->n_cu;
