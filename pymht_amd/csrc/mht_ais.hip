@@ -273,7 +273,9 @@ __device__ __forceinline__ void ct_node_cov(const CtForestArgs& a, int key, floa
 __global__ __launch_bounds__(64) void forest_ct_kernel(const CtForestArgs a) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= a.nT_dev[0]) return;
-    const int first = a.t_first[t], cnt = a.t_leaf_off[t + 1] - a.t_leaf_off[t];
+    int first, cnt;
+    if (a.fused) { first = a.p_firstsurv[t]; cnt = (a.p_status[t] == 0) ? a.p_count[t] : 0; }      // (the previous scan's commit has not run: its per-target results stand in)
+    else { first = a.t_first[t]; cnt = a.t_leaf_off[t + 1] - a.t_leaf_off[t]; }
     for (int i = lane; i < cnt; i += 64) {
         const int nd = first + i;
         if (a.flags[nd] & F_DEAD) continue;

@@ -1252,12 +1252,13 @@ static int forest_ais_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub, const fl
     return rc;
 }
 // constant-turn forest: forest_ct_kernel (mht_ais.hip) over the leaves of the committed table, in front of scan s's grow launch
-static int forest_ct_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub) {
+static int forest_ct_prepass(mht_ctx* ctx, Forest* f, int s, int n_ub, bool fused = false) {
     CtForestArgs ca = {};
     const int li = (s - 1) % f->R, lp = (s - 2 + f->R) % f->R;
     const mht_nodes& in = f->layer[li];
     fill_model_only(ca.model, &f->model); ca.T = f->ct_T;
     ca.nT_dev = &f->cnt->nT; ca.t_first = f->tab[s & 1].first; ca.t_leaf_off = f->tab[s & 1].leaf_off;
+    if (fused) { ca.fused = 1; ca.nT_dev = &f->cnt->nTv[(s - 1) & 1]; ca.p_status = f->t_status; ca.p_count = f->t_count; ca.p_firstsurv = f->t_firstsurv; }      // (as fill_fgrow)
     ca.x = in.x; ca.pd = in.pd; ca.cov = in.cov; ca.flags = in.flags; ca.cap = f->Ncap;
     ca.Pbar_prev = f->ct_Pbar[lp]; ca.Phat_prev = f->ct_Phat[lp]; ca.Proot = f->ct_Proot[li];
     ca.Pbar = f->ct_Pbar[li]; ca.Phat = f->ct_Phat[li];
@@ -1279,7 +1280,11 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         const int rc = flush_commit(ctx, f);
         if (rc) return rc;
     }
-    if (f->ct) {     // constant-turn forest: forest_ct_kernel walks the leaves of the COMMITTED table in front of the grow launch
+    // (constant-turn forest: forest_ct_kernel walks the leaves in front of the grow launch -- of the uncommitted table when the previous scan's
+    // commit is still pending (it then rides in the grow launch like everywhere else: one launch and two boundaries less per scan), MHT_CT_FLUSH=1:
+    // of the committed table, as until the end of round 5)
+    static int ct_flush = -1; if (ct_flush < 0) { const char* e = getenv("MHT_CT_FLUSH"); ct_flush = (e && e[0] == '1') ? 1 : 0; }
+    if (f->ct && ct_flush) {
         const int rc = flush_commit(ctx, f);
         if (rc) return rc;
     }
@@ -1299,7 +1304,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[0], st));
     // ---- 0: AIS-aided children of every leaf (tracker.py:394-396, :417-552), only on scans that carry messages ----------------
     if (ais) MHT_STEP_CHECK(forest_ais_prepass(ctx, f, pl.s, pl.n_ub, z, M));
-    if (f->ct) MHT_STEP_CHECK(forest_ct_prepass(ctx, f, pl.s, pl.n_ub));      // ---- 0': the leaves' own transitions, predictions, gains and children covariances
+    if (f->ct) MHT_STEP_CHECK(forest_ct_prepass(ctx, f, pl.s, pl.n_ub, pl.fused));      // ---- 0': the leaves' own transitions, predictions, gains and children covariances
     // Clusters without a clustering launch (mht_kernels.h: FDyn::uf_epoch): the target workgroups of the grow launch hook their targets
     // into a union-find, the workgroups of the ILP launch derive the cluster tables from it.  Similar-state pruning works on the
     // clustering kernel's list of lone targets between the two launches; the streamed path's initiator rides in the cluster launch.

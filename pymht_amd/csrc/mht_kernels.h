@@ -79,7 +79,8 @@ struct CtGrow {
 };
 struct CtForestArgs {
     Model model; double T;
-    const int32_t* nT_dev; const int32_t* t_first; const int32_t* t_leaf_off;      // the committed target table
+    const int32_t* nT_dev; const int32_t* t_first; const int32_t* t_leaf_off;      // the committed target table ...
+    int fused; const int32_t* p_status; const int32_t* p_count; const int32_t* p_firstsurv;      // ... or (fused) the uncommitted one: the previous scan's per-target results by old slot, as FGrowArgs::p_* (the commit then rides in the grow launch)
     const double* x; const double* pd; const int32_t* cov; const uint8_t* flags; int cap;      // the leaves' layer
     const float* Pbar_prev; const float* Phat_prev; const float* Proot;      // what the leaves' keys resolve against: the layer before / their own layer's roots
     float* Pbar; float* Phat;      // [cap][NP] out: the covariances of the leaves' children
