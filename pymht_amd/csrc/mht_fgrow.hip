@@ -214,7 +214,7 @@ __global__ __launch_bounds__(FG_THREADS, 2) void fgrow_ais_kernel(const FGrowArg
 // name the leaf; no chain workgroups (nothing is shared by value)
 #if MHT_NX == 6
 template <int PQ>
-__global__ __launch_bounds__(FG_THREADS, 2) void fgrow_ct_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
+__global__ __launch_bounds__(FG_THREADS, 3) void fgrow_ct_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }
@@ -241,6 +241,14 @@ size_t fgrow_lds_bytes_cap(int W, int pds, int AW, int cap) {
     return (b + 15) & ~(size_t)15;
 }
 
+// fgrow_ct_kernel: hit masks over the target's candidate list (FG_HWC words per leaf) and a conflict list of its own (see target_part)
+static size_t fgrow_ct_lds_bytes(int W, int pds, int AW) {
+    const int cap = FG_CAP;
+    size_t b = (size_t)2 * W * 64 * 4 + (size_t)cap * sizeof(FLeaf) + (size_t)2 * pds * cap * 4 + (size_t)cap * FG_HWC * 8 + (size_t)AW * 8 +
+               (size_t)(cap + 4) * 4 + 128 + (size_t)W * 64 * 2 + FG_MAP + (size_t)FG_CONF * 4;
+    if (b < 256) b = 256;
+    return (b + 15) & ~(size_t)15;
+}
 size_t fgrow_lds_bytes(int W, int pds, int AW) { return fgrow_lds_bytes_cap(W, pds, AW, FG_CAP); }      // (the batched launch, workgroup per target)
 size_t fgrow_wave_lds_bytes(int W, int pds, int AW) {      // (the batched launch, wavefront per target: four slices)
     size_t b = (size_t)(FG_THREADS / 64) * fw_layout(pds, AW, W * 64).total;
@@ -333,7 +341,7 @@ int launch_fgrow(mht_ctx* ctx, const FGrowArgs& a, FDyn& d, int n_targets_ub, co
     if (a.ct.on) {      // constant-turn forest: its own kernel, no chain workgroups
         fgrow_plan(d, n_targets_ub, a.Tcap, commit != nullptr, false);
         d.n_chain = 0;
-        const size_t lds = fgrow_lds_bytes_cap(d.W, a.pds, a.AW, FG_CAP);
+        const size_t lds = fgrow_ct_lds_bytes(d.W, a.pds, a.AW);
         { const int rc = fgrow_lds_attr(ctx, lds); if (rc) return rc; }
         const bool pub = publish && publish->dst;
         const int grid = fgrow_grid(d) + (pub ? FG_PUB_WGS : 0);

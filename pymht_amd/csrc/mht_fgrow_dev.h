@@ -40,6 +40,8 @@ struct TInfo { int alive, first, cnt, depth, shift; };
 // cannot see through they are vector loads nobody waits for until the staging loop's own wait, which covers them.
 struct TPre { unsigned long long w; int dep; };
 constexpr int FG_MAP = 1024;                          // entries of the child -> leaf table of a chunk (more children: binary search)
+constexpr int FG_HWC = 6;                             // constant-turn kernel: words of a leaf's hit mask over the target's candidate list (384 candidates -- with them the workgroup is 53.3 KB at 2 048 measurements, three per CU; more: CtGrow::hw_spill)
+constexpr int FG_CONF = 256;                          // constant-turn kernel: entries of the union-find's conflict list in LDS (more are linked straight away)
 constexpr int FG_CHAIN_TARGETS = FG_THREADS / 128 > 0 ? FG_THREADS / 128 : 1;     // targets per chain workgroup: wavefront = (target, hit/miss)
 typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the kernel's own argument block (constant address space)
 
@@ -520,13 +522,20 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
     FLeaf* lg = reinterpret_cast<FLeaf*>(zy + Mpad);                                        // [CAP]
     int* s_pp = reinterpret_cast<int*>(lg + CAP);                                        // [CAP][pds] path records of the leaves
     int* s_ap = s_pp + PDS * CAP;                                                        // [CAP][pds] ancestor records
-    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + PDS * CAP);    // [CAP][W] hit masks
-    unsigned long long* tb = hw + (size_t)CAP * W;                                       // [AW] association bitset of the target
+    // Hit masks.  [CAP][W] words over the scan's measurements -- except in the constant-turn kernel (long scans: W = 32 at 2 048 measurements
+    // is 24.6 KB of a 71 KB workgroup, two per CU): there a leaf's hits are bits over the target's CANDIDATE list (the measurements inside its
+    // box, in ascending order: a few dozen), FG_HWC words per leaf; a target with more candidates than that keeps full-width masks in a block
+    // of global memory of its slot (CtGrow::hw_spill).
+    constexpr bool CMP = CT != 0;
+    const int HWS = CMP ? FG_HWC : W;                                                    // words per leaf in LDS
+    unsigned long long* hw = reinterpret_cast<unsigned long long*>(s_ap + PDS * CAP);    // [CAP][HWS] hit masks
+    unsigned long long* tb = hw + (size_t)CAP * HWS;                                     // [AW] association bitset of the target
     int* s_pref = reinterpret_cast<int*>(tb + AW);                                          // [CAP + 1]
     int* s_misc = s_pref + CAP + 4;                                                      // [32]
     unsigned short* cand = reinterpret_cast<unsigned short*>(s_misc + 32);                  // [Mpad]
     unsigned char* s_map = reinterpret_cast<unsigned char*>(cand + Mpad);                   // [FG_MAP] leaf of the chunk's r-th child
-    int* s_ais = reinterpret_cast<int*>(s_map + FG_MAP);                                    // AIS forest: [CAP][4] fused children (count, first record), bound identity
+    int* s_conf = reinterpret_cast<int*>(s_map + FG_MAP);                                   // constant-turn kernel: [FG_CONF] the union-find's conflict list (cand lives until the emission there)
+    int* s_ais = reinterpret_cast<int*>(s_map + FG_MAP);                                    // AIS forest: [CAP][4] fused children (count, first record), bound identity (never together with s_conf)
     FLeafX* lgx = reinterpret_cast<FLeafX*>(s_ais + 4 * CAP);                              // AIS forest: [CAP] float64 gains of a promoted target's leaves
     int& s_ncand = s_misc[0];
     int& s_base = s_misc[1];
@@ -634,7 +643,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             const int n = (cnt - c0 < CAP) ? cnt - c0 : CAP;
             const bool first_emit = (pass == 1 && c0 == 0);
             // ---- phase 1: predict, one leaf per lane of wavefronts 0 and 1; the gains come from the table -----------------------
-            for (int w = tid; w < CAP * W; w += FG_THREADS) hw[w] = 0ull;
+            if (!CMP) for (int w = tid; w < CAP * W; w += FG_THREADS) hw[w] = 0ull;      // (constant-turn kernel: cleared behind the candidate count, as many words as are used)
             if (tid == 0) s_ncand = 0;
             int last = -1, last2 = -1, nfv = 0, offv = 0;      // (last2, nfv, offv: AIS forest)
             if (wave < 2) {          // (both wavefronts whole: the box reduction below runs over all their lanes)
@@ -823,6 +832,20 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             }
             const int x0 = min(s_boxp[0], s_boxp[4]), x1 = max(s_boxp[1], s_boxp[5]);
             const int y0 = min(s_boxp[2], s_boxp[6]), y1 = max(s_boxp[3], s_boxp[7]);
+            if (CMP) {      // the list in ASCENDING order (the hit masks index it, the children of a leaf are emitted in its order): one wavefront, no atomics
+                if (wave == 0) {
+                    int nc0 = 0;
+                    for (int j0 = 0; j0 < Mpad; j0 += 64) {
+                        const int j = j0 + lane;
+                        const int kx = fg_sortable(zx[j]), ky = fg_sortable(zy[j]);
+                        const bool in = (kx >= x0) && (kx <= x1) && (ky >= y0) && (ky <= y1);
+                        const unsigned long long bal = __ballot(in);
+                        if (in) cand[nc0 + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+                        nc0 += __popcll(bal);
+                    }
+                    if (lane == 0) s_ncand = nc0;
+                }
+            } else
             for (int j0 = 0; j0 < Mpad; j0 += FG_THREADS) {
                 const int j = j0 + tid;
                 bool in = false;
@@ -839,11 +862,23 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             __syncthreads();
             FG_STAMP(3);
             // ---- phase 2 (b): thread = (leaf, candidate): the leaf's own conservative float32 box, then the exact reference-order NIS
+            // (constant-turn kernel: where the leaves' hit words live for this chunk -- LDS, bits = positions in the candidate list, or the slot's
+            // block of global memory with full-width masks when the list is longer than FG_HWC words)
+            const int nc_all = s_ncand;
+            const int nblk = CMP ? (nc_all + 63) >> 6 : W;
+            const bool spill = CMP && (nblk > FG_HWC || d.ct_spill);      // (ct_spill: testing, MHT_CT_SPILL=1 -- every target through the global block)
+            unsigned long long* hwg = (CMP && spill) ? a.ct.hw_spill + (size_t)bslot * CAP * W : nullptr;
+            const int hstride = CMP ? (spill ? W : nblk) : W;
+            if (CMP) {
+                if (spill) { for (int w = tid; w < n * W; w += FG_THREADS) hwg[w] = 0ull; }
+                else { for (int w = tid; w < n * nblk; w += FG_THREADS) hw[w] = 0ull; }
+                __syncthreads();
+            }
             {
                 const int nc = s_ncand;
                 const int sh = (n > 1) ? 32 - __clz(n - 1) : 0;      // leaves padded to a power of two
                 for (int w = tid; w < (nc << sh); w += FG_THREADS) {
-                    const int l = w & ((1 << sh) - 1), j = cand[w >> sh];
+                    const int l = w & ((1 << sh) - 1), ci = w >> sh, j = cand[ci];
                     if (l >= n) continue;
                     const FLeaf& g = lg[l];
                     if (!g.valid) continue;
@@ -861,7 +896,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                             hit = gate_pair<double>(zh, g.sinv, mx, my, a.model.eta2, zt, nis);
                         }
                         if (hit) {
-                            atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
+                            if (!CMP) atomicOr(&hw[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
+                            else if (spill) atomicOr(&hwg[(size_t)l * W + (j >> 6)], 1ull << (j & 63));
+                            else atomicOr(&hw[(size_t)l * nblk + (ci >> 6)], 1ull << (ci & 63));
                             atomicOr(&tb[curw + (j >> 6)], 1ull << (j & 63));
                         }
                     }
@@ -874,6 +911,9 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             if (wave == 0) {
                 int h0 = 0, h1 = 0;
                 const int l1 = (lane + 64 < CAP) ? lane + 64 : lane;      // (second half of the chunk: lanes beyond it re-read their own row)
+                if (CMP && spill) { for (int w = 0; w < W; ++w) { h0 += __popcll(hwg[(size_t)lane * W + w]); h1 += __popcll(hwg[(size_t)l1 * W + w]); } }
+                else if (CMP) { if (lane < n) for (int w = 0; w < nblk; ++w) h0 += __popcll(hw[(size_t)lane * nblk + w]); if (lane + 64 < n) for (int w = 0; w < nblk; ++w) h1 += __popcll(hw[(size_t)l1 * nblk + w]); }
+                else
                 for (int w = 0; w < W; ++w) { h0 += __popcll(hw[(size_t)lane * W + w]); h1 += __popcll(hw[(size_t)l1 * W + w]); }
                 if (AIS) { h0 += s_ais[lane * 4]; h1 += s_ais[l1 * 4]; }      // (fused children behind the radar children)
                 const int m0 = (lane < n && lg[lane].valid) ? 1 + h0 : 0, m1 = (lane + 64 < n && lg[l1].valid) ? 1 + h1 : 0;
@@ -916,7 +956,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 // (overlapping launch: the compacted index is not known yet -- hooked under the SLOT, which is the index unless a target died in
                 // the previous scan; the end of the workgroup redoes it in that case)
                 const int pos = ovl ? t : (d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t);
-                uf_claim(a.uf_owner, a.uf_parent, d.uf_epoch, pos, tb, AW, lane, reinterpret_cast<int*>(cand), Mpad / 2, &s_misc[17]);
+                uf_claim(a.uf_owner, a.uf_parent, d.uf_epoch, pos, tb, AW, lane, CMP ? s_conf : reinterpret_cast<int*>(cand), CMP ? FG_CONF : Mpad / 2, &s_misc[17]);
             } else if (wave == 1 && first_emit && !d.uf_epoch) {
                 // edges of the clustering graph = set bits of the association bitset (complete here: every leaf's last real
                 // measurement and the hits; with two passes the count pass has seen all chunks)
@@ -956,7 +996,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                 if (d.uf_epoch) {      // the targets this one shares a node with (uf_claim above): one link each (the last wavefront: emission reaches it last)
                     if (wave == FG_THREADS / 64 - 1) {
                         const int pos = ovl ? t : (d.fused ? (s_red[0] + s_red[1] + s_red[2] + s_red[3]) : t);
-                        const int* conf = reinterpret_cast<const int*>(cand);
+                        const int* conf = CMP ? s_conf : reinterpret_cast<const int*>(cand);
                         for (int i = lane; i < s_misc[17]; i += 64) uf_link(a.uf_parent, d.uf_epoch, pos, conf[i]);
                     }
                 } else if (wave == 1) {      // edge list: (target << 16 | node) for every set bit (this wavefront's share of phase 4 is the lightest)
@@ -1030,8 +1070,13 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
                             if (g.f32state) fg_emit_child<float, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
                             else fg_emit_child<double, PQ, 1>(a, d, -1, g, l, c, k, nhr, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, nullptr, nullptr, &gx);
                         }
-                    } else if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
-                    else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, nh, hw + (size_t)l * W, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32);
+                    } else {
+                        // (constant-turn kernel: the leaf's hit words index the candidate list -- unless they were spilled, full width, to global memory)
+                        const unsigned long long* hwl = (CMP && spill) ? hwg + (size_t)l * W : hw + (size_t)l * hstride;
+                        const unsigned short* cmap = (CMP && !spill) ? cand : nullptr;
+                        if (g.f32state) fg_emit_child<float, PQ>(a, d, -1, g, l, c, k, nh, hwl, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, cmap);
+                        else fg_emit_child<double, PQ>(a, d, -1, g, l, c, k, nh, hwl, zx, zy, s_pp, s_ap, depth, shift, rootc, root_f32, cmap);
+                    }
                 }
                 run += ctot;
             }

@@ -289,7 +289,7 @@ struct Forest {
     // the roots born into it; for the newest layer's leaves the predictions and gains forest_ct_kernel leaves for the grow launch
     bool ct = false; double ct_T = 0.0;
     float* ct_Pbar[MAXR] = {}; float* ct_Phat[MAXR] = {}; float* ct_Proot[MAXR] = {};
-    float4* ct_gains = nullptr; double* ct_xbar = nullptr; double* ct_zhat = nullptr;
+    float4* ct_gains = nullptr; double* ct_xbar = nullptr; double* ct_zhat = nullptr; unsigned long long* ct_hw_spill = nullptr;
     bool ais = false; int ais_half = 0;
     int32_t* l_mmsi[MAXR] = {}; int32_t* l_hmmsi[MAXR] = {};
     int32_t* ais_nf = nullptr; int32_t* ais_off = nullptr; AisRec* ais_rec = nullptr; int ais_rec_cap = 0; unsigned* ais_count = nullptr;
@@ -363,6 +363,7 @@ struct Forest {
     // one launch per scan (mht_blp.hip: blp_grow_kernel): the ILP launch of the last scan has NOT been queued -- it rides in front of the next
     // scan's grow roles (forest_step_impl), or is launched alone by whoever needs its results first (flush_ilp, at the head of flush_commit).
     // MHT_MERGE=1 at creation turns it on: measured slower than the launch pair, so the pair stays the default
+    bool ct_spill = false;         // testing: MHT_CT_SPILL=1 at creation -- fgrow_ct_kernel keeps every target's hit masks in the global spill block
     bool grid_by_hint = true;      // MHT_BLP_GRID_HINT=0 at creation: the ILP launch sized by the target count alone, as until round 5
     bool merge_on = false; bool ilp_pending = false; BlpArgs pending_blp = {}; int pending_blp_grid = 0; int merged_launches = 0; unsigned long long role_tick_total = 0;
     // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
@@ -420,6 +421,7 @@ struct Forest {
         if (ct) {
             for (int s = 0; s < R; ++s) { ct_Pbar[s] = ar.take<float>((size_t)NP * Ncap); ct_Phat[s] = ar.take<float>((size_t)NP * Ncap); ct_Proot[s] = ar.take<float>((size_t)NP * Tcap); }
             ct_gains = ar.take<float4>((size_t)GKQ * Ncap); ct_xbar = ar.take<double>((size_t)NX * Ncap); ct_zhat = ar.take<double>((size_t)2 * Ncap);
+            ct_hw_spill = ar.take<unsigned long long>((size_t)Tcap * FG_CAP * (Mpad / 64));      // (fgrow_ct_kernel: full-width hit masks of a target with more candidates than its LDS words hold; touched only then)
         }
         if (ais) {
             for (int s = 0; s < R; ++s) { l_mmsi[s] = ar.take<int32_t>(Ncap); l_hmmsi[s] = ar.take<int32_t>(Ncap); }
@@ -672,6 +674,7 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
         f->root_base = f->over_base + FG_REGIONS * f->region_cap;
     }
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
+    { const char* e = getenv("MHT_CT_SPILL"); f->ct_spill = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_GRID_HINT"); f->grid_by_hint = !(e && e[0] == '0'); }
     { const char* e = getenv("MHT_MERGE"); f->merge_on = e && e[0] == '1'; }      // (one launch per scan, blp_grow_kernel: built, correct, SLOWER than the launch pair -- DESIGN section 4; off unless asked for)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
@@ -977,7 +980,7 @@ static void fill_fgrow(const Forest* f, int s, bool fused, FGrowArgs& g) {
     g.rec0 = f->rec0; g.new_index = f->new_index; g.ni_flag = &f->cnt->ni_flag;
     g.uf_owner = f->uf_owner; g.uf_parent = f->uf_parent2[s & 1];      // (by scan parity: the grow launch of scan s + 1 links while the ILP launch of scan s still reads)
      g.uf_team_state = f->teams ? f->team_state2[s & 1] : nullptr;
-    if (f->ct) { g.ct.on = 1; g.ct.gains = f->ct_gains; g.ct.xbar = f->ct_xbar; g.ct.zhat = f->ct_zhat; }
+    if (f->ct) { g.ct.on = 1; g.ct.gains = f->ct_gains; g.ct.xbar = f->ct_xbar; g.ct.zhat = f->ct_zhat; g.ct.hw_spill = f->ct_hw_spill; }
     if (f->ais) {
         g.ais.nf = f->ais_nf; g.ais.off = f->ais_off; g.ais.rec = f->ais_rec; g.ais.half = f->ais_half;
         g.ais.hmmsi_in = f->l_hmmsi[(s - 1) % f->R]; g.ais.ommsi = f->l_mmsi[s % f->R]; g.ais.ohmmsi = f->l_hmmsi[s % f->R];
@@ -1327,6 +1330,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.ovl = (pl.fused && f->pub_scan == pl.s - 1 && f->pending_dyn.scan == pl.s - 1) ? 1 : 0;
         d.c_wait = f->blp_done_total;
         grow_ovl = d.ovl != 0;
+        d.ct_spill = f->ct_spill ? 1 : 0;
         d.z_flag = &f->cnt->z_flag; d.z_tag = f->z_tag_step;
         { static int os = -1; if (os < 0) { const char* e = getenv("MHT_OVL_STAMPS"); os = (e && e[0] == '1') ? 1 : 0; } d.stamp_end = os; }
         const bool adm = f->adm_pending && pl.fused;      // (flush_commit clears both)

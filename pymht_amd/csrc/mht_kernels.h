@@ -76,6 +76,7 @@ struct CtGrow {
     const float4* gains;      // [cap][GKQ]
     const double* xbar;       // [NX][cap]
     const double* zhat;       // [2][cap]
+    unsigned long long* hw_spill;      // [Tcap][FG_CAP][ceil(max_meas / 64)] full-width hit masks of a target whose candidate list outgrows the LDS words (fgrow_ct_kernel: FG_HWC)
 };
 struct CtForestArgs {
     Model model; double T;
@@ -169,6 +170,7 @@ struct FDyn {
                                    // report's workgroups for the previous scan's ILP launch (c_wait)
     int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)
     int gentle;                    // blp_grow_kernel: waits may be long and many at once -- poll sparingly (mht_commit.h: spin_until)
+    int ct_spill;                  // testing (MHT_CT_SPILL=1): fgrow_ct_kernel keeps every target's hit masks in the global spill block
     unsigned long long c_wait;     // FCounts::blp_done the commit waits for (0: the ILP launch has ended, as stream order says)
     unsigned uf_epoch;             // != 0 (2 x the scan number): no edge list -- the target workgroups hook their targets into a device-wide
                                    // union-find over the measurement nodes they use, and the ILP launch derives the clusters from it

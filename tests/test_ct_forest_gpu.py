@@ -41,10 +41,17 @@ def _make(g, **kw):
     return trk, acc
 
 
-def test_constant_turn_forest_replays_trace(gold_dir):
+@pytest.mark.parametrize("spill", [False, True])
+def test_constant_turn_forest_replays_trace(gold_dir, spill, monkeypatch):
+    """spill: the grow kernel of the constant-turn forest keeps a leaf's hits as bits over the target's candidate list (a few LDS words per leaf);
+    a target with more candidates than those words hold takes full-width masks in a block of global memory -- forced for every target here
+    (MHT_CT_SPILL=1, read when the forest is created)."""
     from pymht_amd.utils.classDefinitions import MeasurementList
     g = np.load(os.path.join(gold_dir, "g23_trace_ct6.npz"))
+    if spill:
+        monkeypatch.setenv("MHT_CT_SPILL", "1")
     trk, acc = _make(g)
+    monkeypatch.delenv("MHT_CT_SPILL", raising=False)
     assert trk.nx == 6 and acc == [bool(a) for a in g["accepted"]]
     n_ilp, worst = 0, 0.0
     for k in range(int(g["n_scans"])):
