@@ -1127,8 +1127,12 @@ __host__ __device__ __forceinline__ FWLayout fw_layout(int pds, int AW, int Mpad
     FWLayout o;
     int b = 0;
     o.lf = b; b += FW_LP * (int)sizeof(FLeaf);
+#ifdef MHT_FW_PARK_RECORDS      // (until the end of round 5: the leaves' path / ancestor records parked in LDS for the emission, 4 KB of a wavefront's 16 KB)
     o.pp = b; b += FW_LP * pds * 4;
     o.ap = b; b += FW_LP * pds * 4;
+#else
+    o.pp = b; o.ap = b;      // (the emission reads them where phase 1 read them: the leaves of a pass are consecutive nodes, their records consecutive in global memory and in this XCD's L2)
+#endif
     o.mask = b; b += FW_MASKW * 8;
     o.tb = b; b += AW * 8;
     o.cand = b; b += (Mpad * 2 + 15) & ~15;
@@ -1247,10 +1251,12 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
                 g.valid = valid; g.src = src; g.flags = fl; g.f32state = (fl & F_STATE_F32) ? 1 : 0; g.cn = cn; g.pd = pd;
 #pragma unroll
                 for (int q = 0; q < PQ; ++q) {
+#ifdef MHT_FW_PARK_RECORDS
                     if (lane < LP) {
                         reinterpret_cast<int4*>(s_pp + lane * PDS)[q] = pq[q];
                         reinterpret_cast<int4*>(s_ap + lane * PDS)[q] = aq[q];
                     }
+#endif
                     const int pe[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1438,8 +1444,13 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
 #pragma unroll
                         for (int q = 0; q < (int)(sizeof(FLeaf) / 16); ++q) dstq[q] = srcq[q];
                     }
-                    if (gc.f32state) fg_emit_child<float, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, s_pp, s_ap, depth, shift, rootc, root_f32, cand, z2);
-                    else fg_emit_child<double, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, s_pp, s_ap, depth, shift, rootc, root_f32, cand, z2);
+#ifdef MHT_FW_PARK_RECORDS
+                    const int* e_pp = s_pp; const int* e_ap = s_ap;
+#else
+                    const int* e_pp = a.in_path + (size_t)(first + c0) * PDS; const int* e_ap = a.in_apath + (size_t)(first + c0) * PDS;      // (leaf l of the pass = node first + c0 + l)
+#endif
+                    if (gc.f32state) fg_emit_child<float, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, e_pp, e_ap, depth, shift, rootc, root_f32, cand, z2);
+                    else fg_emit_child<double, PQ>(a, d, -1, gc, l, c, k, nh, mk + l * nblk, zdummy, zdummy, e_pp, e_ap, depth, shift, rootc, root_f32, cand, z2);
                 }
                 FW_STAMP(6);
                 // The gains one scan ahead (chain_part's job, folded into the target's wavefront here: a launch of many sectors has no idle
