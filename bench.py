@@ -173,6 +173,23 @@ def prepass(sc, device, n_untimed=0):
     return births, np.array(stats), final, api_s, init_s
 
 
+_GROUP_STREAMS = []
+
+
+def pick_streams(n, prios, device):
+    """The HIP streams the groups of sectors run on: made ONCE per process, four of them up front, and every run takes the first n.  The
+    runtime maps streams onto a few hardware queues as they are first used and later streams SHARE the queues of earlier ones: a second
+    multi-sector run on streams of its own could land both of its groups on one queue -- its launch chains then run one after the other
+    (measured: 16 sectors in two groups 49 k instead of 80 k scans/s whenever the four-sector run had taken four streams before it,
+    profiles/r05_merge_ab.txt).  The first streams of a process sit on queues of their own."""
+    want = max(n, 4)
+    base = [0, -1, 1, 0]
+    while len(_GROUP_STREAMS) < want:
+        q = len(_GROUP_STREAMS)
+        _GROUP_STREAMS.append(torch.cuda.Stream(device=device, priority=(prios[q % len(prios)] if len(prios) > 2 or q >= 4 else base[q % 4])))
+    return _GROUP_STREAMS[:n]
+
+
 class Replay:
     """Drives the forest through the raw C ABI with every input resident in HBM."""
 
@@ -501,7 +518,7 @@ def main():
         # the same one -- the groups then run one after the other instead of side by side: 43 k instead of 74 k scans/s at 16 sectors,
         # decided by chance per process)
         prios = [int(v) for v in os.environ.get("MHT_BENCH_PRIOS", "0,-1,1,0" if NG > 2 else "0,-1").split(",")]
-        streams = [torch.cuda.Stream(device=local, priority=prios[q % len(prios)]) for q in range(NG)]
+        streams = pick_streams(NG, prios, local)
         rps = []
         for q in range(S):
             with torch.cuda.stream(streams[q % NG]):
