@@ -34,6 +34,8 @@ def build_library(force=False, verbose=True, nx=4):
     concurrent callers (one process per GPU all importing the package at once): an exclusive file lock serialises them, the second one
     finds a fresh library; the output is written to a temporary file and renamed, so a reader never sees a half-written .so."""
     LIB = lib_path(nx)
+    if os.environ.get("MHT_LIB_VARIANT") and os.path.exists(LIB):
+        return LIB      # an experiment build made by hand (other flags, other sources): never rebuilt from the tree's sources
     if not force and not _stale(LIB):
         return LIB
     import fcntl

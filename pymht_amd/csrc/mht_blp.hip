@@ -142,19 +142,39 @@ __device__ __forceinline__ void block_min_pair(double& v, int& i, Red* r) {
 
 // ---- storage policies -----------------------------------------------------------------------------------------
 // Columns are addressed by a policy-local index; rows by a policy-local id in [0, nrows()).
+#ifndef MHT_GS_CK
+#define MHT_GS_CK 1
+#endif
 struct GStore {      // HBM: column = global child index, row = global measurement-node id, row set = LDS bitset
     const BlpArgs* a; const int32_t* mem; const unsigned long long* uw; int UW, PD; size_t cap;
     double* pu; int32_t* pusage; int32_t* pmark;      // prices / usage / marks by measurement node: the workgroup's own copy (a team member's, or the shared one)
     int32_t *best_h, *ub_sel, *ch, *lix; double *best_rc, *cst, *uus, *lrc, *rest, *mn;
-    __device__ __forceinline__ int col_begin(int k) const { return a->tchild[mem[k]]; }
-    __device__ __forceinline__ int col_end(int k) const { return a->tcend[mem[k]]; }
+    // (r5) ck: the members' column ranges are cbL[k] .. ceL[k] (LDS, filled by solve_cluster for clusters of <= cap_k targets) instead of two
+    // dependent global look-ups (member -> target -> range) in front of every member's sweep.
+    // (Tried and backed out: the rows' prices / usage counters / marks in the LDS solver's row tables, addressed by the node's dense rank in
+    // the row bitset -- the rank costs two LDS reads and a 64-bit popcount per look-up and the tables become generic pointers (flat
+    // accesses): G20 131 -> 155 ms, profiles/r05_ilp_tail.txt.)
+    bool ck; const int32_t *cbL, *ceL;
+    __device__ __forceinline__ int row(int m) const { return m; }
+    __device__ __forceinline__ int col_begin(int k) const { return (MHT_GS_CK && ck) ? cbL[k] : a->tchild[mem[k]]; }
+    __device__ __forceinline__ int col_end(int k) const { return (MHT_GS_CK && ck) ? ceL[k] : a->tcend[mem[k]]; }
     __device__ __forceinline__ double cost(int h) const { return a->cost[h]; }
     __device__ __forceinline__ int ent(int d, int h) const { return a->pds ? a->path[(size_t)h * a->pds + d] : a->path[(size_t)d * cap + h]; }
-    __device__ __forceinline__ double& u(int m) const { return pu[m]; }
-    __device__ __forceinline__ int32_t& usage(int m) const { return pusage[m]; }
-    __device__ __forceinline__ int32_t& mark(int m) const { return pmark[m]; }
+    __device__ __forceinline__ double& u(int m) const { return pu[row(m)]; }
+    __device__ __forceinline__ int32_t& usage(int m) const { return pusage[row(m)]; }
+    __device__ __forceinline__ int32_t& mark(int m) const { return pmark[row(m)]; }
     __device__ __forceinline__ int to_global(int h) const { return h; }
+    // The rows' prices / usage counters live in HBM scratch: every row a thread visits is a round trip to the L2 of its own (the sums that
+    // are formed over them keep the loads from overlapping).  A thread per WORD of the bitset walks up to 64 rows one after the other -- the
+    // 188 rows of G20 sit in three words: three threads, 64 round trips each, four times per subgradient step (2/3 of its 90 us).  Up to
+    // FOR_ROWS_FLAT words a thread per BIT: at most UW / 4 looks at the bitset (LDS) and ~nR / 256 rows per thread.
+    static constexpr int FOR_ROWS_FLAT = 256;
     template <typename F> __device__ __forceinline__ void for_rows(F f) const {
+        if (UW <= FOR_ROWS_FLAT) {
+            for (int m = threadIdx.x; m < UW * 64; m += BLP_THREADS)
+                if ((uw[m >> 6] >> (m & 63)) & 1ull) f(m);
+            return;
+        }
         for (int w = threadIdx.x; w < UW; w += BLP_THREADS) {
             unsigned long long bits = uw[w];
             while (bits) {
@@ -305,19 +325,130 @@ template <typename S> __device__ __forceinline__ double priced_sum(const S& s, i
     return block_sum(priced_part(s, h), r);
 }
 
-// per target the minimiser of the reduced cost (lowest column wins ties) -> best_h[k], best_rc[k]
-__device__ __forceinline__ void compute_minimisers(const GStore& s, int K, Red* r) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < K; k += BLP_THREADS / 64) {
+// One wavefront's sweep over the columns [hb, he) of a member on HBM scratch: this lane's (reduced cost, lowest index) minimum among the
+// columns compatible with the marks (COMPAT) -- SWEEP_U columns in flight per lane.  A column is two dependent round trips to the L2 (its
+// rows, then their prices / marks); a member of a giant cluster has a few hundred columns, so a lane that takes them one at a time pays
+// those round trips three to five times per member and a sweep over 44 members (11 per wavefront) is ~80 us of nothing but latency -- the
+// time of every subgradient step and of every node of the branch and bound on HBM scratch (G20: 0.4 ms per node).  The ILP workgroups
+// are one per CU (LDS), i.e. one wavefront per SIMD: the registers the batch needs are there for the taking.  The columns of a lane are
+// still visited in ascending order and compared with strict <, every reduced cost is summed in the same order: same minimisers, bit for bit.
+#ifndef MHT_SWEEP_U
+#define MHT_SWEEP_U 4
+#endif
+constexpr int SWEEP_U = MHT_SWEEP_U;
+struct RowBatch { int e[SWEEP_U][8]; double c[SWEEP_U]; };
+// rows and costs of the columns h0, h0 + 64, ... of a member [hb, he) -- loads only, nothing waits for them here
+__device__ __forceinline__ void rows_load(const GStore& s, int hb, int h0, int he, RowBatch& b) {
+#pragma unroll
+    for (int q = 0; q < SWEEP_U; ++q) {
+        const int h = h0 + 64 * q, hc = h < he ? h : hb;      // (clamped: every member has a column)
+        rows8(s, hc, b.e[q]);
+        b.c[q] = s.cost(hc);
+    }
+}
+// ... their prices (and marks), the reduced costs, this lane's running minimum
+template <bool COMPAT> __device__ __forceinline__ void rows_finish(const GStore& s, const RowBatch& b, int h0, int he, double& bv, int& bi) {
+    double uv[SWEEP_U][8];
+    int mk[SWEEP_U], mv[SWEEP_U][8];
+    // (levels d >= PD hold no row in any column -- a uniform test: no look-up is issued for them; within PD every look-up is unconditional,
+    // node 0 standing in for "no row": the sweep is bound by the number of gathers it issues)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if (d < s.PD) {
+#pragma unroll
+            for (int q = 0; q < SWEEP_U; ++q) {
+                const int m = b.e[q][d] >= 0 ? b.e[q][d] : 0;
+                uv[q][d] = s.pu[m];
+                if (COMPAT) mv[q][d] = s.pmark[m];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SWEEP_U; ++q) { uv[q][d] = 0.0; mv[q][d] = 0; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SWEEP_U; ++q) {
+        mk[q] = 0;
+        if (COMPAT) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) mk[q] |= (b.e[q][d] >= 0) ? mv[q][d] : 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SWEEP_U; ++q) {
+        const int h = h0 + 64 * q;
+        double rc = b.c[q];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) rc = (b.e[q][d] >= 0) ? rc + uv[q][d] : rc;      // (reduced_cost()'s order of additions)
+        if (h < he && mk[q] == 0 && (bi < 0 || rc < bv)) { bv = rc; bi = h; }
+    }
+}
+// The wavefront's members one after the other: member(i) -> k, out(i, value, column) with the (reduced cost, lowest index) minimum of member
+// i among its columns (COMPAT: those compatible with the marks), uniform over the wavefront.  The rows of member i + 1 are on their way
+// while member i's prices are: one round trip per member instead of two.
+template <bool COMPAT, typename M, typename O> __device__ __forceinline__ void sweep_wave(const GStore& s, int n, int lane, M member, O out) {
+    if (!(s.PD <= 8 && MHT_ROWS8)) {
+        for (int i = 0; i < n; ++i) {
+            const int k = member(i);
+            double bv = DINF;
+            int bi = -1;
+            for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+                if (COMPAT && !compatible(s, h)) continue;
+                const double rc = reduced_cost(s, h);
+                if (bi < 0 || rc < bv) { bv = rc; bi = h; }
+            }
+            wave_min_pair(bv, bi);
+            out(i, bv, bi);
+        }
+        return;
+    }
+    RowBatch cur, nxt;
+    int hb = 0, he = 0, nhb = 0, nhe = 0;
+    if (n > 0) {
+        const int k = member(0);
+        hb = s.col_begin(k); he = s.col_end(k);
+        rows_load(s, hb, hb + lane, he, cur);
+    }
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 < n) {
+            const int k1 = member(i + 1);
+            nhb = s.col_begin(k1); nhe = s.col_end(k1);
+            rows_load(s, nhb, nhb + lane, nhe, nxt);
+        }
+        double bv = DINF;
+        int bi = -1;
+        rows_finish<COMPAT>(s, cur, hb + lane, he, bv, bi);
+        for (int h0 = hb + lane + 64 * SWEEP_U; h0 < he; h0 += 64 * SWEEP_U) {      // a member of more than 64 * SWEEP_U columns
+            RowBatch t;
+            rows_load(s, hb, h0, he, t);
+            rows_finish<COMPAT>(s, t, h0, he, bv, bi);
+        }
+        wave_min_pair(bv, bi);
+        out(i, bv, bi);
+        cur = nxt; hb = nhb; he = nhe;
+    }
+}
+template <bool COMPAT, typename M, typename O> __device__ __forceinline__ void sweep_wave(const LStore& s, int n, int lane, M member, O out) {
+    for (int i = 0; i < n; ++i) {
+        const int k = member(i);
         double bv = DINF;
         int bi = -1;
         for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
+            if (COMPAT && !compatible(s, h)) continue;
             const double rc = reduced_cost(s, h);
             if (bi < 0 || rc < bv) { bv = rc; bi = h; }
         }
         wave_min_pair(bv, bi);
-        if (lane == 0) { s.best_h[k] = bi; s.best_rc[k] = bv; }
+        out(i, bv, bi);
     }
+}
+
+// per target the minimiser of the reduced cost (lowest column wins ties) -> best_h[k], best_rc[k]
+__device__ __forceinline__ void compute_minimisers(const GStore& s, int K, Red* r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = BLP_THREADS / 64;
+    sweep_wave<false>(s, K > wave ? (K - wave + NW - 1) / NW : 0, lane, [&](int i) { return wave + NW * i; },
+                      [&](int i, double bv, int bi) { if (lane == 0) { s.best_h[wave + NW * i] = bi; s.best_rc[wave + NW * i] = bv; } });
     __threadfence_block();
     __syncthreads();
 }
@@ -1011,6 +1142,9 @@ constexpr int TEAM_LEVEL = MHT_TEAM_LEVEL;      // the search is dealt out at th
 #endif
 __device__ __forceinline__ constexpr int team_level(const LStore&) { return TEAM_LEVEL; }
 __device__ __forceinline__ constexpr int team_level(const GStore&) { return MHT_TEAM_LEVEL_HBM; }
+// (Tried in round 5 and dropped: subtrees CLAIMED through a table -- first member to arrive takes it -- instead of dealt out by hash.  Exact and
+// balanced, but the members all start on the same few subtrees in sequence and good incumbents arrive later: G20 14.1 k nodes instead of
+// 11.4 k, 122 ms against 118, profiles/r05_ilp_tail.txt.)
 __device__ __forceinline__ unsigned team_hash(int c0, int c1) {      // (level-0 column, level-1 column) -> member: price-independent
     unsigned h = (unsigned)c0 * 0x9E3779B1u ^ ((unsigned)c1 * 0x85EBCA6Bu + 0x7F4A7C15u);
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
@@ -1258,6 +1392,13 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     __syncthreads();
     int level = 0;
     bool enter = true;
+#ifdef MHT_BLP_TRACE
+    int tr_eval = 0, tr_upper = 0;
+    unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_q = 0, tr_n = wall_clock64();
+#define TR_MARK(i) do { const unsigned long long _n = wall_clock64(); tr_t[i] += _n - tr_q; tr_q = _n; } while (0)
+#else
+#define TR_MARK(i) do {} while (0)
+#endif
     status = MHT_BLP_BRANCHED;
     // team search: `own` = cost of the selection in THIS member's ub_sel[]; UB = the pruning bound = min(own, best value any member has
     // published).  The root node is processed with the member's own (deterministic) incumbent, so that every member sees the same
@@ -1297,27 +1438,33 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                 continue;
             }
             const int rounds = (snap && level < BB_RE_LEVELS) ? BB_NODE_STEPS : 0;
+#ifdef MHT_BLP_TRACE
+            if (team && level <= team_level(s)) ++tr_upper;
+#endif
             bool pruned = false;
             double rs_all = 0.0, usumU = 0.0, best_lb = -DINF;
             int best_rd = -1;
             bool final_eval = false;          // one more evaluation under the restored best prices, no step after it
             double* sl = snap ? snap + (size_t)(level < BB_RE_LEVELS ? level : 0) * a.bb_snap_rows : nullptr;
+            // (lane i holds the member of the wavefront's i-th position: ord[] is in HBM for a giant cluster, a round trip in front of every
+            // member's sweep otherwise)
+            int my_k = 0;
+            { const int p = level + wave + (BLP_THREADS / 64) * lane; if (p < K) my_k = ord[p]; }
             for (int rd = 0; rd <= rounds + 1; ++rd) {
+#ifdef MHT_BLP_TRACE
+                ++tr_eval;
+                { const unsigned long long _n = wall_clock64(); tr_t[6] += _n - tr_n; tr_q = _n; }      // [6]: outside the evaluations
+#endif
                 // minimisers of the remaining targets among the columns compatible with the fixed ones
-                for (int p = level + wave; p < K; p += BLP_THREADS / 64) {
-                    const int k = ord[p];
-                    double bv = DINF;
-                    int bi = -1;
-                    for (int h = s.col_begin(k) + lane; h < s.col_end(k); h += 64) {
-                        if (!compatible(s, h)) continue;
-                        const double rc = reduced_cost(s, h);
-                        if (bi < 0 || rc < bv) { bv = rc; bi = h; }
-                    }
-                    wave_min_pair(bv, bi);
-                    if (lane == 0) { s.mn[p] = (bi < 0) ? DINF : bv; bh[p] = bi; }
+                {
+                    constexpr int NW = BLP_THREADS / 64;
+                    const int p0 = level + wave;
+                    sweep_wave<true>(s, K > p0 ? (K - p0 + NW - 1) / NW : 0, lane, [&](int i) { return i < 64 ? __shfl(my_k, i) : ord[p0 + NW * i]; },
+                                     [&](int i, double bv, int bi) { if (lane == 0) { s.mn[p0 + NW * i] = (bi < 0) ? DINF : bv; bh[p0 + NW * i] = bi; } });
                 }
                 __threadfence_block();
                 __syncthreads();
+                TR_MARK(0);
                 double rs = 0.0, cs = 0.0;
                 int dead = 0;
                 for (int p = level + tid; p < K; p += BLP_THREADS) {
@@ -1326,6 +1473,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     else { rs += v; cs += s.cost(bh[p]); }
                 }
                 dead = block_or(dead, r);
+                TR_MARK(1);
                 if (dead) { pruned = true; break; }
                 int conflict = 0, slack = 0;
                 double nrm = 0.0, us = 0.0;
@@ -1338,6 +1486,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     __threadfence_block();
                     __syncthreads();
                 }
+                TR_MARK(2);
                 s.for_rows([&](int m) {
                     if (s.mark(m)) return;                      // blocked by a fixed column: not part of the residual problem
                     const double um = s.u(m);
@@ -1368,6 +1517,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     slack = (f >> 1) & 1;
                 }
                 const double lb = s.cst[level] + rs_all - usumU;
+                TR_MARK(3);
                 bool stop = false;
                 if (rounds > 0 && !final_eval && lb > best_lb) {       // keep the best prices of the node (a Polyak step with a loose
                     best_lb = lb;                                      // upper bound can overshoot badly)
@@ -1388,6 +1538,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     }
                 }
                 if (!stop && lb >= UB - 1e-12 * fmax(1.0, fabs(UB))) { pruned = true; stop = true; }
+                TR_MARK(4);
                 const bool step_on = !stop && !final_eval && rd < rounds && nrm > 0.0;
                 // no further step: if the last evaluated prices are not the node's best, go back to those and evaluate once more
                 const bool redo = !stop && !final_eval && !step_on && rounds > 0 && best_rd != rd;
@@ -1407,6 +1558,10 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
                     __threadfence_block();
                     __syncthreads();
                 }
+                TR_MARK(5);
+#ifdef MHT_BLP_TRACE
+                tr_n = wall_clock64();
+#endif
                 if (redo) { final_eval = true; continue; }
                 if (stop || !step_on) break;
             }
@@ -1464,6 +1619,11 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
         ++level;
         enter = true;
     }
+#ifdef MHT_BLP_TRACE
+    if (tid == 0 && team) printf("[blp] member %d of %d: %d nodes (%d at or above the deal-out level), %d evaluations, left at %.2f ms; us per evaluation: sweep %.1f sums %.1f usage %.1f rows %.1f keep %.1f step %.1f outside %.1f\n", tm.q, tm.W, nodes, tr_upper, tr_eval,
+                                 1e-5 * (double)(wall_clock64() - stamp[0]), 1e-2 * tr_t[0] / tr_eval, 1e-2 * tr_t[1] / tr_eval, 1e-2 * tr_t[2] / tr_eval, 1e-2 * tr_t[3] / tr_eval,
+                                 1e-2 * tr_t[4] / tr_eval, 1e-2 * tr_t[5] / tr_eval, 1e-2 * tr_t[6] / tr_eval);
+#endif
     ub = own;      // (the cost of what ub_sel[] holds: a team member may have pruned with a better value found elsewhere)
     for (int l = 0; l < level; ++l) set_marks(s, s.ch[l], 0);     // leave no marks behind
     if (slot >= 0 && tid == 0) atomicExch(&a.bb_busy[slot], 0);
@@ -1855,10 +2015,16 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         gs.a = &a; gs.mem = mem; gs.uw = uw; gs.UW = UW; gs.PD = a.PD; gs.cap = (size_t)a.cap;
         const size_t om = team_hbm ? (size_t)tm.q * a.tm_sm : 0, os = (team_hbm ? (size_t)tm.q * a.tm_ss : 0) + (size_t)slot;      // this member's copies
         gs.pu = a.u + om; gs.pusage = a.usage + om; gs.pmark = a.mark + om;
+        gs.ck = small_k;      // (colb / gbase were filled above)
+        gs.cbL = s.gbase; gs.ceL = s.lix;
+        if (gs.ck) {
+            for (int k = tid; k < K; k += BLP_THREADS) s.lix[k] = s.gbase[k] + (s.colb[k + 1] - s.colb[k]);
+            __syncthreads();
+        }
         gs.best_h = a.best_h + os; gs.best_rc = a.best_rc + os; gs.ub_sel = a.bb_best + os; gs.ch = a.bb_ch + os;
         gs.cst = a.bb_cost + os; gs.uus = a.bb_uused + os; gs.lrc = a.bb_last_rc + os; gs.lix = a.bb_last_idx + os;
         gs.rest = a.bb_rest + os; gs.mn = a.bb_min + os;
-        gs.for_rows([&](int m) { gs.pu[m] = 0.0; gs.pusage[m] = 0; gs.pmark[m] = 0; });      // (usage / marks are zero between uses; a member's copy may never have been touched)
+        gs.for_rows([&](int m) { gs.u(m) = 0.0; gs.usage(m) = 0; gs.mark(m) = 0; });      // (usage / marks are zero between uses; a member's copy may never have been touched)
         __threadfence_block();
         __syncthreads();
         double ub = DINF;
@@ -1870,6 +2036,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
 #endif
         if (status == MHT_BLP_REDUCE) {
             // ---- reduced-cost fixing left few enough columns: rebuild the cluster from them in LDS (see reducible()) -------
+            // (the rebuild re-uses the LDS tables: the column ranges are taken from global memory from here on)
+            gs.ck = false;
             if (tid == 0) {
                 int acc = 0;
                 for (int k = 0; k < K; ++k) { s.colb[k] = acc; acc += gs.lix[k]; }
