@@ -320,3 +320,33 @@ def test_prune_seam_matches_oracle_trees():
         assert np.array_equal(nr.cpu().numpy(), want_root), trial
         assert set(np.nonzero(keep.cpu().numpy())[0].tolist()) == alive, trial
     ctx.close()
+
+
+def test_blp_hbm_policy_both_row_passes_and_column_range_sources(gpu_ctx, gold_dir, monkeypatch):
+    """(r5) The HBM storage policy has two forms of its passes over a cluster's rows (a thread per BIT of the row bitset up to 256 words,
+    a thread per WORD beyond) and two sources of the members' column ranges (LDS for clusters of <= cap_k = 256 targets, the target
+    tables in global memory beyond): recorded instances with their row numbers spread over > 16 384 nodes (the per-word form) give the
+    recorded optima, and a chain of 300 conflicting targets (ranges from global memory) the exact optimum of the oracle's solver."""
+    monkeypatch.setenv("MHT_BLP_FORCE_HBM", "1")
+    for name in ("g6_ilp_cfg3", "g7_ilp_hard"):
+        for inst in load_instances(os.path.join(gold_dir, name + ".npz"))[::5]:
+            wide = dict(inst)
+            wide["cols"] = [np.asarray(c, dtype=np.int64) * 131 + 7 for c in inst["cols"]]      # (injective: the same conflicts, > 256 bitset words)
+            if max((int(c.max()) for c in wide["cols"] if len(c)), default=0) < 16384:
+                continue
+            for max_iter in (200, 0):
+                sel, obj, st, it, nd = gpu_blp(gpu_ctx, wide, max_iter=max_iter)
+                assert st in (1, 2) and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(obj)) and sel == inst["sel"].tolist()
+    monkeypatch.delenv("MHT_BLP_FORCE_HBM")
+    rng = np.random.default_rng(5)
+    nT = 300
+    cols, sizes, cost = [], [], []
+    for t in range(nT):      # target t wants row t or row t + 1 (its neighbour's), or a private row, or nothing
+        cols += [np.array([t]), np.array([t + 1]), np.array([nT + 1 + t]), np.array([], dtype=np.int64)]
+        cost += [-3.0 - rng.uniform(), -3.0 - rng.uniform(), -1.0 - rng.uniform(), 0.0]
+        sizes.append(4)
+    inst = dict(cols=cols, sizes=np.array(sizes), cost=np.array(cost))
+    ref_sel, ref_obj = orc.solve_blp_exact([c.tolist() for c in cols], sizes, cost)[:2]
+    sel, obj, st, it, nd = gpu_blp(gpu_ctx, inst, max_iter=400)
+    assert st in (1, 2), st
+    assert abs(obj - float(ref_obj)) <= 1e-9 * max(1.0, abs(obj))
