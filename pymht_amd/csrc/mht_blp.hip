@@ -332,8 +332,10 @@ template <typename S> __device__ __forceinline__ double priced_sum(const S& s, i
 // time of every subgradient step and of every node of the branch and bound on HBM scratch (G20: 0.4 ms per node).  The ILP workgroups
 // are one per CU (LDS), i.e. one wavefront per SIMD: the registers the batch needs are there for the taking.  The columns of a lane are
 // still visited in ascending order and compared with strict <, every reduced cost is summed in the same order: same minimisers, bit for bit.
+// (SWEEP_U measured on G20 with the next member's rows in flight, profiles/r05_ilp_tail.txt: 1: 111 ms, 2: 111, 3: 119, 4: 118, 8: 170 -- once the members are
+// pipelined the batch size buys nothing and its registers cost: the batch lives twice, this member's and the next one's)
 #ifndef MHT_SWEEP_U
-#define MHT_SWEEP_U 4
+#define MHT_SWEEP_U 2
 #endif
 constexpr int SWEEP_U = MHT_SWEEP_U;
 struct RowBatch { int e[SWEEP_U][8]; double c[SWEEP_U]; };

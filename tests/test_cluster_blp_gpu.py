@@ -162,7 +162,7 @@ def test_blp_team_on_hbm_scratch(gpu_ctx, gold_dir, monkeypatch):
     sel, obj, status, iters, nodes = gpu_blp(gpu_ctx, inst, max_iter=200, node_limit=1 << 22)
     t_team = gpu_blp.last_call_s
     assert sel == inst["sel"].tolist() and abs(obj - inst["obj"]) <= 1e-9 * max(1.0, abs(inst["obj"])) and status == 2
-    assert t_team < 0.5, "the HBM team needed %.2f s" % t_team      # (0.23 s until round 5's batched sweeps, 0.12 s since: profiles/r05_ilp_tail.txt; the call adds launches and a read-back)
+    assert t_team < 0.5, "the HBM team needed %.2f s" % t_team      # (0.23 s until round 5's batched sweeps, 0.11 s since: profiles/r05_ilp_tail.txt; the call adds launches and a read-back)
     monkeypatch.setenv("MHT_BLP_NO_TEAMS", "1")
     sel1, obj1, status1, _, nodes1 = gpu_blp(gpu_ctx, inst, max_iter=200, node_limit=1 << 22)
     assert sel1 == sel and status1 == 2
