@@ -47,8 +47,33 @@ def build_library(force=False, verbose=True, nx=4):
             hipcc = os.environ.get("HIPCC", "hipcc")
             srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
             extra = os.environ.get("MHT_EXTRA_HIPCC_FLAGS", "").split()      # development: e.g. -DMHT_GROW_STAMPS (tools/grow_profile.py)
+            # one object per translation unit (no relocatable device code: the units share headers only), compiled side by side and kept
+            # under build/: a change to one .hip recompiles that unit, a change to a header or to the flags recompiles all
+            odir = os.path.join(HERE, "build", "nx%d%s" % (nx, os.environ.get("MHT_LIB_VARIANT", "")))
+            os.makedirs(odir, exist_ok=True)
+            cflags = [f for f in FLAGS if f != "-shared"] + (["-DMHT_NX=%d" % nx] if nx != 4 else []) + extra
+            stamp = os.path.join(odir, "flags.txt")
+            old_flags = open(stamp).read() if os.path.exists(stamp) else None
+            hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+            hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "mht_amd.h")))
+            todo = []
+            for s in srcs:
+                o = os.path.join(odir, os.path.basename(s)[:-4] + ".o")
+                if force or old_flags != " ".join(cflags) or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+                    todo.append((s, o))
+            import concurrent.futures as cf
+
+            def compile_one(so):
+                cmd = [hipcc] + cflags + ["-c", so[0], "-o", so[1]]
+                if verbose:
+                    print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
+                subprocess.check_call(cmd)
+            with cf.ThreadPoolExecutor(max(1, min(len(todo), os.cpu_count() or 4))) as ex:
+                list(ex.map(compile_one, todo))
+            with open(stamp, "w") as fh:
+                fh.write(" ".join(cflags))
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = [hipcc] + FLAGS + (["-DMHT_NX=%d" % nx] if nx != 4 else []) + extra + srcs + ["-o", tmp]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(odir, os.path.basename(s)[:-4] + ".o") for s in srcs] + ["-o", tmp]
             if verbose:
                 print("[pymht_amd.build]", " ".join(cmd), file=sys.stderr)
             try:

@@ -1468,6 +1468,10 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             if (hh != 0ull && age >= 1 && age <= 8192 && h_team == 0) {
                 int gh = h_multi + h_multi / 8 + (h_single + 3) / 4 + 8;      // (an eighth more multi-target clusters than last time; the rest loops)
                 if (gh < 32) gh = 32;
+                // (the hint may be thousands of scans old and targets may have been added since: a workgroup's tables hold 4 multi-target
+                // clusters and 32 single-target ones -- UfPersist::own / single -- so THIS scan's target bound keeps the grid from below)
+                const int g_min = f->nT_ub_step / 8 + 1;
+                if (gh < g_min) gh = g_min;
                 if (gh < grid) grid = gh;
             }
         }
