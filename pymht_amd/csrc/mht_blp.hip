@@ -1786,9 +1786,6 @@ __device__ __forceinline__ TgtPre load_target_cr(const BlpArgs& a, int t, const 
     if (a.uf_epoch) p.lab = cr.root;
     return p;
 }
-}  // namespace mht
-#include "mht_blp_wave.h"      // small clusters on one wavefront (solve_wave)
-namespace mht {
 // my_t: member `threadIdx.x` of the cluster if the caller has it at hand (-1: read from the member list), pre_in: its record if already fetched
 __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, unsigned long long* uw, Red* r, unsigned char* lds,
                                               const Team tm = Team{0, 1, nullptr}, const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr, const int dbg_bx = -1) {
@@ -2430,7 +2427,7 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
     return true;
 }
 
-template <bool UF> __device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps = nullptr, const int wsel = -1);
+template <bool UF> __device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps = nullptr);
 __device__ __forceinline__ void blp_stamp_begin(const BlpArgs& a, int bx);
 template <bool UF = false>
 __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, const int bx, const int gx, UfPersist* ps = nullptr, const UfFetch* fe = nullptr) {      // workgroup bx of gx
@@ -2457,8 +2454,6 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
     // (ONE call site of the solver: the workgroup's own clusters first, then the single-target clusters, then -- if it has no cluster
     // of its own -- its share of a team's search)
     int own_i = bx, own_q = 0;
-    bool singles_early = false;      // wavefronts 1.. took their single-target clusters next to wavefront 0's solve_wave
-    unsigned char* const solver_lds = lds + (size_t)a.cap_uw * 8 + RED_SLOT;
     for (int stage = UF ? -1 : 0; stage < 3; ) {
         ClRef cr = ClRef{-1, 0, 0, -1};
         int ti = -1, mt = -1;
@@ -2487,7 +2482,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             else ti = -1;
         } else if (stage == 1) {
             stage = 2;
-            blp_singles<UF>(a, bx, gx, nSingle, ps, singles_early ? 0 : -1);
+            blp_singles<UF>(a, bx, gx, nSingle, ps);
             continue;
         } else {
             stage = 3;
@@ -2500,42 +2495,15 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             tm = Team{q, team_W(ti), &a.team_state[ti].gub};
         }
         if (a.dbg && threadIdx.x == 0 && bx < 3900 && stage == 0) a.dbg[32 + (size_t)bx * 16 + 13] = wall_clock64();
-        // A small cluster goes to ONE wavefront first (mht_blp_wave.h: the coordinate rounds without a block barrier); the others take the
-        // workgroup's single-target clusters meanwhile.  What that solver does not finish -- it gives up exactly where the coordinate
-        // rounds end -- is solved from scratch by the whole workgroup, as ever.
-        if (stage == 0 && a.wave_on && a.t_alive && a.pds == 8 && a.PD <= 8 && !a.force_hbm && a.tier == 0 && a.shard_n <= 1 && a.n_mnodes <= 65535 &&
-            cr.K >= 2 && cr.K <= WV_MAXK && tm.W == 1) {
-            if ((threadIdx.x >> 6) == 0) {
-                const int lane = threadIdx.x & 63;
-                int tkk = 0;
-                TgtPre pp = {};
-                if (lane < cr.K) {
-                    tkk = mt >= 0 ? mt : a.cl_members[cr.p0 + lane];
-                    pp = (mt >= 0 && my_pre) ? *my_pre : load_target_cr(a, tkk, cr);
-                }
-                const bool ok = solve_wave(a, cr, tkk, pp, solver_lds, WV_COLS_SOLO, bx);
-                if (lane == 0) red->i[0] = ok ? 1 : 0;
-            } else if (!singles_early) {
-                blp_singles<UF>(a, bx, gx, nSingle, ps, 1);
-            }
-            singles_early = true;
-            __threadfence_block();
-            __syncthreads();
-            const int ok = red->i[0];
-            __syncthreads();
-            if (ok) continue;
-        }
-        solve_cluster(a, cr, uw, red, solver_lds, tm, ti, mt, mt >= 0 ? my_pre : nullptr, bx);
+        solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr, bx);
     }
 }
 
 // targets alone in their cluster: one wavefront each, dealt out from the END of the grid (the workgroups without an ILP)
-// wsel: -1 = every wavefront takes its share, 0 = wavefront 0 only, 1 = all but wavefront 0 (the shares are per wavefront: no barrier in here)
 template <bool UF>
-__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps, const int wsel) {
+__device__ __forceinline__ void blp_singles(const BlpArgs& a, const int bx, const int gx, const int nSingle, const UfPersist* ps) {
     // targets alone in their cluster: min cumulativeNLLR, `<=` => the LAST minimal leaf wins (pyTarget.py:449)
     const int lane = threadIdx.x & 63;
-    if ((wsel == 0 && (threadIdx.x >> 6) != 0) || (wsel == 1 && (threadIdx.x >> 6) == 0)) return;
     const int gw = (gx - 1 - bx) * (BLP_THREADS / 64) + (threadIdx.x >> 6);
     int j = 0;
     for (int i = gw; i < nSingle; i += gx * (BLP_THREADS / 64), ++j) {

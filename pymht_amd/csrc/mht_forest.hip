@@ -1037,10 +1037,6 @@ static void fill_blp(const Forest* f, int s, BlpArgs& b) {
     // (clusters from the grow launch's union-find: switched on per scan by the caller, b.uf_epoch = scan number)
     b.uf_parent = f->uf_parent2[s & 1]; b.nT_dev = &f->cnt->nT; b.uf_cap = f->Tcap; b.status_other = f->status2 + ((s - 1) & 1); b.alloc_reset = f->alloc2[s & 1];
     b.t_cluster = f->t_cluster;
-    // small clusters by ONE wavefront (mht_blp_wave.h): exact, and measured on the headline stream (profiles/r06_wave_solver.txt) -- a round-0 pair 9.5 us instead of
-    // 11.1, but the clusters a launch ENDS with (300-450 columns, 1-3 further rounds) 29 us instead of 21: one SIMD's instruction issue against four.
-    // Off in the one-sector launch (MHT_BLP_WAVE=1: on); the batched launches of a group of sectors use it (throughput, not latency, counts there).
-    { static int wv = -1; if (wv < 0) { const char* e = getenv("MHT_BLP_WAVE"); wv = (e && e[0] == '1') ? 1 : 0; } b.wave_on = wv; }
     { static int bs = -1; if (bs < 0) { const char* e = getenv("MHT_BLP_STAMPS"); bs = (e && e[0] == '1') ? 1 : 0; } b.dbg = (bs && f->debug) ? f->grow_dbg : nullptr; }
 }
 

@@ -316,7 +316,6 @@ struct BlpArgs {
     const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
                                                         // target died in the previous scan, the union-find was redone under epoch | 1
     int wt_commit;                 // blp_grow_kernel: what the commit reads of this launch is written through (mht_blp.hip: st_commit)
-    int wave_on;                   // small clusters are tried by one wavefront first (mht_blp_wave.h); 0 (MHT_BLP_WAVE=0): the workgroup solver takes every cluster
     unsigned uf_lds_off;           // offset of the workgroup's UfPersist block in the dynamic LDS (behind the solver's tables; set by launch_blp)
 };
 
