@@ -317,7 +317,7 @@ def ilp_accounting(sc, births, device, n_warm, n_scans):
                     "or the GPU branch and bound after the dual rounds did not certify; nnz(A1) from the path records of a sample of the columns" % n_scans}
 
 
-def cpu_baseline(sc, n_warm, n_timed):
+def cpu_baseline(sc, n_warm, n_timed, budget_s=None):
     """The oracle (NumPy restatement of the reference algorithm, validated bitwise against the reference) on the
     host: stages Process+Cluster+Optim+Terminate+N-Prune of `n_timed` scans after `n_warm` warm-up scans."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -341,7 +341,11 @@ def cpu_baseline(sc, n_warm, n_timed):
     for x in roots_of(sc, model):
         o.initiate_target(sc["t0"], x.copy(), orc.model_P0() if four else model.P0.copy(), status="preinitialized")
     hot, stats = 0.0, []
+    t_b = time.time()
     for k in range(n_warm + n_timed):
+        if budget_s is not None and k > n_warm and time.time() - t_b > budget_s:      # (bounded: the timed sample ends here)
+            n_timed = k - n_warm
+            break
         info = o.add_scan(float(sc["times"][k]), sc["scans"][k])
         if k >= n_warm:
             hot += sum(o.toc[s] for s in ("Process", "Cluster", "Optim", "Terminate", "N-Prune"))
@@ -353,6 +357,97 @@ def cpu_baseline(sc, n_warm, n_timed):
                        "Process+Cluster+Optim+Terminate+N-Prune; mean L=%d G=%d M=%d; gate %.0f ms, cluster+ILP %.0f ms per scan"
                        % (n_warm, n_warm + n_timed - 1, n_warm, st[:, 0].mean(), st[:, 1].mean(), st[:, 2].mean(),
                           1e3 * st[:, 3].mean(), 1e3 * st[:, 4].mean()))
+
+
+def steady_windows(config, seed, centre, device, warm, n_win=3, win=20, long_k=400):
+    """Extras that make 2 % steps measurable (the headline's timed window is K = 20 scans, ~1 ms): the same stream replayed in a run of
+    its own -- `n_win` back-to-back windows of `win` scans, then one window of `long_k` scans, each bracketed by a device synchronise --
+    and checked against its own pre-pass at the end.  Returns (value_steady, windows dict)."""
+    from pymht_amd.utils.scenario import make_config
+    n_total = warm + n_win * win + long_k
+    sc2 = make_config(config, seed=seed, n_scans=n_total, centre=centre, confine=True)
+    births2, _, final2, _, _ = prepass(sc2, device, warm)
+    rp = Replay(sc2, births2, device)
+    for _ in range(warm):
+        rp.step()
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(n_win):
+        t0 = time.perf_counter()
+        for _ in range(win):
+            rp.step()
+        torch.cuda.synchronize()
+        rates.append(win / (time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    for _ in range(long_k):
+        rp.step()
+    torch.cuda.synchronize()
+    steady = long_k / (time.perf_counter() - t0)
+    rep, recs = rp.report()
+    ok = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0] == final2 and rep.error == 0
+    rp.close()
+    return steady, {"windows": n_win, "steps_per_window": win, "min": float(min(rates)), "median": float(np.median(rates)), "all": [float(v) for v in rates],
+                    "steady_steps": long_k, "replay_matches_prepass": bool(ok),
+                    "note": "a replay of its own of the same stream (same seed, longer): %d windows of %d scans back to back, then %d scans = value_steady; scans/s" % (n_win, win, long_k)}
+
+
+def config_extra(name, device, warm, steps, cpu_warm, cpu_timed, cpu_budget_s):
+    """A bounded line for another BASELINE config (cfg2: 50 targets / 200 measurements / N = 3; cfg5: constant-turn six-state model, 2 000
+    targets x ~2 000 measurements, N = 6) so that the driver's record holds them: pre-pass through the drop-in API, timed raw replay of
+    `steps` scans behind `warm`, the same end-state check as the headline, the grow stage's roofline from HIP-event stage times, and the
+    CPU restatement on a few steady-state scans of the same stream (bounded by `cpu_budget_s` of wall clock)."""
+    from pymht_amd.utils.scenario import make_config
+    sc = make_config(name, seed=5446, n_scans=warm + steps, confine=True)
+    nx = model_of(sc).C_RADAR.shape[1]
+    births, stats, final, api_s, _ = prepass(sc, device, warm)
+    rp = Replay(sc, births, device)
+    for _ in range(warm):
+        rp.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rp.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rep, recs = rp.report()
+    ok = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0] == final and rep.error == 0
+    rp._lib_mod.check(rp.lib.mht_forest_set_timing(rp.h, 1))
+    ms = np.zeros(5)
+    buf = (C.c_float * 5)()
+    n = C.c_int32(0)
+    nt = min(16, steps)
+    # (stage times of a few more scans of the stream's tail are not available: the stream ends here -- timed on a second replay)
+    rp.close()
+    rp = Replay(sc, births, device)
+    for _ in range(warm):
+        rp.step()
+    rp._lib_mod.check(rp.lib.mht_forest_set_timing(rp.h, 1))
+    for _ in range(nt):
+        rp.step()
+    rp._lib_mod.check(rp.lib.mht_forest_stage_times(rp.h, C.byref(buf), C.byref(n)))
+    ms = np.array(list(buf)) / nt
+    rp.close()
+    tm = stats[warm:warm + steps]
+    Lm, Gm, Mm = float(tm[:, 0].mean()), float(tm[:, 1].mean()), float(tm[:, 2].mean())
+    per_leaf = (8 * nx + 4 * nx * nx + 16) + (8 * nx + 4 * nx * nx + 8 + 4 * nx * nx)
+    per_pair = 8 * nx + 16
+    b_gate = per_leaf * Lm + per_pair * Gm + 8.0 * Mm
+    gbs = b_gate / (ms[0] * 1e-3) / 1e9 if ms[0] > 0 else 0.0
+    out = {"name": name, "workload": "%d targets, ~%d measurements per scan, N-scan=%d, %d-state model %s" % (len(sc["x0"]), int(Mm), int(sc["N"]), nx, model_of(sc).__name__.split(".")[-1]),
+           "value": steps / el, "unit": "scans/s", "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "replay_matches_prepass": bool(ok),
+           "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "ilps_per_scan": float(tm[:, 3].mean()), "api_scans_per_sec": 1.0 / api_s,
+           "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3])},
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": b_gate, "traffic": None,
+                        "kernel": "grow stage (fgrow_ct_kernel + forest_ct_kernel for the constant-turn model, fgrow_kernel else), HIP events on the ctx stream, mean of %d scans" % nt}}
+    if cpu_timed > 0:
+        t_c = time.time()
+        try:
+            cb = cpu_baseline(sc, cpu_warm, cpu_timed, budget_s=cpu_budget_s)
+        except Exception as e:      # noqa: BLE001
+            cb = {"error": repr(e)[:200]}
+        cb["wall_s"] = round(time.time() - t_c, 1)
+        out["cpu_baseline"] = cb
+    return out
 
 
 T_START = time.time()
@@ -437,18 +532,11 @@ def main():
         one_scan = rp.step
     for _ in range(W):
         one_scan()
-    # (MHT_MERGE=1, one launch per scan: a step leaves its ILP launch for the next step's launch -- mht_synchronize queues it.  Called in front
-    # of the clock and behind the last timed step, so that the timed region holds exactly K grow stages and K ILP stages, the last ILP launch included)
-    one_launch = os.environ.get("MHT_MERGE") == "1"
-    if one_launch:
-        rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         one_scan()
     t_enq = time.perf_counter()      # (the host has queued the K scans: how far ahead of the device it runs)
-    if one_launch:
-        rp._lib_mod.check(rp.lib.mht_synchronize(rp.h))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -458,8 +546,6 @@ def main():
     same_work = (got == final) and rep.error == 0
     uf_ovl = np.zeros(2, dtype=np.int32)      # scans clustered inside the grow launch, grow launches that overlapped the previous scan's ILP launch
     rp.lib.mht_forest_debug_read(rp.h, b"uf_ovl", uf_ovl.ctypes.data_as(C.c_void_p), 8)
-    merged = np.zeros(1, dtype=np.int32)      # scans whose ILP launch went out as ONE launch with the next scan's grow stage (blp_grow_kernel)
-    rp.lib.mht_forest_debug_read(rp.h, b"merged_launches", merged.ctypes.data_as(C.c_void_p), 4)
     rp.close()
     elapsed, same_work = parallel.reduce_clock(elapsed, same_work, dist, device="cuda")
     # one picture of all sectors (outside the timed region; KB-sized all-gather over RCCL)
@@ -616,7 +702,7 @@ def main():
                                "one independent sector per GPU" + (" -- STRONG: the same sector on every GPU, ILPs spread by cluster" if strong else ""), "name": args.config, "targets": int(timed[:, 6].mean()),
                    "leaves_per_scan": Lm, "gated_pairs_per_scan": Gm, "meas_per_scan": Mm, "n_scan": int(sc["N"]),
                    "ilps_per_scan": float(timed[:, 3].mean()), "ilps_branched": int(timed[:, 4].sum()), "tracks_all_sectors": int(sum(len(i) for i, _ in picture)),
-                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work, "host_us_per_scan_queued": round(1e6 * (t_enq - t0) / K, 2), "scans_clustered_in_grow_launch": int(uf_ovl[0]), "grow_launches_overlapping_ilp": int(uf_ovl[1]), "scans_as_one_launch": int(merged[0]),
+                   "blp_dual_iters_max": int(timed[:, 5].max()), "replay_matches_prepass": same_work, "host_us_per_scan_queued": round(1e6 * (t_enq - t0) / K, 2), "scans_clustered_in_grow_launch": int(uf_ovl[0]), "grow_launches_overlapping_ilp": int(uf_ovl[1]),
                    "pre_roll_scans": PRE},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},

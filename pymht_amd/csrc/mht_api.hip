@@ -12,7 +12,6 @@ void set_error(const char* fmt, ...) {
 }
 void forest_destroy(mht_ctx* ctx);
 int forest_sync_side(mht_ctx* ctx);      // mht_forest.hip
-int forest_flush_ilp(mht_ctx* ctx);     // mht_forest.hip
 }  // namespace mht
 
 extern "C" int mht_abi_version(void) { return MHT_ABI_VERSION; }
@@ -56,7 +55,6 @@ extern "C" int mht_destroy(mht_ctx* ctx) {
 
 extern "C" int mht_synchronize(mht_ctx* ctx) {
     MHT_REQUIRE(ctx, "mht_synchronize: null ctx");
-    { const int rc = mht::forest_flush_ilp(ctx); if (rc) return rc; }      // (an ILP launch a step left for the next step's launch: now)
     MHT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return mht::forest_sync_side(ctx);      // (the streamed scans' initiator launches run on a stream of the forest's own)
 }

@@ -22,8 +22,7 @@
 // is copied into LDS once (costs, rows as dense local ids, prices, usage counters, marks) and every dual step runs
 // out of LDS; larger clusters run the same code on HBM scratch (L2 resident).
 #include "mht_kernels.h"
-#include "mht_init_dev.h"
-#include "mht_fgrow_dev.h"
+#include "mht_commit.h"
 #include <stdlib.h>
 
 namespace mht {
@@ -1661,14 +1660,6 @@ __device__ __forceinline__ void blp_publish(const BlpArgs& a, int t, int key, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the root score's store has left)
     __hip_atomic_store(&a.rec0[t], tgt_rec(a.pub_scan, key != -1, rf, j, count, count > 0 ? first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// What the commit reads of a scan's ILP launch.  The commit of the launch pair waits for every ILP workgroup's agent-scope RELEASE (an L2
-// write-back per workgroup: cheap while nothing else is writing).  The one-launch-per-scan kernel cannot afford those -- its grow roles
-// have megabytes of children dirty in every L2 all the time -- so there (BlpArgs::wt_commit) these few words are
-// written THROUGH, like the targets' records, and a workgroup counts itself off behind `s_waitcnt vmcnt(0)` alone.
-template <typename T> __device__ __forceinline__ void st_commit(T* p, T v, bool wt) {
-    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, const TgtPre& p, bool store, int* rf_out = nullptr) {
     const int kc = a.kc;
     const double cn = a.cnllr[s];
@@ -1709,11 +1700,10 @@ __device__ __forceinline__ int finish_target(const BlpArgs& a, int t, int s, con
     const double rc = moved ? rc_l : p.rootc;
     const uint8_t rf = moved ? (uint8_t)((rf_l & F_SCORE_F32) ? 1 : 0) : p.rootf;
     if (store) {
-        const bool wt = a.wt_commit != 0;
-        st_commit(&a.t_alive[t], (int32_t)status, wt);                 // 0 = alive, else the termination reason
-        st_commit(&a.t_jdrop[t], (int32_t)j, wt);
+        a.t_alive[t] = status;                 // 0 = alive, else the termination reason
+        a.t_jdrop[t] = j;
         a.t_score[t] = score;
-        st_commit(&a.w_root_scan[t], (int32_t)rscan, wt); st_commit(&a.w_root_node[t], (int32_t)rnode, wt); st_commit(&a.w_root_f32[t], (uint8_t)rf, wt);
+        a.w_root_scan[t] = rscan; a.w_root_node[t] = rnode; a.w_root_f32[t] = rf;
         if (a.rec0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.w_root_cnllr[t]), (unsigned long long)__double_as_longlong(rc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.w_root_cnllr[t] = rc;
         mht_target_report& r = a.rec[t];
@@ -1758,7 +1748,7 @@ __device__ __forceinline__ void sweep_survivors(const BlpArgs& a, int t, int j, 
         }
     }
     if (lane == 0) {
-        st_commit(&a.t_count[t], (int32_t)count, a.wt_commit != 0); st_commit(&a.t_firstsurv[t], (int32_t)first, a.wt_commit != 0);
+        a.t_count[t] = count; a.t_firstsurv[t] = first;
         if (a.rec0) blp_publish(a, t, key, j, rf >= 0 ? rf : (int)a.w_root_f32[t], count, first);
     }
 }
@@ -1971,7 +1961,6 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
     const bool team_hbm = tm.W > 1 && !use_lds && a.tm_sm > 0 && K <= TEAM_SEL;
     if (tm.q > 0 && !team && !team_hbm) return;
     const int32_t* final_sel = nullptr;      // team search: the best member's selection (global columns), read by the last finisher
-    int32_t team_nodes = 0;
     int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
     double ub_reduced = DINF;
     // every member of a team files what it found (global columns); the LAST one to finish takes the best of all -- value, then the lowest
@@ -2130,7 +2119,6 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
             if (tm.q > 0) return;      // the dual phase is deterministic: every member holds the same certificate, the owner finishes
         } else if (team) {
             if (!team_file(tm, team_idx, K, [&](int k) { return s.to_global(s.ub_sel[k]); }, ub, status, iters, nodes, final_sel)) return;
-            team_nodes = nodes;
         }
         stamp[4] = wall_clock64();
         int rf_mine = -1;
@@ -2173,8 +2161,8 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         g[8] = t_begin; g[9] = t_setup; g[10] = stamp[4]; g[11] = wall_clock64();
     }
     if (tid == 0) {
-        st_commit(&a.cl_status[c], (int32_t)status, a.wt_commit != 0);
-        st_commit(&a.cl_iters[c], (int32_t)iters, a.wt_commit != 0);
+        a.cl_status[c] = status;
+        a.cl_iters[c] = iters;
         a.cl_nodes[c] = nodes;
         if (a.cl_time) {
             a.cl_time[8 * c] = (int)(t_setup - t_begin);
@@ -2388,13 +2376,12 @@ __device__ __forceinline__ bool uf_prologue(const BlpArgs& a, const UfFetch& fe,
                 gmem[t] = ms[t];
                 if (h == t) cl_ptr[par[h]] = hp[h];
             }
-            for (int i = tid; i < nMulti; i += BLP_THREADS) st_commit(&multi[i], (int32_t)par[ml[i]], a.wt_commit != 0);
+            for (int i = tid; i < nMulti; i += BLP_THREADS) multi[i] = par[ml[i]];
             for (int i = tid; i < nSingle; i += BLP_THREADS) single[i] = sl[i];
             if (a.team_list && tid < nTeam) const_cast<int32_t*>(a.team_list)[tid] = par[s_tl[tid]];
             if (tid == 0) {
                 cl_ptr[nC] = nT;
-                const bool wt = a.wt_commit != 0;
-                st_commit(&counts[0], (int32_t)nC, wt); st_commit(&counts[1], (int32_t)nMulti, wt); st_commit(&counts[2], (int32_t)nSingle, wt); st_commit(&counts[3], 0, wt); counts[4] = 0; counts[5] = nTeam;
+                counts[0] = nC; counts[1] = nMulti; counts[2] = nSingle; counts[3] = 0; counts[4] = 0; counts[5] = nTeam;
                 // (the counters of the other parity's status word, which the cluster kernel cleared for the scan after this one, are zeroed by
                 // that word's commit: the next scan's grow launch may be running already)
             }
@@ -2661,7 +2648,6 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a_in)
     if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();      // stage stamp: clustering starts
     // (this launch is ordered behind the scan's grow launch: whoever reads this word -- the scan's initiator on its own queue -- knows that launch is complete)
     if (a.begun && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.begun, (unsigned long long)a.pub_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.started && threadIdx.x == 0) atomicAdd(a.started, 1ull);      // (resident: the gate in front of the next grow launch counts these)
     const int gx = (int)gridDim.x, pb = (int)blockIdx.x, bx = pb;
     blp_body<true>(a, lds, bx, gx, ps, &fe);
     if (!fe.s_over) blp_stamp_end(a);
@@ -2676,106 +2662,6 @@ __global__ __launch_bounds__(BLP_THREADS) void blp_uf_kernel(const BlpArgs a_in)
     }
     if (a.dbg && threadIdx.x == 0 && bx < 3900) { a.dbg[32 + (size_t)bx * 16 + 15] = wall_clock64(); a.dbg[32 + (size_t)bx * 16 + 14] = ((unsigned long long)pb << 8) | (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7); }
 }
-// ---- ONE launch per scan: the ILP workgroups of scan k take the grow roles of scan k + 1 (r5) ---------------------------------------------
-// The launch pair's period ends with the slowest cluster of the scan, the dispatch of the next grow launch on the XCD it ran on, and its
-// targets' workgroups behind that ("What the launch pair's critical path is made of").  Here a workgroup that has
-// finished its clusters (and counted itself off, as in blp_uf_kernel) takes grow roles of the NEXT scan by ticket -- role 0 the commit of
-// scan k, then a target or a pair of chain wavefronts per role, exactly the bodies of fgrow_kernel's workgroups (mht_fgrow_dev.h) in
-// their overlapping form: a target role waits for ITS target's record and for nothing else.  What a target owes at its end -- its entries
-// under the compacted index, which only the commit knows -- is parked in LDS (TailList) and follows behind the workgroup's last role.
-// No second dispatch, no XCD that has to drain first, no kernel boundary between ILP launch k and grow launch k + 1; the launch needs scan
-// k + 1 when it is queued, so the host defers ILP launch k to the next mht_forest_step (and launches it alone when somebody asks for its
-// results first: flush_ilp, mht_forest.hip).  Every workgroup must be resident (a grow role may wait for a record of a workgroup that
-// has not started): the grid is bounded by the CUs, one 155 KB workgroup each.
-struct ScanArgs {
-    BlpArgs b;                       // ILP launch of scan k (as blp_uf_kernel takes it)
-    FGrowArgs g; CommitArgs cm; FDyn d;      // grow launch of scan k + 1 (as fgrow_kernel takes them)
-    unsigned long long* tick;        // role tickets: a counter that is never reset (FCounts::role_tick) ...
-    unsigned long long tick_base;    // ... and its value at the start of this launch (every launch draws n_roles + gridDim.x tickets: the host keeps count)
-    int n_roles;                     // commit + target slots + chain workgroups of the grow launch this stands for
-    int gx_ilp;                      // workgroups 0 .. gx_ilp - 1 carry the ILP launch's shares (one resident per CU at least); the others of the grid only play grow roles
-    unsigned tail_off;               // offset of the parked ends' LDS block (behind the grow roles' own LDS)
-};
-constexpr int SCAN_CONF_CAP = 256;
-constexpr bool SCAN_KERNEL_OK = FG_THREADS == BLP_THREADS;      // blp_grow_kernel: the grow roles run on the ILP workgroups
-__host__ __device__ constexpr size_t scan_tail_bytes(int AW) { return 64 + (size_t)TAIL_MAX * 16 + (size_t)SCAN_CONF_CAP * 4 + (size_t)TAIL_MAX * AW * 8; }
-typedef const __attribute__((address_space(4))) BlpArgs* KBlp;
-__device__ __forceinline__ void load_kernarg_blp(BlpArgs& a, KBlp p) { __builtin_memcpy(&a, p, sizeof(BlpArgs)); }
-template <int PQ, int CAP>
-__global__ __launch_bounds__(BLP_THREADS, 2) void blp_grow_kernel(const ScanArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const UfFetch fe = uf_prefetch(UfHead{sa.b.status, sa.b.nT_dev, sa.b.ni_flag, sa.b.uf_parent, sa.b.uf_cap, sa.b.uf_ovl});
-    typedef const __attribute__((address_space(4))) ScanArgs* KScan;
-    KScan kp = (KScan)__builtin_amdgcn_kernarg_segment_ptr();      // (the argument block is the kernel's only argument: offset 0)
-    asm volatile("" : "+s"(kp) : : "memory");
-#ifdef MHT_GROW_STAMPS
-    { unsigned long long* dbg0 = kp->d.dbg; if (dbg0 && threadIdx.x == 0) dbg0[32 + (size_t)(1000 + blockIdx.x) * 16] = wall_clock64(); }
-#endif
-    if ((int)blockIdx.x < kp->gx_ilp) {
-        BlpArgs a;
-        load_kernarg_blp(a, (KBlp)&kp->b);
-        UfPersist* ps = reinterpret_cast<UfPersist*>(lds + a.uf_lds_off);
-        if (a.status && blockIdx.x == 0 && threadIdx.x == 0) const_cast<DevStatus*>(a.status)->t[1] = wall_clock64();
-        if (a.begun && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.begun, (unsigned long long)a.pub_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int gx = kp->gx_ilp, bx = (int)blockIdx.x;
-        blp_body<true>(a, lds, bx, gx, ps, &fe);
-        if (!fe.s_over) blp_stamp_end(a);
-        __syncthreads();
-        if (threadIdx.x == 0) {      // this workgroup's share of scan k is out: released, counted off (the commit role waits for the count)
-            // (no agent-scope release: what the commit reads of this workgroup was written through, st_commit)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAdd(a.blp_done, 1ull);
-        }
-    }
-    // ---- grow roles of scan k + 1 ----------------------------------------------------------------------------------------------------
-    asm volatile("" : "+s"(kp) : : "memory");
-    const KArgs gp = (KArgs)&kp->g;
-    typedef const __attribute__((address_space(4))) CommitArgs* KCm;
-    const KCm cmp = (KCm)&kp->cm;
-    FDyn d = *(const FDyn*)(&kp->d);
-    d.gentle = 1;
-    const int n_roles = kp->n_roles;
-    unsigned long long* tick = kp->tick;
-    unsigned char* tailp = lds + kp->tail_off;
-    int* s_role = reinterpret_cast<int*>(tailp);                  // [16]: ticket, conflict count
-    TailList tl;
-    tl.n = 0;
-    tl.rec = s_role + 16;                                         // [TAIL_MAX][4]
-    tl.conf = tl.rec + TAIL_MAX * 4;                              // [SCAN_CONF_CAP]
-    tl.conf_cap = SCAN_CONF_CAP;
-    tl.nconf = s_role + 1;
-    tl.slot = reinterpret_cast<unsigned long long*>(s_role + 2);
-    tl.tb = reinterpret_cast<unsigned long long*>(tl.conf + SCAN_CONF_CAP);      // [TAIL_MAX][AW]
-    const unsigned long long tick_base = kp->tick_base;
-#ifdef MHT_GROW_STAMPS      // (tools/merge_profile.py) row 1000 + workgroup of the debug block: [0] entry, [1] counted off, [2 + 2 i], [3 + 2 i] start / end of its i-th role, [14] the roles (10 bits each), [15] exit
-#define SCAN_STAMP(k, v) do { if (d.dbg && threadIdx.x == 0) d.dbg[32 + (size_t)(1000 + blockIdx.x) * 16 + (k)] = (v); } while (0)
-    SCAN_STAMP(1, wall_clock64());
-    unsigned long long roles_seen = 0ull;
-    int n_seen = 0;
-#else
-#define SCAN_STAMP(k, v)
-#endif
-    for (;;) {
-        __syncthreads();      // (the role before is through with the LDS)
-        if (threadIdx.x == 0) s_role[0] = (int)(atomicAdd(tick, 1ull) - tick_base);      // (one returning atomic; the workgroup's last draw -- the one beyond the roles -- is counted by the host)
-        __syncthreads();
-        const int role = s_role[0];
-        if (role >= n_roles) break;
-        if (tl.n == TAIL_MAX) tail_drain(*gp, d, tl);
-#ifdef MHT_GROW_STAMPS
-        if (n_seen < 6) { SCAN_STAMP(2 + 2 * n_seen, wall_clock64()); roles_seen |= (unsigned long long)(role & 1023) << (10 * n_seen); }
-#endif
-        fgrow_body<PQ, CAP>(gp, *cmp, d, lds, role, &tl);
-#ifdef MHT_GROW_STAMPS
-        if (n_seen < 6) SCAN_STAMP(3 + 2 * n_seen, wall_clock64());
-        ++n_seen;
-#endif
-    }
-    SCAN_STAMP(14, roles_seen | ((unsigned long long)n_seen << 60));
-    tail_drain(*gp, d, tl);
-    SCAN_STAMP(15, wall_clock64());
-}
-
 // a group of sectors per launch, argument blocks read from HBM (written once, at group creation).  Workgroups are dealt out
 // sector-interleaved in dispatch order (blockIdx.x fastest): the first n * nMulti workgroups to reach the machine are the ones that
 // carry ILPs, of ALL sectors -- with sector = blockIdx.y the last sector's ILPs queued behind every other sector's idle workgroups
@@ -2866,23 +2752,6 @@ size_t blp_set_tier(BlpArgs& a, int tier) {
     return blp_lds_bytes(a.cap_h, a.cap_r, a.cap_k, a.cap_uw);
 }
 
-// The drop-in path's ILP launch: the device M-of-N initiator (step 7, tracker.py:264-278; mht_init_dev.h) rides along as ONE more
-// workgroup.  It needs the scan and the used-measurement bytes of the scan's grow launch, nothing of the clustering or the ILPs, and
-// what it gives birth to is admitted in the NEXT scan's grow launch -- next to the clustering (cluster_init_kernel) it made that
-// launch 15 us instead of 8.7; here its ~45 barrier-separated phases hide behind the slowest ILP of the scan.
-__global__ __launch_bounds__(BLP_THREADS) void blp_init_kernel(const BlpArgs a, const InitArgs in, const int32_t* sticky_overflow) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int gx = (int)gridDim.x - 1;
-    if ((int)blockIdx.x == gx) {
-        if ((a.status && a.status->overflow) || (sticky_overflow && *sticky_overflow)) return;      // void scan: nothing is initiated
-        initiator_body<false, BLP_THREADS>(in);
-        return;
-    }
-    blp_stamp_begin(a, blockIdx.x);
-    blp_body(a, lds, blockIdx.x, gx);
-    blp_stamp_end(a);
-}
-
 // can the ILP launch of a forest with this many target slots / measurement nodes derive its clusters itself (union-find prologue)?
 bool blp_uf_fits(int Tcap, int n_mnodes) {
     BlpArgs b = {};
@@ -2891,7 +2760,7 @@ bool blp_uf_fits(int Tcap, int n_mnodes) {
     return Tcap <= 8192 && (((lds > pro ? lds : pro) + 15) & ~(size_t)15) + BLP_UF_PERSIST <= 158 * 1024;
 }
 
-int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, const int32_t* sticky_overflow) {
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid) {
     BlpArgs b = a;
     const size_t lds = blp_set_tier(b, 0);
     if (lds > 158 * 1024) {
@@ -2900,7 +2769,6 @@ int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, c
     }
     if (ctx->lds_attr_blp < lds) {
         MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->lds_attr_blp = lds;
     }
     if (b.uf_epoch) {      // clusters from the grow launch's union-find
@@ -2908,8 +2776,8 @@ int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, c
         body = (body + 15) & ~(size_t)15;
         b.uf_lds_off = (unsigned)body;
         const size_t lds_uf = body + BLP_UF_PERSIST;
-        if (lds_uf > 158 * 1024 || init) {
-            set_error("blp: the union-find prologue of %d targets does not fit the launch's LDS (%zu bytes), or an initiator was handed in", b.uf_cap, lds_uf);
+        if (lds_uf > 158 * 1024) {
+            set_error("blp: the union-find prologue of %d targets does not fit the launch's LDS (%zu bytes)", b.uf_cap, lds_uf);
             return MHT_E_CAPACITY;
         }
         if (ctx->lds_attr_blp_uf < lds_uf) {
@@ -2920,62 +2788,7 @@ int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init, c
         MHT_HIP_CHECK(hipGetLastError());
         return MHT_OK;
     }
-    if (init) hipLaunchKernelGGL(blp_init_kernel, dim3(grid + 1), dim3(BLP_THREADS), lds, ctx->stream, b, *init, sticky_overflow);
-    else hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);
-    MHT_HIP_CHECK(hipGetLastError());
-    return MHT_OK;
-}
-
-// One launch for ILP launch k and grow launch k + 1 (blp_grow_kernel).  `a` as launch_blp takes it, `g` / `d` / `cm` as launch_fgrow does
-// (an overlapping launch with the commit riding along: d.fused, d.ovl); MHT_E_CAPACITY when the pair does not fit one launch (the caller
-// then launches the two as before).
-// LDS tier of the one-launch-per-scan kernel: TWO workgroups per CU (the second one of a CU plays grow roles from the start), so the solver's
-// tables get half a CU's LDS -- 960 columns / 512 measurement nodes / 128 targets per cluster out of LDS, larger clusters on HBM scratch
-// (the launch pair at 1 024 / 512 / 128: 50.05 us per scan against 49.59 at the default tier, profiles/r05_merge_ab.txt)
-static size_t scan_set_tier(BlpArgs& b) {
-    const size_t lds0 = blp_set_tier(b, 0);
-    if (b.cap_h > 960) { b.cap_h = 960; b.cap_r = 512; b.cap_k = 128; return blp_set_tier_bytes(b); }
-    return lds0;
-}
-bool blp_grow_fits(mht_ctx* ctx, const BlpArgs& a, int grid, int W, int pds, int AW) {
-    if (!SCAN_KERNEL_OK) return false;
-    BlpArgs b = a;
-    const size_t lds = scan_set_tier(b);
-    size_t body = lds > uf_prologue_bytes((size_t)b.uf_cap) ? lds : uf_prologue_bytes((size_t)b.uf_cap);
-    body = ((body + 15) & ~(size_t)15) + BLP_UF_PERSIST;
-    const size_t grow = (fgrow_lds_bytes_cap(W, pds, AW, FG_CAP_SOLO) + 15) & ~(size_t)15;
-    const size_t need = grow + scan_tail_bytes(AW);
-    return grid <= ctx->n_cu && (pds == 8 || pds == 16) && (body > need ? body : need) <= 79 * 1024;
-}
-int launch_blp_grow(mht_ctx* ctx, const BlpArgs& a, int grid, const FGrowArgs& g, FDyn& d, int n_targets_ub, const CommitArgs& cm, unsigned long long* tick, unsigned long long* tick_total) {
-    ScanArgs sa;
-    sa.b = a;
-    const size_t lds = scan_set_tier(sa.b);
-    size_t body = lds > uf_prologue_bytes((size_t)sa.b.uf_cap) ? lds : uf_prologue_bytes((size_t)sa.b.uf_cap);
-    body = (body + 15) & ~(size_t)15;
-    sa.b.uf_lds_off = (unsigned)body;
-    size_t lds_uf = body + BLP_UF_PERSIST;
-    fgrow_plan(d, n_targets_ub, g.Tcap, true, false);
-    const size_t grow = (fgrow_lds_bytes_cap(d.W, g.pds, g.AW, FG_CAP_SOLO) + 15) & ~(size_t)15;
-    const size_t need = grow + scan_tail_bytes(g.AW);
-    if (lds_uf < need) lds_uf = need;
-    MHT_REQUIRE(grid <= ctx->n_cu && lds_uf <= 79 * 1024 && sa.b.uf_epoch && sa.b.blp_done && d.fused && d.ovl, "launch_blp_grow: the pair does not fit one launch");
-    sa.gx_ilp = grid;
-    sa.b.wt_commit = 1;      // (no agent-scope release per workgroup in this kernel: see st_commit)
-    const int grid_all = 2 * ctx->n_cu;
-    sa.g = g; sa.cm = cm; sa.d = d; sa.tick = tick; sa.tick_base = *tick_total;
-    sa.n_roles = fgrow_grid_of(d);
-    *tick_total += (unsigned long long)sa.n_roles + (unsigned long long)(2 * ctx->n_cu);
-    sa.tail_off = (unsigned)grow;
-    static size_t attr[2] = {0, 0};
-    const int v = g.pds == 8 ? 0 : 1;
-    if (attr[v] < lds_uf) {
-        if (v == 0) MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_grow_kernel<2, FG_CAP_SOLO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_uf));
-        else MHT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blp_grow_kernel<4, FG_CAP_SOLO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_uf));
-        attr[v] = lds_uf;
-    }
-    if (v == 0) hipLaunchKernelGGL((blp_grow_kernel<2, FG_CAP_SOLO>), dim3(grid_all), dim3(BLP_THREADS), lds_uf, ctx->stream, sa);
-    else hipLaunchKernelGGL((blp_grow_kernel<4, FG_CAP_SOLO>), dim3(grid_all), dim3(BLP_THREADS), lds_uf, ctx->stream, sa);
+    hipLaunchKernelGGL(blp_kernel, dim3(grid), dim3(BLP_THREADS), lds, ctx->stream, b);
     MHT_HIP_CHECK(hipGetLastError());
     return MHT_OK;
 }

@@ -36,15 +36,10 @@ struct FCounts {          // device-side counters of the forest
     unsigned long long init_flag;
     // the staging kernel's tag (stage_scan_kernel): the scan in the device buffer is complete when it equals FDyn::z_tag
     unsigned long long z_flag;
-    unsigned long long role_tick, init_tick;      // tickets {scan, count}: FDyn::role_tick, initiator_side_kernel (first_come_ticket)
+    unsigned long long init_tick;      // ticket {scan, count} of initiator_side_kernel (first_come_ticket)
     // the scan whose ILP launch has begun, i.e. whose grow launch is complete (blp_uf_kernel, first workgroup): what the scan's initiator
     // waits for when it is launched on a queue of its own (initiator_side_kernel)
     unsigned long long ilp_begun;
-    // workgroups of blp_uf_kernel that have STARTED, over all launches (never reset: the host knows the total).  Two-queue mode
-    // (Forest::tq_on): the next scan's grow launch sits on another hardware queue behind a gate kernel that waits for this count -- its
-    // 43 KB workgroups must not take a CU before every 155 KB ILP workgroup of the scan before has one
-    unsigned long long ilp_started;
-    unsigned long long tq_flag;      // (MHT_TQ_FLAGS=1: the scan whose grow launch on the second queue is complete, posted by tq_post_kernel)
 };
 // Ticket among the few workgroups of a launch that may play a role: 0 for the first one to arrive in launch `tag`, 1, 2, ... for the
 // others.  The word carries the tag of the launch it was last used in, so nothing has to be reset (launches may skip the scheme).
@@ -63,38 +58,17 @@ __device__ __forceinline__ unsigned first_come_ticket(unsigned long long* word, 
 // Spin on a word another kernel / workgroup publishes (agent-scope loads, s_sleep between polls).  Bounded: a wait that does not end
 // within ~2 s gives up (returns false) instead of hanging the device; the caller voids the scan.
 constexpr unsigned long long SPIN_TICKS = 200000000ull;      // 10 ns ticks
-// gentle: hundreds of workgroups may wait for many microseconds (blp_grow_kernel: grow roles taken long before their target's record is out):
-// after a few quick polls the sleeps get long, so that the polls do not load the fabric the ILP workgroups work through
 template <typename PRED>
-__device__ __forceinline__ bool spin_until(const unsigned long long* p, PRED ok, unsigned long long& v, const int gentle = 0) {
+__device__ __forceinline__ bool spin_until(const unsigned long long* p, PRED ok, unsigned long long& v) {
     v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ok(v)) return true;
     const unsigned long long t0 = wall_clock64();
-    for (int n = 0;; ++n) {
-        if (gentle >= 2 && n >= 2) __builtin_amdgcn_s_sleep(40);       // ~1 us
-        else if (gentle && n >= 4) __builtin_amdgcn_s_sleep(12);       // ~0.3 us
-        else __builtin_amdgcn_s_sleep(2);
+    for (;;) {
+        __builtin_amdgcn_s_sleep(2);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ok(v)) return true;
         if (wall_clock64() - t0 > SPIN_TICKS) return false;
     }
-}
-
-// The same for a whole workgroup (every thread calls): ONE wavefront polls, the others wait at the barrier -- a word that hundreds of
-// workgroups wait for is a hot spot of the fabric when every wavefront of every one of them polls it (blp_grow_kernel, measured: the
-// polls of ~500 workgroups' 2 000 wavefronts on the commit's word made every load of the device several times slower).  `slot`: two
-// LDS words the caller does not use across the call.
-template <typename PRED>
-__device__ __forceinline__ bool spin_until_block(const unsigned long long* p, PRED ok, unsigned long long& v, const int gentle, unsigned long long* slot) {
-    if (threadIdx.x < 64) {
-        const bool r = spin_until(p, ok, v, gentle);
-        if (threadIdx.x == 0) { slot[0] = v; slot[1] = r ? 1ull : 0ull; }
-    }
-    __syncthreads();
-    v = slot[0];
-    const bool r = slot[1] != 0ull;
-    __syncthreads();
-    return r;
 }
 
 struct TTable {           // one buffer of the target table
@@ -110,7 +84,7 @@ struct ReportHeader {     // device image of mht_scan_report up to the host poin
     int32_t t_process, t_cluster, t_optim, t_scan;      // device time of the stages in 10 ns ticks (mht_scan_report)
 };
 
-struct CommitDyn { int scan, M, W; unsigned long long wait_done; int keep_used = 0; int gentle = 0; };      // keep_used: the used-measurement bytes are cleared by the caller (the scan's initiator may still be reading them)      // wait_done != 0: the scan's ILP launch may still be running -- wait until FCounts::blp_done has reached it      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
+struct CommitDyn { int scan, M, W; unsigned long long wait_done; int keep_used = 0; };      // keep_used: the used-measurement bytes are cleared by the caller (the scan's initiator may still be reading them)      // wait_done != 0: the scan's ILP launch may still be running -- wait until FCounts::blp_done has reached it      // what changes from scan to scan (everything in CommitArgs repeats with period 2 x ring length)
 
 struct CommitArgs {
     TTable cur, nxt;
@@ -149,8 +123,7 @@ __device__ __forceinline__ int commit_body(const CARGS& a, const CommitDyn dyn, 
         // this grow launch overlaps the scan's ILP launch: its workgroups count themselves off behind an agent-scope release of what they
         // wrote; every wavefront waits for the last of them, then drops what its CU may have cached
         unsigned long long v;
-        const bool ok = dyn.gentle ? spin_until_block(&a.cnt->blp_done, [&](unsigned long long x) { return x >= dyn.wait_done; }, v, 2, reinterpret_cast<unsigned long long*>(sm + 2 * (NT / 64) + 8))
-                                   : spin_until(&a.cnt->blp_done, [&](unsigned long long x) { return x >= dyn.wait_done; }, v);
+        const bool ok = spin_until(&a.cnt->blp_done, [&](unsigned long long x) { return x >= dyn.wait_done; }, v);
         if (!ok && tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 6); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_kernel(const FGrowArgs a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_grow = d.fused + d.n_main + d.n_chain;
     if ((int)blockIdx.x >= n_grow) { publish_part(pub, (int)blockIdx.x - n_grow); return; }      // (only launched when pub.dst is set)
-    fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem, fg_role_of_block(d, smem));
+    fgrow_body<PQ, CAP>((KArgs)__builtin_amdgcn_kernarg_segment_ptr(), cm, d, smem);
 }
 
 // The streaming drop-in path (mht_forest_scan with the device initiator): the previous scan's commit, the admission of what its
@@ -49,23 +49,11 @@ template <int PQ, int CAP = FG_CAP_SOLO>
 __global__ __launch_bounds__(FG_THREADS, 3) void fgrow_adm_kernel(const FGrowArgs a, const CommitArgs cm, const FDyn d, const PublishArgs pub, const AddArgs ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    const int bx = fg_role_of_block(d, smem), n_grow = 1 + d.n_main + d.n_chain;      // (d.fused = 1)
+    const int bx = (int)blockIdx.x, n_grow = 1 + d.n_main + d.n_chain;      // (d.fused = 1)
     if (bx == 0) {
         int* sm = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) { DevStatus* st = ap->status; st->t[0] = wall_clock64(); st->t[2] = 0; st->t[3] = 0; st->t[4] = 0; }
         if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
-        if (d.stage_src) {      // the scan, out of pinned host memory (FDyn::stage_src): written through, acknowledged, then the tag the target workgroups wait for
-            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(d.z));
-            for (int i = threadIdx.x; i < d.stage_n16; i += FG_THREADS) {
-                const float4 v = d.stage_src[i];
-                unsigned long long* q = reinterpret_cast<unsigned long long*>(dst + i);
-                __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned long long*>(d.z_flag), d.z_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         // (what the initiator confirmed is known since the previous launch: fetched in front of the commit, off the critical path)
         int n_cand = ad.n;
         if (ad.n_dev && !d.adm_wait) { const int nd = *ad.n_dev; n_cand = nd < n_cand ? nd : n_cand; }

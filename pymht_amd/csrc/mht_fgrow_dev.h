@@ -1,6 +1,5 @@
-// Device code of the grow stage (target_part / target_wave / chain_part / fgrow_body): everything the kernels of mht_fgrow.hip are made of,
-// in a header so that the one-launch-per-scan kernel of mht_blp.hip (blp_grow_kernel: the ILP workgroups of scan k take the grow roles of
-// scan k + 1 when their clusters are done) can instantiate the same bodies.  See mht_fgrow.hip for the design notes.
+// Device code of the grow stage (target_part / target_wave / chain_part / fgrow_body): everything the kernels of mht_fgrow.hip are made of.
+// See mht_fgrow.hip for the design notes.
 #pragma once
 #include "mht_kernels.h"
 #include "mht_commit.h"
@@ -48,7 +47,7 @@ typedef const __attribute__((address_space(4))) FGrowArgs* KArgs;      // the ke
 // what a workgroup needs to know about target slot t of the table this scan runs on; every index is clamped so that the
 // loads go out unconditionally (one round trip), dead or out-of-range slots are masked afterwards
 template <bool OVL = true, typename ARGS = void>
-__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT, int* rf_out = nullptr, const int void_scan = 0, const bool pre = false, const TPre pv = TPre{0ull, 0}, unsigned long long* slot = nullptr) {
+__device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t, int nT, int* rf_out = nullptr, const int void_scan = 0, const bool pre = false, const TPre pv = TPre{0ull, 0}) {
     TInfo r;
     const int tc = (t < a.Tcap) ? t : 0;
     if (OVL && d.fused && d.ovl) {
@@ -62,24 +61,10 @@ __device__ __forceinline__ TInfo target_info(const ARGS& a, const FDyn& d, int t
         if (ok) {
             if (pre) w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv.w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pv.w);
             else w = __hip_atomic_load(&a.rec0[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (slot && d.gentle && !void_scan) {
-                // blp_grow_kernel: the whole workgroup waits for ONE target.  Wavefront 0 alone looks (and polls, if the record is not there),
-                // the others take its word behind the barrier: the waves' own first looks may disagree, and hundreds of workgroups polling with
-                // every wavefront are a hot spot of the fabric (mht_commit.h: spin_until_block)
-                if (threadIdx.x < 64) {
-                    bool r = true;
-                    if ((unsigned)(w >> TGT_REC_TAG) != tag) r = spin_until(&a.rec0[tc], [&](unsigned long long x) { return (unsigned)(x >> TGT_REC_TAG) == tag; }, w, 1);
-                    if (threadIdx.x == 0) { slot[0] = w; slot[1] = r ? 1ull : 0ull; }
-                }
-                __syncthreads();
-                w = slot[0];
-                ok = slot[1] != 0ull;
-                __syncthreads();
-                if (!ok && (threadIdx.x & 63) == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 1); }
-            } else if ((unsigned)(w >> TGT_REC_TAG) != tag) {
+            if ((unsigned)(w >> TGT_REC_TAG) != tag) {
                 if (void_scan) ok = false;      // (a void scan publishes nothing: the caller leaves)
                 else {
-                    ok = spin_until(&a.rec0[tc], [&](unsigned long long x) { return (unsigned)(x >> TGT_REC_TAG) == tag; }, w, d.gentle);
+                    ok = spin_until(&a.rec0[tc], [&](unsigned long long x) { return (unsigned)(x >> TGT_REC_TAG) == tag; }, w);
                     if (!ok && (threadIdx.x & 63) == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 1); }      // (the wait timed out: the scan is void)
                 }
             }
@@ -463,27 +448,14 @@ __device__ __forceinline__ void fg_single_leaf(const ARGS& a, int src, bool f32s
 // ---- the end of a target workgroup of an OVERLAPPING launch, as a piece of its own ----------------------------------------------------
 // What a target still owes once its children are out is indexed by its COMPACTED index, which only the commit of the previous scan knows
 // (FCounts::ni_flag): tchild / tcend and -- when a target died in that scan -- its place in the union-find under the alternative epoch.
-// In the grow launch every target has a workgroup of its own, which simply waits for the word.  The workgroups of the one-launch-per-scan
-// kernel (mht_blp.hip: blp_grow_kernel) take one grow role after the other: they park what the end needs in LDS (TailList) and go on;
-// the parked ends run when the workgroup has no role left (the commit has long posted its word by then).
-constexpr int TAIL_MAX = 8;       // parked ends per workgroup (a ninth target waits for the word first)
-struct TailList {
-    int n;                       // parked ends (every thread keeps the same count)
-    int* rec;                    // LDS [TAIL_MAX][4]: target slot, first child, children
-    unsigned long long* tb;      // [TAIL_MAX][AW] copies of the targets' association bitsets (LDS)
-    int* conf;                   // LDS scratch of the redo's conflict list
-    int conf_cap;
-    int* nconf;                  // one LDS word
-    unsigned long long* slot;    // two LDS words (spin_until_block)
-};
-// one parked end (the whole workgroup calls; `tb` = the target's association bitset in LDS).  Returns false when the wait timed out.
+// Every target has a workgroup of its own, which simply waits for the word.
+// (the whole workgroup calls; `tb` = the target's association bitset in LDS).  Returns false when the wait timed out.
 template <typename ARGS>
-__device__ __forceinline__ bool target_tail(const ARGS& a, const FDyn& d, int t, int base, int fin_tot, const unsigned long long* tb, int* conf, int conf_cap, int* nconf, unsigned long long* slot = nullptr) {
+__device__ __forceinline__ bool target_tail(const ARGS& a, const FDyn& d, int t, int base, int fin_tot, const unsigned long long* tb, int* conf, int conf_cap, int* nconf) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tc = (t < a.Tcap) ? t : 0;
     unsigned long long v;
-    const bool ok = (slot && d.gentle) ? spin_until_block(a.ni_flag, [&](unsigned long long x) { return (unsigned)x == (unsigned)d.c_scan; }, v, 2, slot)
-                                       : spin_until(a.ni_flag, [&](unsigned long long x) { return (unsigned)x == (unsigned)d.c_scan; }, v);
+    const bool ok = spin_until(a.ni_flag, [&](unsigned long long x) { return (unsigned)x == (unsigned)d.c_scan; }, v);
     const bool moved = ok && ((v >> 32) & 1ull);      // some target died: slots and compacted indices differ
     const int pos = !ok ? -1 : (moved ? __hip_atomic_load(&a.new_index[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t);
     if (pos < 0) { if (tid == 0) { a.status->overflow = 2; atomicOr(&a.status->pad[0], 1 << 3); } return false; }      // (timed out; a live target always has an index)
@@ -497,19 +469,8 @@ __device__ __forceinline__ bool target_tail(const ARGS& a, const FDyn& d, int t,
     }
     return true;
 }
-// every parked end of the workgroup (blp_grow_kernel: behind its last role, or when the list is full)
-template <typename ARGS>
-__device__ __forceinline__ void tail_drain(const ARGS& a, const FDyn& d, TailList& tl) {
-    __syncthreads();
-    for (int i = 0; i < tl.n; ++i) {
-        if (!target_tail(a, d, tl.rec[i * 4], tl.rec[i * 4 + 1], tl.rec[i * 4 + 2], tl.tb + (size_t)i * a.AW, tl.conf, tl.conf_cap, tl.nconf, tl.slot)) break;
-        __syncthreads();      // (the conflict list is re-used)
-    }
-    tl.n = 0;
-}
-
 template <int PQ, int CAP, int AIS = 0, bool LEAN = false, int CT = 0>
-__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, unsigned char* smem, const int bslot, const int born = 0, TailList* park = nullptr) {
+__device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, unsigned char* smem, const int bslot, const int born = 0) {
     FDyn d = d0;
     if (LEAN) { d.uf_epoch = 0u; d.ovl = 0; d.stamp_end = 0; }
     constexpr int PDS = PQ * 4;
@@ -570,7 +531,7 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
             zx[j] = v.x;
             zy[j] = v.y;
         }
-    const TInfo ti = target_info<!LEAN>(a, d, t, nT, &rf_rec, po | so, ovl, tpre, reinterpret_cast<unsigned long long*>(s_misc + 20));
+    const TInfo ti = target_info<!LEAN>(a, d, t, nT, &rf_rec, po | so, ovl, tpre);
     const int tc = (t < a.Tcap) ? t : 0;
     // (overlapping launch: the root's score was written through in front of the target's record)
     const double rootc = born ? a.b_root_cnllr[tc]
@@ -1092,13 +1053,6 @@ __device__ __forceinline__ void target_part(KArgs ap0, const FDyn& d0, int t, un
         // place in the union-find, taken under the slot next to the emission, stands.  Otherwise: once more, under the compacted index and
         // the scan's alternative epoch, which the ILP launch then reads.)
         __syncthreads();      // (the candidate list's LDS is free: the union-find's list goes there)
-        if (park && park->n < TAIL_MAX) {      // (blp_grow_kernel: the workgroup has other roles to play; see target_tail)
-            const int i = park->n;
-            for (int w = tid; w < AW; w += FG_THREADS) park->tb[(size_t)i * AW + w] = tb[w];
-            if (tid == 0) { park->rec[i * 4] = t; park->rec[i * 4 + 1] = base; park->rec[i * 4 + 2] = fin_tot; }
-            park->n = i + 1;
-            return;
-        }
         target_tail(a, d, t, base, fin_tot, tb, reinterpret_cast<int*>(cand), Mpad / 2, &s_misc[17]);
     }
 }
@@ -1158,8 +1112,10 @@ __device__ __forceinline__ void target_wave(KArgs ap0, const FDyn& d, int t, uns
     const int M = d.M, W = d.W, Mpad = W * 64, AW = a.AW;
     const FWLayout lo = fw_layout(PDS, AW, Mpad);
     FLeaf* lg = reinterpret_cast<FLeaf*>(sm + lo.lf);
+#ifdef MHT_FW_PARK_RECORDS
     int* s_pp = reinterpret_cast<int*>(sm + lo.pp);
     int* s_ap = reinterpret_cast<int*>(sm + lo.ap);
+#endif
     unsigned long long* mk = reinterpret_cast<unsigned long long*>(sm + lo.mask);
     unsigned long long* tb = reinterpret_cast<unsigned long long*>(sm + lo.tb);
     unsigned short* cand = reinterpret_cast<unsigned short*>(sm + lo.cand);
@@ -1551,7 +1507,7 @@ __device__ __forceinline__ void publish_part(const PublishArgs& p, int w, int n_
 }
 
 template <int PQ, int CAP, typename CARGS, int AIS = 0, bool LEAN = false, int CT = 0>
-__device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem, const int bid0 = (int)blockIdx.x, TailList* park = nullptr) {
+__device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem, const int bid0 = (int)blockIdx.x) {
     int bid = bid0;
     // stage stamps of this scan (DevStatus::t): the grow stage starts here.  Taken by a workgroup that is not at the edge of its
     // register budget -- the commit workgroup (first of the launch) or, without one, the first chain workgroup (the whole launch is
@@ -1562,7 +1518,7 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         if (d.uf_epoch && ap->uf_team_state && threadIdx.x < TEAM_MAX) { ap->uf_team_state[threadIdx.x].gub = ~0ull; ap->uf_team_state[threadIdx.x].done = 0; }
     };
     if (d.fused) {           // deferred commit of the previous scan: workgroup 0 runs it
-        if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull, 0, d.gentle}, reinterpret_cast<int*>(smem)); return; }
+        if (bid == 0) { stamp(); commit_body<FG_THREADS>(cm, CommitDyn{d.c_scan, d.c_M, d.c_W, d.ovl ? d.c_wait : 0ull, 0}, reinterpret_cast<int*>(smem)); return; }
         bid -= 1;
     }
     if (bid >= d.n_main) { if (!d.fused && bid == d.n_main) stamp(); chain_part<!LEAN, AIS>(*ap, d, bid - d.n_main); return; }
@@ -1574,25 +1530,12 @@ __device__ __forceinline__ void fgrow_body(KArgs ap, const CARGS& cm, const FDyn
         target_wave<PQ>(ap, d, t, smem + (size_t)wave * fw_layout(PQ * 4, ap->AW, d.W * 64).total);
     } else {
         if (CT && !d.fused && bid == 0) stamp();      // (no commit and no chain workgroup in a constant-turn launch)
-        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS, LEAN, CT>(ap, d, bid, smem, bid, 0, park);
+        target_part<PQ, (CAP == 0 ? FG_CAP : CAP), AIS, LEAN, CT>(ap, d, bid, smem, bid, 0);
         if (d.stamp_end && threadIdx.x == 0) atomicMax(&ap->status->t[5], (unsigned long long)wall_clock64());
     }
 }
 
 template <int PQ, int CAP, typename CARGS>
 __device__ __forceinline__ void fgrow_body_lean(KArgs ap, const CARGS& cm, const FDyn& d, unsigned char* smem) { fgrow_body<PQ, CAP, CARGS, 0, true>(ap, cm, d, smem); }
-
-// (see FDyn::role_tick) the role -- the block index the rest of the kernel works with -- of one of the launch's first eight workgroups
-__device__ __forceinline__ int fg_role_of_block(const FDyn& d, unsigned char* smem) {
-    int bx = (int)blockIdx.x;
-    if (d.role_tick && bx < 8 && (int)gridDim.x >= 8) {
-        int* s = reinterpret_cast<int*>(smem);
-        if (threadIdx.x == 0) s[0] = (int)first_come_ticket(d.role_tick, (unsigned)d.c_scan + 1u);
-        __syncthreads();
-        bx = s[0];
-        __syncthreads();      // (the LDS is the role's from here on)
-    }
-    return bx;
-}
 
 }  // namespace mht

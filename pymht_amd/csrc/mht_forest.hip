@@ -308,7 +308,6 @@ struct Forest {
     unsigned long long* uf_owner = nullptr; unsigned long long* uf_parent2[2] = {nullptr, nullptr}; bool uf_ok = false; int uf_scans = 0;
     // overlap of a scan's ILP launch with the next scan's grow launch (mht_kernels.h: TGT_REC_*, FDyn::ovl): the per-target records, the
     // scan whose ILP launch published them, the total its workgroups will have counted off (FCounts::blp_done), launches made any-order
-    const float* z_stage_src = nullptr; int z_stage_n16 = 0, z_stage_slot = -1;      // the scan being stepped still sits in pinned host memory: the grow launch pulls it itself (FDyn::stage_src), or a staging kernel in front of it
     unsigned long long z_tag_step = 0;      // != 0: the scan being stepped was staged without an event wait on the ctx stream (FDyn::z_tag); z_wait_slot: its slot
     int z_wait_slot = -1;
     int init_flag_scan = 0;      // last scan whose initiator posts FCounts::init_flag
@@ -335,19 +334,11 @@ struct Forest {
     char* report_host2[2] = {nullptr, nullptr}; hipEvent_t rep_ev[2] = {nullptr, nullptr}; int rep_slot = 0; bool rep_inflight = false; bool rep_started[2] = {false, false};
     int host_block_scan[2] = {0, 0};      // scan whose report the host block holds (or is receiving: rep_ev of the block), 0 = none
     hipStream_t stage_stream = nullptr; bool stage_stream_tried = false;
-    // Two-queue mode (MHT_TWO_QUEUES=1; replay path; an EXPERIMENT that lost, kept behind its switch -- profiles/r05_two_queue_ab.txt): the
-    // overlapping grow launch of scan k + 1 goes onto a stream of its own -- another hardware queue shares the CUs with the ILP launch of
-    // scan k workgroup by workgroup, where the same queue hands over an XCD only when it has drained (profiles/r04_anyorder_ubench.txt) --
-    // behind a one-workgroup gate that waits until every ILP workgroup is resident (without it the 43 KB grow workgroups take CUs the
-    // 155 KB ILP workgroups still need, and wait for them: deadlock, seen); the ILP launch of scan k + 1 waits for it through an event
-    // (61 us per scan) or through a posted word and a gate kernel on the ctx stream (MHT_TQ_FLAGS=1: 51.4-52.4 us) against 49.3 us on one
-    // queue: what the CU-granular overlap buys, the extra launch boundaries take
-    bool tq_on = false; hipStream_t tq_stream = nullptr; hipEvent_t tq_ev = nullptr; unsigned long long ilp_started_total = 0; int tq_launches = 0;
     // the streamed scans' initiator launches go onto the SIDE stream, each one behind the staging kernel of the scan after its own (it is
     // queued by the next call, or by whoever needs its births first: launch_deferred_init): see forest_step_impl
     bool init_ev_lazy = false; bool init_deferred = false; bool init_side_q = true; bool serial_prof = false;      // serial_prof: no launch may wait for a launch on another queue (the staging goes by event too)
     InitArgs init_def_args; const DevStatus* init_def_status = nullptr; unsigned long long init_def_ztag = 0;
-    hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_in_blp = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
+    hipEvent_t grow_ev = nullptr, init_ev = nullptr; bool init_ev_pending = false; bool init_side = false;      // MHT_INIT_SIDE=1: the initiator as a launch of its own on the side stream (default: inside the cluster launch)
     float* z_dev; float* z_host; hipEvent_t z_ev[Z_RING] = {}; bool z_used[Z_RING] = {}; int z_slot = 0;
     hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0; int z_guard_due = -1;      // consumer guard of the staging ring (step_host_impl)
     // small staging for add_targets / leaves / chain
@@ -360,12 +351,8 @@ struct Forest {
     // the target-side commit of the last launched scan has not run yet: it rides in the next grow_kernel, or is launched
     // on its own by whoever needs the committed state first (report, births, exports)
     bool commit_pending = false; CommitArgs pending = {}; CommitDyn pending_dyn = {};
-    // one launch per scan (mht_blp.hip: blp_grow_kernel): the ILP launch of the last scan has NOT been queued -- it rides in front of the next
-    // scan's grow roles (forest_step_impl), or is launched alone by whoever needs its results first (flush_ilp, at the head of flush_commit).
-    // MHT_MERGE=1 at creation turns it on: measured slower than the launch pair, so the pair stays the default
     bool ct_spill = false;         // testing: MHT_CT_SPILL=1 at creation -- fgrow_ct_kernel keeps every target's hit masks in the global spill block
     bool grid_by_hint = true;      // MHT_BLP_GRID_HINT=0 at creation: the ILP launch sized by the target count alone, as until round 5
-    bool merge_on = false; bool ilp_pending = false; BlpArgs pending_blp = {}; int pending_blp_grid = 0; int merged_launches = 0; unsigned long long role_tick_total = 0;
     // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
     // workgroup 0 of the next scan's grow launch (fgrow_adm_kernel), or run as post_scan_kernel when somebody needs the state first
     bool adm_pending = false; AddArgs adm = {}; bool adm_fuse = true;      // MHT_ADM_FUSE=0: admission in a launch of its own behind every scan
@@ -487,7 +474,6 @@ void forest_destroy(mht_ctx* ctx) {
     if (!f) return;
     ::hp_print();
     if (f->stage_stream) (void)hipStreamSynchronize(f->stage_stream);
-    if (f->tq_stream) (void)hipStreamSynchronize(f->tq_stream);
     if (f->arena.base) (void)hipFree(f->arena.base);
     for (int b = 0; b < 2; ++b) {
         if (f->report_host2[b]) (void)hipHostFree(f->report_host2[b]);
@@ -501,8 +487,6 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->stage_host) (void)hipHostFree(f->stage_host);
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
-    if (f->tq_stream) (void)hipStreamDestroy(f->tq_stream);
-    if (f->tq_ev) (void)hipEventDestroy(f->tq_ev);
     if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
     if (f->init_ev) (void)hipEventDestroy(f->init_ev);
     if (f->evp) {
@@ -562,18 +546,7 @@ static PublishArgs publish_args(Forest* f) {      // the report of scan f->scan 
     p.src = f->report_dev2[f->scan & 1]; p.dst = f->report_host_dev[f->scan & 1]; p.rec_off = (int)f->rec_off; p.birth_off = (int)f->birth_off;
     return p;
 }
-// the ILP launch a step left for the next step's launch (Forest::ilp_pending), now and alone
-static int flush_ilp(mht_ctx* ctx, Forest* f) {
-    if (!f->ilp_pending) return MHT_OK;
-    f->ilp_pending = false;
-    MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    const int rc = launch_blp(ctx, f->pending_blp, f->pending_blp_grid, nullptr, &f->cnt->overflow);
-    if (rc) f->dead = true;
-    return rc;
-}
-int forest_flush_ilp(mht_ctx* ctx) { return (ctx && ctx->forest) ? flush_ilp(ctx, ctx->forest) : MHT_OK; }
 static int flush_commit(mht_ctx* ctx, Forest* f, bool publish = false) {
-    { const int rc = flush_ilp(ctx, f); if (rc) return rc; }      // (the commit reads what that launch writes)
     if (!f->commit_pending) return MHT_OK;
     if (f->adm_pending) {      // commit + admission of the initiator's births, as one launch (what mht_forest_scan deferred)
         { const int rc = wait_init_ev(ctx, f); if (rc) return rc; }      // (the initiator ran on the side stream)
@@ -676,12 +649,10 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->debug = getenv("MHT_GROW_DEBUG") != nullptr;
     { const char* e = getenv("MHT_CT_SPILL"); f->ct_spill = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_GRID_HINT"); f->grid_by_hint = !(e && e[0] == '0'); }
-    { const char* e = getenv("MHT_MERGE"); f->merge_on = e && e[0] == '1'; }      // (one launch per scan, blp_grow_kernel: built, correct, SLOWER than the launch pair -- DESIGN section 4; off unless asked for)
     { const char* e = getenv("MHT_BLP_FORCE_HBM"); f->force_hbm = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_ENUM"); f->no_enum = e && e[0] == '1'; }
     { const char* e = getenv("MHT_BLP_NO_TEAMS"); f->teams = !(e && e[0] == '1'); }
     { const char* e = getenv("MHT_ADM_FUSE"); f->adm_fuse = !(e && e[0] == '0'); }
-    { const char* e = getenv("MHT_INIT_IN_BLP"); f->init_in_blp = (e && e[0] == '1'); }      // (measured on the headline stream: at 256 threads the initiator needs 39 us, the ILPs 25 -- 84 us per streamed scan against 74; worth it where the ILP stage is long)
     { const char* e = getenv("MHT_INIT_SIDE"); f->init_side = (e && e[0] == '1'); }      // (measured: the two event operations per scan cost the host more than the 6 us save the device -- 91 against 76 us per streamed scan)
     MHT_HIP_CHECK(hipEventCreateWithFlags(&f->grow_ev, hipEventDisableTiming));
     MHT_HIP_CHECK(hipEventCreateWithFlags(&f->init_ev, hipEventDisableTiming));
@@ -689,7 +660,6 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     f->cluster_big = !cluster_fits_lds(f->Tcap, f->n_mnodes);
     { const char* e = getenv("MHT_NO_UF"); f->uf_ok = !(e && e[0] == '1') && blp_uf_fits(f->Tcap, f->n_mnodes); }
     { const char* e = getenv("MHT_NO_OVERLAP"); f->ovl_ok = !(e && e[0] == '1'); }
-    { const char* e = getenv("MHT_TWO_QUEUES"); f->tq_on = (e && e[0] == '1'); }
     { const char* e = getenv("MHT_INIT_QUEUE"); f->init_side_q = !(e && e[0] == '0'); }
     { const char* e = getenv("MHT_REPORT_FLAG"); f->rep_flag_ok = !(e && e[0] == '0'); }
     // (rocprofv3 --pmc runs ONE kernel at a time across all queues, in the order the queues happen to be served: a launch that waits for a
@@ -859,18 +829,10 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     MHT_REQUIRE(n >= 0 && (n == 0 || (x0 && P0 && flags && pd && meas)), "mht_forest_add_targets_dev: null input");
     if (n == 0) return MHT_OK;
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    // Candidates in device memory whose fate the caller does not ask for, behind a scan whose commit still waits for its ride in the next
-    // grow launch: the admission CAN ride along (fgrow_adm_kernel: workgroup 0 commits, then admits; the newborn targets are grown by extra
-    // workgroups of that launch) -- what the streamed path does with the initiator's births.  Measured on the headline replay and left
-    // off (MHT_ADD_RIDE=1): two launches less, but 256 threads instead of 1 024 for the neighbour sweep and the newborn targets' grow
-    // behind it inside the launch -- scans with a birth got longer (fgrow_adm_kernel p95 99 us), 19.1 k -> 18.5 k scans/s over 20 scans.
-    static int add_ride = -1; if (add_ride < 0) { const char* e = getenv("MHT_ADD_RIDE"); add_ride = (e && e[0] == '1') ? 1 : 0; }
-    const bool ride = add_ride && !ids && !accepted && n <= 256 && f->commit_pending && !f->adm_pending && f->adm_fuse && !f->ais && !f->timing && !f->pub_deferred &&
-                      f->uf_ok && !(f->prune_thr > 0.f);
-    // (not riding, but the scan's commit is still pending and the batch fits one launch: commit and admission as ONE launch -- post_scan_kernel,
+    // (the scan's commit is still pending and the batch fits one launch: commit and admission as ONE launch -- post_scan_kernel,
     // what flush_commit runs for a pending admission -- instead of a commit launch and an admission launch)
-    const bool fuse = !ride && n <= 2048 && f->commit_pending && !f->adm_pending && !f->ais && !f->pub_deferred;
-    if (!ride && !fuse) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    const bool fuse = n <= 2048 && f->commit_pending && !f->adm_pending && !f->ais && !f->pub_deferred;
+    if (!fuse) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
     AddArgs a = {};
     a.n = n; a.x0 = x0; a.pd = pd; a.P0 = P0; a.meas = meas; a.flags = flags; a.ids = ids; a.accepted = accepted;
     a.check = check_neighbours; a.thr = f->cfg.merge_threshold;
@@ -883,8 +845,7 @@ extern "C" int mht_forest_add_targets_dev(mht_ctx* ctx, int32_t n, const double*
     fill_model_only(a.model, &f->model); a.vt = f->vt; a.root_base = f->root_base; a.ct_Proot = f->ct ? f->ct_Proot[f->scan % f->R] : nullptr;
     if (f->ais) { a.mmsi = f->l_mmsi[f->scan % f->R]; a.hmmsi = f->l_hmmsi[f->scan % f->R]; }
     MHT_REQUIRE(n <= f->Tcap, "mht_forest_add_targets: %d candidates exceed max_targets", n);
-    if (ride) { f->adm = a; f->adm_pending = true; }
-    else if (fuse) { f->adm = a; f->adm_pending = true; const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    if (fuse) { f->adm = a; f->adm_pending = true; const int rc = flush_commit(ctx, f); if (rc) return rc; }
     else
     // the kernel keeps the candidates admitted so far in LDS (2048 entries): larger batches go in chunks, candidates of
     // earlier chunks are leaves of the forest by then and are tested as such
@@ -1112,16 +1073,6 @@ __global__ __launch_bounds__(256) void vt_rebuild_kernel(const RebuildArgs a) {
     }
 }
 
-// two-queue mode: the gate in front of a grow launch on the forest's second queue (Forest::tq_on)
-__global__ __launch_bounds__(64) void tq_gate_kernel(const unsigned long long* started, unsigned long long want, int32_t* sticky_overflow) {
-    unsigned long long v;
-    if (!spin_until(started, [&](unsigned long long x) { return x >= want; }, v) && threadIdx.x == 0) *sticky_overflow = 2;
-}
-// (experiment MHT_TQ_FLAGS=1: instead of an event from the second queue, a one-thread kernel behind the grow launch posts a word and a gate in
-// front of the ILP launch on the ctx stream waits for it: two in-queue boundaries instead of a cross-queue barrier packet)
-__global__ void tq_post_kernel(unsigned long long* word, unsigned long long v) {
-    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 struct StepPlan { int s; bool fused; int n_ub; int W; bool rebuilt; };
 // Switches the forest to the other generation of its value table in front of scan s (the newest layer is s - 1).
 static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
@@ -1142,7 +1093,7 @@ static int vt_switch_generation(mht_ctx* ctx, Forest* f, int s) {
     f->rebuilds += 1;
     return MHT_OK;
 }
-static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl, bool carries_admission = false, bool keeps_ilp = false) {
+static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, const char* who, StepPlan& pl, bool carries_admission = false) {
     MHT_REQUIRE(M >= 0 && M <= f->cfg.max_meas, "%s: M=%d exceeds max_meas=%d", who, M, f->cfg.max_meas);
     MHT_REQUIRE(z || M == 0, "%s: z is null", who);
     if (f->dead) {
@@ -1151,7 +1102,6 @@ static int forest_begin_step(mht_ctx* ctx, Forest* f, const float* z, int M, con
     }
     if (f->timing) MHT_REQUIRE(f->timed_steps < EV_POOL, "%s: %d timed steps pending, read them with mht_forest_stage_times", who, EV_POOL);
     if (f->adm_pending && !carries_admission) { const int rc = flush_commit(ctx, f); if (rc) return rc; }      // (only the one-sector grow launch takes the admission along)
-    if (!keeps_ilp) { const int rc = flush_ilp(ctx, f); if (rc) return rc; }      // (only forest_step_impl lets a pending ILP launch ride in its own launch)
     const int s = ++f->scan;
     pl.rebuilt = false;
     if (f->hint_host) {      // value table three quarters full (as of the last commit the host has seen) and the other generation free again?
@@ -1211,7 +1161,7 @@ void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned cha
 
 // will a step with this initiator take the union-find path with the initiator as a launch of its own (forest_step_impl: use_uf)?
 static bool forest_streams_uf(const Forest* f, const mht_initiator* init) {
-    return f->uf_ok && !(f->prune_thr > 0.f) && (!init || (f->adm_fuse && !f->ais && !f->timing && !f->init_in_blp && !f->init_side));
+    return f->uf_ok && !(f->prune_thr > 0.f) && (!init || (f->adm_fuse && !f->ais && !f->timing && !f->init_side));
 }
 // a reader of the staged scan other than the grow launch / the initiator's launch is about to be queued on the ctx stream: the event wait
 // the step skipped (step_host_impl)
@@ -1292,7 +1242,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         if (rc) return rc;
     }
     StepPlan pl;
-    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais, true); if (rc) { f->ais_armed = false; return rc; } }
+    { const int rc = forest_begin_step(ctx, f, z, M, "mht_forest_step", pl, !ais); if (rc) { f->ais_armed = false; return rc; } }
     if (ais) pl.W = (M + f->ais_nA + 63) / 64;      // (the messages are measurement nodes M .. M + nA - 1 of this scan)
     hipStream_t st = ctx->stream;
     hipEvent_t* ev = nullptr;
@@ -1340,15 +1290,6 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         d.adm_wait = adm_ovl ? 1 : 0;
         const bool any_order = d.ovl && f->ovl_ok && (!adm || adm_ovl) && (!f->pub_deferred || adm_ovl) && !ais && !f->timing && (!f->debug || ovl_force);
         if (any_order) f->ovl_launches += 1;
-        if (f->z_stage_src) {
-            if (adm) { d.stage_src = reinterpret_cast<const float4*>(f->z_stage_src); d.stage_n16 = f->z_stage_n16; }
-            else {      // (no commit + admission workgroup in this launch -- first scan, or the commit was flushed: a staging kernel in front of it)
-                hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float4*>(f->z_stage_src), reinterpret_cast<float4*>(const_cast<float*>(z)),
-                                   f->z_stage_n16, static_cast<unsigned long long*>(nullptr), 0ull);
-                MHT_STEP_HIP(hipGetLastError());
-                d.z_tag = 0; f->z_tag_step = 0;
-            }
-        }
         hp_mark(3);
         MHT_STEP_CHECK(launch_deferred_init(ctx, f));      // (the previous scan's initiator: behind this scan's staging kernel, in front of this launch)
         if (adm && f->init_ev_pending) {
@@ -1360,43 +1301,9 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             f->pub_args.done = reinterpret_cast<unsigned long long*>(f->report_host_dev[f->pub_slot] + f->done_off);
             f->pub_args.tag = (unsigned long long)(pl.s - 1) | (1ull << 40);
         } else { f->pub_args.done = nullptr; f->pub_args.tag = 0; }
-        const bool tq = any_order && f->tq_on && !adm && !f->pub_deferred && !init && f->ilp_started_total > 0;
-        if (tq) {
-            MHT_STEP_CHECK(flush_ilp(ctx, f));
-            if (!f->tq_stream) {
-                MHT_STEP_HIP(hipStreamCreateWithFlags(&f->tq_stream, hipStreamNonBlocking));
-                MHT_STEP_HIP(hipEventCreateWithFlags(&f->tq_ev, hipEventDisableTiming));
-            }
-            static int flags = -1; if (flags < 0) { const char* e = getenv("MHT_TQ_FLAGS"); flags = (e && e[0] == '1') ? 1 : 0; }
-            hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, f->tq_stream, static_cast<const unsigned long long*>(&f->cnt->ilp_started), f->ilp_started_total, &f->cnt->overflow);
-            MHT_STEP_HIP(hipGetLastError());
-            hipStream_t keep = ctx->stream;
-            ctx->stream = f->tq_stream;
-            const int rc_grow = launch_fgrow(ctx, g, d, pl.n_ub, &f->pending, nullptr, nullptr, false);
-            ctx->stream = keep;
-            MHT_STEP_CHECK(rc_grow);
-            if (flags) {
-                hipLaunchKernelGGL(tq_post_kernel, dim3(1), dim3(64), 0, f->tq_stream, &f->cnt->tq_flag, (unsigned long long)pl.s);
-                hipLaunchKernelGGL(tq_gate_kernel, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(&f->cnt->tq_flag), (unsigned long long)pl.s, &f->cnt->overflow);
-                MHT_STEP_HIP(hipGetLastError());
-            } else {
-            MHT_STEP_HIP(hipEventRecord(f->tq_ev, f->tq_stream));
-            MHT_STEP_HIP(hipStreamWaitEvent(st, f->tq_ev, 0));      // (this scan's ILP launch, next on the ctx stream, needs the whole grow launch)
-            }
-            f->tq_launches += 1;
-        } else if (f->ilp_pending && d.ovl && pl.fused && !adm && !f->pub_deferred && !ais && !f->ct && !f->timing && !init && !f->z_stage_src && !d.z_tag &&
-                   g.ais.half == 0 && blp_grow_fits(ctx, f->pending_blp, f->pending_blp_grid, d.W, g.pds, g.AW)) {
-            // the previous scan's ILP launch has not been queued: ONE launch, its workgroups take this scan's grow roles when their clusters are done
-            f->ilp_pending = false;
-            MHT_STEP_CHECK(launch_blp_grow(ctx, f->pending_blp, f->pending_blp_grid, g, d, pl.n_ub, f->pending, &f->cnt->role_tick, &f->role_tick_total));
-            f->merged_launches += 1;
-        } else {
-        MHT_STEP_CHECK(flush_ilp(ctx, f));
         MHT_STEP_CHECK(launch_fgrow(ctx, g, d, pl.n_ub, pl.fused ? &f->pending : nullptr, f->pub_deferred ? &f->pub_args : nullptr, adm ? &f->adm : nullptr, any_order));
-        }
         hp_mark(4);
         f->adm_pending = false;
-        if (f->z_stage_slot >= 0) MHT_STEP_HIP(hipEventRecord(f->z_ev[f->z_stage_slot], st));      // (the host may refill the pinned slot once this launch has run)
         if (f->z_guard_due >= 0) { MHT_STEP_HIP(hipEventRecord(f->z_guard_ev[f->z_guard_due], st)); f->z_guard_due = -1; }      // (step_host_impl: consumer guard of the staging ring)
         if (f->pub_deferred) {      // the previous scan's report went along: the host waits for this launch
             if (pub_flag) { f->rep_by_flag[f->pub_slot] = true; f->rep_tag[f->pub_slot] = f->pub_args.tag; }
@@ -1410,7 +1317,6 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
     hp_mark(5);
     if (f->timing) MHT_STEP_HIP(hipEventRecord(ev[1], st));
     // ---- 2: cluster (tracker.py:218-221) ---------------------------------------------------------------------------
-    InitArgs init_blp = {}; bool have_init_blp = false;
     if (use_uf) f->uf_scans += 1;
     else {
         ClusterArgs c;
@@ -1420,10 +1326,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
-            if (f->init_in_blp && f->adm_fuse && !f->ais) {      // the initiator rides in the ILP launch (blp_init_kernel): hidden behind the slowest ILP
-                init_blp = ia; have_init_blp = true;
-                MHT_STEP_CHECK(launch_cluster(ctx, c));
-            } else if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
+            if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
                 MHT_STEP_HIP(hipEventRecord(f->grow_ev, st));                       // behind the grow launch
                 MHT_STEP_HIP(hipStreamWaitEvent(f->stage_stream, f->grow_ev, 0));
                 hipLaunchKernelGGL(initiator_side_kernel, dim3(1), dim3(INIT_THREADS), 0, f->stage_stream, ia, static_cast<const DevStatus*>(c.status), static_cast<const int32_t*>(&f->cnt->overflow));
@@ -1475,26 +1378,12 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
                 if (gh < grid) grid = gh;
             }
         }
-        { static int gcap = -1; if (gcap < 0) { const char* e = getenv("MHT_BLP_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && use_uf && grid > gcap) grid = gcap; }      // (development)
-        if (use_uf && f->tq_on && !init) {      // (two-queue mode: every ILP workgroup resident at once -- one per CU -- and counted in)
-            if (grid > ctx->n_cu) grid = ctx->n_cu;
-            b.started = &f->cnt->ilp_started;
-            f->ilp_started_total += (unsigned long long)grid;
-        }
         if (use_uf) {
             b.rec0 = f->rec0; b.blp_done = &f->cnt->blp_done; b.pub_scan = (unsigned)pl.s; b.begun = &f->cnt->ilp_begun;
             b.pub_ub = f->nT_ub_step < 1 ? 1 : (f->nT_ub_step < f->Tcap ? f->nT_ub_step : f->Tcap);      // (the next grow launch has one target workgroup at least)
         }
         hp_mark(6);
-        // one launch per scan: this ILP launch waits for the next step, whose grow roles its workgroups will take (blp_grow_kernel) -- when the
-        // next call is not a plain step, or somebody asks for results first, flush_ilp launches it alone
-        const bool defer_ilp = use_uf && f->merge_on && !init && !have_init_blp && !ais && !f->ct && !f->timing && (!f->debug || getenv("MHT_OVL_FORCE")) && !f->tq_on && !(f->prune_thr > 0.f) && !f->in_groups &&
-                               !f->adm_pending && !f->pub_deferred && f->ovl_ok && f->ais == false;
-        if (defer_ilp) {
-            if (grid > ctx->n_cu) grid = ctx->n_cu;      // (every workgroup resident: a grow role may wait for a record of any of them)
-            f->pending_blp = b; f->pending_blp_grid = grid; f->ilp_pending = true;
-        } else
-        MHT_STEP_CHECK(launch_blp(ctx, b, grid, have_init_blp ? &init_blp : nullptr, &f->cnt->overflow));
+        MHT_STEP_CHECK(launch_blp(ctx, b, grid));
         hp_mark(7);
         if (use_uf) { f->pub_scan = pl.s; f->blp_done_total += (unsigned long long)grid; }
         if (use_uf && init) {
@@ -1505,7 +1394,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];
             ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
-            if (f->init_side_q && f->stage_stream && f->z_tag_step && !f->z_stage_src) {      // (launch_deferred_init)
+            if (f->init_side_q && f->stage_stream && f->z_tag_step) {      // (launch_deferred_init)
                 f->init_deferred = true; f->init_def_args = ia; f->init_def_status = f->status2 + (pl.s & 1); f->init_def_ztag = f->z_tag_step;
                 f->init_ev_pending = true; f->init_ev_lazy = true;      // (whoever needs the births without the flag: init_ev, recorded then)
             } else
@@ -1837,7 +1726,6 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     MHT_REQUIRE(ictx == ctx, "mht_forest_initiate: the initiator belongs to another context");
     MHT_REQUIRE(cap <= BIRTH_CAP, "mht_forest_initiate: the initiator's max_born=%d exceeds the report's %d", cap, BIRTH_CAP);
     MHT_HIP_CHECK(hipSetDevice(ctx->device));
-    { const int rc = flush_ilp(ctx, f); if (rc) return rc; }
     InitArgs ia = {};
     char* report_dev = f->report_dev2[f->scan & 1];
     const bool init_done = f->init_ran_scan == f->scan;      // (mht_forest_scan: it ran inside this scan's cluster launch)
@@ -1946,16 +1834,6 @@ static int step_host_impl(mht_ctx* ctx, const float* z_host, int32_t M, bool mar
         // readers -- the grow launch's target workgroups, the initiator's launch -- wait for the tag (it is there long before: the host
         // runs ahead).  Any other reader of this scan on the ctx stream gets the event wait first (z_wait_slot, flush_z_wait).
         f->z_tag_step = by_flag ? (unsigned long long)f->z_count : 0ull;
-        static int in_launch = -1; if (in_launch < 0) { const char* e = getenv("MHT_STAGE_IN_LAUNCH"); in_launch = (e && e[0] == '1') ? 1 : 0; }
-        if (by_flag && in_launch) {      // (development) pulled by the grow launch itself (forest_step_impl, FDyn::stage_src: ~5 us in front of every grow launch); z_ev[slot] is recorded behind that launch
-            f->z_stage_src = f->z_host_dev + (size_t)slot * 2 * f->Mpad; f->z_stage_n16 = n16; f->z_stage_slot = slot;
-            f->z_wait_slot = -1;
-            f->z_used[slot] = true;
-            f->z_cur = zd;
-            const int rc = forest_step_impl(ctx, zd, M, init, now);
-            f->z_tag_step = 0; f->z_stage_src = nullptr; f->z_stage_slot = -1;
-            return rc;
-        }
         hipLaunchKernelGGL(stage_scan_kernel, dim3(1), dim3(256), 0, sst, reinterpret_cast<const float4*>(f->z_host_dev + (size_t)slot * 2 * f->Mpad),
                            reinterpret_cast<float4*>(zd), n16, by_flag ? &f->cnt->z_flag : nullptr, f->z_tag_step);
         MHT_HIP_CHECK(hipGetLastError());
@@ -2331,19 +2209,9 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
         *static_cast<int32_t*>(host) = f->rebuilds;
         return MHT_OK;
     }
-    if (!strcmp(name, "tq_launches")) {      // (host-side counter: grow launches that went onto the second queue)
-        MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'tq_launches' is one int32");
-        *static_cast<int32_t*>(host) = f->tq_launches;
-        return MHT_OK;
-    }
     if (!strcmp(name, "uf_ovl")) {      // (host-side counters: scans clustered by the union-find, grow launches made any-order)
         MHT_REQUIRE(bytes == 8, "mht_forest_debug_read: 'uf_ovl' is two int32");
         static_cast<int32_t*>(host)[0] = f->uf_scans; static_cast<int32_t*>(host)[1] = f->ovl_launches;
-        return MHT_OK;
-    }
-    if (!strcmp(name, "merged_launches")) {      // (host-side counter: scans whose ILP launch and the next scan's grow launch went out as ONE launch)
-        MHT_REQUIRE(bytes == 4, "mht_forest_debug_read: 'merged_launches' is one int32");
-        *static_cast<int32_t*>(host) = f->merged_launches;
         return MHT_OK;
     }
     if (!strcmp(name, "status2")) { src = f->status2; avail = 2 * sizeof(DevStatus); }

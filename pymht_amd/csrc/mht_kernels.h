@@ -157,19 +157,9 @@ struct FDyn {
     // the scan was staged by a small kernel on the forest's side stream and the ctx stream did NOT wait for it (streamed path): whoever
     // reads the scan first waits until z_flag[0] == z_tag (stage_scan_kernel posts it behind its written-through stores); 0: nothing to wait for
     const unsigned long long* z_flag; unsigned long long z_tag;
-    // ... or by this launch itself (fgrow_adm_kernel, streamed path): its first workgroup pulls the scan out of pinned host memory before it
-    // waits for the previous scan's ILP launch, and posts the tag -- no launch on another queue stands between the host and the target
-    // workgroups that wait for the scan (a staging kernel queued behind the initiator's launch on a shared hardware queue would wait for
-    // that launch, which waits for a CU, which the waiting target workgroups hold).  null: staged elsewhere
-    const float4* stage_src; int stage_n16;
-    // overlapping launch: which of its first eight workgroups (one per XCD) plays workgroup 0 -- the commit -- is decided by a ticket: the
-    // first one to START (the XCD the previous scan's ILP launch drained first; the dispatcher's XCD rotation is not ours to know;
-    // mht_commit.h: first_come_ticket).  null: block 0 as ever
-    unsigned long long* role_tick;
     int adm_wait;                  // fgrow_adm_kernel launched any-order: the admission waits for the previous scan's initiator (FCounts::init_flag), the
                                    // report's workgroups for the previous scan's ILP launch (c_wait)
     int stamp_end;                 // development (MHT_OVL_STAMPS=1): the target workgroups leave their end time in DevStatus::t[5] (atomic max)
-    int gentle;                    // blp_grow_kernel: waits may be long and many at once -- poll sparingly (mht_commit.h: spin_until)
     int ct_spill;                  // testing (MHT_CT_SPILL=1): fgrow_ct_kernel keeps every target's hit masks in the global spill block
     unsigned long long c_wait;     // FCounts::blp_done the commit waits for (0: the ILP launch has ended, as stream order says)
     unsigned uf_epoch;             // != 0 (2 x the scan number): no edge list -- the target workgroups hook their targets into a device-wide
@@ -311,11 +301,9 @@ struct BlpArgs {
     // counter the workgroups count themselves off on when they leave; the scan's tag
     unsigned long long* rec0; int pub_ub; unsigned long long* blp_done; unsigned pub_scan;
     unsigned long long* begun;             // != null: the launch's first workgroup posts pub_scan here at entry (FCounts::ilp_begun)
-    unsigned long long* started;           // != null: every workgroup counts itself in at entry (FCounts::ilp_started; two-queue mode)
     unsigned long long* dbg;       // development only (MHT_BLP_STAMPS=1 with MHT_GROW_DEBUG): [32 + workgroup * 16 + k] wall-clock ticks of blp_uf_kernel's phases
     const unsigned long long* ni_flag; int uf_ovl;      // uf_ovl: the scan's grow launch overlapped the previous ILP launch -- if ni_flag says that a
                                                         // target died in the previous scan, the union-find was redone under epoch | 1
-    int wt_commit;                 // blp_grow_kernel: what the commit reads of this launch is written through (mht_blp.hip: st_commit)
     unsigned uf_lds_off;           // offset of the workgroup's UfPersist block in the dynamic LDS (behind the solver's tables; set by launch_blp)
 };
 
@@ -373,11 +361,8 @@ size_t cluster_lds_bytes(int Tcap, int n_mnodes);
 int cluster_elds(int Tcap, int n_mnodes);
 bool cluster_fits_lds(int Tcap, int n_mnodes);
 size_t cluster_big_ints(int Tcap, int n_mnodes);
-int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid, const InitArgs* init = nullptr, const int32_t* sticky_overflow = nullptr);      // init: the initiator rides as one more workgroup
+int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
 bool blp_uf_fits(int Tcap, int n_mnodes);
-// ILP launch k and grow launch k + 1 as ONE launch (mht_blp.hip: blp_grow_kernel)
-bool blp_grow_fits(mht_ctx* ctx, const BlpArgs& a, int grid, int W, int pds, int AW);
-int launch_blp_grow(mht_ctx* ctx, const BlpArgs& a, int grid, const FGrowArgs& g, FDyn& d, int n_targets_ub, const CommitArgs& cm, unsigned long long* tick, unsigned long long* tick_total);
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
 void forest_destroy(mht_ctx* ctx);
 

@@ -18,11 +18,7 @@ BUDGET = {
     "mht_gate.hip": {"grow_kernel": (0, 128)},
     # blp_uf_kernel = the ILP launch of the replay / streamed path since round 4 (cluster tables derived in its prologue): one 155 KB workgroup per
     # CU, so all 256 registers are its to use -- what must not come back is scratch (spilled arguments in front of every workgroup)
-    # blp_grow_kernel (MHT_MERGE=1: ILP launch k and grow launch k + 1 as one launch, two workgroups per CU): both bodies inlined
-    # (r5, ILP tail) the sweeps of a giant cluster on HBM scratch keep SWEEP_U = 2 columns per lane in flight, two members deep: the one-per-CU
-    # kernels take the registers from the 512 a SIMD has for its single wavefront (256 + accumulation registers, no scratch); blp_grow_kernel
-    # is capped at 256 by its two workgroups per CU and spills that path -- giant clusters only, in an experiment that is off by default
-    "mht_blp.hip": {"blp_kernelE": (32, 256), "blp_uf_kernel": (0, 256), "blp_grow_kernel": (1024, 256)},      # (two per CU: 256 registers for both bodies -- an experiment that is off by default)
+    "mht_blp.hip": {"blp_kernelE": (32, 256), "blp_uf_kernel": (0, 256)},
     # cluster_init_kernel / post_scan_kernel<false> are on the path of every streamed scan: the initiator in them is compiled WITHOUT the AIS
     # seeding phase (its matrices spill 400 bytes per lane at the 128 registers 1024 threads leave); <true> only runs on scans with messages
     "mht_cluster.hip": {"cluster_kernel": (0, 128), "cluster_init_kernel": (160, 128)},

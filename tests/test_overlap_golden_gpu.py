@@ -75,16 +75,12 @@ def test_streamed_api_last_scan_equals_reference(name, gold_dir):
     trk.close()
 
 
-@pytest.mark.parametrize("name,one_launch,peek", [("g6b_trace_cfg3_long", False, 0), ("g6b_trace_cfg3_long", True, 0), ("g6_trace_cfg3", True, 0),
-                                                  ("g6b_trace_cfg3_long", True, 5)])
-def test_raw_replay_last_scan_equals_reference(name, one_launch, peek, gold_dir, monkeypatch):
+@pytest.mark.parametrize("name,peek", [("g6b_trace_cfg3_long", 0), ("g6_trace_cfg3", 0), ("g6b_trace_cfg3_long", 5)])
+def test_raw_replay_last_scan_equals_reference(name, peek, gold_dir):
     """(ii) what bench.py times: `mht_forest_step` on scans resident in HBM, the births of an untimed pre-pass through the API replayed with
     `mht_forest_add_targets_dev`, no report read until the end.
-    one_launch: the same through the one-launch-per-scan kernel (MHT_MERGE=1 at creation: `blp_grow_kernel`, the ILP workgroups of scan k
-    play the grow roles of scan k + 1; the ILP launch of a step is left for the next step's launch or flushed by whoever reads first) --
-    slower than the launch pair and therefore off by default, but built and pinned against the same traces.
-    peek: a report is read behind every peek-th scan -- the pending ILP launch is then launched alone (flush_ilp) and the next step starts
-    a fresh chain."""
+    peek: a report is read behind every peek-th scan -- the pending commit is flushed and the next step starts a fresh chain of
+    overlapping launches."""
     import torch
     from pymht_amd import _lib
     from pymht_amd.utils.classDefinitions import MeasurementList
@@ -110,10 +106,7 @@ def test_raw_replay_last_scan_equals_reference(name, one_launch, peek, gold_dir,
             assert np.array_equal(np.array([b[1] for b in births[k]], dtype=np.float64), g["s%02d_born_P" % k])
     pre.close()
     # raw replay
-    if one_launch:
-        monkeypatch.setenv("MHT_MERGE", "1")      # (read when the forest is created)
     trk = _make(g, useInitiator=False)
-    monkeypatch.delenv("MHT_MERGE", raising=False)
     lib, h, dev = trk._lib, trk._ctx.handle, trk._ctx.device
     zs = [np.ascontiguousarray(g["s%02d_z" % k], dtype=np.float32) for k in range(n)]
     zall = torch.from_numpy(np.concatenate(zs, axis=0)).to(dev)
@@ -138,9 +131,6 @@ def test_raw_replay_last_scan_equals_reference(name, one_launch, peek, gold_dir,
             _lib.check(lib.mht_forest_report(h, C.byref(rp)))
             assert rp.error == 0 and rp.scan == k + 1
     uf, ovl = _uf_ovl(trk)
-    merged = np.zeros(1, dtype=np.int32)
-    lib.mht_forest_debug_read(h, b"merged_launches", merged.ctypes.data_as(C.c_void_p), 4)
-    assert (int(merged[0]) > n // (3 if peek else 2)) if one_launch else (int(merged[0]) == 0), "scans whose ILP launch and the next grow launch were ONE launch: %d" % int(merged[0])
     rep = _lib.MhtScanReport()
     _lib.check(lib.mht_forest_report(h, C.byref(rep)))
     assert rep.error == 0
