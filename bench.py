@@ -71,7 +71,7 @@ def pmc_traffic_live(config, timeout_s=180.0):
         d = tempfile.mkdtemp(prefix="mht_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config", config,
-                   "--cpu-scans", "0", "--sectors", "0", "--steps", "40", "--warmup", "8", "--pmc", "off"]
+                   "--cpu-scans", "0", "--sectors", "0", "--steps", "40", "--warmup", "8", "--pmc", "off", "--extras", "off"]
             left = timeout_s - (time.time() - t0)
             if left < 20:
                 return None, "time budget of the counter passes used up"
@@ -340,23 +340,23 @@ def cpu_baseline(sc, n_warm, n_timed, budget_s=None):
                           model=None if four else model)
     for x in roots_of(sc, model):
         o.initiate_target(sc["t0"], x.copy(), orc.model_P0() if four else model.P0.copy(), status="preinitialized")
-    hot, stats = 0.0, []
+    per = []
     t_b = time.time()
     for k in range(n_warm + n_timed):
-        if budget_s is not None and k > n_warm and time.time() - t_b > budget_s:      # (bounded: the timed sample ends here)
-            n_timed = k - n_warm
+        if budget_s is not None and k >= 2 and time.time() - t_b > budget_s:      # (bounded: the sample is the last scans that were reached)
             break
         info = o.add_scan(float(sc["times"][k]), sc["scans"][k])
-        if k >= n_warm:
-            hot += sum(o.toc[s] for s in ("Process", "Cluster", "Optim", "Terminate", "N-Prune"))
-            stats.append((info["L"], info["G"], info["M"], o.toc["Process"], o.toc["Cluster"] + o.toc["Optim"]))
-    st = np.array(stats)
+        per.append((sum(o.toc[s] for s in ("Process", "Cluster", "Optim", "Terminate", "N-Prune")), info["L"], info["G"], info["M"], o.toc["Process"], o.toc["Cluster"] + o.toc["Optim"]))
+    n_done = len(per)
+    n_timed = max(1, min(n_timed, n_done - min(n_warm, n_done - 1)))
+    st = np.array(per[n_done - n_timed:])
+    hot = float(st[:, 0].sum())
     return dict(value=n_timed / hot, unit="scans/s", cores=1, kind="port",
                 sample="oracle/mht_oracle.py (NumPy restatement, bit-identical to the reference in the dev container), "
-                       "1 thread, scans %d..%d of the same scan stream after %d warm-up scans; stages "
+                       "1 thread, scans %d..%d of the same scan stream after %d warm-up scans%s; stages "
                        "Process+Cluster+Optim+Terminate+N-Prune; mean L=%d G=%d M=%d; gate %.0f ms, cluster+ILP %.0f ms per scan"
-                       % (n_warm, n_warm + n_timed - 1, n_warm, st[:, 0].mean(), st[:, 1].mean(), st[:, 2].mean(),
-                          1e3 * st[:, 3].mean(), 1e3 * st[:, 4].mean()))
+                       % (n_done - n_timed, n_done - 1, n_done - n_timed, "" if budget_s is None else " (bounded to %.0f s of wall clock)" % budget_s,
+                          st[:, 1].mean(), st[:, 2].mean(), st[:, 3].mean(), 1e3 * st[:, 4].mean(), 1e3 * st[:, 5].mean()))
 
 
 def steady_windows(config, seed, centre, device, warm, n_win=3, win=20, long_k=400):
@@ -411,13 +411,11 @@ def config_extra(name, device, warm, steps, cpu_warm, cpu_timed, cpu_budget_s):
     el = time.perf_counter() - t0
     rep, recs = rp.report()
     ok = [(int(r["id"]), int(r["sel_meas"])) for r in recs if int(r["status"]) == 0] == final and rep.error == 0
-    rp._lib_mod.check(rp.lib.mht_forest_set_timing(rp.h, 1))
-    ms = np.zeros(5)
     buf = (C.c_float * 5)()
     n = C.c_int32(0)
     nt = min(16, steps)
-    # (stage times of a few more scans of the stream's tail are not available: the stream ends here -- timed on a second replay)
     rp.close()
+    # (per-stage times need event-synchronised launches: a second replay of the first timed scans)
     rp = Replay(sc, births, device)
     for _ in range(warm):
         rp.step()
@@ -465,6 +463,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank tracks its own sector (BASELINE config 4); strong: ALL ranks track the same sector, "
                          "its independent clusters' ILPs spread over the ranks (one all-reduce of the selections per scan)")
+    ap.add_argument("--extras", default="auto", help="auto: on one GPU with the headline config the line also carries value_steady / value_windows (a longer replay of the same "
+                    "stream) and bounded lines for BASELINE configs 2 and 5 (`configs`); off: none of them")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
                     help="auto: roofline.traffic is measured by two rocprofv3 counter passes over a short replay (rank 0, one GPU; ~40 s); "
                          "off: the figure of profiles/ is quoted and labelled as not measured by this run")
@@ -634,12 +634,29 @@ def main():
         barrier()
         okm = True
         t_grow = [[] for _ in rps]
+        t_union = []
+
+        def stamps(r):      # DevStatus::t of the scan just stepped: [0] grow start, [1] cluster start (absolute device wall clock, 10 ns ticks)
+            a = np.zeros(2 * 8, dtype=np.uint64)
+            r._lib_mod.check(r.lib.mht_forest_debug_read(r.h, b"status2", a.ctypes.data_as(C.c_void_p), a.nbytes))
+            w = a.reshape(2, 8)[:, 2:].astype(np.int64)[r.k & 1]
+            return int(w[0]), int(w[1])
         for tail in range(NTAIL):      # (untimed: every report read synchronises) device stamps of these scans' launches: grow start -> cluster start of the sector's group
             group_step()
             for q, r in enumerate(rps):
                 repm, recm = r.report()
                 okm = okm and repm.error == 0
                 t_grow[q].append(repm.t_process * 1e-8)
+            if not solo:      # the UNION of the groups' grow intervals of this scan (the groups run side by side on their own streams: their launches overlap)
+                iv = sorted(stamps(rps[gi]) for gi in range(NG))
+                tot, cur0, cur1 = 0, iv[0][0], iv[0][1]
+                for a0, a1 in iv[1:]:
+                    if a0 <= cur1:
+                        cur1 = max(cur1, a1)
+                    else:
+                        tot += cur1 - cur0
+                        cur0, cur1 = a0, a1
+                t_union.append((tot + cur1 - cur0) * 1e-8)
         for q, r in enumerate(rps):
             if fins[q] is not None:      # the sector must end where its own single tracker ended (same scans, same births): selections of every live track
                 repq, recq = r.report()
@@ -652,13 +669,15 @@ def main():
         tmulti, okm = parallel.reduce_clock(tm1 - tm0, okm, dist, device="cuda")
         # algorithmic bytes of ALL sectors' grow stages of one scan over the duration of their batched grow launch(es)
         bytes_scan = sum(float(per_leaf) * st[W:W + Km, 0].mean() + float(per_pair) * st[W:W + Km, 1].mean() + 8.0 * st[W:W + Km, 2].mean() for st in sts)
-        tg = float(np.mean(t_grow)) * NG if not solo else float(np.sum(t_grow))      # NG groups' grow launches per scan, one after the other at worst
+        # all sectors' bytes over the time during which ANY group's grow launch of the scan was running (device stamps; rounds 2-5 multiplied the mean
+        # launch time by the number of groups, i.e. assumed that the groups' launches run one after the other)
+        tg = float(np.mean(t_union)) if t_union else float(np.sum(t_grow))
         gbs = bytes_scan / tg / 1e9 if tg > 0 else 0.0
         return {"sectors_per_gpu": S, "steps_per_sector": Km, "scans_per_sec": world * S * Km / tmulti,
                 "ms_per_scan_aggregate": 1e3 * tmulti / (S * Km), "ok": okm, "groups": NG,
                 "x_single_sector": None,
-                "roofline": {"bound": "hbm", "kernel": "fgrow_batch_kernel: the grow stage of all sectors of a group in one launch (device wall-clock stamps, mean over 8 scans behind the timed ones)",
-                             "algorithmic_bytes_all_sectors": bytes_scan, "grow_us_per_scan_all_groups": 1e6 * tg, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                "roofline": {"bound": "hbm", "kernel": "fgrow_batch_kernel: the grow stage of all sectors of a group in one launch; time = union of the groups' grow intervals per scan (absolute device wall-clock stamps, mean over 8 scans behind the timed ones)",
+                             "algorithmic_bytes_all_sectors": bytes_scan, "grow_us_per_scan_all_groups": 1e6 * tg, "grow_us_per_group_launch": 1e6 * float(np.mean(t_grow)), "achieved": gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "note": "independent sectors in %d group(s), one batched launch set per group and scan (mht_group_step, grid.y = "
                         "sector), groups on separate HIP streams; the single-sector path is a chain of dependent round trips that "
@@ -692,6 +711,19 @@ def main():
         if "scans_per_sec" in m_:      # (a failed extra carries its error instead)
             m_["x_single_sector"] = m_["scans_per_sec"] / ((1 if strong else world) * K / elapsed)
     ilp_acc = ilp_accounting(sc, births, local, W, min(K, 32)) if rank == 0 else None
+    extras_on = args.extras != "off" and rank == 0 and world == 1 and args.config == "cfg3" and not strong
+    value_steady = value_windows = None
+    configs_extra = []
+    if extras_on:
+        try:
+            value_steady, value_windows = steady_windows(args.config, parallel.sector_seed(5446, srank), parallel.sector_centre(srank), local, W)
+        except Exception as e:      # noqa: BLE001  (an extra: its failure must not cost the run its headline line)
+            value_windows = {"error": repr(e)[:300]}
+        for nm, wm, st_, cw, ct in (("cfg2", 16 + 10, 100, 8, 8), ("cfg5", 16 + 6, 60, 9, 2)):
+            try:
+                configs_extra.append(config_extra(nm, local, wm, st_, cw, ct if args.cpu_scans > 0 else 0, 25.0))
+            except Exception as e:      # noqa: BLE001
+                configs_extra.append({"name": nm, "error": repr(e)[:300]})
     out = {
         "metric": "scans/sec at ~5k+ leaf hypotheses x 500 measurements (per-scan gate + cluster + ILP + N-scan prune)",
         "value": (1 if strong else world) * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -706,6 +738,9 @@ def main():
                    "pre_roll_scans": PRE},
         "stage_ms": {"gate": float(ms[0]), "cluster": float(ms[1]), "ilp": float(ms[2]), "prune": float(ms[3]),
                      "device_total": float(ms[4])},
+        "value_steady": value_steady,
+        "value_windows": value_windows,
+        "configs": configs_extra,
         "multi_sector": multi,
         "multi_sector_all": multi_all,
         "ilp": ilp_acc,
