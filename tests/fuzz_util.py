@@ -181,3 +181,58 @@ def run_case_ais(seed, max_leaves=2500, budget_s=20.0):
         return True, desc, msg + ' L=%d fused=%d ilp=%d %.1fs' % (st["L"], nf, o.n_ilp, time.time() - t0)
     finally:
         trk.close()
+
+
+def run_case_ct(seed, max_leaves=2500, budget_s=15.0):
+    """Constant-turn forests (pymht_amd/models/ct.py, six states; MHT_FOREST_CT): every hypothesis its own Phi(T, w), formed on the device
+    from its f64 sin / cos.  Random scenario as above, every root with a RANDOM turn rate w (from exactly 0 and |w| below the model's
+    straight-line threshold through gentle turns to 0.6 rad/s) and turn-rate derivative a, against the live oracle whose per-leaf arithmetic
+    is the reference's kalman.predict_single + kalman.precalc restated (oracle.process_leaves_ct; kalman.py:67-70, :82-101).
+    Decisions -- gating counts, unused measurements, target lists, clusters, selections, leaf sets, number of ILPs -- exact; states 1e-6."""
+    from test_tracker_gpu import tracker_selected, states_close, SCORE_ATOL
+    from trace_util import make_oracle
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import ct
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc, N, eta2, desc = scenario_of(seed)
+    prng = np.random.default_rng(seed + 4242)
+    T = len(sc["x0"])
+    kind = prng.integers(0, 5, size=T)
+    w = np.where(kind == 0, 0.0, np.where(kind == 1, prng.uniform(-1e-9, 1e-9, size=T), np.where(kind == 2, prng.normal(0.0, 0.02, size=T),
+                 np.where(kind == 3, prng.uniform(-0.6, 0.6, size=T), prng.normal(0.0, 0.15, size=T)))))
+    a = np.where(prng.uniform(size=T) < 0.5, 0.0, prng.normal(0.0, 1e-3, size=T))
+    x0 = np.concatenate([sc["x0"], w[:, None], a[:, None]], axis=1)
+    desc += ' CT |w|max=%.3f' % float(np.abs(w).max())
+    trk = Tracker(ct, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2, useInitiator=False, maxTargets=256, maxNodes=1 << 18, maxMeasurements=512)
+    t0 = time.time()
+    try:
+        acc = []
+        for x in x0:
+            n0 = trk.nTargets
+            trk.initiateTarget(Target(sc["t0"], None, x.copy(), ct.P0, status="preinitialized"))
+            acc.append(trk.nTargets > n0)
+        g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=N, eta2=eta2, x0=x0, t0=sc["t0"], accepted=acc)
+        o = make_oracle(g, with_initiator=False, model=ct)
+        st, msg = {"L": 0}, ''
+        for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+            if time.time() - t0 > budget_s or (k > 0 and st["L"] > max_leaves):
+                msg = 'stopped after scan %d' % k
+                break
+            info = o.add_scan(float(t), z)
+            trk.addMeasurementList(MeasurementList(float(t), z))
+            st = trk.lastScanStats
+            os_, ts = o.selected(), tracker_selected(trk, 6)
+            lb, tb = o.leaf_batch(), trk.leafBatch()
+            checks = [(st["L"], st["G"]) == (info["L"], info["G"]), np.array_equal(st["unused"], info["unused"]),
+                      [r.ID for r in o.targets] == [r.ID for r in trk.__targetList__],
+                      np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
+                      states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
+                      len(o.clusters) == len(trk.__clusterList__) and all(np.array_equal(a_, np.asarray(b_)) for a_, b_ in zip(o.clusters, trk.__clusterList__)),
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=1e-6),
+                      o.n_ilp == trk.nOptimSolved]
+            if not all(checks):
+                return False, desc, 'MISMATCH at scan %d: gating %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))
+        return True, desc, msg + ' L=%d ilp=%d %.1fs' % (st["L"], o.n_ilp, time.time() - t0)
+    finally:
+        trk.close()

@@ -67,3 +67,18 @@ def test_fuzz_slice_streamed():
         if not ok:
             bad.append(desc + ' ' + msg)
     assert not bad, "\n".join(bad)
+
+
+def test_fuzz_slice_constant_turn():
+    """Constant-turn forests (BASELINE config 5's model) with random turn rates against the live oracle (fuzz_util.run_case_ct): Phi(T, w)
+    is formed on the device from its own f64 sin / cos -- a float32 entry one ulp off NumPy's is the class of difference that can flip a
+    gate decision, so decisions are compared exactly on random scenarios (tools/fuzz_ct.py runs the campaign: profiles/r06_fuzz_ct.txt)."""
+    from fuzz_util import run_case_ct
+    n = int(os.environ.get("MHT_FUZZ_CT_CASES", "80"))
+    seed0 = int(os.environ.get("MHT_FUZZ_SEED", "20000")) + 700000
+    bad = []
+    for case in range(n):
+        ok, desc, msg = run_case_ct(seed0 + case, max_leaves=1500, budget_s=6.0)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+    assert not bad, "\n".join(bad)

@@ -29,6 +29,48 @@ BUDGET = {
 }
 
 
+# the six-state build (-DMHT_NX=6, libmht_amd6.so): BASELINE config 5's constant-turn forest.  fgrow_ct_kernel: three workgroups per CU
+# (launch bounds; 147-150 registers measured), forest_ct_kernel (per-leaf Phi(T, w) + covariance chain in front of the grow launch): two
+# wavefronts per SIMD at 189 registers -- neither may spill
+BUDGET6 = {
+    "mht_fgrow.hip": {"fgrow_ct_kernel": (0, 168), "fgrow_kernelILi2ELi128": (0, 168)},      # (the second: the one-sector grow kernel with the linear six-state stand-in, models/ca.py)
+    "mht_ais.hip": {"forest_ct_kernel": (0, 200)},
+}
+
+
+def _report(src, tmp_path, extra=()):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from pymht_amd.build import FLAGS
+    flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [hipcc] + flags + list(extra) + ["-c", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"),
+                                           os.path.join(CSRC, src), "-o", str(tmp_path / "o.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stderr
+    found = {}
+    for m in re.finditer(r"Function Name: (\S+)", text):
+        seg = text[m.end():m.end() + 4000]
+        nxt = seg.find("Function Name:")
+        seg = seg if nxt < 0 else seg[:nxt]
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", seg).group(1))
+        vgpr = int(re.search(r"VGPRs: (\d+)", seg).group(1))
+        found[m.group(1)] = (scratch, vgpr)
+    return found
+
+
+@pytest.mark.parametrize("src", sorted(BUDGET6))
+def test_scratch_and_register_budget_six_state_build(src, tmp_path):
+    found = _report(src, tmp_path, ["-DMHT_NX=6"])
+    for kern, (max_scratch, max_vgpr) in BUDGET6[src].items():
+        hits = [v for k, v in found.items() if kern in k]
+        assert hits, "kernel %s not found in the compiler report of %s (-DMHT_NX=6)" % (kern, src)
+        for scratch, vgpr in hits:
+            assert scratch <= max_scratch, "%s (six-state build) uses %d B of scratch per lane (budget %d)" % (kern, scratch, max_scratch)
+            assert vgpr <= max_vgpr, "%s (six-state build) needs %d VGPRs (budget %d)" % (kern, vgpr, max_vgpr)
+
+
 @pytest.mark.parametrize("src", sorted(BUDGET))
 def test_scratch_and_register_budget(src, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
