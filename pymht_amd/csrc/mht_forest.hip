@@ -1362,7 +1362,9 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
         // others work through: at the headline size 160-192 workgroups instead of 258 are 1 us per scan (profiles/r05_merge_ab.txt, "ILP grid").
         // The commit leaves the last scan's counts in the host-mapped hint block; a scan with a team-sized cluster keeps the workgroups
         // without a cluster (they are the teams).
-        if (use_uf && f->hint_host && f->grid_by_hint) {
+        // (a wall-clock budget per cluster is set: the width of a team -- and with it which non-proven incumbent a budget-limited search returns -- follows
+        // the grid, so the grid stays the full one and does not depend on when the host happened to read the hint word)
+        if (use_uf && f->hint_host && f->grid_by_hint && !(f->blp_time_limit > 0 && f->nT_ub_step >= TEAM_MIN_K)) {
             const unsigned long long hh = reinterpret_cast<volatile unsigned long long*>(f->hint_host)[2];
             const int h_scan = (int)(hh >> 48), h_multi = (int)((hh >> 32) & 0xffffu), h_single = (int)((hh >> 8) & 0xffffffu), h_team = (int)(hh & 0xffu);
             const int age = (pl.s - h_scan) & 0xffff;

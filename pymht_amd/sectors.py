@@ -34,7 +34,11 @@ class SectorGroup:
         self._M = (C.c_int32 * max(n, 1))()
 
     def step_dev(self, z_ptrs, Ms):
-        """Raw replay: device pointers (ints) and measurement counts, one per sector; asynchronous, nothing is fetched."""
+        """Raw replay: device pointers (ints) and measurement counts, one per sector; asynchronous, nothing is fetched.  Only for groups
+        whose members all share the batched launches (no AIS-aided or constant-turn member: those have launches of their own and are
+        stepped through `addMeasurementLists`)."""
+        if any(self._own) and len(z_ptrs) != len(self._batched):
+            raise ValueError("SectorGroup.step_dev: %d of the %d members have launches of their own (AIS-aided / constant-turn): use addMeasurementLists" % (sum(self._own), len(self.trackers)))
         for i, (p, m) in enumerate(zip(z_ptrs, Ms)):
             self._zp[i] = p
             self._M[i] = m
@@ -58,15 +62,17 @@ class SectorGroup:
         if self._batched:
             zs = [self.trackers[i]._stage_scan(scanLists[i], pruneSimilar=ps[i]) for i in self._batched]
             self.step_dev([z.data_ptr() for z in zs], [int(z.shape[0]) for z in zs])
-        for i, trk in enumerate(self.trackers):      # (the members with launches of their own queue theirs behind the group's)
-            if self._own[i]:
-                if getattr(trk, "_ais", False):
-                    trk.addMeasurementList(scanLists[i], ais[i], pruneSimilar=ps[i], **kwargs)
-                else:
-                    trk.addMeasurementList(scanLists[i], pruneSimilar=ps[i])
-        for i in self._batched:
-            trk = self.trackers[i]
-            trk._after_step(scanLists[i], trk._staged_np, None)
+        try:
+            for i, trk in enumerate(self.trackers):      # (the members with launches of their own queue theirs behind the group's)
+                if self._own[i]:
+                    if getattr(trk, "_ais", False):
+                        trk.addMeasurementList(scanLists[i], ais[i], pruneSimilar=ps[i], **kwargs)
+                    else:
+                        trk.addMeasurementList(scanLists[i], pruneSimilar=ps[i])
+        finally:      # (a member of its own that refuses its scan must not leave the batched members stepped on the device and not folded on the host)
+            for i in self._batched:
+                trk = self.trackers[i]
+                trk._after_step(scanLists[i], trk._staged_np, None)
 
     def close(self):
         if self._h:

@@ -58,13 +58,16 @@ class DeviceTarget(Target):
         if self._P_lazy:
             self._P_lazy = False
             t = self._tracker
+            # (the constructor's placeholder is the tracker-wide default P_0, not this node's covariance: a node the device cannot answer for
+            # any more -- it has left the ring, or reports are still pending -- has NO covariance to show, not a wrong one)
+            self._P = None
             if t is not None and self._node >= 0 and self.scanNumber is not None and 0 <= len(t.__scanHistory__) - self.scanNumber < t._cfg.n_scan + 4:
                 try:
                     P = t._window_chain(self.scanNumber, self._node)[4]
                     if len(P):
                         self._P = np.array(P[0]).reshape(t.nx, t.nx)
                 except _lib.MhtError:
-                    pass      # (the node has left the device ring: the placeholder stays)
+                    pass      # (the node has left the device ring)
         return self._P
 
     @P_0.setter
@@ -442,6 +445,8 @@ class Tracker():
         self._scanrecs.append((tic, rep.t_process, rep.t_cluster, rep.t_optim, rep.t_scan, stage, rep.n_ilp, rep.n_leaves_in, rep.n_children,
                                nRadarMeas, rep.n_leaves_out, rep.n_clusters, rep.n_branched, rep.blp_iters_max, rep.n_limit, used_raw,
                                len(self._tbl_), time.time() - t_init, total))
+        if len(self._scanrecs) >= 256:      # (a host that streams for hours without reading toc / runtimeLog: the tuples -- each holds its scan's tic and used-measurement words -- do not pile up)
+            self._materialise()
         if total > self.radarPeriod * 0.6 or tic.get('_print'):
             self._materialise()
             if total > 0.1 and os.environ.get("MHT_STALL_DEBUG") == "1":      # (development: which part of a scan was slow)
