@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --cpu-scans 0 --sectors 0 --pmc off"
+B="python $root/bench.py --cpu-scans 0 --sectors 0 --pmc off --extras off ${CFG:+--config $CFG}"
 rocprofv3 --kernel-trace -d $out/kt -o kt -- $B --steps 200 --warmup 40 > $out/bench_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $out/pf -o pf -- $B --steps 60 --warmup 8 > $out/bench_pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/pw -o pw -- $B --steps 60 --warmup 8 > $out/bench_pw.log 2>&1
