@@ -56,7 +56,6 @@ for cap_h, cap_k in ((256, 8), (512, 8), (512, 16), (768, 16), (1024, 16), (1024
     fit = (a[:, 1] <= cap_h) & (a[:, 0] <= cap_k)
     per_scan = np.mean([np.all((r[:, 1] <= cap_h) & (r[:, 0] <= cap_k)) for r in rows])
     print("tier %4d columns / %2d targets: %.2f %% of the clusters fit, %.0f %% of the scans have nothing beyond it" % (cap_h, cap_k, 100 * fit.mean(), 100 * per_scan))
-print("solved by one wavefront (mht_blp_wave.h): %.2f %% of the clusters; the others: K %s columns %s rounds %s" % (100 * a[:, 7].mean(), a[a[:, 7] == 0, 0][:12].astype(int), a[a[:, 7] == 0, 1][:12].astype(int), a[a[:, 7] == 0, 2][:12].astype(int)))
 print("rounds histogram:", np.bincount(a[:, 2].astype(int)))
 print("status histogram:", np.bincount(a[:, 3].astype(int)))
 w = np.array(worst)
