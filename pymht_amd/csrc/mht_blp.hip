@@ -1844,7 +1844,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
                     const int v = __shfl_up(incl, o);
                     if (tid >= o) incl += v;
                 }
-                if (k < K) { s.colb[k] = carry + incl - n; s.gbase[k] = gb; }
+                if (k < K) { s.colb[k] = carry + incl - n; s.gbase[k] = gb; if (pre_ok && K <= 64) s.lix[k] = pre.j; }      // (lix: the member's prune depth until the solver takes the table -- the copy below prefetches the survivors' sweep with it)
                 carry += __shfl(incl, 63);
             }
             if (tid == 0) { s.colb[K] = carry; s_nH = carry; }
@@ -1864,6 +1864,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         return;
     }
     const bool lds_cols = small_k && nH <= L_MAXH && a.PD <= 8 && !a.force_hbm;
+    // the epilogue's survivor test needs ONE ancestor-table entry per child (level j - 1 of its target): fetched with the column, parked in gcolL (only a
+    // REDUCED cluster uses that table for something else, and it sweeps its members' ranges generically): one global round trip less behind the solve
+    // (+0.5 % over 400 scans, profiles/r06_experiments.txt; the new root's record fetched speculatively through the same entry: measured, -0.2 %, not kept)
+    const bool anc_pf = lds_cols && pre_ok && K <= 64 && a.t_alive && a.pds == 8;
     s.nH = nH; s.PD = a.PD; s.K = K;
     // ---- measurement nodes of the cluster (union of the rows of its columns); in the LDS case the columns are
     //      copied in the same sweep: every thread issues the PD+1 loads of a column back to back (one round trip)
@@ -1871,23 +1875,26 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         // two columns per thread and pass: all 2 x (PD + 1) global loads are issued before the first is consumed, so a
         // cluster of up to 512 columns is copied in ONE global round trip (the loop is latency, not bandwidth, bound)
         for (int h0 = tid; h0 < nH; h0 += 2 * BLP_THREADS) {
-            int g[2], ev[2][8];
+            int g[2], ev[2][8], jm[2], an[2];
             double cs[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int h = h0 + q * BLP_THREADS;
-                g[q] = -1;
+                g[q] = -1; jm[q] = 0;
                 if (h < nH) {
                     int lo = 0, hi = K;
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.colb[mid] <= h) lo = mid; else hi = mid; }
                     g[q] = s.gbase[lo] + (h - s.colb[lo]);
                     s.membL[h] = (unsigned short)lo;
+                    if (anc_pf) jm[q] = s.lix[lo];
                 }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {      // unconditional loads (clamped index), masked afterwards: no branch between them
                 const int gq = g[q] >= 0 ? g[q] : 0;
                 cs[q] = a.cost[gq];
+                an[q] = -1;
+                if (anc_pf) an[q] = a.apath[(size_t)gq * 8 + (jm[q] > 0 ? jm[q] - 1 : 0)];
                 if (a.pds) {      // forest: one 32-byte record per column (entries beyond PD are -1)
                     const int4* rec = reinterpret_cast<const int4*>(a.path + (size_t)gq * a.pds);
                     const int4 r0 = rec[0], r1 = rec[1];
@@ -1907,6 +1914,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
                 const int h = h0 + q * BLP_THREADS;
                 if (g[q] < 0) continue;
                 s.costL[h] = cs[q];
+                if (anc_pf) s.gcolL[h] = an[q];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     s.entL[h * 8 + d] = (unsigned short)(ev[q][d] < 0 ? 0xffff : ev[q][d]);     // global node id for now
@@ -2145,7 +2153,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
                 const int key = s.ch[m];
                 if (key == KEY_DEAD) continue;
                 const int g = s.gbase[m] + (h - s.colb[m]);
-                const bool sv = key == KEY_ALL || a.apath[(size_t)g * a.pds + (s.ub_sel[m] - 1)] == key;
+                const bool sv = key == KEY_ALL || (anc_pf ? s.gcolL[h] : a.apath[(size_t)g * a.pds + (s.ub_sel[m] - 1)]) == key;
                 if (sv) { atomicAdd(&s.lix[m], 1); atomicMin(&s.best_h[m], g); }
             }
             __syncthreads();
