@@ -1015,6 +1015,7 @@ static void fill_similar(const Forest* f, int s, SimilarArgs& a) {
     a.status = f->status2 + (s & 1);
     a.mmsi = f->ais ? f->l_mmsi[s % f->R] : nullptr;
     if (f->ais) { a.t_window = f->tab[cb].window; a.t_depth = f->tab[cb].depth; }
+    if (f->ct) { const int lp = (s - 1 + f->R) % f->R; a.ct_Phat = f->ct_Phat[lp]; a.ct_Pbar = f->ct_Pbar[lp]; }      // (the children's covariances live in the PARENT layer's arrays)
 }
 
 // N-scan prune (tracker.py:256-259), target side: surviving leaf ranges -> target table / roots / report, for scan s
@@ -2025,7 +2026,6 @@ extern "C" int mht_forest_set_prune_similar(mht_ctx* ctx, double threshold) {
     MHT_REQUIRE(!(threshold != threshold), "mht_forest_set_prune_similar: threshold is NaN");
     Forest* f = ctx->forest;
     MHT_REQUIRE(!f->shard_open, "mht_forest_set_prune_similar: a sharded step is open");
-    MHT_REQUIRE(!(f->ct && threshold > 0.0), "mht_forest_set_prune_similar: not available in a constant-turn forest (MHT_FOREST_CT)");
     f->prune_thr = threshold > 0.0 ? (float)threshold : 0.f;
     return MHT_OK;
 }

@@ -319,6 +319,10 @@ struct SimilarArgs {
     const DevStatus* status;
     const int32_t* mmsi;                                    // AIS forest: children updated with an AIS message are not merged (pyTarget.py:371-375), else null
     int32_t* t_window; const int32_t* t_depth;              // AIS forest (else null): the table the scan ran on -- the lone targets' association sets are rebuilt from their trees (WIN_REBUILT_*)
+    // constant-turn forest (else null): the covariances of this scan's children by PARENT node -- P_hat of every hit child, P_bar of the missed-detection
+    // child (CtGrow: key = 2 x parent + hit/miss).  The merged node takes the missed-detection child's slot AND its key: a mean that is not the hit
+    // children's covariance itself is written over the parent's P_bar entry (the missed-detection hypothesis it belonged to is gone)
+    const float* ct_Phat; float* ct_Pbar;
 };
 
 // forest_ais_kernel (mht_ais.hip): the fused children of every leaf of the newest layer, in front of the grow launch of a scan with AIS messages

@@ -53,6 +53,11 @@ template <typename TS, typename TP> __device__ __forceinline__ void fuse_group(c
         if (!is_near(a, g, p0x, p0y)) continue;
         const uint8_t fg = a.flags[g];
         TP P[NP];
+        if (sizeof(TP) == 4 && a.ct_Phat) {      // constant-turn forest: the hit children of node (key >> 1) share its P_hat
+            const float* src = a.ct_Phat + (size_t)(a.cov[g] >> 1) * NP;
+#pragma unroll
+            for (int e = 0; e < NP; ++e) P[e] = (TP)src[e];
+        } else
         sim_load(a.vt, a.vt.child[a.cov[g]], P);
         if (first < 0) {
             first = g; fl = fg;
@@ -88,6 +93,10 @@ template <typename TS, typename TP> __device__ __forceinline__ void fuse_group(c
     a.flags[h] = mfl;
     if (same) {
         a.cov[h] = a.cov[first];
+    } else if (sizeof(TP) == 4 && a.ct_Pbar) {      // constant-turn forest: the mean under the missed-detection child's own key (see SimilarArgs)
+        float* dst = a.ct_Pbar + (size_t)(a.cov[h] >> 1) * NP;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) dst[e] = (float)Ps[e];
     } else {
         const double pd = a.pd[h];
         if (sizeof(TP) == 8) {      // a float64 mean: two ids for the value, two for its pseudo parent (mht_vtab.h)

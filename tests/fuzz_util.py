@@ -183,12 +183,14 @@ def run_case_ais(seed, max_leaves=2500, budget_s=20.0):
         trk.close()
 
 
-def run_case_ct(seed, max_leaves=2500, budget_s=15.0):
+def run_case_ct(seed, max_leaves=2500, budget_s=15.0, similar=False):
     """Constant-turn forests (pymht_amd/models/ct.py, six states; MHT_FOREST_CT): every hypothesis its own Phi(T, w), formed on the device
     from its f64 sin / cos.  Random scenario as above, every root with a RANDOM turn rate w (from exactly 0 and |w| below the model's
     straight-line threshold through gentle turns to 0.6 rad/s) and turn-rate derivative a, against the live oracle whose per-leaf arithmetic
     is the reference's kalman.predict_single + kalman.precalc restated (oracle.process_leaves_ct; kalman.py:67-70, :82-101).
-    Decisions -- gating counts, unused measurements, target lists, clusters, selections, leaf sets, number of ILPs -- exact; states 1e-6."""
+    Decisions -- gating counts, unused measurements, target lists, clusters, selections, leaf sets, number of ILPs -- exact; states and
+    covariances of all leaves 1e-6.  similar=True: similar-state pruning (tracker.py:230-231, :1233-1239; pyTarget.py:358-412) switched on and off at
+    random from scan to scan with a random merge radius -- the merged node's mean covariance lives under the missed-detection child's key."""
     from test_tracker_gpu import tracker_selected, states_close, SCORE_ATOL
     from trace_util import make_oracle
     from pymht_amd.tracker import Tracker
@@ -203,8 +205,10 @@ def run_case_ct(seed, max_leaves=2500, budget_s=15.0):
                  np.where(kind == 3, prng.uniform(-0.6, 0.6, size=T), prng.normal(0.0, 0.15, size=T)))))
     a = np.where(prng.uniform(size=T) < 0.5, 0.0, prng.normal(0.0, 1e-3, size=T))
     x0 = np.concatenate([sc["x0"], w[:, None], a[:, None]], axis=1)
-    desc += ' CT |w|max=%.3f' % float(np.abs(w).max())
-    trk = Tracker(ct, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2, useInitiator=False, maxTargets=256, maxNodes=1 << 18, maxMeasurements=512)
+    thr = float(prng.choice([4.0, 6.0, 12.0])) if similar else 4
+    desc += ' CT |w|max=%.3f' % float(np.abs(w).max()) + (' similar thr=%.0f' % thr if similar else '')
+    trk = Tracker(ct, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=N, eta2=eta2, useInitiator=False, maxTargets=256, maxNodes=1 << 18, maxMeasurements=512,
+                  pruneThreshold=thr)
     t0 = time.time()
     try:
         acc = []
@@ -219,8 +223,9 @@ def run_case_ct(seed, max_leaves=2500, budget_s=15.0):
             if time.time() - t0 > budget_s or (k > 0 and st["L"] > max_leaves):
                 msg = 'stopped after scan %d' % k
                 break
-            info = o.add_scan(float(t), z)
-            trk.addMeasurementList(MeasurementList(float(t), z))
+            on = bool(similar and prng.uniform() < 0.75)
+            info = o.add_scan(float(t), z, prune_similar=on, prune_threshold=thr)
+            trk.addMeasurementList(MeasurementList(float(t), z), pruneSimilar=on)
             st = trk.lastScanStats
             os_, ts = o.selected(), tracker_selected(trk, 6)
             lb, tb = o.leaf_batch(), trk.leafBatch()
@@ -229,7 +234,8 @@ def run_case_ct(seed, max_leaves=2500, budget_s=15.0):
                       np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]),
                       states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL),
                       len(o.clusters) == len(trk.__clusterList__) and all(np.array_equal(a_, np.asarray(b_)) for a_, b_ in zip(o.clusters, trk.__clusterList__)),
-                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=1e-6),
+                      np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]) and states_close(lb["x"], tb["x"], rel=1e-6)
+                      and states_close(lb["P"], np.asarray(tb["P"], dtype=np.float64), rel=1e-6),
                       o.n_ilp == trk.nOptimSolved]
             if not all(checks):
                 return False, desc, 'MISMATCH at scan %d: gating %s unused %s targets %s selection %s states %s clusters %s leaves %s ilps %s' % ((k,) + tuple(checks))

@@ -92,12 +92,15 @@ def test_constant_turn_forest_replays_trace(gold_dir, spill, monkeypatch):
     trk.close()
 
 
-def test_constant_turn_forest_refusals():
-    from pymht_amd.tracker import Tracker
-    from pymht_amd.models import ct
-    from pymht_amd import _lib
-    from pymht_amd.utils.classDefinitions import MeasurementList
-    trk = Tracker(ct, 2.5, 1e-6, 1e-4, useInitiator=False, maxTargets=64, maxNodes=1 << 14, maxMeasurements=128)
-    with pytest.raises((_lib.MhtError, AssertionError, RuntimeError)):      # similar-state pruning is not available in a constant-turn forest
-        trk.addMeasurementList(MeasurementList(2.5, np.zeros((0, 2), dtype=np.float32)), pruneSimilar=True)
-    trk.close()
+def test_constant_turn_forest_similar_state_pruning():
+    """Similar-state pruning (tracker.py:1233-1239, pyTarget.py:358-412 are model-agnostic) in a constant-turn forest: the merged node takes the
+    missed-detection child's slot and key, and a mean covariance that is not the hit children's own is written over the parent's P_bar entry
+    (csrc/mht_similar.hip).  Random scenarios with the switch toggled per scan against the live oracle: decisions exact, states AND covariances of
+    all leaves 1e-6 (fuzz_util.run_case_ct(similar=True))."""
+    from fuzz_util import run_case_ct
+    bad, merged_seen = [], 0
+    for case in range(40):
+        ok, desc, msg = run_case_ct(880000 + case, max_leaves=1500, budget_s=6.0, similar=True)
+        if not ok:
+            bad.append(desc + ' ' + msg)
+    assert not bad, "\n".join(bad)

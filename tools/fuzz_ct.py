@@ -1,5 +1,6 @@
 """Constant-turn fuzz campaign: random scenarios with random turn rates through the constant-turn forest (Tracker(models.ct, ...)) against
-the live oracle (tests/fuzz_util.py::run_case_ct), scan by scan.   python tools/fuzz_ct.py [n_cases] [first_seed]"""
+the live oracle (tests/fuzz_util.py::run_case_ct), scan by scan.   python tools/fuzz_ct.py [n_cases] [first_seed] [similar]
+(third argument "similar": with similar-state pruning switched on and off at random)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -7,10 +8,11 @@ from fuzz_util import run_case_ct
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
+similar = len(sys.argv) > 3 and sys.argv[3] == 'similar'
 bad, scans_ilp = 0, 0
 for case in range(n_cases):
     try:
-        ok, desc, msg = run_case_ct(seed0 + case)
+        ok, desc, msg = run_case_ct(seed0 + case, similar=similar)
     except Exception as e:
         ok, desc, msg = False, 'seed %d' % (seed0 + case), 'ERROR ' + repr(e)[:300]
     if not ok or case % 50 == 0:
