@@ -543,3 +543,46 @@ def test_report_two_scans_back_raw_abi():
     assert rc == 0 and s_ == 7
     trk._pendq = []
     trk.close()
+
+
+def test_ilp_grid_hint_survives_a_bulk_admission():
+    """The ILP launch is sized by the LAST scan's cluster counts (a host-mapped hint word; mht_forest.hip) -- a workgroup's tables hold 4
+    multi-target and 32 single-target clusters, so a stale small hint must not size a launch for many more targets than it was taken
+    from (advisor, round 5: after a few one-target scans a bulk `initiateTarget` left 32 workgroups for 1 300 targets and the clusters
+    beyond the tables kept stale selections).  One target for three scans, then 1 299 more at once, then three more scans: every scan
+    against the oracle (gating counts, selections, states, clusters, leaf sets)."""
+    from test_tracker_gpu import tracker_selected, states_close, SCORE_ATOL
+    from trace_util import make_oracle
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_scenario
+    import mht_oracle as orc
+    sc = make_scenario(T=1300, radius=9000.0, lambda_phi=2e-8, n_scans=6, P_d=0.9, period=2.5, seed=4711)
+    trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=5.99, useInitiator=False, maxTargets=2048, maxNodes=1 << 17, maxMeasurements=2048)
+    try:
+        first = [Target(sc["t0"], None, sc["x0"][0].copy(), pv.P0, status="preinitialized")]
+        assert len(trk._add_targets(first)) == 1
+        g = dict(period=sc["period"], lambda_phi=sc["lambda_phi"], lambda_nu=1e-4, P_d=sc["P_d"], N=3, eta2=5.99, x0=sc["x0"][:1], t0=sc["t0"], accepted=[True])
+        o = make_oracle(g, with_initiator=False)
+        for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+            if k == 3:      # the bulk admission: the other targets where they are now
+                xs = sc["truth"][2][1:]
+                cands = [Target(float(sc["times"][2]), None, x.copy(), pv.P0, status="preinitialized") for x in xs]
+                admitted = set(id(c) for c in trk._add_targets(cands))
+                acc = [o.initiate_target(float(sc["times"][2]), x.copy(), orc.model_P0(), status="preinitialized") for x in xs]
+                assert acc == [id(c) in admitted for c in cands] and sum(acc) > 1250
+            info = o.add_scan(float(t), z)
+            trk.addMeasurementList(MeasurementList(float(t), z))
+            st = trk.lastScanStats
+            os_, ts = o.selected(), tracker_selected(trk)
+            assert (st["L"], st["G"]) == (info["L"], info["G"]) and np.array_equal(st["unused"], info["unused"]), k
+            assert np.array_equal(os_["ID"], ts["ID"]) and np.array_equal(os_["meas"], ts["meas"]), k
+            assert states_close(os_["x"], ts["x"]) and np.allclose(os_["cnllr"], ts["cnllr"], rtol=0, atol=SCORE_ATOL), k
+            assert len(o.clusters) == len(trk.__clusterList__) and o.n_ilp == trk.nOptimSolved, k
+            lb, tb = o.leaf_batch(), trk.leafBatch()
+            assert np.array_equal(lb["ID"], tb["ID"]) and np.array_equal(lb["meas"], tb["meas"]), k
+        assert trk.nTargets > 1200
+    finally:
+        trk.close()
