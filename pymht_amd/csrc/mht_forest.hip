@@ -461,7 +461,7 @@ struct Forest {
         bb_rest = ar.take<double>(S); bb_min = ar.take<double>(S);
         sel = ar.take<int32_t>(Tcap); cl_status = ar.take<int32_t>(Tcap); cl_iters = ar.take<int32_t>(Tcap); cl_nodes = ar.take<int32_t>(Tcap); cl_time = ar.take<int32_t>((size_t)8 * Tcap); grow_dbg = ar.take<unsigned long long>(32 + 16 * 4000); commit_log = ar.take<int32_t>(64 * 16);
         t_status = ar.take<int32_t>(Tcap); t_jdrop = ar.take<int32_t>(Tcap); t_count = ar.take<int32_t>(Tcap); t_firstsurv = ar.take<int32_t>(Tcap);
-        new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap); t_score = ar.take<double>(Tcap);
+        new_index = ar.take<int32_t>(Tcap); near = ar.take<int32_t>(Tcap > 2048 ? Tcap : 2048); t_score = ar.take<double>(Tcap);      // (near: per candidate of one admission call, at most 2048 -- mht_forest_add_targets chunks)
         w_root_scan = ar.take<int32_t>(Tcap); w_root_node = ar.take<int32_t>(Tcap); w_root_cnllr = ar.take<double>(Tcap); w_root_f32 = ar.take<uint8_t>(Tcap);
         cnt = ar.take<FCounts>(1);
         report_dev2[0] = ar.take<char>(report_bytes); report_dev2[1] = ar.take<char>(report_bytes);
@@ -1326,7 +1326,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             InitArgs ia;
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];      // (written by this scan's grow launch, packed and cleared by its commit later)
-            ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
+            ia.bhint = f->bhint_dev; ia.forest_overflow = &f->cnt->overflow; ia.scan_no = pl.s;
             if (f->init_side && f->stage_stream && f->adm_fuse && !f->ais && !f->timing) {
                 MHT_STEP_HIP(hipEventRecord(f->grow_ev, st));                       // behind the grow launch
                 MHT_STEP_HIP(hipStreamWaitEvent(f->stage_stream, f->grow_ev, 0));
@@ -1396,7 +1396,7 @@ static int forest_step_impl(mht_ctx* ctx, const float* z, int32_t M, mht_initiat
             InitArgs ia;
             initiator_scan_args(init, z, M, nullptr, now, ia);
             ia.used_b = f->used_bytes[pl.s & 1];
-            ia.bhint = f->bhint_dev; ia.scan_no = pl.s;
+            ia.bhint = f->bhint_dev; ia.forest_overflow = &f->cnt->overflow; ia.scan_no = pl.s;
             if (f->init_side_q && f->stage_stream && f->z_tag_step) {      // (launch_deferred_init)
                 f->init_deferred = true; f->init_def_args = ia; f->init_def_status = f->status2 + (pl.s & 1); f->init_def_ztag = f->z_tag_step;
                 f->init_ev_pending = true; f->init_ev_lazy = true;      // (whoever needs the births without the flag: init_ev, recorded then)
@@ -1739,7 +1739,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
         initiator_ais_ptrs(in, &au.msgs, &au.used);
         au.mmsi = f->l_mmsi[f->scan % f->R]; au.first = f->tab[nb_].first; au.leaf_off = f->tab[nb_].leaf_off; au.cnt = f->cnt;
     }
-    if (!init_done) { initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia); ia.bhint = f->bhint_dev; ia.scan_no = f->scan; }
+    if (!init_done) { initiator_scan_args(in, z, M, reinterpret_cast<const unsigned long long*>(report_dev + f->used_off), now, ia); ia.bhint = f->bhint_dev; ia.forest_overflow = &f->cnt->overflow; ia.scan_no = f->scan; }
     AddArgs a = {};
     a.n = cap; a.n_dev = bn; a.x0 = bx; a.pd = bpd; a.P0 = bP; a.meas = bme; a.flags = bfl; a.ids = nullptr; a.accepted = nullptr;
     a.check = 1; a.thr = f->cfg.merge_threshold;
@@ -1999,7 +1999,7 @@ static int report_expose(mht_ctx* ctx, Forest* f, int slot, mht_scan_report* out
     }
     if (h->error) {
         f->dead = true;
-        set_error("forest: a pool overflowed during scan %d (max_nodes=%d, max_targets=%d): children=%d", h->scan,
+        set_error("forest: a pool overflowed during scan %d (max_nodes=%d, max_targets=%d, or the initiator's max_born / max_prelim behind it): children=%d", h->scan,
                   f->Ncap, f->Tcap, h->n_children);
         return MHT_E_CAPACITY;
     }

@@ -50,6 +50,10 @@ struct InitArgs {
     // host-mapped ring (or null): word [scan & 63] = scan << 32 | candidates born in that scan, as soon as the number exists -- the
     // forest's host side sizes the next grids with it instead of born_cap (mht_forest.hip: Forest::births_between)
     unsigned long long* bhint; int scan_no;
+    // the forest's sticky capacity flag (FCounts::overflow) when the initiator runs behind a forest's scan, else null: a candidate, track or
+    // edge list that did not fit voids the forest like a full node pool does (MHT_E_CAPACITY at the scan's report) -- the stand-alone seam
+    // reports InitDev::overflow from mht_initiator_born
+    int32_t* forest_overflow;
 };
 
 // np.linalg.inv of the 4 x 4 float32 matrix of PreliminaryTrack.compareSimilarity (m_of_n.py:205-206): numpy.linalg computes in
@@ -201,7 +205,7 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
 // between the scan's commit and the admission of the new targets).
 // AIS = false compiles the seeding phase (1b) out: the kernels on the path of every streamed scan (cluster_init_kernel; post_scan_kernel
 // without messages) keep the register budget they had -- 1024 threads leave 128 registers, the phase's matrices spill 400 bytes per lane.
-// NT = threads of the workgroup (1024 in the kernels of its own; 256 when it rides in the ILP launch, mht_blp.hip: blp_init_kernel)
+// NT = threads of the workgroup (1024 in the kernels that run it)
 #ifdef MHT_INIT_STAMPS
 #define INIT_STAMP(k) do { if (threadIdx.x == 0) init_t[k] = wall_clock64(); } while (0)
 #else
@@ -662,6 +666,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         st.have_last = 1;
         st.last_time = a.now;
         st.n_unused_out = nU;
+        if (st.overflow && a.forest_overflow) *a.forest_overflow = 1;
 #ifdef MHT_INIT_STAMPS
         init_t[8] = wall_clock64();
         if (a.scan_no == 200 || a.scan_no == 201)

@@ -19,7 +19,7 @@ from ..pyTarget import Target
 GATE_PROBABILITY = 0.99
 GAMMA = float(chi2(df=2).ppf(GATE_PROBABILITY))      # m_of_n.py:12-16
 import os
-MAX_BORN = int(os.environ.get("MHT_MAX_BORN", "128"))      # new targets one scan can give birth to (more: MHT_E_CAPACITY)
+MAX_BORN = int(os.environ.get("MHT_MAX_BORN", "256"))      # confirmed tracks of one scan, before merging (more: MHT_E_CAPACITY); 256 = the report's BIRTH_CAP
 
 
 class Initiator:

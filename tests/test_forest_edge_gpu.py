@@ -586,3 +586,31 @@ def test_ilp_grid_hint_survives_a_bulk_admission():
         assert trk.nTargets > 1200
     finally:
         trk.close()
+
+
+def test_more_births_than_the_initiator_holds_is_a_capacity_error(monkeypatch):
+    """Round 6's fuzz campaign (seed 1695381: 124 confirmed tracks in one scan against max_born = 128 before merging) showed the
+    candidates beyond the initiator's capacity dropped WITHOUT an error when the initiator runs behind the forest's scan: only the
+    stand-alone seam (mht_initiator_born) read InitDev::overflow.  Now the forest's sticky flag takes it: MHT_E_CAPACITY, dead forest."""
+    from pymht_amd import _lib
+    from pymht_amd.initiators import m_of_n
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    monkeypatch.setattr(m_of_n, "MAX_BORN", 3)
+    sc = _scenario(T=2, radius=300.0, lambda_phi=1e-6, n_scans=6, seed=5)
+    trk = _mk(sc, N=3)
+    p0 = np.array([[x, y] for y in (-150.0, 150.0) for x in (-180.0, -60.0, 60.0, 180.0)], np.float32)
+    v = np.array([4.0, 1.0], np.float32)
+    with pytest.raises(_lib.MhtError) as ei:
+        for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):      # eight steady strangers: preliminary tracks in the second scan, confirmed in the third
+            zz = np.concatenate([np.asarray(z, np.float32).reshape(-1, 2), p0 + v * np.float32(t - sc["times"][0])]).astype(np.float32)
+            trk.addMeasurementList(MeasurementList(float(t), zz))
+    assert ei.value.code in (_lib.MHT_E_CAPACITY, _lib.MHT_E_STATE)
+    trk.close()
+
+
+def test_a_hundred_births_in_one_scan_match_the_oracle():
+    """The scene that found it: four targets in ~380 clutter points per scan (lambda 1.5e-4, dt 4 s): 41 births in the fourth scan, 123
+    admitted of 124 in the fifth -- target lists, states and selections against the oracle on every scan (tests/fuzz_util.py)."""
+    from fuzz_util import run_case
+    ok, desc, msg = run_case(1695381)
+    assert ok, (desc, msg)
