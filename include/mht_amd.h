@@ -392,6 +392,15 @@ int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, 
 int mht_forest_chain_f64(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                          double* x, double* cnllr, double* P, uint8_t* flags, int32_t* n_out);
 
+/* The streaming form (Tracker._apply_report: the window ancestors of the tracks a scan terminated, tracker.py:353-381 keeps them): the
+ * chains of `count` nodes of layer `scan` are gathered by ONE launch queued behind what is already on the forest's stream, into a pinned
+ * block of the library; nothing waits.  *ticket names the block; it stays valid until 8 later tickets have been issued.  f64 != 0:
+ * float64 covariances as mht_forest_chain_f64.  mht_forest_chains_fetch waits for that launch only (not for scans queued behind it)
+ * and copies chain `index` out: arrays as mht_forest_chain / _f64 (P: float32 or float64 [max_len][16] as asked at begin). */
+int mht_forest_chains_begin(mht_ctx* ctx, int32_t scan, const int32_t* start_nodes, int32_t count, int32_t max_len, int32_t f64, int64_t* ticket);
+int mht_forest_chains_fetch(mht_ctx* ctx, int64_t ticket, int32_t index, int32_t* nodes, int32_t* meas, double* x, double* cnllr, void* P,
+                            uint8_t* flags, int32_t* n_out);
+
 /* ---- step 7 of a scan: M-of-N track initiation on the device (tracker.py:264-278 -> initiators/m_of_n.py:215-478) -------------
  * What Tracker.__init__ hands to m_of_n.Initiator (tracker.py:66-72) plus the model constants the initiator imports (pv.P0, pv.Q's
  * sigmaQ, m_of_n.py:12-16 gamma = chi2(2).ppf(0.99)). */

@@ -159,6 +159,8 @@ def _declare(lib, nx=4):
         "mht_forest_set_blp_time_limit": [vp, dbl],
         "mht_forest_chain": [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_chain_f64": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
+        "mht_forest_chains_begin": [vp, i32, vp, i32, i32, i32, C.POINTER(C.c_int64)],
+        "mht_forest_chains_fetch": [vp, C.c_int64, i32, vp, vp, vp, vp, vp, vp, C.POINTER(i32)],
         "mht_forest_debug_read": [vp, C.c_char_p, vp, i64],
         "mht_forest_set_timing": [vp, i32],
         "mht_forest_stage_times": [vp, C.POINTER(C.c_float * 5), C.POINTER(i32)],

@@ -237,24 +237,49 @@ __global__ void leaves_kernel(const LeavesArgs a, const LeavesCt ct) {
 }
 
 struct ChainArgs { mht_nodes layers[MAXR]; VTab vt[2]; int lgen[MAXR]; int R; int scan, node, max_len; int32_t* nodes; int32_t* meas; double* x; double* cnllr; float* P; int32_t* n_out; double* P64; uint8_t* flags; };
-__global__ void chain_kernel(const ChainArgs a, const CtLayers ct) {
-    if (threadIdx.x || blockIdx.x) return;
-    int nd = a.node, sc = a.scan, n = 0;
+__device__ __forceinline__ int chain_walk(const ChainArgs& a, const CtLayers& ct, int nd, int32_t* nodes, int32_t* meas, double* x, double* cnllr, float* P, double* P64, uint8_t* flags) {
+    int sc = a.scan, n = 0;
     while (nd >= 0 && n < a.max_len && sc >= 0) {
         const mht_nodes& l = a.layers[sc % a.R];
-        a.nodes[n] = nd;
-        a.meas[n] = l.meas[nd];
-        a.cnllr[n] = l.cnllr[nd];
-        for (int k = 0; k < NX; ++k) a.x[n * NX + k] = l.x[(size_t)k * l.cap + nd];
+        nodes[n] = nd;
+        meas[n] = l.meas[nd];
+        cnllr[n] = l.cnllr[nd];
+        for (int k = 0; k < NX; ++k) x[n * NX + k] = l.x[(size_t)k * l.cap + nd];
         const VTab& v = a.vt[a.lgen[sc % a.R]];      // (the generation of the value table this layer's keys belong to)
-        if (ct.on) export_cov_ct(ct, sc % a.R, (sc + a.R - 1) % a.R, l.cov[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
-        else export_cov(v, l.cov[nd], l.flags[nd], a.P ? a.P + (size_t)n * NP : nullptr, a.P64 ? a.P64 + (size_t)n * NP : nullptr);
-        if (a.flags) a.flags[n] = l.flags[nd];
+        if (ct.on) export_cov_ct(ct, sc % a.R, (sc + a.R - 1) % a.R, l.cov[nd], P ? P + (size_t)n * NP : nullptr, P64 ? P64 + (size_t)n * NP : nullptr);
+        else export_cov(v, l.cov[nd], l.flags[nd], P ? P + (size_t)n * NP : nullptr, P64 ? P64 + (size_t)n * NP : nullptr);
+        if (flags) flags[n] = l.flags[nd];
         ++n;
         nd = l.parent[nd];
         --sc;
     }
-    *a.n_out = n;
+    return n;
+}
+__global__ void chain_kernel(const ChainArgs a, const CtLayers ct) {
+    if (threadIdx.x || blockIdx.x) return;
+    *a.n_out = chain_walk(a, ct, a.node, a.nodes, a.meas, a.x, a.cnllr, a.P, a.P64, a.flags);
+}
+// A batch of chains (mht_forest_chains_begin): one thread per chain, every chain a record of its own in a block of host-mapped pinned memory
+// (the start nodes are read from its head) -- nothing is copied, nobody waits; layout of a record: ChainRec
+struct ChainRec { size_t o_m, o_x, o_c, o_P, o_fl, stride; };
+__host__ __device__ __forceinline__ ChainRec chain_rec(int len, int PB) {
+    ChainRec r;
+    r.o_m = 8 + (size_t)len * 4;                                  // [0] n, [8] nodes
+    r.o_x = (r.o_m + (size_t)len * 4 + 7) & ~(size_t)7;
+    r.o_c = r.o_x + (size_t)len * (NX * 8);
+    r.o_P = r.o_c + (size_t)len * 8;
+    r.o_fl = r.o_P + (size_t)len * ((size_t)NP * PB);
+    r.stride = (r.o_fl + (size_t)len + 15) & ~(size_t)15;
+    return r;
+}
+__global__ void chains_kernel(const ChainArgs a, const CtLayers ct, const int32_t* start, int count, char* out, int PB) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const ChainRec r = chain_rec(a.max_len, PB);
+    char* o = out + (size_t)i * r.stride;
+    const int n = chain_walk(a, ct, start[i], (int32_t*)(o + 8), (int32_t*)(o + r.o_m), (double*)(o + r.o_x), (double*)(o + r.o_c), PB == 4 ? (float*)(o + r.o_P) : nullptr,
+                             PB == 8 ? (double*)(o + r.o_P) : nullptr, (uint8_t*)(o + r.o_fl));
+    *(int32_t*)o = n;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -343,6 +368,10 @@ struct Forest {
     hipEvent_t z_guard_ev[2] = {nullptr, nullptr}; long long z_count = 0; int z_guard_due = -1;      // consumer guard of the staging ring (step_host_impl)
     // small staging for add_targets / leaves / chain
     Scratch stage_dev; void* stage_host = nullptr; size_t stage_host_bytes = 0;
+    // mht_forest_chains_begin: a ring of host-mapped pinned blocks, one per ticket (a ticket lives until CHAIN_SLOTS later ones were issued)
+    static constexpr int CHAIN_SLOTS = 8;
+    struct ChainSlot { char* host = nullptr; char* dev = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; long long ticket = -1; int count = 0, len = 0, pb = 4; bool pending = false; };
+    ChainSlot chain_slots[CHAIN_SLOTS]; long long chain_next = 0;
     // host-side mirrors
     int scan = 0; int nT_ub = 0; int L_ub = 0; bool report_pending = false; int last_M = 0; bool dead = false;
     int nT_ub_prev = 0;      // ... of the scan before it (grid of a grow launch that carries that scan's commit)
@@ -485,6 +514,7 @@ void forest_destroy(mht_ctx* ctx) {
     if (f->hint_host) (void)hipHostFree(f->hint_host);
     if (f->bhint_host) (void)hipHostFree(f->bhint_host);
     if (f->stage_host) (void)hipHostFree(f->stage_host);
+    for (auto& cs : f->chain_slots) { if (cs.ev) (void)hipEventDestroy(cs.ev); if (cs.host) (void)hipHostFree(cs.host); }
     f->stage_dev.release();
     if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
     if (f->grow_ev) (void)hipEventDestroy(f->grow_ev);
@@ -2104,6 +2134,16 @@ extern "C" int mht_forest_leaves_f64(mht_ctx* ctx, int32_t capacity, double* x, 
     return forest_leaves_impl(ctx, capacity, x, P, 8, cnllr, meas, target, id, node, flags, n_out);
 }
 
+static void chain_args_of(Forest* f, ChainArgs& a, CtLayers& cl) {
+    for (int k = 0; k < f->R; ++k) { a.layers[k] = f->layer[k]; a.lgen[k] = f->layer_gen[k]; }
+    a.vt[0] = f->vts[0]; a.vt[1] = f->vts[1];
+    a.R = f->R;
+    if (f->ct) {
+        cl.on = 1;
+        for (int k = 0; k < f->R; ++k) { cl.Pbar[k] = f->ct_Pbar[k]; cl.Phat[k] = f->ct_Phat[k]; cl.Proot[k] = f->ct_Proot[k]; }
+    }
+}
+
 static int forest_chain_impl(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                              double* x, double* cnllr, void* P, int PB, uint8_t* flags, int32_t* n_out) {
     MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_chain: null argument");
@@ -2124,16 +2164,11 @@ static int forest_chain_impl(mht_ctx* ctx, int32_t scan, int32_t node, int32_t m
     char* d = static_cast<char*>(f->stage_dev.ptr);
     char* h = static_cast<char*>(f->stage_host);
     ChainArgs a = {};
-    for (int k = 0; k < f->R; ++k) { a.layers[k] = f->layer[k]; a.lgen[k] = f->layer_gen[k]; }
-    a.vt[0] = f->vts[0]; a.vt[1] = f->vts[1];
-    a.R = f->R; a.scan = scan; a.node = node; a.max_len = len;
+    CtLayers cl = {};
+    chain_args_of(f, a, cl);
+    a.scan = scan; a.node = node; a.max_len = len;
     a.nodes = (int32_t*)(d + o_n); a.meas = (int32_t*)(d + o_m); a.x = (double*)(d + o_x); a.cnllr = (double*)(d + o_c);
     a.P = PB == 4 ? (float*)(d + o_P) : nullptr; a.P64 = PB == 8 ? (double*)(d + o_P) : nullptr; a.flags = (uint8_t*)(d + o_fl); a.n_out = (int32_t*)(d + o_k);
-    CtLayers cl = {};
-    if (f->ct) {
-        cl.on = 1;
-        for (int k = 0; k < f->R; ++k) { cl.Pbar[k] = f->ct_Pbar[k]; cl.Phat[k] = f->ct_Phat[k]; cl.Proot[k] = f->ct_Proot[k]; }
-    }
     hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a, cl);
     MHT_HIP_CHECK(hipGetLastError());
     MHT_HIP_CHECK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
@@ -2155,6 +2190,67 @@ extern "C" int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_
 extern "C" int mht_forest_chain_f64(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                                     double* x, double* cnllr, double* P, uint8_t* flags, int32_t* n_out) {
     return forest_chain_impl(ctx, scan, node, max_len, nodes, meas, x, cnllr, P, 8, flags, n_out);
+}
+
+extern "C" int mht_forest_chains_begin(mht_ctx* ctx, int32_t scan, const int32_t* start_nodes, int32_t count, int32_t max_len, int32_t f64, int64_t* ticket) {
+    MHT_REQUIRE(ctx && ctx->forest && start_nodes && ticket, "mht_forest_chains_begin: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(scan >= 0 && scan <= f->scan && f->scan - scan < f->R, "mht_forest_chains_begin: scan %d is outside the window", scan);
+    MHT_REQUIRE(count >= 1 && count <= f->Tcap && max_len >= 1, "mht_forest_chains_begin: bad count / max_len");
+    for (int i = 0; i < count; ++i) MHT_REQUIRE(start_nodes[i] >= 0 && start_nodes[i] < f->Ncap, "mht_forest_chains_begin: bad node %d", start_nodes[i]);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    // (a layer older than the newest scan's is final: its commit is queued at the latest with the newest scan's grow launch, and this launch runs behind it)
+    if (scan == f->scan) { const int rc = flush_commit(ctx, f); if (rc) return rc; }
+    int len = max_len;
+    const int avail = f->R - (f->scan - scan);   // layers still in the ring going backwards
+    if (len > avail) len = avail;
+    const int PB = f64 ? 8 : 4;
+    const ChainRec r = chain_rec(len, PB);
+    const size_t head = ((size_t)count * 4 + 15) & ~(size_t)15, total = head + (size_t)count * r.stride;
+    Forest::ChainSlot& cs = f->chain_slots[f->chain_next % Forest::CHAIN_SLOTS];
+    if (!cs.ev) MHT_HIP_CHECK(hipEventCreateWithFlags(&cs.ev, hipEventDisableTiming));
+    if (cs.pending) { MHT_HIP_CHECK(hipEventSynchronize(cs.ev)); cs.pending = false; }      // (the ticket that owned this block expires)
+    if (cs.bytes < total) {
+        if (cs.host) MHT_HIP_CHECK(hipHostFree(cs.host));
+        cs.host = nullptr; cs.bytes = 0;
+        MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cs.host), total + 4096, hipHostMallocMapped));
+        MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&cs.dev), cs.host, 0));
+        cs.bytes = total + 4096;
+    }
+    memcpy(cs.host, start_nodes, (size_t)count * 4);
+    ChainArgs a = {};
+    CtLayers cl = {};
+    chain_args_of(f, a, cl);
+    a.scan = scan; a.max_len = len;
+    hipLaunchKernelGGL(chains_kernel, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, a, cl, reinterpret_cast<const int32_t*>(cs.dev), count, cs.dev + head, PB);
+    MHT_HIP_CHECK(hipGetLastError());
+    MHT_HIP_CHECK(hipEventRecord(cs.ev, ctx->stream));
+    cs.pending = true; cs.count = count; cs.len = len; cs.pb = PB; cs.ticket = f->chain_next;
+    *ticket = f->chain_next++;
+    return MHT_OK;
+}
+
+extern "C" int mht_forest_chains_fetch(mht_ctx* ctx, int64_t ticket, int32_t index, int32_t* nodes, int32_t* meas, double* x, double* cnllr, void* P, uint8_t* flags,
+                                       int32_t* n_out) {
+    MHT_REQUIRE(ctx && ctx->forest && n_out, "mht_forest_chains_fetch: null argument");
+    Forest* f = ctx->forest;
+    MHT_REQUIRE(ticket >= 0 && ticket < f->chain_next, "mht_forest_chains_fetch: unknown ticket %lld", (long long)ticket);
+    Forest::ChainSlot& cs = f->chain_slots[ticket % Forest::CHAIN_SLOTS];
+    MHT_REQUIRE(cs.ticket == ticket, "mht_forest_chains_fetch: ticket %lld has expired (%d later ones were issued)", (long long)ticket, Forest::CHAIN_SLOTS);
+    MHT_REQUIRE(index >= 0 && index < cs.count, "mht_forest_chains_fetch: chain %d of %d", index, cs.count);
+    MHT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (cs.pending) { MHT_HIP_CHECK(hipEventSynchronize(cs.ev)); cs.pending = false; }
+    const ChainRec r = chain_rec(cs.len, cs.pb);
+    const char* o = cs.host + (((size_t)cs.count * 4 + 15) & ~(size_t)15) + (size_t)index * r.stride;
+    const int n = *(const int32_t*)o;
+    *n_out = n;
+    if (nodes) memcpy(nodes, o + 8, (size_t)n * 4);
+    if (meas) memcpy(meas, o + r.o_m, (size_t)n * 4);
+    if (x) memcpy(x, o + r.o_x, (size_t)n * (NX * 8));
+    if (cnllr) memcpy(cnllr, o + r.o_c, (size_t)n * 8);
+    if (P) memcpy(P, o + r.o_P, (size_t)n * ((size_t)NP * cs.pb));
+    if (flags) memcpy(flags, o + r.o_fl, (size_t)n);
+    return MHT_OK;
 }
 
 extern "C" int mht_forest_set_timing(mht_ctx* ctx, int32_t enable) {

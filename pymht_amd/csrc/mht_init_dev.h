@@ -669,7 +669,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         if (st.overflow && a.forest_overflow) *a.forest_overflow = 1;
 #ifdef MHT_INIT_STAMPS
         init_t[8] = wall_clock64();
-        if (a.scan_no == 200 || a.scan_no == 201)
+        if (a.scan_no == 100 || a.scan_no == 101 || a.scan_no == 200 || a.scan_no == 201)
             printf("[init %d] nU %d n_seed %d: head %.2f | phase1 %.2f | unused' %.2f | pairs %.2f | gnn %.2f | new tracks %.2f | leftovers %.2f | merge+end %.2f | total %.2f us\n", a.scan_no, nU, n_seed,
                    1e-2 * (double)(init_t[1] - init_t[0]), 1e-2 * (double)(init_t[2] - init_t[1]), 1e-2 * (double)(init_t[3] - init_t[2]), 1e-2 * (double)(init_t[4] - init_t[3]),
                    1e-2 * (double)(init_t[5] - init_t[4]), 1e-2 * (double)(init_t[6] - init_t[5]), 1e-2 * (double)(init_t[7] - init_t[6]), 1e-2 * (double)(init_t[8] - init_t[7]), 1e-2 * (double)(init_t[8] - init_t[0]));

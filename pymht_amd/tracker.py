@@ -198,7 +198,9 @@ class Tracker():
         self._history = []          # chunks of committed roots: dict(id, scan, node, meas, x, cnllr, time) arrays
         self._history_mmsi = []     # AIS forest: the identities of those roots, chunk by chunk (0 = none)
         self._last_ais_scan = -(1 << 30)      # last scan that carried AIS messages
-        self._dead_chunks = []      # (records, scan time, scan number, z) of terminated tracks
+        self._dead_chunks = []      # [records, scan time, scan number, z, window chains or None, ticket, fold number] of terminated tracks
+        self._chain_pending = []    # the entries of _dead_chunks whose chains are still on their way (mht_forest_chains_begin)
+        self._fold_no = 0
         self._birth = {}            # Target.ID -> (time, scan, x, P, meas, measurement, status)
         self._views = {}            # cache of lazily built views, dropped at every scan
         self._scanStatsLog = [] if kwargs.get('logScanStats', False) else None      # lastScanStats (+ nTargets) of every scan (property scanStatsLog)
@@ -399,6 +401,9 @@ class Tracker():
         in pays a few microseconds per scan here, not thirty."""
         t_fold = time.perf_counter()
         t_init = time.time()
+        self._fold_no += 1
+        if self._chain_pending:      # (chains begun two folds ago were gathered in front of the scan this fold's report belongs to)
+            self._resolve_chains(self._fold_no - 2)
         rep = self._rep
         rc = self._lib.mht_forest_report_get(self._ctx.handle, which, self._rep_ref)
         if rc == _lib.MHT_E_LIMIT:
@@ -544,8 +549,15 @@ class Tracker():
             # terminated tracks keep their whole history (the reference's _pruneEverythingExceptHistory): the window ancestors of the
             # last selected node are fetched now, while they are still in the device ring
             dead = recs[~alive]
-            chains = [self._window_chain(scanNumber, int(r["sel_node"])) for r in dead]
-            self._dead_chunks.append((dead, scanTime, scanNumber, z, chains))
+            # (ONE gather launch queued behind the scans in flight, fetched two folds later -- it has long arrived then -- or by whoever
+            # looks at the terminated tracks first: a fetch per track stopped the stream for a round trip through the device, 130 us each)
+            ticket = C.c_int64(0)
+            start = np.ascontiguousarray(dead["sel_node"], dtype=np.int32)
+            _lib.check(self._lib.mht_forest_chains_begin(self._ctx.handle, scanNumber, start.ctypes.data_as(C.c_void_p), len(start), self._cfg.n_scan + 2,
+                                                         1 if self._ais else 0, C.byref(ticket)))
+            entry = [dead, scanTime, scanNumber, z, None, ticket.value, self._fold_no]
+            self._dead_chunks.append(entry)
+            self._chain_pending.append(entry)
             live = recs[alive]
             moved = live["root_scan"] != prev["root_scan"][alive]
         if moved.any():      # the root of these targets advanced: the new roots join the committed history
@@ -704,8 +716,9 @@ class Tracker():
     @property
     def __terminatedTargets__(self):
         self._drain()
+        self._resolve_chains()
         out = []
-        for recs, scanTime, scanNumber, z, chains in self._dead_chunks:
+        for recs, scanTime, scanNumber, z, chains, _, _ in self._dead_chunks:
             for r, chain in zip(recs, chains):
                 v = self._node_view(r, scanTime, scanNumber, z)
                 tid, rs = int(r["id"]), int(r["root_scan"])
@@ -778,6 +791,33 @@ class Tracker():
         _lib.check(self._lib.mht_forest_chain(self._ctx.handle, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P), C.byref(n)))
         k = n.value
         return nodes[:k], meas[:k], x[:k], cn[:k], P[:k]
+
+    def _resolve_chains(self, older_than=None):
+        """Take the window chains of terminated tracks out of the library's pinned blocks (mht_forest_chains_fetch): all that are pending,
+        or those begun before fold `older_than` (their gather launch ran long ago: no wait)."""
+        while self._chain_pending and (older_than is None or self._chain_pending[0][6] < older_than):
+            entry = self._chain_pending.pop(0)
+            n_max = self._cfg.n_scan + 2
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            chains = []
+            for i in range(len(entry[0])):
+                nodes = np.zeros(n_max, dtype=np.int32)
+                meas = np.zeros(n_max, dtype=np.int32)
+                x = np.zeros((n_max, self.nx))
+                cn = np.zeros(n_max)
+                n = C.c_int32(0)
+                if self._ais:      # (dtypes per node as _window_chain)
+                    P64 = np.zeros((n_max, self.nx * self.nx))
+                    fl = np.zeros(n_max, dtype=np.uint8)
+                    _lib.check(self._lib.mht_forest_chains_fetch(self._ctx.handle, entry[5], i, p(nodes), p(meas), p(x), p(cn), p(P64), p(fl), C.byref(n)))
+                    k = n.value
+                    chains.append((nodes[:k], meas[:k], x[:k], cn[:k], [P64[j] if (fl[j] & _F_COV_F64) else P64[j].astype(np.float32) for j in range(k)]))
+                else:
+                    P = np.zeros((n_max, self.nx * self.nx), dtype=np.float32)
+                    _lib.check(self._lib.mht_forest_chains_fetch(self._ctx.handle, entry[5], i, p(nodes), p(meas), p(x), p(cn), p(P), None, C.byref(n)))
+                    k = n.value
+                    chains.append((nodes[:k], meas[:k], x[:k], cn[:k], P[:k]))
+            entry[4] = chains
 
     def _link_chain(self, view, target_id, chain, root_scan, root_node, root_view):
         """Hang the window ancestors `chain` under `view`; where the chain reaches (root_scan, root_node) it continues with
