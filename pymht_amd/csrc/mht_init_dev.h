@@ -64,7 +64,7 @@ struct InitArgs {
 // the float32 elimination of rounds 1-2 (a decision test only: d' S^-1 d <= 1).
 // LU with partial pivoting of an n x n float32 system (n <= 4), as LAPACK sgetrf/sgetri order it closely enough: inverse by solving
 // for the unit columns
-static __device__ inline bool inv_small_f32(const float* a_in, int n, float* out) {
+static __device__ __attribute__((noinline)) bool inv_small_f32(const float* a_in, int n, float* out) {
     float a[16], b[16];
     for (int i = 0; i < n * n; ++i) { a[i] = a_in[i]; b[i] = 0.f; }
     for (int i = 0; i < n; ++i) b[i * n + i] = 1.f;
@@ -91,8 +91,15 @@ static __device__ inline bool inv_small_f32(const float* a_in, int n, float* out
 
 
 static __device__ inline bool inv_small(const float* s, int n, float* out) {
-    if (n != 4 || s[1] != 0.f || s[3] != 0.f || s[4] != 0.f || s[6] != 0.f || s[9] != 0.f || s[11] != 0.f || s[12] != 0.f || s[14] != 0.f)
-        return inv_small_f32(s, n, out);
+    if (n != 4 || s[1] != 0.f || s[3] != 0.f || s[4] != 0.f || s[6] != 0.f || s[9] != 0.f || s[11] != 0.f || s[12] != 0.f || s[14] != 0.f) {
+        // (a real call, through copies: the general elimination indexes its arrays dynamically -- inlined, every call site carried its 128 bytes of
+        // scratch and ~60 live registers; with the caller's own arrays as arguments they would have to live in memory on the fast path as well)
+        float ti[16], to[16];
+        for (int e = 0; e < n * n; ++e) ti[e] = s[e];
+        const bool ok = inv_small_f32(ti, n, to);
+        for (int e = 0; e < n * n; ++e) out[e] = to[e];
+        return ok;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) out[e] = 0.f;
 #pragma unroll
@@ -211,6 +218,17 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
 #else
 #define INIT_STAMP(k)
 #endif
+__device__ __forceinline__ unsigned long long lt_mask64(int lane) { return (1ull << lane) - 1ull; }
+// PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1.  deltaState.T.dot(S_inv).dot(deltaState) (m_of_n.py:207): vector x matrix = gemv (two
+// interleaved FMA chains per column, added), then vector . vector = sdot (float32 products summed in float64, one rounding at the end)
+__device__ __forceinline__ bool prelim_similar(float d0, float d1, float d2, float d3, const float (&Si)[16]) {
+    const float t0 = fmaf(d2, Si[8], d0 * Si[0]) + fmaf(d3, Si[12], d1 * Si[4]), t1 = fmaf(d2, Si[9], d0 * Si[1]) + fmaf(d3, Si[13], d1 * Si[5]);
+    const float t2 = fmaf(d2, Si[10], d0 * Si[2]) + fmaf(d3, Si[14], d1 * Si[6]), t3 = fmaf(d2, Si[11], d0 * Si[3]) + fmaf(d3, Si[15], d1 * Si[7]);
+    double sacc = (double)(t0 * d0);
+    sacc += (double)(t1 * d1); sacc += (double)(t2 * d2); sacc += (double)(t3 * d3);
+    return (float)sacc <= 1.0f;
+}
+
 template <bool AIS = true, int NT = INIT_THREADS>
 static __device__ void initiator_body(const InitArgs& a) {
 #ifdef MHT_INIT_STAMPS
@@ -532,15 +550,22 @@ static __device__ void initiator_body(const InitArgs& a) {
         INIT_STAMP(4);
         gnn_solve<NT>(a, n_seed, nU2, E2);
         INIT_STAMP(5);
-        // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference)
+        // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference: m_of_n.py:440-452).
+        // 64 initiators at a time (every wavefront fetches the same matches and each lane forms its own candidate):
+        //   (a) the block's candidates against the tracks there were at the block's start -- all threads, a track's S^-1 once for all candidates;
+        //   (b) the order dependence INSIDE the block -- a candidate is also tested against the block's earlier candidates that were kept, whose
+        //       covariance is P0 -- resolved by wavefront 0 with shuffles, no barrier;  (c) the kept ones appended.
+        // Two barriers per 64 initiators; until round 6 it was three per MATCH with a global round trip between them (38-43 of the kernel's
+        // 120 us on a stream with ~60 initiators per scan, profiles/r06_initiator_phases.txt).
         __shared__ int s_sn[4];      // (16 bytes, see s_cnt)
-        int& s_similar = s_sn[0];
+        unsigned* s_old = reinterpret_cast<unsigned*>(&s_sn[2]);      // [2] bit b: candidate b of the block is similar to a track kept before the block
+        __shared__ float s_si0[16];  // inv(P0 + R_ais), [0] of s_sn: it exists
         int& s_np = s_sn[1];
         if (tid == 0) s_np = n_keep;
         __syncthreads();
-        // (the matches are fetched 64 initiators at a time -- every wavefront reads the same words -- and each lane forms its own
-        // candidate: walking match_row[] one element at a time was one dependent global round trip per initiator, matched or not,
-        // and four more per match: half of the kernel's time on the headline stream with its ~40 initiators per scan)
+        bool have_si0 = false;
+        // PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1.  deltaState.T.dot(S_inv).dot(deltaState) (m_of_n.py:207): vector x matrix =
+        // gemv (two interleaved FMA chains per column, added), then vector . vector = sdot (float32 products summed in float64, one rounding at the end)
         for (int base = 0; base < n_seed; base += 64) {
           const int i_l = base + lane;
           const int qv = (i_l < n_seed) ? a.match_row[i_l] : -1;      // (global memory, written before the barrier)
@@ -550,41 +575,70 @@ static __device__ void initiator_body(const InitArgs& a) {
               c0 = a.z[2 * j]; c1 = a.z[2 * j + 1];
               c2 = (c0 - a.seeds[2 * i_l]) / (float)dts; c3 = (c1 - a.seeds[2 * i_l + 1]) / (float)dts;
           }
-          unsigned long long todo = __ballot(qv >= 0);
-          while (todo) {                                        // uniform: initiator order
-            const int bsel = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            float cand[4];
-            cand[0] = __shfl(c0, bsel); cand[1] = __shfl(c1, bsel); cand[2] = __shfl(c2, bsel); cand[3] = __shfl(c3, bsel);
-            if (tid == 0) s_similar = 0;
-            __syncthreads();
-            const int np = s_np;
-            for (int p = tid; p < np; p += NT) {     // PreliminaryTrack.compareSimilarity: d' inv(P + R_ais) d <= 1
-                float d[4], S[16], Si[16];
-                for (int e = 0; e < 4; ++e) d[e] = a.pstate2[(size_t)p * 4 + e] - cand[e];
-                for (int e = 0; e < 16; ++e) S[e] = a.pcov2[(size_t)p * 16 + e] + ((e % 5 == 0) ? 9.0f : 0.f);
-                if (inv_small(S, 4, Si)) {
-                    // deltaState.T.dot(S_inv).dot(deltaState) (m_of_n.py:207): vector x matrix = gemv (two interleaved FMA chains per
-                    // column, added), then vector . vector = sdot (float32 products summed in float64, one rounding at the end)
-                    float t[4];
-                    for (int c = 0; c < 4; ++c) t[c] = fmaf(d[2], Si[8 + c], d[0] * Si[c]) + fmaf(d[3], Si[12 + c], d[1] * Si[4 + c]);
-                    double sacc = (double)(t[0] * d[0]);
-                    for (int k = 1; k < 4; ++k) sacc += (double)(t[k] * d[k]);
-                    const float sim = (float)sacc;
-                    if (sim <= 1.0f) s_similar = 1;
-                }
-            }
-            __syncthreads();
-            if (!s_similar) {
-                if (np < a.Pcap) {
-                    if (tid < 4) a.pstate2[(size_t)np * 4 + tid] = cand[tid];
-                    if (tid < 16) a.pcov2[(size_t)np * 16 + tid] = a.P0[tid];
-                    if (tid == 0) { a.pn2[np] = 0; a.pm2[np] = 0; if (a.pmmsi2) a.pmmsi2[np] = 0; s_np = np + 1; }
-                } else if (tid == 0) st.overflow = 1;
-            }
-            __threadfence_block();
-            __syncthreads();
+          const unsigned long long todo = __ballot(qv >= 0);      // (uniform: the same in every wavefront)
+          if (todo == 0ull) continue;
+          if (tid < 2) s_old[tid] = 0u;
+          __syncthreads();
+          const int np0 = s_np;
+          {   // (a)
+              unsigned long long hit = 0ull;
+              // (uniform bound: the shuffles below need every lane of the wavefront; lanes beyond the last track redo track 0.  One slot more than
+              // there are tracks: its thread inverts S of a NEW track, covariance P0, for (b) -- through this call site: inv_small's general
+              // fallback indexes dynamically, every inlined copy is another 128 bytes of scratch per lane)
+#pragma nounroll
+              for (int pb = 0; pb <= np0; pb += NT) {
+                  const bool have = pb + tid < np0, virt = pb + tid == np0 && !have_si0;
+                  const int p = have ? pb + tid : 0;
+                  float xs[4], S[16], Si[16];
+                  for (int e = 0; e < 4; ++e) xs[e] = a.pstate2[(size_t)p * 4 + e];
+                  for (int e = 0; e < 16; ++e) S[e] = (virt ? a.P0[e] : a.pcov2[(size_t)p * 16 + e]) + ((e % 5 == 0) ? 9.0f : 0.f);
+                  const bool inv_ok = inv_small(S, 4, Si);
+                  if (virt) { for (int e = 0; e < 16; ++e) s_si0[e] = Si[e]; s_sn[0] = inv_ok ? 1 : 0; }
+                  const bool ok = have && inv_ok;
+                  unsigned long long td = todo;
+#pragma nounroll
+                  while (td) {      // (uniform)
+                      const int b = __ffsll((long long)td) - 1;
+                      td &= td - 1ull;
+                      const float d[4] = {xs[0] - __shfl(c0, b), xs[1] - __shfl(c1, b), xs[2] - __shfl(c2, b), xs[3] - __shfl(c3, b)};
+                      if (ok && prelim_similar(d[0], d[1], d[2], d[3], Si)) hit |= 1ull << b;
+                  }
+              }
+              unsigned lo = (unsigned)hit, hi = (unsigned)(hit >> 32);
+              for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+              if (lane == 0 && (lo | hi)) { if (lo) atomicOr(&s_old[0], lo); if (hi) atomicOr(&s_old[1], hi); }
           }
+          __syncthreads();
+          if (tid < 64) {   // (b), (c): wavefront 0
+              const unsigned long long old = ((unsigned long long)s_old[1] << 32) | s_old[0];
+              float Si0[16];                                 // a new track's covariance is P0: S = P0 + R_ais, the same for all of them
+              for (int e = 0; e < 16; ++e) Si0[e] = s_si0[e];
+              const bool inv0 = s_sn[0] != 0;
+              bool mine = qv >= 0 && !((old >> lane) & 1ull);      // still a candidate
+              unsigned long long td = todo & ~old;
+              while (td) {      // (uniform) in initiator order: candidate b is kept; later candidates similar to it are not
+                  const int b = __ffsll((long long)td) - 1;
+                  td &= td - 1ull;
+                  const float d[4] = {__shfl(c0, b) - c0, __shfl(c1, b) - c1, __shfl(c2, b) - c2, __shfl(c3, b) - c3};      // (track - candidate)
+                  if (mine && lane > b && inv0 && prelim_similar(d[0], d[1], d[2], d[3], Si0)) mine = false;
+                  td &= __ballot(mine);
+              }
+              const unsigned long long kept = __ballot(mine);
+              const int n_new = __popcll(kept);
+              if (mine) {
+                  const int np = np0 + __popcll(kept & lt_mask64(lane));
+                  if (np < a.Pcap) {
+                      const float cand[4] = {c0, c1, c2, c3};
+                      for (int e = 0; e < 4; ++e) a.pstate2[(size_t)np * 4 + e] = cand[e];
+                      for (int e = 0; e < 16; ++e) a.pcov2[(size_t)np * 16 + e] = a.P0[e];
+                      a.pn2[np] = 0; a.pm2[np] = 0; if (a.pmmsi2) a.pmmsi2[np] = 0;
+                  } else st.overflow = 1;
+              }
+              if (lane == 0) s_np = (np0 + n_new < a.Pcap) ? np0 + n_new : a.Pcap;
+          }
+          have_si0 = true;
+          __threadfence_block();
+          __syncthreads();
         }
         n_pre_now = s_np;
     }
