@@ -519,12 +519,15 @@ def main():
     # ---- timed replay ---------------------------------------------------------------------------------------------
     rp = Replay(sc, births, local)
     if strong:          # one tracker over all ranks: cluster c's ILP on rank c % world, selections all-reduced (MAX) every scan
-        sel_rel = torch.full((rp.trk._cfg.max_targets,), -1, dtype=torch.int32, device=rp.trk._ctx.device)
+        import ctypes as C_
+        nw = C_.c_int32(0)      # (the exchange block: selections + the ranks' files for a giant component searched by teams across the ranks)
+        rp._lib_mod.check(rp.lib.mht_forest_sharded_words(rp.h, world, C_.byref(nw)))
+        sel_rel = torch.full((nw.value,), -1, dtype=torch.int32, device=rp.trk._ctx.device)
 
         def one_scan():
             k = rp.k
-            rp._lib_mod.check(rp.lib.mht_forest_step_sharded_begin(rp.h, rp.z.data_ptr() + int(rp.zoff[k]) * 8, rp.M[k], world, rank,
-                                                                   sel_rel.data_ptr()))
+            rp._lib_mod.check(rp.lib.mht_forest_step_sharded_begin2(rp.h, rp.z.data_ptr() + int(rp.zoff[k]) * 8, rp.M[k], world, rank,
+                                                                    sel_rel.data_ptr(), nw.value))
             parallel.merge_selections(sel_rel, dist)
             rp._lib_mod.check(rp.lib.mht_forest_step_sharded_end(rp.h, sel_rel.data_ptr()))
             rp.births_after_step()

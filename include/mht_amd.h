@@ -381,7 +381,7 @@ int mht_forest_set_timing(mht_ctx* ctx, int32_t enable);
 int mht_forest_stage_times(mht_ctx* ctx, float* ms5, int32_t* n_steps);
 /* Tooling: copy a named internal per-cluster array of the last step to the host ("cl_status", "cl_iters",
  * "cl_nodes", "cl_time" [2 int32 per cluster: setup / total in 10 ns ticks], "cl_ptr", "cl_members", "multi_list",
- * "cl_counts", "tchild").  Synchronises. */
+ * "cl_counts", "cl_owner", "team_list", "tchild").  Synchronises. */
 int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host, int64_t bytes);
 /* Ancestor chain of one node: walks parents from (scan, node) towards the root of time, at most max_len steps
  * (bounded by the ring of n_scan + 4 layers: with k scans queued behind `scan`, n_scan + 4 - k layers are left).  Outputs host arrays
@@ -452,6 +452,13 @@ int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t
  * Asynchronous on the ctx stream. */
 int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel);
 int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel);
+/* A gating graph that is ONE big component on several devices (tracker.py:1155-1217 is one CBC call; any exact split will do): with an
+ * exchange block of mht_forest_sharded_words() int32 -- [max_targets] selections as above, then [shard_n][8][260] files -- the clusters of
+ * >= 24 targets (at most 8 per scan) are searched by ALL devices: the subtrees of the branch and bound are dealt out over every device's
+ * workgroups, every device files its best selection and its value in its own slots (-1 = empty), the SAME element-wise MAX all-reduce over
+ * the whole block gathers the files, and mht_forest_step_sharded_end (given the block) lets the smallest value win -- on every device alike. */
+int mht_forest_sharded_words(mht_ctx* ctx, int32_t shard_n, int32_t* n_words);
+int mht_forest_step_sharded_begin2(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* xch, int32_t n_words);
 
 /* One radar scan of Tracker.addMeasurementList (tracker.py:162-307) in one call, nothing waits for the device: steps 1-6
  * (mht_forest_step_host), step 7 (mht_forest_initiate, skipped when `in` is NULL), mht_forest_report_begin.

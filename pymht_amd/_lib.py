@@ -172,6 +172,8 @@ def _declare(lib, nx=4):
         "mht_forest_scan": [vp, vp, vp, i32, dbl],
         "mht_forest_step_sharded_begin": [vp, vp, i32, i32, i32, vp],
         "mht_forest_step_sharded_end": [vp, vp],
+        "mht_forest_sharded_words": [vp, i32, C.POINTER(i32)],
+        "mht_forest_step_sharded_begin2": [vp, vp, i32, i32, i32, vp, i32],
         "mht_group_create": [C.POINTER(vp), i32, C.POINTER(vp)],
         "mht_group_step": [vp, C.POINTER(vp), C.POINTER(i32)],
         "mht_group_destroy": [vp],

@@ -1128,7 +1128,14 @@ __device__ __forceinline__ bool reducible(const BlpArgs& a, const GStore& s, int
 // Solves one cluster; on return ub_sel[k] holds the chosen (policy-local) column of member k.
 // `ub` in: cost of a feasible selection already sitting in s.ub_sel[] (DINF: none); out: cost of the selection returned there.
 // A member of a team (see mht_kernels.h: TEAM_*): q of W, the team's shared incumbent word.  W = 1: a cluster searched by its own workgroup only.
-struct Team { int q, W; unsigned long long* gub; };
+struct Team {
+    int q, W; unsigned long long* gub;
+    // a team that spans the devices of a cluster-sharded step (BlpArgs::shard_team): the subtrees are dealt out over Wg = W x devices members,
+    // this one is number qg; the incumbent word and the members' files stay per device, the devices' best selections meet in the exchange
+    int qg, Wg;
+    __device__ Team(int q_, int W_, unsigned long long* g_) : q(q_), W(W_), gub(g_), qg(q_), Wg(W_) {}
+    __device__ Team(int q_, int W_, unsigned long long* g_, int qg_, int Wg_) : q(q_), W(W_), gub(g_), qg(qg_), Wg(Wg_) {}
+};
 #ifndef MHT_TEAM_LEVEL
 #define MHT_TEAM_LEVEL 5
 #endif
@@ -1152,7 +1159,7 @@ __device__ __forceinline__ unsigned team_hash(int c0, int c1) {      // (level-0
     return h;
 }
 template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& a, const S& s, int K, Red* r, int& status, int& iters, int& nodes, unsigned long long* stamp,
-                                                                 double& ub, const Team tm = Team{0, 1, nullptr}) {
+                                                                 double& ub, const Team tm = Team(0, 1, nullptr)) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double& UB = ub;
     double best_LB = -DINF, theta = 1.0, utot = 0.0;
@@ -1405,7 +1412,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
     // published).  The root node is processed with the member's own (deterministic) incumbent, so that every member sees the same
     // prices and the same level-0 candidates; from level 1 on the shared value prunes.
     double own = UB;
-    const bool team = tm.W > 1 && tm.gub != nullptr;
+    const bool team = tm.Wg > 1 && tm.gub != nullptr;
     if (team && tid == 0 && UB < DINF) atomicMin(tm.gub, enum_key(UB));
     while (true) {
         if (team && enter && level >= 1) {
@@ -1600,7 +1607,7 @@ template <typename S> __device__ __forceinline__ void solve_core(const BlpArgs& 
             unsigned hsh = 0x9E3779B9u;
             for (int l = 0; l < team_level(s); ++l) hsh = team_hash((int)hsh, s.to_global(s.ch[l]));
             hsh = team_hash((int)hsh, s.to_global(bi));
-            foreign = hsh % (unsigned)tm.W != (unsigned)tm.q;
+            foreign = hsh % (unsigned)tm.Wg != (unsigned)tm.qg;
         }
         if (foreign) {
             // another member's subtree: step over the candidate (the enumeration state moves on, nothing is fixed)
@@ -1778,7 +1785,7 @@ __device__ __forceinline__ TgtPre load_target_cr(const BlpArgs& a, int t, const 
 }
 // my_t: member `threadIdx.x` of the cluster if the caller has it at hand (-1: read from the member list), pre_in: its record if already fetched
 __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, unsigned long long* uw, Red* r, unsigned char* lds,
-                                              const Team tm = Team{0, 1, nullptr}, const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr, const int dbg_bx = -1) {
+                                              const Team tm = Team(0, 1, nullptr), const int team_idx = -1, const int my_t = -1, const TgtPre* pre_in = nullptr, const int dbg_bx = -1) {
     const int tid = threadIdx.x;
     const int c = cr.c;
     const int K = cr.K;
@@ -1960,19 +1967,20 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
     bool use_lds = lds_cols && nR < L_MAXR;
     // a team searches a cluster that is solved out of LDS from the start (every member holds its own copy); a cluster on HBM scratch
     // (shared) is its owner's alone
-    bool team = tm.W > 1 && use_lds;
+    bool team = tm.Wg > 1 && use_lds;
     // ... and a cluster on HBM scratch when every member has a copy of that scratch to itself (BlpArgs::tm_sm / tm_ss: prices, usage and
     // marks by measurement node, the per-member tables): the members replicate the HBM dual phase as well, reach the same decision about
     // reduced-cost fixing (same prices, same feasible point), rebuild the same LDS problem or -- if the survivors do not fit -- share the
     // branch and bound on HBM.  (Round 3 first handed the owner's reduced problem over to waiting members; a cluster that could not be
     // reduced -- 44 targets, 7 831 columns: 14 900 nodes at 0.25 ms -- stayed with one workgroup for 3.7 s.)
-    const bool team_hbm = tm.W > 1 && !use_lds && a.tm_sm > 0 && K <= TEAM_SEL;
+    const bool team_hbm = tm.Wg > 1 && !use_lds && a.tm_sm > 0 && K <= TEAM_SEL;
     if (tm.q > 0 && !team && !team_hbm) return;
     const int32_t* final_sel = nullptr;      // team search: the best member's selection (global columns), read by the last finisher
     int nHl = nH;      // columns of the LDS store (fewer than nH after a reduction)
     double ub_reduced = DINF;
     // every member of a team files what it found (global columns); the LAST one to finish takes the best of all -- value, then the lowest
     // member -- and goes on to the cluster's epilogue (true), the others are done (false).  Nobody waits.
+    double best_io = DINF;      // (team_file: the value of the selection the last finisher goes on with)
     auto team_file = [&](const Team& tmm, int tidx, int Kk, auto sel_of, double ubv, int& st_io, int& it_io, int& nd_io, const int32_t*& fsel) -> bool {
         TeamResult* res = a.team_res + (size_t)tidx * TEAM_W;
         TeamResult& me = res[tmm.q];
@@ -1998,15 +2006,28 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
                 any_limit |= (st == MHT_BLP_NODE_LIMIT);
                 if (u < bub) { bub = u; bq = q; }      // (ties: the lowest member)
             }
-            r->i[0] = bq; r->i[1] = any_limit; r->i[2] = nsum; r->i[3] = itmax;
+            r->i[0] = bq; r->i[1] = any_limit; r->i[2] = nsum; r->i[3] = itmax; r->d[0] = bub;
         }
         __syncthreads();
         fsel = res[r->i[0]].sel;
+        best_io = r->d[0];
         st_io = r->i[1] ? MHT_BLP_NODE_LIMIT : MHT_BLP_BRANCHED;
         nd_io = r->i[2];
         it_io = r->i[3];
         __syncthreads();
         return true;
+    };
+    // a team that spans the devices of a cluster-sharded step: this device's best selection goes to its slot of the exchange block (BlpArgs::shard_team:
+    // [device][team slot][XT_WORDS] int32, -1 = empty; the value as three non-negative chunks of its order-preserving key so that the exchange's
+    // element-wise MAX is a gather), NOT to sel_rel -- the devices' selections of one cluster must not mix; shard_team_resolve_kernel picks the winner
+    const bool xteam = tm.Wg != tm.W && a.shard_team != nullptr && team_idx >= 0;
+    auto xteam_out = [&](auto sel_of, double value) {
+        int32_t* o = a.shard_team + ((size_t)a.shard_i * TEAM_MAX + team_idx) * XT_WORDS;
+        for (int k = tid; k < K; k += BLP_THREADS) { const int h = sel_of(k); a.sel[mem[k]] = h; o[4 + k] = h - a.tchild[mem[k]]; }
+        if (tid == 0) {
+            const unsigned long long key = enum_key(value);
+            o[0] = (int32_t)(key >> 42); o[1] = (int32_t)((key >> 21) & 0x1fffffu); o[2] = (int32_t)(key & 0x1fffffu); o[3] = K;
+        }
     };
     if (!use_lds) {
         // ---- HBM scratch: the same solver, generic column access ----------------------------------------------------
@@ -2027,7 +2048,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         __threadfence_block();
         __syncthreads();
         double ub = DINF;
-        solve_core(a, gs, K, r, status, iters, nodes, stamp, ub, team_hbm ? tm : Team{0, 1, nullptr});
+        solve_core(a, gs, K, r, status, iters, nodes, stamp, ub, team_hbm ? tm : Team(0, 1, nullptr));
         ub_reduced = ub;
 #ifdef MHT_BLP_TRACE
         if (tid == 0) printf("[blp] cluster %d K=%d nH=%d: HBM phase status %d iters %d nodes %d, %.2f ms (setup %.2f)\n", c, K, nH, status, iters, nodes,
@@ -2090,13 +2111,17 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
                 if (!team_file(tm, team_idx, K, [&](int k) { return gs.ub_sel[k]; }, ub, status, iters, nodes, final_sel)) return;
             }
             stamp[4] = wall_clock64();
+            if (xteam) {
+                xteam_out([&](int k) { return final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs.ub_sel[k]; },
+                          final_sel ? best_io : ub);
+            } else
             for (int k = tid; k < K; k += BLP_THREADS) {
                 const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs.ub_sel[k];
                 a.sel[mem[k]] = h;
                 if (a.sel_rel) a.sel_rel[mem[k]] = h - a.tchild[mem[k]];
                 if (a.t_alive) gs.ch[k] = finish_target(a, mem[k], h, pre_ok ? pre : load_target_cr(a, mem[k], cr), true);
             }
-            prune_members(a, mem, K, gs.ch);
+            if (!xteam) prune_members(a, mem, K, gs.ch);
         }
     }
     if (use_lds) {
@@ -2119,7 +2144,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
 #ifdef MHT_BLP_TRACE
         if (tid == 0 && s.reduced) printf("[blp] cluster %d: rebuilt with %d columns %d rows at %.2f ms\n", c, nHl, nR, 1e-5 * (double)(wall_clock64() - t_begin));
 #endif
-        solve_core(a, s, K, r, status, iters, nodes, stamp, ub, team ? tm : Team{0, 1, nullptr});
+        solve_core(a, s, K, r, status, iters, nodes, stamp, ub, team ? tm : Team(0, 1, nullptr));
 #ifdef MHT_BLP_TRACE
         if (tid == 0 && s.reduced) printf("[blp] cluster %d: LDS phase status %d iters %d nodes %d at %.2f ms\n", c, status, iters, nodes, 1e-5 * (double)(wall_clock64() - t_begin));
 #endif
@@ -2130,6 +2155,10 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
         }
         stamp[4] = wall_clock64();
         int rf_mine = -1;
+        if (xteam) {      // (a sharded step solves only: t_alive is null, the per-target end of the scan follows the exchange)
+            xteam_out([&](int k) { return final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s.to_global(s.ub_sel[k]); },
+                      final_sel ? best_io : ub);
+        } else
         for (int k = tid; k < K; k += BLP_THREADS) {
             const int h = final_sel ? __hip_atomic_load(const_cast<int32_t*>(final_sel) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s.to_global(s.ub_sel[k]);
             a.sel[mem[k]] = h;
@@ -2442,17 +2471,20 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
     // so; see blp_epilogue_kernel)
     // teams (mht_kernels.h: TEAM_*): the launch's workgroups without a cluster of their own (block index >= nMulti) are dealt out to
     // the clusters of the team list; member 0 of a team is the workgroup that owns the cluster anyway
-    bool teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
+    // (a cluster-sharded step with an exchange block for them: the clusters of the team list are searched by every device's team together -- the
+    // subtrees dealt out over all members of all devices --, also when a device has no idle workgroup to add to its own member)
+    const bool xteams = a.shard_n > 1 && a.shard_team != nullptr;
+    bool teams_on = a.team_list && a.tier != 1 && (xteams || (a.shard_n <= 1 && gx > nMulti));
     int nTeam = teams_on ? (UF ? 0 : a.counts[5]) : 0;
     int nIdle = gx - nMulti;
-    auto team_W = [&](int ti) { const int w = 1 + (nIdle - ti + nTeam - 1) / nTeam; return w < TEAM_W ? w : TEAM_W; };
+    auto team_W = [&](int ti) { const int w = nIdle > ti ? 1 + (nIdle - ti + nTeam - 1) / nTeam : 1; return w < TEAM_W ? w : TEAM_W; };
     // (ONE call site of the solver: the workgroup's own clusters first, then the single-target clusters, then -- if it has no cluster
     // of its own -- its share of a team's search)
     int own_i = bx, own_q = 0;
     for (int stage = UF ? -1 : 0; stage < 3; ) {
         ClRef cr = ClRef{-1, 0, 0, -1};
         int ti = -1, mt = -1;
-        Team tm = Team{0, 1, nullptr};
+        Team tm = Team(0, 1, nullptr);
         if (UF && stage == -1) {
             // clusters from the grow launch's union-find: the tables first (INSIDE the staged loop: what the compiler hoists in front of the
             // loop -- the solver's argument loads and address arithmetic, ~2 us -- then runs while the parents are on their way)
@@ -2461,7 +2493,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             blp_stamp_begin(a, bx);
             if (a.dbg && threadIdx.x == 0 && bx < 3900) a.dbg[32 + (size_t)bx * 16 + 12] = wall_clock64();
             nMulti = ps->nMulti; nSingle = ps->nSingle;
-            teams_on = a.team_list && a.tier != 1 && a.shard_n <= 1 && gx > nMulti;
+            teams_on = a.team_list && a.tier != 1 && (xteams || (a.shard_n <= 1 && gx > nMulti));
             nTeam = teams_on ? ps->nTeam : 0;
             nIdle = gx - nMulti;
             continue;
@@ -2470,10 +2502,11 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             if (UF) { cr = ps->own[own_q]; mt = own_q == 0 ? my_t : -1; ++own_q; }
             else cr = cl_ref(a, work[own_i]);
             own_i += gx;
-            if (a.shard_n > 1 && (a.cl_owner ? a.cl_owner[cr.c] : cr.c % a.shard_n) != a.shard_i) continue;
             if (nTeam > 0 && cr.K >= TEAM_MIN_K)
                 for (int q = 0; q < nTeam; ++q) if ((UF ? ps->team[q].c : a.team_list[q]) == cr.c) ti = q;
-            if (ti >= 0 && team_W(ti) > 1) tm = Team{0, team_W(ti), &a.team_state[ti].gub};
+            if (a.shard_n > 1 && !(xteams && ti >= 0) && (a.cl_owner ? a.cl_owner[cr.c] : cr.c % a.shard_n) != a.shard_i) continue;
+            if (ti >= 0 && xteams) tm = Team(0, team_W(ti), &a.team_state[ti].gub, a.shard_i, team_W(ti) * a.shard_n);      // (member q of device i: number q x devices + i)
+            else if (ti >= 0 && team_W(ti) > 1) tm = Team(0, team_W(ti), &a.team_state[ti].gub);
             else ti = -1;
         } else if (stage == 1) {
             stage = 2;
@@ -2487,7 +2520,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             if (q >= team_W(ti)) break;
             __syncthreads();      // (the wavefronts of this workgroup are done with the single-target clusters)
             cr = UF ? ps->team[ti] : cl_ref(a, a.team_list[ti]);
-            tm = Team{q, team_W(ti), &a.team_state[ti].gub};
+            tm = xteams ? Team(q, team_W(ti), &a.team_state[ti].gub, q * a.shard_n + a.shard_i, team_W(ti) * a.shard_n) : Team(q, team_W(ti), &a.team_state[ti].gub);
         }
         if (a.dbg && threadIdx.x == 0 && bx < 3900 && stage == 0) a.dbg[32 + (size_t)bx * 16 + 13] = wall_clock64();
         solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr, bx);
@@ -2709,6 +2742,33 @@ int launch_blp_light_batch(mht_ctx* ctx, const PBatch& av, int n_sectors, int gr
 // sit at different node indices), every device runs the per-target end of the scan for ALL targets: termination test, N-scan
 // prune decision, new root, report record, surviving leaf range -- what blp_kernel does behind its own solves (tracker.py:891-916,
 // pyTarget.py:343-356).  One wavefront per target.
+// Behind the exchange of a cluster-sharded step: every device holds every device's file for the clusters searched by teams across devices
+// (BlpArgs::shard_team).  Per slot the smallest value wins, ties go to the lowest device -- the same decision on every device -- and the winner's
+// child ordinals become the members' sel_rel entries.
+__global__ __launch_bounds__(TEAM_SEL) void shard_team_resolve_kernel(const BlpArgs a, const int shard_n) {
+    if (a.status && a.status->overflow) return;
+    const int ti = blockIdx.x;
+    if (ti >= a.counts[5]) return;
+    const ClRef cr = cl_ref(a, a.team_list[ti]);
+    int best = -1;
+    unsigned long long bk = ~0ull;
+    for (int d = 0; d < shard_n; ++d) {      // (uniform)
+        const int32_t* o = a.shard_team + ((size_t)d * TEAM_MAX + ti) * XT_WORDS;
+        if (o[3] != cr.K) continue;      // (empty: -1)
+        const unsigned long long key = ((unsigned long long)(unsigned)o[0] << 42) | ((unsigned long long)(unsigned)o[1] << 21) | (unsigned long long)(unsigned)o[2];
+        if (best < 0 || key < bk) { best = d; bk = key; }
+    }
+    if (best < 0) return;      // (no device filed: the cluster was not searched by a team -- its owner's entries are in sel_rel already)
+    const int32_t* o = a.shard_team + ((size_t)best * TEAM_MAX + ti) * XT_WORDS;
+    for (int k = threadIdx.x; k < cr.K; k += blockDim.x) a.sel_rel[a.cl_members[cr.p0 + k]] = o[4 + k];
+}
+
+int launch_shard_team_resolve(mht_ctx* ctx, const BlpArgs& a, int shard_n) {
+    hipLaunchKernelGGL(shard_team_resolve_kernel, dim3(TEAM_MAX), dim3(TEAM_SEL), 0, ctx->stream, a, shard_n);
+    MHT_HIP_CHECK(hipGetLastError());
+    return MHT_OK;
+}
+
 __global__ __launch_bounds__(BLP_THREADS) void blp_epilogue_kernel(const BlpArgs a, const int32_t* nT_dev) {
     if (a.status && a.status->overflow) return;
     const int nT = *nT_dev, lane = threadIdx.x & 63;

@@ -350,7 +350,11 @@ __device__ __forceinline__ void cluster_body(const ClusterArgs& a, unsigned char
             if (h == t) {
                 a.multi_list[atomicAdd(&s_edges, 1)] = c;
                 if (a.team_list && K >= TEAM_MIN_K) {      // large cluster: its branch and bound (if it needs one) is shared by a team
-                    const int q = atomicAdd(&s_team, 1);
+                    // slot = rank among the large clusters' heads: the same list on every device of a cluster-sharded step (the members of a team
+                    // that spans devices file their results by slot), also when there are more than TEAM_MAX of them.  Rare: a loop over the heads below
+                    int q = 0;
+                    for (int u = 0; u < t; ++u) q += (lab[u] == u && cnt[u] >= TEAM_MIN_K) ? 1 : 0;
+                    atomicAdd(&s_team, 1);
                     if (q < TEAM_MAX) a.team_list[q] = c;
                 }
             }

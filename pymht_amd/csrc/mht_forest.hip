@@ -385,7 +385,7 @@ struct Forest {
     // streaming drop-in path: the admission of what the scan's initiator gave birth to is pending WITH the commit -- both ride in
     // workgroup 0 of the next scan's grow launch (fgrow_adm_kernel), or run as post_scan_kernel when somebody needs the state first
     bool adm_pending = false; AddArgs adm = {}; bool adm_fuse = true;      // MHT_ADM_FUSE=0: admission in a launch of its own behind every scan
-    bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0;      // cluster-sharded step between _begin and _end
+    bool shard_open = false; int shard_plan_s = 0, shard_plan_W = 0, shard_M = 0, shard_xn = 0;      // cluster-sharded step between _begin and _end
     long long blp_time_limit = 0;   // wall-clock budget per ILP in 10 ns ticks, 0 = none (mht_forest_set_blp_time_limit)
     float prune_thr = 0.f;       // similar-state pruning (mht_similar.hip): threshold in metres, 0 = off (mht_forest_set_prune_similar)
     int in_groups = 0;           // mht_group_create snapshots the ILP argument blocks of its members: settings behind them are frozen while > 0
@@ -1458,7 +1458,27 @@ extern "C" int mht_forest_step(mht_ctx* ctx, const float* z, int32_t M) { return
 // one all-reduce(MAX) over them between _begin and _end gives every device every selection; _end then runs the per-target end of
 // the scan (termination, N-scan pruning) for all targets, so the forests stay identical.  A gating graph that is ONE component is
 // solved by one device while the others wait: the one-GPU fallback the north star asks for.
+// A gating graph that is ONE big component (mht_forest_step_sharded_begin2 with an exchange block of mht_forest_sharded_words words): the clusters of
+// the team list (>= TEAM_MIN_K targets, at most TEAM_MAX per scan) are searched by ALL devices -- the subtrees of the branch and bound are dealt out over
+// the members of every device's team (Team::qg / Wg), every device files its best selection and its value in its own slots of the block, the
+// all-reduce(MAX) that merges the selections gathers the files as well (empty slots are -1), and _end2 lets the smallest value win on every device
+// alike.  tracker.py:1155-1217 is one CBC call: any exact split is acceptable.
+extern "C" int mht_forest_sharded_words(mht_ctx* ctx, int32_t shard_n, int32_t* n_words) {
+    MHT_REQUIRE(ctx && ctx->forest && n_words && shard_n >= 1, "mht_forest_sharded_words: bad argument");
+    *n_words = ctx->forest->Tcap + shard_n * TEAM_MAX * XT_WORDS;
+    return MHT_OK;
+}
+
+static int sharded_begin_impl(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel, int32_t n_words);
 extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel) {
+    return sharded_begin_impl(ctx, z, M, shard_n, shard_i, sel_rel, 0);
+}
+extern "C" int mht_forest_step_sharded_begin2(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* xch, int32_t n_words) {
+    MHT_REQUIRE(ctx && ctx->forest && n_words >= ctx->forest->Tcap + shard_n * TEAM_MAX * XT_WORDS,
+                "mht_forest_step_sharded_begin2: the exchange block needs mht_forest_sharded_words() words");
+    return sharded_begin_impl(ctx, z, M, shard_n, shard_i, xch, n_words);
+}
+static int sharded_begin_impl(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel, int32_t n_words) {
     MHT_REQUIRE(ctx && ctx->forest && sel_rel, "mht_forest_step_sharded_begin: null argument");
     MHT_REQUIRE(shard_n >= 1 && shard_i >= 0 && shard_i < shard_n, "mht_forest_step_sharded_begin: bad shard %d of %d", shard_i, shard_n);
     Forest* f = ctx->forest;
@@ -1509,12 +1529,16 @@ extern "C" int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32
         fill_blp(f, pl.s, b);
         b.shard_n = shard_n; b.shard_i = shard_i; b.sel_rel = sel_rel; b.cl_owner = f->cl_owner;
         b.t_alive = nullptr;      // solve only: the per-target end of the scan follows the exchange (mht_forest_step_sharded_end)
+        if (n_words > 0 && shard_n > 1) {      // teams across the devices: the files' slots start empty
+            b.shard_team = sel_rel + f->Tcap;
+            MHT_HIP_CHECK(hipMemsetAsync(b.shard_team, 0xff, (size_t)shard_n * TEAM_MAX * XT_WORDS * sizeof(int32_t), ctx->stream));
+        }
         int grid = f->nT_ub_step / 2 + 8;
         if (grid > 1024) grid = 1024;
         rc = launch_blp(ctx, b, grid);
     }
     if (rc) { f->dead = true; return rc; }
-    f->shard_open = true; f->shard_plan_s = pl.s; f->shard_plan_W = pl.W; f->shard_M = M;
+    f->shard_open = true; f->shard_plan_s = pl.s; f->shard_plan_W = pl.W; f->shard_M = M; f->shard_xn = (n_words > 0 && shard_n > 1) ? shard_n : 0;
     return MHT_OK;
 }
 
@@ -1526,7 +1550,12 @@ extern "C" int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel)
     BlpArgs b;
     fill_blp(f, f->shard_plan_s, b);
     b.sel_rel = const_cast<int32_t*>(sel_rel);
-    const int rc = launch_blp_epilogue(ctx, b, &f->cnt->nT, f->nT_ub_step);
+    int rc = MHT_OK;
+    if (f->shard_xn > 1) {      // (begun with mht_forest_step_sharded_begin2: the winners of the teams across the devices first)
+        b.shard_team = b.sel_rel + f->Tcap;
+        rc = launch_shard_team_resolve(ctx, b, f->shard_xn);
+    }
+    if (!rc) rc = launch_blp_epilogue(ctx, b, &f->cnt->nT, f->nT_ub_step);
     f->shard_open = false;
     if (rc) { f->dead = true; return rc; }
     StepPlan pl = {};
@@ -2323,6 +2352,7 @@ extern "C" int mht_forest_debug_read(mht_ctx* ctx, const char* name, void* host,
     else if (!strcmp(name, "multi_list")) { src = f->multi_list; avail = T * 4; }
     else if (!strcmp(name, "cl_counts")) { src = f->cl_counts; avail = 8 * 4; }
     else if (!strcmp(name, "cl_owner")) { src = f->cl_owner; avail = T * 4; }
+    else if (!strcmp(name, "team_list")) { src = f->team_list; avail = TEAM_MAX * 4; }
     else if (!strcmp(name, "tchild")) { src = f->tchild; avail = (T + 1) * 4; }
     else if (!strcmp(name, "tcend")) { src = f->tcend; avail = (T + 1) * 4; }
     else if (!strcmp(name, "Gk")) { src = f->vt.Gk; avail = (size_t)f->vt.vcap * 2 * GKF * 4; }                  // gains by key

@@ -193,6 +193,7 @@ struct PBatch { const void* p[GROUP_MAX]; };      // one argument block (in HBM)
 #define MHT_TEAM_W 32
 #endif
 constexpr int TEAM_MIN_K = 24, TEAM_MAX = 8, TEAM_W = MHT_TEAM_W, TEAM_SEL = 256;
+constexpr int XT_WORDS = 4 + TEAM_SEL;      // a device's file in the exchange block of a cluster-sharded step (BlpArgs::shard_team): value key [3], K, child ordinals [K]
 struct TeamResult { double ub; int32_t status, nodes, iters, pad; int32_t sel[TEAM_SEL]; };      // what a member found (global column per target)
 struct TeamState { unsigned long long gub; int32_t done, pad[13]; };                    // per team: shared incumbent key, finished members, TeamProblem filed
 // (A giant cluster -- more columns than the LDS tables hold -- runs its dual phase on HBM scratch: every member has its own copy of that
@@ -279,6 +280,7 @@ struct BlpArgs {
     int32_t* big_list; int32_t* big_count;
     int shard_n, shard_i;           // cluster sharding over devices with identical forests (0 / 1: off)
     const int32_t* cl_owner;        // [T] device of every multi-target cluster (cluster kernel: LPT by column count); null: cluster c on device c % shard_n
+    int32_t* shard_team;            // [shard_n][TEAM_MAX][XT_WORDS] or null: the clusters of the team list are searched by ALL devices (Team::qg / Wg), each files its best here
     int32_t* sel_rel;               // [T] or null: selected child relative to the target's block (tchild[t]); -1 = not solved here      // clusters tier 1 left for tier 2 (count reset by the cluster kernel: counts[4])
     const DevStatus* status;        // forest mode: per-scan status word (overflow => do nothing)
     // forest epilogue (null for the stateless seam): track termination + N-scan prune decision per target
@@ -368,6 +370,7 @@ size_t cluster_big_ints(int Tcap, int n_mnodes);
 int launch_blp(mht_ctx* ctx, const BlpArgs& a, int grid);
 bool blp_uf_fits(int Tcap, int n_mnodes);
 int launch_blp_epilogue(mht_ctx* ctx, const BlpArgs& a, const int32_t* nT_dev, int n_targets_ub);
+int launch_shard_team_resolve(mht_ctx* ctx, const BlpArgs& a, int shard_n);
 void forest_destroy(mht_ctx* ctx);
 
 }  // namespace mht

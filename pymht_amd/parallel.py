@@ -94,7 +94,14 @@ class ClusterShardedTracker:
         import torch
         self.trk, self.shard_n, self.shard_i = tracker, int(shard_n), int(shard_i)
         self.exchange = exchange if exchange is not None else (lambda t: merge_selections(t, dist, always_exchange))
-        self.sel_rel = torch.full((tracker._cfg.max_targets,), -1, dtype=torch.int32, device=tracker._ctx.device)
+        # the exchange block: a selection per target slot, then every rank's files for the clusters searched by teams ACROSS the ranks (a gating
+        # graph that is one big component: mht_forest_step_sharded_begin2) -- one all-reduce(MAX) over the whole block merges the one and gathers the other
+        import ctypes as C
+        from . import _lib
+        nw = C.c_int32(0)
+        _lib.check(tracker._lib.mht_forest_sharded_words(tracker._ctx.handle, self.shard_n, C.byref(nw)))
+        self.n_words = nw.value
+        self.sel_rel = torch.full((self.n_words,), -1, dtype=torch.int32, device=tracker._ctx.device)
 
     def begin(self, scanList, aisList=None, **kwargs):
         """Grow, cluster and this rank's share of the ILPs (asynchronous).  `pruneSimilar=True` (tracker.py:230): similar-state
@@ -112,8 +119,8 @@ class ClusterShardedTracker:
             trk._last_ais_scan = len(trk.__scanHistory__) + 1
         zd = trk._upload_scan(self._z)
         self.sel_rel.fill_(-1)      # (the device resets the live targets' entries itself; this also clears slots of targets long gone)
-        _lib.check(trk._lib.mht_forest_step_sharded_begin(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,
-                                                          self.sel_rel.data_ptr()))
+        _lib.check(trk._lib.mht_forest_step_sharded_begin2(trk._ctx.handle, zd, self._z.shape[0], self.shard_n, self.shard_i,
+                                                           self.sel_rel.data_ptr(), self.n_words))
         self._scan = scanList
 
     def end(self):

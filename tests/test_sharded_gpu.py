@@ -294,3 +294,62 @@ def test_cluster_sharded_ais_trace_equals_reference(name):
     finally:
         for q in parts:
             q.trk.close()
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_giant_component_is_searched_by_every_shard(shards):
+    """A gating graph that is one big component (tracker.py:1155-1217: one CBC call): the dense scenario of
+    test_cluster_blp_gpu.py::test_blp_team_search_equals_single_workgroup_search, whose 30-60-target clusters branch.  With the exchange
+    block of mht_forest_step_sharded_begin2 every shard searches its share of the subtrees and files its best selection; the merged
+    block lets the smallest value win on every shard -- the same decisions as one device, scan by scan, and on the scans with a team
+    cluster every shard has filed (nobody waited for an owner)."""
+    import torch
+    from pymht_amd.parallel import ClusterShardedTracker
+    from pymht_amd.tracker import Tracker
+    from pymht_amd.pyTarget import Target
+    from pymht_amd.models import pv
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    from pymht_amd.utils.scenario import make_scenario
+    sc = make_scenario(T=66, radius=201.0, lambda_phi=1.5e-4, n_scans=7, P_d=0.73, period=2.5, seed=5494)
+
+    def mk():
+        trk = Tracker(pv, sc["period"], sc["lambda_phi"], 1e-4, P_d=sc["P_d"], N=3, eta2=9.21, useInitiator=False, maxTargets=512, maxNodes=1 << 18)
+        trk._add_targets([Target(sc["t0"], None, x.copy(), pv.P0, status="preinitialized") for x in sc["x0"]])
+        return trk
+
+    solo = mk()
+    parts = [ClusterShardedTracker(mk(), shards, i, exchange=lambda t: None) for i in range(shards)]
+    T, XT = 512, 260
+    filed_scans = branched = 0
+    for k, (z, t) in enumerate(zip(sc["scans"], sc["times"])):
+        sl = MeasurementList(float(t), z)
+        solo.addMeasurementList(sl)
+        for p in parts:
+            p.begin(sl)
+        blocks = torch.stack([p.sel_rel for p in parts])
+        assert int((blocks >= 0).int().sum(dim=0).max()) <= 1, "two shards wrote the same word of the exchange block"
+        files = blocks[:, T:].reshape(shards, shards, 8, XT).cpu().numpy()      # [written by shard][slot of shard][team slot][words]
+        n_team = int(_rd(parts[0].trk, "cl_counts", 8)[5])
+        for i in range(shards):
+            assert (files[i, [j for j in range(shards) if j != i]] == -1).all(), "a shard wrote into another shard's slots"
+            for q in range(n_team):
+                assert files[i, i, q, 3] >= 24, "shard %d did not file for team cluster %d in scan %d" % (i, q, k)
+        if n_team:
+            filed_scans += 1
+            # the members' entries of the selection part are empty: nobody's selection may leak past the vote
+            ptr, lst = _rd(parts[0].trk, "cl_ptr", 513), _rd(parts[0].trk, "team_list", 8)
+            mem = _rd(parts[0].trk, "cl_members", 512)
+            for q in range(n_team):
+                c = int(lst[q])
+                assert (blocks[:, mem[ptr[c]:ptr[c + 1]]] == -1).all()
+        merged = blocks.max(dim=0).values
+        for p in parts:
+            p.sel_rel.copy_(merged)
+            p.end()
+        for i, p in enumerate(parts):
+            _same(p.trk, solo, "scan %d shard %d" % (k, i))
+        branched += solo.lastScanStats["branched"]
+    assert filed_scans >= 2 and branched > 0
+    for p in parts:
+        p.trk.close()
+    solo.close()
