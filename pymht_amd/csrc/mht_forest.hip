@@ -758,6 +758,14 @@ static int forest_create_impl(mht_ctx* ctx, const mht_model* model, const mht_fo
     for (int b = 0; b < Z_RING; ++b) MHT_HIP_CHECK(hipEventCreateWithFlags(&f->z_ev[b], hipEventDisableTiming));
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->z_host_dev), f->z_host, 0));
     for (int b = 0; b < 2; ++b) MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->report_host_dev[b]), f->report_host2[b], 0));
+    // (the blocks of mht_forest_chains_begin: pinned memory is allocated HERE, not when the first track dies in the middle of a stream -- hipHostMalloc takes
+    // milliseconds; 128 KB hold ~130 chains of a window of 5, a larger batch grows its block)
+    for (auto& cs : f->chain_slots) {
+        MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cs.host), 128 * 1024, hipHostMallocMapped));
+        MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&cs.dev), cs.host, 0));
+        cs.bytes = 128 * 1024;
+        MHT_HIP_CHECK(hipEventCreateWithFlags(&cs.ev, hipEventDisableTiming));
+    }
     MHT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&f->hint_host), 64, hipHostMallocMapped));
     memset(f->hint_host, 0, 64);
     MHT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hint_dev), f->hint_host, 0));
