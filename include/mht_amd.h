@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MHT_ABI_VERSION 5
+#define MHT_ABI_VERSION 6
 
 /* State dimension of the library build the header is used with: 4 (libmht_amd.so: the reference's CV model, models/pv.py) or 6
  * (libmht_amd6.so: the same sources compiled with -DMHT_NX=6 for BASELINE config 5's six-state model).  It sizes the model matrices
@@ -392,7 +392,7 @@ int mht_forest_chain(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, 
 int mht_forest_chain_f64(mht_ctx* ctx, int32_t scan, int32_t node, int32_t max_len, int32_t* nodes, int32_t* meas,
                          double* x, double* cnllr, double* P, uint8_t* flags, int32_t* n_out);
 
-/* The streaming form (Tracker._apply_report: the window ancestors of the tracks a scan terminated, tracker.py:353-381 keeps them): the
+/* The streaming form (ABI 6; Tracker._apply_report: the window ancestors of the tracks a scan terminated, tracker.py:353-381 keeps them): the
  * chains of `count` nodes of layer `scan` are gathered by ONE launch queued behind what is already on the forest's stream, into a pinned
  * block of the library; nothing waits.  *ticket names the block; it stays valid until 8 later tickets have been issued.  f64 != 0:
  * float64 covariances as mht_forest_chain_f64.  mht_forest_chains_fetch waits for that launch only (not for scans queued behind it)
@@ -452,7 +452,7 @@ int mht_forest_initiate(mht_ctx* ctx, mht_initiator* in, const float* z, int32_t
  * Asynchronous on the ctx stream. */
 int mht_forest_step_sharded_begin(mht_ctx* ctx, const float* z, int32_t M, int32_t shard_n, int32_t shard_i, int32_t* sel_rel);
 int mht_forest_step_sharded_end(mht_ctx* ctx, const int32_t* sel_rel);
-/* A gating graph that is ONE big component on several devices (tracker.py:1155-1217 is one CBC call; any exact split will do): with an
+/* (ABI 6) A gating graph that is ONE big component on several devices (tracker.py:1155-1217 is one CBC call; any exact split will do): with an
  * exchange block of mht_forest_sharded_words() int32 -- [max_targets] selections as above, then [shard_n][8][260] files -- the clusters of
  * >= 24 targets (at most 8 per scan) are searched by ALL devices: the subtrees of the branch and bound are dealt out over every device's
  * workgroups, every device files its best selection and its value in its own slots (-1 = empty), the SAME element-wise MAX all-reduce over

@@ -14,7 +14,7 @@ def test_library_loads_and_exports_header_symbols():
     for nx in (4, 6):
         lib = _lib.load(nx=nx)
         assert os.path.exists(build.lib_path(nx))
-        assert lib.mht_abi_version() == 5
+        assert lib.mht_abi_version() == 6
         for name in names:
             assert hasattr(lib, name), "%s does not export %s" % (os.path.basename(build.lib_path(nx)), name)
 
