@@ -615,3 +615,59 @@ def test_a_hundred_births_in_one_scan_match_the_oracle():
     from fuzz_util import run_case
     ok, desc, msg = run_case(1695381)
     assert ok, (desc, msg)
+
+
+def test_chains_gathered_in_one_launch_equal_the_synchronous_walk():
+    """mht_forest_chains_begin / _fetch (the window chains of terminated tracks, gathered without stopping the stream) against
+    mht_forest_chain node by node: 400 leaves at once (a block that outgrows the 128 KB pinned at creation), float32 and float64 form,
+    a ticket that is fetched late (behind two more scans) and one that has expired (eight later tickets)."""
+    import ctypes as C
+    from pymht_amd import _lib
+    from pymht_amd.utils.classDefinitions import MeasurementList
+    sc = _scenario(T=60, radius=500.0, lambda_phi=4e-5, n_scans=9, P_d=0.8, seed=11)
+    trk = _mk(sc, N=4, useInitiator=False)
+    lib, h = trk._lib, trk._ctx.handle
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def sync_chain(scan, node, n_max):
+        nodes, meas, x, cn, P, n = np.zeros(n_max, np.int32), np.zeros(n_max, np.int32), np.zeros((n_max, 4)), np.zeros(n_max), np.zeros((n_max, 16), np.float32), C.c_int32(0)
+        _lib.check(lib.mht_forest_chain(h, scan, node, n_max, p(nodes), p(meas), p(x), p(cn), p(P), C.byref(n)))
+        k = n.value
+        return nodes[:k].copy(), meas[:k].copy(), x[:k].copy(), cn[:k].copy(), P[:k].copy()
+
+    def fetch(ticket, i, n_max, f64):
+        nodes, meas, x, cn, n = np.zeros(n_max, np.int32), np.zeros(n_max, np.int32), np.zeros((n_max, 4)), np.zeros(n_max), C.c_int32(0)
+        P, fl = np.zeros((n_max, 16), np.float64 if f64 else np.float32), np.zeros(n_max, np.uint8)
+        _lib.check(lib.mht_forest_chains_fetch(h, ticket, i, p(nodes), p(meas), p(x), p(cn), p(P), p(fl), C.byref(n)))
+        k = n.value
+        return nodes[:k].copy(), meas[:k].copy(), x[:k].copy(), cn[:k].copy(), P[:k].copy()
+
+    for z, t in zip(sc["scans"][:6], sc["times"][:6]):
+        trk.addMeasurementList(MeasurementList(float(t), z))
+    scan = len(trk.__scanHistory__)
+    start = np.ascontiguousarray(trk.leafBatch()["node"][:400], dtype=np.int32)
+    assert len(start) >= 300
+    n_max = 6
+    want = [sync_chain(scan, int(nd), n_max) for nd in start]
+    t32, t64 = C.c_int64(-1), C.c_int64(-1)
+    _lib.check(lib.mht_forest_chains_begin(h, scan, p(start), len(start), n_max, 0, C.byref(t32)))
+    _lib.check(lib.mht_forest_chains_begin(h, scan, p(start), len(start), n_max, 1, C.byref(t64)))
+    for z, t in zip(sc["scans"][6:8], sc["times"][6:8]):      # (two more scans are queued and run before anybody looks)
+        trk.addMeasurementList(MeasurementList(float(t), z))
+    for i in (0, 1, 57, len(start) - 1):
+        for got, tk in ((fetch(t32.value, i, n_max, False), "f32"), (fetch(t64.value, i, n_max, True), "f64")):
+            assert len(got[0]) == len(want[i][0]) >= 2, (i, tk)
+            for a_, b_ in zip(got[:4], want[i][:4]):
+                assert np.array_equal(a_, b_), (i, tk)
+            assert np.array_equal(got[4].astype(np.float32), want[i][4]), (i, tk)
+    # eight later tickets: the first one's block has been reused
+    scan = len(trk.__scanHistory__)
+    one = np.ascontiguousarray(trk.leafBatch()["node"][:3], dtype=np.int32)
+    tk = C.c_int64(-1)
+    for _ in range(8):
+        _lib.check(lib.mht_forest_chains_begin(h, scan, p(one), 3, n_max, 0, C.byref(tk)))
+    with pytest.raises(_lib.MhtError) as ei:
+        fetch(t32.value, 0, n_max, False)
+    assert ei.value.code == _lib.MHT_E_INVALID and "expired" in str(ei.value)
+    assert len(fetch(tk.value, 2, n_max, False)[0]) >= 2
+    trk.close()
