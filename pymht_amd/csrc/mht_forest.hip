@@ -398,6 +398,7 @@ struct Forest {
     // births issued behind scan s, before scan s+1 (ring by s % 64): host-driven ones exactly, the device initiator's as an upper
     // bound (its capacity) until the scan's report says how many candidates there were
     int births_after[64] = {}; int births_init_ub[64] = {};
+    int init_mreq = 0;      // m_required of the radar-only device initiator behind this forest's scans (0: unknown / AIS messages may start tracks: no bound from the preliminary tracks)
     unsigned long long* bhint_host = nullptr; unsigned long long* bhint_dev = nullptr;      // ring of 64: what the device initiator says it gave birth to (InitArgs::bhint)
     long long births_between(int k, int s) const {      // births issued behind scans k .. s-1
         long long b = 0;
@@ -405,7 +406,16 @@ struct Forest {
             int ub = births_init_ub[j % 64];
             if (ub > 0 && bhint_host) {      // the initiator of scan j has finished: its candidates are counted
                 const unsigned long long h = reinterpret_cast<volatile unsigned long long*>(bhint_host)[j % 64];
-                if ((int)(h >> 32) == j && (int)(h & 0xffffffffu) < ub) ub = (int)(h & 0xffffffffu);
+                if ((int)(h >> 32) == j) { if ((int)(h & 0xffffu) < ub) ub = (int)(h & 0xffffu); }
+                else if (init_mreq > 0) {
+                    // still running: a track confirmed in scan j has been updated in m_required scans, one per scan, so it was a preliminary track
+                    // behind every scan j - m_required .. j - 1 -- the count the initiator posted for any of them bounds scan j's births (typically
+                    // a few dozen against a capacity of 256: that many fewer idle target workgroups in the next grow launch)
+                    for (int q = j - 1; q >= j - init_mreq && q >= 1; --q) {
+                        const unsigned long long hq = reinterpret_cast<volatile unsigned long long*>(bhint_host)[q % 64];
+                        if ((int)(hq >> 32) == q && (int)((hq >> 16) & 0xffffu) < ub) ub = (int)((hq >> 16) & 0xffffu);
+                    }
+                }
             }
             b += births_after[j % 64] + ub;
         }
@@ -1195,6 +1205,7 @@ void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigne
 void initiator_born_ptrs(const mht_initiator* in, const double** x, const float** P, const uint8_t** fl, const double** pd, const int32_t** meas,
                          const int32_t** n, int* cap, mht_ctx** ctx);
 int initiator_ais_pending(const mht_initiator* in);
+int initiator_mreq(const mht_initiator* in);
 void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned char** used);
 }
 
@@ -1844,6 +1855,7 @@ static int forest_initiate_impl(mht_ctx* ctx, mht_initiator* in, const float* z,
     f->L_ub = (f->L_ub + cap < f->Ncap) ? f->L_ub + cap : f->Ncap;
     f->births_since_step += cap;
     f->births_init_ub[f->scan % 64] = cap;
+    f->init_mreq = f->ais ? 0 : initiator_mreq(in);
     f->report_pending = true;      // (the births block of the report changed)
     return MHT_OK;
 }

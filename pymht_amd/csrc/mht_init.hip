@@ -85,6 +85,7 @@ void initiator_scan_args(mht_initiator* in, const float* z, int M, const unsigne
     in->ais_pending = 0; in->ais_used_valid = false; in->ais_used_by_forest = false;
 }
 int initiator_ais_pending(const mht_initiator* in) { return in->ais_pending; }
+int initiator_mreq(const mht_initiator* in) { return in->cfg.m_required; }
 void initiator_ais_ptrs(mht_initiator* in, const AisInitMsg** msgs, unsigned char** used) {      // the forest fills the used flags behind its commit
     *msgs = in->args.ais; *used = const_cast<unsigned char*>(in->args.ais_used);
     in->ais_used_by_forest = true;

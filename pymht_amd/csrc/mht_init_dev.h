@@ -47,8 +47,8 @@ struct InitArgs {
     int Acap;
     // output: born candidates, in the reference's order
     double* born_x; float* born_P; uint8_t* born_flags; double* born_pd; int32_t* born_meas; int32_t* born_n; int born_cap;
-    // host-mapped ring (or null): word [scan & 63] = scan << 32 | candidates born in that scan, as soon as the number exists -- the
-    // forest's host side sizes the next grids with it instead of born_cap (mht_forest.hip: Forest::births_between)
+    // host-mapped ring (or null): word [scan & 63] = scan << 32 | preliminary tracks kept behind that scan << 16 | candidates born in that scan, as soon as
+    // the numbers exist -- the forest's host side sizes the next grids with them instead of born_cap (mht_forest.hip: Forest::births_between)
     unsigned long long* bhint; int scan_no;
     // the forest's sticky capacity flag (FCounts::overflow) when the initiator runs behind a forest's scan, else null: a candidate, track or
     // edge list that did not fit voids the forest like a full node pool does (MHT_E_CAPACITY at the scan's report) -- the stand-alone seam
@@ -713,7 +713,8 @@ static __device__ void initiator_body(const InitArgs& a) {
         }
         for (int i = 0; i < out; ++i) { a.born_flags[i] = F_STATE_F32 | F_SCORE_F32; a.born_pd[i] = a.default_pd; }
         *a.born_n = out;
-        if (a.bhint) __hip_atomic_store(a.bhint + (a.scan_no & 63), ((unsigned long long)(unsigned)a.scan_no << 32) | (unsigned long long)(unsigned)out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.bhint) __hip_atomic_store(a.bhint + (a.scan_no & 63), ((unsigned long long)(unsigned)a.scan_no << 32) | ((unsigned long long)(unsigned)(n_pre_now & 0xffff) << 16) | (unsigned long long)(unsigned)(out & 0xffff),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         st.n_born = out;
         st.n_prelim = n_pre_now;
         st.n_seeds = n_left;
