@@ -181,7 +181,8 @@ __global__ __launch_bounds__(INIT_THREADS) void initiator_side_kernel(const Init
     __syncthreads();
     const bool gave_up = s_gave_up != 0;
     if (gave_up && threadIdx.x == 0 && sticky_overflow) *const_cast<int32_t*>(sticky_overflow) = 2;
-    if (!gave_up && !((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in);      // (void scan: nothing is initiated)
+    __shared__ __attribute__((aligned(16))) unsigned char s_gnn[INIT_GNN_LDS];      // (8 KB with the rest: what a 155 KB workgroup of the ILP launch leaves of a CU's LDS)
+    if (!gave_up && !((status && status->overflow) || (sticky_overflow && *sticky_overflow))) initiator_body<false>(in, s_gnn, INIT_GNN_LDS);      // (void scan: nothing is initiated)
     if (done_flag) {      // the next scan's grow launch may be running already: its admission waits for this word (FCounts::init_flag)
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -21,7 +21,10 @@
 
 
 namespace mht {
-__global__ __launch_bounds__(INIT_THREADS) void initiator_kernel(const InitArgs a) { initiator_body(a); }
+__global__ __launch_bounds__(INIT_THREADS) void initiator_kernel(const InitArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_gnn[INIT_GNN_LDS];
+    initiator_body(a, s_gnn, INIT_GNN_LDS);
+}
 }  // namespace mht
 
 // ------------------------------------------------------------------------------------------------------------------------------

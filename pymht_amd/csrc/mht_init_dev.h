@@ -116,11 +116,11 @@ static __device__ inline bool inv_small(const float* s, int n, float* out) {
 // ---- GNN: minimum-cost maximum-cardinality matching of the allowed graph -------------------------------------------------------
 // rows 0..n1-1, columns 0..n2-1, edges (e_row, e_col, e_cost)[0..E).  One thread per connected component: successive shortest
 // augmenting paths (Bellman-Ford on the residual graph; components have a handful of nodes).  match_row[r] = column or -1.
-template <int NT>
-static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
+template <int NT, typename G>
+static __device__ __forceinline__ void gnn_core(const G& a, int n1, int n2, int E) {
     const int tid = threadIdx.x;
     const int V = n1 + n2;
-    for (int v = tid; v < V; v += NT) { a.node_parent[v] = v; a.row_head[v] = -1; a.comp_head[v] = -1; }
+    for (int v = tid; v < V; v += NT) { a.node_parent[v] = v; if (v < n1) { a.row_head[v] = -1; a.comp_head[v] = -1; } }      // (heads by ROW: a component's root is its smallest node, a row)
     for (int r = tid; r < n1; r += NT) a.match_row[r] = -1;
     for (int c = tid; c < n2; c += NT) a.match_col[c] = -1;
     __threadfence_block();
@@ -208,6 +208,54 @@ static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E) {
     __syncthreads();
 }
 
+
+// The tables of the solver: in global scratch (InitArgs, any size), or -- GnnLds -- in the few KB of LDS the kernels that run the initiator NEXT to the
+// ILP launch can have (a 155 KB workgroup of that launch leaves 8 KB of a CU's LDS): the per-component part is one THREAD walking chained lists, ~60
+// dependent look-ups for the largest component of a dense scan, 0.7 us each in global memory (profiles/r06_initiator_phases.txt).  16-bit indices
+// where no atomic touches them.
+struct GnnGlobal {
+    int32_t* e_row; int32_t* e_col; double* e_cost; int32_t* e_next; int32_t* node_parent; int32_t* row_head; int32_t* row_next; int32_t* comp_head;
+    int32_t* match_row; int32_t* match_col; double* bf_dist; int32_t* bf_pred;
+};
+struct GnnLds {
+    short* e_row; short* e_col; double* e_cost; short* e_next; int32_t* node_parent; int32_t* row_head; short* row_next; int32_t* comp_head;
+    short* match_row; short* match_col; double* bf_dist; short* bf_pred;
+};
+__device__ __forceinline__ size_t gnn_lds_bytes(int n1, int n2, int E) {
+    const size_t V = (size_t)n1 + n2;
+    return (size_t)E * 8 + V * 8 + V * 4 + ((size_t)2 * n1 * 4) + (size_t)E * 6 + V * 2 + (size_t)n1 * 2 + (size_t)n1 * 2 + (size_t)n2 * 2 + 64;
+}
+template <int NT>
+static __device__ void gnn_solve(const InitArgs& a, int n1, int n2, int E, unsigned char* lds = nullptr, int lds_bytes = 0) {
+    const int tid = threadIdx.x;
+    const int V = n1 + n2;
+    if (lds && E > 0 && V < 32000 && E < 32000 && gnn_lds_bytes(n1, n2, E) <= (size_t)lds_bytes) {      // (uniform)
+        GnnLds g;
+        unsigned char* p = lds;
+        g.e_cost = reinterpret_cast<double*>(p); p += (size_t)E * 8;
+        g.bf_dist = reinterpret_cast<double*>(p); p += (size_t)V * 8;
+        g.node_parent = reinterpret_cast<int32_t*>(p); p += (size_t)V * 4;
+        g.row_head = reinterpret_cast<int32_t*>(p); p += (size_t)n1 * 4;
+        g.comp_head = reinterpret_cast<int32_t*>(p); p += (size_t)n1 * 4;
+        g.e_row = reinterpret_cast<short*>(p); p += (size_t)E * 2;
+        g.e_col = reinterpret_cast<short*>(p); p += (size_t)E * 2;
+        g.e_next = reinterpret_cast<short*>(p); p += (size_t)E * 2;
+        g.bf_pred = reinterpret_cast<short*>(p); p += (size_t)V * 2;
+        g.row_next = reinterpret_cast<short*>(p); p += (size_t)n1 * 2;
+        g.match_row = reinterpret_cast<short*>(p); p += (size_t)n1 * 2;
+        g.match_col = reinterpret_cast<short*>(p);
+        for (int e = tid; e < E; e += NT) { g.e_row[e] = (short)a.e_row[e]; g.e_col[e] = (short)a.e_col[e]; g.e_cost[e] = a.e_cost[e]; }
+        __syncthreads();
+        gnn_core<NT>(g, n1, n2, E);
+        for (int r = tid; r < n1; r += NT) a.match_row[r] = g.match_row[r];
+        for (int c = tid; c < n2; c += NT) a.match_col[c] = g.match_col[c];
+        __threadfence_block();
+        __syncthreads();
+        return;
+    }
+    gnn_core<NT>(GnnGlobal{a.e_row, a.e_col, a.e_cost, a.e_next, a.node_parent, a.row_head, a.row_next, a.comp_head, a.match_row, a.match_col, a.bf_dist, a.bf_pred}, n1, n2, E);
+}
+
 // One scan of the initiator, by ONE workgroup of NT threads (INIT_THREADS in initiator_kernel; the forest runs it inside post_scan_kernel,
 // between the scan's commit and the admission of the new targets).
 // AIS = false compiles the seeding phase (1b) out: the kernels on the path of every streamed scan (cluster_init_kernel; post_scan_kernel
@@ -229,8 +277,9 @@ __device__ __forceinline__ bool prelim_similar(float d0, float d1, float d2, flo
     return (float)sacc <= 1.0f;
 }
 
+constexpr int INIT_GNN_LDS = 7424;      // LDS the kernels that run the initiator next to the ILP launch give the assignment's tables (8 KB in all with the body's own: see GnnLds)
 template <bool AIS = true, int NT = INIT_THREADS>
-static __device__ void initiator_body(const InitArgs& a) {
+static __device__ void initiator_body(const InitArgs& a, unsigned char* gnn_lds = nullptr, int gnn_lds_bytes = 0) {
 #ifdef MHT_INIT_STAMPS
     unsigned long long init_t[10] = {};
 #endif
@@ -421,7 +470,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         if (E > INIT_ECAP) { if (tid == 0) st.overflow = 1; E = INIT_ECAP; }
         __threadfence_block();
         __syncthreads();
-        gnn_solve<NT>(a, n_pre, nU, E);
+        gnn_solve<NT>(a, n_pre, nU, E, gnn_lds, gnn_lds_bytes);
         }
         // Kalman update of the matched tracks, counters
         for (int i = tid; i < n_pre; i += NT) {
@@ -548,7 +597,7 @@ static __device__ void initiator_body(const InitArgs& a) {
         __threadfence_block();
         __syncthreads();
         INIT_STAMP(4);
-        gnn_solve<NT>(a, n_seed, nU2, E2);
+        gnn_solve<NT>(a, n_seed, nU2, E2, gnn_lds, gnn_lds_bytes);
         INIT_STAMP(5);
         // new preliminary tracks in initiator order, each tested against every track kept so far (sequential like the reference: m_of_n.py:440-452).
         // 64 initiators at a time (every wavefront fetches the same matches and each lane forms its own candidate):

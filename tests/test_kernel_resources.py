@@ -95,6 +95,10 @@ def test_scratch_and_register_budget(src, tmp_path):
         vgpr = int(re.search(r"VGPRs: (\d+)", seg).group(1))
         spill = int(re.search(r"VGPRs Spill: (\d+)", seg).group(1))
         found[m.group(1)] = (scratch, vgpr, spill)
+        if "initiator_side_kernel" in m.group(1):
+            # the initiator runs NEXT to the ILP launch: its workgroup must fit the LDS a 155 KB ILP workgroup leaves of a CU (160 KB), or it waits for that launch to drain
+            lds_b = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", seg).group(1))
+            assert lds_b <= 8192, "initiator_side_kernel uses %d bytes of LDS (8 192 fit next to an ILP workgroup)" % lds_b
     for kern, budget in BUDGET[src].items():
         max_scratch, max_vgpr = budget[:2]
         hits = [v for k, v in found.items() if kern in k]
