@@ -478,6 +478,26 @@ class Tracker():
     def _materialise(self):
         """The per-scan tuples `_finish_scan` left -> the reference's `toc` / `runtimeLog` / `lastScanStats` (and the scan log)."""
         recs, self._scanrecs = self._scanrecs, []
+        if len(recs) > 1:
+            # all but the newest scan only add a row to `runtimeLog` (and to the scan log when it is kept); `toc`, `tic`, `lastScanStats` are the newest
+            # scan's.  One pass per column instead of a dictionary per scan: a streaming host pays 0.5 us per scan for this, not 2.7 (it runs every
+            # 256 scans, in the middle of the stream)
+            older = recs[:-1]
+            rl = self._runtimeLog_
+            rl['Total'].extend(r[18] for r in older)
+            rl['Init'].extend(r[17] for r in older)
+            rl['Process'].extend(r[1] * 1e-8 if r[5] is None else r[5][0] for r in older)
+            rl['Cluster'].extend(r[2] * 1e-8 if r[5] is None else r[5][1] for r in older)
+            rl['Optim'].extend(r[3] * 1e-8 if r[5] is None else r[5][2] for r in older)
+            rl['N-Prune'].extend(0.0 if r[5] is None else r[5][3] for r in older)
+            zeros = [0.0] * len(older)
+            for k in ('ILP-Prune', 'DynN', 'Terminate'):
+                rl[k].extend(zeros)
+            if self._scanStatsLog is not None:
+                for r in older:
+                    self._scanStatsLog.append(dict(L=r[7], G=r[8] - r[7], M=r[9], leaves_out=r[10], clusters=r[11], ilp=r[6], branched=r[12], blp_iters_max=r[13],
+                                                   limit=r[14], unused=self._unused_of(r[15], r[9]), nTargets=r[16]))
+            recs = recs[-1:]
         for (tic, t_process, t_cluster, t_optim, t_scan, stage, n_ilp, n_leaves_in, n_children, nRadarMeas, n_leaves_out, n_clusters, n_branched,
              blp_iters_max, n_limit, used_raw, n_tbl, t_init, total) in recs:
             self.tic = tic
