@@ -2020,7 +2020,7 @@ __device__ __forceinline__ void solve_cluster(const BlpArgs& a, const ClRef cr, 
     // a team that spans the devices of a cluster-sharded step: this device's best selection goes to its slot of the exchange block (BlpArgs::shard_team:
     // [device][team slot][XT_WORDS] int32, -1 = empty; the value as three non-negative chunks of its order-preserving key so that the exchange's
     // element-wise MAX is a gather), NOT to sel_rel -- the devices' selections of one cluster must not mix; shard_team_resolve_kernel picks the winner
-    const bool xteam = tm.Wg != tm.W && a.shard_team != nullptr && team_idx >= 0;
+    const bool xteam = tm.Wg != tm.W && a.shard_team != nullptr && team_idx >= 0 && K <= TEAM_SEL;
     auto xteam_out = [&](auto sel_of, double value) {
         int32_t* o = a.shard_team + ((size_t)a.shard_i * TEAM_MAX + team_idx) * XT_WORDS;
         for (int k = tid; k < K; k += BLP_THREADS) { const int h = sel_of(k); a.sel[mem[k]] = h; o[4 + k] = h - a.tchild[mem[k]]; }
@@ -2504,8 +2504,9 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             own_i += gx;
             if (nTeam > 0 && cr.K >= TEAM_MIN_K)
                 for (int q = 0; q < nTeam; ++q) if ((UF ? ps->team[q].c : a.team_list[q]) == cr.c) ti = q;
-            if (a.shard_n > 1 && !(xteams && ti >= 0) && (a.cl_owner ? a.cl_owner[cr.c] : cr.c % a.shard_n) != a.shard_i) continue;
-            if (ti >= 0 && xteams) tm = Team(0, team_W(ti), &a.team_state[ti].gub, a.shard_i, team_W(ti) * a.shard_n);      // (member q of device i: number q x devices + i)
+            const bool xt = xteams && ti >= 0 && cr.K <= TEAM_SEL;      // (a file holds TEAM_SEL selections: a larger cluster stays with its owner)
+            if (a.shard_n > 1 && !xt && (a.cl_owner ? a.cl_owner[cr.c] : cr.c % a.shard_n) != a.shard_i) continue;
+            if (xt) tm = Team(0, team_W(ti), &a.team_state[ti].gub, a.shard_i, team_W(ti) * a.shard_n);      // (member q of device i: number q x devices + i)
             else if (ti >= 0 && team_W(ti) > 1) tm = Team(0, team_W(ti), &a.team_state[ti].gub);
             else ti = -1;
         } else if (stage == 1) {
@@ -2520,7 +2521,7 @@ __device__ __forceinline__ void blp_body(const BlpArgs& a, unsigned char* lds, c
             if (q >= team_W(ti)) break;
             __syncthreads();      // (the wavefronts of this workgroup are done with the single-target clusters)
             cr = UF ? ps->team[ti] : cl_ref(a, a.team_list[ti]);
-            tm = xteams ? Team(q, team_W(ti), &a.team_state[ti].gub, q * a.shard_n + a.shard_i, team_W(ti) * a.shard_n) : Team(q, team_W(ti), &a.team_state[ti].gub);
+            tm = (xteams && cr.K <= TEAM_SEL) ? Team(q, team_W(ti), &a.team_state[ti].gub, q * a.shard_n + a.shard_i, team_W(ti) * a.shard_n) : Team(q, team_W(ti), &a.team_state[ti].gub);
         }
         if (a.dbg && threadIdx.x == 0 && bx < 3900 && stage == 0) a.dbg[32 + (size_t)bx * 16 + 13] = wall_clock64();
         solve_cluster(a, cr, uw, red, lds + (size_t)a.cap_uw * 8 + RED_SLOT, tm, ti, mt, mt >= 0 ? my_pre : nullptr, bx);
