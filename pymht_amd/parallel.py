@@ -82,6 +82,47 @@ def merge_selections(sel_rel, dist=None, always=False):
     return sel_rel
 
 
+# ---- the files of a giant component searched by the teams of all ranks (mht_forest_step_sharded_begin2; csrc/mht_blp.hip: xteam_out,
+# shard_team_resolve_kernel) -- the host-side statement of the block's layout and of the vote, for tests and tooling ----------------------
+TEAM_MAX, TEAM_SEL = 8, 256
+XT_WORDS = 4 + TEAM_SEL
+
+
+def value_key(v):
+    """The order-preserving 64-bit key of a float64 objective (csrc/mht_blp.hip: enum_key) as the three non-negative chunks a file carries
+    (22 + 21 + 21 bits): every word of a file is >= 0, so the all-reduce(MAX) over blocks whose foreign slots are -1 is a gather."""
+    b = int(np.float64(v).view(np.uint64))
+    k = (~b) & 0xFFFFFFFFFFFFFFFF if (b >> 63) else (b | 0x8000000000000000)
+    return k >> 42, (k >> 21) & 0x1FFFFF, k & 0x1FFFFF
+
+
+def write_team_file(block, max_targets, rank, slot, value, sel_rel):
+    """What rank `rank` files for team slot `slot`: its best objective and the members' child ordinals (a numpy / torch int32 block)."""
+    o = max_targets + (rank * TEAM_MAX + slot) * XT_WORDS
+    k0, k1, k2 = value_key(value)
+    block[o], block[o + 1], block[o + 2], block[o + 3] = k0, k1, k2, len(sel_rel)
+    for i, s_ in enumerate(sel_rel):
+        block[o + 4 + i] = int(s_)
+
+
+def team_winners(block, max_targets, world):
+    """The vote every rank takes on the merged block: per slot the smallest value, ties to the lowest rank -> {slot: (rank, selections)}."""
+    b = np.asarray(block)
+    out = {}
+    for slot in range(TEAM_MAX):
+        best = None
+        for r in range(world):
+            o = max_targets + (r * TEAM_MAX + slot) * XT_WORDS
+            if b[o + 3] < 0:
+                continue
+            key = (int(b[o]) << 42) | (int(b[o + 1]) << 21) | int(b[o + 2])
+            if best is None or key < best[0]:
+                best = (key, r, b[o + 4:o + 4 + int(b[o + 3])].tolist())
+        if best is not None:
+            out[slot] = (best[1], best[2])
+    return out
+
+
 class ClusterShardedTracker:
     """ONE tracker on `shard_n` devices: wraps a `pymht_amd.tracker.Tracker` (rank `shard_i`'s copy of the forest) and steps it with
     `mht_forest_step_sharded_begin` -> exchange -> `mht_forest_step_sharded_end`.

@@ -90,3 +90,53 @@ def test_selection_exchange_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == (100 + np.arange(40)).tolist()      # every rank ends up with every selection
+
+
+def _team_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pymht_amd import parallel
+    # the exchange block of mht_forest_step_sharded_begin2: T selections, then every rank's files for the clusters searched by the teams
+    # of ALL ranks.  Rank r solved the ordinary clusters c with c % world == r and files ITS best selection of two giant clusters
+    # (targets 30..59 in slot 0, 70..99 in slot 1) with the value it reached; the ranks' values differ, one of them is negative,
+    # two are one ulp apart
+    T = 128
+    block = np.full(T + world * parallel.TEAM_MAX * parallel.XT_WORDS, -1, dtype=np.int32)
+    labels = np.arange(T) // 3
+    giant = ((np.arange(T) >= 30) & (np.arange(T) < 60)) | ((np.arange(T) >= 70) & (np.arange(T) < 100))
+    block[:T] = np.where((labels % world == rank) & ~giant, 100 + np.arange(T), -1)
+    v0 = [412.5, np.nextafter(412.5, 0.0)][rank]          # slot 0: rank 1 is one ulp better
+    v1 = [-3.25, -3.0][rank]                              # slot 1: rank 0 is better (negative values order the other way round in the raw bits)
+    parallel.write_team_file(block, T, rank, 0, v0, 1000 * (rank + 1) + np.arange(30))
+    parallel.write_team_file(block, T, rank, 1, v1, 2000 * (rank + 1) + np.arange(30))
+    assert (block[T:][block[T:] != -1] >= 0).all()      # every filed word is non-negative: MAX against -1 is a gather
+    out = parallel.merge_selections(torch.from_numpy(block), dist).numpy()
+    win = parallel.team_winners(out, T, world)
+    q.put((rank, out[:T].tolist(), {k: (v[0], v[1][:3]) for k, v in win.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_team_files_are_gathered_by_the_same_all_reduce():
+    """The giant-component exchange (pymht_amd.parallel.write_team_file / team_winners = csrc/mht_blp.hip xteam_out /
+    shard_team_resolve_kernel): ONE all-reduce(MAX) merges the selections and gathers every rank's file; every rank then takes the same
+    vote -- smallest value, also across the sign and at one ulp."""
+    world, port = 2, 29633 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_team_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    sel, win = res[0][1], res[0][2]
+    giant = [t for t in range(128) if 30 <= t < 60 or 70 <= t < 100]
+    assert all(sel[t] == -1 for t in giant) and all(sel[t] == 100 + t for t in range(128) if t not in giant)
+    assert win == {0: (1, [2000, 2001, 2002]), 1: (0, [2000, 2001, 2002])}

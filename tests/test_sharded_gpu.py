@@ -343,9 +343,18 @@ def test_giant_component_is_searched_by_every_shard(shards):
                 c = int(lst[q])
                 assert (blocks[:, mem[ptr[c]:ptr[c + 1]]] == -1).all()
         merged = blocks.max(dim=0).values
+        from pymht_amd.parallel import team_winners
+        win = team_winners(merged.cpu().numpy(), T, shards)      # (the host's statement of the vote)
+        assert sorted(win) == list(range(n_team))
         for p in parts:
             p.sel_rel.copy_(merged)
             p.end()
+        if n_team:
+            for p in parts:      # the device's vote (shard_team_resolve_kernel) wrote the winner's ordinals into the members' entries
+                got = p.sel_rel.cpu().numpy()
+                for q in range(n_team):
+                    c = int(lst[q])
+                    assert got[mem[ptr[c]:ptr[c + 1]]].tolist() == win[q][1], (k, q)
         for i, p in enumerate(parts):
             _same(p.trk, solo, "scan %d shard %d" % (k, i))
         branched += solo.lastScanStats["branched"]
