@@ -408,7 +408,7 @@ typedef struct mht_initiator_config {
     int32_t m_required, n_checks;   /* Tracker.M_required / N_checks */
     int32_t max_meas;               /* measurements per scan */
     int32_t max_prelim;             /* preliminary tracks kept */
-    int32_t max_born;               /* new targets per scan */
+    int32_t max_born;               /* confirmed tracks per scan, before merging (behind a forest: at most 256, the report's capacity; more in a scan: MHT_E_CAPACITY) */
     double v_max;                   /* Tracker.maxSpeedMS */
     double gamma;                   /* gate of the preliminary tracks */
     double merge_threshold;         /* Tracker.mergeThreshold */
