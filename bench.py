@@ -457,7 +457,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="cfg3")
-    ap.add_argument("--sectors", default="4,16", help="concurrent independent sectors per GPU for the multi_sector figures, comma separated (0 disables)")
+    ap.add_argument("--sectors", default="4,16,64", help="concurrent independent sectors per GPU for the multi_sector figures, comma separated (0 disables)")
     ap.add_argument("--cpu-scans", type=int, default=16, help="timed oracle scans for cpu_baseline (0 disables)")
     ap.add_argument("--cpu-warm", type=int, default=8)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -602,7 +602,9 @@ def main():
         # dependent kernels interleave on the device (while one group's ILP kernel holds a workgroup per CU, the other's grow runs)
         # (up to four sectors: a group per sector -- four launch chains side by side, 45.6 k scans/s against 41.8 k in two groups of two;
         # sixteen sectors: two groups of eight, 75 k against 58 k in four groups and 53 k in eight -- profiles/r05_merge_ab.txt, "groups")
-        NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "4" if S <= 4 else "2")), S))
+        # (thirty-two sectors and more: four groups -- 32: 117.8 k against 104.2 k in two groups, 64: 134.6 k against 119.7 k in two and 101.8 k in eight;
+        # 128 sectors: 130 k in eight groups, 102 k in sixteen -- profiles/r06_experiments.txt, "sectors per GPU")
+        NG = max(1, min(int(os.environ.get("MHT_BENCH_GROUPS", "4" if (S <= 4 or S >= 32) else "2")), S))
         # (streams of DIFFERENT priority: the runtime maps streams to a few hardware queues, and two streams of equal priority may land on
         # the same one -- the groups then run one after the other instead of side by side: 43 k instead of 74 k scans/s at 16 sectors,
         # decided by chance per process)
